@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  TEST INFRASTRUCTURE -- never imported by the product.
+
+Runs ONLY in the build container, where the upstream reference is mounted
+read-only at /root/reference.  It imports the reference's own Python classes
+(MeasureVAE, VAETrainer, LatentRNN, LatentRNNTrainer) behind three stub modules
+(music21, glob2, tensorboard_logger -- absent from this image, and only used by
+the dataset / logging layers that are out of scope), drives them with
+deterministic weights and inputs from inpaintnet_amd.synthetic, and writes the
+inputs + the reference's outputs to tests/golden/*.npz.  Those fixtures are
+data; no reference source travels.
+
+    python oracle/gen_golden.py            # regenerates every fixture
+
+Control of randomness in the reference:
+  * eps of Normal.rsample    -> torch.distributions.normal._standard_normal patched
+  * teacher-forcing coin     -> random.random patched in MeasureVAE.decoder / LatentRNN.latent_rnn
+  * dropout                  -> model.eval(), or dropout prob 0.0 in the constructors
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _stub_modules():
+    def mod(name, **a):
+        m = types.ModuleType(name)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+        return m
+    m21 = mod("music21")
+    for s in ["interval", "note", "harmony", "expressions", "meter", "abcFormat", "stream",
+              "duration", "pitch", "repeat", "exceptions21", "converter"]:
+        setattr(m21, s, mod("music21." + s))
+    sys.modules["music21.abcFormat"].ABCHandlerException = type("E", (Exception,), {})
+    mod("glob2", glob=lambda p: [])
+    mod("tensorboard_logger", configure=lambda *a, **k: None, log_value=lambda *a, **k: None)
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+
+
+_stub_modules()
+import warnings  # noqa: E402
+warnings.filterwarnings("ignore")
+import torch  # noqa: E402
+import torch.distributions.normal as _tdn  # noqa: E402
+
+from MeasureVAE.measure_vae import MeasureVAE  # noqa: E402
+from MeasureVAE.vae_trainer import VAETrainer  # noqa: E402
+import MeasureVAE.decoder as ref_decoder_mod  # noqa: E402
+from LatentRNN.latent_rnn import LatentRNN  # noqa: E402
+import LatentRNN.latent_rnn as ref_latent_mod  # noqa: E402
+from LatentRNN.latent_rnn_trainer import LatentRNNTrainer  # noqa: E402
+
+from inpaintnet_amd import synthetic  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class FakeDataset:
+    def __init__(self, V):
+        self.note2index_dicts = [{i: i for i in range(V)}]
+        self.n_bars = 16
+        self.subdivision = 6
+        self.num_beats_per_bar = 4
+        self.num_voices = 1
+
+    def __repr__(self):
+        return "Fake"
+
+
+class EpsQueue:
+    """Replaces torch.distributions.normal._standard_normal with a FIFO of
+    pre-generated eps tensors; records what it handed out."""
+
+    def __init__(self):
+        self.q = []
+        self.orig = _tdn._standard_normal
+
+    def __enter__(self):
+        def fake(shape, dtype, device):
+            e = self.q.pop(0)
+            assert tuple(e.shape) == tuple(shape), (e.shape, shape)
+            return e
+        _tdn._standard_normal = fake
+        return self
+
+    def __exit__(self, *a):
+        _tdn._standard_normal = self.orig
+
+    def push(self, name, shape, seed=0):
+        e = torch.from_numpy(synthetic.det_normal(name, shape, 1.0, seed))
+        self.q.append(e)
+        return e
+
+
+def set_coin(value):
+    f = (lambda: value)
+    ref_decoder_mod.random.random = f
+    ref_latent_mod.random.random = f
+
+
+def load_det_weights(model, seed=0):
+    sd = model.state_dict()
+    new = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape), seed)) for k, v in sd.items()}
+    model.load_state_dict(new)
+    return {k: v.numpy().copy() for k, v in new.items()}
+
+
+def top2_margin(w):
+    s, _ = torch.sort(w, dim=-1, descending=True)
+    return (s[..., 0] - s[..., 1]).numpy()
+
+
+CFGS = {
+    # name: (V, E, H, Z, batch)
+    "small": dict(V=12, E=4, H=16, Z=8, B=5),
+    "mid": dict(V=20, E=6, H=48, Z=24, B=3),
+    "full": dict(V=48, E=10, H=512, Z=256, B=5),
+}
+
+
+def build_vae(c, dropout=0.0):
+    return MeasureVAE(FakeDataset(c["V"]), note_embedding_dim=c["E"],
+                      encoder_hidden_size=c["H"], latent_space_dim=c["Z"],
+                      decoder_hidden_size=c["H"], encoder_dropout_prob=dropout,
+                      decoder_dropout_prob=dropout)
+
+
+def grads_of(model, full):
+    out = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().numpy().astype(np.float32)
+        if full:
+            out["grad/" + k] = g.copy()
+        else:
+            flat = g.reshape(-1)
+            out["gradnorm/" + k] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+            out["gradsum/" + k] = np.float64(flat.astype(np.float64).sum())
+            out["gradhead/" + k] = flat[:64].copy()
+            out["gradtail/" + k] = flat[-64:].copy()
+    return out
+
+
+def param_digest(model, full):
+    out = {}
+    for k, p in model.named_parameters():
+        v = p.detach().numpy().astype(np.float32)
+        if full:
+            out[k] = v.copy()
+        else:
+            flat = v.reshape(-1)
+            out["sum/" + k] = np.float64(flat.astype(np.float64).sum())
+            out["norm/" + k] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+            out["head/" + k] = flat[:64].copy()
+    return out
+
+
+def gen_vae(name, c):
+    V, Z, B = c["V"], c["Z"], c["B"]
+    full_tensors = name != "full"
+    model = build_vae(c, dropout=0.0)
+    weights = load_det_weights(model)
+    tokens = torch.from_numpy(synthetic.det_tokens("tokens/" + name, (B, 24), V))
+    fx = {"tokens": tokens.numpy()}
+    if full_tensors:
+        for k, v in weights.items():
+            fx["param/" + k] = v
+
+    # --- encoder (a2) --------------------------------------------------------
+    model.eval()
+    with torch.no_grad():
+        dist = model.encoder(tokens)
+    fx["enc_mu"] = dist.loc.numpy()
+    fx["enc_logsigma"] = dist.scale.log().numpy()
+    fx["enc_sigma"] = dist.scale.numpy()
+
+    # --- decoder eval / free-running argmax (a4-a6) --------------------------
+    z = torch.from_numpy(synthetic.det_normal("z/" + name, (B, Z), 1.0))
+    fx["dec_z"] = z.numpy()
+    with torch.no_grad():
+        w, s = model.decoder(z, tokens, train=False)
+    fx["dec_eval_weights"] = w.numpy()
+    fx["dec_eval_samples"] = s.numpy()
+    fx["dec_eval_margin"] = top2_margin(w)
+
+    # --- decoder teacher-forced (train=True, coin < 0.5), dropout prob = 0 ----
+    model.train()
+    set_coin(0.0)
+    with torch.no_grad():
+        w, s = model.decoder(z, tokens, train=True)
+    fx["dec_tf_weights"] = w.numpy()
+    fx["dec_tf_samples"] = s.numpy()
+
+    # --- full VAE train steps through the reference trainer (a7,a8,a10) ------
+    for mode, coin in (("tf", 0.0), ("fr", 0.9)):
+        model = build_vae(c, dropout=0.0)
+        load_det_weights(model)
+        trainer = VAETrainer(FakeDataset(V), model, lr=1e-4)
+        model.train()
+        set_coin(coin)
+        losses = []
+        with EpsQueue() as q:
+            for step in range(5):
+                eps = q.push(f"eps/{name}/{step}", (B, Z))
+                fx[f"step_{mode}_eps{step}"] = eps.numpy()
+                trainer.zero_grad()
+                weights_, samples_, z_dist, prior_dist, z_tilde, z_prior = model(tokens, train=True)
+                ce = trainer.mean_crossentropy_loss(weights=weights_, targets=tokens)
+                kl = trainer.compute_kld_loss(z_dist, prior_dist)
+                acc = trainer.mean_accuracy(weights=weights_, targets=tokens)
+                loss = ce + kl
+                loss.backward()
+                if step == 0:
+                    fx[f"step_{mode}_weights"] = weights_.detach().numpy()
+                    fx[f"step_{mode}_samples"] = samples_.detach().numpy()
+                    fx[f"step_{mode}_margin"] = top2_margin(weights_.detach())
+                    fx[f"step_{mode}_z"] = z_tilde.detach().numpy()
+                    for k, v in grads_of(model, full_tensors).items():
+                        fx[f"step_{mode}_{k}"] = v
+                assert not q.q, "eps queue must be fully consumed each step"
+                trainer.step()
+                losses.append([loss.item(), ce.item(), kl.item(), acc.item()])
+                if step in (0, 4):
+                    for k, v in param_digest(model, name == "small").items():
+                        fx[f"step_{mode}_after{step + 1}/{k}"] = v
+        fx[f"step_{mode}_losses"] = np.array(losses, dtype=np.float64)
+
+    np.savez_compressed(os.path.join(OUT, f"vae_{name}.npz"), **fx)
+    print("wrote vae_%s.npz  (%d arrays)" % (name, len(fx)))
+
+
+def gen_latent(name, c, auto_reg, coin):
+    """LatentRNN forward + one trainer step (a11-a15).  Frozen VAE, dropout 0."""
+    V, Z, B = c["V"], c["Z"], c["B"]
+    H = c["H"]
+    full_tensors = name != "full"
+    vae = build_vae(c, dropout=0.0)
+    load_det_weights(vae)
+    model = LatentRNN(FakeDataset(V), vae, num_rnn_layers=2, rnn_hidden_size=H, dropout=0.0,
+                      rnn_class=torch.nn.GRU, auto_reg=auto_reg, teacher_forcing=True)
+    wts = load_det_weights(model)  # covers vae_model.* as well, same names -> same values
+    tag = f"latent_{name}_{'ar' if auto_reg else 'nar'}_{'tf' if coin < 0.5 else 'fr'}"
+    fx = {}
+    if full_tensors:
+        for k, v in wts.items():
+            fx["param/" + k] = v
+    score = torch.from_numpy(synthetic.folk_score(B, V, seed=3))  # (B,1,384) int32
+    fx["score"] = score.numpy()
+    n_past, n_target, n_future = 6, 4, 6
+    trainer = LatentRNNTrainer(FakeDataset(V), model, lr=1e-4)
+    past, future, target = LatentRNNTrainer.split_score(score, n_past, n_future, n_target, 24)
+    fx["split"] = np.array([n_past, n_target, n_future])
+    model.train()
+    set_coin(coin)
+    with EpsQueue() as q:
+        e_p = q.push(f"eps_p/{tag}", (B * n_past, Z))
+        e_f = q.push(f"eps_f/{tag}", (B * n_future, Z))
+        e_t = q.push(f"eps_t/{tag}", (B * n_target, Z))
+        fx["eps_past"], fx["eps_future"], fx["eps_target"] = e_p.numpy(), e_f.numpy(), e_t.numpy()
+        if auto_reg and coin >= 0.5:
+            # free-running AR re-encodes each generated measure but the last one's z is unused
+            for i in range(n_target):
+                e = q.push(f"eps_ar{i}/{tag}", (B, Z))
+                fx[f"eps_ar{i}"] = e.numpy()
+        trainer.zero_grad()
+        weights, samples, gen_z = model(past, future, target, n_target, train=True)
+    loss = trainer.mean_crossentropy_loss_alt(weights=weights, targets=target)
+    acc = trainer.mean_accuracy_alt(weights=weights, targets=target)
+    loss.backward()
+    fx["weights"] = weights.detach().numpy()
+    fx["samples"] = samples.detach().numpy()
+    fx["margin"] = top2_margin(weights.detach())
+    fx["gen_z"] = gen_z.detach().numpy()
+    fx["loss_acc"] = np.array([loss.item(), acc.item()], dtype=np.float64)
+    for k, v in grads_of(model, full_tensors).items():
+        fx[k] = v
+    assert all(p.grad is None for p in vae.parameters())
+    trainer.step()
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            v = p.detach().numpy()
+            if full_tensors:
+                fx["after1/" + k] = v.copy()
+            else:
+                fx["after1sum/" + k] = np.float64(v.astype(np.float64).sum())
+                fx["after1head/" + k] = v.reshape(-1)[:64].copy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
+    print("wrote %s.npz (%d arrays)" % (tag, len(fx)))
+
+
+def gen_split_helpers():
+    """split_score / split_to_measures / process_batch_data index contract (a9, a15)."""
+    V = 12
+    score = torch.from_numpy(synthetic.folk_score(3, V, seed=5))
+    fx = {"score": score.numpy()}
+    for (p, t, f) in [(6, 4, 6), (1, 2, 13), (8, 6, 2)]:
+        a, b, c_ = LatentRNNTrainer.split_score(score, p, f, t, 24)
+        fx[f"past_{p}_{t}_{f}"] = a.numpy()
+        fx[f"future_{p}_{t}_{f}"] = b.numpy()
+        fx[f"target_{p}_{t}_{f}"] = c_.numpy()
+    np.savez_compressed(os.path.join(OUT, "split_helpers.npz"), **fx)
+    print("wrote split_helpers.npz")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["vae", "latent", "split"]
+    if "vae" in which:
+        for n, c in CFGS.items():
+            gen_vae(n, c)
+    if "latent" in which:
+        for n in ("small", "full"):
+            c = dict(CFGS[n])
+            if n == "full":
+                c["B"] = 2
+            gen_latent(n, c, auto_reg=False, coin=0.9)
+            gen_latent(n, c, auto_reg=True, coin=0.0)
+            gen_latent(n, c, auto_reg=True, coin=0.9)
+    if "split" in which:
+        gen_split_helpers()

@@ -1,0 +1,309 @@
+"""CPU oracle: plain-PyTorch fp32 restatement of the InpaintNet hot path.
+
+TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product (inpaintnet_amd/) never
+does, and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  Every function below is checked against golden vectors
+captured from the upstream reference itself (oracle/gen_golden.py imports
+/root/reference in the build container and writes tests/golden/*.npz);
+tests/test_oracle_golden.py is the check.
+
+What is restated (reference file:line each function follows):
+  gru_cell / gru_layer / gru_stack  torch.nn.GRU semantics as used at
+                                    MeasureVAE/encoder.py:28-35,125; decoder.py:342-367,469,499;
+                                    LatentRNN/latent_rnn.py:53-82,186-193,231
+  encoder_forward                   MeasureVAE/encoder.py:104-134
+  decoder_forward                   MeasureVAE/decoder.py:392-529
+  vae_forward                       MeasureVAE/measure_vae.py:97-134
+  vae_loss                          MeasureVAE/vae_trainer.py:16-40,128-139; utils/trainer.py:271-306
+  adam_step                         torch.optim.Adam as built at utils/trainer.py:32-35 (torch 2.10 form)
+  latent_forward                    LatentRNN/latent_rnn.py:110-263
+  latent_loss                       LatentRNN/latent_rnn_trainer.py:36-67; utils/trainer.py:344-376
+  split_score                       LatentRNN/latent_rnn_trainer.py:134-176
+
+Parameters are passed as a dict keyed by the reference's state_dict names
+(SURVEY.md App. B), e.g. 'encoder.lstm.weight_ih_l0_reverse'.  Gradients come
+from autograd over this explicit arithmetic.
+
+Injection points for the reference's random draws: eps (rsample), the
+teacher-forcing coin (an explicit bool), and dropout masks (dict of
+pre-scaled {0, 1/(1-p)} tensors; None = no dropout).
+
+Argmax tie rule: lowest index.  (torch-CPU topk used by the reference at
+decoder.py:511 is implementation-defined on ties; fixtures only assert rows
+with a unique maximum.)
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+SELU_ALPHA = 1.6732632423543772
+SELU_SCALE = 1.0507009873554805
+
+
+def selu(x):
+    return SELU_SCALE * torch.where(x > 0, x, SELU_ALPHA * (torch.exp(x) - 1.0))
+
+
+def argmax_first(w):
+    """Lowest index among maxima, last dim."""
+    m = w.max(dim=-1, keepdim=True).values
+    V = w.shape[-1]
+    idx = torch.arange(V, device=w.device).expand_as(w)
+    return torch.where(w == m, idx, torch.full_like(idx, V)).min(dim=-1).values
+
+
+# ----------------------------------------------------------------------------
+# GRU
+# ----------------------------------------------------------------------------
+def gru_cell(gi, h, w_hh, b_hh):
+    """gi = W_ih x + b_ih already formed. Gate rows ordered [r|z|n]."""
+    H = h.shape[-1]
+    gh = h @ w_hh.t() + b_hh
+    r = torch.sigmoid(gi[..., :H] + gh[..., :H])
+    z = torch.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
+    n = torch.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
+    return (1.0 - z) * n + z * h
+
+
+def gru_layer(x, h0, w_ih, w_hh, b_ih, b_hh, reverse=False):
+    """x (B,T,K) -> out (B,T,H), h_T.  One direction of one layer."""
+    B, T, _ = x.shape
+    gi_all = x @ w_ih.t() + b_ih
+    h = h0
+    outs = [None] * T
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        h = gru_cell(gi_all[:, t], h, w_hh, b_hh)
+        outs[t] = h
+    return torch.stack(outs, 1), h
+
+
+def gru_stack(x, h0, P, prefix, num_layers, bidirectional, masks=None):
+    """Multi-layer (bi)GRU, batch_first.  h0: (L*D, B, H).  masks: list of
+    length L-1 of pre-scaled dropout masks applied to layer l's output before
+    layer l+1 (torch semantics: not after the last layer).  Returns
+    (top-layer output (B,T,D*H), h_n (L*D,B,H) ordered [l0f,l0b,l1f,l1b])."""
+    D = 2 if bidirectional else 1
+    inp = x
+    h_n = []
+    for l in range(num_layers):
+        outs = []
+        for d in range(D):
+            sfx = f"_l{l}" + ("_reverse" if d == 1 else "")
+            o, hT = gru_layer(inp, h0[l * D + d],
+                              P[f"{prefix}.weight_ih{sfx}"], P[f"{prefix}.weight_hh{sfx}"],
+                              P[f"{prefix}.bias_ih{sfx}"], P[f"{prefix}.bias_hh{sfx}"],
+                              reverse=(d == 1))
+            outs.append(o)
+            h_n.append(hT)
+        inp = torch.cat(outs, 2) if D == 2 else outs[0]
+        if l < num_layers - 1 and masks is not None and masks[l] is not None:
+            inp = inp * masks[l]
+    return inp, torch.stack(h_n, 0)
+
+
+def gru_stack_fast(x, h0, P, prefix, num_layers, bidirectional):
+    """Same contraction through torch's fused aten::gru (what nn.GRU calls on
+    CPU) -- used only for the cpu_baseline timing leg, eval/no-dropout."""
+    D = 2 if bidirectional else 1
+    flat = []
+    for l in range(num_layers):
+        for d in range(D):
+            sfx = f"_l{l}" + ("_reverse" if d == 1 else "")
+            flat += [P[f"{prefix}.weight_ih{sfx}"], P[f"{prefix}.weight_hh{sfx}"],
+                     P[f"{prefix}.bias_ih{sfx}"], P[f"{prefix}.bias_hh{sfx}"]]
+    out, hn = torch._VF.gru(x, h0, flat, True, num_layers, 0.0, False, bidirectional, True)
+    return out, hn
+
+
+# ----------------------------------------------------------------------------
+# MeasureVAE
+# ----------------------------------------------------------------------------
+def encoder_forward(P, tokens, masks=None, prefix="encoder", fast=False):
+    """tokens (B,T) int64 -> (mu, logsigma) each (B,Z).  encoder.py:104-134."""
+    B = tokens.shape[0]
+    emb = P[f"{prefix}.note_embedding_layer.weight"][tokens]
+    H = P[f"{prefix}.lstm.weight_hh_l0"].shape[1]
+    h0 = torch.zeros(4, B, H, dtype=emb.dtype)
+    if fast:
+        _, hn = gru_stack_fast(emb, h0, P, f"{prefix}.lstm", 2, True)
+    else:
+        _, hn = gru_stack(emb, h0, P, f"{prefix}.lstm", 2, True, masks)
+    hcat = hn.transpose(0, 1).contiguous().view(B, -1)
+
+    def head(name):
+        a = selu(hcat @ P[f"{prefix}.{name}.0.weight"].t() + P[f"{prefix}.{name}.0.bias"])
+        return a @ P[f"{prefix}.{name}.2.weight"].t() + P[f"{prefix}.{name}.2.bias"]
+    return head("linear_mean"), head("linear_log_std")
+
+
+def decoder_forward(P, z, target, teacher_forced, masks=None, prefix="decoder",
+                    beats=4, ticks_per_beat=6):
+    """z (B,Z), target (B,T) int64 (used iff teacher_forced) ->
+    weights (B,T,V) post-ReLU logits, samples (B,1,T) int64.  decoder.py:412-529.
+    masks: {'beat': (B,beats,H) or None, 'tick': (B,T,H) or None}, pre-scaled."""
+    B = z.shape[0]
+    H = P[f"{prefix}.rnn_beat.weight_hh_l0"].shape[1]
+    masks = masks or {}
+    # beat rnn (forward_beat_rnn, decoder.py:455-471)
+    hb0 = selu(z @ P[f"{prefix}.z_to_beat_rnn_input.0.weight"].t() + P[f"{prefix}.z_to_beat_rnn_input.0.bias"])
+    h_beat = hb0.view(B, 2, H).transpose(0, 1).contiguous()
+    beat_in = P[f"{prefix}.b_0"].view(1, 1, 1).expand(B, beats, 1)
+    bm = masks.get("beat")
+    beat_out, _ = gru_stack(beat_in, h_beat, P, f"{prefix}.rnn_beat", 2, False,
+                            [bm] if bm is not None else None)
+    # tick rnn (forward_tick_rnn, decoder.py:473-529)
+    E = P[f"{prefix}.note_embedding_layer.weight"]
+    prev = P[f"{prefix}.x_0"].view(1, -1).expand(B, -1)
+    tm = masks.get("tick")
+    pf = f"{prefix}.rnn_tick"
+    weights, samples = [], []
+    for i in range(beats):
+        o_i = beat_out[:, i]
+        ht0 = selu(o_i @ P[f"{prefix}.beat_emb_to_tick_rnn_hidden.0.weight"].t()
+                   + P[f"{prefix}.beat_emb_to_tick_rnn_hidden.0.bias"])
+        hid = ht0.view(B, 2, H).transpose(0, 1)
+        h_l0, h_l1 = hid[0], hid[1]
+        c_i = selu(o_i @ P[f"{prefix}.beat_emb_to_tick_rnn_input.0.weight"].t()
+                   + P[f"{prefix}.beat_emb_to_tick_rnn_input.0.bias"])
+        for j in range(ticks_per_beat):
+            t = i * ticks_per_beat + j
+            u = torch.cat((prev, c_i), 1)
+            gi0 = u @ P[f"{pf}.weight_ih_l0"].t() + P[f"{pf}.bias_ih_l0"]
+            h_l0 = gru_cell(gi0, h_l0, P[f"{pf}.weight_hh_l0"], P[f"{pf}.bias_hh_l0"])
+            x1 = h_l0 if tm is None else h_l0 * tm[:, t]
+            gi1 = x1 @ P[f"{pf}.weight_ih_l1"].t() + P[f"{pf}.bias_ih_l1"]
+            h_l1 = gru_cell(gi1, h_l1, P[f"{pf}.weight_hh_l1"], P[f"{pf}.bias_hh_l1"])
+            w_t = torch.relu(h_l1 @ P[f"{prefix}.tick_emb_to_note_emb.0.weight"].t()
+                             + P[f"{prefix}.tick_emb_to_note_emb.0.bias"])
+            tok = target[:, t] if teacher_forced else argmax_first(w_t.detach())
+            prev = E[tok]
+            weights.append(w_t)
+            samples.append(tok)
+    return torch.stack(weights, 1), torch.stack(samples, 1).unsqueeze(1)
+
+
+def vae_forward(P, tokens, eps, teacher_forced, masks=None):
+    """measure_vae.py:97-134 with eps injected.  Returns weights, samples, mu, logsigma, z."""
+    masks = masks or {}
+    mu, ls = encoder_forward(P, tokens, [masks.get("enc")] if masks.get("enc") is not None else None)
+    z = mu + eps * torch.exp(ls)
+    w, s = decoder_forward(P, z, tokens, teacher_forced, masks)
+    return w, s, mu, ls, z
+
+
+def cross_entropy_mean(weights, targets):
+    V = weights.shape[-1]
+    return F.cross_entropy(weights.reshape(-1, V), targets.reshape(-1), reduction="mean")
+
+
+def accuracy_mean(weights, targets):
+    return (argmax_first(weights.reshape(-1, weights.shape[-1])) == targets.reshape(-1)).float().mean()
+
+
+def kld(mu, ls, beta=1e-3):
+    """beta * mean_b sum_d KL(N(mu,sigma)||N(0,1)) = 0.5(s^2+mu^2-1) - ls.  vae_trainer.py:128-139."""
+    k = 0.5 * (torch.exp(2.0 * ls) + mu * mu - 1.0) - ls
+    return beta * k.sum(1).mean()
+
+
+def vae_loss(weights, tokens, mu, ls):
+    ce = cross_entropy_mean(weights, tokens)
+    kl = kld(mu, ls)
+    return ce + kl, ce, kl, accuracy_mean(weights.detach(), tokens)
+
+
+def adam_step(params, grads, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """In-place, torch 2.10 single-tensor form. t is 1-based."""
+    bc1 = 1.0 - b1 ** t
+    bc2 = 1.0 - b2 ** t
+    for k in params:
+        g = grads[k]
+        m[k].mul_(b1).add_(g, alpha=1.0 - b1)
+        v[k].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        denom = (v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        params[k].addcdiv_(m[k], denom, value=-lr / bc1)
+
+
+# ----------------------------------------------------------------------------
+# LatentRNN
+# ----------------------------------------------------------------------------
+def split_score(score, n_past, n_future, n_target, measure_len=24):
+    """(B,1,L) -> past (B,np,24), future (B,nf,24), target (B,nt,24) int64."""
+    B = score.shape[0]
+    m = score.reshape(B, -1, measure_len)
+    n = m.shape[1]
+    assert n == n_past + n_future + n_target
+    return (m[:, :n_past].long().contiguous(), m[:, n - n_future:].long().contiguous(),
+            m[:, n_past:n - n_future].long().contiguous())
+
+
+def latent_get_z(P, measures, eps, enc_mask=None):
+    """get_z_seq, latent_rnn.py:161-174: z SAMPLES from the frozen encoder."""
+    B, n, T = measures.shape
+    mu, ls = encoder_forward(P, measures.reshape(-1, T), enc_mask, prefix="vae_model.encoder")
+    z = mu + eps * torch.exp(ls)
+    return z.view(B, n, -1)
+
+
+def latent_forward(P, past, future, target, eps_p, eps_f, eps_t, auto_reg=False,
+                   teacher_forcing=False, eps_ar=None, masks=None):
+    """latent_rnn.py:110-263.  Returns weights (B,nt,T,V), samples (B,1,nt*T), gen_z (B,nt,Z).
+    masks: {'ctx_past','ctx_future','gen': layer0->1 masks; 'dec': list of per-measure decoder masks}."""
+    masks = masks or {}
+    B, nt, T = target.shape
+    with torch.no_grad():
+        zp = latent_get_z(P, past, eps_p)
+        zf = latent_get_z(P, future, eps_f)
+        zt = latent_get_z(P, target, eps_t)
+    H = P["context_rnn_past.weight_hh_l0"].shape[1]
+    h0 = torch.zeros(4, B, H)
+
+    def m1(k):
+        return [masks[k]] if masks.get(k) is not None else None
+    _, cp = gru_stack(zp, h0, P, "context_rnn_past", 2, True, m1("ctx_past"))
+    _, cf = gru_stack(zf, h0, P, "context_rnn_future", 2, True, m1("ctx_future"))
+    ctx = torch.cat((cp, cf), 2)
+    dec_masks = masks.get("dec") or [None] * nt
+
+    def decode(zi, i):
+        return decoder_forward(P, zi, None, False, dec_masks[i], prefix="vae_model.decoder")
+
+    Wg, bg = P["generation_linear.weight"], P["generation_linear.bias"]
+    weights, samples = [], []
+    if teacher_forcing or not auto_reg:
+        if auto_reg:
+            gen_in = torch.cat((zp[:, -1:].contiguous(), zt[:, :-1]), 1)
+        else:
+            gen_in = P["x_0"].expand(B, nt, -1)
+        out, _ = gru_stack(gen_in, ctx, P, "generation_rnn", 2, True, m1("gen"))
+        gen_z = out.reshape(B * nt, -1) @ Wg.t() + bg
+        gen_z = gen_z.view(B, nt, -1)
+        for i in range(nt):
+            w, s = decode(gen_z[:, i], i)
+            weights.append(w)
+            samples.append(s)
+    else:
+        hidden = ctx
+        gen_in = zp[:, -1:].contiguous()
+        zs = []
+        for i in range(nt):
+            out, hidden = gru_stack(gen_in, hidden, P, "generation_rnn", 2, True, m1("gen"))
+            gz = out.reshape(B, -1) @ Wg.t() + bg
+            zs.append(gz)
+            w, s = decode(gz, i)
+            weights.append(w)
+            samples.append(s)
+            with torch.no_grad():
+                gen_in = latent_get_z(P, s, eps_ar[i])
+        gen_z = torch.stack(zs, 1)
+    return torch.stack(weights, 1), torch.cat(samples, 2), gen_z
+
+
+def latent_loss(weights, target):
+    V = weights.shape[-1]
+    ce = F.cross_entropy(weights.reshape(-1, V), target.reshape(-1), reduction="mean")
+    return ce, accuracy_mean(weights.detach(), target)

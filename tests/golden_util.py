@@ -1,0 +1,52 @@
+"""Helpers shared by the oracle and GPU parity tests."""
+import os
+
+import numpy as np
+import torch
+
+from inpaintnet_amd import layout, synthetic
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CFGS = {
+    "small": dict(V=12, E=4, H=16, Z=8),
+    "mid": dict(V=20, E=6, H=48, Z=24),
+    "full": dict(V=48, E=10, H=512, Z=256),
+}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def vae_params(name, fx=None, prefix=""):
+    """state_dict-keyed float32 torch tensors for the fixture's model (regenerated
+    from the deterministic generator; cross-checked against stored copies when present)."""
+    c = CFGS[name]
+    shapes = layout.vae_param_shapes(c["V"], c["E"], c["H"], c["Z"], c["H"], prefix=prefix)
+    P = {k: torch.from_numpy(synthetic.det_param(k, s)) for k, s in shapes.items()}
+    if fx is not None:
+        for k in P:
+            key = "param/" + k
+            if key in fx.files:
+                assert np.array_equal(fx[key], P[k].numpy()), k
+    return P
+
+
+def latent_params(name, auto_reg):
+    c = CFGS[name]
+    P = vae_params(name, prefix="vae_model.")
+    shapes = layout.latent_param_shapes(c["Z"], c["H"], auto_reg)
+    for k, s in shapes.items():
+        P[k] = torch.from_numpy(synthetic.det_param(k, s))
+    return P
+
+
+def unique_rows(margin, tol=1e-4):
+    return margin > tol
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
