@@ -1,0 +1,146 @@
+/* inpaintnet_hip.h -- C ABI of the MI355X (gfx950) InpaintNet hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI: its callers see Python classes
+ * (SURVEY.md section 8b).  This header is the C-ABI the repo introduces
+ * UNDERNEATH those classes; each entry point cites the reference method whose
+ * arithmetic it replaces.  The modules of inpaintnet_amd/ bind it with ctypes and expose
+ * the reference's own signatures (MeasureVAE.forward, LatentRNN.forward,
+ * Trainer.step ...); INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    stated; the caller owns all memory (parameters, gradients, optimizer
+ *    state, workspaces, outputs).  The library never allocates device memory.
+ *  - all floating point is fp32; token tensors are int64 (as produced by
+ *    utils/helpers.py:17-26 to_cuda_variable_long).
+ *  - calls are asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - return value: 0 = ok, -1 = invalid argument, -2 = launch/runtime failure.
+ *  - parameters live in ONE flat fp32 arena per model, laid out in the
+ *    reference's state_dict() order; gradients / Adam
+ *    moments use arenas of identical layout.  inet_*_param_info() is the
+ *    single description of that layout.
+ *  - a workspace written by a *_fwd call with save=1 must be handed unchanged to
+ *    the matching *_bwd call.
+ */
+#ifndef INPAINTNET_HIP_H
+#define INPAINTNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INET_ABI_VERSION 1
+
+typedef struct inet_vae_config {
+    int32_t num_notes;      /* V  = len(dataset.note2index_dicts[0])   measure_vae.py:56   */
+    int32_t emb_dim;        /* E  note_embedding_dim (10)              measure_vae.py:13   */
+    int32_t enc_hidden;     /* encoder_hidden_size (512); 2 layers, bidirectional          */
+    int32_t z_dim;          /* latent_space_dim (256)                                      */
+    int32_t dec_hidden;     /* decoder_hidden_size (512); 2 layers                         */
+    int32_t beats;          /* 4, hard-coded at decoder.py:446                             */
+    int32_t ticks_per_beat; /* 6, hard-coded at decoder.py:450                             */
+} inet_vae_config;
+
+typedef struct inet_latent_config {
+    int32_t z_dim;          /* vae_model.latent_space_dim                latent_rnn.py:48  */
+    int32_t rnn_hidden;     /* rnn_hidden_size (512): context GRUs; generator uses 2x      */
+    int32_t auto_reg;       /* generator input = z (1) or the scalar x_0 (0)  :70-74       */
+} inet_latent_config;
+
+int inet_abi_version(void);
+
+/* ---- parameter arena layout -------------------------------------------------------- */
+/* MeasureVAE state_dict (encoder.* then decoder.*), MeasureVAE/encoder.py:28-52, decoder.py:335-372 */
+int     inet_vae_param_count(const inet_vae_config* cfg);
+int64_t inet_vae_param_floats(const inet_vae_config* cfg);
+/* name: caller buffer; dims: int64[4]; returns 0 or -1 */
+int     inet_vae_param_info(const inet_vae_config* cfg, int index, char* name, int name_cap,
+                            int64_t* offset_floats, int64_t* dims, int* ndim);
+/* trainable LatentRNN parameters (context_rnn_past/future, generation_rnn, generation_linear, x_0),
+ * LatentRNN/latent_rnn.py:53-83 */
+int     inet_latent_param_count(const inet_latent_config* cfg);
+int64_t inet_latent_param_floats(const inet_latent_config* cfg);
+int     inet_latent_param_info(const inet_latent_config* cfg, int index, char* name, int name_cap,
+                               int64_t* offset_floats, int64_t* dims, int* ndim);
+
+/* ---- MeasureVAE encoder: Encoder.forward, MeasureVAE/encoder.py:104-134 -------------- */
+int64_t inet_vae_encoder_ws_bytes(const inet_vae_config* cfg, int batch, int save);
+/* tokens [B,T] int64 row-major (T = beats*ticks_per_beat); params: VAE arena;
+ * mask: null, or [T,B,2H] fp32 pre-scaled {0,1/(1-p)} inter-layer dropout mask (time-major);
+ * outputs mu, logsigma [B,Z] */
+int inet_vae_encoder_fwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
+                         const float* mask, float* mu, float* logsigma, void* ws, int save, void* stream);
+/* autograd of the above (utils/trainer.py:150 loss.backward): accumulates into `grads` (VAE arena layout) */
+int inet_vae_encoder_bwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
+                         float* grads, const float* mask, const float* dmu, const float* dlogsigma, void* ws,
+                         void* stream);
+
+/* ---- MeasureVAE decoder: HierarchicalDecoder.forward, MeasureVAE/decoder.py:412-529 -- */
+int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int save);
+/* z [B,Z]; target [B,T] int64 (read iff teacher_forced); mask_beat [beats,B,H], mask_tick [T,B,H] or null;
+ * weights [B,T,V] post-ReLU logits; samples [B,1,T] int64 (argmax, lowest index on ties; = target if teacher forced) */
+int inet_vae_decoder_fwd(const inet_vae_config* cfg, int batch, const float* z, const int64_t* target,
+                         int teacher_forced, const float* params, const float* mask_beat, const float* mask_tick,
+                         float* weights, int64_t* samples, void* ws, int save, void* stream);
+/* dweights [B,T,V] = dLoss/dweights; weights = the forward output; grads may be null (frozen decoder:
+ * LatentRNN/latent_rnn.py:42-43) in which case only dz [B,Z] is produced.  `tokens_in` are the tokens that
+ * were fed back (= samples of the forward call). */
+int inet_vae_decoder_bwd(const inet_vae_config* cfg, int batch, const float* dweights, const float* weights,
+                         const int64_t* tokens_in, const float* params, float* grads, const float* mask_beat,
+                         const float* mask_tick, float* dz, void* ws, void* stream);
+
+/* ---- losses: VAETrainer.loss_and_acc_for_batch, vae_trainer.py:16-40,128-139; utils/trainer.py:271-306 */
+/* rows of V logits (row stride ld_w); out3[0] += sum_rows (lse - w[target]); out3[1] += #correct (argmax_first);
+ * dW (nullable, row stride ld_dw) = (softmax - onehot) * scale */
+int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
+                       int64_t ld_dw, float scale, float* loss_sum, float* correct, void* stream);
+/* z = mu + eps*exp(logsigma) (measure_vae.py:119); sigma out (nullable); kl_sum += sum(0.5(s^2+mu^2-1) - ls) */
+int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, float* z, float* sigma, int64_t n,
+                    float* kl_sum, void* stream);
+/* dmu = dz + kscale*mu; dlogsigma = dz*eps*sigma + kscale*(sigma^2-1) */
+int inet_latent_bwd(const float* dz, const float* mu, const float* logsigma, const float* eps, float kscale,
+                    float* dmu, float* dlogsigma, int64_t n, void* stream);
+
+/* ---- optimizer: torch.optim.Adam as built at utils/trainer.py:32-35, stepped at :172-177 -------- */
+/* p,g,m,v: arenas of n floats; step is 1-based; grads are multiplied by gscale first (1/world_size for DP) */
+int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int step, float gscale, void* stream);
+
+/* ---- dropout masks (nn.GRU inter-layer dropout, encoder.py:32, decoder.py:346,365) --- */
+int inet_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- generic 2-layer bidirectional GRU: nn.GRU(batch_first, bidirectional, num_layers=2) as used at
+ *      LatentRNN/latent_rnn.py:53-82,186-193,228-233 ------------------------------------ */
+/* weights: pointer to the 16 tensors of the GRU in state_dict order inside an arena
+ * (weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0, *_l0_reverse, *_l1, *_l1_reverse), each 16-byte aligned
+ * as produced by inet_latent_param_info.  x [B,T,K] batch-first (or x_scalar: device pointer to ONE float
+ * broadcast as a [B,T,1] input when K == 1 and x == null); h0 [4,B,H] or null (zeros);
+ * mask null or [T,B,2H]; out (nullable) [B,T,2H]; h_n (nullable) [4,B,H]. */
+int64_t inet_bigru2_ws_bytes(int batch, int T, int K, int H, int save);
+int inet_bigru2_fwd(int batch, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
+                    const float* h0, const float* mask, float* out, float* h_n, void* ws, int save, void* stream);
+/* dout (nullable) [B,T,2H], dh_n (nullable) [4,B,H]; grads: same 16-tensor block in the grad arena;
+ * dx (nullable) [B,T,K]; dx_scalar (nullable, 1 float, accumulated); dh0 (nullable) [4,B,H] */
+int inet_bigru2_bwd(int batch, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
+                    float* grads, const float* mask, const float* dout, const float* dh_n, float* dx,
+                    float* dx_scalar, float* dh0, void* ws, void* stream);
+
+/* ---- generic fp32 MFMA GEMM (nn.Linear and friends): C[M,N] (op)= epi(A . B^T + bias) -- */
+/* a_kmajor/b_kmajor: 0 => operand(row,k) = P[row*ld + k]; 1 => P[k*ld + row].
+ * epi: 0 none, 1 SELU, 2 ReLU, 3 *selu'(aux), 4 *aux, 5 *(aux>0).  acc: 0 store, 1 add. */
+int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+              int64_t ldc, int M, int N, int K, const float* bias, const float* aux, int64_t ldaux, int epi,
+              int acc, void* stream);
+
+/* single GRU step (test hook for the fused step kernel; semantics of torch.nn.GRUCell with the input-side
+ * gate pre-activations gi [B,3H] already formed) -- r,z,n,ghn,hprev saves are nullable [B,H] */
+int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
+                  float* h_new, float* sv5, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INPAINTNET_HIP_H */

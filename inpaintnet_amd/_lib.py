@@ -1,0 +1,122 @@
+"""ctypes binding of libinpaintnet_hip.so (include/inpaintnet_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call
+fails, this module raises.  Build with `python -c 'import __graft_entry__ as g; g.build()'`
+(or inpaintnet_amd._lib.build()).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinpaintnet_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip"]
+
+_lib = None
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [("num_notes", C.c_int32), ("emb_dim", C.c_int32), ("enc_hidden", C.c_int32),
+                ("z_dim", C.c_int32), ("dec_hidden", C.c_int32), ("beats", C.c_int32),
+                ("ticks_per_beat", C.c_int32)]
+
+
+class LatentConfig(C.Structure):
+    _fields_ = [("z_dim", C.c_int32), ("rnn_hidden", C.c_int32), ("auto_reg", C.c_int32)]
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP source for gfx950 into the in-tree shared library."""
+    srcs = [os.path.join(CSRC, f) for f in SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "inpaintnet_hip.h"))
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print("[inpaintnet_amd] " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_U = C.c_uint64
+_CFG = C.POINTER(VaeConfig)
+_LCFG = C.POINTER(LatentConfig)
+
+_SIGNATURES = {
+    "inet_abi_version": (C.c_int, []),
+    "inet_vae_param_count": (C.c_int, [_CFG]),
+    "inet_vae_param_floats": (_L, [_CFG]),
+    "inet_vae_param_info": (C.c_int, [_CFG, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
+    "inet_latent_param_count": (C.c_int, [_LCFG]),
+    "inet_latent_param_floats": (_L, [_LCFG]),
+    "inet_latent_param_info": (C.c_int, [_LCFG, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
+    "inet_vae_encoder_ws_bytes": (_L, [_CFG, _I, _I]),
+    "inet_vae_encoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "inet_vae_encoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "inet_vae_decoder_ws_bytes": (_L, [_CFG, _I, _I]),
+    "inet_vae_decoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "inet_vae_decoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "inet_cross_entropy": (C.c_int, [_P, _L, _I, _I, _P, _P, _L, _F, _P, _P, _P]),
+    "inet_reparam_kl": (C.c_int, [_P, _P, _P, _P, _P, _L, _P, _P]),
+    "inet_latent_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _P, _L, _P]),
+    "inet_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "inet_dropout_mask": (C.c_int, [_P, _L, _F, _U, _U, _P]),
+    "inet_bigru2_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "inet_bigru2_fwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "inet_bigru2_bwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "inet_gemm": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _P]),
+    "inet_gru_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """The loaded library; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.inet_abi_version() != 1:
+            raise ImportError("libinpaintnet_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+class InetError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc == -1:
+        raise ValueError(f"{what}: invalid argument (rc=-1)")
+    if rc != 0:
+        raise InetError(f"{what}: HIP launch/runtime failure (rc={rc})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,243 @@
+// extern "C" surface declared in include/inpaintnet_hip.h.
+#include <cstring>
+#include "seq.h"
+#include "layout.h"
+#include "vae.h"
+
+namespace {
+
+bool cfg_ok(const inet_vae_config* c) {
+    return c && c->num_notes > 0 && c->emb_dim > 0 && c->enc_hidden > 0 && c->enc_hidden % 16 == 0 &&
+           c->dec_hidden > 0 && c->dec_hidden % 16 == 0 && c->z_dim > 0 && c->beats > 0 && c->beats <= 4 &&
+           c->ticks_per_beat > 0;
+}
+
+int entry_info(const ArenaBuilder& ab, int index, char* name, int cap, int64_t* off, int64_t* dims, int* ndim) {
+    if (index < 0 || index >= (int)ab.entries.size()) return -1;
+    const ParamEntry& e = ab.entries[index];
+    if (name && cap > 0) { std::strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (off) *off = e.offset;
+    if (dims) for (int i = 0; i < 4; ++i) dims[i] = e.dims[i];
+    if (ndim) *ndim = e.ndim;
+    return 0;
+}
+
+// pointers to the 16 tensors of a 2-layer bidirectional nn.GRU laid out by ArenaBuilder::add_gru
+void bigru_ptrs(const float* w, float* g, int K, int H, GruDirPtr* P) {
+    ArenaBuilder ab;
+    GruDirOff off[4];
+    ab.add_gru("g", K, H, 2, true, off);
+    for (int i = 0; i < 4; ++i) {
+        P[i].w_ih = w + off[i].w_ih; P[i].w_hh = w + off[i].w_hh; P[i].b_ih = w + off[i].b_ih; P[i].b_hh = w + off[i].b_hh;
+        P[i].dw_ih = g ? g + off[i].w_ih : nullptr; P[i].dw_hh = g ? g + off[i].w_hh : nullptr;
+        P[i].db_ih = g ? g + off[i].b_ih : nullptr; P[i].db_hh = g ? g + off[i].b_hh : nullptr;
+        P[i].K = off[i].K;
+    }
+}
+
+struct BiWs {
+    BiGru2Ws g;
+    float *x_tm, *gi0, *gvec, *out_tm, *dout_tm, *dx_tm, *tmp3h;
+};
+size_t bi_carve(int B, int T, int K, int H, int save, void* base, BiWs& w) {
+    Carver cv(base);
+    const size_t TB = (size_t)T * B;
+    w.x_tm = cv.take<float>(TB * K);
+    w.gi0 = cv.take<float>(TB * 6 * H);
+    w.gvec = cv.take<float>(6 * H);
+    w.out_tm = nullptr;
+    bigru2_carve(cv, B, T, H, save, w.g);
+    if (save) {
+        w.dout_tm = cv.take<float>(TB * 2 * H);
+        w.dx_tm = cv.take<float>(TB * K);
+        w.tmp3h = cv.take<float>(3 * H);
+    } else {
+        w.dout_tm = w.dx_tm = w.tmp3h = nullptr;
+    }
+    return cv.bytes();
+}
+
+}  // namespace
+
+extern "C" {
+
+int inet_abi_version(void) { return INET_ABI_VERSION; }
+
+int inet_vae_param_count(const inet_vae_config* cfg) {
+    if (!cfg_ok(cfg)) return -1;
+    return (int)VaeLayout(*cfg).ab.entries.size();
+}
+int64_t inet_vae_param_floats(const inet_vae_config* cfg) {
+    if (!cfg_ok(cfg)) return -1;
+    return VaeLayout(*cfg).ab.total;
+}
+int inet_vae_param_info(const inet_vae_config* cfg, int index, char* name, int name_cap, int64_t* offset_floats,
+                        int64_t* dims, int* ndim) {
+    if (!cfg_ok(cfg)) return -1;
+    return entry_info(VaeLayout(*cfg).ab, index, name, name_cap, offset_floats, dims, ndim);
+}
+int inet_latent_param_count(const inet_latent_config* cfg) {
+    if (!cfg || cfg->rnn_hidden % 16) return -1;
+    return (int)LatentLayout(*cfg).ab.entries.size();
+}
+int64_t inet_latent_param_floats(const inet_latent_config* cfg) {
+    if (!cfg || cfg->rnn_hidden % 16) return -1;
+    return LatentLayout(*cfg).ab.total;
+}
+int inet_latent_param_info(const inet_latent_config* cfg, int index, char* name, int name_cap, int64_t* offset_floats,
+                           int64_t* dims, int* ndim) {
+    if (!cfg || cfg->rnn_hidden % 16) return -1;
+    return entry_info(LatentLayout(*cfg).ab, index, name, name_cap, offset_floats, dims, ndim);
+}
+
+int64_t inet_vae_encoder_ws_bytes(const inet_vae_config* cfg, int batch, int save) {
+    if (!cfg_ok(cfg) || batch <= 0) return -1;
+    return (int64_t)vae_encoder_ws_bytes(*cfg, batch, save);
+}
+int inet_vae_encoder_fwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
+                         const float* mask, float* mu, float* logsigma, void* ws, int save, void* stream) {
+    if (!cfg_ok(cfg) || batch <= 0 || !tokens || !params || !mu || !logsigma || !ws) return -1;
+    return vae_encoder_fwd(*cfg, batch, (const long long*)tokens, params, mask, mu, logsigma, ws, save, (hipStream_t)stream);
+}
+int inet_vae_encoder_bwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
+                         float* grads, const float* mask, const float* dmu, const float* dlogsigma, void* ws,
+                         void* stream) {
+    if (!cfg_ok(cfg) || batch <= 0 || !tokens || !params || !grads || !dmu || !dlogsigma || !ws) return -1;
+    return vae_encoder_bwd(*cfg, batch, (const long long*)tokens, params, grads, mask, dmu, dlogsigma, ws, (hipStream_t)stream);
+}
+int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int save) {
+    if (!cfg_ok(cfg) || batch <= 0) return -1;
+    return (int64_t)vae_decoder_ws_bytes(*cfg, batch, save);
+}
+int inet_vae_decoder_fwd(const inet_vae_config* cfg, int batch, const float* z, const int64_t* target,
+                         int teacher_forced, const float* params, const float* mask_beat, const float* mask_tick,
+                         float* weights, int64_t* samples, void* ws, int save, void* stream) {
+    if (!cfg_ok(cfg) || batch <= 0 || !z || !params || !weights || !samples || !ws) return -1;
+    return vae_decoder_fwd(*cfg, batch, z, (const long long*)target, teacher_forced, params, mask_beat, mask_tick,
+                           weights, (long long*)samples, ws, save, (hipStream_t)stream);
+}
+int inet_vae_decoder_bwd(const inet_vae_config* cfg, int batch, const float* dweights, const float* weights,
+                         const int64_t* tokens_in, const float* params, float* grads, const float* mask_beat,
+                         const float* mask_tick, float* dz, void* ws, void* stream) {
+    if (!cfg_ok(cfg) || batch <= 0 || !dweights || !weights || !tokens_in || !params || !ws) return -1;
+    return vae_decoder_bwd(*cfg, batch, dweights, weights, (const long long*)tokens_in, params, grads, mask_beat,
+                           mask_tick, dz, ws, (hipStream_t)stream);
+}
+
+int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
+                       int64_t ld_dw, float scale, float* loss_sum, float* correct, void* stream) {
+    if (!weights || !targets || !loss_sum || !correct || rows <= 0 || V <= 0) return -1;
+    return pw_cross_entropy(weights, ld_w, rows, V, (const long long*)targets, dW, ld_dw, scale, loss_sum, correct,
+                            (hipStream_t)stream);
+}
+int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, float* z, float* sigma, int64_t n,
+                    float* kl_sum, void* stream) {
+    if (!mu || !logsigma || n <= 0) return -1;
+    return pw_reparam_kl(mu, logsigma, eps, z, sigma, n, kl_sum, (hipStream_t)stream);
+}
+int inet_latent_bwd(const float* dz, const float* mu, const float* logsigma, const float* eps, float kscale,
+                    float* dmu, float* dlogsigma, int64_t n, void* stream) {
+    if (!mu || !logsigma || !dmu || !dlogsigma || n <= 0) return -1;
+    return pw_latent_bwd(dz, mu, logsigma, eps, kscale, dmu, dlogsigma, n, (hipStream_t)stream);
+}
+int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, int step, float gscale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return -1;
+    return pw_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, (hipStream_t)stream);
+}
+int inet_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out || n <= 0 || p < 0.f || p >= 1.f) return -1;
+    return pw_dropout_mask(out, n, p, seed, offset, (hipStream_t)stream);
+}
+
+int64_t inet_bigru2_ws_bytes(int batch, int T, int K, int H, int save) {
+    if (batch <= 0 || T <= 0 || K <= 0 || H <= 0 || H % 16) return -1;
+    BiWs w;
+    return (int64_t)bi_carve(batch, T, K, H, save, nullptr, w);
+}
+
+int inet_bigru2_fwd(int B, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
+                    const float* h0, const float* mask, float* out, float* h_n, void* ws, int save, void* stream) {
+    if (B <= 0 || T <= 0 || K <= 0 || H <= 0 || H % 16 || !weights || !ws) return -1;
+    if (!x && !(x_scalar && K == 1)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    BiWs w;
+    bi_carve(B, T, K, H, save, ws, w);
+    GruDirPtr P[4];
+    bigru_ptrs(weights, nullptr, K, H, P);
+    BiGru2In in{};
+    if (x) {
+        INET_TRY(pw_swap01(x, B, T, K, w.x_tm, s));                  // [B,T,K] -> [T,B,K]
+        for (int dir = 0; dir < 2; ++dir)
+            INET_TRY(linear_fwd(w.x_tm, K, P[dir].w_ih, K, P[dir].b_ih, w.gi0 + dir * 3L * H, 6L * H, T * B, 3 * H, K, EPI_NONE, s));
+        in.gi0[0] = w.gi0; in.gi0[1] = w.gi0 + 3L * H; in.gi0_ld = 6L * H; in.gi0_ts = (long)B * 6 * H;
+    } else {
+        for (int dir = 0; dir < 2; ++dir) {
+            INET_TRY(pw_axpb(x_scalar, P[dir].w_ih, 1, P[dir].b_ih, w.gvec + dir * 3L * H, 3 * H, s));
+            in.gvec[dir] = w.gvec + dir * 3L * H;
+        }
+    }
+    const long BH = (long)B * H;
+    float* hn[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (h_n) for (int i = 0; i < 4; ++i) hn[i] = h_n + i * BH;
+    INET_TRY(bigru2_core_fwd(B, T, H, P, in, h0, mask, h_n ? hn : nullptr, H, w.g, save, s));
+    if (out) INET_TRY(pw_swap01(w.g.h1, T, B, 2 * H, out, s));       // [T,B,2H] -> [B,T,2H]
+    return 0;
+}
+
+int inet_bigru2_bwd(int B, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
+                    float* grads, const float* mask, const float* dout, const float* dh_n, float* dx,
+                    float* dx_scalar, float* dh0, void* ws, void* stream) {
+    if (B <= 0 || T <= 0 || K <= 0 || H <= 0 || H % 16 || !weights || !ws) return -1;
+    if (!x && !(x_scalar && K == 1)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    BiWs w;
+    bi_carve(B, T, K, H, 1, ws, w);
+    GruDirPtr P[4];
+    bigru_ptrs(weights, grads, K, H, P);
+    const long BH = (long)B * H;
+    if (dout) INET_TRY(pw_swap01(dout, B, T, 2 * H, w.dout_tm, s));
+    const float* dhn[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (dh_n) for (int i = 0; i < 4; ++i) dhn[i] = dh_n + i * BH;
+    INET_TRY(bigru2_core_bwd(B, T, H, P, mask, dout ? w.dout_tm : nullptr, dh_n ? dhn : nullptr, H, dh0, w.g, s));
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* dgi = w.g.dgi0 + dir * 3L * H;
+        if (x) {
+            if (grads) INET_TRY(linear_wgrad(dgi, 6L * H, w.x_tm, K, P[dir].dw_ih, K, T * B, 3 * H, K, s));
+            if (dx) INET_TRY(linear_dgrad(dgi, 6L * H, P[dir].w_ih, K, w.dx_tm, K, T * B, 3 * H, K, EPI_NONE, nullptr, 0,
+                                          dir == 0 ? ACC_STORE : ACC_ADD, s));
+        } else if (grads) {
+            if (hipMemsetAsync(w.tmp3h, 0, 3 * H * sizeof(float), s) != hipSuccess) return -2;
+            INET_TRY(pw_colsum(dgi, 6L * H, T * B, 3 * H, w.tmp3h, s));
+            if (!dx_scalar) return -1;
+            INET_TRY(pw_beat_input_grad(w.tmp3h, P[dir].w_ih, 1, x_scalar, P[dir].dw_ih, dx_scalar, 3 * H, s));
+        }
+    }
+    if (x && dx) INET_TRY(pw_swap01(w.dx_tm, T, B, K, dx, s));
+    return 0;
+}
+
+int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+              int64_t ldc, int M, int N, int K, const float* bias, const float* aux, int64_t ldaux, int epi, int acc,
+              void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 5 || acc < 0 || acc > 1) return -1;
+    return launch_gemm(gemm_args(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias, epi, aux, ldaux, acc),
+                       (hipStream_t)stream);
+}
+
+int inet_gru_step(int B, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
+                  float* h_new, float* sv5, void* stream) {
+    if (B <= 0 || H <= 0 || H % 16 || !gi || !h_prev || !W_hh || !b_hh || !h_new) return -1;
+    GruFwdBatch bt{};
+    bt.H = H; bt.nprob = 1;
+    GruFwdProb& P = bt.p[0];
+    P.B = B; P.h_prev = h_prev; P.ld_hprev = H; P.W_hh = W_hh; P.b_hh = b_hh;
+    P.gi_dense = gi; P.ld_gi = 3L * H; P.h_new = h_new; P.ld_hnew = H;
+    if (sv5) {
+        const long as = (long)B * H;
+        P.sv_r = sv5; P.sv_z = sv5 + as; P.sv_n = sv5 + 2 * as; P.sv_ghn = sv5 + 3 * as; P.sv_hprev = sv5 + 4 * as;
+    }
+    return launch_gru_fwd(bt, (hipStream_t)stream);
+}
+
+}  // extern "C"

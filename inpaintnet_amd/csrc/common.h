@@ -1,0 +1,104 @@
+// Shared device helpers and launch-argument structs for the gfx950 kernels.
+// Everything in csrc/ targets CDNA4 (MI355X) only: 64-lane wavefronts, f32-input
+// MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32), 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16-byte global load from a pointer that is only guaranteed 4-byte aligned
+// (weight sub-blocks such as rnn_tick.weight_ih_l0[:, E:] start mid-row).
+// gfx950 under HSA runs in unaligned-access mode; this lowers to one
+// global_load_dwordx4.
+struct __attribute__((packed, aligned(4))) f4u_t { float x, y, z, w; };
+__device__ __forceinline__ f32x4 ld4u(const float* p) {
+    f4u_t v = *reinterpret_cast<const f4u_t*>(p);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4u(float* p, f32x4 v) {
+    f4u_t s{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f4u_t*>(p) = s;
+}
+
+#define SELU_ALPHA 1.6732632423543772f
+#define SELU_SCALE 1.0507009873554805f
+
+__device__ __forceinline__ float selu_f(float x) {
+    return SELU_SCALE * (x > 0.f ? x : SELU_ALPHA * (expf(x) - 1.f));
+}
+// derivative of SELU expressed through its OUTPUT a = selu(x)
+__device__ __forceinline__ float selu_grad_from_out(float a) {
+    return a > 0.f ? SELU_SCALE : a + SELU_SCALE * SELU_ALPHA;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+    return tanhf(x);
+}
+
+// ---------------------------------------------------------------------------
+// Generic fp32 MFMA GEMM:  C[M,N] (op)= epi( sum_k A(m,k) * B(n,k) )
+// ---------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_SELU = 1, EPI_RELU = 2, EPI_MUL_SELU_GRAD = 3, EPI_MUL_AUX = 4, EPI_MUL_POS = 5 };
+enum { ACC_STORE = 0, ACC_ADD = 1, ACC_ATOMIC = 2 };
+
+struct GemmArgs {
+    const float* A; long lda; int a_kmajor;   // 0: A(m,k) = A[m*lda + k]   1: A(m,k) = A[k*lda + m]
+    const float* B; long ldb; int b_kmajor;   // 0: B(n,k) = B[n*ldb + k]   1: B(n,k) = B[k*ldb + n]
+    float* C; long ldc;
+    int M, N, K;
+    const float* bias;                        // [N] or null
+    const float* aux; long ldaux;             // epilogue operand, indexed like C
+    int epi;                                  // EPI_*
+    int acc;                                  // ACC_*
+    int k_per_split;                          // K range handled by one blockIdx.z
+};
+
+// ---------------------------------------------------------------------------
+// GRU single-step kernels (one launch = one time step of up to 4 independent
+// "problems": directions of a bi-GRU, the 4 beats of the tick RNN, ...)
+// ---------------------------------------------------------------------------
+struct GruFwdProb {
+    int B;                                    // batch rows of this problem
+    const float* h_prev; long ld_hprev;       // [B,H]
+    const float* W_hh; const float* b_hh;     // [3H,H], [3H]
+    // gate pre-activations from the input side, summed:
+    const float* gi_dense; long ld_gi;        // [B,3H] or null
+    const float* gi_table; long ld_table;     // table[idx[b*idx_stride]] rows of 3H, or null
+    const long long* idx; long idx_stride;
+    const float* gi_vec;                      // [3H] broadcast or null
+    const float* x; long ldx; int K2;         // in-kernel input contraction x[B,K2] * W_ih[3H,K2]^T (+ b_ih), or null
+    const float* W_ih; long ld_wih; const float* b_ih;
+    // outputs
+    float* h_new; long ld_hnew;               // [B,H]
+    float* h_masked; long ld_hm;              // optional h_new * mask
+    const float* mask; long ld_mask;
+    float* h_copy; long ld_hc;                // optional second plain copy of h_new
+    // saved for backward (all [B,H], row stride H), or null
+    float* sv_r; float* sv_z; float* sv_n; float* sv_ghn; float* sv_hprev;
+};
+struct GruFwdBatch { int H; int nprob; GruFwdProb p[4]; };
+
+struct GruBwdProb {
+    int B;
+    // recurrent term: dh += dgh_next[B,3H] * W_hh  (given as W_hhT [H,3H])
+    const float* dgh_next; long ld_dgh;       // null => no recurrent term
+    const float* W_hhT;                       // [H,3H]
+    const float* dhz_next;                    // [B,H] (dh' * z of the later step) or null
+    const float* dout; long ld_dout;          // [B,H] external gradient into this step's output, or null
+    const float* dout2; long ld_dout2;        // second external gradient (e.g. final-hidden grad), or null
+    // pointwise part (null sv_r => only write dh to dh_out)
+    const float* sv_r; const float* sv_z; const float* sv_n; const float* sv_ghn; const float* sv_hprev;
+    float* dgi; long ld_dgi;                  // [B,3H]
+    float* dgh; long ld_dghout;               // [B,3H]
+    float* dhz;                               // [B,H]
+    float* dh_out; long ld_dhout;             // [B,H] (only when no pointwise part): gradient wrt the initial hidden
+    int dh_out_accumulate;
+};
+struct GruBwdBatch { int H; int nprob; GruBwdProb p[4]; };
+
+// host-side launchers (defined in the .hip files)
+int launch_gemm(const GemmArgs& g, hipStream_t s);
+int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s);
+int launch_gru_bwd(const GruBwdBatch& b, hipStream_t s);

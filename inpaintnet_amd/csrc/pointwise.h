@@ -1,0 +1,30 @@
+// Host-side launchers of the HBM-bound helper kernels (pointwise.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+int pw_transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, hipStream_t s);
+int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
+                     float scale, float* loss_sum, float* correct, hipStream_t s);
+int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,
+                  hipStream_t s);
+int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, float* dmu,
+                  float* dls, long n, hipStream_t s);
+int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+            float gscale, hipStream_t s);
+int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);
+int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
+              hipStream_t s);
+int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s);
+int pw_swap01(const float* in, int A, int B, int K, float* out, hipStream_t s);
+int pw_argmax(const float* W, long ld_w, int rows, int V, long long* out, long stride, hipStream_t s);
+int pw_fill_i64(long long* p, long n, long long v, hipStream_t s);
+int pw_copy2d(float* dst, long ld_d, const float* src, long ld_s, const float* pos, long ld_p, int rows, int cols,
+              hipStream_t s);
+int pw_dlogits_relayout(const float* dW, const float* Wt, int B, int T, int V, float* out, hipStream_t s);
+int pw_group_sum(const float* in, int groups, int G, long inner, float* out, hipStream_t s);
+int pw_axpb(const float* a, const float* x, long incx, const float* b, float* y, int n, hipStream_t s);
+int pw_beat_input_grad(const float* sv, const float* w, long incw, const float* b0, float* dw, float* db0, int n,
+                       hipStream_t s);
+int pw_dropout_mask(float* out, long n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
+int pw_scale(float* x, long n, float a, hipStream_t s);

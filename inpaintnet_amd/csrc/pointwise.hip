@@ -1,0 +1,393 @@
+// HBM-bound helpers of the hot path: wavefront-reduced softmax / cross-entropy /
+// accuracy, KL + reparameterisation, argmax with the lowest-index tie rule,
+// fused Adam over the flat arena, column sums (bias gradients), one-hot
+// expansion (embedding gradients as MFMA contractions instead of contended
+// atomics), transposes, dropout-mask generation.  All are grid-stride,
+// coalesced along the contiguous dimension, 64-lane wave reductions via DPP
+// shuffles.
+#include "common.h"
+#include "pointwise.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// out[c*ld_out + r] = in[r*ld_in + c]
+__global__ void transpose_kernel(const float* __restrict__ in, long ld_in, float* __restrict__ out, long ld_out,
+                                 int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) out[(long)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// One wavefront per row of V logits.  loss_sum += lse - w[target];
+// correct += (argmax_first(w) == target); dW = (softmax - onehot) * scale.
+__global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int V,
+                          const long long* __restrict__ tgt, float* __restrict__ dW, long ld_dw, float scale,
+                          float* __restrict__ loss_sum, float* __restrict__ correct) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float lsum = 0.f, csum = 0.f;
+    for (int row = wave; row < rows; row += nwaves) {
+        const float* w = W + (long)row * ld_w;
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, w[v]);
+        m = wave_max(m);
+        float se = 0.f;
+        int am = 0x7fffffff;
+        for (int v = lane; v < V; v += 64) {
+            const float x = w[v];
+            se += expf(x - m);
+            if (x == m) am = min(am, v);
+        }
+        se = wave_sum(se);
+        am = wave_min_i(am);
+        const int tg = (int)tgt[row];
+        const float lse = m + logf(se);
+        if (lane == 0) {
+            lsum += lse - w[tg];
+            csum += (am == tg) ? 1.f : 0.f;
+        }
+        if (dW) {
+            float* d = dW + (long)row * ld_dw;
+            const float inv = 1.f / se;
+            for (int v = lane; v < V; v += 64) d[v] = (expf(w[v] - m) * inv - (v == tg ? 1.f : 0.f)) * scale;
+        }
+    }
+    // lanes != 0 hold zeros
+    lsum = wave_sum(lsum);
+    csum = wave_sum(csum);
+    if (lane == 0) {
+        unsafeAtomicAdd(loss_sum, lsum);
+        unsafeAtomicAdd(correct, csum);
+    }
+}
+
+// z = mu + eps * exp(ls);  kl_sum += sum 0.5(sigma^2 + mu^2 - 1) - ls
+__global__ void reparam_kl_kernel(const float* __restrict__ mu, const float* __restrict__ ls,
+                                  const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ sigma,
+                                  long n, float* __restrict__ kl_sum) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float l = ls[i], m = mu[i];
+        const float s = expf(l);
+        if (z) z[i] = m + (eps ? eps[i] : 0.f) * s;
+        if (sigma) sigma[i] = s;
+        acc += 0.5f * (s * s + m * m - 1.f) - l;
+    }
+    if (kl_sum) {
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(kl_sum, acc);
+    }
+}
+
+// dmu = dz + kscale*mu ;  dls = dz*eps*sigma + kscale*(sigma^2 - 1)      (kscale = beta / B)
+__global__ void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mu,
+                                  const float* __restrict__ ls, const float* __restrict__ eps, float kscale,
+                                  float* __restrict__ dmu, float* __restrict__ dls, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float s = expf(ls[i]);
+        const float g = dz ? dz[i] : 0.f;
+        dmu[i] = g + kscale * mu[i];
+        dls[i] = g * (eps ? eps[i] : 0.f) * s + kscale * (s * s - 1.f);
+    }
+}
+
+// torch.optim.Adam (2.x single-tensor form): denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2,
+                            float eps, float gscale) {
+    const long n4 = n >> 2;
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    f32x4* m4 = reinterpret_cast<f32x4*>(m);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gscale;
+            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+            pp[e] -= lr_over_bc1 * (mm[e] / denom);
+        }
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    // tail (n is a multiple of 4 for arenas; kept for generality)
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gscale;
+        const float mm = b1 * m[i] + (1.f - b1) * gr;
+        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mm; v[i] = vv;
+        p[i] -= lr_over_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+    }
+}
+
+// out[n] (+)= sum_m X[m*ld + n].  Block = 64 columns x 4 row-lanes; grid.y splits rows; atomics combine.
+__global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + rl; r < r1; r += 4) s += X[(long)r * ld + c];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        unsafeAtomicAdd(out + c, s);
+    }
+}
+
+// onehot[row, idx[(row/inner)*s_outer + (row%inner)*s_inner]] = 1 on a zeroed [rows, W] buffer
+__global__ void onehot_kernel(const long long* __restrict__ idx, int inner, long s_outer, long s_inner, int rows, int W,
+                              float* __restrict__ out) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        const long long v = idx[(long)(r / inner) * s_outer + (long)(r % inner) * s_inner];
+        if (v >= 0 && v < W) out[(long)r * W + v] = 1.f;
+    }
+}
+
+// x *= m      or      x *= selu'(a)  (a = SELU output)
+__global__ void mul_kernel(float* __restrict__ x, const float* __restrict__ m, long n, int selu_grad) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] *= selu_grad ? selu_grad_from_out(m[i]) : m[i];
+}
+
+// in [A][B][K] -> out [B][A][K]
+__global__ void swap01_kernel(const float* __restrict__ in, int A, int B, int K, float* __restrict__ out) {
+    const long n = (long)A * B * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const long ab = i / K;
+        const int b = (int)(ab % B), a = (int)(ab / B);
+        out[((long)b * A + a) * K + k] = in[i];
+    }
+}
+
+// samples[b*stride] = argmax_first(W[b,:]); one wavefront per row
+__global__ void argmax_kernel(const float* __restrict__ W, long ld_w, int rows, int V, long long* __restrict__ out,
+                              long stride) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int row = wave; row < rows; row += nwaves) {
+        const float* w = W + (long)row * ld_w;
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, w[v]);
+        m = wave_max(m);
+        int am = 0x7fffffff;
+        for (int v = lane; v < V; v += 64) if (w[v] == m) am = min(am, v);
+        am = wave_min_i(am);
+        if (lane == 0) out[(long)row * stride] = am;
+    }
+}
+
+__global__ void fill_i64_kernel(long long* p, long n, long long v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// dst[r*ld_d + c] = src[r*ld_s + c] * (mask ? (mask[r*ld_m + c] > 0) : 1)   (generic strided 2D copy)
+__global__ void copy2d_kernel(float* __restrict__ dst, long ld_d, const float* __restrict__ src, long ld_s,
+                              const float* __restrict__ pos, long ld_p, int rows, int cols) {
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        float v = src[(long)r * ld_s + c];
+        if (pos && !(pos[(long)r * ld_p + c] > 0.f)) v = 0.f;
+        dst[(long)r * ld_d + c] = v;
+    }
+}
+
+// [B,T,V] batch-first d(post-ReLU logits) -> [T,B,V] time-major d(pre-ReLU logits)
+__global__ void dlogits_relayout_kernel(const float* __restrict__ dW, const float* __restrict__ Wt, int B, int T, int V,
+                                        float* __restrict__ out) {
+    const long n = (long)B * T * V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(i % V);
+        const long bt = i / V;
+        const int tt = (int)(bt % T), b = (int)(bt / T);
+        const float g = Wt[i] > 0.f ? dW[i] : 0.f;
+        out[((long)tt * B + b) * V + v] = g;
+    }
+}
+
+// out[g][b][c] = sum_{j<G} in[(g*G + j)][b][c]   (sum the ticks of each beat)
+__global__ void group_sum_kernel(const float* __restrict__ in, int groups, int G, long inner, float* __restrict__ out) {
+    const long n = (long)groups * inner;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / inner, r = i % inner;
+        float s = 0.f;
+        for (int j = 0; j < G; ++j) s += in[((long)g * G + j) * inner + r];
+        out[i] = s;
+    }
+}
+
+// y[i] = a * x[i*incx] + (b ? b[i] : 0)
+__global__ void axpb_kernel(const float* a_ptr, const float* __restrict__ x, long incx, const float* __restrict__ b,
+                            float* __restrict__ y, int n) {
+    const float a = *a_ptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        y[i] = a * x[(long)i * incx] + (b ? b[i] : 0.f);
+}
+
+// Beat-RNN layer-0 input gradients: gi = b0 * w + b_ih  =>  dw[i*incw] += b0 * s[i];  db0 += sum_i s[i]*w[i*incw]
+__global__ void beat_input_grad_kernel(const float* __restrict__ s, const float* __restrict__ w, long incw,
+                                       const float* b0, float* __restrict__ dw, float* __restrict__ db0, int n) {
+    const float bb = *b0;
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float si = s[i];
+        dw[(long)i * incw] += bb * si;
+        acc += si * w[(long)i * incw];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(db0, acc);
+}
+
+// Counter-based dropout mask: out = keep ? 1/(1-p) : 0, keep ~ Bernoulli(1-p).
+// splitmix64-style hash of (seed, stream offset + element index): reproducible,
+// rank-offsettable, no state.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void dropout_mask_kernel(float* __restrict__ out, long n, float p, uint64_t seed, uint64_t offset) {
+    const float scale = 1.f / (1.f - p);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const uint64_t h = mix64(mix64(seed) ^ (offset + (uint64_t)i));
+        out[i] = ((uint32_t)(h >> 32) >= thr) ? scale : 0.f;
+    }
+}
+
+__global__ void scale_kernel(float* __restrict__ x, long n, float a) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= a;
+}
+
+inline int grid_for(long n, int block = 256, int cap = 2048) {
+    long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -2; }
+
+}  // namespace
+
+int pw_transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, hipStream_t s) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols);
+    return ok();
+}
+int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
+                     float scale, float* loss_sum, float* correct, hipStream_t s) {
+    const int g = grid_for((long)rows * 64, 256, 1024);
+    hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, loss_sum, correct);
+    return ok();
+}
+int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(reparam_kl_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, s, mu, ls, eps, z, sigma, n, kl_sum);
+    return ok();
+}
+int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, float* dmu,
+                  float* dls, long n, hipStream_t s) {
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, s, dz, mu, ls, eps, kscale, dmu, dls, n);
+    return ok();
+}
+int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+            float gscale, hipStream_t s) {
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale);
+    return ok();
+}
+int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s) {
+    int gy = (M + 255) / 256;
+    if (gy > 64) gy = 64;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, s, X, ld, M, N, out);
+    return ok();
+}
+int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
+              hipStream_t s) {
+    if (zero_first && hipMemsetAsync(out, 0, (size_t)rows * W * sizeof(float), s) != hipSuccess) return -2;
+    hipLaunchKernelGGL(onehot_kernel, dim3(grid_for(rows)), dim3(256), 0, s, idx, inner, s_outer, s_inner, rows, W, out);
+    return ok();
+}
+int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s) {
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, m, n, selu_grad);
+    return ok();
+}
+int pw_swap01(const float* in, int A, int B, int K, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(swap01_kernel, dim3(grid_for((long)A * B * K)), dim3(256), 0, s, in, A, B, K, out);
+    return ok();
+}
+int pw_argmax(const float* W, long ld_w, int rows, int V, long long* out, long stride, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(grid_for((long)rows * 64, 256, 1024)), dim3(256), 0, s, W, ld_w, rows, V, out, stride);
+    return ok();
+}
+int pw_fill_i64(long long* p, long n, long long v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, n, v);
+    return ok();
+}
+int pw_copy2d(float* dst, long ld_d, const float* src, long ld_s, const float* pos, long ld_p, int rows, int cols,
+              hipStream_t s) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((long)rows * cols)), dim3(256), 0, s, dst, ld_d, src, ld_s, pos, ld_p, rows, cols);
+    return ok();
+}
+int pw_dlogits_relayout(const float* dW, const float* Wt, int B, int T, int V, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(dlogits_relayout_kernel, dim3(grid_for((long)B * T * V)), dim3(256), 0, s, dW, Wt, B, T, V, out);
+    return ok();
+}
+int pw_group_sum(const float* in, int groups, int G, long inner, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for((long)groups * inner)), dim3(256), 0, s, in, groups, G, inner, out);
+    return ok();
+}
+int pw_axpb(const float* a, const float* x, long incx, const float* b, float* y, int n, hipStream_t s) {
+    hipLaunchKernelGGL(axpb_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, x, incx, b, y, n);
+    return ok();
+}
+int pw_beat_input_grad(const float* sv, const float* w, long incw, const float* b0, float* dw, float* db0, int n,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(beat_input_grad_kernel, dim3(grid_for(n)), dim3(256), 0, s, sv, w, incw, b0, dw, db0, n);
+    return ok();
+}
+int pw_dropout_mask(float* out, long n, float p, uint64_t seed, uint64_t offset, hipStream_t s) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, n, p, seed, offset);
+    return ok();
+}
+int pw_scale(float* x, long n, float a, hipStream_t s) {
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n, a);
+    return ok();
+}

@@ -1,0 +1,108 @@
+// Host-side sequencing of the fused step kernels: one GRU layer (1..4 independent
+// "directions"/problems per launch) forward and backward through time, the
+// batched weight-gradient contractions, and the 2-layer bidirectional stack used
+// by the MeasureVAE encoder and the LatentRNN context/generator GRUs.
+// All activations are time-major: row (t,b) of a sequence buffer lives at
+// base + t*ts + b*ld.
+#pragma once
+#include "common.h"
+#include "pointwise.h"
+
+#define INET_TRY(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
+
+struct Carver {
+    char* base; size_t off;
+    explicit Carver(void* b) : base((char*)b), off(0) {}
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+    size_t bytes() const { return (off + 255) & ~(size_t)255; }
+};
+
+struct DirFwd {
+    const float* W_hh; const float* b_hh;
+    const float* gi; long gi_ld, gi_ts;                       // dense input-side pre-activations, or null
+    const float* table; long table_ld;                        // gathered rows, or null
+    const long long* idx; long idx_bs, idx_ts;                // token of (t,b) = idx[b*idx_bs + t*idx_ts]
+    const float* gvec;                                        // [3H] broadcast, or null
+    const float* h0; long h0_ld;                              // initial hidden [B,H]
+    float* out; long out_ld, out_ts;                          // raw outputs
+    float* outm; long outm_ld, outm_ts;                       // dropout-masked outputs (or null)
+    const float* mask; long mask_ld, mask_ts;
+    float* hlast; long hlast_ld;                              // extra copy of the final hidden (or null)
+    float* sv; long sv_astride;                               // 5 saved arrays (r,z,n,ghn,hprev), each [T][B][H]; or null
+    int reverse;
+};
+
+struct DirBwd {
+    const float* W_hhT;                                       // [H,3H]
+    const float* dout; long dout_ld, dout_ts;                 // dLoss/d out(t), or null
+    const float* dhn; long dhn_ld;                            // dLoss/d final hidden, or null
+    const float* sv; long sv_astride;
+    float* dgi; long dgi_ld, dgi_ts;                          // [T][B][3H] (strided)
+    float* dgh;                                               // [T][B][3H] dense
+    float* dhz;                                               // [2][B][H]
+    float* dh0; long dh0_ld; int dh0_acc;                     // dLoss/d initial hidden, or null
+    int reverse;
+};
+
+int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
+int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
+// dW_hh += dgh^T hprev ; db_hh += colsum(dgh) ; db_ih += colsum(dgi)       (rows = T*B, contiguous in t then b)
+int gru_dir_wgrad(int H, int B, int T, const float* dgh, const float* dgi, long dgi_ld, const float* sv_hprev,
+                  float* dW_hh, float* db_hh, float* db_ih, hipStream_t s);
+
+inline GemmArgs gemm_args(const float* A, long lda, int akm, const float* Bm, long ldb, int bkm, float* C, long ldc,
+                          int M, int N, int K, const float* bias = nullptr, int epi = EPI_NONE,
+                          const float* aux = nullptr, long ldaux = 0, int acc = ACC_STORE) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.a_kmajor = akm; g.B = Bm; g.ldb = ldb; g.b_kmajor = bkm; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.epi = epi; g.acc = acc;
+    g.k_per_split = K;
+    return g;
+}
+// y[M,N] = epi(x[M,K] W[N,K]^T + b)                       (nn.Linear forward)
+inline int linear_fwd(const float* x, long ldx, const float* W, long ldw, const float* b, float* y, long ldy, int M,
+                      int N, int K, int epi, hipStream_t s) {
+    return launch_gemm(gemm_args(x, ldx, 0, W, ldw, 0, y, ldy, M, N, K, b, epi), s);
+}
+// dx[M,K] (op)= epi(dy[M,N] W[N,K])                        (dgrad)
+inline int linear_dgrad(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N, int K,
+                        int epi, const float* aux, long ldaux, int acc, hipStream_t s) {
+    return launch_gemm(gemm_args(dy, lddy, 0, W, ldw, 1, dx, lddx, M, K, N, nullptr, epi, aux, ldaux, acc), s);
+}
+// dW[N,K] += dy[M,N]^T x[M,K]                              (wgrad)
+inline int linear_wgrad(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M, int N, int K,
+                        hipStream_t s) {
+    return launch_gemm(gemm_args(dy, lddy, 1, x, ldx, 1, dW, lddw, N, K, M, nullptr, EPI_NONE, nullptr, 0, ACC_ADD), s);
+}
+
+// ---- 2-layer bidirectional GRU core --------------------------------------------------
+struct GruDirPtr { const float *w_ih, *w_hh, *b_ih, *b_hh; float *dw_ih, *dw_hh, *db_ih, *db_hh; int K; };
+
+struct BiGru2Ws {
+    float *zeros, *x1raw, *x1m, *gi1, *h1, *sv[4];
+    float *whhT[4], *dgi1, *dgh[4], *dhz, *dx1, *dgi0;
+};
+size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w);
+
+// Layer-0 input-side pre-activations come from the caller, per direction d:
+//   dense  gi0[d]   rows (t,b) at gi0[d] + t*gi0_ts + b*gi0_ld     (or null)
+//   table  tab[d] (+ idx, idx_bs, idx_ts)                           (or null)
+//   gvec   gvec[d]                                                  (or null)
+struct BiGru2In {
+    const float* gi0[2]; long gi0_ld, gi0_ts;
+    const float* tab[2]; long tab_ld; const long long* idx; long idx_bs, idx_ts;
+    const float* gvec[2];
+};
+// h0: [4][B][H] or null.  mask: [T][B][2H] or null.  hn4: 4 destinations (ld given) for final hiddens or null.
+int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P /*[4]*/, const BiGru2In& in, const float* h0,
+                    const float* mask, float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s);
+// dout1: gradient wrt the top layer outputs [T][B][2H] (or null); dhn[4] (ld) gradients wrt final hiddens (or null each).
+// Produces w.dgi0 [T][B][6H] (layer-0 input-side gate gradients, fwd dir cols 0..3H, reverse 3H..6H), accumulates the
+// recurrent / layer-1 weight gradients into P[*].d* (skipped when P[0].dw_hh is null), dh0 [4][B][H] (or null).
+int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, const float* dout1,
+                    const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s);

@@ -1,0 +1,216 @@
+#include "seq.h"
+
+int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
+    const long BH = (long)B * H;
+    for (int step = 0; step < T; ++step) {
+        GruFwdBatch bt{};
+        bt.H = H; bt.nprob = nd;
+        for (int i = 0; i < nd; ++i) {
+            const DirFwd& D = d[i];
+            GruFwdProb& P = bt.p[i];
+            const int t = D.reverse ? T - 1 - step : step;
+            const int tp = D.reverse ? t + 1 : t - 1;
+            P.B = B;
+            if (step == 0) { P.h_prev = D.h0; P.ld_hprev = D.h0_ld; }
+            else { P.h_prev = D.out + (long)tp * D.out_ts; P.ld_hprev = D.out_ld; }
+            P.W_hh = D.W_hh; P.b_hh = D.b_hh;
+            if (D.gi) { P.gi_dense = D.gi + (long)t * D.gi_ts; P.ld_gi = D.gi_ld; }
+            if (D.table) {
+                P.gi_table = D.table; P.ld_table = D.table_ld;
+                P.idx = D.idx + (long)t * D.idx_ts; P.idx_stride = D.idx_bs;
+            }
+            P.gi_vec = D.gvec;
+            P.h_new = D.out + (long)t * D.out_ts; P.ld_hnew = D.out_ld;
+            if (D.outm) {
+                P.h_masked = D.outm + (long)t * D.outm_ts; P.ld_hm = D.outm_ld;
+                P.mask = D.mask ? D.mask + (long)t * D.mask_ts : nullptr; P.ld_mask = D.mask_ld;
+            }
+            if (D.hlast && step == T - 1) { P.h_copy = D.hlast; P.ld_hc = D.hlast_ld; }
+            if (D.sv) {
+                float* b0 = D.sv + (long)t * BH;
+                P.sv_r = b0; P.sv_z = b0 + D.sv_astride; P.sv_n = b0 + 2 * D.sv_astride;
+                P.sv_ghn = b0 + 3 * D.sv_astride; P.sv_hprev = b0 + 4 * D.sv_astride;
+            }
+        }
+        INET_TRY(launch_gru_fwd(bt, s));
+    }
+    return 0;
+}
+
+int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
+    const long BH = (long)B * H, B3H = 3 * BH;
+    for (int step = T - 1; step >= 0; --step) {
+        GruBwdBatch bt{};
+        bt.H = H; bt.nprob = nd;
+        for (int i = 0; i < nd; ++i) {
+            const DirBwd& D = d[i];
+            GruBwdProb& P = bt.p[i];
+            const int t = D.reverse ? T - 1 - step : step;
+            const int tn = D.reverse ? t - 1 : t + 1;          // the step processed just before (later in time order)
+            P.B = B;
+            if (step != T - 1) {
+                P.dgh_next = D.dgh + (long)tn * B3H; P.ld_dgh = 3L * H;
+                P.W_hhT = D.W_hhT;
+                P.dhz_next = D.dhz + (long)((step + 1) & 1) * BH;
+            } else if (D.dhn) {
+                P.dout2 = D.dhn; P.ld_dout2 = D.dhn_ld;
+            }
+            if (D.dout) { P.dout = D.dout + (long)t * D.dout_ts; P.ld_dout = D.dout_ld; }
+            const float* b0 = D.sv + (long)t * BH;
+            P.sv_r = b0; P.sv_z = b0 + D.sv_astride; P.sv_n = b0 + 2 * D.sv_astride;
+            P.sv_ghn = b0 + 3 * D.sv_astride; P.sv_hprev = b0 + 4 * D.sv_astride;
+            P.dgi = D.dgi + (long)t * D.dgi_ts; P.ld_dgi = D.dgi_ld;
+            P.dgh = D.dgh + (long)t * B3H; P.ld_dghout = 3L * H;
+            P.dhz = D.dhz + (long)(step & 1) * BH;
+        }
+        INET_TRY(launch_gru_bwd(bt, s));
+    }
+    bool any = false, all = true;
+    for (int i = 0; i < nd; ++i) { if (d[i].dh0) any = true; else all = false; }
+    if (any) {
+        if (!all) return -1;
+        GruBwdBatch bt{};
+        bt.H = H; bt.nprob = nd;
+        for (int i = 0; i < nd; ++i) {
+            const DirBwd& D = d[i];
+            GruBwdProb& P = bt.p[i];
+            const int t0 = D.reverse ? T - 1 : 0;
+            P.B = B;
+            P.dgh_next = D.dgh + (long)t0 * B3H; P.ld_dgh = 3L * H;
+            P.W_hhT = D.W_hhT;
+            P.dhz_next = D.dhz;                                 // step 0 wrote slot 0
+            P.dh_out = D.dh0; P.ld_dhout = D.dh0_ld; P.dh_out_accumulate = D.dh0_acc;
+        }
+        INET_TRY(launch_gru_bwd(bt, s));
+    }
+    return 0;
+}
+
+int gru_dir_wgrad(int H, int B, int T, const float* dgh, const float* dgi, long dgi_ld, const float* sv_hprev,
+                  float* dW_hh, float* db_hh, float* db_ih, hipStream_t s) {
+    const int rows = T * B;
+    INET_TRY(linear_wgrad(dgh, 3L * H, sv_hprev, H, dW_hh, H, rows, 3 * H, H, s));
+    INET_TRY(pw_colsum(dgh, 3L * H, rows, 3 * H, db_hh, s));
+    INET_TRY(pw_colsum(dgi, dgi_ld, rows, 3 * H, db_ih, s));
+    return 0;
+}
+
+size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
+    const size_t BH = (size_t)B * H, TBH = (size_t)T * BH;
+    w.zeros = c.take<float>(BH);
+    w.x1raw = c.take<float>(2 * TBH);
+    w.x1m = c.take<float>(2 * TBH);
+    w.gi1 = c.take<float>(6 * TBH);
+    w.h1 = c.take<float>(2 * TBH);
+    for (int i = 0; i < 4; ++i) w.sv[i] = save ? c.take<float>(5 * TBH) : nullptr;
+    if (save) {
+        for (int i = 0; i < 4; ++i) w.whhT[i] = c.take<float>((size_t)3 * H * H);
+        w.dgi1 = c.take<float>(6 * TBH);
+        for (int i = 0; i < 4; ++i) w.dgh[i] = c.take<float>(3 * TBH);
+        w.dhz = c.take<float>(4 * BH);
+        w.dx1 = c.take<float>(2 * TBH);
+        w.dgi0 = c.take<float>(6 * TBH);
+    } else {
+        for (int i = 0; i < 4; ++i) { w.whhT[i] = nullptr; w.dgh[i] = nullptr; }
+        w.dgi1 = w.dhz = w.dx1 = w.dgi0 = nullptr;
+    }
+    return c.bytes();
+}
+
+int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in, const float* h0, const float* mask,
+                    float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s) {
+    const long BH = (long)B * H, TBH = (long)T * BH;
+    if (!h0 && hipMemsetAsync(w.zeros, 0, BH * sizeof(float), s) != hipSuccess) return -2;
+    DirFwd d[2];
+    for (int dir = 0; dir < 2; ++dir) {
+        DirFwd& D = d[dir];
+        D = DirFwd{};
+        D.W_hh = P[dir].w_hh; D.b_hh = P[dir].b_hh;
+        if (in.gi0[dir]) { D.gi = in.gi0[dir]; D.gi_ld = in.gi0_ld; D.gi_ts = in.gi0_ts; }
+        if (in.tab[dir]) { D.table = in.tab[dir]; D.table_ld = in.tab_ld; D.idx = in.idx; D.idx_bs = in.idx_bs; D.idx_ts = in.idx_ts; }
+        D.gvec = in.gvec[dir];
+        D.h0 = h0 ? h0 + dir * BH : w.zeros; D.h0_ld = H;
+        D.out = w.x1raw + dir * H; D.out_ld = 2L * H; D.out_ts = 2 * BH;
+        if (mask) {
+            D.outm = w.x1m + dir * H; D.outm_ld = 2L * H; D.outm_ts = 2 * BH;
+            D.mask = mask + dir * H; D.mask_ld = 2L * H; D.mask_ts = 2 * BH;
+        }
+        if (hn && hn[dir]) { D.hlast = hn[dir]; D.hlast_ld = hn_ld; }
+        if (save) { D.sv = w.sv[dir]; D.sv_astride = TBH; }
+        D.reverse = dir;
+    }
+    INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
+    const float* x1 = mask ? w.x1m : w.x1raw;
+    for (int dir = 0; dir < 2; ++dir)
+        INET_TRY(linear_fwd(x1, 2L * H, P[2 + dir].w_ih, 2L * H, P[2 + dir].b_ih, w.gi1 + dir * 3L * H, 6L * H,
+                            T * B, 3 * H, 2 * H, EPI_NONE, s));
+    for (int dir = 0; dir < 2; ++dir) {
+        DirFwd& D = d[dir];
+        D = DirFwd{};
+        D.W_hh = P[2 + dir].w_hh; D.b_hh = P[2 + dir].b_hh;
+        D.gi = w.gi1 + dir * 3L * H; D.gi_ld = 6L * H; D.gi_ts = 6 * BH;
+        D.h0 = h0 ? h0 + (2 + dir) * BH : w.zeros; D.h0_ld = H;
+        D.out = w.h1 + dir * H; D.out_ld = 2L * H; D.out_ts = 2 * BH;
+        if (hn && hn[2 + dir]) { D.hlast = hn[2 + dir]; D.hlast_ld = hn_ld; }
+        if (save) { D.sv = w.sv[2 + dir]; D.sv_astride = TBH; }
+        D.reverse = dir;
+    }
+    INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
+    return 0;
+}
+
+int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, const float* dout1,
+                    const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s) {
+    const long BH = (long)B * H, TBH = (long)T * BH;
+    const bool wg = P[0].dw_hh != nullptr;
+    for (int i = 0; i < 4; ++i) INET_TRY(pw_transpose(P[i].w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+    // ---- layer 1 ----
+    DirBwd d[2];
+    for (int dir = 0; dir < 2; ++dir) {
+        DirBwd& D = d[dir];
+        D = DirBwd{};
+        D.W_hhT = w.whhT[2 + dir];
+        if (dout1) { D.dout = dout1 + dir * H; D.dout_ld = 2L * H; D.dout_ts = 2 * BH; }
+        if (dhn && dhn[2 + dir]) { D.dhn = dhn[2 + dir]; D.dhn_ld = dhn_ld; }
+        D.sv = w.sv[2 + dir]; D.sv_astride = TBH;
+        D.dgi = w.dgi1 + dir * 3L * H; D.dgi_ld = 6L * H; D.dgi_ts = 6 * BH;
+        D.dgh = w.dgh[2 + dir];
+        D.dhz = w.dhz + dir * 2 * BH;
+        if (dh0) { D.dh0 = dh0 + (2 + dir) * BH; D.dh0_ld = H; D.dh0_acc = 0; }
+        D.reverse = dir;
+    }
+    INET_TRY(gru_layer_bwd(H, B, T, 2, d, s));
+    const float* x1 = mask ? w.x1m : w.x1raw;
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* dgi = w.dgi1 + dir * 3L * H;
+        if (wg) {
+            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[2 + dir], dgi, 6L * H, w.sv[2 + dir] + 4 * TBH, P[2 + dir].dw_hh,
+                                   P[2 + dir].db_hh, P[2 + dir].db_ih, s));
+            INET_TRY(linear_wgrad(dgi, 6L * H, x1, 2L * H, P[2 + dir].dw_ih, 2L * H, T * B, 3 * H, 2 * H, s));
+        }
+        // dx1 [TB,2H] (+)= dgi1_dir [TB,3H] . W_ih_l1_dir [3H,2H]
+        INET_TRY(linear_dgrad(dgi, 6L * H, P[2 + dir].w_ih, 2L * H, w.dx1, 2L * H, T * B, 3 * H, 2 * H, EPI_NONE, nullptr,
+                              0, dir == 0 ? ACC_STORE : ACC_ADD, s));
+    }
+    if (mask) INET_TRY(pw_mul(w.dx1, mask, 2 * TBH, 0, s));
+    // ---- layer 0 ----
+    for (int dir = 0; dir < 2; ++dir) {
+        DirBwd& D = d[dir];
+        D = DirBwd{};
+        D.W_hhT = w.whhT[dir];
+        D.dout = w.dx1 + dir * H; D.dout_ld = 2L * H; D.dout_ts = 2 * BH;
+        if (dhn && dhn[dir]) { D.dhn = dhn[dir]; D.dhn_ld = dhn_ld; }
+        D.sv = w.sv[dir]; D.sv_astride = TBH;
+        D.dgi = w.dgi0 + dir * 3L * H; D.dgi_ld = 6L * H; D.dgi_ts = 6 * BH;
+        D.dgh = w.dgh[dir];
+        D.dhz = w.dhz + dir * 2 * BH;
+        if (dh0) { D.dh0 = dh0 + dir * BH; D.dh0_ld = H; D.dh0_acc = 0; }
+        D.reverse = dir;
+    }
+    INET_TRY(gru_layer_bwd(H, B, T, 2, d, s));
+    if (wg)
+        for (int dir = 0; dir < 2; ++dir)
+            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[dir], w.dgi0 + dir * 3L * H, 6L * H, w.sv[dir] + 4 * TBH, P[dir].dw_hh,
+                                   P[dir].db_hh, P[dir].db_ih, s));
+    return 0;
+}

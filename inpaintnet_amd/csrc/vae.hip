@@ -1,0 +1,423 @@
+// MeasureVAE encoder / hierarchical decoder: host-side orchestration of the
+// gfx950 kernels.  Follows MeasureVAE/encoder.py:104-134 and
+// MeasureVAE/decoder.py:392-529 of the reference; see oracle/torch_ref.py for
+// the CPU restatement these are tested against.
+//
+// Algebraic re-arrangements (exact in real arithmetic, fp32 round-off only):
+//  * embedding -> GRU layer-0 input projection is folded into a gather table
+//    Table[v] = E[v] . W_ih[:, :E]^T + b_ih  (V x 3H), rebuilt per call because
+//    the weights train; the fused step kernel gathers Table[token].
+//  * the beat-constant half of the tick GRU input, c_i . W_ih[:, E:]^T, is hoisted
+//    out of the 6 ticks of a beat.
+//  * embedding gradients are one-hot MFMA contractions (no contended atomics).
+//  * in the backward pass the 4 beats are independent through the tick GRU's
+//    hidden state (it is re-initialised per beat), so BPTT runs 6 steps over 4
+//    problems instead of 24 steps.
+#include "seq.h"
+#include "layout.h"
+#include "vae.h"
+
+namespace {
+
+struct EncWs {
+    float *tabF, *tabR, *hcat, *a_mu, *a_ls;
+    BiGru2Ws g;
+    float *d_amu, *d_als, *dhcat, *onehot, *dtab;
+};
+
+size_t enc_carve(const inet_vae_config& c, int B, int save, void* base, EncWs& w) {
+    Carver cv(base);
+    const int T = c.beats * c.ticks_per_beat, H = c.enc_hidden, V = c.num_notes;
+    w.tabF = cv.take<float>((size_t)V * 3 * H);
+    w.tabR = cv.take<float>((size_t)V * 3 * H);
+    w.hcat = cv.take<float>((size_t)B * 4 * H);
+    w.a_mu = cv.take<float>((size_t)B * 2 * H);
+    w.a_ls = cv.take<float>((size_t)B * 2 * H);
+    bigru2_carve(cv, B, T, H, save, w.g);
+    if (save) {
+        w.d_amu = cv.take<float>((size_t)B * 2 * H);
+        w.d_als = cv.take<float>((size_t)B * 2 * H);
+        w.dhcat = cv.take<float>((size_t)B * 4 * H);
+        w.onehot = cv.take<float>((size_t)T * B * V);
+        w.dtab = cv.take<float>((size_t)V * 3 * H);
+    } else {
+        w.d_amu = w.d_als = w.dhcat = w.onehot = w.dtab = nullptr;
+    }
+    return cv.bytes();
+}
+
+void enc_ptrs(const VaeLayout& L, const float* p, float* g, GruDirPtr* P) {
+    for (int i = 0; i < 4; ++i) {
+        const GruDirOff& o = L.enc[i];
+        P[i].w_ih = p + o.w_ih; P[i].w_hh = p + o.w_hh; P[i].b_ih = p + o.b_ih; P[i].b_hh = p + o.b_hh;
+        P[i].dw_ih = g ? g + o.w_ih : nullptr; P[i].dw_hh = g ? g + o.w_hh : nullptr;
+        P[i].db_ih = g ? g + o.b_ih : nullptr; P[i].db_hh = g ? g + o.b_hh : nullptr;
+        P[i].K = o.K;
+    }
+}
+
+}  // namespace
+
+size_t vae_encoder_ws_bytes(const inet_vae_config& c, int B, int save) {
+    EncWs w;
+    return enc_carve(c, B, save, nullptr, w);
+}
+
+int vae_encoder_fwd(const inet_vae_config& c, int B, const long long* tokens, const float* p, const float* mask,
+                    float* mu, float* logsigma, void* ws, int save, hipStream_t s) {
+    const int T = c.beats * c.ticks_per_beat, H = c.enc_hidden, V = c.num_notes, E = c.emb_dim, Z = c.z_dim;
+    VaeLayout L(c);
+    EncWs w;
+    enc_carve(c, B, save, ws, w);
+    GruDirPtr P[4];
+    enc_ptrs(L, p, nullptr, P);
+    // gather tables: E_enc [V,E] x W_ih_l0[dir] [3H,E]^T + b_ih
+    INET_TRY(linear_fwd(p + L.enc_emb, E, P[0].w_ih, E, P[0].b_ih, w.tabF, 3L * H, V, 3 * H, E, EPI_NONE, s));
+    INET_TRY(linear_fwd(p + L.enc_emb, E, P[1].w_ih, E, P[1].b_ih, w.tabR, 3L * H, V, 3 * H, E, EPI_NONE, s));
+    BiGru2In in{};
+    in.tab[0] = w.tabF; in.tab[1] = w.tabR; in.tab_ld = 3L * H;
+    in.idx = tokens; in.idx_bs = T; in.idx_ts = 1;
+    // final hiddens land directly in hcat = [l0f | l0b | l1f | l1b]   (encoder.py:126-127)
+    float* hn[4] = {w.hcat, w.hcat + H, w.hcat + 2 * H, w.hcat + 3 * H};
+    INET_TRY(bigru2_core_fwd(B, T, H, P, in, nullptr, mask, hn, 4L * H, w.g, save, s));
+    INET_TRY(linear_fwd(w.hcat, 4L * H, p + L.mean_w0, 4L * H, p + L.mean_b0, w.a_mu, 2L * H, B, 2 * H, 4 * H, EPI_SELU, s));
+    INET_TRY(linear_fwd(w.a_mu, 2L * H, p + L.mean_w2, 2L * H, p + L.mean_b2, mu, Z, B, Z, 2 * H, EPI_NONE, s));
+    INET_TRY(linear_fwd(w.hcat, 4L * H, p + L.ls_w0, 4L * H, p + L.ls_b0, w.a_ls, 2L * H, B, 2 * H, 4 * H, EPI_SELU, s));
+    INET_TRY(linear_fwd(w.a_ls, 2L * H, p + L.ls_w2, 2L * H, p + L.ls_b2, logsigma, Z, B, Z, 2 * H, EPI_NONE, s));
+    return 0;
+}
+
+int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, const float* p, float* g,
+                    const float* mask, const float* dmu, const float* dls, void* ws, hipStream_t s) {
+    const int T = c.beats * c.ticks_per_beat, H = c.enc_hidden, V = c.num_notes, E = c.emb_dim, Z = c.z_dim;
+    if (!g) return -1;
+    VaeLayout L(c);
+    EncWs w;
+    enc_carve(c, B, 1, ws, w);
+    GruDirPtr P[4];
+    enc_ptrs(L, p, g, P);
+    // heads
+    INET_TRY(linear_dgrad(dmu, Z, p + L.mean_w2, 2L * H, w.d_amu, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_mu, 2L * H, ACC_STORE, s));
+    INET_TRY(linear_dgrad(dls, Z, p + L.ls_w2, 2L * H, w.d_als, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_ls, 2L * H, ACC_STORE, s));
+    INET_TRY(linear_wgrad(dmu, Z, w.a_mu, 2L * H, g + L.mean_w2, 2L * H, B, Z, 2 * H, s));
+    INET_TRY(linear_wgrad(dls, Z, w.a_ls, 2L * H, g + L.ls_w2, 2L * H, B, Z, 2 * H, s));
+    INET_TRY(pw_colsum(dmu, Z, B, Z, g + L.mean_b2, s));
+    INET_TRY(pw_colsum(dls, Z, B, Z, g + L.ls_b2, s));
+    INET_TRY(linear_dgrad(w.d_amu, 2L * H, p + L.mean_w0, 4L * H, w.dhcat, 4L * H, B, 2 * H, 4 * H, EPI_NONE, nullptr, 0, ACC_STORE, s));
+    INET_TRY(linear_dgrad(w.d_als, 2L * H, p + L.ls_w0, 4L * H, w.dhcat, 4L * H, B, 2 * H, 4 * H, EPI_NONE, nullptr, 0, ACC_ADD, s));
+    INET_TRY(linear_wgrad(w.d_amu, 2L * H, w.hcat, 4L * H, g + L.mean_w0, 4L * H, B, 2 * H, 4 * H, s));
+    INET_TRY(linear_wgrad(w.d_als, 2L * H, w.hcat, 4L * H, g + L.ls_w0, 4L * H, B, 2 * H, 4 * H, s));
+    INET_TRY(pw_colsum(w.d_amu, 2L * H, B, 2 * H, g + L.mean_b0, s));
+    INET_TRY(pw_colsum(w.d_als, 2L * H, B, 2 * H, g + L.ls_b0, s));
+    // GRU stack
+    const float* dhn[4] = {w.dhcat, w.dhcat + H, w.dhcat + 2 * H, w.dhcat + 3 * H};
+    INET_TRY(bigru2_core_bwd(B, T, H, P, mask, nullptr, dhn, 4L * H, nullptr, w.g, s));
+    // embedding / layer-0 input weights through the gather table
+    INET_TRY(pw_onehot(tokens, B, 1, T, T * B, V, w.onehot, 1, s));          // row (t,b) -> tokens[b*T + t]
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* dgi = w.g.dgi0 + dir * 3L * H;
+        // dTable [V,3H] = onehot^T [V,TB] . dgi0 [TB,3H]
+        INET_TRY(launch_gemm(gemm_args(w.onehot, V, 1, dgi, 6L * H, 1, w.dtab, 3L * H, V, 3 * H, T * B), s));
+        // dW_ih_l0 [3H,E] += dTable^T . E_enc ;  dE_enc [V,E] += dTable . W_ih_l0
+        INET_TRY(linear_wgrad(w.dtab, 3L * H, p + L.enc_emb, E, P[dir].dw_ih, E, V, 3 * H, E, s));
+        INET_TRY(linear_dgrad(w.dtab, 3L * H, P[dir].w_ih, E, g + L.enc_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, s));
+    }
+    return 0;
+}
+
+// =====================================================================================
+// Decoder
+// =====================================================================================
+namespace {
+
+struct DecWs {
+    float *zsave, *hb0, *gvec0, *beat0, *beat0m, *svb0, *gi1b, *beat_out, *svb1;
+    float *ht0, *c_all, *cgi, *table;
+    long long* idxV;
+    float *h0seq, *h0m, *svt0, *h1seq, *svt1;
+    // backward
+    float *whhT[4], *dlg, *dh1top, *dgi1t, *dgh1t, *dhz, *dht0, *dx1t, *dgi0t, *dgh0t, *dcgi, *dc_all, *onehot, *dtable;
+    float *dbeat_out, *dgi1b, *dgh1b, *dxb, *dgi0b, *dgh0b, *dhb0, *tmp3h;
+};
+
+size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w) {
+    Carver cv(base);
+    const size_t nb = c.beats, T = (size_t)c.beats * c.ticks_per_beat, H = c.dec_hidden, V = c.num_notes, Z = c.z_dim;
+    const size_t BH = (size_t)B * H;
+    w.zsave = cv.take<float>((size_t)B * Z);
+    w.hb0 = cv.take<float>(2 * BH);
+    w.gvec0 = cv.take<float>(3 * H);
+    w.beat0 = cv.take<float>(nb * BH);
+    w.beat0m = cv.take<float>(nb * BH);
+    w.svb0 = save ? cv.take<float>(5 * nb * BH) : nullptr;
+    w.gi1b = cv.take<float>(3 * nb * BH);
+    w.beat_out = cv.take<float>(nb * BH);
+    w.svb1 = save ? cv.take<float>(5 * nb * BH) : nullptr;
+    w.ht0 = cv.take<float>(2 * nb * BH);
+    w.c_all = cv.take<float>(nb * BH);
+    w.cgi = cv.take<float>(3 * nb * BH);
+    w.table = cv.take<float>((V + 1) * 3 * H);
+    w.idxV = cv.take<long long>(B);
+    w.h0seq = cv.take<float>(T * BH);
+    w.h0m = cv.take<float>(T * BH);
+    w.svt0 = save ? cv.take<float>(5 * T * BH) : nullptr;
+    w.h1seq = cv.take<float>(T * BH);
+    w.svt1 = save ? cv.take<float>(5 * T * BH) : nullptr;
+    if (save) {
+        for (int i = 0; i < 4; ++i) w.whhT[i] = cv.take<float>(3 * H * H);
+        w.dlg = cv.take<float>(T * B * V);
+        w.dh1top = cv.take<float>(T * BH);
+        w.dgi1t = cv.take<float>(3 * T * BH);
+        w.dgh1t = cv.take<float>(3 * T * BH);
+        w.dhz = cv.take<float>(2 * nb * BH);
+        w.dht0 = cv.take<float>(2 * nb * BH);
+        w.dx1t = cv.take<float>(T * BH);
+        w.dgi0t = cv.take<float>(3 * T * BH);
+        w.dgh0t = cv.take<float>(3 * T * BH);
+        w.dcgi = cv.take<float>(3 * nb * BH);
+        w.dc_all = cv.take<float>(nb * BH);
+        w.onehot = cv.take<float>(T * B * (V + 1));
+        w.dtable = cv.take<float>((V + 1) * 3 * H);
+        w.dbeat_out = cv.take<float>(nb * BH);
+        w.dgi1b = cv.take<float>(3 * nb * BH);
+        w.dgh1b = cv.take<float>(3 * nb * BH);
+        w.dxb = cv.take<float>(nb * BH);
+        w.dgi0b = cv.take<float>(3 * nb * BH);
+        w.dgh0b = cv.take<float>(3 * nb * BH);
+        w.dhb0 = cv.take<float>(2 * BH);
+        w.tmp3h = cv.take<float>(3 * H);
+    }
+    return cv.bytes();
+}
+
+}  // namespace
+
+size_t vae_decoder_ws_bytes(const inet_vae_config& c, int B, int save) {
+    DecWs w{};
+    return dec_carve(c, B, save, nullptr, w);
+}
+
+int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long long* target, int teacher_forced,
+                    const float* p, const float* mask_beat, const float* mask_tick, float* weights,
+                    long long* samples, void* ws, int save, hipStream_t s) {
+    const int nb = c.beats, G = c.ticks_per_beat, T = nb * G, H = c.dec_hidden, V = c.num_notes, E = c.emb_dim, Z = c.z_dim;
+    const long BH = (long)B * H;
+    if (nb > 4) return -1;
+    if (teacher_forced && !target) return -1;
+    VaeLayout L(c);
+    DecWs w{};
+    dec_carve(c, B, save, ws, w);
+    if (save && hipMemcpyAsync(w.zsave, z, (size_t)B * Z * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+
+    // ---- beat RNN (forward_beat_rnn, decoder.py:455-471) ----
+    INET_TRY(linear_fwd(z, Z, p + L.zb_w, Z, p + L.zb_b, w.hb0, 2L * H, B, 2 * H, Z, EPI_SELU, s));
+    INET_TRY(pw_axpb(p + L.b_0, p + L.beat[0].w_ih, 1, p + L.beat[0].b_ih, w.gvec0, 3 * H, s));
+    DirFwd d{};
+    d.W_hh = p + L.beat[0].w_hh; d.b_hh = p + L.beat[0].b_hh;
+    d.gvec = w.gvec0;
+    d.h0 = w.hb0; d.h0_ld = 2L * H;
+    d.out = w.beat0; d.out_ld = H; d.out_ts = BH;
+    if (mask_beat) { d.outm = w.beat0m; d.outm_ld = H; d.outm_ts = BH; d.mask = mask_beat; d.mask_ld = H; d.mask_ts = BH; }
+    if (save) { d.sv = w.svb0; d.sv_astride = nb * BH; }
+    INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
+    const float* xb = mask_beat ? w.beat0m : w.beat0;
+    INET_TRY(linear_fwd(xb, H, p + L.beat[1].w_ih, H, p + L.beat[1].b_ih, w.gi1b, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
+    d = DirFwd{};
+    d.W_hh = p + L.beat[1].w_hh; d.b_hh = p + L.beat[1].b_hh;
+    d.gi = w.gi1b; d.gi_ld = 3L * H; d.gi_ts = 3 * BH;
+    d.h0 = w.hb0 + H; d.h0_ld = 2L * H;
+    d.out = w.beat_out; d.out_ld = H; d.out_ts = BH;
+    if (save) { d.sv = w.svb1; d.sv_astride = nb * BH; }
+    INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
+
+    // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
+    INET_TRY(linear_fwd(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU, s));
+    INET_TRY(linear_fwd(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU, s));
+    const float* wih0 = p + L.tick[0].w_ih;                   // [3H, E+H]
+    const long ldw0 = E + H;
+    INET_TRY(linear_fwd(w.c_all, H, wih0 + E, ldw0, nullptr, w.cgi, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
+    // gather table: rows 0..V-1 = E_dec . W_ih[:, :E]^T + b_ih ; row V = x_0 . W_ih[:, :E]^T + b_ih
+    INET_TRY(linear_fwd(p + L.dec_emb, E, wih0, ldw0, p + L.tick[0].b_ih, w.table, 3L * H, V, 3 * H, E, EPI_NONE, s));
+    INET_TRY(linear_fwd(p + L.x_0, E, wih0, ldw0, p + L.tick[0].b_ih, w.table + (long)V * 3 * H, 3L * H, 1, 3 * H, E, EPI_NONE, s));
+    INET_TRY(pw_fill_i64(w.idxV, B, V, s));
+    if (teacher_forced &&
+        hipMemcpyAsync(samples, target, (size_t)B * T * sizeof(long long), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return -2;
+
+    // ---- tick RNN (forward_tick_rnn, decoder.py:473-529) ----
+    for (int t = 0; t < T; ++t) {
+        const int i = t / G, j = t % G;
+        GruFwdBatch b0{};
+        b0.H = H; b0.nprob = 1;
+        GruFwdProb& P0 = b0.p[0];
+        P0.B = B;
+        if (j == 0) { P0.h_prev = w.ht0 + (long)i * B * 2 * H; P0.ld_hprev = 2L * H; }
+        else { P0.h_prev = w.h0seq + (long)(t - 1) * BH; P0.ld_hprev = H; }
+        P0.W_hh = p + L.tick[0].w_hh; P0.b_hh = p + L.tick[0].b_hh;
+        P0.gi_dense = w.cgi + (long)i * B * 3 * H; P0.ld_gi = 3L * H;
+        P0.gi_table = w.table; P0.ld_table = 3L * H;
+        if (t == 0) { P0.idx = w.idxV; P0.idx_stride = 1; }
+        else { P0.idx = samples + (t - 1); P0.idx_stride = T; }
+        P0.h_new = w.h0seq + (long)t * BH; P0.ld_hnew = H;
+        if (mask_tick) { P0.h_masked = w.h0m + (long)t * BH; P0.ld_hm = H; P0.mask = mask_tick + (long)t * BH; P0.ld_mask = H; }
+        if (save) {
+            float* q = w.svt0 + (long)t * BH; const long as = (long)T * BH;
+            P0.sv_r = q; P0.sv_z = q + as; P0.sv_n = q + 2 * as; P0.sv_ghn = q + 3 * as; P0.sv_hprev = q + 4 * as;
+        }
+        INET_TRY(launch_gru_fwd(b0, s));
+
+        GruFwdBatch b1{};
+        b1.H = H; b1.nprob = 1;
+        GruFwdProb& P1 = b1.p[0];
+        P1.B = B;
+        if (j == 0) { P1.h_prev = w.ht0 + (long)i * B * 2 * H + H; P1.ld_hprev = 2L * H; }
+        else { P1.h_prev = w.h1seq + (long)(t - 1) * BH; P1.ld_hprev = H; }
+        P1.W_hh = p + L.tick[1].w_hh; P1.b_hh = p + L.tick[1].b_hh;
+        P1.x = (mask_tick ? w.h0m : w.h0seq) + (long)t * BH; P1.ldx = H; P1.K2 = H;
+        P1.W_ih = p + L.tick[1].w_ih; P1.ld_wih = H; P1.b_ih = p + L.tick[1].b_ih;
+        P1.h_new = w.h1seq + (long)t * BH; P1.ld_hnew = H;
+        if (save) {
+            float* q = w.svt1 + (long)t * BH; const long as = (long)T * BH;
+            P1.sv_r = q; P1.sv_z = q + as; P1.sv_n = q + 2 * as; P1.sv_ghn = q + 3 * as; P1.sv_hprev = q + 4 * as;
+        }
+        INET_TRY(launch_gru_fwd(b1, s));
+
+        // logits = ReLU(h_top . Wo^T + bo) straight into weights[:, t, :]
+        INET_TRY(linear_fwd(w.h1seq + (long)t * BH, H, p + L.out_w, H, p + L.out_b, weights + (long)t * V, (long)T * V,
+                            B, V, H, EPI_RELU, s));
+        if (!teacher_forced) INET_TRY(pw_argmax(weights + (long)t * V, (long)T * V, B, V, samples + t, T, s));
+    }
+    return 0;
+}
+
+int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, const float* weights,
+                    const long long* tokens_in, const float* p, float* g, const float* mask_beat,
+                    const float* mask_tick, float* dz, void* ws, hipStream_t s) {
+    const int nb = c.beats, G = c.ticks_per_beat, T = nb * G, H = c.dec_hidden, V = c.num_notes, E = c.emb_dim, Z = c.z_dim;
+    const long BH = (long)B * H, TBH = (long)T * BH;
+    VaeLayout L(c);
+    DecWs w{};
+    dec_carve(c, B, 1, ws, w);
+    const GruDirOff* gr[4] = {&L.beat[0], &L.beat[1], &L.tick[0], &L.tick[1]};
+    for (int i = 0; i < 4; ++i) INET_TRY(pw_transpose(p + gr[i]->w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+
+    // ---- output projection ----
+    INET_TRY(pw_dlogits_relayout(dweights, weights, B, T, V, w.dlg, s));
+    if (g) {
+        INET_TRY(linear_wgrad(w.dlg, V, w.h1seq, H, g + L.out_w, H, T * B, V, H, s));
+        INET_TRY(pw_colsum(w.dlg, V, T * B, V, g + L.out_b, s));
+    }
+    INET_TRY(linear_dgrad(w.dlg, V, p + L.out_w, H, w.dh1top, H, T * B, V, H, EPI_NONE, nullptr, 0, ACC_STORE, s));
+
+    // ---- tick RNN layer 1: 6 steps x 4 beats ----
+    DirBwd d[4];
+    for (int i = 0; i < nb; ++i) {
+        DirBwd& D = d[i];
+        D = DirBwd{};
+        D.W_hhT = w.whhT[3];
+        D.dout = w.dh1top + (long)i * G * BH; D.dout_ld = H; D.dout_ts = BH;
+        D.sv = w.svt1 + (long)i * G * BH; D.sv_astride = TBH;
+        D.dgi = w.dgi1t + (long)i * G * 3 * BH; D.dgi_ld = 3L * H; D.dgi_ts = 3 * BH;
+        D.dgh = w.dgh1t + (long)i * G * 3 * BH;
+        D.dhz = w.dhz + (long)i * 2 * BH;
+        D.dh0 = w.dht0 + (long)i * B * 2 * H + H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
+    }
+    INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
+    const float* x1 = mask_tick ? w.h0m : w.h0seq;
+    if (g) {
+        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh1t, w.dgi1t, 3L * H, w.svt1 + 4 * TBH, g + L.tick[1].w_hh,
+                               g + L.tick[1].b_hh, g + L.tick[1].b_ih, s));
+        INET_TRY(linear_wgrad(w.dgi1t, 3L * H, x1, H, g + L.tick[1].w_ih, H, T * B, 3 * H, H, s));
+    }
+    INET_TRY(linear_dgrad(w.dgi1t, 3L * H, p + L.tick[1].w_ih, H, w.dx1t, H, T * B, 3 * H, H,
+                          mask_tick ? EPI_MUL_AUX : EPI_NONE, mask_tick, H, ACC_STORE, s));
+
+    // ---- tick RNN layer 0 ----
+    for (int i = 0; i < nb; ++i) {
+        DirBwd& D = d[i];
+        D = DirBwd{};
+        D.W_hhT = w.whhT[2];
+        D.dout = w.dx1t + (long)i * G * BH; D.dout_ld = H; D.dout_ts = BH;
+        D.sv = w.svt0 + (long)i * G * BH; D.sv_astride = TBH;
+        D.dgi = w.dgi0t + (long)i * G * 3 * BH; D.dgi_ld = 3L * H; D.dgi_ts = 3 * BH;
+        D.dgh = w.dgh0t + (long)i * G * 3 * BH;
+        D.dhz = w.dhz + (long)i * 2 * BH;
+        D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
+    }
+    INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
+    const float* wih0 = p + L.tick[0].w_ih;
+    const long ldw0 = E + H;
+    if (g)
+        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.dgi0t, 3L * H, w.svt0 + 4 * TBH, g + L.tick[0].w_hh,
+                               g + L.tick[0].b_hh, g + L.tick[0].b_ih, s));
+    // beat-constant input half:  dcgi[i] = sum_j dgi0[6i+j]
+    INET_TRY(pw_group_sum(w.dgi0t, nb, G, 3 * BH, w.dcgi, s));
+    INET_TRY(linear_dgrad(w.dcgi, 3L * H, wih0 + E, ldw0, w.dc_all, H, nb * B, 3 * H, H, EPI_MUL_SELU_GRAD, w.c_all, H,
+                          ACC_STORE, s));
+    if (g) {
+        INET_TRY(linear_wgrad(w.dcgi, 3L * H, w.c_all, H, g + L.tick[0].w_ih + E, ldw0, nb * B, 3 * H, H, s));
+        // token-embedding half through the gather table
+        if (hipMemsetAsync(w.onehot, 0, (size_t)T * B * (V + 1) * sizeof(float), s) != hipSuccess) return -2;
+        INET_TRY(pw_onehot(w.idxV, B, 0, 1, B, V + 1, w.onehot, 0, s));                               // t = 0: x_0 row
+        INET_TRY(pw_onehot(tokens_in, B, 1, T, (T - 1) * B, V + 1, w.onehot + (long)B * (V + 1), 0, s));  // t >= 1: token t-1
+        INET_TRY(launch_gemm(gemm_args(w.onehot, V + 1, 1, w.dgi0t, 3L * H, 1, w.dtable, 3L * H, V + 1, 3 * H, T * B), s));
+        INET_TRY(linear_wgrad(w.dtable, 3L * H, p + L.dec_emb, E, g + L.tick[0].w_ih, ldw0, V, 3 * H, E, s));
+        INET_TRY(linear_wgrad(w.dtable + (long)V * 3 * H, 3L * H, p + L.x_0, E, g + L.tick[0].w_ih, ldw0, 1, 3 * H, E, s));
+        INET_TRY(linear_dgrad(w.dtable, 3L * H, wih0, ldw0, g + L.dec_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, s));
+        INET_TRY(linear_dgrad(w.dtable + (long)V * 3 * H, 3L * H, wih0, ldw0, g + L.x_0, E, 1, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, s));
+    }
+
+    // ---- beat -> tick linears (decoder.py:494-495) ----
+    INET_TRY(pw_mul(w.dht0, w.ht0, 2L * nb * BH, 1, s));
+    INET_TRY(linear_dgrad(w.dht0, 2L * H, p + L.bh_w, H, w.dbeat_out, H, nb * B, 2 * H, H, EPI_NONE, nullptr, 0, ACC_STORE, s));
+    INET_TRY(linear_dgrad(w.dc_all, H, p + L.bi_w, H, w.dbeat_out, H, nb * B, H, H, EPI_NONE, nullptr, 0, ACC_ADD, s));
+    if (g) {
+        INET_TRY(linear_wgrad(w.dht0, 2L * H, w.beat_out, H, g + L.bh_w, H, nb * B, 2 * H, H, s));
+        INET_TRY(pw_colsum(w.dht0, 2L * H, nb * B, 2 * H, g + L.bh_b, s));
+        INET_TRY(linear_wgrad(w.dc_all, H, w.beat_out, H, g + L.bi_w, H, nb * B, H, H, s));
+        INET_TRY(pw_colsum(w.dc_all, H, nb * B, H, g + L.bi_b, s));
+    }
+
+    // ---- beat RNN ----
+    DirBwd b{};
+    b.W_hhT = w.whhT[1];
+    b.dout = w.dbeat_out; b.dout_ld = H; b.dout_ts = BH;
+    b.sv = w.svb1; b.sv_astride = nb * BH;
+    b.dgi = w.dgi1b; b.dgi_ld = 3L * H; b.dgi_ts = 3 * BH;
+    b.dgh = w.dgh1b; b.dhz = w.dhz;
+    b.dh0 = w.dhb0 + H; b.dh0_ld = 2L * H;
+    INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
+    const float* xb = mask_beat ? w.beat0m : w.beat0;
+    if (g) {
+        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh1b, w.dgi1b, 3L * H, w.svb1 + 4 * nb * BH, g + L.beat[1].w_hh,
+                               g + L.beat[1].b_hh, g + L.beat[1].b_ih, s));
+        INET_TRY(linear_wgrad(w.dgi1b, 3L * H, xb, H, g + L.beat[1].w_ih, H, nb * B, 3 * H, H, s));
+    }
+    INET_TRY(linear_dgrad(w.dgi1b, 3L * H, p + L.beat[1].w_ih, H, w.dxb, H, nb * B, 3 * H, H,
+                          mask_beat ? EPI_MUL_AUX : EPI_NONE, mask_beat, H, ACC_STORE, s));
+    b = DirBwd{};
+    b.W_hhT = w.whhT[0];
+    b.dout = w.dxb; b.dout_ld = H; b.dout_ts = BH;
+    b.sv = w.svb0; b.sv_astride = nb * BH;
+    b.dgi = w.dgi0b; b.dgi_ld = 3L * H; b.dgi_ts = 3 * BH;
+    b.dgh = w.dgh0b; b.dhz = w.dhz;
+    b.dh0 = w.dhb0; b.dh0_ld = 2L * H;
+    INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
+    if (g) {
+        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh0b, w.dgi0b, 3L * H, w.svb0 + 4 * nb * BH, g + L.beat[0].w_hh,
+                               g + L.beat[0].b_hh, g + L.beat[0].b_ih, s));
+        // gi = b_0 * W_ih[:,0] + b_ih
+        if (hipMemsetAsync(w.tmp3h, 0, 3 * H * sizeof(float), s) != hipSuccess) return -2;
+        INET_TRY(pw_colsum(w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h, s));
+        INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H, s));
+    }
+
+    // ---- z -> beat hidden ----
+    INET_TRY(pw_mul(w.dhb0, w.hb0, 2 * BH, 1, s));
+    if (dz) INET_TRY(linear_dgrad(w.dhb0, 2L * H, p + L.zb_w, Z, dz, Z, B, 2 * H, Z, EPI_NONE, nullptr, 0, ACC_STORE, s));
+    if (g) {
+        INET_TRY(linear_wgrad(w.dhb0, 2L * H, w.zsave, Z, g + L.zb_w, Z, B, 2 * H, Z, s));
+        INET_TRY(pw_colsum(w.dhb0, 2L * H, B, 2 * H, g + L.zb_b, s));
+    }
+    return 0;
+}

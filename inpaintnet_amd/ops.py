@@ -1,0 +1,214 @@
+"""Thin functional layer over the C-ABI: torch tensors in, torch tensors out.
+
+torch is used here only for device memory and the current stream; every number
+is produced by the HIP kernels behind include/inpaintnet_hip.h.  All functions
+are asynchronous on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import VaeConfig, LatentConfig, check, ptr, stream_ptr
+
+
+def _f32c(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+def _i64c(t):
+    assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+def vae_config(num_notes, emb_dim=10, enc_hidden=512, z_dim=256, dec_hidden=512, beats=4, ticks_per_beat=6):
+    return VaeConfig(num_notes, emb_dim, enc_hidden, z_dim, dec_hidden, beats, ticks_per_beat)
+
+
+def _entries(cfg, count_fn, info_fn):
+    n = count_fn(C.byref(cfg))
+    if n < 0:
+        raise ValueError("invalid model configuration (hidden sizes must be multiples of 16)")
+    out = []
+    for i in range(n):
+        name = C.create_string_buffer(160)
+        off = C.c_int64()
+        dims = (C.c_int64 * 4)()
+        nd = C.c_int()
+        check(info_fn(C.byref(cfg), i, name, 160, C.byref(off), dims, C.byref(nd)), "param_info")
+        out.append((name.value.decode(), off.value, tuple(dims[j] for j in range(nd.value))))
+    return out
+
+
+def vae_param_table(cfg):
+    """[(state_dict key, offset in floats, shape)], total floats -- from the C library."""
+    L = _lib.lib()
+    return _entries(cfg, L.inet_vae_param_count, L.inet_vae_param_info), L.inet_vae_param_floats(C.byref(cfg))
+
+
+def latent_param_table(cfg):
+    L = _lib.lib()
+    return _entries(cfg, L.inet_latent_param_count, L.inet_latent_param_info), L.inet_latent_param_floats(C.byref(cfg))
+
+
+def _ws(nbytes, device):
+    return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=device)
+
+
+# ----------------------------------------------------------------------------- encoder
+def encoder_ws(cfg, B, save, device):
+    n = _lib.lib().inet_vae_encoder_ws_bytes(C.byref(cfg), B, int(save))
+    if n < 0:
+        raise ValueError("encoder_ws: invalid arguments")
+    return _ws(n, device)
+
+
+def encoder_fwd(cfg, tokens, params, mask=None, save=False, ws=None):
+    """tokens [B,T] int64 -> mu, logsigma [B,Z], ws"""
+    _i64c(tokens); _f32c(params)
+    B = tokens.shape[0]
+    if ws is None:
+        ws = encoder_ws(cfg, B, save, tokens.device)
+    mu = torch.empty(B, cfg.z_dim, dtype=torch.float32, device=tokens.device)
+    ls = torch.empty_like(mu)
+    check(_lib.lib().inet_vae_encoder_fwd(C.byref(cfg), B, ptr(tokens), ptr(params), ptr(mask), ptr(mu), ptr(ls),
+                                          ptr(ws), int(save), stream_ptr()), "inet_vae_encoder_fwd")
+    return mu, ls, ws
+
+
+def encoder_bwd(cfg, tokens, params, grads, mask, dmu, dls, ws):
+    B = tokens.shape[0]
+    _f32c(dmu); _f32c(dls); _f32c(grads)
+    check(_lib.lib().inet_vae_encoder_bwd(C.byref(cfg), B, ptr(tokens), ptr(params), ptr(grads), ptr(mask), ptr(dmu),
+                                          ptr(dls), ptr(ws), stream_ptr()), "inet_vae_encoder_bwd")
+
+
+# ----------------------------------------------------------------------------- decoder
+def decoder_ws(cfg, B, save, device):
+    n = _lib.lib().inet_vae_decoder_ws_bytes(C.byref(cfg), B, int(save))
+    if n < 0:
+        raise ValueError("decoder_ws: invalid arguments")
+    return _ws(n, device)
+
+
+def decoder_fwd(cfg, z, target, teacher_forced, params, mask_beat=None, mask_tick=None, save=False, ws=None):
+    """z [B,Z] -> weights [B,T,V], samples [B,1,T] int64, ws"""
+    _f32c(z); _f32c(params)
+    B = z.shape[0]
+    T = cfg.beats * cfg.ticks_per_beat
+    if target is not None:
+        _i64c(target)
+    if ws is None:
+        ws = decoder_ws(cfg, B, save, z.device)
+    weights = torch.empty(B, T, cfg.num_notes, dtype=torch.float32, device=z.device)
+    samples = torch.empty(B, 1, T, dtype=torch.int64, device=z.device)
+    check(_lib.lib().inet_vae_decoder_fwd(C.byref(cfg), B, ptr(z), ptr(target), int(bool(teacher_forced)), ptr(params),
+                                          ptr(mask_beat), ptr(mask_tick), ptr(weights), ptr(samples), ptr(ws),
+                                          int(save), stream_ptr()), "inet_vae_decoder_fwd")
+    return weights, samples, ws
+
+
+def decoder_bwd(cfg, dweights, weights, samples, params, grads, mask_beat, mask_tick, ws, need_dz=True):
+    B = weights.shape[0]
+    _f32c(dweights); _f32c(weights); _i64c(samples)
+    dz = torch.empty(B, cfg.z_dim, dtype=torch.float32, device=weights.device) if need_dz else None
+    check(_lib.lib().inet_vae_decoder_bwd(C.byref(cfg), B, ptr(dweights), ptr(weights), ptr(samples), ptr(params),
+                                          ptr(grads), ptr(mask_beat), ptr(mask_tick), ptr(dz), ptr(ws), stream_ptr()),
+          "inet_vae_decoder_bwd")
+    return dz
+
+
+# ----------------------------------------------------------------------------- losses
+def cross_entropy(weights2d, targets1d, out2, dW=None, scale=1.0):
+    """weights2d [rows,V] (row stride = stride(0)); out2: 2-float accumulator (loss_sum, correct)."""
+    rows, V = weights2d.shape
+    assert weights2d.stride(1) == 1
+    _i64c(targets1d)
+    check(_lib.lib().inet_cross_entropy(ptr(weights2d), weights2d.stride(0), rows, V, ptr(targets1d), ptr(dW),
+                                        dW.stride(0) if dW is not None else 0, float(scale), ptr(out2[0:1]),
+                                        ptr(out2[1:2]), stream_ptr()), "inet_cross_entropy")
+
+
+def reparam_kl(mu, ls, eps, kl_sum=None, want_sigma=False):
+    _f32c(mu); _f32c(ls)
+    z = torch.empty_like(mu)
+    sigma = torch.empty_like(mu) if want_sigma else None
+    check(_lib.lib().inet_reparam_kl(ptr(mu), ptr(ls), ptr(eps), ptr(z), ptr(sigma), mu.numel(), ptr(kl_sum),
+                                     stream_ptr()), "inet_reparam_kl")
+    return z, sigma
+
+
+def latent_bwd(dz, mu, ls, eps, kscale):
+    dmu = torch.empty_like(mu)
+    dls = torch.empty_like(mu)
+    check(_lib.lib().inet_latent_bwd(ptr(dz), ptr(mu), ptr(ls), ptr(eps), float(kscale), ptr(dmu), ptr(dls),
+                                     mu.numel(), stream_ptr()), "inet_latent_bwd")
+    return dmu, dls
+
+
+def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0):
+    for t in (p, g, m, v):
+        _f32c(t)
+    check(_lib.lib().inet_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(b1), float(b2),
+                                    float(eps), int(step), float(gscale), stream_ptr()), "inet_adam_step")
+
+
+def dropout_mask(shape, p, seed, offset, device):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.lib().inet_dropout_mask(ptr(out), out.numel(), float(p), int(seed) & (2 ** 64 - 1),
+                                       int(offset) & (2 ** 64 - 1), stream_ptr()), "inet_dropout_mask")
+    return out
+
+
+# ----------------------------------------------------------------------------- generic ops
+def gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, epi=0, aux=None, out=None, accumulate=False):
+    """C[M,N] (op)= epi(sum_k A(m,k) B(n,k) + bias).  A, B are 2-D (possibly row-strided) fp32 tensors."""
+    assert A.stride(1) == 1 and B.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(_lib.lib().inet_gemm(ptr(A), A.stride(0), int(a_kmajor), ptr(B), B.stride(0), int(b_kmajor), ptr(out),
+                               out.stride(0), M, N, K, ptr(bias), ptr(aux), aux.stride(0) if aux is not None else 0,
+                               int(epi), int(accumulate), stream_ptr()), "inet_gemm")
+    return out
+
+
+def gru_step(gi, h_prev, W_hh, b_hh, save=False):
+    B, H = h_prev.shape
+    h_new = torch.empty_like(h_prev)
+    sv = torch.empty(5, B, H, dtype=torch.float32, device=gi.device) if save else None
+    check(_lib.lib().inet_gru_step(B, H, ptr(_f32c(gi)), ptr(_f32c(h_prev)), ptr(_f32c(W_hh)), ptr(_f32c(b_hh)),
+                                   ptr(h_new), ptr(sv), stream_ptr()), "inet_gru_step")
+    return h_new, sv
+
+
+def bigru2_ws(B, T, K, H, save, device):
+    n = _lib.lib().inet_bigru2_ws_bytes(B, T, K, H, int(save))
+    if n < 0:
+        raise ValueError("bigru2_ws: invalid arguments")
+    return _ws(n, device)
+
+
+def bigru2_fwd(x, x_scalar, weights, H, B, T, K, h0=None, mask=None, want_out=True, want_hn=True, save=False,
+               ws=None):
+    """x [B,T,K] or None (then x_scalar: 1-element tensor, K == 1).  weights: view of the arena starting at
+    the GRU's weight_ih_l0.  Returns out [B,T,2H] | None, h_n [4,B,H] | None, ws."""
+    dev = weights.device
+    if ws is None:
+        ws = bigru2_ws(B, T, K, H, save, dev)
+    out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev) if want_out else None
+    hn = torch.empty(4, B, H, dtype=torch.float32, device=dev) if want_hn else None
+    check(_lib.lib().inet_bigru2_fwd(B, T, K, H, ptr(x), ptr(x_scalar), ptr(weights), ptr(h0), ptr(mask), ptr(out),
+                                     ptr(hn), ptr(ws), int(save), stream_ptr()), "inet_bigru2_fwd")
+    return out, hn, ws
+
+
+def bigru2_bwd(x, x_scalar, weights, grads, H, B, T, K, mask, dout, dhn, ws, want_dx=False, dx_scalar=None,
+               want_dh0=False):
+    dev = weights.device
+    dx = torch.empty(B, T, K, dtype=torch.float32, device=dev) if (want_dx and x is not None) else None
+    dh0 = torch.empty(4, B, H, dtype=torch.float32, device=dev) if want_dh0 else None
+    check(_lib.lib().inet_bigru2_bwd(B, T, K, H, ptr(x), ptr(x_scalar), ptr(weights), ptr(grads), ptr(mask),
+                                     ptr(dout), ptr(dhn), ptr(dx), ptr(dx_scalar), ptr(dh0), ptr(ws), stream_ptr()),
+          "inet_bigru2_bwd")
+    return dx, dh0

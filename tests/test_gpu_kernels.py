@@ -1,0 +1,350 @@
+"""GPU parity tests, kernel level up to module level.  Everything goes through the
+C-ABI (inpaintnet_amd.ops -> libinpaintnet_hip.so) and is compared with the CPU
+oracle (oracle/torch_ref.py) and with the golden vectors captured from the reference.
+
+Tolerances: fp32 with a different summation order than MKL -> 1e-4 relative on
+loss-level scalars (north_star), 2e-4 of the tensor's max-abs on activations and
+gradients; token indices exact on rows whose top-2 margin exceeds 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from inpaintnet_amd import ops
+
+DEV = "cuda:0"
+
+
+def relmax(a, b):
+    a = a.detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def pack(table, total, P, prefix=""):
+    flat = torch.zeros(total, dtype=torch.float32)
+    for name, off, shape in table:
+        t = P[prefix + name].detach().reshape(-1)
+        flat[off:off + t.numel()] = t
+    return flat.to(DEV)
+
+
+def unpack(table, flat, name):
+    for n, off, shape in table:
+        if n == name:
+            num = int(np.prod(shape))
+            return flat[off:off + num].reshape(shape)
+    raise KeyError(name)
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(5, 12, 4), (70, 33, 10), (256, 1536, 512), (130, 200, 1000),
+                                   (1536, 512, 6144), (48, 1536, 6144), (300, 7, 37)])
+def test_gemm_layouts(akm, bkm, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + akm * 2 + bkm)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad = (A.t().contiguous() if akm else A).to(DEV)
+    Bd = (B.t().contiguous() if bkm else B).to(DEV)
+    C = ops.gemm(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm)
+    assert relmax(C, ref) < 2e-5
+    # accumulate into a live destination
+    C0 = torch.randn(M, N, generator=g)
+    C1 = C0.to(DEV).clone()
+    ops.gemm(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, out=C1, accumulate=True)
+    assert relmax(C1, ref + C0.double()) < 2e-5
+
+
+def test_gemm_strided_unaligned_and_epilogues():
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 77, 50, 128
+    # B operand = columns 10.. of a [N, 10+K] matrix (rows start 8-byte aligned only), as rnn_tick.weight_ih_l0[:, E:]
+    Wfull = torch.randn(N, 10 + K, generator=g)
+    A = torch.randn(M, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    Wd = Wfull.to(DEV)
+    pre = A.double() @ Wfull[:, 10:].double().t() + bias.double()
+    out = ops.gemm(A.to(DEV), Wd[:, 10:], M, N, K, bias=bias.to(DEV), epi=1)
+    assert relmax(out, O.selu(pre)) < 2e-5
+    out = ops.gemm(A.to(DEV), Wd[:, 10:], M, N, K, bias=bias.to(DEV), epi=2)
+    assert relmax(out, torch.relu(pre)) < 2e-5
+    sg = torch.where(aux > 0, torch.tensor(O.SELU_SCALE), aux + O.SELU_SCALE * O.SELU_ALPHA).double()
+    out = ops.gemm(A.to(DEV), Wd[:, 10:], M, N, K, bias=bias.to(DEV), epi=3, aux=aux.to(DEV))
+    assert relmax(out, pre * sg) < 2e-5
+    out = ops.gemm(A.to(DEV), Wd[:, 10:], M, N, K, epi=4, aux=aux.to(DEV))
+    assert relmax(out, (pre - bias.double()) * aux.double()) < 2e-5
+    out = ops.gemm(A.to(DEV), Wd[:, 10:], M, N, K, epi=5, aux=aux.to(DEV))
+    assert relmax(out, (pre - bias.double()) * (aux > 0).double()) < 2e-5
+    # strided destination (weights[:, t, :] style)
+    big = torch.zeros(M, 3, N, device=DEV)
+    ops.gemm(A.to(DEV), Wd[:, 10:], M, N, K, out=big[:, 1, :])
+    assert relmax(big[:, 1, :], pre - bias.double()) < 2e-5
+    assert float(big[:, 0, :].abs().max()) == 0.0 and float(big[:, 2, :].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------- GRU step
+@pytest.mark.parametrize("B,H", [(2, 16), (5, 48), (33, 64), (256, 512), (128, 1024)])
+def test_gru_step_matches_cell(B, H):
+    g = torch.Generator().manual_seed(B + H)
+    gi = torch.randn(B, 3 * H, generator=g)
+    h = torch.randn(B, H, generator=g)
+    W = torch.randn(3 * H, H, generator=g) / np.sqrt(H)
+    b = torch.randn(3 * H, generator=g) * 0.1
+    ref = O.gru_cell(gi.double(), h.double(), W.double(), b.double())
+    out, sv = ops.gru_step(gi.to(DEV), h.to(DEV), W.to(DEV), b.to(DEV), save=True)
+    assert relmax(out, ref) < 2e-5
+    gh = h.double() @ W.double().t() + b.double()
+    r = torch.sigmoid(gi[:, :H].double() + gh[:, :H])
+    assert relmax(sv[0], r) < 2e-5
+    assert relmax(sv[3], gh[:, 2 * H:]) < 2e-5
+    assert torch.equal(sv[4].cpu(), h)
+
+
+# ------------------------------------------------------------------------------- encoder / decoder vs reference goldens
+@pytest.mark.parametrize("name", ["small", "mid", "full"])
+def test_encoder_forward_golden(name):
+    fx = G.load("vae_" + name)
+    c = G.CFGS[name]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    P = G.vae_params(name, fx)
+    params = pack(table, total, P)
+    tok = torch.from_numpy(fx["tokens"]).to(DEV)
+    mu, ls, _ = ops.encoder_fwd(cfg, tok, params)
+    assert relmax(mu, fx["enc_mu"]) < 1e-4
+    assert relmax(ls, fx["enc_logsigma"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["small", "mid", "full"])
+def test_decoder_forward_golden(name):
+    fx = G.load("vae_" + name)
+    c = G.CFGS[name]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params(name, fx))
+    tok = torch.from_numpy(fx["tokens"]).to(DEV)
+    z = torch.from_numpy(fx["dec_z"]).to(DEV)
+    w, s, _ = ops.decoder_fwd(cfg, z, None, False, params)
+    assert relmax(w, fx["dec_eval_weights"]) < 1e-4
+    ok = G.unique_rows(fx["dec_eval_margin"])
+    assert s.shape == fx["dec_eval_samples"].shape and s.dtype == torch.int64
+    assert np.array_equal(s.cpu().numpy()[:, 0][ok], fx["dec_eval_samples"][:, 0][ok])
+    w, s, _ = ops.decoder_fwd(cfg, z, tok, True, params)
+    assert relmax(w, fx["dec_tf_weights"]) < 1e-4
+    assert np.array_equal(s.cpu().numpy(), fx["dec_tf_samples"])
+
+
+def _vae_step_hip(cfg, table, params, grads, tok, eps, teacher_forced, masks=None):
+    """One forward + loss + backward of the MeasureVAE through the C-ABI. Returns (loss, ce, kl, acc, weights, samples, z)."""
+    masks = masks or {}
+    B, T = tok.shape
+    V = cfg.num_notes
+    mu, ls, ews = ops.encoder_fwd(cfg, tok, params, mask=masks.get("enc"), save=True)
+    acc3 = torch.zeros(3, device=DEV)
+    z, _ = ops.reparam_kl(mu, ls, eps, kl_sum=acc3[2:3])
+    w, s, dws = ops.decoder_fwd(cfg, z, tok, teacher_forced, params, masks.get("beat"), masks.get("tick"), save=True)
+    dW = torch.empty_like(w)
+    ops.cross_entropy(w.view(B * T, V), tok.reshape(-1), acc3, dW=dW.view(B * T, V), scale=1.0 / (B * T))
+    dz = ops.decoder_bwd(cfg, dW, w, s, params, grads, masks.get("beat"), masks.get("tick"), dws)
+    dmu, dls = ops.latent_bwd(dz, mu, ls, eps, 1e-3 / B)
+    ops.encoder_bwd(cfg, tok, params, grads, masks.get("enc"), dmu, dls, ews)
+    a = acc3.cpu().double()
+    ce = a[0] / (B * T)
+    kl = 1e-3 * a[2] / B
+    return float(ce + kl), float(ce), float(kl), float(a[1] / (B * T)), w, s, z
+
+
+@pytest.mark.parametrize("name", ["small", "mid", "full"])
+@pytest.mark.parametrize("mode", ["tf", "fr"])
+def test_vae_train_steps_golden(name, mode):
+    """Loss / CE / KL / accuracy trajectory over 5 Adam steps, first-step gradients and the
+    parameters after steps 1 and 5 -- against the reference's own trainer (tests/golden)."""
+    fx = G.load("vae_" + name)
+    c = G.CFGS[name]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params(name, fx))
+    grads = torch.zeros_like(params)
+    m = torch.zeros_like(params)
+    v = torch.zeros_like(params)
+    tok = torch.from_numpy(fx["tokens"]).to(DEV)
+    ref = fx[f"step_{mode}_losses"]
+    for step in range(5):
+        eps = torch.from_numpy(fx[f"step_{mode}_eps{step}"]).to(DEV)
+        grads.zero_()
+        loss, ce, kl, acc, w, s, z = _vae_step_hip(cfg, table, params, grads, tok, eps, mode == "tf")
+        assert abs(loss - ref[step][0]) <= 1e-4 * abs(ref[step][0]), (step, loss, ref[step])
+        assert abs(ce - ref[step][1]) <= 1e-4 * abs(ref[step][1])
+        assert abs(kl - ref[step][2]) <= 1e-4 * abs(ref[step][2])
+        if step == 0:
+            assert relmax(w, fx[f"step_{mode}_weights"]) < 1e-4
+            assert relmax(z, fx[f"step_{mode}_z"]) < 1e-4
+            ok = G.unique_rows(fx[f"step_{mode}_margin"])
+            assert np.array_equal(s.cpu().numpy()[:, 0][ok], fx[f"step_{mode}_samples"][:, 0][ok])
+            assert abs(acc - ref[0][3]) < 1e-6
+            bad = []
+            for pname, off, shape in table:
+                gg = unpack(table, grads, pname).cpu().numpy()
+                if name != "full":
+                    r = fx[f"step_{mode}_grad/{pname}"]
+                    err = np.abs(gg - r).max() / (np.abs(r).max() + 1e-7)
+                else:
+                    rn = float(fx[f"step_{mode}_gradnorm/{pname}"])
+                    gn = float(np.sqrt((gg.astype(np.float64) ** 2).sum()))
+                    err = abs(gn - rn) / (rn + 1e-12)
+                    rh = fx[f"step_{mode}_gradhead/{pname}"]
+                    err = max(err, float(np.abs(gg.reshape(-1)[:64] - rh).max() / (np.abs(gg).max() + 1e-12)))
+                    rt = fx[f"step_{mode}_gradtail/{pname}"]
+                    err = max(err, float(np.abs(gg.reshape(-1)[-64:] - rt).max() / (np.abs(gg).max() + 1e-12)))
+                if not err < 5e-4:
+                    bad.append((pname, float(err)))
+            assert not bad, bad
+        ops.adam_step(params, grads, m, v, 1e-4, step + 1)
+        if step in (0, 4):
+            for pname, off, shape in table:
+                pv = unpack(table, params, pname).cpu().numpy()
+                if name == "small":
+                    r = fx[f"step_{mode}_after{step + 1}/{pname}"]
+                    assert np.abs(pv - r).max() < 1e-5, (pname, step)
+                else:
+                    r = fx[f"step_{mode}_after{step + 1}/head/{pname}"]
+                    assert np.abs(pv.reshape(-1)[:64] - r).max() < 1e-5, (pname, step)
+
+
+def test_vae_step_with_dropout_masks_vs_oracle():
+    """Mask-in dropout (encoder l0->l1, beat l0->l1, tick l0->l1): HIP path vs the oracle with identical masks."""
+    name = "mid"
+    c = G.CFGS[name]
+    B, T, H = 7, 24, c["H"]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    P = G.vae_params(name)
+    params = pack(table, total, P)
+    g = torch.Generator().manual_seed(11)
+    tok = torch.randint(0, c["V"], (B, T), generator=g)
+    eps = torch.randn(B, c["Z"], generator=g)
+    m_enc = ops.dropout_mask((T, B, 2 * H), 0.5, 123, 0, DEV)
+    m_beat = ops.dropout_mask((4, B, H), 0.5, 123, 10 ** 6, DEV)
+    m_tick = ops.dropout_mask((T, B, H), 0.5, 123, 2 * 10 ** 6, DEV)
+    for mm in (m_enc, m_beat, m_tick):
+        frac = float((mm > 0).float().mean())
+        assert 0.42 < frac < 0.58 and set(np.unique(mm.cpu().numpy()).tolist()) <= {0.0, 2.0}
+    for p in P.values():
+        p.requires_grad_(True)
+    om = {"enc": m_enc.cpu().permute(1, 0, 2), "beat": m_beat.cpu().permute(1, 0, 2), "tick": m_tick.cpu().permute(1, 0, 2)}
+    for tf in (True, False):
+        for p in P.values():
+            p.grad = None
+        w, s, mu, ls, z = O.vae_forward(P, tok, eps, tf, om)
+        loss, ce, kl, acc = O.vae_loss(w, tok, mu, ls)
+        loss.backward()
+        grads = torch.zeros_like(params)
+        hl, hce, hkl, hacc, hw, hs, hz = _vae_step_hip(cfg, table, params, grads, tok.to(DEV), eps.to(DEV), tf,
+                                                        {"enc": m_enc, "beat": m_beat, "tick": m_tick})
+        assert abs(hl - loss.item()) < 1e-4 * abs(loss.item())
+        assert relmax(hw, w) < 1e-4
+        bad = []
+        for pname, off, shape in table:
+            gg = unpack(table, grads, pname).cpu()
+            err = float((gg - P[pname].grad).abs().max() / (P[pname].grad.abs().max() + 1e-7))
+            if not err < 5e-4:
+                bad.append((pname, err))
+        assert not bad, (tf, bad)
+
+
+# ------------------------------------------------------------------------------- losses / optimizer
+def test_cross_entropy_and_kl_kernels():
+    g = torch.Generator().manual_seed(3)
+    for rows, V in [(48, 12), (6144, 48), (100, 130)]:
+        w = torch.relu(torch.randn(rows, V, generator=g))
+        t = torch.randint(0, V, (rows,), generator=g)
+        wr = w.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(wr, t, reduction="sum")
+        ref.backward()
+        out = torch.zeros(2, device=DEV)
+        dW = torch.empty(rows, V, device=DEV)
+        ops.cross_entropy(w.to(DEV), t.to(DEV), out, dW=dW, scale=1.0)
+        assert abs(float(out[0]) - ref.item()) < 1e-4 * abs(ref.item())
+        assert float(out[1]) == float((O.argmax_first(w) == t).sum())
+        assert relmax(dW, wr.grad) < 1e-5
+    mu = torch.randn(33, 24, generator=g)
+    ls = torch.randn(33, 24, generator=g) * 0.3
+    eps = torch.randn(33, 24, generator=g)
+    acc = torch.zeros(1, device=DEV)
+    z, sig = ops.reparam_kl(mu.to(DEV), ls.to(DEV), eps.to(DEV), kl_sum=acc, want_sigma=True)
+    assert relmax(z, mu + eps * ls.exp()) < 1e-6
+    kref = (0.5 * (torch.exp(2 * ls.double()) + mu.double() ** 2 - 1) - ls.double()).sum()
+    assert abs(float(acc) - kref.item()) < 1e-5 * abs(kref.item())
+
+
+def test_adam_kernel_matches_torch():
+    g = torch.Generator().manual_seed(9)
+    n = 10007 * 4
+    p = torch.randn(n, generator=g)
+    pt = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([pt], lr=1e-4)
+    pd = p.to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * (10.0 ** (-step))
+        pt.grad = gr.clone()
+        opt.step()
+        ops.adam_step(pd, gr.to(DEV), m, v, 1e-4, step)
+        assert float((pd.cpu() - pt.detach()).abs().max()) < 2e-7
+
+
+# ------------------------------------------------------------------------------- generic bi-GRU (LatentRNN building block)
+@pytest.mark.parametrize("B,T,K,H,scalar", [(3, 5, 8, 16, False), (4, 4, 1, 32, True), (6, 6, 24, 48, False)])
+def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
+    from inpaintnet_amd import layout
+    g = torch.Generator().manual_seed(B * 100 + T * 10 + K)
+    shapes = layout._gru("g", K, H, 2, True)
+    offs, total = layout.arena_offsets(dict(shapes))
+    P = {k: (torch.randn(*s, generator=g) * (0.3 if "weight" in k else 0.1)) for k, s in shapes}
+    flat = torch.zeros(total)
+    for k, (off, s) in offs.items():
+        flat[off:off + P[k].numel()] = P[k].reshape(-1)
+    flat = flat.to(DEV)
+    for p in P.values():
+        p.requires_grad_(True)
+    h0 = torch.randn(4, B, H, generator=g).requires_grad_(True)
+    mask = (torch.rand(T, B, 2 * H, generator=g) > 0.5).float() * 2.0
+    if scalar:
+        xs = torch.randn(1, generator=g).requires_grad_(True)
+        x = xs.view(1, 1, 1).expand(B, T, 1)
+    else:
+        x = torch.randn(B, T, K, generator=g).requires_grad_(True)
+    out, hn = O.gru_stack(x, h0, P, "g", 2, True, [mask.permute(1, 0, 2)])
+    wo = torch.randn(B, T, 2 * H, generator=g)
+    wh = torch.randn(4, B, H, generator=g)
+    ((out * wo).sum() + (hn * wh).sum()).backward()
+    xd = None if scalar else x.detach().to(DEV)
+    xsd = xs.detach().to(DEV) if scalar else None
+    o, h, ws = ops.bigru2_fwd(xd, xsd, flat, H, B, T, K, h0=h0.detach().to(DEV), mask=mask.to(DEV), save=True)
+    assert relmax(o, out) < 5e-5 and relmax(h, hn) < 5e-5
+    grads = torch.zeros_like(flat)
+    dxs = torch.zeros(1, device=DEV) if scalar else None
+    dx, dh0 = ops.bigru2_bwd(xd, xsd, flat, grads, H, B, T, K, mask.to(DEV), wo.to(DEV), wh.to(DEV), ws,
+                             want_dx=not scalar, dx_scalar=dxs, want_dh0=True)
+    assert relmax(dh0, h0.grad) < 2e-4
+    if scalar:
+        assert abs(float(dxs) - float(xs.grad)) < 2e-4 * abs(float(xs.grad))
+    else:
+        assert relmax(dx, x.grad) < 2e-4
+    bad = []
+    for k, (off, s) in offs.items():
+        gg = grads[off:off + P[k].numel()].reshape(s).cpu()
+        err = float((gg - P[k].grad).abs().max() / (P[k].grad.abs().max() + 1e-7))
+        if not err < 5e-4:
+            bad.append((k, err))
+    assert not bad, bad
