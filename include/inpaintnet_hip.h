@@ -21,7 +21,8 @@
  *    moments use arenas of identical layout.  inet_*_param_info() is the
  *    single description of that layout.
  *  - a workspace written by a *_fwd call with save=1 must be handed unchanged to
- *    the matching *_bwd call.
+ *    the matching *_bwd call; every call checks ws_bytes against *_ws_bytes() and
+ *    returns -1 rather than touching an undersized workspace.
  */
 #ifndef INPAINTNET_HIP_H
 #define INPAINTNET_HIP_H
@@ -72,11 +73,12 @@ int64_t inet_vae_encoder_ws_bytes(const inet_vae_config* cfg, int batch, int sav
  * mask: null, or [T,B,2H] fp32 pre-scaled {0,1/(1-p)} inter-layer dropout mask (time-major);
  * outputs mu, logsigma [B,Z] */
 int inet_vae_encoder_fwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
-                         const float* mask, float* mu, float* logsigma, void* ws, int save, void* stream);
+                         const float* mask, float* mu, float* logsigma, void* ws, int64_t ws_bytes, int save,
+                         void* stream);
 /* autograd of the above (utils/trainer.py:150 loss.backward): accumulates into `grads` (VAE arena layout) */
 int inet_vae_encoder_bwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
                          float* grads, const float* mask, const float* dmu, const float* dlogsigma, void* ws,
-                         void* stream);
+                         int64_t ws_bytes, void* stream);
 
 /* ---- MeasureVAE decoder: HierarchicalDecoder.forward, MeasureVAE/decoder.py:412-529 -- */
 int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int save);
@@ -84,13 +86,13 @@ int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int sav
  * weights [B,T,V] post-ReLU logits; samples [B,1,T] int64 (argmax, lowest index on ties; = target if teacher forced) */
 int inet_vae_decoder_fwd(const inet_vae_config* cfg, int batch, const float* z, const int64_t* target,
                          int teacher_forced, const float* params, const float* mask_beat, const float* mask_tick,
-                         float* weights, int64_t* samples, void* ws, int save, void* stream);
+                         float* weights, int64_t* samples, void* ws, int64_t ws_bytes, int save, void* stream);
 /* dweights [B,T,V] = dLoss/dweights; weights = the forward output; grads may be null (frozen decoder:
  * LatentRNN/latent_rnn.py:42-43) in which case only dz [B,Z] is produced.  `tokens_in` are the tokens that
  * were fed back (= samples of the forward call). */
 int inet_vae_decoder_bwd(const inet_vae_config* cfg, int batch, const float* dweights, const float* weights,
                          const int64_t* tokens_in, const float* params, float* grads, const float* mask_beat,
-                         const float* mask_tick, float* dz, void* ws, void* stream);
+                         const float* mask_tick, float* dz, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- losses: VAETrainer.loss_and_acc_for_batch, vae_trainer.py:16-40,128-139; utils/trainer.py:271-306 */
 /* rows of V logits (row stride ld_w); out3[0] += sum_rows (lse - w[target]); out3[1] += #correct (argmax_first);
@@ -121,12 +123,13 @@ int inet_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t of
  * mask null or [T,B,2H]; out (nullable) [B,T,2H]; h_n (nullable) [4,B,H]. */
 int64_t inet_bigru2_ws_bytes(int batch, int T, int K, int H, int save);
 int inet_bigru2_fwd(int batch, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
-                    const float* h0, const float* mask, float* out, float* h_n, void* ws, int save, void* stream);
+                    const float* h0, const float* mask, float* out, float* h_n, void* ws, int64_t ws_bytes, int save,
+                    void* stream);
 /* dout (nullable) [B,T,2H], dh_n (nullable) [4,B,H]; grads: same 16-tensor block in the grad arena;
  * dx (nullable) [B,T,K]; dx_scalar (nullable, 1 float, accumulated); dh0 (nullable) [4,B,H] */
 int inet_bigru2_bwd(int batch, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
                     float* grads, const float* mask, const float* dout, const float* dh_n, float* dx,
-                    float* dx_scalar, float* dh0, void* ws, void* stream);
+                    float* dx_scalar, float* dh0, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- generic fp32 MFMA GEMM (nn.Linear and friends): C[M,N] (op)= epi(A . B^T + bias) -- */
 /* a_kmajor/b_kmajor: 0 => operand(row,k) = P[row*ld + k]; 1 => P[k*ld + row].
@@ -139,6 +142,13 @@ int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t
  * gate pre-activations gi [B,3H] already formed) -- r,z,n,ghn,hprev saves are nullable [B,H] */
 int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
                   float* h_new, float* sv5, void* stream);
+
+/* ---- measurement hooks (bench.py roofline line; not part of the reference surface) --------------- */
+/* class 0 = batched MFMA GEMM, 1 = fused GRU step forward, 2 = fused GRU step backward.  While enabled every
+ * launch of those kernels is bracketed by hipEventRecord on its stream; read() synchronises and returns the
+ * number of launches, the summed event time (ms) and the summed algorithmic FLOPs (2*M*N*K) of the class. */
+int inet_prof_enable(int on);
+int inet_prof_read(int cls, int64_t* launches, double* total_ms, double* total_flops);
 
 #ifdef __cplusplus
 }

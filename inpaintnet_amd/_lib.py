@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip"]
 
 _lib = None
 
@@ -60,21 +60,23 @@ _SIGNATURES = {
     "inet_latent_param_floats": (_L, [_LCFG]),
     "inet_latent_param_info": (C.c_int, [_LCFG, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
     "inet_vae_encoder_ws_bytes": (_L, [_CFG, _I, _I]),
-    "inet_vae_encoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "inet_vae_encoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "inet_vae_encoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "inet_vae_encoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "inet_vae_decoder_ws_bytes": (_L, [_CFG, _I, _I]),
-    "inet_vae_decoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "inet_vae_decoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "inet_vae_decoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "inet_vae_decoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "inet_cross_entropy": (C.c_int, [_P, _L, _I, _I, _P, _P, _L, _F, _P, _P, _P]),
     "inet_reparam_kl": (C.c_int, [_P, _P, _P, _P, _P, _L, _P, _P]),
     "inet_latent_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _P, _L, _P]),
     "inet_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
     "inet_dropout_mask": (C.c_int, [_P, _L, _F, _U, _U, _P]),
     "inet_bigru2_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
-    "inet_bigru2_fwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "inet_bigru2_bwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "inet_bigru2_fwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "inet_bigru2_bwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "inet_gemm": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _P]),
     "inet_gru_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "inet_prof_enable": (C.c_int, [_I]),
+    "inet_prof_read": (C.c_int, [_I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -95,14 +95,17 @@ int64_t inet_vae_encoder_ws_bytes(const inet_vae_config* cfg, int batch, int sav
     return (int64_t)vae_encoder_ws_bytes(*cfg, batch, save);
 }
 int inet_vae_encoder_fwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
-                         const float* mask, float* mu, float* logsigma, void* ws, int save, void* stream) {
+                         const float* mask, float* mu, float* logsigma, void* ws, int64_t ws_bytes, int save,
+                         void* stream) {
     if (!cfg_ok(cfg) || batch <= 0 || !tokens || !params || !mu || !logsigma || !ws) return -1;
+    if (ws_bytes < (int64_t)vae_encoder_ws_bytes(*cfg, batch, save)) return -1;
     return vae_encoder_fwd(*cfg, batch, (const long long*)tokens, params, mask, mu, logsigma, ws, save, (hipStream_t)stream);
 }
 int inet_vae_encoder_bwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
                          float* grads, const float* mask, const float* dmu, const float* dlogsigma, void* ws,
-                         void* stream) {
+                         int64_t ws_bytes, void* stream) {
     if (!cfg_ok(cfg) || batch <= 0 || !tokens || !params || !grads || !dmu || !dlogsigma || !ws) return -1;
+    if (ws_bytes < (int64_t)vae_encoder_ws_bytes(*cfg, batch, 1)) return -1;
     return vae_encoder_bwd(*cfg, batch, (const long long*)tokens, params, grads, mask, dmu, dlogsigma, ws, (hipStream_t)stream);
 }
 int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int save) {
@@ -111,15 +114,17 @@ int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int sav
 }
 int inet_vae_decoder_fwd(const inet_vae_config* cfg, int batch, const float* z, const int64_t* target,
                          int teacher_forced, const float* params, const float* mask_beat, const float* mask_tick,
-                         float* weights, int64_t* samples, void* ws, int save, void* stream) {
+                         float* weights, int64_t* samples, void* ws, int64_t ws_bytes, int save, void* stream) {
     if (!cfg_ok(cfg) || batch <= 0 || !z || !params || !weights || !samples || !ws) return -1;
+    if (ws_bytes < (int64_t)vae_decoder_ws_bytes(*cfg, batch, save)) return -1;
     return vae_decoder_fwd(*cfg, batch, z, (const long long*)target, teacher_forced, params, mask_beat, mask_tick,
                            weights, (long long*)samples, ws, save, (hipStream_t)stream);
 }
 int inet_vae_decoder_bwd(const inet_vae_config* cfg, int batch, const float* dweights, const float* weights,
                          const int64_t* tokens_in, const float* params, float* grads, const float* mask_beat,
-                         const float* mask_tick, float* dz, void* ws, void* stream) {
+                         const float* mask_tick, float* dz, void* ws, int64_t ws_bytes, void* stream) {
     if (!cfg_ok(cfg) || batch <= 0 || !dweights || !weights || !tokens_in || !params || !ws) return -1;
+    if (ws_bytes < (int64_t)vae_decoder_ws_bytes(*cfg, batch, 1)) return -1;
     return vae_decoder_bwd(*cfg, batch, dweights, weights, (const long long*)tokens_in, params, grads, mask_beat,
                            mask_tick, dz, ws, (hipStream_t)stream);
 }
@@ -157,8 +162,10 @@ int64_t inet_bigru2_ws_bytes(int batch, int T, int K, int H, int save) {
 }
 
 int inet_bigru2_fwd(int B, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
-                    const float* h0, const float* mask, float* out, float* h_n, void* ws, int save, void* stream) {
+                    const float* h0, const float* mask, float* out, float* h_n, void* ws, int64_t ws_bytes, int save,
+                    void* stream) {
     if (B <= 0 || T <= 0 || K <= 0 || H <= 0 || H % 16 || !weights || !ws) return -1;
+    if (ws_bytes < inet_bigru2_ws_bytes(B, T, K, H, save)) return -1;
     if (!x && !(x_scalar && K == 1)) return -1;
     hipStream_t s = (hipStream_t)stream;
     BiWs w;
@@ -187,8 +194,9 @@ int inet_bigru2_fwd(int B, int T, int K, int H, const float* x, const float* x_s
 
 int inet_bigru2_bwd(int B, int T, int K, int H, const float* x, const float* x_scalar, const float* weights,
                     float* grads, const float* mask, const float* dout, const float* dh_n, float* dx,
-                    float* dx_scalar, float* dh0, void* ws, void* stream) {
+                    float* dx_scalar, float* dh0, void* ws, int64_t ws_bytes, void* stream) {
     if (B <= 0 || T <= 0 || K <= 0 || H <= 0 || H % 16 || !weights || !ws) return -1;
+    if (ws_bytes < inet_bigru2_ws_bytes(B, T, K, H, 1)) return -1;
     if (!x && !(x_scalar && K == 1)) return -1;
     hipStream_t s = (hipStream_t)stream;
     BiWs w;

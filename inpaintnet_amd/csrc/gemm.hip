@@ -20,6 +20,7 @@
 // conflict-free ds_read_b32.  The k index owned by lane-half h in MFMA step i
 // of a 32-chunk is 8*(i/4) + 4*h + i%4 for both operands.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -253,5 +254,6 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
         g.acc = ACC_ATOMIC;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
+    ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s);
     return useL ? launch_cfg<128, 128>(g, grid, s) : launch_cfg<64, 64>(g, grid, s);
 }

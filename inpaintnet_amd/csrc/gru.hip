@@ -21,6 +21,7 @@
 // bidirectional layers / the four beats run as blockIdx.z "problems" in the
 // same launch.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -266,6 +267,9 @@ int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s) {
     }
     if (maxB <= 0) return 0;
     dim3 grid(b.H / TH, (maxB + TM_ROWS - 1) / TM_ROWS, b.nprob);
+    double fl = 0;
+    for (int i = 0; i < b.nprob; ++i) fl += 2.0 * b.p[i].B * 3.0 * b.H * (b.H + (hasx ? b.p[i].K2 : 0));
+    ProfScope prof(PROF_GRU_FWD, fl, s);
     if (hasx) hipLaunchKernelGGL(gru_step_fwd_kernel<true>, grid, dim3(256), 0, s, b);
     else hipLaunchKernelGGL(gru_step_fwd_kernel<false>, grid, dim3(256), 0, s, b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -277,6 +281,9 @@ int launch_gru_bwd(const GruBwdBatch& b, hipStream_t s) {
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].B > maxB) maxB = b.p[i].B;
     if (maxB <= 0) return 0;
     dim3 grid(b.H / TH, (maxB + TM_ROWS - 1) / TM_ROWS, b.nprob);
+    double fl = 0;
+    for (int i = 0; i < b.nprob; ++i) if (b.p[i].dgh_next) fl += 2.0 * b.p[i].B * 3.0 * b.H * b.H;
+    ProfScope prof(PROF_GRU_BWD, fl, s);
     hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, s, b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

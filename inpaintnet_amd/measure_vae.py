@@ -1,0 +1,326 @@
+"""MeasureVAE with the reference's Python surface, computed by the HIP library.
+
+Mirrors MeasureVAE/measure_vae.py:10-169, MeasureVAE/encoder.py:9-134 and
+MeasureVAE/decoder.py:313-529 of the reference: same constructor arguments,
+attributes, method names, return arities, shapes and dtypes.  Each module is one
+torch.autograd.Function whose forward/backward are single calls into the C-ABI
+(include/inpaintnet_hip.h); parameter gradients are accumulated straight into
+the model's flat gradient arena (`model.grad`) by the backward kernels.
+"""
+import os
+import random
+
+import torch
+from torch import distributions
+
+from . import ops
+from .model import Model, default_device
+
+_mask_counter = [0]
+
+
+def _next_mask_offset(n):
+    off = _mask_counter[0]
+    _mask_counter[0] += int(n)
+    return off
+
+
+def set_dropout_seed(seed, rank=0):
+    """Seed of the counter-based dropout stream (rank-offset for data parallel)."""
+    _DropState.seed = (int(seed) * 1000003 + int(rank) * 7919) & (2 ** 63 - 1)
+    _mask_counter[0] = 0
+
+
+class _DropState:
+    seed = 0x5eed
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, enc, tokens, mask):
+        need = ctx.needs_input_grad[0]           # grad mode is off inside forward(): ask the ctx
+        mu, ls, ws = ops.encoder_fwd(enc.cfg, tokens, flat, mask=mask, save=need)
+        ctx.enc, ctx.tokens, ctx.mask, ctx.ws = enc, tokens, mask, ws
+        return mu, ls
+
+    @staticmethod
+    def backward(ctx, dmu, dls):
+        enc = ctx.enc
+        ops.encoder_bwd(enc.cfg, ctx.tokens, enc.owner.flat, enc.owner.grad, ctx.mask, dmu.contiguous(),
+                        dls.contiguous(), ctx.ws)
+        ctx.ws = None
+        return None, None, None, None
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, flat, dec, target, teacher_forced, mask_beat, mask_tick):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        weights, samples, ws = ops.decoder_fwd(dec.cfg, z.contiguous(), target, teacher_forced, flat, mask_beat,
+                                               mask_tick, save=need)
+        ctx.dec, ctx.ws, ctx.mb, ctx.mt = dec, ws, mask_beat, mask_tick
+        ctx.save_for_backward(weights, samples)
+        ctx.mark_non_differentiable(samples)
+        return weights, samples
+
+    @staticmethod
+    def backward(ctx, dweights, _dsamples):
+        dec = ctx.dec
+        weights, samples = ctx.saved_tensors
+        grads = dec.owner.grad if dec.owner.trainable else None
+        dz = ops.decoder_bwd(dec.cfg, dweights.contiguous(), weights, samples, dec.owner.flat, grads, ctx.mb, ctx.mt,
+                             ctx.ws, need_dz=ctx.needs_input_grad[0])
+        ctx.ws = None
+        return dz, None, None, None, None, None, None
+
+
+class _ReparamFn(torch.autograd.Function):
+    """z = mu + eps * exp(logsigma), sigma  (measure_vae.py:119 rsample)."""
+
+    @staticmethod
+    def forward(ctx, mu, ls, eps):
+        z, sigma = ops.reparam_kl(mu, ls, eps, kl_sum=None, want_sigma=True)
+        ctx.save_for_backward(mu, ls, eps)
+        ctx.mark_non_differentiable(sigma)
+        return z, sigma
+
+    @staticmethod
+    def backward(ctx, dz, _ds):
+        mu, ls, eps = ctx.saved_tensors
+        dmu, dls = ops.latent_bwd(dz.contiguous(), mu, ls, eps, 0.0)
+        return dmu, dls, None
+
+
+class NormalLogScale(distributions.Normal):
+    """torch Normal whose log-scale (the encoder's actual output) is kept alongside, so
+    the KL kernel needs no log() round trip.  rsample()/sample() draw eps with torch's
+    device generator and combine on the GPU with the reparameterisation kernel."""
+
+    def __init__(self, loc, log_scale, scale):
+        super().__init__(loc, scale, validate_args=False)
+        self.log_scale = log_scale
+
+    def rsample(self, sample_shape=torch.Size(), eps=None):
+        if len(sample_shape) != 0:
+            return super().rsample(sample_shape)
+        if eps is None:
+            eps = torch.randn_like(self.loc)
+        z, _ = _ReparamFn.apply(self.loc, self.log_scale, eps)
+        self.last_eps = eps
+        return z
+
+
+class Encoder(torch.nn.Module):
+    """MeasureVAE/encoder.py:9-134."""
+
+    def __init__(self, owner, prefix, note_embedding_dim, rnn_hidden_size, num_layers, num_notes, dropout,
+                 bidirectional, z_dim, rnn_class):
+        super().__init__()
+        if num_layers != 2 or not bidirectional:
+            raise NotImplementedError("the HIP encoder implements the reference configuration: 2 layers, bidirectional")
+        object.__setattr__(self, "owner", owner)
+        self.prefix = prefix
+        self.bidirectional = bidirectional
+        self.num_directions = 2
+        self.note_embedding_dim = note_embedding_dim
+        self.num_layers = num_layers
+        self.rnn_hidden_size = rnn_hidden_size
+        self.z_dim = z_dim
+        self.dropout = dropout
+        self.rnn_class = rnn_class
+        self.num_notes = num_notes
+
+    @property
+    def cfg(self):
+        return self.owner.cfg
+
+    def __repr__(self):
+        return f'Encoder(' \
+               f'{self.note_embedding_dim},' \
+               f'{self.rnn_class},' \
+               f'{self.num_layers},' \
+               f'{self.rnn_hidden_size},' \
+               f'{self.dropout},' \
+               f'{self.bidirectional},' \
+               f'{self.z_dim},' \
+               f')'
+
+    def forward(self, score_tensor, mask=None):
+        """score_tensor (B, 24) int64 -> Normal(loc, scale)   (encoder.py:104-134)"""
+        batch_size, T = score_tensor.size()
+        tokens = score_tensor.contiguous()
+        if mask is None and self.training and self.dropout > 0:
+            n = T * batch_size * 2 * self.rnn_hidden_size
+            mask = ops.dropout_mask((T, batch_size, 2 * self.rnn_hidden_size), self.dropout, _DropState.seed,
+                                    _next_mask_offset(n), tokens.device)
+        mu, ls = _EncoderFn.apply(self.owner.flat_for_autograd(), self, tokens, mask)
+        return NormalLogScale(mu, ls, _ExpFn.apply(ls))
+
+
+class _ExpFn(torch.autograd.Function):
+    """sigma = exp(logsigma)  (encoder.py:133), by the reparameterisation kernel."""
+
+    @staticmethod
+    def forward(ctx, ls):
+        _, sigma = ops.reparam_kl(ls, ls, None, kl_sum=None, want_sigma=True)
+        ctx.save_for_backward(sigma)
+        return sigma
+
+    @staticmethod
+    def backward(ctx, dsigma):
+        (sigma,) = ctx.saved_tensors
+        return dsigma * sigma
+
+
+class HierarchicalDecoder(torch.nn.Module):
+    """MeasureVAE/decoder.py:313-529."""
+
+    def __init__(self, owner, prefix, note_embedding_dim, num_notes, z_dim, num_layers, rnn_hidden_size, dropout,
+                 rnn_class):
+        super().__init__()
+        if num_layers != 2:
+            raise NotImplementedError("the HIP decoder implements the reference configuration: 2 layers")
+        object.__setattr__(self, "owner", owner)
+        self.prefix = prefix
+        self.name = 'HierarchicalDecoder'
+        self.num_notes = num_notes
+        self.note_embedding_dim = note_embedding_dim
+        self.z_dim = z_dim
+        self.rnn_class = rnn_class
+        self.num_layers = num_layers
+        self.rnn_hidden_size = rnn_hidden_size
+        self.dropout = dropout
+        self.use_teacher_forcing = True
+        self.teacher_forcing_prob = 0.5
+        self.sampling = 'argmax'
+
+    @property
+    def cfg(self):
+        return self.owner.cfg
+
+    def __repr__(self):
+        return f'{self.name}' \
+               f'{self.note_embedding_dim},' \
+               f'{self.rnn_class},' \
+               f'{self.num_layers},' \
+               f'{self.rnn_hidden_size},' \
+               f'{self.dropout},' \
+               f')'
+
+    def forward(self, z, score_tensor, train, masks=None, teacher_forced=None):
+        """z (B,Z), score_tensor (B,24) -> weights (B,24,V), samples (B,1,24)   (decoder.py:412-453).
+        One Bernoulli(0.5) teacher-forcing coin per call when train=True (decoder.py:431-434); it can be
+        injected with `teacher_forced=`."""
+        if teacher_forced is None:
+            if self.use_teacher_forcing and train:
+                teacher_forced = random.random() < self.teacher_forcing_prob
+            else:
+                teacher_forced = False
+        if train and self.sampling != 'argmax':
+            raise NotImplementedError("only argmax sampling (the reference default, decoder.py:376) is implemented")
+        batch_size_z, z_dim = z.size()
+        assert z_dim == self.z_dim
+        batch_size = score_tensor.size(0)
+        assert batch_size == batch_size_z
+        T = self.cfg.beats * self.cfg.ticks_per_beat
+        target = None
+        if teacher_forced:
+            target = score_tensor.detach()
+            if target.dtype != torch.int64:
+                target = target.long()
+            target = target.contiguous()
+        mb = mt = None
+        if masks is not None:
+            mb, mt = masks
+        elif self.training and self.dropout > 0:
+            H = self.rnn_hidden_size
+            dev = z.device
+            mb = ops.dropout_mask((self.cfg.beats, batch_size, H), self.dropout, _DropState.seed,
+                                  _next_mask_offset(self.cfg.beats * batch_size * H), dev)
+            mt = ops.dropout_mask((T, batch_size, H), self.dropout, _DropState.seed,
+                                  _next_mask_offset(T * batch_size * H), dev)
+        weights, samples = _DecoderFn.apply(z, self.owner.flat_for_autograd(), self, target, teacher_forced, mb, mt)
+        return weights, samples
+
+
+class MeasureVAE(Model):
+    """MeasureVAE/measure_vae.py:10-169."""
+
+    def __init__(self, dataset, note_embedding_dim=10, metadata_embedding_dim=2, num_encoder_layers=2,
+                 encoder_hidden_size=512, encoder_dropout_prob=0.5, latent_space_dim=256, num_decoder_layers=2,
+                 decoder_hidden_size=512, decoder_dropout_prob=0.5, has_metadata=False, device=None):
+        super().__init__()
+        self.num_beats_per_measure = 4
+        self.num_ticks_per_measure = 24
+        self.num_ticks_per_beat = int(self.num_ticks_per_measure / self.num_beats_per_measure)
+        self.dataset = dataset.__repr__()
+        self.note_embedding_dim = note_embedding_dim
+        self.metadata_embedding_dim = metadata_embedding_dim
+        self.num_encoder_layers = num_encoder_layers
+        self.encoder_hidden_size = encoder_hidden_size
+        self.encoder_dropout_prob = encoder_dropout_prob
+        self.latent_space_dim = latent_space_dim
+        self.num_decoder_layers = num_decoder_layers
+        self.decoder_hidden_size = decoder_hidden_size
+        self.decoder_dropout_prob = decoder_dropout_prob
+        self.has_metadata = has_metadata
+        self.num_notes = len(dataset.note2index_dicts[0])
+        self.trainable = True
+        self.cfg = ops.vae_config(self.num_notes, note_embedding_dim, encoder_hidden_size, latent_space_dim,
+                                  decoder_hidden_size, self.num_beats_per_measure, self.num_ticks_per_beat)
+        table, total = ops.vae_param_table(self.cfg)
+        self._alloc_arena(table, total, device or default_device())
+        self._flat_leaf = None
+        self.encoder = Encoder(self, "encoder", note_embedding_dim, encoder_hidden_size, num_encoder_layers,
+                               self.num_notes, encoder_dropout_prob, True, latent_space_dim, torch.nn.GRU)
+        self.decoder = HierarchicalDecoder(self, "decoder", note_embedding_dim, self.num_notes, latent_space_dim,
+                                           num_decoder_layers, decoder_hidden_size, decoder_dropout_prob,
+                                           torch.nn.GRU)
+        self.init_reference_style()
+        cur_dir = os.path.dirname(os.path.realpath(__file__))
+        self.filepath = os.path.join(cur_dir, 'models/', self.__repr__())
+
+    def flat_for_autograd(self):
+        """The arena as an autograd leaf, so that the module Functions are recorded whenever the model is
+        trainable.  Its own .grad is never populated: the backward kernels write into self.grad."""
+        if not self.trainable:
+            return self.flat
+        if self._flat_leaf is None:
+            self._flat_leaf = self.flat.detach().requires_grad_(True)     # shares storage
+        return self._flat_leaf
+
+    def freeze(self):
+        """for p in vae.parameters(): p.requires_grad = False   (latent_rnn.py:42-43)"""
+        self.trainable = False
+
+    def __repr__(self):
+        return f'MeasureVAE(' \
+               f'{self.dataset},' \
+               f'{self.encoder.__repr__()},' \
+               f'{self.decoder.__repr__()},' \
+               f')'
+
+    def forward(self, measure_score_tensor, train=True, eps=None, teacher_forced=None):
+        """(B,24) int64 -> (weights, samples, z_dist, prior_dist, z_tilde, z_prior)   (measure_vae.py:97-134)"""
+        seq_len = measure_score_tensor.size(1)
+        assert seq_len == self.num_ticks_per_measure
+        z_dist = self.encoder(measure_score_tensor)
+        z_tilde = z_dist.rsample(eps=eps)
+        prior_dist = distributions.Normal(loc=torch.zeros_like(z_dist.loc), scale=torch.ones_like(z_dist.scale),
+                                          validate_args=False)
+        z_prior = prior_dist.sample()
+        weights, samples = self.decoder(z=z_tilde, score_tensor=measure_score_tensor, train=train,
+                                        teacher_forced=teacher_forced)
+        return weights, samples, z_dist, prior_dist, z_tilde, z_prior
+
+    def forward_test(self, measure_score_tensor):
+        """(B,M,24) -> weights (B,M,24,V), samples (B,1,24M)   (measure_vae.py:136-169).  The M measures are
+        independent, so they run as one batch of B*M."""
+        batch_size, num_measures, seq_len = measure_score_tensor.size()
+        assert seq_len == self.num_ticks_per_measure
+        flat_in = measure_score_tensor.reshape(batch_size * num_measures, seq_len).contiguous()
+        z = self.encoder(flat_in).rsample()
+        w, s = self.decoder(z=z, score_tensor=flat_in, train=False)
+        weights = w.view(batch_size, num_measures, seq_len, -1)
+        samples = s.view(batch_size, 1, num_measures * seq_len)
+        return weights, samples

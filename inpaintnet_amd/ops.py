@@ -73,7 +73,7 @@ def encoder_fwd(cfg, tokens, params, mask=None, save=False, ws=None):
     mu = torch.empty(B, cfg.z_dim, dtype=torch.float32, device=tokens.device)
     ls = torch.empty_like(mu)
     check(_lib.lib().inet_vae_encoder_fwd(C.byref(cfg), B, ptr(tokens), ptr(params), ptr(mask), ptr(mu), ptr(ls),
-                                          ptr(ws), int(save), stream_ptr()), "inet_vae_encoder_fwd")
+                                          ptr(ws), ws.numel() * 4, int(save), stream_ptr()), "inet_vae_encoder_fwd")
     return mu, ls, ws
 
 
@@ -81,7 +81,7 @@ def encoder_bwd(cfg, tokens, params, grads, mask, dmu, dls, ws):
     B = tokens.shape[0]
     _f32c(dmu); _f32c(dls); _f32c(grads)
     check(_lib.lib().inet_vae_encoder_bwd(C.byref(cfg), B, ptr(tokens), ptr(params), ptr(grads), ptr(mask), ptr(dmu),
-                                          ptr(dls), ptr(ws), stream_ptr()), "inet_vae_encoder_bwd")
+                                          ptr(dls), ptr(ws), ws.numel() * 4, stream_ptr()), "inet_vae_encoder_bwd")
 
 
 # ----------------------------------------------------------------------------- decoder
@@ -105,7 +105,7 @@ def decoder_fwd(cfg, z, target, teacher_forced, params, mask_beat=None, mask_tic
     samples = torch.empty(B, 1, T, dtype=torch.int64, device=z.device)
     check(_lib.lib().inet_vae_decoder_fwd(C.byref(cfg), B, ptr(z), ptr(target), int(bool(teacher_forced)), ptr(params),
                                           ptr(mask_beat), ptr(mask_tick), ptr(weights), ptr(samples), ptr(ws),
-                                          int(save), stream_ptr()), "inet_vae_decoder_fwd")
+                                          ws.numel() * 4, int(save), stream_ptr()), "inet_vae_decoder_fwd")
     return weights, samples, ws
 
 
@@ -114,8 +114,8 @@ def decoder_bwd(cfg, dweights, weights, samples, params, grads, mask_beat, mask_
     _f32c(dweights); _f32c(weights); _i64c(samples)
     dz = torch.empty(B, cfg.z_dim, dtype=torch.float32, device=weights.device) if need_dz else None
     check(_lib.lib().inet_vae_decoder_bwd(C.byref(cfg), B, ptr(dweights), ptr(weights), ptr(samples), ptr(params),
-                                          ptr(grads), ptr(mask_beat), ptr(mask_tick), ptr(dz), ptr(ws), stream_ptr()),
-          "inet_vae_decoder_bwd")
+                                          ptr(grads), ptr(mask_beat), ptr(mask_tick), ptr(dz), ptr(ws), ws.numel() * 4,
+                                          stream_ptr()), "inet_vae_decoder_bwd")
     return dz
 
 
@@ -161,6 +161,26 @@ def dropout_mask(shape, p, seed, offset, device):
     return out
 
 
+# ----------------------------------------------------------------------------- measurement hooks
+PROF_CLASSES = ("gemm_f32_mfma", "gru_step_fwd", "gru_step_bwd")
+
+
+def prof_enable(on):
+    check(_lib.lib().inet_prof_enable(int(bool(on))), "inet_prof_enable")
+
+
+def prof_read():
+    """{class: (launches, total_ms, total_flops)} for the launches since prof_enable(True)."""
+    out = {}
+    for i, name in enumerate(PROF_CLASSES):
+        n = C.c_int64()
+        ms = C.c_double()
+        fl = C.c_double()
+        check(_lib.lib().inet_prof_read(i, C.byref(n), C.byref(ms), C.byref(fl)), "inet_prof_read")
+        out[name] = (n.value, ms.value, fl.value)
+    return out
+
+
 # ----------------------------------------------------------------------------- generic ops
 def gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, epi=0, aux=None, out=None, accumulate=False):
     """C[M,N] (op)= epi(sum_k A(m,k) B(n,k) + bias).  A, B are 2-D (possibly row-strided) fp32 tensors."""
@@ -199,7 +219,7 @@ def bigru2_fwd(x, x_scalar, weights, H, B, T, K, h0=None, mask=None, want_out=Tr
     out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev) if want_out else None
     hn = torch.empty(4, B, H, dtype=torch.float32, device=dev) if want_hn else None
     check(_lib.lib().inet_bigru2_fwd(B, T, K, H, ptr(x), ptr(x_scalar), ptr(weights), ptr(h0), ptr(mask), ptr(out),
-                                     ptr(hn), ptr(ws), int(save), stream_ptr()), "inet_bigru2_fwd")
+                                     ptr(hn), ptr(ws), ws.numel() * 4, int(save), stream_ptr()), "inet_bigru2_fwd")
     return out, hn, ws
 
 
@@ -209,6 +229,6 @@ def bigru2_bwd(x, x_scalar, weights, grads, H, B, T, K, mask, dout, dhn, ws, wan
     dx = torch.empty(B, T, K, dtype=torch.float32, device=dev) if (want_dx and x is not None) else None
     dh0 = torch.empty(4, B, H, dtype=torch.float32, device=dev) if want_dh0 else None
     check(_lib.lib().inet_bigru2_bwd(B, T, K, H, ptr(x), ptr(x_scalar), ptr(weights), ptr(grads), ptr(mask),
-                                     ptr(dout), ptr(dhn), ptr(dx), ptr(dx_scalar), ptr(dh0), ptr(ws), stream_ptr()),
-          "inet_bigru2_bwd")
+                                     ptr(dout), ptr(dhn), ptr(dx), ptr(dx_scalar), ptr(dh0), ptr(ws), ws.numel() * 4,
+                                     stream_ptr()), "inet_bigru2_bwd")
     return dx, dh0

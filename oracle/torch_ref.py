@@ -307,3 +307,78 @@ def latent_loss(weights, target):
     V = weights.shape[-1]
     ce = F.cross_entropy(weights.reshape(-1, V), target.reshape(-1), reduction="mean")
     return ce, accuracy_mean(weights.detach(), target)
+
+
+# ----------------------------------------------------------------------------
+# CPU baseline leg (bench.py cpu_baseline, kind "port"): the same training step
+# expressed the way the reference runs it on CPU -- fused aten::gru calls (what
+# nn.GRU dispatches to), one call per tick in the decoder, dropout active,
+# autograd backward, torch.optim.Adam.  Checked against the explicit restatement
+# above in tests/test_oracle_golden.py (dropout off).
+# ----------------------------------------------------------------------------
+def _flat_gru(P, prefix, num_layers, bidirectional):
+    D = 2 if bidirectional else 1
+    flat = []
+    for l in range(num_layers):
+        for d in range(D):
+            sfx = f"_l{l}" + ("_reverse" if d == 1 else "")
+            flat += [P[f"{prefix}.weight_ih{sfx}"], P[f"{prefix}.weight_hh{sfx}"],
+                     P[f"{prefix}.bias_ih{sfx}"], P[f"{prefix}.bias_hh{sfx}"]]
+    return flat
+
+
+def vae_forward_fast(P, tokens, eps, teacher_forced, dropout=0.0, train=False):
+    B, T = tokens.shape
+    He = P["encoder.lstm.weight_hh_l0"].shape[1]
+    emb = P["encoder.note_embedding_layer.weight"][tokens]
+    _, hn = torch._VF.gru(emb, torch.zeros(4, B, He), _flat_gru(P, "encoder.lstm", 2, True), True, 2, dropout, train,
+                          True, True)
+    hcat = hn.transpose(0, 1).contiguous().view(B, -1)
+
+    def head(name):
+        a = F.selu(F.linear(hcat, P[f"encoder.{name}.0.weight"], P[f"encoder.{name}.0.bias"]))
+        return F.linear(a, P[f"encoder.{name}.2.weight"], P[f"encoder.{name}.2.bias"])
+    mu, ls = head("linear_mean"), head("linear_log_std")
+    z = mu + eps * torch.exp(ls)
+    H = P["decoder.rnn_beat.weight_hh_l0"].shape[1]
+    hb0 = F.selu(F.linear(z, P["decoder.z_to_beat_rnn_input.0.weight"], P["decoder.z_to_beat_rnn_input.0.bias"]))
+    h_beat = hb0.view(B, 2, H).transpose(0, 1).contiguous()
+    beat_in = P["decoder.b_0"].view(1, 1, 1).expand(B, 4, 1)
+    beat_out, _ = torch._VF.gru(beat_in, h_beat, _flat_gru(P, "decoder.rnn_beat", 2, False), True, 2, dropout, train,
+                                False, True)
+    tick_w = _flat_gru(P, "decoder.rnn_tick", 2, False)
+    E = P["decoder.note_embedding_layer.weight"]
+    prev = P["decoder.x_0"].view(1, 1, -1).expand(B, 1, -1)
+    weights = []
+    for i in range(4):
+        o_i = beat_out[:, i]
+        hid = F.selu(F.linear(o_i, P["decoder.beat_emb_to_tick_rnn_hidden.0.weight"],
+                              P["decoder.beat_emb_to_tick_rnn_hidden.0.bias"])).view(B, 2, H).transpose(0, 1).contiguous()
+        c_i = F.selu(F.linear(o_i, P["decoder.beat_emb_to_tick_rnn_input.0.weight"],
+                              P["decoder.beat_emb_to_tick_rnn_input.0.bias"])).unsqueeze(1)
+        for j in range(6):
+            out, hid = torch._VF.gru(torch.cat((prev, c_i), 2), hid, tick_w, True, 2, dropout, train, False, True)
+            w_t = torch.relu(F.linear(out[:, 0], P["decoder.tick_emb_to_note_emb.0.weight"],
+                                      P["decoder.tick_emb_to_note_emb.0.bias"]))
+            tok = tokens[:, i * 6 + j] if teacher_forced else w_t.detach().argmax(1)
+            prev = E[tok].unsqueeze(1)
+            weights.append(w_t)
+    return torch.stack(weights, 1), mu, ls
+
+
+class CpuVaeTrainStep:
+    """fwd + CE + KL + bwd + Adam of the MeasureVAE on host cores (baseline only)."""
+
+    def __init__(self, P, lr=1e-4, dropout=0.5):
+        self.P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        self.opt = torch.optim.Adam(list(self.P.values()), lr=lr)
+        self.dropout = dropout
+
+    def step(self, tokens, teacher_forced):
+        self.opt.zero_grad()
+        eps = torch.randn(tokens.shape[0], self.P["encoder.linear_mean.2.bias"].shape[0])
+        w, mu, ls = vae_forward_fast(self.P, tokens, eps, teacher_forced, self.dropout, True)
+        loss, ce, kl, acc = vae_loss(w, tokens, mu, ls)
+        loss.backward()
+        self.opt.step()
+        return float(loss)
