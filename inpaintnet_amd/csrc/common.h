@@ -93,6 +93,7 @@ struct GruBwdProb {
     float* dgi; long ld_dgi;                  // [B,3H]
     float* dgh; long ld_dghout;               // [B,3H]
     float* dhz;                               // [B,H]
+    float* db_ih; float* db_hh;               // [3H] bias gradients, accumulated with atomics (or null)
     float* dh_out; long ld_dhout;             // [B,H] (only when no pointwise part): gradient wrt the initial hidden
     int dh_out_accumulate;
 };

@@ -30,7 +30,12 @@ struct OperandTile {
     static constexpr int PITCH = KM ? (R + 4) : 36;         // words
     static constexpr int WORDS = KM ? 32 * PITCH : R * PITCH;
 
-    // global -> registers.  rows_total: valid extent of the row index, kend: valid extent of k
+    // global -> registers.  rows_total: valid extent of the row index, kend: valid extent of k.
+    // FAST = this 32-deep chunk lies inside [0,kend) and (k-major operands) the tile lies inside the row range:
+    // every load is then an unconditional 16-byte load.  (Per-lane "load or zero" branches make hipcc wrap each
+    // load in an exec-mask branch and serialise the round trips -- measured 2x on this kernel.)  Rows past the
+    // end are CLAMPED, not zeroed: they only feed output rows/columns the epilogue never stores.
+    template <bool FAST>
     __device__ static __forceinline__ void load(f32x4 (&v)[NV], const float* __restrict__ P, long ld,
                                                 int row0, int rows_total, int k0, int kend, int t) {
         if (!KM) {
@@ -38,40 +43,37 @@ struct OperandTile {
             const int k = k0 + c4 * 4;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int row = row0 + (t >> 3) + 32 * i;
-                f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                if (row < rows_total) {
-                    const float* p = P + (long)row * ld + k;
-                    if (k + 3 < kend) {
-                        x = ld4u(p);
-                    } else {
+                const int row = min(row0 + (t >> 3) + 32 * i, rows_total - 1);
+                const float* p = P + (long)row * ld + k;
+                if (FAST) {
+                    v[i] = ld4u(p);
+                } else {
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (k + e < kend) x[e] = p[e];
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < kend) x[e] = p[e];
+                    v[i] = x;
                 }
-                v[i] = x;
             }
         } else {
             constexpr int VPR = R / 4;                       // float4 per k-row
-            constexpr int KSTEP = 256 / VPR;
-            const int c4 = t % VPR;
-            const int row = row0 + c4 * 4;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int k = k0 + t / VPR + KSTEP * i;
-                f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                if (k < kend) {
-                    const float* p = P + (long)k * ld + row;
-                    if (row + 3 < rows_total) {
-                        x = ld4u(p);
-                    } else {
+                const int e = t + 256 * i;
+                const int k = k0 + e / VPR;
+                const int row = row0 + (e % VPR) * 4;
+                if (FAST) {
+                    v[i] = ld4u(P + (long)k * ld + row);
+                } else {
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (k < kend) {
+                        const float* p = P + (long)k * ld + row;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (row + e < rows_total) x[e] = p[e];
+                        for (int q = 0; q < 4; ++q)
+                            if (row + q < rows_total) x[q] = p[q];
                     }
+                    v[i] = x;
                 }
-                v[i] = x;
             }
         }
     }
@@ -87,12 +89,10 @@ struct OperandTile {
             }
         } else {
             constexpr int VPR = R / 4;
-            constexpr int KSTEP = 256 / VPR;
-            const int c4 = t % VPR;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int k = t / VPR + KSTEP * i;
-                *reinterpret_cast<f32x4*>(lds + k * PITCH + c4 * 4) = v[i];
+                const int e = t + 256 * i;
+                *reinterpret_cast<f32x4*>(lds + (e / VPR) * PITCH + (e % VPR) * 4) = v[i];
             }
         }
     }
@@ -122,11 +122,11 @@ __device__ __forceinline__ float apply_epi(float v, int epi, float aux) {
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM>
+template <int TM, int TN, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = OperandTile<BM, AKM>;
     using TB = OperandTile<BN, BKM>;
-    constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int STAGE = TA::WORDS + TB::WORDS;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
@@ -147,9 +147,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[TA::NV], rb[TB::NV];
+    const bool a_in = !AKM || (m0 + BM <= g.M);     // block-uniform: k-major tiles need all rows in range
+    const bool b_in = !BKM || (n0 + BN <= g.N);
+    auto gload = [&](int c) {
+        const int k0 = kbeg + c * 32;
+        const bool kfull = k0 + 32 <= kend;
+        if (kfull && a_in) TA::template load<true>(ra, g.A, g.lda, m0, g.M, k0, kend, t);
+        else TA::template load<false>(ra, g.A, g.lda, m0, g.M, k0, kend, t);
+        if (kfull && b_in) TB::template load<true>(rb, g.B, g.ldb, n0, g.N, k0, kend, t);
+        else TB::template load<false>(rb, g.B, g.ldb, n0, g.N, k0, kend, t);
+    };
     if (nchunks > 0) {
-        TA::load(ra, g.A, g.lda, m0, g.M, kbeg, kend, t);
-        TB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend, t);
+        gload(0);
         TA::store(ra, lds, t);
         TB::store(rb, lds + TA::WORDS, t);
     }
@@ -158,10 +167,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const float* As = lds + (c & 1) * STAGE;
         const float* Bs = As + TA::WORDS;
         const bool more = c + 1 < nchunks;
-        if (more) {
-            TA::load(ra, g.A, g.lda, m0, g.M, kbeg + (c + 1) * 32, kend, t);
-            TB::load(rb, g.B, g.ldb, n0, g.N, kbeg + (c + 1) * 32, kend, t);
-        }
+        if (more) gload(c + 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 fa[TM], fb[TN];
@@ -212,36 +218,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
 }
 
-template <int BM, int BN>
+template <int TM, int TN>
 int launch_cfg(const GemmArgs& g, dim3 grid, hipStream_t s) {
-    if (!g.a_kmajor && !g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, g);
-    else if (!g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, g);
-    else if (g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, g);
+    if (!g.a_kmajor && !g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, dim3(256), 0, s, g);
+    else if (!g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, dim3(256), 0, s, g);
+    else if (g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, dim3(256), 0, s, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+struct TileCfg { int tm, tn, wgs_per_cu; double eff; };
+// block tile = 64*tm x 64*tn; residency from the LDS footprint (2 stages); eff = relative MFMA efficiency
+const TileCfg kCfgs[] = {
+    {1, 1, 4, 0.50}, {2, 2, 2, 0.75}, {3, 1, 2, 0.65}, {3, 2, 1, 0.85}, {3, 3, 1, 0.90},
+};
+
 }  // namespace
 
-// Picks the block tile and a split-K factor so that even the skinny (M = batch)
-// and the short-and-deep (wgrad: K = T*B) products put >= ~2 workgroups on each
-// of the 256 CUs.  Split-K partial sums are combined with f32 hardware atomics
-// into a zeroed (ACC_STORE) or live (ACC_ADD) destination.
+// Tile / split-K selection.  The hot shapes have M or K = T*B = 6144 and N in {512,1024,1536}: with 256 CUs
+// the wave quantisation of a fixed 128x128 tiling costs up to 44 % (576 tiles over 512 slots), so the block
+// tile is chosen per call among 64^2, 128^2, 192x64, 192x128, 192^2 together with a split-K factor to make the
+// number of workgroups a near-multiple of the resident slots; e.g. 6144x1536 -> 192^2 = 256 tiles = 1 per CU.
+// Split-K partial sums are combined with f32 hardware atomics into a zeroed (ACC_STORE) or live (ACC_ADD)
+// destination; it is only used when there is no non-linear epilogue.
 int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     GemmArgs g = gin;
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.K <= 0) return -1;
-    const long tilesL = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const bool useL = tilesL >= 192;
-    const int BM = useL ? 128 : 64, BN = BM;
-    const long tiles = (long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    int splits = 1;
-    if (g.epi == EPI_NONE && tiles < 384 && g.K >= 256) {
-        splits = (int)((512 + tiles - 1) / tiles);
-        const int maxs = g.K / 128;
-        if (splits > maxs) splits = maxs;
-        if (splits < 1) splits = 1;
+    const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    double best = 1e300;
+    int bi = 0, bs = 1;
+    for (int ci = 0; ci < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++ci) {
+        const TileCfg& c = kCfgs[ci];
+        const long tiles = (long)((g.M + 64 * c.tm - 1) / (64 * c.tm)) * ((g.N + 64 * c.tn - 1) / (64 * c.tn));
+        for (int sp : kSplits) {
+            if (sp > 1 && (g.epi != EPI_NONE || g.K / sp < 256)) break;
+            const long wgs = tiles * sp;
+            const long slots = 256L * c.wgs_per_cu;
+            const long rounds = (wgs + slots - 1) / slots;
+            const int conc = (int)((wgs < slots ? (wgs + 255) / 256 : c.wgs_per_cu));      // co-resident WGs per CU
+            const double kk = (double)((g.K + sp - 1) / sp + 64);                            // + fixed prologue/epilogue
+            double cost = rounds * conc * (64.0 * c.tm) * (64.0 * c.tn) * kk / c.eff;
+            if (sp > 1) cost += 0.15 * (double)g.M * g.N * sp / 256.0 * 64.0;                // atomic epilogue traffic
+            if (cost < best) { best = cost; bi = ci; bs = sp; }
+        }
     }
+    const TileCfg& c = kCfgs[bi];
+    const int BM = 64 * c.tm, BN = 64 * c.tn;
+    int splits = bs;
     int kps = (g.K + splits - 1) / splits;
     kps = (kps + 31) / 32 * 32;
     splits = (g.K + kps - 1) / kps;
@@ -255,5 +279,11 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
     ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s);
-    return useL ? launch_cfg<128, 128>(g, grid, s) : launch_cfg<64, 64>(g, grid, s);
+    switch (bi) {
+        case 0: return launch_cfg<1, 1>(g, grid, s);
+        case 1: return launch_cfg<2, 2>(g, grid, s);
+        case 2: return launch_cfg<3, 1>(g, grid, s);
+        case 3: return launch_cfg<3, 2>(g, grid, s);
+        default: return launch_cfg<3, 3>(g, grid, s);
+    }
 }

@@ -4,108 +4,132 @@
 // embedding-derived gate pre-activations by token index, the sigmoid/tanh gate
 // math, the state update, the dropout-masked copy for the next layer and the
 // activations the backward pass needs -- no intermediate ever touches HBM.
+// The backward step fuses dh = dgh_next x W_hh + (direct terms), the gate
+// derivative math and the bias-gradient column sums.
 //
 // Why one launch per step and not one persistent kernel: every step needs the
 // whole previous hidden state (an all-to-all over the 256 CUs).  On MI355X a
 // dependent kernel boundary costs ~1.5 us, an in-kernel grid barrier 4-7 us
-// (MI355X_MICROARCH.md price list), so the boundary IS the cheapest barrier;
-// the step sequence is captured in a hipGraph by the host to remove launch cost.
+// (MI355X_MICROARCH.md price list), so the boundary IS the cheapest barrier.
 //
 // Geometry (gfx950): workgroup = 4 wavefronts, output tile = 32 batch rows x 16
-// hidden units x {r,z,n} gates, i.e. all three gate columns of the same hidden
-// units so the gate math is register-local.  The 4 waves split K (each takes 16
-// of every 64-deep chunk; operands staged through LDS in full 256-byte row
-// segments, pitch 72 words = conflict-free ds_read_b128), accumulate with
-// v_mfma_f32_16x16x4_f32 (exact f32), and are combined through LDS before the
-// epilogue.  At B=256,H=512 this is 8 x 32 = 256 workgroups = one per CU, and
-// bidirectional layers / the four beats run as blockIdx.z "problems" in the
-// same launch.
+// hidden units x {r,z,n} gates -- all three gate columns of the same hidden units,
+// so the gate math is register-local.  At B=256,H=512 that is 8 x 32 = 256
+// workgroups = one per CU; bidirectional layers / the four beats run as
+// blockIdx.z "problems" of the same launch.
+//
+// The step is latency-bound (0.4 GFLOP behind a dependency), so the four waves of
+// a workgroup do NOT share a staged tile: each wave owns a contiguous quarter of
+// K and streams its own MFMA fragments straight from L2 into registers
+// (16 B per lane = 4 consecutive k of one row, which IS the operand layout of
+// v_mfma_f32_16x16x4_f32 up to a k-permutation common to A and B), software-
+// pipelined two groups of 4 k-steps deep with counted vmcnt waits.  No LDS, no
+// barrier in the main loop; the only LDS traffic is the final cross-wave
+// reduction of the partial accumulators.  (Round-1 profile: the LDS-staged
+// version spent ~0.9 us per 64-deep chunk on load->barrier->ds_read latency,
+// 14.5 us per step; see profiles/.)
 #include "common.h"
 #include "prof.h"
 
 namespace {
 
-constexpr int KC = 64;        // k-chunk depth staged in LDS
-constexpr int PITCH = 72;     // LDS row pitch in words (== 8 mod 64)
 constexpr int TM_ROWS = 32;   // batch rows per workgroup
 constexpr int TH = 16;        // hidden units per workgroup
+constexpr int GD = 4;         // k-steps (of 16) per pipeline group
 
-// One K-segment:  acc[ms][g] += A[32 rows, K] * Bg[16 rows, K]^T   for g < NB.
-// A rows beyond `rowsA` and k beyond K are zero filled.  B rows are always valid.
-// lds: 2 stages of (32 + NB*16) rows x PITCH words.
+// Fragments of one k-step (16 k) for this wave: A rows (2 sub-tiles of 16), NB groups of 16 B rows.
+template <int NB>
+struct Frag {
+    f32x4 a[2];
+    f32x4 b[NB];
+};
+
+// One k-step of fragments.  GUARD=false: every load is an unconditional 16-byte load (K multiple of 16).
+// A rows past the batch are clamped, not zeroed: they only feed output rows that are never stored.
+// (Per-lane "load or zero" guards make hipcc wrap each load in an exec-mask branch and wait vmcnt(0) per
+// element -- the round trips serialise; the guarded form is kept only for K not a multiple of 512.)
+template <int NB, bool GUARD>
+__device__ __forceinline__ void load_step(Frag<NB>& f, const float* __restrict__ A, long lda, int row0, int rowsA,
+                                          const float* __restrict__ Bm, long ldb, const int (&brow)[NB], int K, int s,
+                                          int i16, int q) {
+    const int k = 16 * s + 4 * q;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int row = min(row0 + 16 * ms + i16, rowsA - 1);
+        const float* p = A + (long)row * lda + k;
+        if (!GUARD) f.a[ms] = ld4u(p);
+        else {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
+            f.a[ms] = x;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const float* p = Bm + (long)(brow[g] + i16) * ldb + k;
+        if (!GUARD) f.b[g] = ld4u(p);
+        else {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
+            f.b[g] = x;
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void mma_step(f32x4 (&acc)[2][4], const int (&slot)[NB], const Frag<NB>& f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+            for (int g = 0; g < NB; ++g)
+                acc[ms][slot[g]] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ms][e], f.b[g][e], acc[ms][slot[g]], 0, 0, 0);
+}
+
+// acc[ms][slot[g]] += A[32 rows, this wave's K quarter] * Bg[16 rows, same K]^T
 template <int NB>
 __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[2][4], const int (&slot)[NB],
                                                const float* __restrict__ A, long lda, int row0, int rowsA,
                                                const float* __restrict__ Bm, long ldb, const int (&brow)[NB],
-                                               int K, float* lds, int t) {
-    constexpr int STAGE = (TM_ROWS + NB * TH) * PITCH;
-    const int lane = t & 63, w = t >> 6;
-    const int c4 = t & 15, rr = t >> 4;            // 16 float4 per 64-deep row; 16 rows per pass
-    const int nchunks = (K + KC - 1) / KC;
-    f32x4 ra[2], rb[NB];
-
-    auto gload = [&](int c) {
-        const int k = c * KC + c4 * 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = row0 + rr + 16 * i;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (row < rowsA) {
-                const float* p = A + (long)row * lda + k;
-                if (k + 3 < K) x = ld4u(p);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
-                }
-            }
-            ra[i] = x;
-        }
-#pragma unroll
-        for (int gi = 0; gi < NB; ++gi) {
-            const float* p = Bm + (long)(brow[gi] + rr) * ldb + k;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (k + 3 < K) x = ld4u(p);
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
-            }
-            rb[gi] = x;
-        }
-    };
-    auto lstore = [&](float* st) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(st + (rr + 16 * i) * PITCH + c4 * 4) = ra[i];
-#pragma unroll
-        for (int gi = 0; gi < NB; ++gi)
-            *reinterpret_cast<f32x4*>(st + (TM_ROWS + gi * TH + rr) * PITCH + c4 * 4) = rb[gi];
-    };
-
-    gload(0);
-    __syncthreads();            // previous users of the LDS stages are done
-    lstore(lds);
-    __syncthreads();
+                                               int K, int t) {
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform -> scalar loop control
     const int i16 = lane & 15, q = lane >> 4;
-    for (int c = 0; c < nchunks; ++c) {
-        const float* st = lds + (c & 1) * STAGE;
-        const bool more = c + 1 < nchunks;
-        if (more) gload(c + 1);
-        // this wave's 16-deep slice of the chunk: lane (i16,q) reads k = 16w + 4q + {0..3}
-        const int koff = 16 * w + 4 * q;
-        f32x4 fa[2], fb[NB];
+    const int S = (K + 15) >> 4;                   // k-steps of 16
+    if ((K & 511) == 0) {
+        // fast path: each wave owns S/4 = multiple of 8 steps; two groups of GD steps in flight, no guards
+        const int Sq = S >> 2;
+        const int s_beg = w * Sq, s_end = s_beg + Sq;
+        Frag<NB> f0[GD], f1[GD];
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms) fa[ms] = *reinterpret_cast<const f32x4*>(st + (16 * ms + i16) * PITCH + koff);
+        for (int d = 0; d < GD; ++d) load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
+        for (int s = s_beg; s < s_end; s += 2 * GD) {
 #pragma unroll
-        for (int gi = 0; gi < NB; ++gi)
-            fb[gi] = *reinterpret_cast<const f32x4*>(st + (TM_ROWS + gi * TH + i16) * PITCH + koff);
+            for (int d = 0; d < GD; ++d)
+                load_step<NB, false>(f1[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + GD + d, i16, q);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int d = 0; d < GD; ++d) mma_step<NB>(acc, slot, f0[d]);
+            if (s + 2 * GD < s_end) {
 #pragma unroll
-            for (int ms = 0; ms < 2; ++ms)
+                for (int d = 0; d < GD; ++d)
+                    load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + 2 * GD + d, i16, q);
+            }
 #pragma unroll
-                for (int gi = 0; gi < NB; ++gi)
-                    acc[ms][slot[gi]] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ms][s], fb[gi][s], acc[ms][slot[gi]], 0, 0, 0);
-        if (more) lstore(lds + ((c + 1) & 1) * STAGE);
-        __syncthreads();
+            for (int d = 0; d < GD; ++d) mma_step<NB>(acc, slot, f1[d]);
+        }
+    } else {
+        // general path (small / odd K): guarded loads, one step at a time
+        const int Sq = (S + 3) >> 2;
+        const int s_beg = w * Sq;
+        const int s_end = min(S, s_beg + Sq);
+        for (int s = s_beg; s < s_end; ++s) {
+            Frag<NB> f;
+            load_step<NB, true>(f, A, lda, row0, rowsA, Bm, ldb, brow, K, s, i16, q);
+            mma_step<NB>(acc, slot, f);
+        }
     }
 }
 
@@ -116,7 +140,6 @@ __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[2][4], const int (&s
 template <int NACC>
 __device__ __forceinline__ void reduce_waves(const f32x4 (&acc)[2][4], float* red, int t, float (&out)[2][NACC]) {
     const int lane = t & 63, w = t >> 6;
-    __syncthreads();
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -138,12 +161,9 @@ __device__ __forceinline__ void reduce_waves(const f32x4 (&acc)[2][4], float* re
         }
 }
 
-constexpr int FWD_LDS_WORDS = 2 * (TM_ROWS + 3 * TH) * PITCH;   // 11520 words; reduction needs 4*4*512 = 8192
-constexpr int BWD_LDS_WORDS = 2 * (TM_ROWS + 1 * TH) * PITCH;   // 6912 words;  reduction needs 4*1*512 = 2048
-
 template <bool HAS_X>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
-    __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 512];
     const GruFwdProb& P = bt.p[blockIdx.z];
     const int H = bt.H;
     const int t = threadIdx.x;
@@ -160,10 +180,10 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
     const int brow[3] = {j0, H + j0, 2 * H + j0};
     if (HAS_X) {
         const int slotx[3] = {0, 1, 2};          // r, z, gi_n
-        ksplit_segment<3>(acc, slotx, P.x, P.ldx, row0, P.B, P.W_ih, P.ld_wih, brow, P.K2, lds, t);
+        ksplit_segment<3>(acc, slotx, P.x, P.ldx, row0, P.B, P.W_ih, P.ld_wih, brow, P.K2, t);
     }
     const int sloth[3] = {0, 1, 3};              // r, z, gh_n
-    ksplit_segment<3>(acc, sloth, P.h_prev, P.ld_hprev, row0, P.B, P.W_hh, (long)H, brow, H, lds, t);
+    ksplit_segment<3>(acc, sloth, P.h_prev, P.ld_hprev, row0, P.B, P.W_hh, (long)H, brow, H, t);
 
     float v[2][4];
     reduce_waves<4>(acc, lds, t, v);
@@ -206,8 +226,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 //   dn   = dh (1-z); dz = dh (hprev - n); dhz = dh z
 //   dn_pre = dn (1-n^2); dz_pre = dz z(1-z); dr_pre = dn_pre ghn r(1-r)
 //   dgi = [dr_pre, dz_pre, dn_pre]      dgh = [dr_pre, dz_pre, dn_pre r]
+//   db_ih += colsum(dgi) ; db_hh += colsum(dgh)               (tile-reduced, one atomic per column per workgroup)
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
-    __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) float lds[4 * 512];
     const GruBwdProb& P = bt.p[blockIdx.z];
     const int H = bt.H;
     const int t = threadIdx.x;
@@ -224,9 +245,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int brow[1] = {j0};
         const int slot[1] = {0};
-        ksplit_segment<1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, lds, t);
+        ksplit_segment<1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t);
         reduce_waves<1>(acc, lds, t, v);
     }
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};            // this thread's column partials: dr, dz, dn, dn*r
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int pos = t + 256 * p;
@@ -252,6 +274,25 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
         gi[j] = dr_pre; gi[H + j] = dz_pre; gi[2 * H + j] = dn_pre;
         float* gh = P.dgh + (long)b * P.ld_dghout;
         gh[j] = dr_pre; gh[H + j] = dz_pre; gh[2 * H + j] = dn_pre * r;
+        bs[0] += dr_pre; bs[1] += dz_pre; bs[2] += dn_pre; bs[3] += dn_pre * r;
+    }
+    if (P.sv_r && P.db_ih) {
+        // thread t holds column (t & 15) for rows (t >> 4) and (t >> 4) + 16: reduce the 16 row-threads per column
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) lds[a * 256 + t] = bs[a];
+        __syncthreads();
+        if (t < 64) {
+            const int a = t >> 4, c = t & 15;
+            float s = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) s += lds[a * 256 + rr * 16 + c];
+            const int j = j0 + c;
+            if (a == 0) { unsafeAtomicAdd(P.db_ih + j, s); unsafeAtomicAdd(P.db_hh + j, s); }
+            else if (a == 1) { unsafeAtomicAdd(P.db_ih + H + j, s); unsafeAtomicAdd(P.db_hh + H + j, s); }
+            else if (a == 2) unsafeAtomicAdd(P.db_ih + 2 * H + j, s);
+            else unsafeAtomicAdd(P.db_hh + 2 * H + j, s);
+        }
     }
 }
 

@@ -78,12 +78,13 @@ __global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int 
             for (int v = lane; v < V; v += 64) d[v] = (expf(w[v] - m) * inv - (v == tg ? 1.f : 0.f)) * scale;
         }
     }
-    // lanes != 0 hold zeros
-    lsum = wave_sum(lsum);
-    csum = wave_sum(csum);
-    if (lane == 0) {
-        unsafeAtomicAdd(loss_sum, lsum);
-        unsafeAtomicAdd(correct, csum);
+    // lane 0 of every wave holds that wave's partials: combine the 4 waves of the block, one atomic pair per block
+    __shared__ float part[2][4];
+    if (lane == 0) { part[0][threadIdx.x >> 6] = lsum; part[1][threadIdx.x >> 6] = csum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(loss_sum, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        unsafeAtomicAdd(correct, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
     }
 }
 
@@ -311,7 +312,7 @@ int pw_transpose(const float* in, long ld_in, float* out, long ld_out, int rows,
 }
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
                      float scale, float* loss_sum, float* correct, hipStream_t s) {
-    const int g = grid_for((long)rows * 64, 256, 1024);
+    const int g = grid_for((long)rows * 64, 256, 256);
     hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, loss_sum, correct);
     return ok();
 }

@@ -45,15 +45,15 @@ struct DirBwd {
     float* dgi; long dgi_ld, dgi_ts;                          // [T][B][3H] (strided)
     float* dgh;                                               // [T][B][3H] dense
     float* dhz;                                               // [2][B][H]
+    float* db_ih; float* db_hh;                               // bias gradients (fused into the step kernel), or null
     float* dh0; long dh0_ld; int dh0_acc;                     // dLoss/d initial hidden, or null
     int reverse;
 };
 
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
-// dW_hh += dgh^T hprev ; db_hh += colsum(dgh) ; db_ih += colsum(dgi)       (rows = T*B, contiguous in t then b)
-int gru_dir_wgrad(int H, int B, int T, const float* dgh, const float* dgi, long dgi_ld, const float* sv_hprev,
-                  float* dW_hh, float* db_hh, float* db_ih, hipStream_t s);
+// dW_hh += dgh^T hprev       (rows = T*B, contiguous in t then b; the bias gradients come from the step kernel)
+int gru_dir_wgrad(int H, int B, int T, const float* dgh, const float* sv_hprev, float* dW_hh, hipStream_t s);
 
 inline GemmArgs gemm_args(const float* A, long lda, int akm, const float* Bm, long ldb, int bkm, float* C, long ldc,
                           int M, int N, int K, const float* bias = nullptr, int epi = EPI_NONE,

@@ -62,6 +62,7 @@ int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
             P.dgi = D.dgi + (long)t * D.dgi_ts; P.ld_dgi = D.dgi_ld;
             P.dgh = D.dgh + (long)t * B3H; P.ld_dghout = 3L * H;
             P.dhz = D.dhz + (long)(step & 1) * BH;
+            P.db_ih = D.db_ih; P.db_hh = D.db_hh;
         }
         INET_TRY(launch_gru_bwd(bt, s));
     }
@@ -86,13 +87,8 @@ int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
     return 0;
 }
 
-int gru_dir_wgrad(int H, int B, int T, const float* dgh, const float* dgi, long dgi_ld, const float* sv_hprev,
-                  float* dW_hh, float* db_hh, float* db_ih, hipStream_t s) {
-    const int rows = T * B;
-    INET_TRY(linear_wgrad(dgh, 3L * H, sv_hprev, H, dW_hh, H, rows, 3 * H, H, s));
-    INET_TRY(pw_colsum(dgh, 3L * H, rows, 3 * H, db_hh, s));
-    INET_TRY(pw_colsum(dgi, dgi_ld, rows, 3 * H, db_ih, s));
-    return 0;
+int gru_dir_wgrad(int H, int B, int T, const float* dgh, const float* sv_hprev, float* dW_hh, hipStream_t s) {
+    return linear_wgrad(dgh, 3L * H, sv_hprev, H, dW_hh, H, T * B, 3 * H, H, s);
 }
 
 size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
@@ -176,6 +172,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.dgi = w.dgi1 + dir * 3L * H; D.dgi_ld = 6L * H; D.dgi_ts = 6 * BH;
         D.dgh = w.dgh[2 + dir];
         D.dhz = w.dhz + dir * 2 * BH;
+        D.db_ih = P[2 + dir].db_ih; D.db_hh = P[2 + dir].db_hh;
         if (dh0) { D.dh0 = dh0 + (2 + dir) * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
     }
@@ -184,8 +181,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     for (int dir = 0; dir < 2; ++dir) {
         const float* dgi = w.dgi1 + dir * 3L * H;
         if (wg) {
-            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[2 + dir], dgi, 6L * H, w.sv[2 + dir] + 4 * TBH, P[2 + dir].dw_hh,
-                                   P[2 + dir].db_hh, P[2 + dir].db_ih, s));
+            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[2 + dir], w.sv[2 + dir] + 4 * TBH, P[2 + dir].dw_hh, s));
             INET_TRY(linear_wgrad(dgi, 6L * H, x1, 2L * H, P[2 + dir].dw_ih, 2L * H, T * B, 3 * H, 2 * H, s));
         }
         // dx1 [TB,2H] (+)= dgi1_dir [TB,3H] . W_ih_l1_dir [3H,2H]
@@ -204,13 +200,13 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.dgi = w.dgi0 + dir * 3L * H; D.dgi_ld = 6L * H; D.dgi_ts = 6 * BH;
         D.dgh = w.dgh[dir];
         D.dhz = w.dhz + dir * 2 * BH;
+        D.db_ih = P[dir].db_ih; D.db_hh = P[dir].db_hh;
         if (dh0) { D.dh0 = dh0 + dir * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
     }
     INET_TRY(gru_layer_bwd(H, B, T, 2, d, s));
     if (wg)
         for (int dir = 0; dir < 2; ++dir)
-            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[dir], w.dgi0 + dir * 3L * H, 6L * H, w.sv[dir] + 4 * TBH, P[dir].dw_hh,
-                                   P[dir].db_hh, P[dir].db_ih, s));
+            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[dir], w.sv[dir] + 4 * TBH, P[dir].dw_hh, s));
     return 0;
 }

@@ -320,13 +320,13 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         D.dgi = w.dgi1t + (long)i * G * 3 * BH; D.dgi_ld = 3L * H; D.dgi_ts = 3 * BH;
         D.dgh = w.dgh1t + (long)i * G * 3 * BH;
         D.dhz = w.dhz + (long)i * 2 * BH;
+        if (g) { D.db_ih = g + L.tick[1].b_ih; D.db_hh = g + L.tick[1].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H + H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
     if (g) {
-        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh1t, w.dgi1t, 3L * H, w.svt1 + 4 * TBH, g + L.tick[1].w_hh,
-                               g + L.tick[1].b_hh, g + L.tick[1].b_ih, s));
+        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh1t, w.svt1 + 4 * TBH, g + L.tick[1].w_hh, s));
         INET_TRY(linear_wgrad(w.dgi1t, 3L * H, x1, H, g + L.tick[1].w_ih, H, T * B, 3 * H, H, s));
     }
     INET_TRY(linear_dgrad(w.dgi1t, 3L * H, p + L.tick[1].w_ih, H, w.dx1t, H, T * B, 3 * H, H,
@@ -342,14 +342,14 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         D.dgi = w.dgi0t + (long)i * G * 3 * BH; D.dgi_ld = 3L * H; D.dgi_ts = 3 * BH;
         D.dgh = w.dgh0t + (long)i * G * 3 * BH;
         D.dhz = w.dhz + (long)i * 2 * BH;
+        if (g) { D.db_ih = g + L.tick[0].b_ih; D.db_hh = g + L.tick[0].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* wih0 = p + L.tick[0].w_ih;
     const long ldw0 = E + H;
     if (g)
-        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.dgi0t, 3L * H, w.svt0 + 4 * TBH, g + L.tick[0].w_hh,
-                               g + L.tick[0].b_hh, g + L.tick[0].b_ih, s));
+        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, s));
     // beat-constant input half:  dcgi[i] = sum_j dgi0[6i+j]
     INET_TRY(pw_group_sum(w.dgi0t, nb, G, 3 * BH, w.dcgi, s));
     INET_TRY(linear_dgrad(w.dcgi, 3L * H, wih0 + E, ldw0, w.dc_all, H, nb * B, 3 * H, H, EPI_MUL_SELU_GRAD, w.c_all, H,
@@ -385,12 +385,12 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     b.sv = w.svb1; b.sv_astride = nb * BH;
     b.dgi = w.dgi1b; b.dgi_ld = 3L * H; b.dgi_ts = 3 * BH;
     b.dgh = w.dgh1b; b.dhz = w.dhz;
+    if (g) { b.db_ih = g + L.beat[1].b_ih; b.db_hh = g + L.beat[1].b_hh; }
     b.dh0 = w.dhb0 + H; b.dh0_ld = 2L * H;
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     if (g) {
-        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh1b, w.dgi1b, 3L * H, w.svb1 + 4 * nb * BH, g + L.beat[1].w_hh,
-                               g + L.beat[1].b_hh, g + L.beat[1].b_ih, s));
+        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh1b, w.svb1 + 4 * nb * BH, g + L.beat[1].w_hh, s));
         INET_TRY(linear_wgrad(w.dgi1b, 3L * H, xb, H, g + L.beat[1].w_ih, H, nb * B, 3 * H, H, s));
     }
     INET_TRY(linear_dgrad(w.dgi1b, 3L * H, p + L.beat[1].w_ih, H, w.dxb, H, nb * B, 3 * H, H,
@@ -401,11 +401,11 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     b.sv = w.svb0; b.sv_astride = nb * BH;
     b.dgi = w.dgi0b; b.dgi_ld = 3L * H; b.dgi_ts = 3 * BH;
     b.dgh = w.dgh0b; b.dhz = w.dhz;
+    if (g) { b.db_ih = g + L.beat[0].b_ih; b.db_hh = g + L.beat[0].b_hh; }
     b.dh0 = w.dhb0; b.dh0_ld = 2L * H;
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     if (g) {
-        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh0b, w.dgi0b, 3L * H, w.svb0 + 4 * nb * BH, g + L.beat[0].w_hh,
-                               g + L.beat[0].b_hh, g + L.beat[0].b_ih, s));
+        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh0b, w.svb0 + 4 * nb * BH, g + L.beat[0].w_hh, s));
         // gi = b_0 * W_ih[:,0] + b_ih
         if (hipMemsetAsync(w.tmp3h, 0, 3 * H * sizeof(float), s) != hipSuccess) return -2;
         INET_TRY(pw_colsum(w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h, s));

@@ -1,0 +1,122 @@
+// Standalone experiment: where does the time of one fused GRU step go?  (hipcc --offload-arch=gfx950 -O3)
+// Variants of the forward step at B x H: full / no epilogue / loads only / MFMA only / empty.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int VAR>
+__global__ __launch_bounds__(256) void step(const float* __restrict__ hp, const float* __restrict__ W,
+                                            const float* __restrict__ gi, const float* __restrict__ bh,
+                                            float* __restrict__ hn, int B, int H) {
+    __shared__ float red[4 * 4 * 512];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 32;
+    if (VAR == 4) { if (t == 0 && hp == nullptr) hn[0] = 0.f; return; }
+    f32x4 acc[2][3];
+    for (int a = 0; a < 2; ++a) for (int g = 0; g < 3; ++g) acc[a][g] = f32x4{0, 0, 0, 0};
+    const int Sq = (H / 16) / 4;
+    const int s0 = w * Sq;
+    f32x4 fa[8][2], fb[8][3];
+    if (VAR != 3) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+#ifdef LINE128
+            const int k = 32 * ((s0 + d) >> 1) + 8 * q + 4 * ((s0 + d) & 1);   // 4 lanes of a row cover one 128-B line per pair of steps
+#else
+            const int k = 16 * (s0 + d) + 4 * q;
+#endif
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) fa[d][ms] = *(const f32x4*)(hp + (long)(row0 + 16 * ms + i16) * H + k);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) fb[d][g] = *(const f32x4*)(W + (long)(g * H + j0 + i16) * H + k);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            for (int ms = 0; ms < 2; ++ms) fa[d][ms] = f32x4{1.f * lane, 2.f, 3.f, 4.f};
+            for (int g = 0; g < 3; ++g) fb[d][g] = f32x4{1.f, 2.f * d, 3.f, 4.f};
+        }
+    }
+    if (VAR != 2) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[ms][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[d][ms][e], fb[d][g][e], acc[ms][g], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            for (int ms = 0; ms < 2; ++ms)
+                for (int g = 0; g < 3; ++g) acc[ms][g] += fa[d][ms] + fb[d][g];
+    }
+    for (int ms = 0; ms < 2; ++ms)
+        for (int a = 0; a < 3; ++a)
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ms + 4 * (lane >> 4) + r;
+                red[(w * 4 + a) * 512 + row * 16 + (lane & 15)] = acc[ms][a][r];
+            }
+    __syncthreads();
+    for (int p = 0; p < 2; ++p) {
+        const int pos = t + 256 * p;
+        const int b = row0 + (pos >> 4), j = j0 + (pos & 15);
+        float v[3];
+        for (int a = 0; a < 3; ++a) {
+            float s = 0;
+            for (int ww = 0; ww < 4; ++ww) s += red[(ww * 4 + a) * 512 + pos];
+            v[a] = s;
+        }
+        if (VAR == 0) {
+            const float* gp = gi + (long)b * 3 * H;
+            float gr = v[0] + gp[j] + bh[j], gz = v[1] + gp[H + j] + bh[H + j], gn = gp[2 * H + j];
+            float r = 1.f / (1.f + expf(-gr)), z = 1.f / (1.f + expf(-gz));
+            float n = tanhf(gn + r * (v[2] + bh[2 * H + j]));
+            hn[(long)b * H + j] = (1.f - z) * n + z * hp[(long)b * H + j];
+        } else {
+            hn[(long)b * H + j] = v[0] + v[1] + v[2];
+        }
+    }
+}
+
+template <int VAR>
+float run(const float* hp, const float* W, const float* gi, const float* bh, float* h2, int B, int H, int iters) {
+    dim3 grid(H / 16, B / 32);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(step<VAR>, grid, dim3(256), 0, 0, hp, W, gi, bh, h2, B, H);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(step<VAR>, grid, dim3(256), 0, 0, hp, W, gi, bh, h2, B, H);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms * 1e3f / iters;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 512;
+    float *hp, *W, *gi, *bh, *h2;
+    hipMalloc(&hp, (size_t)B * H * 4); hipMalloc(&W, (size_t)3 * H * H * 4); hipMalloc(&gi, (size_t)B * 3 * H * 4);
+    hipMalloc(&bh, 3 * H * 4); hipMalloc(&h2, (size_t)B * H * 4);
+    std::vector<float> tmp((size_t)3 * H * H > (size_t)B * 3 * H ? (size_t)3 * H * H : (size_t)B * 3 * H);
+    for (auto& x : tmp) x = (rand() % 2001 - 1000) * 1e-4f;
+    hipMemcpy(hp, tmp.data(), (size_t)B * H * 4, hipMemcpyHostToDevice);
+    hipMemcpy(W, tmp.data(), (size_t)3 * H * H * 4, hipMemcpyHostToDevice);
+    hipMemcpy(gi, tmp.data(), (size_t)B * 3 * H * 4, hipMemcpyHostToDevice);
+    hipMemcpy(bh, tmp.data(), 3 * H * 4, hipMemcpyHostToDevice);
+    const int it = 200;
+    printf("B=%d H=%d  (us per launch, %d back-to-back launches)\n", B, H, it);
+    printf("  full           %7.2f\n", run<0>(hp, W, gi, bh, h2, B, H, it));
+    printf("  no epilogue    %7.2f\n", run<1>(hp, W, gi, bh, h2, B, H, it));
+    printf("  loads only     %7.2f\n", run<2>(hp, W, gi, bh, h2, B, H, it));
+    printf("  mfma only      %7.2f\n", run<3>(hp, W, gi, bh, h2, B, H, it));
+    printf("  empty kernel   %7.2f\n", run<4>(hp, W, gi, bh, h2, B, H, it));
+    return 0;
+}
