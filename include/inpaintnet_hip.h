@@ -138,6 +138,14 @@ int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t
               int64_t ldc, int M, int N, int K, const float* bias, const float* aux, int64_t ldaux, int epi,
               int acc, void* stream);
 
+/* nn.Linear forward / backward (LatentRNN.generation_linear, latent_rnn.py:83,232,250):
+ * y[M,N] = epi(x[M,K] W[N,K]^T + b), epi in {0 none, 1 SELU, 2 ReLU};
+ * backward (no activation): dx[M,K] = dy W (nullable), dW += dy^T x (nullable), db += colsum(dy) (nullable) */
+int inet_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int epi,
+                    void* stream);
+int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N,
+                    int K, void* stream);
+
 /* single GRU step (test hook for the fused step kernel; semantics of torch.nn.GRUCell with the input-side
  * gate pre-activations gi [B,3H] already formed) -- r,z,n,ghn,hprev saves are nullable [B,H] */
 int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,

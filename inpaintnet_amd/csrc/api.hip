@@ -233,6 +233,21 @@ int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t
                        (hipStream_t)stream);
 }
 
+int inet_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int epi,
+                    void* stream) {
+    if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2) return -1;
+    return linear_fwd(x, K, W, K, b, y, N, M, N, K, epi, (hipStream_t)stream);
+}
+int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N,
+                    int K, void* stream) {
+    if (!dy || M <= 0 || N <= 0 || K <= 0) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) { if (!W) return -1; INET_TRY(linear_dgrad(dy, N, W, K, dx, K, M, N, K, EPI_NONE, nullptr, 0, ACC_STORE, s)); }
+    if (dW) { if (!x) return -1; INET_TRY(linear_wgrad(dy, N, x, K, dW, K, M, N, K, s)); }
+    if (db) INET_TRY(pw_colsum(dy, N, M, N, db, s));
+    return 0;
+}
+
 int inet_gru_step(int B, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
                   float* h_new, float* sv5, void* stream) {
     if (B <= 0 || H <= 0 || H % 16 || !gi || !h_prev || !W_hh || !b_hh || !h_new) return -1;

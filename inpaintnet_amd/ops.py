@@ -193,6 +193,24 @@ def gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, epi=0, aux=No
     return out
 
 
+def linear_fwd(x, W, b, epi=0):
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    check(_lib.lib().inet_linear_fwd(ptr(_f32c(x)), ptr(_f32c(W)), ptr(b), ptr(y), M, N, K, int(epi), stream_ptr()),
+          "inet_linear_fwd")
+    return y
+
+
+def linear_bwd(dy, x, W, dW=None, db=None, need_dx=True):
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = torch.empty(M, K, dtype=torch.float32, device=dy.device) if need_dx else None
+    check(_lib.lib().inet_linear_bwd(ptr(_f32c(dy)), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), M, N, K,
+                                     stream_ptr()), "inet_linear_bwd")
+    return dx
+
+
 def gru_step(gi, h_prev, W_hh, b_hh, save=False):
     B, H = h_prev.shape
     h_new = torch.empty_like(h_prev)
