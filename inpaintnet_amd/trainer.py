@@ -19,7 +19,7 @@ from abc import ABC, abstractmethod
 
 import torch
 
-from . import ops
+from . import dp, ops
 
 
 def _dist_ready():
@@ -140,10 +140,7 @@ class Trainer(ABC):
 
     def step(self):
         """utils/trainer.py:172-177 (+ the data-parallel gradient exchange)."""
-        gscale = 1.0
-        if _dist_ready() and torch.distributed.get_world_size() > 1:
-            torch.distributed.all_reduce(self.model.grad, op=torch.distributed.ReduceOp.SUM)
-            gscale = 1.0 / torch.distributed.get_world_size()
+        gscale = dp.allreduce_grads(self.model.grad)
         self.adam_t += 1
         ops.adam_step(self.model.flat, self.model.grad, self.adam_m, self.adam_v, self.lr, self.adam_t,
                       self.betas[0], self.betas[1], self.eps, gscale)
