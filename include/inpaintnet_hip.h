@@ -151,12 +151,18 @@ int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, 
 int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
                   float* h_new, float* sv5, void* stream);
 
+/* ---- runtime options: key 0 = overlap the weight-gradient GEMMs of the backward pass with the BPTT chains on
+ * a second, lower-priority HIP stream (default 1; also INET_SIDE_STREAM=0 in the environment) */
+int inet_set_option(int key, int value);
+
 /* ---- measurement hooks (bench.py roofline line; not part of the reference surface) --------------- */
 /* class 0 = batched MFMA GEMM, 1 = fused GRU step forward, 2 = fused GRU step backward.  While enabled every
  * launch of those kernels is bracketed by hipEventRecord on its stream; read() synchronises and returns the
  * number of launches, the summed event time (ms) and the summed algorithmic FLOPs (2*M*N*K) of the class. */
 int inet_prof_enable(int on);
 int inet_prof_read(int cls, int64_t* launches, double* total_ms, double* total_flops);
+/* per-launch CSV (class,label,us,gflop) of everything recorded since inet_prof_enable(1) */
+int inet_prof_dump(const char* path);
 
 #ifdef __cplusplus
 }

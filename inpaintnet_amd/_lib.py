@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip"]
+SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip"]
 
 _lib = None
 
@@ -77,7 +77,9 @@ _SIGNATURES = {
     "inet_gru_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "inet_linear_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "inet_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "inet_set_option": (C.c_int, [_I, _I]),
     "inet_prof_enable": (C.c_int, [_I]),
+    "inet_prof_dump": (C.c_int, [C.c_char_p]),
     "inet_prof_read": (C.c_int, [_I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

@@ -211,7 +211,7 @@ int inet_bigru2_bwd(int B, int T, int K, int H, const float* x, const float* x_s
     for (int dir = 0; dir < 2; ++dir) {
         const float* dgi = w.g.dgi0 + dir * 3L * H;
         if (x) {
-            if (grads) INET_TRY(linear_wgrad(dgi, 6L * H, w.x_tm, K, P[dir].dw_ih, K, T * B, 3 * H, K, s));
+            if (grads) INET_TRY(linear_wgrad(dgi, 6L * H, w.x_tm, K, P[dir].dw_ih, K, T * B, 3 * H, K, side_fork(s)));
             if (dx) INET_TRY(linear_dgrad(dgi, 6L * H, P[dir].w_ih, K, w.dx_tm, K, T * B, 3 * H, K, EPI_NONE, nullptr, 0,
                                           dir == 0 ? ACC_STORE : ACC_ADD, s));
         } else if (grads) {
@@ -222,7 +222,7 @@ int inet_bigru2_bwd(int B, int T, int K, int H, const float* x, const float* x_s
         }
     }
     if (x && dx) INET_TRY(pw_swap01(w.dx_tm, T, B, K, dx, s));
-    return 0;
+    return side_join(s);
 }
 
 int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
@@ -246,6 +246,11 @@ int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, 
     if (dW) { if (!x) return -1; INET_TRY(linear_wgrad(dy, N, x, K, dW, K, M, N, K, s)); }
     if (db) INET_TRY(pw_colsum(dy, N, M, N, db, s));
     return 0;
+}
+
+int inet_set_option(int key, int value) {
+    if (key == 0) { side_set_enabled(value); return 0; }
+    return -1;
 }
 
 int inet_gru_step(int B, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,

@@ -103,3 +103,5 @@ struct GruBwdBatch { int H; int nprob; GruBwdProb p[4]; };
 int launch_gemm(const GemmArgs& g, hipStream_t s);
 int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s);
 int launch_gru_bwd(const GruBwdBatch& b, hipStream_t s);
+int launch_logits_argmax(const float* h, long ldh, int B, int H, const float* W, const float* bias, int V, float* out,
+                         long ldo, long long* samples, long sstride, hipStream_t s);

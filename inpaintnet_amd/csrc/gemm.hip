@@ -20,6 +20,8 @@
 // conflict-free ds_read_b32.  The k index owned by lane-half h in MFMA step i
 // of a 32-chunk is 8*(i/4) + 4*h + i%4 for both operands.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 #include "prof.h"
 
 namespace {
@@ -230,38 +232,64 @@ int launch_cfg(const GemmArgs& g, dim3 grid, hipStream_t s) {
 struct TileCfg { int tm, tn, wgs_per_cu; double eff; };
 // block tile = 64*tm x 64*tn; residency from the LDS footprint (2 stages); eff = relative MFMA efficiency
 const TileCfg kCfgs[] = {
-    {1, 1, 4, 0.50}, {2, 2, 2, 0.75}, {3, 1, 2, 0.65}, {3, 2, 1, 0.85}, {3, 3, 1, 0.90},
+    {1, 1, 4, 0.60}, {2, 2, 2, 0.75}, {3, 1, 2, 0.70}, {3, 2, 1, 0.80}, {3, 3, 1, 0.85},
 };
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+// second pass of a split-K product with a non-linear epilogue: C = epi(C, aux)   (bias was added by split 0)
+__global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int N, const float* __restrict__ aux,
+                                     long ldaux, int epi) {
+    const long n = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i % N);
+        float* p = C + (long)r * ldc + c;
+        *p = apply_epi(*p, epi, aux ? aux[(long)r * ldaux + c] : 0.f);
+    }
+}
 
 }  // namespace
 
-// Tile / split-K selection.  The hot shapes have M or K = T*B = 6144 and N in {512,1024,1536}: with 256 CUs
-// the wave quantisation of a fixed 128x128 tiling costs up to 44 % (576 tiles over 512 slots), so the block
-// tile is chosen per call among 64^2, 128^2, 192x64, 192x128, 192^2 together with a split-K factor to make the
-// number of workgroups a near-multiple of the resident slots; e.g. 6144x1536 -> 192^2 = 256 tiles = 1 per CU.
-// Split-K partial sums are combined with f32 hardware atomics into a zeroed (ACC_STORE) or live (ACC_ADD)
-// destination; it is only used when there is no non-linear epilogue.
+// Tile / split-K selection by a small cost model (microseconds), calibrated on MI355X (profiles/r01_*):
+//  * a workgroup alone on a CU spends ~0.9 us per 32-deep chunk on the load -> LDS -> MFMA dependency, whatever the
+//    tile; co-resident workgroups overlap that latency until the CU's MFMA pipe (tm*tn*0.43 us per chunk) is full;
+//  * the grid runs in ceil(WGs / (256 * residency)) rounds;
+//  * split-K adds a zero-fill, f32 atomics (~3e5 elements/us chip-wide) and, when the epilogue is non-linear, a
+//    second elementwise pass.
+// Big shapes (M or K = T*B = 6144) end up on 192-wide tiles with exactly 256 workgroups; small ones on 64x64
+// tiles split until every CU holds several workgroups.
 int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     GemmArgs g = gin;
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.K <= 0) return -1;
-    const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    static int force_cfg = -2, force_split = 0;
+    if (force_cfg == -2) {
+        force_cfg = -1;
+        if (const char* v = std::getenv("INET_GEMM_FORCE")) std::sscanf(v, "%d,%d", &force_cfg, &force_split);
+    }
+    const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    const bool nonlinear = g.epi != EPI_NONE;
     double best = 1e300;
     int bi = 0, bs = 1;
-    for (int ci = 0; ci < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++ci) {
+    for (int ci = 0; ci < kNumCfgs; ++ci) {
         const TileCfg& c = kCfgs[ci];
         const long tiles = (long)((g.M + 64 * c.tm - 1) / (64 * c.tm)) * ((g.N + 64 * c.tn - 1) / (64 * c.tn));
         for (int sp : kSplits) {
-            if (sp > 1 && (g.epi != EPI_NONE || g.K / sp < 256)) break;
+            if (sp > 1 && (g.K / sp < 128 || (nonlinear && g.acc != ACC_STORE))) break;
             const long wgs = tiles * sp;
             const long slots = 256L * c.wgs_per_cu;
             const long rounds = (wgs + slots - 1) / slots;
-            const int conc = (int)((wgs < slots ? (wgs + 255) / 256 : c.wgs_per_cu));      // co-resident WGs per CU
-            const double kk = (double)((g.K + sp - 1) / sp + 64);                            // + fixed prologue/epilogue
-            double cost = rounds * conc * (64.0 * c.tm) * (64.0 * c.tn) * kk / c.eff;
-            if (sp > 1) cost += 0.15 * (double)g.M * g.N * sp / 256.0 * 64.0;                // atomic epilogue traffic
+            const double conc = (double)(wgs < slots ? (wgs + 255) / 256 : c.wgs_per_cu);
+            const double chunks = (double)(((g.K + sp - 1) / sp + 31) / 32);
+            const double t_mfma = c.tm * c.tn * 0.4267 / c.eff;
+            const double lat = 0.9 + 0.1 * (c.tm + c.tn - 2);
+            double cost = rounds * ((chunks * lat > conc * chunks * t_mfma ? chunks * lat : conc * chunks * t_mfma) + 1.5);
+            if (sp > 1) cost += 2.0 + (double)g.M * g.N * sp / 3.0e5 + (nonlinear ? 3.0 : 0.0);
             if (cost < best) { best = cost; bi = ci; bs = sp; }
         }
+    }
+    if (force_cfg >= 0 && force_cfg < kNumCfgs) {
+        bi = force_cfg;
+        bs = (nonlinear && g.acc != ACC_STORE) ? 1 : (force_split > 0 ? force_split : 1);
     }
     const TileCfg& c = kCfgs[bi];
     const int BM = 64 * c.tm, BN = 64 * c.tn;
@@ -270,20 +298,36 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     kps = (kps + 31) / 32 * 32;
     splits = (g.K + kps - 1) / kps;
     g.k_per_split = kps;
+    const bool two_pass = splits > 1 && nonlinear;
     if (splits > 1) {
         if (g.acc == ACC_STORE) {
             if (hipMemset2DAsync(g.C, g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, s) != hipSuccess)
                 return -2;
         }
         g.acc = ACC_ATOMIC;
+        if (two_pass) g.epi = EPI_NONE;
     }
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splits);
-    ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s);
-    switch (bi) {
-        case 0: return launch_cfg<1, 1>(g, grid, s);
-        case 1: return launch_cfg<2, 2>(g, grid, s);
-        case 2: return launch_cfg<3, 1>(g, grid, s);
-        case 3: return launch_cfg<3, 2>(g, grid, s);
-        default: return launch_cfg<3, 3>(g, grid, s);
+    char label[96];
+    std::snprintf(label, sizeof label, "M%d N%d K%d %c%c t%dx%d s%d e%d", g.M, g.N, g.K, g.a_kmajor ? 'T' : 'N',
+                  g.b_kmajor ? 'N' : 'T', 64 * c.tm, 64 * c.tn, splits, gin.epi);
+    int rc;
+    {
+        ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label);
+        switch (bi) {
+            case 0: rc = launch_cfg<1, 1>(g, grid, s); break;
+            case 1: rc = launch_cfg<2, 2>(g, grid, s); break;
+            case 2: rc = launch_cfg<3, 1>(g, grid, s); break;
+            case 3: rc = launch_cfg<3, 2>(g, grid, s); break;
+            default: rc = launch_cfg<3, 3>(g, grid, s); break;
+        }
+        if (rc == 0 && two_pass) {
+            long n = (long)g.M * g.N;
+            int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+            hipLaunchKernelGGL(gemm_epilogue_kernel, dim3(blocks), dim3(256), 0, s, g.C, g.ldc, g.M, g.N, gin.aux,
+                               gin.ldaux, gin.epi);
+            rc = hipGetLastError() == hipSuccess ? 0 : -2;
+        }
     }
+    return rc;
 }

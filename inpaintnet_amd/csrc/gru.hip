@@ -296,6 +296,56 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
     }
 }
 
+// Output projection of one decoder tick, fused: weights[:, t, :] = ReLU(h_top[B,H] x W_out[V,H]^T + b) and the
+// next token = argmax (lowest index on ties).  Same register-streamed K-split as the step kernels; V = 16*NB <= 64.
+template <int NB>
+__global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restrict__ h, long ldh, int B, int H,
+                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            float* __restrict__ out, long ldo,
+                                                            long long* __restrict__ samples, long sstride) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * NB * 512 + 32 * 64];
+    float* stash = lds + 4 * NB * 512;
+    const int t = threadIdx.x;
+    const int row0 = blockIdx.x * TM_ROWS;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int brow[NB], slot[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) { brow[g] = 16 * g; slot[g] = g; }
+    ksplit_segment<NB>(acc, slot, h, ldh, row0, B, W, (long)H, brow, H, t);
+    float v[2][NB];
+    reduce_waves<NB>(acc, lds, t, v);
+    constexpr int V = 16 * NB;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int pos = t + 256 * p;
+        const int r = pos >> 4, c = pos & 15;
+        const int b = row0 + r;
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+            float x = v[p][a] + bias[16 * a + c];
+            x = x > 0.f ? x : 0.f;
+            stash[r * 64 + 16 * a + c] = x;
+            if (b < B) out[(long)b * ldo + 16 * a + c] = x;
+        }
+    }
+    if (samples) {
+        __syncthreads();
+        if (t < TM_ROWS && row0 + t < B) {
+            float m = stash[t * 64];
+            int am = 0;
+            for (int j = 1; j < V; ++j) {
+                const float x = stash[t * 64 + j];
+                if (x > m) { m = x; am = j; }
+            }
+            samples[(long)(row0 + t) * sstride] = am;
+        }
+    }
+}
+
 }  // namespace
 
 int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s) {
@@ -326,5 +376,20 @@ int launch_gru_bwd(const GruBwdBatch& b, hipStream_t s) {
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].dgh_next) fl += 2.0 * b.p[i].B * 3.0 * b.H * b.H;
     ProfScope prof(PROF_GRU_BWD, fl, s);
     hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, s, b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// returns 1 if the fused path does not apply (caller falls back to GEMM + argmax)
+int launch_logits_argmax(const float* h, long ldh, int B, int H, const float* W, const float* bias, int V, float* out,
+                         long ldo, long long* samples, long sstride, hipStream_t s) {
+    if (V % 16 != 0 || V > 64 || H % TH != 0) return 1;
+    dim3 grid((B + TM_ROWS - 1) / TM_ROWS);
+    ProfScope prof(PROF_GEMM, 2.0 * B * V * H, s, "logits_argmax");
+    switch (V / 16) {
+        case 1: hipLaunchKernelGGL(logits_argmax_kernel<1>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
+        case 2: hipLaunchKernelGGL(logits_argmax_kernel<2>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
+        case 3: hipLaunchKernelGGL(logits_argmax_kernel<3>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
+        default: hipLaunchKernelGGL(logits_argmax_kernel<4>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

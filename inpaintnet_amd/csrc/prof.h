@@ -11,6 +11,6 @@ enum { PROF_GEMM = 0, PROF_GRU_FWD = 1, PROF_GRU_BWD = 2, PROF_NCLASS = 3 };
 struct ProfScope {
     int idx;
     hipStream_t s;
-    ProfScope(int cls, double flops, hipStream_t stream);
+    ProfScope(int cls, double flops, hipStream_t stream, const char* label = nullptr);
     ~ProfScope();
 };

@@ -7,6 +7,7 @@
 #pragma once
 #include "common.h"
 #include "pointwise.h"
+#include "side.h"
 
 #define INET_TRY(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
 

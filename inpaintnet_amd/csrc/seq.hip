@@ -178,12 +178,16 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     }
     INET_TRY(gru_layer_bwd(H, B, T, 2, d, s));
     const float* x1 = mask ? w.x1m : w.x1raw;
+    if (wg) {
+        hipStream_t ss = side_fork(s);                       // leaf work: overlaps the layer-0 BPTT chain
+        for (int dir = 0; dir < 2; ++dir) {
+            const float* dgi = w.dgi1 + dir * 3L * H;
+            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[2 + dir], w.sv[2 + dir] + 4 * TBH, P[2 + dir].dw_hh, ss));
+            INET_TRY(linear_wgrad(dgi, 6L * H, x1, 2L * H, P[2 + dir].dw_ih, 2L * H, T * B, 3 * H, 2 * H, ss));
+        }
+    }
     for (int dir = 0; dir < 2; ++dir) {
         const float* dgi = w.dgi1 + dir * 3L * H;
-        if (wg) {
-            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[2 + dir], w.sv[2 + dir] + 4 * TBH, P[2 + dir].dw_hh, s));
-            INET_TRY(linear_wgrad(dgi, 6L * H, x1, 2L * H, P[2 + dir].dw_ih, 2L * H, T * B, 3 * H, 2 * H, s));
-        }
         // dx1 [TB,2H] (+)= dgi1_dir [TB,3H] . W_ih_l1_dir [3H,2H]
         INET_TRY(linear_dgrad(dgi, 6L * H, P[2 + dir].w_ih, 2L * H, w.dx1, 2L * H, T * B, 3 * H, 2 * H, EPI_NONE, nullptr,
                               0, dir == 0 ? ACC_STORE : ACC_ADD, s));
@@ -205,8 +209,10 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.reverse = dir;
     }
     INET_TRY(gru_layer_bwd(H, B, T, 2, d, s));
-    if (wg)
+    if (wg) {
+        hipStream_t ss = side_fork(s);
         for (int dir = 0; dir < 2; ++dir)
-            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[dir], w.sv[dir] + 4 * TBH, P[dir].dw_hh, s));
+            INET_TRY(gru_dir_wgrad(H, B, T, w.dgh[dir], w.sv[dir] + 4 * TBH, P[dir].dw_hh, ss));
+    }
     return 0;
 }

@@ -1,0 +1,58 @@
+#include <cstdlib>
+#include <vector>
+#include "side.h"
+
+namespace {
+hipStream_t g_side = nullptr;
+bool g_init = false;
+int g_enabled = -1;
+bool g_dirty = false;                 // something was queued on the side stream since the last join
+std::vector<hipEvent_t> g_pool;
+size_t g_next = 0;
+
+hipEvent_t next_event() {
+    if (g_pool.empty()) {
+        g_pool.resize(64);
+        for (auto& e : g_pool)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    }
+    hipEvent_t e = g_pool[g_next];
+    g_next = (g_next + 1) % g_pool.size();
+    return e;
+}
+}  // namespace
+
+int side_enabled() {
+    if (g_enabled < 0) {
+        const char* v = std::getenv("INET_SIDE_STREAM");
+        g_enabled = (v && v[0] == '0') ? 0 : 1;
+    }
+    return g_enabled;
+}
+void side_set_enabled(int on) { g_enabled = on ? 1 : 0; }
+
+hipStream_t side_fork(hipStream_t main_stream) {
+    if (!side_enabled()) return main_stream;
+    if (!g_init) {
+        g_init = true;
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) g_side = nullptr;
+    }
+    if (!g_side) return main_stream;
+    hipEvent_t e = next_event();
+    if (!e || hipEventRecord(e, main_stream) != hipSuccess || hipStreamWaitEvent(g_side, e, 0) != hipSuccess)
+        return main_stream;
+    g_dirty = true;
+    return g_side;
+}
+
+int side_join(hipStream_t main_stream) {
+    if (!g_dirty || !g_side) return 0;
+    g_dirty = false;
+    hipEvent_t e = next_event();
+    if (!e) return -2;
+    if (hipEventRecord(e, g_side) != hipSuccess) return -2;
+    if (hipStreamWaitEvent(main_stream, e, 0) != hipSuccess) return -2;
+    return 0;
+}

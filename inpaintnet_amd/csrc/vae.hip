@@ -99,30 +99,36 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
     // heads
     INET_TRY(linear_dgrad(dmu, Z, p + L.mean_w2, 2L * H, w.d_amu, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_mu, 2L * H, ACC_STORE, s));
     INET_TRY(linear_dgrad(dls, Z, p + L.ls_w2, 2L * H, w.d_als, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_ls, 2L * H, ACC_STORE, s));
-    INET_TRY(linear_wgrad(dmu, Z, w.a_mu, 2L * H, g + L.mean_w2, 2L * H, B, Z, 2 * H, s));
-    INET_TRY(linear_wgrad(dls, Z, w.a_ls, 2L * H, g + L.ls_w2, 2L * H, B, Z, 2 * H, s));
-    INET_TRY(pw_colsum(dmu, Z, B, Z, g + L.mean_b2, s));
-    INET_TRY(pw_colsum(dls, Z, B, Z, g + L.ls_b2, s));
     INET_TRY(linear_dgrad(w.d_amu, 2L * H, p + L.mean_w0, 4L * H, w.dhcat, 4L * H, B, 2 * H, 4 * H, EPI_NONE, nullptr, 0, ACC_STORE, s));
     INET_TRY(linear_dgrad(w.d_als, 2L * H, p + L.ls_w0, 4L * H, w.dhcat, 4L * H, B, 2 * H, 4 * H, EPI_NONE, nullptr, 0, ACC_ADD, s));
-    INET_TRY(linear_wgrad(w.d_amu, 2L * H, w.hcat, 4L * H, g + L.mean_w0, 4L * H, B, 2 * H, 4 * H, s));
-    INET_TRY(linear_wgrad(w.d_als, 2L * H, w.hcat, 4L * H, g + L.ls_w0, 4L * H, B, 2 * H, 4 * H, s));
-    INET_TRY(pw_colsum(w.d_amu, 2L * H, B, 2 * H, g + L.mean_b0, s));
-    INET_TRY(pw_colsum(w.d_als, 2L * H, B, 2 * H, g + L.ls_b0, s));
+    {   // leaf work (weight / bias gradients of the heads) on the side stream
+        hipStream_t ss = side_fork(s);
+        INET_TRY(linear_wgrad(dmu, Z, w.a_mu, 2L * H, g + L.mean_w2, 2L * H, B, Z, 2 * H, ss));
+        INET_TRY(linear_wgrad(dls, Z, w.a_ls, 2L * H, g + L.ls_w2, 2L * H, B, Z, 2 * H, ss));
+        INET_TRY(pw_colsum(dmu, Z, B, Z, g + L.mean_b2, ss));
+        INET_TRY(pw_colsum(dls, Z, B, Z, g + L.ls_b2, ss));
+        INET_TRY(linear_wgrad(w.d_amu, 2L * H, w.hcat, 4L * H, g + L.mean_w0, 4L * H, B, 2 * H, 4 * H, ss));
+        INET_TRY(linear_wgrad(w.d_als, 2L * H, w.hcat, 4L * H, g + L.ls_w0, 4L * H, B, 2 * H, 4 * H, ss));
+        INET_TRY(pw_colsum(w.d_amu, 2L * H, B, 2 * H, g + L.mean_b0, ss));
+        INET_TRY(pw_colsum(w.d_als, 2L * H, B, 2 * H, g + L.ls_b0, ss));
+    }
     // GRU stack
     const float* dhn[4] = {w.dhcat, w.dhcat + H, w.dhcat + 2 * H, w.dhcat + 3 * H};
     INET_TRY(bigru2_core_bwd(B, T, H, P, mask, nullptr, dhn, 4L * H, nullptr, w.g, s));
     // embedding / layer-0 input weights through the gather table
-    INET_TRY(pw_onehot(tokens, B, 1, T, T * B, V, w.onehot, 1, s));          // row (t,b) -> tokens[b*T + t]
-    for (int dir = 0; dir < 2; ++dir) {
-        const float* dgi = w.g.dgi0 + dir * 3L * H;
-        // dTable [V,3H] = onehot^T [V,TB] . dgi0 [TB,3H]
-        INET_TRY(launch_gemm(gemm_args(w.onehot, V, 1, dgi, 6L * H, 1, w.dtab, 3L * H, V, 3 * H, T * B), s));
-        // dW_ih_l0 [3H,E] += dTable^T . E_enc ;  dE_enc [V,E] += dTable . W_ih_l0
-        INET_TRY(linear_wgrad(w.dtab, 3L * H, p + L.enc_emb, E, P[dir].dw_ih, E, V, 3 * H, E, s));
-        INET_TRY(linear_dgrad(w.dtab, 3L * H, P[dir].w_ih, E, g + L.enc_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, s));
+    {
+        hipStream_t ss = side_fork(s);
+        INET_TRY(pw_onehot(tokens, B, 1, T, T * B, V, w.onehot, 1, ss));     // row (t,b) -> tokens[b*T + t]
+        for (int dir = 0; dir < 2; ++dir) {
+            const float* dgi = w.g.dgi0 + dir * 3L * H;
+            // dTable [V,3H] = onehot^T [V,TB] . dgi0 [TB,3H]
+            INET_TRY(launch_gemm(gemm_args(w.onehot, V, 1, dgi, 6L * H, 1, w.dtab, 3L * H, V, 3 * H, T * B), ss));
+            // dW_ih_l0 [3H,E] += dTable^T . E_enc ;  dE_enc [V,E] += dTable . W_ih_l0
+            INET_TRY(linear_wgrad(w.dtab, 3L * H, p + L.enc_emb, E, P[dir].dw_ih, E, V, 3 * H, E, ss));
+            INET_TRY(linear_dgrad(w.dtab, 3L * H, P[dir].w_ih, E, g + L.enc_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, ss));
+        }
     }
-    return 0;
+    return side_join(s);
 }
 
 // =====================================================================================
@@ -282,10 +288,15 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         }
         INET_TRY(launch_gru_fwd(b1, s));
 
-        // logits = ReLU(h_top . Wo^T + bo) straight into weights[:, t, :]
-        INET_TRY(linear_fwd(w.h1seq + (long)t * BH, H, p + L.out_w, H, p + L.out_b, weights + (long)t * V, (long)T * V,
-                            B, V, H, EPI_RELU, s));
-        if (!teacher_forced) INET_TRY(pw_argmax(weights + (long)t * V, (long)T * V, B, V, samples + t, T, s));
+        // logits = ReLU(h_top . Wo^T + bo) straight into weights[:, t, :], fused with the argmax that feeds tick t+1
+        int rc = launch_logits_argmax(w.h1seq + (long)t * BH, H, B, H, p + L.out_w, p + L.out_b, V, weights + (long)t * V,
+                                      (long)T * V, teacher_forced ? nullptr : samples + t, T, s);
+        if (rc < 0) return rc;
+        if (rc == 1) {                                         // V not a multiple of 16 (or > 64): two kernels
+            INET_TRY(linear_fwd(w.h1seq + (long)t * BH, H, p + L.out_w, H, p + L.out_b, weights + (long)t * V,
+                                (long)T * V, B, V, H, EPI_RELU, s));
+            if (!teacher_forced) INET_TRY(pw_argmax(weights + (long)t * V, (long)T * V, B, V, samples + t, T, s));
+        }
     }
     return 0;
 }
@@ -304,8 +315,9 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     // ---- output projection ----
     INET_TRY(pw_dlogits_relayout(dweights, weights, B, T, V, w.dlg, s));
     if (g) {
-        INET_TRY(linear_wgrad(w.dlg, V, w.h1seq, H, g + L.out_w, H, T * B, V, H, s));
-        INET_TRY(pw_colsum(w.dlg, V, T * B, V, g + L.out_b, s));
+        hipStream_t ss = side_fork(s);
+        INET_TRY(linear_wgrad(w.dlg, V, w.h1seq, H, g + L.out_w, H, T * B, V, H, ss));
+        INET_TRY(pw_colsum(w.dlg, V, T * B, V, g + L.out_b, ss));
     }
     INET_TRY(linear_dgrad(w.dlg, V, p + L.out_w, H, w.dh1top, H, T * B, V, H, EPI_NONE, nullptr, 0, ACC_STORE, s));
 
@@ -326,8 +338,9 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
     if (g) {
-        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh1t, w.svt1 + 4 * TBH, g + L.tick[1].w_hh, s));
-        INET_TRY(linear_wgrad(w.dgi1t, 3L * H, x1, H, g + L.tick[1].w_ih, H, T * B, 3 * H, H, s));
+        hipStream_t ss = side_fork(s);                       // overlaps the layer-0 BPTT chain below
+        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh1t, w.svt1 + 4 * TBH, g + L.tick[1].w_hh, ss));
+        INET_TRY(linear_wgrad(w.dgi1t, 3L * H, x1, H, g + L.tick[1].w_ih, H, T * B, 3 * H, H, ss));
     }
     INET_TRY(linear_dgrad(w.dgi1t, 3L * H, p + L.tick[1].w_ih, H, w.dx1t, H, T * B, 3 * H, H,
                           mask_tick ? EPI_MUL_AUX : EPI_NONE, mask_tick, H, ACC_STORE, s));
@@ -348,23 +361,26 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* wih0 = p + L.tick[0].w_ih;
     const long ldw0 = E + H;
-    if (g)
-        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, s));
+    if (g) {
+        hipStream_t ss = side_fork(s);
+        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, ss));
+    }
     // beat-constant input half:  dcgi[i] = sum_j dgi0[6i+j]
     INET_TRY(pw_group_sum(w.dgi0t, nb, G, 3 * BH, w.dcgi, s));
     INET_TRY(linear_dgrad(w.dcgi, 3L * H, wih0 + E, ldw0, w.dc_all, H, nb * B, 3 * H, H, EPI_MUL_SELU_GRAD, w.c_all, H,
                           ACC_STORE, s));
     if (g) {
-        INET_TRY(linear_wgrad(w.dcgi, 3L * H, w.c_all, H, g + L.tick[0].w_ih + E, ldw0, nb * B, 3 * H, H, s));
+        hipStream_t ss = side_fork(s);
+        INET_TRY(linear_wgrad(w.dcgi, 3L * H, w.c_all, H, g + L.tick[0].w_ih + E, ldw0, nb * B, 3 * H, H, ss));
         // token-embedding half through the gather table
-        if (hipMemsetAsync(w.onehot, 0, (size_t)T * B * (V + 1) * sizeof(float), s) != hipSuccess) return -2;
-        INET_TRY(pw_onehot(w.idxV, B, 0, 1, B, V + 1, w.onehot, 0, s));                               // t = 0: x_0 row
-        INET_TRY(pw_onehot(tokens_in, B, 1, T, (T - 1) * B, V + 1, w.onehot + (long)B * (V + 1), 0, s));  // t >= 1: token t-1
-        INET_TRY(launch_gemm(gemm_args(w.onehot, V + 1, 1, w.dgi0t, 3L * H, 1, w.dtable, 3L * H, V + 1, 3 * H, T * B), s));
-        INET_TRY(linear_wgrad(w.dtable, 3L * H, p + L.dec_emb, E, g + L.tick[0].w_ih, ldw0, V, 3 * H, E, s));
-        INET_TRY(linear_wgrad(w.dtable + (long)V * 3 * H, 3L * H, p + L.x_0, E, g + L.tick[0].w_ih, ldw0, 1, 3 * H, E, s));
-        INET_TRY(linear_dgrad(w.dtable, 3L * H, wih0, ldw0, g + L.dec_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, s));
-        INET_TRY(linear_dgrad(w.dtable + (long)V * 3 * H, 3L * H, wih0, ldw0, g + L.x_0, E, 1, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, s));
+        if (hipMemsetAsync(w.onehot, 0, (size_t)T * B * (V + 1) * sizeof(float), ss) != hipSuccess) return -2;
+        INET_TRY(pw_onehot(w.idxV, B, 0, 1, B, V + 1, w.onehot, 0, ss));                               // t = 0: x_0 row
+        INET_TRY(pw_onehot(tokens_in, B, 1, T, (T - 1) * B, V + 1, w.onehot + (long)B * (V + 1), 0, ss));  // t >= 1: token t-1
+        INET_TRY(launch_gemm(gemm_args(w.onehot, V + 1, 1, w.dgi0t, 3L * H, 1, w.dtable, 3L * H, V + 1, 3 * H, T * B), ss));
+        INET_TRY(linear_wgrad(w.dtable, 3L * H, p + L.dec_emb, E, g + L.tick[0].w_ih, ldw0, V, 3 * H, E, ss));
+        INET_TRY(linear_wgrad(w.dtable + (long)V * 3 * H, 3L * H, p + L.x_0, E, g + L.tick[0].w_ih, ldw0, 1, 3 * H, E, ss));
+        INET_TRY(linear_dgrad(w.dtable, 3L * H, wih0, ldw0, g + L.dec_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, ss));
+        INET_TRY(linear_dgrad(w.dtable + (long)V * 3 * H, 3L * H, wih0, ldw0, g + L.x_0, E, 1, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, ss));
     }
 
     // ---- beat -> tick linears (decoder.py:494-495) ----
@@ -372,10 +388,11 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     INET_TRY(linear_dgrad(w.dht0, 2L * H, p + L.bh_w, H, w.dbeat_out, H, nb * B, 2 * H, H, EPI_NONE, nullptr, 0, ACC_STORE, s));
     INET_TRY(linear_dgrad(w.dc_all, H, p + L.bi_w, H, w.dbeat_out, H, nb * B, H, H, EPI_NONE, nullptr, 0, ACC_ADD, s));
     if (g) {
-        INET_TRY(linear_wgrad(w.dht0, 2L * H, w.beat_out, H, g + L.bh_w, H, nb * B, 2 * H, H, s));
-        INET_TRY(pw_colsum(w.dht0, 2L * H, nb * B, 2 * H, g + L.bh_b, s));
-        INET_TRY(linear_wgrad(w.dc_all, H, w.beat_out, H, g + L.bi_w, H, nb * B, H, H, s));
-        INET_TRY(pw_colsum(w.dc_all, H, nb * B, H, g + L.bi_b, s));
+        hipStream_t ss = side_fork(s);
+        INET_TRY(linear_wgrad(w.dht0, 2L * H, w.beat_out, H, g + L.bh_w, H, nb * B, 2 * H, H, ss));
+        INET_TRY(pw_colsum(w.dht0, 2L * H, nb * B, 2 * H, g + L.bh_b, ss));
+        INET_TRY(linear_wgrad(w.dc_all, H, w.beat_out, H, g + L.bi_w, H, nb * B, H, H, ss));
+        INET_TRY(pw_colsum(w.dc_all, H, nb * B, H, g + L.bi_b, ss));
     }
 
     // ---- beat RNN ----
@@ -390,8 +407,9 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     if (g) {
-        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh1b, w.svb1 + 4 * nb * BH, g + L.beat[1].w_hh, s));
-        INET_TRY(linear_wgrad(w.dgi1b, 3L * H, xb, H, g + L.beat[1].w_ih, H, nb * B, 3 * H, H, s));
+        hipStream_t ss = side_fork(s);
+        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh1b, w.svb1 + 4 * nb * BH, g + L.beat[1].w_hh, ss));
+        INET_TRY(linear_wgrad(w.dgi1b, 3L * H, xb, H, g + L.beat[1].w_ih, H, nb * B, 3 * H, H, ss));
     }
     INET_TRY(linear_dgrad(w.dgi1b, 3L * H, p + L.beat[1].w_ih, H, w.dxb, H, nb * B, 3 * H, H,
                           mask_beat ? EPI_MUL_AUX : EPI_NONE, mask_beat, H, ACC_STORE, s));
@@ -405,19 +423,21 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     b.dh0 = w.dhb0; b.dh0_ld = 2L * H;
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     if (g) {
-        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh0b, w.svb0 + 4 * nb * BH, g + L.beat[0].w_hh, s));
+        hipStream_t ss = side_fork(s);
+        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh0b, w.svb0 + 4 * nb * BH, g + L.beat[0].w_hh, ss));
         // gi = b_0 * W_ih[:,0] + b_ih
-        if (hipMemsetAsync(w.tmp3h, 0, 3 * H * sizeof(float), s) != hipSuccess) return -2;
-        INET_TRY(pw_colsum(w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h, s));
-        INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H, s));
+        if (hipMemsetAsync(w.tmp3h, 0, 3 * H * sizeof(float), ss) != hipSuccess) return -2;
+        INET_TRY(pw_colsum(w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h, ss));
+        INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H, ss));
     }
 
     // ---- z -> beat hidden ----
     INET_TRY(pw_mul(w.dhb0, w.hb0, 2 * BH, 1, s));
     if (dz) INET_TRY(linear_dgrad(w.dhb0, 2L * H, p + L.zb_w, Z, dz, Z, B, 2 * H, Z, EPI_NONE, nullptr, 0, ACC_STORE, s));
     if (g) {
-        INET_TRY(linear_wgrad(w.dhb0, 2L * H, w.zsave, Z, g + L.zb_w, Z, B, 2 * H, Z, s));
-        INET_TRY(pw_colsum(w.dhb0, 2L * H, B, 2 * H, g + L.zb_b, s));
+        hipStream_t ss = side_fork(s);
+        INET_TRY(linear_wgrad(w.dhb0, 2L * H, w.zsave, Z, g + L.zb_w, Z, B, 2 * H, Z, ss));
+        INET_TRY(pw_colsum(w.dhb0, 2L * H, B, 2 * H, g + L.zb_b, ss));
     }
-    return 0;
+    return side_join(s);
 }

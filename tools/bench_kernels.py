@@ -57,4 +57,8 @@ if __name__ == "__main__":
     gemm_case(256, 1024, 2048, 0, 0, "enc head (NT)")
     gemm_case(256, 48, 512, 0, 0, "logits (NT)")
     gemm_case(48, 1536, 6144, 1, 1, "dTable (TN)")
+    gemm_case(1024, 512, 1536, 0, 1, "beat dgrad (NN)")
+    gemm_case(1024, 2048, 256, 1, 1, "small wgrad (TN)")
+    gemm_case(256, 1024, 256, 0, 1, "head dgrad (NN)")
+    gemm_case(1536, 512, 1024, 1, 1, "beat dW (TN)")
     gemm_case(4096, 4096, 4096, 0, 0, "square (NT)")
