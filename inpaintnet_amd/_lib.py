@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinpaintnet_hip.so")
+LIB_PATH = os.environ.get("INET_LIB_PATH") or os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip"]
 

@@ -35,7 +35,6 @@ namespace {
 
 constexpr int TM_ROWS = 32;   // batch rows per workgroup
 constexpr int TH = 16;        // hidden units per workgroup
-constexpr int GD = 4;         // k-steps (of 16) per pipeline group
 
 // Fragments of one k-step (16 k) for this wave: A rows (2 sub-tiles of 16), NB groups of 16 B rows.
 template <int NB>
@@ -90,6 +89,64 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[2][4], const int (&slot)[N
 }
 
 // acc[ms][slot[g]] += A[32 rows, this wave's K quarter] * Bg[16 rows, same K]^T
+//
+// Issue order is the whole game here (measured on the B=256,H=512 step, profiles/r01_c): a wave issues in order, so
+// a load placed behind an MFMA that waits on vmcnt is not even REQUESTED until that data is back.  The fast path
+// therefore puts every load of a group in front of the group's first MFMA (sched_barrier pins it) and makes the
+// group as deep as the register file allows: up to 8 k-steps (40 x 16-byte loads per lane for the forward step)
+// in flight before the first MFMA; a second group is kept in flight only when K is longer than that.
+template <int NB, int GDEPTH>
+__device__ __forceinline__ void ksplit_fast(f32x4 (&acc)[2][4], const int (&slot)[NB], const float* __restrict__ A,
+                                            long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
+                                            const int (&brow)[NB], int K, int s_beg, int s_end, int i16, int q) {
+    Frag<NB> f0[GDEPTH], f1[GDEPTH];
+#pragma unroll
+    for (int d = 0; d < GDEPTH; ++d) load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
+    for (int s = s_beg; s < s_end; s += 2 * GDEPTH) {
+        const bool more1 = s + GDEPTH < s_end, more2 = s + 2 * GDEPTH < s_end;     // wave-uniform
+        if (more1) {
+#pragma unroll
+            for (int d = 0; d < GDEPTH; ++d)
+                load_step<NB, false>(f1[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + GDEPTH + d, i16, q);
+        }
+#ifndef INET_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int d = 0; d < GDEPTH; ++d) mma_step<NB>(acc, slot, f0[d]);
+#ifndef INET_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (more2) {
+#pragma unroll
+            for (int d = 0; d < GDEPTH; ++d)
+                load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + 2 * GDEPTH + d, i16, q);
+        }
+#ifndef INET_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (more1) {
+#pragma unroll
+            for (int d = 0; d < GDEPTH; ++d) mma_step<NB>(acc, slot, f1[d]);
+        }
+#ifndef INET_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+// single group: the wave's whole K range (<= 8 k-steps) is requested before the first MFMA
+template <int NB>
+__device__ __forceinline__ void ksplit_once8(f32x4 (&acc)[2][4], const int (&slot)[NB], const float* __restrict__ A,
+                                             long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
+                                             const int (&brow)[NB], int K, int s_beg, int i16, int q) {
+    Frag<NB> f[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) load_step<NB, false>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) mma_step<NB>(acc, slot, f[d]);
+}
+
 template <int NB>
 __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[2][4], const int (&slot)[NB],
                                                const float* __restrict__ A, long lda, int row0, int rowsA,
@@ -99,27 +156,13 @@ __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[2][4], const int (&s
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform -> scalar loop control
     const int i16 = lane & 15, q = lane >> 4;
     const int S = (K + 15) >> 4;                   // k-steps of 16
-    if ((K & 511) == 0) {
-        // fast path: each wave owns S/4 = multiple of 8 steps; two groups of GD steps in flight, no guards
+    if (K == 512) {
+        ksplit_once8<NB>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * 8, i16, q);
+    } else if ((K & 511) == 0) {
+        // each wave owns S/4 = multiple of 8 steps
         const int Sq = S >> 2;
-        const int s_beg = w * Sq, s_end = s_beg + Sq;
-        Frag<NB> f0[GD], f1[GD];
-#pragma unroll
-        for (int d = 0; d < GD; ++d) load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
-        for (int s = s_beg; s < s_end; s += 2 * GD) {
-#pragma unroll
-            for (int d = 0; d < GD; ++d)
-                load_step<NB, false>(f1[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + GD + d, i16, q);
-#pragma unroll
-            for (int d = 0; d < GD; ++d) mma_step<NB>(acc, slot, f0[d]);
-            if (s + 2 * GD < s_end) {
-#pragma unroll
-                for (int d = 0; d < GD; ++d)
-                    load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + 2 * GD + d, i16, q);
-            }
-#pragma unroll
-            for (int d = 0; d < GD; ++d) mma_step<NB>(acc, slot, f1[d]);
-        }
+        constexpr int GDEPTH = NB == 1 ? 8 : 4;
+        ksplit_fast<NB, GDEPTH>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q);
     } else {
         // general path (small / odd K): guarded loads, one step at a time
         const int Sq = (S + 3) >> 2;
@@ -165,6 +208,7 @@ template <bool HAS_X>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 512];
     const GruFwdProb& P = bt.p[blockIdx.z];
+    warm_kernarg(&P, sizeof(GruFwdProb));
     const int H = bt.H;
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * TH;
@@ -230,6 +274,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 512];
     const GruBwdProb& P = bt.p[blockIdx.z];
+    warm_kernarg(&P, sizeof(GruBwdProb));
     const int H = bt.H;
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * TH;
