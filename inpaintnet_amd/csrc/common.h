@@ -88,7 +88,7 @@ struct GruFwdProb {
     // saved for backward (all [B,H], row stride H), or null
     float* sv_r; float* sv_z; float* sv_n; float* sv_ghn; float* sv_hprev;
 };
-struct GruFwdBatch { int H; int nprob; GruFwdProb p[4]; };
+struct GruFwdBatch { int H; int nprob; int tiles_per_prob; GruFwdProb p[4]; };
 
 struct GruBwdProb {
     int B;
@@ -107,7 +107,7 @@ struct GruBwdProb {
     float* dh_out; long ld_dhout;             // [B,H] (only when no pointwise part): gradient wrt the initial hidden
     int dh_out_accumulate;
 };
-struct GruBwdBatch { int H; int nprob; GruBwdProb p[4]; };
+struct GruBwdBatch { int H; int nprob; int tiles_per_prob; GruBwdProb p[4]; };
 
 // host-side launchers (defined in the .hip files)
 int launch_gemm(const GemmArgs& g, hipStream_t s);

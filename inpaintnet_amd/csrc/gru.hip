@@ -33,13 +33,13 @@
 
 namespace {
 
-constexpr int TM_ROWS = 32;   // batch rows per workgroup
+constexpr int TM_ROWS = 32;   // batch rows per workgroup of the base (MS = 2) geometry
 constexpr int TH = 16;        // hidden units per workgroup
 
-// Fragments of one k-step (16 k) for this wave: A rows (2 sub-tiles of 16), NB groups of 16 B rows.
-template <int NB>
+// Fragments of one k-step (16 k) for this wave: MS sub-tiles of 16 A rows, NB groups of 16 B rows.
+template <int MS, int NB>
 struct Frag {
-    f32x4 a[2];
+    f32x4 a[MS];
     f32x4 b[NB];
 };
 
@@ -47,13 +47,13 @@ struct Frag {
 // A rows past the batch are clamped, not zeroed: they only feed output rows that are never stored.
 // (Per-lane "load or zero" guards make hipcc wrap each load in an exec-mask branch and wait vmcnt(0) per
 // element -- the round trips serialise; the guarded form is kept only for K not a multiple of 512.)
-template <int NB, bool GUARD>
-__device__ __forceinline__ void load_step(Frag<NB>& f, const float* __restrict__ A, long lda, int row0, int rowsA,
+template <int MS, int NB, bool GUARD>
+__device__ __forceinline__ void load_step(Frag<MS, NB>& f, const float* __restrict__ A, long lda, int row0, int rowsA,
                                           const float* __restrict__ Bm, long ldb, const int (&brow)[NB], int K, int s,
                                           int i16, int q) {
     const int k = 16 * s + 4 * q;
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
+    for (int ms = 0; ms < MS; ++ms) {
         const int row = min(row0 + 16 * ms + i16, rowsA - 1);
         const float* p = A + (long)row * lda + k;
         if (!GUARD) f.a[ms] = ld4u(p);
@@ -77,78 +77,66 @@ __device__ __forceinline__ void load_step(Frag<NB>& f, const float* __restrict__
     }
 }
 
-template <int NB>
-__device__ __forceinline__ void mma_step(f32x4 (&acc)[2][4], const int (&slot)[NB], const Frag<NB>& f) {
+template <int MS, int NB>
+__device__ __forceinline__ void mma_step(f32x4 (&acc)[MS][4], const int (&slot)[NB], const Frag<MS, NB>& f) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int g = 0; g < NB; ++g)
                 acc[ms][slot[g]] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ms][e], f.b[g][e], acc[ms][slot[g]], 0, 0, 0);
 }
 
-// acc[ms][slot[g]] += A[32 rows, this wave's K quarter] * Bg[16 rows, same K]^T
+// acc[ms][slot[g]] += A[16*MS rows, this wave's K quarter] * Bg[16 rows, same K]^T
 //
-// Issue order is the whole game here (measured on the B=256,H=512 step, profiles/r01_c): a wave issues in order, so
-// a load placed behind an MFMA that waits on vmcnt is not even REQUESTED until that data is back.  The fast path
-// therefore puts every load of a group in front of the group's first MFMA (sched_barrier pins it) and makes the
-// group as deep as the register file allows: up to 8 k-steps (40 x 16-byte loads per lane for the forward step)
-// in flight before the first MFMA; a second group is kept in flight only when K is longer than that.
-template <int NB, int GDEPTH>
-__device__ __forceinline__ void ksplit_fast(f32x4 (&acc)[2][4], const int (&slot)[NB], const float* __restrict__ A,
+// Issue order is the whole game here (profiles/r01_c): a wave issues in order, so a load placed behind an MFMA that
+// waits on vmcnt is not even REQUESTED until that data is back.  The paths below therefore request as much of the
+// wave's K range as the register file allows before the first MFMA: all of it when K = 512 (8 k-steps, 40 x 16-byte
+// loads per lane for the forward step), otherwise two groups of GDEPTH k-steps kept in flight.
+template <int MS, int NB, int GDEPTH>
+__device__ __forceinline__ void ksplit_fast(f32x4 (&acc)[MS][4], const int (&slot)[NB], const float* __restrict__ A,
                                             long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
                                             const int (&brow)[NB], int K, int s_beg, int s_end, int i16, int q) {
-    Frag<NB> f0[GDEPTH], f1[GDEPTH];
+    Frag<MS, NB> f0[GDEPTH], f1[GDEPTH];
 #pragma unroll
-    for (int d = 0; d < GDEPTH; ++d) load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
+    for (int d = 0; d < GDEPTH; ++d)
+        load_step<MS, NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
     for (int s = s_beg; s < s_end; s += 2 * GDEPTH) {
         const bool more1 = s + GDEPTH < s_end, more2 = s + 2 * GDEPTH < s_end;     // wave-uniform
         if (more1) {
 #pragma unroll
             for (int d = 0; d < GDEPTH; ++d)
-                load_step<NB, false>(f1[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + GDEPTH + d, i16, q);
+                load_step<MS, NB, false>(f1[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + GDEPTH + d, i16, q);
         }
-#ifndef INET_NO_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
-        for (int d = 0; d < GDEPTH; ++d) mma_step<NB>(acc, slot, f0[d]);
-#ifndef INET_NO_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f0[d]);
         if (more2) {
 #pragma unroll
             for (int d = 0; d < GDEPTH; ++d)
-                load_step<NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + 2 * GDEPTH + d, i16, q);
+                load_step<MS, NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + 2 * GDEPTH + d, i16, q);
         }
-#ifndef INET_NO_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (more1) {
 #pragma unroll
-            for (int d = 0; d < GDEPTH; ++d) mma_step<NB>(acc, slot, f1[d]);
+            for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f1[d]);
         }
-#ifndef INET_NO_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 }
 
-// single group: the wave's whole K range (<= 8 k-steps) is requested before the first MFMA
-template <int NB>
-__device__ __forceinline__ void ksplit_once8(f32x4 (&acc)[2][4], const int (&slot)[NB], const float* __restrict__ A,
+// single group: the wave's whole K range (8 k-steps) is requested before the first MFMA
+template <int MS, int NB>
+__device__ __forceinline__ void ksplit_once8(f32x4 (&acc)[MS][4], const int (&slot)[NB], const float* __restrict__ A,
                                              long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
                                              const int (&brow)[NB], int K, int s_beg, int i16, int q) {
-    Frag<NB> f[8];
+    Frag<MS, NB> f[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) load_step<NB, false>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
+    for (int d = 0; d < 8; ++d) load_step<MS, NB, false>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) mma_step<NB>(acc, slot, f[d]);
+    for (int d = 0; d < 8; ++d) mma_step<MS, NB>(acc, slot, f[d]);
 }
 
-template <int NB>
-__device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[2][4], const int (&slot)[NB],
+template <int MS, int NB>
+__device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[MS][4], const int (&slot)[NB],
                                                const float* __restrict__ A, long lda, int row0, int rowsA,
                                                const float* __restrict__ Bm, long ldb, const int (&brow)[NB],
                                                int K, int t) {
@@ -156,84 +144,87 @@ __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[2][4], const int (&s
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform -> scalar loop control
     const int i16 = lane & 15, q = lane >> 4;
     const int S = (K + 15) >> 4;                   // k-steps of 16
-    if (K == 512) {
-        ksplit_once8<NB>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * 8, i16, q);
+    constexpr int FR = MS + NB;                    // float4 fragment registers per k-step
+    if (K == 512 && FR <= 7) {
+        ksplit_once8<MS, NB>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * 8, i16, q);
     } else if ((K & 511) == 0) {
         // each wave owns S/4 = multiple of 8 steps
         const int Sq = S >> 2;
-        constexpr int GDEPTH = NB == 1 ? 8 : 4;
-        ksplit_fast<NB, GDEPTH>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q);
+        constexpr int GDEPTH = FR <= 3 ? 8 : 4;
+        ksplit_fast<MS, NB, GDEPTH>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q);
     } else {
         // general path (small / odd K): guarded loads, one step at a time
         const int Sq = (S + 3) >> 2;
         const int s_beg = w * Sq;
         const int s_end = min(S, s_beg + Sq);
         for (int s = s_beg; s < s_end; ++s) {
-            Frag<NB> f;
-            load_step<NB, true>(f, A, lda, row0, rowsA, Bm, ldb, brow, K, s, i16, q);
-            mma_step<NB>(acc, slot, f);
+            Frag<MS, NB> f;
+            load_step<MS, NB, true>(f, A, lda, row0, rowsA, Bm, ldb, brow, K, s, i16, q);
+            mma_step<MS, NB>(acc, slot, f);
         }
     }
 }
 
-// Cross-wave reduction: every wave dumps its partial accumulators, then thread t
-// owns output positions t and t+256 of the 32x16 tile (pos = row*16 + col) for
-// all NACC accumulators.  C/D map of the 16x16 MFMA: col = lane&15,
-// row = 4*(lane>>4) + reg.
-template <int NACC>
-__device__ __forceinline__ void reduce_waves(const f32x4 (&acc)[2][4], float* red, int t, float (&out)[2][NACC]) {
+// Cross-wave reduction: every wave dumps its partial accumulators, then thread t owns output positions
+// t + 256*p (p < MS) of the (16*MS) x 16 tile (pos = row*16 + col) for all NACC accumulators.
+// C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg.
+template <int MS, int NACC>
+__device__ __forceinline__ void reduce_waves(const f32x4 (&acc)[MS][4], float* red, int t, float (&out)[MS][NACC]) {
     const int lane = t & 63, w = t >> 6;
+    constexpr int TILE = MS * 256;
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
+    for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ms + 4 * (lane >> 4) + r;
-                red[(w * NACC + a) * 512 + row * 16 + (lane & 15)] = acc[ms][a][r];
+                red[(w * NACC + a) * TILE + row * 16 + (lane & 15)] = acc[ms][a][r];
             }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < MS; ++p)
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) s += red[(ww * NACC + a) * 512 + t + 256 * p];
+            for (int ww = 0; ww < 4; ++ww) s += red[(ww * NACC + a) * TILE + t + 256 * p];
             out[p][a] = s;
         }
 }
 
-template <bool HAS_X>
+// Row tiles are numbered over the concatenated problems: blockIdx.y = problem * tiles_per_prob + tile.
+template <bool HAS_X, int MS>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 512];
-    const GruFwdProb& P = bt.p[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) float lds[4 * 4 * MS * 256];
+    const int prob = blockIdx.y / bt.tiles_per_prob;
+    const GruFwdProb& P = bt.p[prob];
     warm_kernarg(&P, sizeof(GruFwdProb));
     const int H = bt.H;
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * TH;
-    const int row0 = blockIdx.y * TM_ROWS;
+    const int row0 = (blockIdx.y % bt.tiles_per_prob) * (16 * MS);
     if (row0 >= P.B) return;
 
-    f32x4 acc[2][4];
+    f32x4 acc[MS][4];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
+    for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int brow[3] = {j0, H + j0, 2 * H + j0};
     if (HAS_X) {
         const int slotx[3] = {0, 1, 2};          // r, z, gi_n
-        ksplit_segment<3>(acc, slotx, P.x, P.ldx, row0, P.B, P.W_ih, P.ld_wih, brow, P.K2, t);
+        ksplit_segment<MS, 3>(acc, slotx, P.x, P.ldx, row0, P.B, P.W_ih, P.ld_wih, brow, P.K2, t);
     }
     const int sloth[3] = {0, 1, 3};              // r, z, gh_n
-    ksplit_segment<3>(acc, sloth, P.h_prev, P.ld_hprev, row0, P.B, P.W_hh, (long)H, brow, H, t);
+    ksplit_segment<MS, 3>(acc, sloth, P.h_prev, P.ld_hprev, row0, P.B, P.W_hh, (long)H, brow, H, t);
 
-    float v[2][4];
-    reduce_waves<4>(acc, lds, t, v);
+    float v[MS][4];
+    reduce_waves<MS, 4>(acc, lds, t, v);
 
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < MS; ++p) {
         const int pos = t + 256 * p;
         const int b = row0 + (pos >> 4);
         const int j = j0 + (pos & 15);
@@ -271,31 +262,35 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 //   dn_pre = dn (1-n^2); dz_pre = dz z(1-z); dr_pre = dn_pre ghn r(1-r)
 //   dgi = [dr_pre, dz_pre, dn_pre]      dgh = [dr_pre, dz_pre, dn_pre r]
 //   db_ih += colsum(dgi) ; db_hh += colsum(dgh)               (tile-reduced, one atomic per column per workgroup)
+template <int MS>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 512];
-    const GruBwdProb& P = bt.p[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) float lds[(4 * MS * 256 > 1024) ? 4 * MS * 256 : 1024];
+    const int prob = blockIdx.y / bt.tiles_per_prob;
+    const GruBwdProb& P = bt.p[prob];
     warm_kernarg(&P, sizeof(GruBwdProb));
     const int H = bt.H;
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * TH;
-    const int row0 = blockIdx.y * TM_ROWS;
+    const int row0 = (blockIdx.y % bt.tiles_per_prob) * (16 * MS);
     if (row0 >= P.B) return;
 
-    float v[2][1] = {{0.f}, {0.f}};
-    if (P.dgh_next) {
-        f32x4 acc[2][4];
+    float v[MS][1];
 #pragma unroll
-        for (int ms = 0; ms < 2; ++ms)
+    for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
+    if (P.dgh_next) {
+        f32x4 acc[MS][4];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int brow[1] = {j0};
         const int slot[1] = {0};
-        ksplit_segment<1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t);
-        reduce_waves<1>(acc, lds, t, v);
+        ksplit_segment<MS, 1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t);
+        reduce_waves<MS, 1>(acc, lds, t, v);
     }
     float bs[4] = {0.f, 0.f, 0.f, 0.f};            // this thread's column partials: dr, dz, dn, dn*r
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < MS; ++p) {
         const int pos = t + 256 * p;
         const int b = row0 + (pos >> 4);
         const int j = j0 + (pos & 15);
@@ -322,7 +317,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
         bs[0] += dr_pre; bs[1] += dz_pre; bs[2] += dn_pre; bs[3] += dn_pre * r;
     }
     if (P.sv_r && P.db_ih) {
-        // thread t holds column (t & 15) for rows (t >> 4) and (t >> 4) + 16: reduce the 16 row-threads per column
+        // thread t holds column (t & 15) for rows (t >> 4) + 16p: reduce the 16 row-threads per column
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 4; ++a) lds[a * 256 + t] = bs[a];
@@ -360,9 +355,9 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restr
     int brow[NB], slot[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) { brow[g] = 16 * g; slot[g] = g; }
-    ksplit_segment<NB>(acc, slot, h, ldh, row0, B, W, (long)H, brow, H, t);
+    ksplit_segment<2, NB>(acc, slot, h, ldh, row0, B, W, (long)H, brow, H, t);
     float v[2][NB];
-    reduce_waves<NB>(acc, lds, t, v);
+    reduce_waves<2, NB>(acc, lds, t, v);
     constexpr int V = 16 * NB;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -391,9 +386,22 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restr
     }
 }
 
+// Rows per workgroup = 16*MS.  One problem of B=256 fills the chip with MS=2 (256 workgroups).  With 2 or 4 problems
+// per launch (directions, beats) the per-CU L2->L1 load path is the limit (~32 GB/s per CU measured), so bigger row
+// tiles are used to keep ~256 workgroups while loading each W slice once per 64 / 128 rows instead of per 32.
+int pick_ms(int nprob, int maxB, int H, int ms_max) {
+    int ms = 2;
+    for (int cand = 4; cand <= ms_max; cand *= 2) {
+        const long wgs = (long)nprob * ((maxB + 16 * cand - 1) / (16 * cand)) * (H / TH);
+        if (wgs >= 256) ms = cand;
+    }
+    return ms;
+}
+
 }  // namespace
 
-int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s) {
+int launch_gru_fwd(const GruFwdBatch& bin, hipStream_t s) {
+    GruFwdBatch b = bin;
     if (b.H % TH != 0 || b.nprob < 1 || b.nprob > 4) return -1;
     int maxB = 0;
     bool hasx = b.p[0].x != nullptr;
@@ -402,25 +410,37 @@ int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s) {
         if ((b.p[i].x != nullptr) != hasx) return -1;
     }
     if (maxB <= 0) return 0;
-    dim3 grid(b.H / TH, (maxB + TM_ROWS - 1) / TM_ROWS, b.nprob);
+    const int ms = pick_ms(b.nprob, maxB, b.H, 4);
+    b.tiles_per_prob = (maxB + 16 * ms - 1) / (16 * ms);
+    dim3 grid(b.H / TH, b.tiles_per_prob * b.nprob, 1);
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) fl += 2.0 * b.p[i].B * 3.0 * b.H * (b.H + (hasx ? b.p[i].K2 : 0));
     ProfScope prof(PROF_GRU_FWD, fl, s);
-    if (hasx) hipLaunchKernelGGL(gru_step_fwd_kernel<true>, grid, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL(gru_step_fwd_kernel<false>, grid, dim3(256), 0, s, b);
+    if (hasx) {
+        if (ms == 2) hipLaunchKernelGGL((gru_step_fwd_kernel<true, 2>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((gru_step_fwd_kernel<true, 4>), grid, dim3(256), 0, s, b);
+    } else {
+        if (ms == 2) hipLaunchKernelGGL((gru_step_fwd_kernel<false, 2>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((gru_step_fwd_kernel<false, 4>), grid, dim3(256), 0, s, b);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int launch_gru_bwd(const GruBwdBatch& b, hipStream_t s) {
+int launch_gru_bwd(const GruBwdBatch& bin, hipStream_t s) {
+    GruBwdBatch b = bin;
     if (b.H % TH != 0 || b.nprob < 1 || b.nprob > 4) return -1;
     int maxB = 0;
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].B > maxB) maxB = b.p[i].B;
     if (maxB <= 0) return 0;
-    dim3 grid(b.H / TH, (maxB + TM_ROWS - 1) / TM_ROWS, b.nprob);
+    const int ms = pick_ms(b.nprob, maxB, b.H, 8);
+    b.tiles_per_prob = (maxB + 16 * ms - 1) / (16 * ms);
+    dim3 grid(b.H / TH, b.tiles_per_prob * b.nprob, 1);
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].dgh_next) fl += 2.0 * b.p[i].B * 3.0 * b.H * b.H;
     ProfScope prof(PROF_GRU_BWD, fl, s);
-    hipLaunchKernelGGL(gru_step_bwd_kernel, grid, dim3(256), 0, s, b);
+    if (ms == 2) hipLaunchKernelGGL(gru_step_bwd_kernel<2>, grid, dim3(256), 0, s, b);
+    else if (ms == 4) hipLaunchKernelGGL(gru_step_bwd_kernel<4>, grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(gru_step_bwd_kernel<8>, grid, dim3(256), 0, s, b);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

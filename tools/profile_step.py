@@ -41,7 +41,7 @@ ops.prof_enable(False)
 rows = list(csv.DictReader(open(out)))
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for r in rows:
-    k = (r["class"], r["label"])
+    k = (r["class"], r["label"] if r["class"] == "0" else "gflop=%.2f" % float(r["gflop"]))
     agg[k][0] += 1; agg[k][1] += float(r["us"]); agg[k][2] += float(r["gflop"])
 tot = sum(v[1] for v in agg.values())
 print(f"total {tot:.0f} us in {len(rows)} MFMA-class launches (free-running step)")
