@@ -62,6 +62,39 @@ def cpu_baseline(batch, max_seconds=25.0):
                       f"{threads} threads of {cores} host cores)"}
 
 
+def latent_rnn_extra(ds, vae, dev, batch=128, steps=10, warmup=3):
+    """Secondary number (BASELINE.json configs[2]): LatentRNN training with the frozen MeasureVAE, 16-measure
+    sequences, past/target/future = 6/4/6, batch 128 sequences, one GPU.  Not the headline metric."""
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.latent_rnn import LatentRNN
+    from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
+    model = LatentRNN(ds, vae, num_rnn_layers=2, rnn_hidden_size=512, dropout=0.5, rnn_class=torch.nn.GRU,
+                      auto_reg=False, teacher_forcing=True)
+    trainer = LatentRNNTrainer(ds, model, lr=1e-4)
+    model.train()
+    score = torch.from_numpy(synthetic.folk_score(batch, NUM_NOTES, seed=9))
+    past, future, target = LatentRNNTrainer.split_score(score, 6, 6, 4, 24)
+
+    def step():
+        trainer.zero_grad()
+        loss, acc = trainer.loss_and_acc_for_batch((past, future, target), 0, train=True)
+        loss.backward()
+        trainer.step()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"latent_rnn_train": {"sequences_per_s": round(batch * steps / dt, 1),
+                                 "measures_per_s": round(16 * batch * steps / dt, 1),
+                                 "ms_per_step": round(1e3 * dt / steps, 3),
+                                 "workload": "LatentRNN (non-AR) + frozen MeasureVAE, 128 sequences x 16 measures, "
+                                             "past/target/future 6/4/6, dropout 0.5"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,6 +186,9 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = latent_rnn_extra(ds, model, dev)
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -176,6 +213,7 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "extras": extras,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -58,12 +58,33 @@ def broadcast_params(flat, src=0):
         torch.distributed.broadcast(flat, src=src)
 
 
+_pending = []        # [(start, stop, work handle)] buckets of the arena already being summed
+
+
+def start_bucket(grad, start, stop):
+    """Begin summing grad[start:stop] over ranks asynchronously (RCCL runs on its own stream, ordered after the
+    work already queued on the current stream).  Called as soon as a contiguous part of the arena is final --
+    the decoder's gradients are complete while the encoder is still back-propagating -- so that part of the
+    exchange hides behind the rest of backward.  No-op for a single process."""
+    if world_size() > 1 and stop > start:
+        work = torch.distributed.all_reduce(grad[start:stop], op=torch.distributed.ReduceOp.SUM, async_op=True)
+        _pending.append((start, stop, work))
+
+
 def allreduce_grads(grad):
-    """Sum the flat gradient arena over ranks in one collective; returns the scale (1/world) the optimizer
-    kernel applies to it."""
+    """Sum the (rest of the) flat gradient arena over ranks and wait for the buckets started earlier; returns the
+    scale (1/world) the optimizer kernel applies to it."""
     w = world_size()
     if w > 1:
-        torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM)
+        done = sorted((a, b) for a, b, _ in _pending)
+        pos = 0
+        for a, b in done + [(grad.numel(), grad.numel())]:
+            if a > pos:
+                torch.distributed.all_reduce(grad[pos:a], op=torch.distributed.ReduceOp.SUM)
+            pos = max(pos, b)
+        for _, _, work in _pending:
+            work.wait()
+    _pending.clear()
     return 1.0 / w
 
 

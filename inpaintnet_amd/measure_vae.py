@@ -13,7 +13,7 @@ import random
 import torch
 from torch import distributions
 
-from . import ops
+from . import dp, ops
 from .model import Model, default_device
 
 _mask_counter = [0]
@@ -71,6 +71,9 @@ class _DecoderFn(torch.autograd.Function):
         dz = ops.decoder_bwd(dec.cfg, dweights.contiguous(), weights, samples, dec.owner.flat, grads, ctx.mb, ctx.mt,
                              ctx.ws, need_dz=ctx.needs_input_grad[0])
         ctx.ws = None
+        if grads is not None:
+            # data parallel: the decoder half of the arena is final now -> start its all-reduce under the encoder's backward
+            dp.start_bucket(grads, dec.owner.decoder_arena_start, grads.numel())
         return dz, None, None, None, None, None, None
 
 
@@ -270,6 +273,7 @@ class MeasureVAE(Model):
                                   decoder_hidden_size, self.num_beats_per_measure, self.num_ticks_per_beat)
         table, total = ops.vae_param_table(self.cfg)
         self._alloc_arena(table, total, device or default_device())
+        self.decoder_arena_start = min(off for name, off, _ in table if name.startswith("decoder."))
         self._flat_leaf = None
         self.encoder = Encoder(self, "encoder", note_embedding_dim, encoder_hidden_size, num_encoder_layers,
                                self.num_notes, encoder_dropout_prob, True, latent_space_dim, torch.nn.GRU)

@@ -54,6 +54,9 @@ def _worker(rank, world, port, out_dir):
     else:
         flat_b = flat.clone()
     dp.broadcast_params(flat_b, src=0)
+    # bucketed exchange: the tail of the arena starts early (as the decoder's gradients do), the rest at step()
+    cut = (flat.numel() // 3) // 4 * 4
+    dp.start_bucket(flat, cut, flat.numel())
     gscale = dp.allreduce_grads(flat)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), grad=(flat * gscale).numpy(), coins=np.array(coins),
              split=np.array(split), loss=loss, bcast=flat_b.numpy(), lo=lo, hi=hi)
