@@ -89,3 +89,26 @@ def arena_offsets(shapes):
         out[k] = (off, tuple(s))
         off += (numel(s) + 3) // 4 * 4
     return out, off
+
+
+def arnn_param_shapes(num_notes, note_emb=10, meta_emb=2, hidden=256, linear_hidden=256, num_layers=2,
+                      meta_values=(6, 6, 1)):
+    """ConstraintModelGaussianReg state_dict (anticipation_rnn_gauss_reg_model.py:72-140), single voice,
+    unary_constraint=True: the note embedding has one extra 'no constraint' row."""
+    V, E, Em, H = num_notes, note_emb, meta_emb, hidden
+    p = [("note_embeddings.0.weight", (V + 1, E))]
+    for i, n in enumerate(meta_values):
+        p.append((f"metadata_embeddings.{i}.weight", (n, Em)))
+
+    def lstm(prefix, k_in):
+        return [(f"{prefix}.weight_ih_l0", (4 * H, k_in)), (f"{prefix}.weight_hh_l0", (4 * H, H)),
+                (f"{prefix}.bias_ih_l0", (4 * H,)), (f"{prefix}.bias_hh_l0", (4 * H,))]
+    for l in range(num_layers):
+        p += lstm(f"lstm_constraint.{l}", Em * len(meta_values) + E if l == 0 else H)
+    for l in range(num_layers):
+        p += lstm(f"lstm_generation.{l}", E + H if l == 0 else H)
+    p.append(("linear_1.weight", (linear_hidden, H)))
+    p.append(("linear_1.bias", (linear_hidden,)))
+    p.append(("linear_ouput_notes.0.weight", (V, linear_hidden)))
+    p.append(("linear_ouput_notes.0.bias", (V,)))
+    return OrderedDict(p)

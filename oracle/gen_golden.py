@@ -60,6 +60,8 @@ import MeasureVAE.decoder as ref_decoder_mod  # noqa: E402
 from LatentRNN.latent_rnn import LatentRNN  # noqa: E402
 import LatentRNN.latent_rnn as ref_latent_mod  # noqa: E402
 from LatentRNN.latent_rnn_trainer import LatentRNNTrainer  # noqa: E402
+from AnticipationRNN.anticipation_rnn_gauss_reg_model import ConstraintModelGaussianReg  # noqa: E402
+from AnticipationRNN.anticipation_rnn_trainer import AnticipationRNNGaussianRegTrainer  # noqa: E402
 
 from inpaintnet_amd import synthetic  # noqa: E402
 
@@ -73,6 +75,11 @@ class FakeDataset:
         self.subdivision = 6
         self.num_beats_per_bar = 4
         self.num_voices = 1
+
+        self.metadatas = [types.SimpleNamespace(num_values=6), types.SimpleNamespace(num_values=6)]
+
+    def empty_score_tensor(self, length):
+        return torch.zeros(self.num_voices, length, dtype=torch.long)
 
     def __repr__(self):
         return "Fake"
@@ -300,6 +307,77 @@ def gen_latent(name, c, auto_reg, coin):
     print("wrote %s.npz (%d arrays)" % (tag, len(fx)))
 
 
+ARNN_CFGS = {
+    "small": dict(V=12, E=4, Em=2, H=16, LH=16, B=3),
+    "full": dict(V=48, E=10, Em=2, H=256, LH=256, B=2),
+}
+
+
+def gen_arnn(name, c):
+    """ConstraintModelGaussianReg + AnticipationRNNGaussianRegTrainer (a16), dropout 0: teacher-forced step with
+    gradients and one Adam step; free-running forward."""
+    V, B, L = c["V"], c["B"], 384
+    full_tensors = name != "full"
+    ds = FakeDataset(V)
+
+    def build():
+        m = ConstraintModelGaussianReg(ds, note_embedding_dim=c["E"], metadata_embedding_dim=c["Em"],
+                                       num_lstm_constraints_units=c["H"], num_lstm_generation_units=c["H"],
+                                       linear_hidden_size=c["LH"], num_layers=2, dropout_input_prob=0.0,
+                                       dropout_prob=0.0, unary_constraint=True, teacher_forcing=True)
+        load_det_weights(m)
+        return m
+    model = build()
+    fx = {}
+    if full_tensors:
+        for k, v in model.state_dict().items():
+            fx["param/" + k] = v.numpy().copy()
+    fx["param_keys"] = np.array(list(model.state_dict().keys()))
+    fx["param_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in model.state_dict().values()])
+    score = torch.from_numpy(synthetic.folk_score(B, V, seed=11)).long()
+    metadata = torch.from_numpy(synthetic.folk_metadata(B)).long()
+    metadata[..., 0] = torch.from_numpy(synthetic.det_tokens("arnn/md0", (B, 1, L), 6))
+    n_past, n_target = 6, 4
+    start_tick, end_tick = (n_past + 1) * 24, (n_past + 1) * 24 + n_target * 24
+    loc = torch.zeros_like(score)
+    loc[:, :, :start_tick] = 1
+    loc[:, :, end_tick:] = 1
+    fx["score"], fx["metadata"], fx["constraints_loc"] = score.numpy(), metadata.numpy(), loc.numpy()
+    fx["ticks"] = np.array([start_tick, end_tick])
+    trainer = AnticipationRNNGaussianRegTrainer(ds, model, lr=1e-4)
+    model.train()
+    set_coin(0.0)                                   # random.random() <= 0.5 -> teacher forcing
+    trainer.zero_grad()
+    loss, acc = trainer.loss_and_acc_for_batch((score, metadata, loc, start_tick, end_tick), 0, train=True)
+    loss.backward()
+    with torch.no_grad():
+        w_all, _ = model._forward_tf(score, metadata, loc)
+    fx["tf_weights_all"] = w_all[0].numpy()
+    fx["tf_loss_acc"] = np.array([loss.item(), acc.item()], dtype=np.float64)
+    for k, v in grads_of(model, full_tensors).items():
+        fx["tf_" + k] = v
+    trainer.step()
+    for k, p in model.named_parameters():
+        v = p.detach().numpy()
+        if full_tensors:
+            fx["tf_after1/" + k] = v.copy()
+        else:
+            fx["tf_after1head/" + k] = v.reshape(-1)[:64].copy()
+    # free-running forward (backward of this path fails on CPU under torch 2.x: in-place write on a saved view)
+    model = build()
+    model.train()
+    set_coin(0.9)
+    with torch.no_grad():
+        w, _ = model(score, metadata, loc, train=True)
+        w_all, gen = model._forward_no_tf(score, metadata, loc)
+    fx["fr_weights_free"] = w[0].numpy()
+    fx["fr_weights_all"] = w_all[0].numpy()
+    fx["fr_gen"] = gen.numpy()
+    fx["fr_margin_row0"] = top2_margin(w_all[0][0])
+    np.savez_compressed(os.path.join(OUT, f"arnn_{name}.npz"), **fx)
+    print("wrote arnn_%s.npz (%d arrays)" % (name, len(fx)))
+
+
 def gen_split_helpers():
     """split_score / split_to_measures / process_batch_data index contract (a9, a15)."""
     V = 12
@@ -316,7 +394,7 @@ def gen_split_helpers():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["vae", "latent", "split"]
+    which = sys.argv[1:] or ["vae", "latent", "arnn", "split"]
     if "vae" in which:
         for n, c in CFGS.items():
             gen_vae(n, c)
@@ -328,5 +406,8 @@ if __name__ == "__main__":
             gen_latent(n, c, auto_reg=False, coin=0.9)
             gen_latent(n, c, auto_reg=True, coin=0.0)
             gen_latent(n, c, auto_reg=True, coin=0.9)
+    if "arnn" in which:
+        for n, c in ARNN_CFGS.items():
+            gen_arnn(n, c)
     if "split" in which:
         gen_split_helpers()

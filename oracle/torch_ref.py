@@ -382,3 +382,103 @@ class CpuVaeTrainStep:
         loss.backward()
         self.opt.step()
         return float(loss)
+
+
+# ----------------------------------------------------------------------------
+# AnticipationRNN (config 5): AnticipationRNN/anticipation_rnn_gauss_reg_model.py
+#   lstm_cell / lstm_layer   torch.nn.LSTM(num_layers=1, batch_first) as stacked by lstm_with_activations (:14-39)
+#   arnn_embed               embed_tensor_score (:448-457), embed_metadata (:478-510), mask_tensor_score (:512-532)
+#   arnn_forward             _forward_tf (:348-404), _forward_no_tf (:190-259), output_lstm_constraints (:459-476)
+#   arnn_loss                anticipation_rnn_trainer.py:21-49,154-182 (single voice)
+# Single-voice datasets only (FolkDataset: num_voices = 1), as everything the reference trains on.
+# ----------------------------------------------------------------------------
+def lstm_cell(gi, h, c, w_hh, b_hh):
+    """gi = W_ih x + b_ih.  Gate rows ordered [i|f|g|o] (torch)."""
+    H = h.shape[-1]
+    g = gi + h @ w_hh.t() + b_hh
+    i = torch.sigmoid(g[..., :H])
+    f = torch.sigmoid(g[..., H:2 * H])
+    gg = torch.tanh(g[..., 2 * H:3 * H])
+    o = torch.sigmoid(g[..., 3 * H:])
+    c2 = f * c + i * gg
+    return o * torch.tanh(c2), c2
+
+
+def lstm_layer(x, h0, c0, P, prefix, reverse=False):
+    """x (B,T,K) -> out (B,T,H), (h_T, c_T).  `reverse` processes t = T-1..0 and returns outputs in original order
+    (= index_select(reversed) -> LSTM -> index_select(reversed), output_lstm_constraints :467-474)."""
+    B, T, _ = x.shape
+    gi = x @ P[f"{prefix}.weight_ih_l0"].t() + P[f"{prefix}.bias_ih_l0"]
+    h, c = h0, c0
+    outs = [None] * T
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        h, c = lstm_cell(gi[:, t], h, c, P[f"{prefix}.weight_hh_l0"], P[f"{prefix}.bias_hh_l0"])
+        outs[t] = h
+    return torch.stack(outs, 1), (h, c)
+
+
+def arnn_embed(P, score, metadata, constraints_loc):
+    """score (B,1,L), metadata (B,1,L,3), constraints_loc (B,1,L) in {0,1} ->
+    x (B,L,E) note embeddings, m (B,L,3*Em+E) constraint-LSTM input."""
+    V = P["note_embeddings.0.weight"].shape[0] - 1
+    tok = score[:, 0]
+    x = P["note_embeddings.0.weight"][tok]
+    md = metadata[:, 0]
+    parts = [P[f"metadata_embeddings.{i}.weight"][md[..., i]] for i in range(md.shape[-1])]
+    loc = constraints_loc[:, 0]
+    masked = tok * loc + V * (1 - loc)
+    parts.append(P["note_embeddings.0.weight"][masked])
+    return x, torch.cat(parts, 2)
+
+
+def _arnn_head(P, h):
+    a = torch.relu(h @ P["linear_1.weight"].t() + P["linear_1.bias"])
+    return a @ P["linear_ouput_notes.0.weight"].t() + P["linear_ouput_notes.0.bias"]
+
+
+def arnn_forward(P, score, metadata, constraints_loc, teacher_forcing, num_layers=2, input_mask=None):
+    """-> weights (B,L,V) for ALL ticks (the caller slices the unconstrained ones, forward :434), gen (B,L) tokens
+    (no-teacher-forcing path only).  input_mask: (B,L,1) pre-scaled Dropout2d mask on the shifted note embeddings."""
+    B, _, L = score.shape
+    x, m = arnn_embed(P, score, metadata, constraints_loc)
+    Hc = P["lstm_constraint.0.weight_hh_l0"].shape[1]
+    z = torch.zeros(B, Hc)
+    oc = m
+    for l in range(num_layers):
+        oc, _ = lstm_layer(oc, z, z, P, f"lstm_constraint.{l}", reverse=True)
+    Hg = P["lstm_generation.0.weight_hh_l0"].shape[1]
+    if teacher_forcing:
+        off = torch.cat((torch.zeros(B, 1, x.shape[2]), x[:, :L - 1]), 1)
+        if input_mask is not None:
+            off = off * input_mask
+        h = torch.cat((off, oc), 2)
+        zg = torch.zeros(B, Hg)
+        for l in range(num_layers):
+            h, _ = lstm_layer(h, zg, zg, P, f"lstm_generation.{l}")
+        return _arnn_head(P, h), None
+    # free running: the argmax of BATCH ELEMENT 0 is written to the whole batch (:253-256)
+    hs = [torch.zeros(B, Hg) for _ in range(num_layers)]
+    cs = [torch.zeros(B, Hg) for _ in range(num_layers)]
+    E = P["note_embeddings.0.weight"]
+    prev = torch.zeros(B, dtype=torch.long)            # start symbol 0 (:218-223)
+    ws, gen = [], []
+    for t in range(L):
+        inp = torch.cat((E[prev], oc[:, t]), 1)
+        for l in range(num_layers):
+            pf = f"lstm_generation.{l}"
+            gi = inp @ P[f"{pf}.weight_ih_l0"].t() + P[f"{pf}.bias_ih_l0"]
+            hs[l], cs[l] = lstm_cell(gi, hs[l], cs[l], P[f"{pf}.weight_hh_l0"], P[f"{pf}.bias_hh_l0"])
+            inp = hs[l]
+        w = _arnn_head(P, inp)
+        ws.append(w)
+        tok = argmax_first(w[0].detach())
+        prev = tok.expand(B).clone()
+        gen.append(prev)
+    return torch.stack(ws, 1), torch.stack(gen, 1)
+
+
+def arnn_loss(weights_free, targets_free):
+    """mean CE / accuracy over (B, n_free) rows (anticipation_rnn_trainer.py:154-182, one voice)."""
+    V = weights_free.shape[-1]
+    ce = F.cross_entropy(weights_free.reshape(-1, V), targets_free.reshape(-1), reduction="mean")
+    return ce, accuracy_mean(weights_free.detach(), targets_free)

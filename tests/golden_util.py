@@ -50,3 +50,22 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+ARNN_CFGS = {
+    "small": dict(V=12, E=4, Em=2, H=16, LH=16),
+    "full": dict(V=48, E=10, Em=2, H=256, LH=256),
+}
+
+
+def arnn_params(name, fx=None):
+    c = ARNN_CFGS[name]
+    shapes = layout.arnn_param_shapes(c["V"], c["E"], c["Em"], c["H"], c["LH"])
+    P = {k: torch.from_numpy(synthetic.det_param(k, s)) for k, s in shapes.items()}
+    if fx is not None:
+        assert list(fx["param_keys"]) == list(shapes)
+        for k, shp in zip(fx["param_keys"], fx["param_shapes"]):
+            assert tuple(int(d) for d in str(shp).split(",")) == tuple(shapes[str(k)]), k
+        for k in P:
+            if "param/" + k in fx.files:
+                assert np.array_equal(fx["param/" + k], P[k].numpy()), k
+    return P
