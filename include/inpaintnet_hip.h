@@ -146,6 +146,31 @@ int inet_linear_fwd(const float* x, const float* W, const float* b, float* y, in
 int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N,
                     int K, void* stream);
 
+/* ---- single-layer LSTM over T steps: torch.nn.LSTM(num_layers=1, batch_first) as stacked by
+ *      lstm_with_activations, AnticipationRNN/anticipation_rnn_gauss_reg_model.py:14-39,110-133.
+ * gi [T,B,4H] time-major input-side pre-activations (x W_ih^T + b_ih, formed by inet_linear_fwd); gate order i,f,g,o;
+ * h0/c0 [B,H] or null (zeros); reverse != 0 processes t = T-1..0 (the constraint LSTM, :467-474); out [T,B,H];
+ * hT/cT nullable [B,H].  Backward: dout [T,B,H] (nullable), dhT/dcT (nullable) -> dgi [T,B,4H] (gate gradients: the
+ * caller forms dx and dW_ih with inet_linear_bwd); dW_hh/db_ih/db_hh accumulated when all three are given. */
+int64_t inet_lstm_ws_bytes(int batch, int T, int H, int save);
+int inet_lstm_fwd(int batch, int T, int H, const float* gi, const float* W_hh, const float* b_hh, const float* h0,
+                  const float* c0, int reverse, float* out, float* hT, float* cT, void* ws, int64_t ws_bytes, int save,
+                  void* stream);
+int inet_lstm_bwd(int batch, int T, int H, const float* W_hh, const float* h0, const float* out, const float* dout,
+                  const float* dhT, const float* dcT, int reverse, float* dgi, float* dW_hh, float* db_ih, float* db_hh,
+                  float* dh0, float* dc0, void* ws, int64_t ws_bytes, void* stream);
+/* nn.Embedding forward / backward (rows of E floats gathered by int64 index; backward accumulates with atomics).
+ * row_scale (nullable, [rows]) multiplies each gathered row: the Dropout2d on the shifted note embeddings
+ * (drop_input, anticipation_rnn_gauss_reg_model.py:437-442) and the all-zero first time step (:373-376). */
+int inet_embedding_fwd(const float* table, const int64_t* idx, int64_t rows, int E, float* out, const float* row_scale,
+                       void* stream);
+int inet_embedding_bwd(const float* dout, const int64_t* idx, int64_t rows, int E, float* dtable, const float* row_scale,
+                       void* stream);
+/* dpre = dy where y > 0 else 0   (backward of the ReLU fused into inet_linear_fwd epi=2) */
+int inet_relu_bwd(const float* dy, const float* y, float* dpre, int64_t n, void* stream);
+/* out[r*stride] = argmax_v w[r*ld + v], lowest index on ties (Tensor.max(1) / np.argmax semantics) */
+int inet_argmax(const float* w, int64_t ld, int rows, int V, int64_t* out, int64_t stride, void* stream);
+
 /* single GRU step (test hook for the fused step kernel; semantics of torch.nn.GRUCell with the input-side
  * gate pre-activations gi [B,3H] already formed) -- r,z,n,ghn,hprev saves are nullable [B,H] */
 int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,

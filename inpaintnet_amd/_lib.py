@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INET_LIB_PATH") or os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip"]
+SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip"]
 
 _lib = None
 
@@ -77,6 +77,13 @@ _SIGNATURES = {
     "inet_gru_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "inet_linear_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "inet_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "inet_lstm_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "inet_lstm_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
+    "inet_lstm_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "inet_embedding_fwd": (C.c_int, [_P, _P, _L, _I, _P, _P, _P]),
+    "inet_embedding_bwd": (C.c_int, [_P, _P, _L, _I, _P, _P, _P]),
+    "inet_relu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
+    "inet_argmax": (C.c_int, [_P, _L, _I, _I, _P, _L, _P]),
     "inet_set_option": (C.c_int, [_I, _I]),
     "inet_prof_enable": (C.c_int, [_I]),
     "inet_prof_dump": (C.c_int, [C.c_char_p]),

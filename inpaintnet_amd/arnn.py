@@ -1,0 +1,302 @@
+"""AnticipationRNN (BASELINE.json config 5) with the reference's Python surface on the HIP kernels.
+
+Mirrors AnticipationRNN/anticipation_rnn_gauss_reg_model.py (ConstraintModelGaussianReg: forward,
+_forward_tf :348-404, _forward_no_tf :190-259, embed_*, output_lstm_constraints :459-476, mask_tensor_score
+:512-532) and AnticipationRNN/anticipation_rnn_trainer.py (loss / accuracy / constraint sampling) for
+single-voice datasets (FolkDataset: num_voices = 1 -- everything the reference trains on).  The LSTM cells run
+in the fused step kernels of csrc/lstm.hip (same K-split geometry as the GRU steps); input projections,
+the Linear+ReLU head and the embedding gathers are the batched kernels of the C-ABI.
+
+Out of scope as in SURVEY.md section 2.1: generate()/generation() (music21 I/O), forward_inpaint, the unused
+gaussian_regularization.
+"""
+import os
+import random
+
+import torch
+
+from . import layout, ops
+from .helpers import to_cuda_variable_long
+from .latent_rnn_trainer import LatentRNNTrainer
+from .measure_vae import _DropState, _next_mask_offset
+from .model import Model, default_device
+from .trainer import Trainer
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, owner, name, idx, row_scale):
+        ctx.args = (owner, name, idx, row_scale)
+        return ops.embedding_fwd(owner.param(name), idx, row_scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        owner, name, idx, row_scale = ctx.args
+        ops.embedding_bwd(dout.contiguous(), idx, owner.param_grad(name), row_scale)
+        return None, None, None, None, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = [ReLU](x W^T + b)"""
+
+    @staticmethod
+    def forward(ctx, x, flat, owner, w_name, b_name, relu):
+        y = ops.linear_fwd(x.contiguous(), owner.param(w_name), owner.param(b_name), epi=2 if relu else 0)
+        ctx.args = (owner, w_name, b_name, relu)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        owner, w_name, b_name, relu = ctx.args
+        x, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if relu:
+            dy = ops.relu_bwd(dy, y)
+        dx = ops.linear_bwd(dy, x.contiguous(), owner.param(w_name), owner.param_grad(w_name),
+                            owner.param_grad(b_name), need_dx=ctx.needs_input_grad[0])
+        return dx, None, None, None, None, None
+
+
+class _LstmLayerFn(torch.autograd.Function):
+    """One nn.LSTM(num_layers=1) over a time-major sequence x [T,B,K]; optional carried state (single steps of the
+    free-running path)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, flat, owner, prefix, reverse):
+        T, B, K = x.shape
+        W_ih, W_hh = owner.param(prefix + ".weight_ih_l0"), owner.param(prefix + ".weight_hh_l0")
+        H = W_hh.shape[1]
+        need = any(ctx.needs_input_grad[:4])
+        x2 = x.contiguous().view(T * B, K)
+        gi = ops.linear_fwd(x2, W_ih, owner.param(prefix + ".bias_ih_l0"))
+        out, hT, cT, ws = ops.lstm_fwd(gi.view(T, B, 4 * H), W_hh, owner.param(prefix + ".bias_hh_l0"), H,
+                                       reverse=reverse, h0=h0, c0=c0, save=need, want_state=True)
+        ctx.args = (owner, prefix, reverse, H, ws, h0)
+        ctx.save_for_backward(x2, out)
+        return out, hT, cT
+
+    @staticmethod
+    def backward(ctx, dout, dhT, dcT):
+        owner, prefix, reverse, H, ws, h0 = ctx.args
+        ctx.args = None
+        x2, out = ctx.saved_tensors
+        T, B, _ = out.shape
+        g = owner.param_grad
+        dgi, dh0, dc0 = ops.lstm_bwd(owner.param(prefix + ".weight_hh_l0"), out, dout.contiguous(), H, reverse, ws,
+                                     dW_hh=g(prefix + ".weight_hh_l0"), db_ih=g(prefix + ".bias_ih_l0"),
+                                     db_hh=g(prefix + ".bias_hh_l0"), h0=h0, dhT=dhT.contiguous(),
+                                     dcT=dcT.contiguous(), want_dstate=ctx.needs_input_grad[1])
+        dx = ops.linear_bwd(dgi.view(T * B, 4 * H), x2, owner.param(prefix + ".weight_ih_l0"),
+                            g(prefix + ".weight_ih_l0"), None, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(T, B, -1) if dx is not None else None), dh0, dc0, None, None, None, None
+
+
+class ConstraintModelGaussianReg(Model):
+    def __init__(self, dataset, note_embedding_dim=20, metadata_embedding_dim=30, num_lstm_constraints_units=256,
+                 num_lstm_generation_units=256, linear_hidden_size=128, num_layers=1, dropout_input_prob=0.2,
+                 dropout_prob=0.5, unary_constraint=False, teacher_forcing=True, device=None):
+        super().__init__()
+        if dataset.num_voices != 1 or not unary_constraint:
+            raise NotImplementedError("single-voice datasets with unary_constraint=True (train_arnn_reg.py:100)")
+        if num_lstm_constraints_units != num_lstm_generation_units:
+            raise NotImplementedError("the reference sizes the generation LSTMs with the constraint units (:125-133)")
+        self.dataset = dataset
+        self.use_teacher_forcing = teacher_forcing
+        self.teacher_forcing_prob = 0.5
+        self.num_layers = num_layers
+        self.num_units_linear = linear_hidden_size
+        self.unary_constraint = unary_constraint
+        self.note_embedding_dim = note_embedding_dim
+        self.num_lstm_generation_units = num_lstm_generation_units
+        self.num_lstm_constraints_units = num_lstm_constraints_units
+        self.metadata_embedding_dim = metadata_embedding_dim
+        self.num_notes_per_voice = [len(d) for d in dataset.note2index_dicts]
+        self.num_elements_per_metadata = [m.num_values for m in dataset.metadatas] + [dataset.num_voices]
+        self.dropout_input_prob = dropout_input_prob
+        self.dropout_prob = dropout_prob
+        self.trainable = True
+        shapes = layout.arnn_param_shapes(self.num_notes_per_voice[0], note_embedding_dim, metadata_embedding_dim,
+                                          num_lstm_constraints_units, linear_hidden_size, num_layers,
+                                          tuple(self.num_elements_per_metadata))
+        offs, total = layout.arena_offsets(shapes)
+        self._alloc_arena([(k, off, shp) for k, (off, shp) in offs.items()], total, device or default_device())
+        self._flat_leaf = None
+        self.init_torch_defaults()
+        cur_dir = os.path.dirname(os.path.realpath(__file__))
+        self.filepath = os.path.join(cur_dir, 'models/', self.__repr__())
+
+    @torch.no_grad()
+    def init_torch_defaults(self):
+        """torch defaults (the reference applies no custom init): Embedding N(0,1); LSTM and Linear U(+-1/sqrt(fan))."""
+        for name, _, shape in self._table:
+            v = self._views[name]
+            if "embeddings" in name:
+                v.copy_(torch.randn(shape))
+            elif "lstm" in name:
+                b = 1.0 / (self.num_lstm_constraints_units ** 0.5)
+                v.copy_((torch.rand(shape) * 2 - 1) * b)
+            else:
+                fan = shape[1] if len(shape) == 2 else self._views[name.replace("bias", "weight")].shape[1]
+                v.copy_((torch.rand(shape) * 2 - 1) / fan ** 0.5)
+
+    def __repr__(self):
+        filestr = f'AnticipationRNNReg(' \
+                  f'{self.dataset.__repr__()},' \
+                  f'{self.note_embedding_dim},' \
+                  f'{self.metadata_embedding_dim},' \
+                  f'{self.num_lstm_constraints_units},' \
+                  f'{self.num_lstm_generation_units},' \
+                  f'{self.num_units_linear},' \
+                  f'{self.num_layers},' \
+                  f'{self.dropout_input_prob},' \
+                  f'{self.dropout_prob},' \
+                  f'{self.unary_constraint},' \
+                  f')'
+        return filestr + (',tf' if self.use_teacher_forcing else ',no_tf')
+
+    def flat_for_autograd(self):
+        if self._flat_leaf is None:
+            self._flat_leaf = self.flat.detach().requires_grad_(True)
+        return self._flat_leaf
+
+    # ---- building blocks (time-major [L,B,*] internally) ----------------------------------------------------
+    def _embed(self, name, idx_tm, row_scale=None):
+        L, B = idx_tm.shape
+        e = _EmbeddingFn.apply(self.flat_for_autograd(), self, name, idx_tm.contiguous().view(-1), row_scale)
+        return e.view(L, B, -1)
+
+    def _lstm(self, prefix, x_tm, reverse, state=None):
+        h0, c0 = state if state is not None else (None, None)
+        return _LstmLayerFn.apply(x_tm, h0, c0, self.flat_for_autograd(), self, prefix, reverse)
+
+    def _head(self, h2d):
+        a = _LinearFn.apply(h2d, self.flat_for_autograd(), self, "linear_1.weight", "linear_1.bias", True)
+        return _LinearFn.apply(a, self.flat_for_autograd(), self, "linear_ouput_notes.0.weight",
+                               "linear_ouput_notes.0.bias", False)
+
+    def mask_tensor_score(self, tensor_score, constraints_location=None):
+        """tokens where constrained, the extra 'no constraint' symbol elsewhere (:512-532)"""
+        if constraints_location is None:
+            p = random.random() * 0.5
+            constraints_location = (torch.rand(*tensor_score.size(), device=tensor_score.device) < p).long()
+        no_constraint = self.num_notes_per_voice[0]
+        return tensor_score * constraints_location + no_constraint * (1 - constraints_location)
+
+    def _constraints(self, score_tensor, metadata_tensor, constraints_loc):
+        """output_lstm_constraints(embed_metadata(...)) -> [L,B,H]"""
+        md_tm = metadata_tensor[:, 0].permute(1, 0, 2)                         # [L,B,3]
+        parts = [self._embed(f"metadata_embeddings.{i}.weight", md_tm[..., i]) for i in range(md_tm.shape[-1])]
+        masked = self.mask_tensor_score(score_tensor, constraints_loc)[:, 0].t()  # [L,B]
+        parts.append(self._embed("note_embeddings.0.weight", masked))
+        oc = torch.cat(parts, 2)
+        for l in range(self.num_layers):
+            oc, _, _ = self._lstm(f"lstm_constraint.{l}", oc, True)
+        return oc
+
+    def _forward_tf(self, score_tensor, metadata_tensor, constraints_loc):
+        """-> [weights (B,L,V)], None   (:348-404)"""
+        B, _, L = score_tensor.shape
+        oc = self._constraints(score_tensor, metadata_tensor, constraints_loc)
+        tok_tm = score_tensor[:, 0].t()                                        # [L,B]
+        shifted = torch.cat((torch.zeros_like(tok_tm[:1]), tok_tm[:-1]), 0)
+        scale = torch.ones(L, B, dtype=torch.float32, device=tok_tm.device)
+        if self.training and self.dropout_input_prob > 0:                      # Dropout2d drops whole time steps (:437-442)
+            scale = ops.dropout_mask((L, B), self.dropout_input_prob, _DropState.seed, _next_mask_offset(L * B),
+                                     tok_tm.device)
+        scale[0] = 0.0                                                         # the sequence is offset by a zero vector
+        off = self._embed("note_embeddings.0.weight", shifted, scale.view(-1))
+        h = torch.cat((off, oc), 2)
+        for l in range(self.num_layers):
+            h, _, _ = self._lstm(f"lstm_generation.{l}", h, False)
+        w = self._head(h.view(L * B, -1)).view(L, B, -1).permute(1, 0, 2)
+        return [w], None
+
+    def _forward_no_tf(self, score_tensor, metadata_tensor, constraints_loc):
+        """-> [weights (B,L,V)], gen_chorale (B,1,L): the argmax of BATCH ELEMENT 0 is fed to the whole batch
+        (:190-259, quirk at :253-256)."""
+        B, _, L = score_tensor.shape
+        oc = self._constraints(score_tensor, metadata_tensor, constraints_loc)
+        dev = score_tensor.device
+        prev = torch.zeros(1, B, dtype=torch.int64, device=dev)               # start symbol 0
+        states = [None] * self.num_layers
+        ws, gen = [], []
+        for t in range(L):
+            inp = torch.cat((self._embed("note_embeddings.0.weight", prev), oc[t:t + 1]), 2)
+            for l in range(self.num_layers):
+                inp, hT, cT = self._lstm(f"lstm_generation.{l}", inp, False, states[l])
+                states[l] = (hT, cT)
+            w = self._head(inp.view(B, -1))
+            ws.append(w)
+            tok = ops.argmax_rows(w.detach()[0:1])                             # batch element 0
+            prev = tok.view(1, 1).expand(1, B).contiguous()
+            gen.append(prev)
+        return [torch.stack(ws, 1)], torch.cat(gen, 0).t().unsqueeze(1).contiguous()
+
+    def forward(self, score_tensor, metadata_tensor, constraints_loc, start_tick=None, end_tick=None, train=True,
+                teacher_forcing=None):
+        """-> list (one per voice) of (B, n_unconstrained, V) weights, extra   (:406-435)"""
+        if teacher_forcing is None:
+            if self.use_teacher_forcing and train:
+                teacher_forcing = random.random() <= self.teacher_forcing_prob
+            else:
+                teacher_forcing = False
+        fwd = self._forward_tf if teacher_forcing else self._forward_no_tf
+        weights, add_args = fwd(score_tensor, metadata_tensor, constraints_loc)
+        free = (constraints_loc[0, 0, :] == 0).nonzero().squeeze(-1)
+        return [w[:, free, :] for w in weights], add_args
+
+
+class AnticipationRNNGaussianRegTrainer(Trainer):
+    """AnticipationRNN/anticipation_rnn_trainer.py:8-182"""
+
+    def __init__(self, dataset, model, lr=1e-4, early_stopping=False):
+        super().__init__(dataset, model, lr, early_stopping)
+        self.min_num_measures_target = 2
+        self.max_num_measure_target = 6
+        self.measure_seq_len = self.dataset.subdivision * self.dataset.num_beats_per_bar
+
+    def loss_and_acc_for_batch(self, batch, epoch_num=None, train=True):
+        score_tensor, metadata_tensor, constraints_loc, start_tick, end_tick = batch
+        weights, _ = self.model(score_tensor=score_tensor, metadata_tensor=metadata_tensor,
+                                constraints_loc=constraints_loc, start_tick=start_tick, end_tick=end_tick, train=train)
+        free = (constraints_loc[0, 0, :] == 0).nonzero().squeeze(-1)
+        targets = score_tensor[:, :, free].transpose(0, 1)                     # (voice, batch, n_free)
+        return self.mean_crossentropy_loss_and_accuracy_voices(weights, targets)
+
+    @staticmethod
+    def mean_crossentropy_loss_and_accuracy_voices(weights, targets):
+        """mean over voices of the per-voice mean CE / accuracy (:154-182)"""
+        loss = acc = 0
+        for i, w in enumerate(weights):
+            l, a = Trainer.mean_crossentropy_loss_and_accuracy(w, targets[i])
+            loss, acc = loss + l, acc + a
+        return loss / len(weights), acc / len(weights)
+
+    def process_batch_data(self, batch):
+        score_tensor, metadata_tensor = batch
+        constraint_loc, start_tick, end_tick = self.get_constraints_location(score_tensor)
+        return (to_cuda_variable_long(score_tensor), to_cuda_variable_long(metadata_tensor),
+                to_cuda_variable_long(constraint_loc), start_tick, end_tick)
+
+    def get_constraints_location(self, score_tensor, extra_outs=False, fix_num_target=None):
+        """1 = constrained (given) tick, 0 = to be generated: a window of n_target measures (:93-128)"""
+        num_measures = LatentRNNTrainer.split_to_measures(score_tensor, self.measure_seq_len).size(1)
+        assert num_measures == self.dataset.n_bars
+        if fix_num_target is None:
+            num_target = int(torch.randint(low=self.min_num_measures_target, high=self.max_num_measure_target + 1,
+                                           size=(1,)).item())
+        else:
+            num_target = fix_num_target
+        num_past = int(torch.randint(low=1, high=num_measures - num_target - 1, size=(1,)).item())
+        start_tick = (num_past + 1) * self.measure_seq_len
+        end_tick = start_tick + num_target * self.measure_seq_len
+        constraints_location = torch.zeros_like(score_tensor)
+        if start_tick > 0:
+            constraints_location[:, :, :start_tick] = 1
+        if end_tick < constraints_location.size(2) - 1:
+            constraints_location[:, :, end_tick:] = 1
+        return constraints_location, start_tick, end_tick
+
+    def update_scheduler(self, epoch_num):
+        return

@@ -3,6 +3,7 @@
 #include "seq.h"
 #include "layout.h"
 #include "vae.h"
+#include "lstm.h"
 
 namespace {
 
@@ -246,6 +247,45 @@ int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, 
     if (dW) { if (!x) return -1; INET_TRY(linear_wgrad(dy, N, x, K, dW, K, M, N, K, s)); }
     if (db) INET_TRY(pw_colsum(dy, N, M, N, db, s));
     return 0;
+}
+
+int64_t inet_lstm_ws_bytes(int batch, int T, int H, int save) {
+    if (batch <= 0 || T <= 0 || H <= 0 || H % 16) return -1;
+    return (int64_t)lstm_ws_bytes(batch, T, H, save);
+}
+int inet_lstm_fwd(int B, int T, int H, const float* gi, const float* W_hh, const float* b_hh, const float* h0,
+                  const float* c0, int reverse, float* out, float* hT, float* cT, void* ws, int64_t ws_bytes, int save,
+                  void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || H % 16 || !gi || !W_hh || !b_hh || !out || !ws) return -1;
+    if (ws_bytes < (int64_t)lstm_ws_bytes(B, T, H, save)) return -1;
+    return lstm_seq_fwd(B, T, H, gi, W_hh, b_hh, h0, c0, reverse, out, hT, cT, ws, save, (hipStream_t)stream);
+}
+int inet_lstm_bwd(int B, int T, int H, const float* W_hh, const float* h0, const float* out, const float* dout,
+                  const float* dhT, const float* dcT, int reverse, float* dgi, float* dW_hh, float* db_ih, float* db_hh,
+                  float* dh0, float* dc0, void* ws, int64_t ws_bytes, void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || H % 16 || !W_hh || !out || !dgi || !ws) return -1;
+    if ((dW_hh != nullptr) != (db_hh != nullptr) || (dW_hh != nullptr) != (db_ih != nullptr)) return -1;
+    if (ws_bytes < (int64_t)lstm_ws_bytes(B, T, H, 1)) return -1;
+    return lstm_seq_bwd(B, T, H, W_hh, h0, out, dout, dhT, dcT, reverse, dgi, dW_hh, db_ih, db_hh, dh0, dc0, ws,
+                        (hipStream_t)stream);
+}
+int inet_embedding_fwd(const float* table, const int64_t* idx, int64_t rows, int E, float* out, const float* row_scale,
+                       void* stream) {
+    if (!table || !idx || !out || rows <= 0 || E <= 0) return -1;
+    return pw_embedding_fwd(table, (const long long*)idx, rows, E, out, row_scale, (hipStream_t)stream);
+}
+int inet_embedding_bwd(const float* dout, const int64_t* idx, int64_t rows, int E, float* dtable, const float* row_scale,
+                       void* stream) {
+    if (!dout || !idx || !dtable || rows <= 0 || E <= 0) return -1;
+    return pw_embedding_bwd(dout, (const long long*)idx, rows, E, dtable, row_scale, (hipStream_t)stream);
+}
+int inet_relu_bwd(const float* dy, const float* y, float* dpre, int64_t n, void* stream) {
+    if (!dy || !y || !dpre || n <= 0) return -1;
+    return pw_copy2d(dpre, n, dy, n, y, n, 1, (int)n, (hipStream_t)stream);
+}
+int inet_argmax(const float* w, int64_t ld, int rows, int V, int64_t* out, int64_t stride, void* stream) {
+    if (!w || !out || rows <= 0 || V <= 0) return -1;
+    return pw_argmax(w, ld, rows, V, (long long*)out, stride, (hipStream_t)stream);
 }
 
 int inet_set_option(int key, int value) {

@@ -29,169 +29,12 @@
 // version spent ~0.9 us per 64-deep chunk on load->barrier->ds_read latency,
 // 14.5 us per step; see profiles/.)
 #include "common.h"
+#include "ksplit.h"
 #include "prof.h"
 
 namespace {
 
-constexpr int TM_ROWS = 32;   // batch rows per workgroup of the base (MS = 2) geometry
-constexpr int TH = 16;        // hidden units per workgroup
-
-// Fragments of one k-step (16 k) for this wave: MS sub-tiles of 16 A rows, NB groups of 16 B rows.
-template <int MS, int NB>
-struct Frag {
-    f32x4 a[MS];
-    f32x4 b[NB];
-};
-
-// One k-step of fragments.  GUARD=false: every load is an unconditional 16-byte load (K multiple of 16).
-// A rows past the batch are clamped, not zeroed: they only feed output rows that are never stored.
-// (Per-lane "load or zero" guards make hipcc wrap each load in an exec-mask branch and wait vmcnt(0) per
-// element -- the round trips serialise; the guarded form is kept only for K not a multiple of 512.)
-template <int MS, int NB, bool GUARD>
-__device__ __forceinline__ void load_step(Frag<MS, NB>& f, const float* __restrict__ A, long lda, int row0, int rowsA,
-                                          const float* __restrict__ Bm, long ldb, const int (&brow)[NB], int K, int s,
-                                          int i16, int q) {
-    const int k = 16 * s + 4 * q;
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
-        const int row = min(row0 + 16 * ms + i16, rowsA - 1);
-        const float* p = A + (long)row * lda + k;
-        if (!GUARD) f.a[ms] = ld4u(p);
-        else {
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
-            f.a[ms] = x;
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < NB; ++g) {
-        const float* p = Bm + (long)(brow[g] + i16) * ldb + k;
-        if (!GUARD) f.b[g] = ld4u(p);
-        else {
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
-            f.b[g] = x;
-        }
-    }
-}
-
-template <int MS, int NB>
-__device__ __forceinline__ void mma_step(f32x4 (&acc)[MS][4], const int (&slot)[NB], const Frag<MS, NB>& f) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-            for (int g = 0; g < NB; ++g)
-                acc[ms][slot[g]] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ms][e], f.b[g][e], acc[ms][slot[g]], 0, 0, 0);
-}
-
-// acc[ms][slot[g]] += A[16*MS rows, this wave's K quarter] * Bg[16 rows, same K]^T
-//
-// Issue order is the whole game here (profiles/r01_c): a wave issues in order, so a load placed behind an MFMA that
-// waits on vmcnt is not even REQUESTED until that data is back.  The paths below therefore request as much of the
-// wave's K range as the register file allows before the first MFMA: all of it when K = 512 (8 k-steps, 40 x 16-byte
-// loads per lane for the forward step), otherwise two groups of GDEPTH k-steps kept in flight.
-template <int MS, int NB, int GDEPTH>
-__device__ __forceinline__ void ksplit_fast(f32x4 (&acc)[MS][4], const int (&slot)[NB], const float* __restrict__ A,
-                                            long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
-                                            const int (&brow)[NB], int K, int s_beg, int s_end, int i16, int q) {
-    Frag<MS, NB> f0[GDEPTH], f1[GDEPTH];
-#pragma unroll
-    for (int d = 0; d < GDEPTH; ++d)
-        load_step<MS, NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
-    for (int s = s_beg; s < s_end; s += 2 * GDEPTH) {
-        const bool more1 = s + GDEPTH < s_end, more2 = s + 2 * GDEPTH < s_end;     // wave-uniform
-        if (more1) {
-#pragma unroll
-            for (int d = 0; d < GDEPTH; ++d)
-                load_step<MS, NB, false>(f1[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + GDEPTH + d, i16, q);
-        }
-#pragma unroll
-        for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f0[d]);
-        if (more2) {
-#pragma unroll
-            for (int d = 0; d < GDEPTH; ++d)
-                load_step<MS, NB, false>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + 2 * GDEPTH + d, i16, q);
-        }
-        if (more1) {
-#pragma unroll
-            for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f1[d]);
-        }
-    }
-}
-
-// single group: the wave's whole K range (8 k-steps) is requested before the first MFMA
-template <int MS, int NB>
-__device__ __forceinline__ void ksplit_once8(f32x4 (&acc)[MS][4], const int (&slot)[NB], const float* __restrict__ A,
-                                             long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
-                                             const int (&brow)[NB], int K, int s_beg, int i16, int q) {
-    Frag<MS, NB> f[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) load_step<MS, NB, false>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
-#pragma unroll
-    for (int d = 0; d < 8; ++d) mma_step<MS, NB>(acc, slot, f[d]);
-}
-
-template <int MS, int NB>
-__device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[MS][4], const int (&slot)[NB],
-                                               const float* __restrict__ A, long lda, int row0, int rowsA,
-                                               const float* __restrict__ Bm, long ldb, const int (&brow)[NB],
-                                               int K, int t) {
-    const int lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform -> scalar loop control
-    const int i16 = lane & 15, q = lane >> 4;
-    const int S = (K + 15) >> 4;                   // k-steps of 16
-    constexpr int FR = MS + NB;                    // float4 fragment registers per k-step
-    if (K == 512 && FR <= 7) {
-        ksplit_once8<MS, NB>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * 8, i16, q);
-    } else if ((K & 511) == 0) {
-        // each wave owns S/4 = multiple of 8 steps
-        const int Sq = S >> 2;
-        constexpr int GDEPTH = FR <= 3 ? 8 : 4;
-        ksplit_fast<MS, NB, GDEPTH>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q);
-    } else {
-        // general path (small / odd K): guarded loads, one step at a time
-        const int Sq = (S + 3) >> 2;
-        const int s_beg = w * Sq;
-        const int s_end = min(S, s_beg + Sq);
-        for (int s = s_beg; s < s_end; ++s) {
-            Frag<MS, NB> f;
-            load_step<MS, NB, true>(f, A, lda, row0, rowsA, Bm, ldb, brow, K, s, i16, q);
-            mma_step<MS, NB>(acc, slot, f);
-        }
-    }
-}
-
-// Cross-wave reduction: every wave dumps its partial accumulators, then thread t owns output positions
-// t + 256*p (p < MS) of the (16*MS) x 16 tile (pos = row*16 + col) for all NACC accumulators.
-// C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg.
-template <int MS, int NACC>
-__device__ __forceinline__ void reduce_waves(const f32x4 (&acc)[MS][4], float* red, int t, float (&out)[MS][NACC]) {
-    const int lane = t & 63, w = t >> 6;
-    constexpr int TILE = MS * 256;
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-        for (int a = 0; a < NACC; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * ms + 4 * (lane >> 4) + r;
-                red[(w * NACC + a) * TILE + row * 16 + (lane & 15)] = acc[ms][a][r];
-            }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < MS; ++p)
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-            float s = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) s += red[(ww * NACC + a) * TILE + t + 256 * p];
-            out[p][a] = s;
-        }
-}
+using namespace ksplit;
 
 // Row tiles are numbered over the concatenated problems: blockIdx.y = problem * tiles_per_prob + tile.
 template <bool HAS_X, int MS>

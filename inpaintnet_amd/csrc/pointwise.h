@@ -28,3 +28,7 @@ int pw_beat_input_grad(const float* sv, const float* w, long incw, const float* 
                        hipStream_t s);
 int pw_dropout_mask(float* out, long n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
 int pw_scale(float* x, long n, float a, hipStream_t s);
+int pw_embedding_fwd(const float* table, const long long* idx, long rows, int E, float* out, const float* row_scale,
+                     hipStream_t s);
+int pw_embedding_bwd(const float* dout, const long long* idx, long rows, int E, float* dtable, const float* row_scale,
+                     hipStream_t s);

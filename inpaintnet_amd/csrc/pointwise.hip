@@ -295,6 +295,26 @@ __global__ void scale_kernel(float* __restrict__ x, long n, float a) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= a;
 }
 
+// out[r, :] = table[idx[r], :]
+__global__ void embedding_fwd_kernel(const float* __restrict__ table, const long long* __restrict__ idx, long rows, int E,
+                                     float* __restrict__ out, const float* __restrict__ row_scale) {
+    const long n = rows * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / E; const int e = (int)(i % E);
+        out[i] = table[idx[r] * E + e] * (row_scale ? row_scale[r] : 1.f);
+    }
+}
+// dtable[idx[r], :] += dout[r, :]
+__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ idx, long rows, int E,
+                                     float* __restrict__ dtable, const float* __restrict__ row_scale) {
+    const long n = rows * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / E; const int e = (int)(i % E);
+        const float sc = row_scale ? row_scale[r] : 1.f;
+        if (sc != 0.f) unsafeAtomicAdd(dtable + idx[r] * E + e, dout[i] * sc);
+    }
+}
+
 inline int grid_for(long n, int block = 256, int cap = 2048) {
     long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -390,5 +410,16 @@ int pw_dropout_mask(float* out, long n, float p, uint64_t seed, uint64_t offset,
 }
 int pw_scale(float* x, long n, float a, hipStream_t s) {
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n, a);
+    return ok();
+}
+
+int pw_embedding_fwd(const float* table, const long long* idx, long rows, int E, float* out, const float* row_scale,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(rows * E)), dim3(256), 0, s, table, idx, rows, E, out, row_scale);
+    return ok();
+}
+int pw_embedding_bwd(const float* dout, const long long* idx, long rows, int E, float* dtable, const float* row_scale,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(rows * E)), dim3(256), 0, s, dout, idx, rows, E, dtable, row_scale);
     return ok();
 }

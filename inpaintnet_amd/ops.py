@@ -211,6 +211,69 @@ def linear_bwd(dy, x, W, dW=None, db=None, need_dx=True):
     return dx
 
 
+def lstm_ws(B, T, H, save, device):
+    n = _lib.lib().inet_lstm_ws_bytes(B, T, H, int(save))
+    if n < 0:
+        raise ValueError("lstm_ws: invalid arguments")
+    return _ws(n, device)
+
+
+def lstm_fwd(gi_tm, W_hh, b_hh, H, reverse=False, h0=None, c0=None, save=False, want_state=False):
+    """gi_tm [T,B,4H] -> out [T,B,H] (+ hT, cT), ws"""
+    T, B, _ = gi_tm.shape
+    dev = gi_tm.device
+    ws = lstm_ws(B, T, H, save, dev)
+    out = torch.empty(T, B, H, dtype=torch.float32, device=dev)
+    hT = torch.empty(B, H, dtype=torch.float32, device=dev) if want_state else None
+    cT = torch.empty(B, H, dtype=torch.float32, device=dev) if want_state else None
+    check(_lib.lib().inet_lstm_fwd(B, T, H, ptr(_f32c(gi_tm)), ptr(W_hh), ptr(b_hh), ptr(h0), ptr(c0), int(reverse),
+                                   ptr(out), ptr(hT), ptr(cT), ptr(ws), ws.numel() * 4, int(save), stream_ptr()),
+          "inet_lstm_fwd")
+    return out, hT, cT, ws
+
+
+def lstm_bwd(W_hh, out, dout, H, reverse, ws, dW_hh=None, db_ih=None, db_hh=None, h0=None, dhT=None, dcT=None,
+             want_dstate=False):
+    T, B, _ = out.shape
+    dev = out.device
+    dgi = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
+    dh0 = torch.empty(B, H, dtype=torch.float32, device=dev) if want_dstate else None
+    dc0 = torch.empty(B, H, dtype=torch.float32, device=dev) if want_dstate else None
+    check(_lib.lib().inet_lstm_bwd(B, T, H, ptr(W_hh), ptr(h0), ptr(out), ptr(dout), ptr(dhT), ptr(dcT), int(reverse),
+                                   ptr(dgi), ptr(dW_hh), ptr(db_ih), ptr(db_hh), ptr(dh0), ptr(dc0), ptr(ws),
+                                   ws.numel() * 4, stream_ptr()), "inet_lstm_bwd")
+    return dgi, dh0, dc0
+
+
+def embedding_fwd(table, idx, row_scale=None):
+    rows = idx.numel()
+    E = table.shape[1]
+    out = torch.empty(rows, E, dtype=torch.float32, device=table.device)
+    check(_lib.lib().inet_embedding_fwd(ptr(table), ptr(_i64c(idx)), rows, E, ptr(out), ptr(row_scale), stream_ptr()),
+          "inet_embedding_fwd")
+    return out
+
+
+def embedding_bwd(dout, idx, dtable, row_scale=None):
+    rows = idx.numel()
+    check(_lib.lib().inet_embedding_bwd(ptr(_f32c(dout)), ptr(_i64c(idx)), rows, dtable.shape[1], ptr(dtable),
+                                        ptr(row_scale), stream_ptr()), "inet_embedding_bwd")
+
+
+def relu_bwd(dy, y):
+    out = torch.empty_like(dy)
+    check(_lib.lib().inet_relu_bwd(ptr(_f32c(dy)), ptr(_f32c(y)), ptr(out), dy.numel(), stream_ptr()), "inet_relu_bwd")
+    return out
+
+
+def argmax_rows(w2d, out=None):
+    rows, V = w2d.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=w2d.device)
+    check(_lib.lib().inet_argmax(ptr(w2d), w2d.stride(0), rows, V, ptr(out), 1, stream_ptr()), "inet_argmax")
+    return out
+
+
 def gru_step(gi, h_prev, W_hh, b_hh, save=False):
     B, H = h_prev.shape
     h_new = torch.empty_like(h_prev)

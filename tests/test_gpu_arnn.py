@@ -1,0 +1,160 @@
+"""GPU parity of the AnticipationRNN (BASELINE config 5) against golden vectors captured
+from the reference's ConstraintModelGaussianReg + AnticipationRNNGaussianRegTrainer, and against the oracle's autograd
+for the free-running path (whose backward the reference cannot run on CPU under torch 2.x)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from inpaintnet_amd import ops, synthetic
+    from inpaintnet_amd.arnn import AnticipationRNNGaussianRegTrainer, ConstraintModelGaussianReg
+
+
+def build(name):
+    c = G.ARNN_CFGS[name]
+    ds = synthetic.SyntheticFolkDataset(num_notes=c["V"])
+    ds.metadatas = [types.SimpleNamespace(num_values=6), types.SimpleNamespace(num_values=6)]
+    model = ConstraintModelGaussianReg(ds, note_embedding_dim=c["E"], metadata_embedding_dim=c["Em"],
+                                       num_lstm_constraints_units=c["H"], num_lstm_generation_units=c["H"],
+                                       linear_hidden_size=c["LH"], num_layers=2, dropout_input_prob=0.0,
+                                       dropout_prob=0.0, unary_constraint=True, teacher_forcing=True)
+    model.load_state_dict(G.arnn_params(name))
+    return ds, model
+
+
+def test_lstm_layer_kernel_vs_oracle():
+    g = torch.Generator().manual_seed(4)
+    for (B, T, K, H, rev) in [(3, 5, 6, 16, False), (33, 7, 20, 32, True), (32, 12, 266, 256, False)]:
+        P = {"l.weight_ih_l0": torch.randn(4 * H, K, generator=g) * 0.2, "l.weight_hh_l0": torch.randn(4 * H, H, generator=g) * 0.2,
+             "l.bias_ih_l0": torch.randn(4 * H, generator=g) * 0.1, "l.bias_hh_l0": torch.randn(4 * H, generator=g) * 0.1}
+        for p in P.values():
+            p.requires_grad_(True)
+        x = torch.randn(B, T, K, generator=g).requires_grad_(True)
+        h0 = torch.randn(B, H, generator=g).requires_grad_(True)
+        c0 = torch.randn(B, H, generator=g).requires_grad_(True)
+        out, (hT, cT) = O.lstm_layer(x, h0, c0, P, "l", reverse=rev)
+        wo = torch.randn(B, T, H, generator=g)
+        wh, wc = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+        ((out * wo).sum() + (hT * wh).sum() + (cT * wc).sum()).backward()
+        d = {k: v.detach().cuda() for k, v in P.items()}
+        x_tm = x.detach().permute(1, 0, 2).contiguous().cuda()
+        gi = ops.linear_fwd(x_tm.view(T * B, K), d["l.weight_ih_l0"], d["l.bias_ih_l0"]).view(T, B, 4 * H)
+        o, h, c, ws = ops.lstm_fwd(gi, d["l.weight_hh_l0"], d["l.bias_hh_l0"], H, reverse=rev, h0=h0.detach().cuda(),
+                                   c0=c0.detach().cuda(), save=True, want_state=True)
+        assert G.rel_err(o.permute(1, 0, 2).cpu(), out.detach()) < 5e-5
+        assert G.rel_err(h.cpu(), hT.detach()) < 5e-5 and G.rel_err(c.cpu(), cT.detach()) < 5e-5
+        dW = torch.zeros(4 * H, H, device="cuda"); dbi = torch.zeros(4 * H, device="cuda"); dbh = torch.zeros(4 * H, device="cuda")
+        dgi, dh0, dc0 = ops.lstm_bwd(d["l.weight_hh_l0"], o, wo.permute(1, 0, 2).contiguous().cuda(), H, rev, ws, dW, dbi, dbh,
+                                     h0=h0.detach().cuda(), dhT=wh.cuda(), dcT=wc.cuda(), want_dstate=True)
+        torch.cuda.synchronize()
+        assert G.rel_err(dW.cpu(), P["l.weight_hh_l0"].grad) < 5e-4
+        assert G.rel_err(dbh.cpu(), P["l.bias_hh_l0"].grad) < 5e-4 and G.rel_err(dbi.cpu(), P["l.bias_ih_l0"].grad) < 5e-4
+        assert G.rel_err(dh0.cpu(), h0.grad) < 5e-4 and G.rel_err(dc0.cpu(), c0.grad) < 5e-4
+        dx = ops.linear_bwd(dgi.view(T * B, 4 * H), x_tm.view(T * B, K), d["l.weight_ih_l0"], need_dx=True)
+        assert G.rel_err(dx.view(T, B, K).permute(1, 0, 2).cpu(), x.grad) < 5e-4
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_arnn_teacher_forced_step_golden(name):
+    fx = G.load("arnn_" + name)
+    ds, model = build(name)
+    trainer = AnticipationRNNGaussianRegTrainer(ds, model, lr=1e-4)
+    model.train()
+    score = torch.from_numpy(fx["score"]).cuda()
+    md = torch.from_numpy(fx["metadata"]).cuda()
+    loc = torch.from_numpy(fx["constraints_loc"]).cuda()
+    a, b = [int(x) for x in fx["ticks"]]
+    with torch.no_grad():
+        w_all, _ = model._forward_tf(score, md, loc)
+    assert w_all[0].shape == fx["tf_weights_all"].shape
+    assert G.rel_err(w_all[0].cpu(), fx["tf_weights_all"]) < 1e-4
+    trainer.zero_grad()
+    weights, _ = model(score, md, loc, a, b, train=True, teacher_forcing=True)
+    assert weights[0].shape == (score.shape[0], b - a, G.ARNN_CFGS[name]["V"])
+    targets = score[:, :, a:b].transpose(0, 1)
+    loss, acc = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, targets)
+    loss.backward()
+    assert abs(float(loss.detach()) - fx["tf_loss_acc"][0]) < 1e-4 * abs(fx["tf_loss_acc"][0])
+    assert abs(float(acc) - fx["tf_loss_acc"][1]) < 1e-6
+    bad = []
+    for k, _ in model.named_parameters():
+        g = model.param_grad(k).cpu().numpy()
+        if name == "small":
+            key = "tf_grad/" + k
+            ref = fx[key] if key in fx.files else np.zeros_like(g)
+            err = np.abs(g - ref).max() / (np.abs(ref).max() + 1e-7)
+        else:
+            key = "tf_gradnorm/" + k
+            rn = float(fx[key]) if key in fx.files else 0.0
+            err = abs(float(np.sqrt((g.astype(np.float64) ** 2).sum())) - rn) / (rn + 1e-9)
+        if not err < 1e-3:
+            bad.append((k, float(err)))
+    assert not bad, bad
+    trainer.step()
+    for k, _ in model.named_parameters():
+        v = model.param(k).cpu().numpy()
+        if name == "small":
+            assert np.abs(v - fx["tf_after1/" + k]).max() < 1e-5, k
+        else:
+            assert np.abs(v.reshape(-1)[:64] - fx["tf_after1head/" + k]).max() < 1e-5, k
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_arnn_free_running_forward_golden(name):
+    fx = G.load("arnn_" + name)
+    ds, model = build(name)
+    model.train()
+    score = torch.from_numpy(fx["score"]).cuda()
+    md = torch.from_numpy(fx["metadata"]).cuda()
+    loc = torch.from_numpy(fx["constraints_loc"]).cuda()
+    a, b = [int(x) for x in fx["ticks"]]
+    with torch.no_grad():
+        weights, gen = model(score, md, loc, a, b, train=True, teacher_forcing=False)
+    ok = fx["fr_margin_row0"] > 1e-4
+    first_bad = int(np.argmin(ok)) if not ok.all() else len(ok)
+    assert gen.shape == fx["fr_gen"].shape
+    assert np.array_equal(gen.cpu().numpy()[:, 0, :first_bad], fx["fr_gen"][:, 0, :first_bad])
+    if first_bad == len(ok):
+        assert G.rel_err(weights[0].cpu(), fx["fr_weights_free"]) < 2e-4
+
+
+def test_arnn_free_running_backward_vs_oracle():
+    """The reference trains through this path on GPU; its backward cannot run on CPU (in-place on a saved view), so
+    the gradient check is against the oracle's autograd over the same arithmetic."""
+    name = "small"
+    fx = G.load("arnn_" + name)
+    ds, model = build(name)
+    model.train()
+    L = 48                                                       # a shorter window keeps the CPU side quick
+    score = torch.from_numpy(fx["score"])[:, :, :L]
+    md = torch.from_numpy(fx["metadata"])[:, :, :L]
+    loc = torch.zeros_like(score)
+    loc[:, :, :12] = 1
+    loc[:, :, 36:] = 1
+    P = G.arnn_params(name)
+    for p in P.values():
+        p.requires_grad_(True)
+    w_all, gen = O.arnn_forward(P, score, md, loc, teacher_forcing=False)
+    loss, acc = O.arnn_loss(w_all[:, 12:36], score[:, 0, 12:36])
+    loss.backward()
+    model.zero_grad()
+    weights, g2 = model(score.cuda(), md.cuda(), loc.cuda(), train=True, teacher_forcing=False)
+    trainer = AnticipationRNNGaussianRegTrainer(ds, model)
+    l2, a2 = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, score.cuda()[:, :, 12:36].transpose(0, 1))
+    l2.backward()
+    if np.array_equal(g2.cpu().numpy()[:, 0], gen.numpy()):
+        assert abs(float(l2.detach()) - loss.item()) < 1e-4 * abs(loss.item())
+        bad = []
+        for k in P:
+            gr = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+            err = float((model.param_grad(k).cpu() - gr).abs().max() / (gr.abs().max() + 1e-7))
+            if not err < 2e-3:
+                bad.append((k, err))
+        assert not bad, bad
