@@ -95,6 +95,47 @@ def latent_rnn_extra(ds, vae, dev, batch=128, steps=10, warmup=3):
                                              "past/target/future 6/4/6, dropout 0.5"}}
 
 
+def arnn_extra(batch=32, steps=8, warmup=2):
+    """Secondary number (BASELINE.json configs[4]): AnticipationRNN gauss-reg model, teacher-forced training step,
+    batch 32 sequences of 384 ticks, script defaults of train_arnn_reg.py.  Not the headline metric."""
+    import types
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.arnn import AnticipationRNNGaussianRegTrainer, ConstraintModelGaussianReg
+    ds = synthetic.SyntheticFolkDataset(num_notes=NUM_NOTES)
+    ds.metadatas = [types.SimpleNamespace(num_values=6), types.SimpleNamespace(num_values=6)]
+    model = ConstraintModelGaussianReg(ds, note_embedding_dim=10, metadata_embedding_dim=2,
+                                       num_lstm_constraints_units=256, num_lstm_generation_units=256,
+                                       linear_hidden_size=256, num_layers=2, dropout_input_prob=0.2, dropout_prob=0.2,
+                                       unary_constraint=True, teacher_forcing=True)
+    trainer = AnticipationRNNGaussianRegTrainer(ds, model, lr=1e-4)
+    model.train()
+    score = torch.from_numpy(synthetic.folk_score(batch, NUM_NOTES, seed=21))
+    md = torch.from_numpy(synthetic.folk_metadata(batch))
+    torch.manual_seed(5)
+    data = trainer.process_batch_data((score, md))
+
+    def step():
+        trainer.zero_grad()
+        weights, _ = model(data[0], data[1], data[2], data[3], data[4], train=True, teacher_forcing=True)
+        free = (data[2][0, 0, :] == 0).nonzero().squeeze(-1)
+        loss, acc = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, data[0][:, :, free].transpose(0, 1))
+        loss.backward()
+        trainer.step()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"anticipation_rnn_train": {"sequences_per_s": round(batch * steps / dt, 1),
+                                       "measures_per_s": round(16 * batch * steps / dt, 1),
+                                       "ms_per_step": round(1e3 * dt / steps, 3),
+                                       "workload": "AnticipationRNN gauss-reg (LSTM 2x2 layers, H=256), teacher-forced "
+                                                   "train step, 32 sequences x 384 ticks"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +230,7 @@ def main():
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = latent_rnn_extra(ds, model, dev)
+        extras.update(arnn_extra())
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
