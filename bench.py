@@ -95,6 +95,30 @@ def latent_rnn_extra(ds, vae, dev, batch=128, steps=10, warmup=3):
                                              "past/target/future 6/4/6, dropout 0.5"}}
 
 
+def decode_latency_extra(vae, iters=20):
+    """Inference-side number for the fused tick decode (SURVEY 8d 'K7'): full HierarchicalDecoder.forward in eval
+    mode (beat GRU + 24 ticks x [layer-0 step, layer-1 step, projection+argmax]) at small batch.  The HBM figure
+    counts the 26.44 MB of decoder weights ONCE per call, as SURVEY.md section 8d prescribes."""
+    out = {}
+    vae.eval()
+    for b in (1, 16, 256):
+        z = torch.randn(b, vae.latent_space_dim, device=vae.flat.device)
+        dummy = torch.zeros(b, 24, device=z.device)
+        with torch.no_grad():
+            for _ in range(3):
+                vae.decoder(z, dummy, train=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                vae.decoder(z, dummy, train=False)
+            torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / iters
+        out[f"b{b}"] = {"ms_per_call": round(ms, 4), "measures_per_s": round(b / ms * 1e3, 1),
+                        "weights_once_GBps": round(26.44e6 / (ms * 1e-3) / 1e9, 2)}
+    vae.train()
+    return {"decoder_eval": out}
+
+
 def arnn_extra(batch=32, steps=8, warmup=2):
     """Secondary number (BASELINE.json configs[4]): AnticipationRNN gauss-reg model, teacher-forced training step,
     batch 32 sequences of 384 ticks, script defaults of train_arnn_reg.py.  Not the headline metric."""
@@ -231,6 +255,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         extras = latent_rnn_extra(ds, model, dev)
         extras.update(arnn_extra())
+        extras.update(decode_latency_extra(model))
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -16,6 +16,7 @@
 #include "seq.h"
 #include "layout.h"
 #include "vae.h"
+#include <cstdlib>
 
 namespace {
 
@@ -140,7 +141,7 @@ struct DecWs {
     float *zsave, *hb0, *gvec0, *beat0, *beat0m, *svb0, *gi1b, *beat_out, *svb1;
     float *ht0, *c_all, *cgi, *table;
     long long* idxV;
-    float *h0seq, *h0m, *svt0, *h1seq, *svt1;
+    float *h0seq, *h0m, *svt0, *h1seq, *svt1, *wtm;
     // backward
     float *whhT[4], *dlg, *dh1top, *dgi1t, *dgh1t, *dhz, *dht0, *dx1t, *dgi0t, *dgh0t, *dcgi, *dc_all, *onehot, *dtable;
     float *dbeat_out, *dgi1b, *dgh1b, *dxb, *dgi0b, *dgh0b, *dhb0, *tmp3h;
@@ -169,6 +170,7 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.svt0 = save ? cv.take<float>(5 * T * BH) : nullptr;
     w.h1seq = cv.take<float>(T * BH);
     w.svt1 = save ? cv.take<float>(5 * T * BH) : nullptr;
+    w.wtm = cv.take<float>(T * B * V);
     if (save) {
         for (int i = 0; i < 4; ++i) w.whhT[i] = cv.take<float>(3 * H * H);
         w.dlg = cv.take<float>(T * B * V);
@@ -251,6 +253,51 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         return -2;
 
     // ---- tick RNN (forward_tick_rnn, decoder.py:473-529) ----
+    static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
+    if (teacher_forced && tf_batch) {
+        // Every input token is known, and the tick GRU's hidden state is re-initialised per beat, so the 4 beats are
+        // independent: 6 steps x 4 problems per layer instead of 24 dependent steps, and ONE output projection.
+        const long as = (long)T * BH;
+        for (int j = 0; j < G; ++j) {
+            GruFwdBatch b0{}, b1{};
+            b0.H = b1.H = H; b0.nprob = b1.nprob = nb;
+            for (int i = 0; i < nb; ++i) {
+                const int t = i * G + j;
+                GruFwdProb& P0 = b0.p[i];
+                P0.B = B;
+                if (j == 0) { P0.h_prev = w.ht0 + (long)i * B * 2 * H; P0.ld_hprev = 2L * H; }
+                else { P0.h_prev = w.h0seq + (long)(t - 1) * BH; P0.ld_hprev = H; }
+                P0.W_hh = p + L.tick[0].w_hh; P0.b_hh = p + L.tick[0].b_hh;
+                P0.gi_dense = w.cgi + (long)i * B * 3 * H; P0.ld_gi = 3L * H;
+                P0.gi_table = w.table; P0.ld_table = 3L * H;
+                if (t == 0) { P0.idx = w.idxV; P0.idx_stride = 1; }
+                else { P0.idx = samples + (t - 1); P0.idx_stride = T; }
+                P0.h_new = w.h0seq + (long)t * BH; P0.ld_hnew = H;
+                if (mask_tick) { P0.h_masked = w.h0m + (long)t * BH; P0.ld_hm = H; P0.mask = mask_tick + (long)t * BH; P0.ld_mask = H; }
+                if (save) {
+                    float* q = w.svt0 + (long)t * BH;
+                    P0.sv_r = q; P0.sv_z = q + as; P0.sv_n = q + 2 * as; P0.sv_ghn = q + 3 * as; P0.sv_hprev = q + 4 * as;
+                }
+                GruFwdProb& P1 = b1.p[i];
+                P1.B = B;
+                if (j == 0) { P1.h_prev = w.ht0 + (long)i * B * 2 * H + H; P1.ld_hprev = 2L * H; }
+                else { P1.h_prev = w.h1seq + (long)(t - 1) * BH; P1.ld_hprev = H; }
+                P1.W_hh = p + L.tick[1].w_hh; P1.b_hh = p + L.tick[1].b_hh;
+                P1.x = (mask_tick ? w.h0m : w.h0seq) + (long)t * BH; P1.ldx = H; P1.K2 = H;
+                P1.W_ih = p + L.tick[1].w_ih; P1.ld_wih = H; P1.b_ih = p + L.tick[1].b_ih;
+                P1.h_new = w.h1seq + (long)t * BH; P1.ld_hnew = H;
+                if (save) {
+                    float* q = w.svt1 + (long)t * BH;
+                    P1.sv_r = q; P1.sv_z = q + as; P1.sv_n = q + 2 * as; P1.sv_ghn = q + 3 * as; P1.sv_hprev = q + 4 * as;
+                }
+            }
+            INET_TRY(launch_gru_fwd(b0, s));
+            INET_TRY(launch_gru_fwd(b1, s));
+        }
+        INET_TRY(linear_fwd(w.h1seq, H, p + L.out_w, H, p + L.out_b, w.wtm, V, T * B, V, H, EPI_RELU, s));
+        INET_TRY(pw_swap01(w.wtm, T, B, V, weights, s));             // [T,B,V] -> [B,T,V]
+        return 0;
+    }
     for (int t = 0; t < T; ++t) {
         const int i = t / G, j = t % G;
         GruFwdBatch b0{};

@@ -10,8 +10,13 @@ struct __attribute__((packed, aligned(4))) f4u_t { float x, y, z, w; };
 __device__ __forceinline__ f32x4 ld4u(const float* p) { f4u_t v = *reinterpret_cast<const f4u_t*>(p); return f32x4{v.x, v.y, v.z, v.w}; }
 #ifdef USE_LD4U
 #define LD(p) ld4u(p)
+#elif defined(USE_NT)
+#define LD(p) __builtin_nontemporal_load((const f32x4*)(p))
 #else
 #define LD(p) (*(const f32x4*)(p))
+#endif
+#ifndef NW
+#define NW 4
 #endif
 #ifdef USE_CLAMP
 #define ROW(r) min((r), B - 1)
@@ -20,10 +25,10 @@ __device__ __forceinline__ f32x4 ld4u(const float* p) { f4u_t v = *reinterpret_c
 #endif
 
 template <int VAR>
-__global__ __launch_bounds__(256) void step(const float* __restrict__ hp, const float* __restrict__ W,
+__global__ __launch_bounds__(64 * NW) void step(const float* __restrict__ hp, const float* __restrict__ W,
                                             const float* __restrict__ gi, const float* __restrict__ bh,
                                             float* __restrict__ hn, int B, int H, float* __restrict__ sv) {
-    __shared__ float red[4 * 4 * 512];
+    __shared__ float red[NW * 4 * 512];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int i16 = lane & 15, q = lane >> 4;
@@ -31,12 +36,13 @@ __global__ __launch_bounds__(256) void step(const float* __restrict__ hp, const 
     if (VAR == 4) { if (t == 0 && hp == nullptr) hn[0] = 0.f; return; }
     f32x4 acc[2][3];
     for (int a = 0; a < 2; ++a) for (int g = 0; g < 3; ++g) acc[a][g] = f32x4{0, 0, 0, 0};
-    const int Sq = (H / 16) / 4;
+    const int Sq = (H / 16) / NW;
     const int s0 = w * Sq;
-    f32x4 fa[8][2], fb[8][3];
+    constexpr int ND = 32 / NW;
+    f32x4 fa[ND][2], fb[ND][3];
     if (VAR != 3) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
+        for (int d = 0; d < ND; ++d) {
 #ifdef LINE128
             const int k = 32 * ((s0 + d) >> 1) + 8 * q + 4 * ((s0 + d) & 1);   // 4 lanes of a row cover one 128-B line per pair of steps
 #else
@@ -49,14 +55,14 @@ __global__ __launch_bounds__(256) void step(const float* __restrict__ hp, const 
         }
     } else {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
+        for (int d = 0; d < ND; ++d) {
             for (int ms = 0; ms < 2; ++ms) fa[d][ms] = f32x4{1.f * lane, 2.f, 3.f, 4.f};
             for (int g = 0; g < 3; ++g) fb[d][g] = f32x4{1.f, 2.f * d, 3.f, 4.f};
         }
     }
     if (VAR != 2) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d)
+        for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void step(const float* __restrict__ hp, const 
                         acc[ms][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[d][ms][e], fb[d][g][e], acc[ms][g], 0, 0, 0);
     } else {
 #pragma unroll
-        for (int d = 0; d < 8; ++d)
+        for (int d = 0; d < ND; ++d)
             for (int ms = 0; ms < 2; ++ms)
                 for (int g = 0; g < 3; ++g) acc[ms][g] += fa[d][ms] + fb[d][g];
     }
@@ -77,13 +83,13 @@ __global__ __launch_bounds__(256) void step(const float* __restrict__ hp, const 
                 red[(w * 4 + a) * 512 + row * 16 + (lane & 15)] = acc[ms][a][r];
             }
     __syncthreads();
-    for (int p = 0; p < 2; ++p) {
-        const int pos = t + 256 * p;
+    for (int p = 0; p < 512 / (64 * NW); ++p) {
+        const int pos = t + 64 * NW * p;
         const int b = row0 + (pos >> 4), j = j0 + (pos & 15);
         float v[3];
         for (int a = 0; a < 3; ++a) {
             float s = 0;
-            for (int ww = 0; ww < 4; ++ww) s += red[(ww * 4 + a) * 512 + pos];
+            for (int ww = 0; ww < NW; ++ww) s += red[(ww * 4 + a) * 512 + pos];
             v[a] = s;
         }
         if (VAR == 0 || VAR >= 5) {
@@ -108,9 +114,9 @@ float run(const float* hp, const float* W, const float* gi, const float* bh, flo
     dim3 grid(H / 16, B / 32);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(step<VAR>, grid, dim3(256), 0, 0, hp, W, gi, bh, h2, B, H, sv);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(step<VAR>, grid, dim3(64 * NW), 0, 0, hp, W, gi, bh, h2, B, H, sv);
     hipEventRecord(a, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(step<VAR>, grid, dim3(256), 0, 0, hp, W, gi, bh, h2, B, H, sv);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(step<VAR>, grid, dim3(64 * NW), 0, 0, hp, W, gi, bh, h2, B, H, sv);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
@@ -126,7 +132,7 @@ float run_chain(float* hA, float* hB, const float* W, const float* gi_all, const
     for (int it = 0; it < iters; ++it)
         for (int t = 0; t < T; ++t) {
             float* src = (t & 1) ? hB : hA; float* dst = (t & 1) ? hA : hB;
-            hipLaunchKernelGGL(step<5>, grid, dim3(256), 0, 0, src, W, gi_all + (size_t)t * B * 3 * H, bh, dst, B, H,
+            hipLaunchKernelGGL(step<5>, grid, dim3(64 * NW), 0, 0, src, W, gi_all + (size_t)t * B * 3 * H, bh, dst, B, H,
                                sv_all + (size_t)t * 5 * B * H);
         }
     hipEventRecord(b, 0);
