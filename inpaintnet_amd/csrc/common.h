@@ -22,15 +22,11 @@ __device__ __forceinline__ void st4u(float* p, f32x4 v) {
     *reinterpret_cast<f4u_t*>(p) = s;
 }
 
-// Pull a kernarg sub-struct through the scalar cache in ONE batch of s_loads at kernel entry.  hipcc sinks every
-// `args.field` read to its first use, so an epilogue that touches a dozen pointers pays a dozen dependent
-// kernarg round trips (L2/HBM misses: a fresh kernarg block per launch) -- measured ~3.5 us on the 11 us GRU step.
-__device__ __forceinline__ void warm_kernarg(const void* p, int bytes) {
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-    unsigned long long acc = 0;
-    for (int i = 0; i < bytes / 8; ++i) acc ^= q[i];
-    asm volatile("" ::"s"(acc));
-}
+// NOTE on kernarg structs: never read a by-value kernel-argument struct through a type-punned pointer (an earlier
+// "warm the kernarg with one batch of s_loads" helper did).  It defeats the compiler's proof that pointers stored in
+// kernel arguments are global: every access through them becomes flat_load/flat_store, flat operations tick both
+// vmcnt and lgkmcnt, and the waits degrade to vmcnt(0) lgkmcnt(0) -- a two-deep load pipeline silently becomes
+// load -> drain -> compute (profiles/r01_f).
 
 #define SELU_ALPHA 1.6732632423543772f
 #define SELU_SCALE 1.0507009873554805f
@@ -87,6 +83,13 @@ struct GruFwdProb {
     float* h_copy; long ld_hc;                // optional second plain copy of h_new
     // saved for backward (all [B,H], row stride H), or null
     float* sv_r; float* sv_z; float* sv_n; float* sv_ghn; float* sv_hprev;
+    // Fragment-major ("packed", ksplit.h) twins of the contraction operands.  When hpk_prev and Wpk_hh (and, with x,
+    // xpk and Wpk_ih) are given for EVERY problem of a launch the contraction streams those instead of the row-major
+    // ones (which must still be valid: the epilogue reads h_prev).  Requires H % 256 == 0 (and K2 % 256 == 0).
+    const float* hpk_prev; const float* Wpk_hh;   // [ceil(B/16)][H/16][64][4], [3H/16][H/16][64][4]
+    const float* xpk; const float* Wpk_ih;        // [ceil(B/16)][K2/16][64][4], [3H/16][K2/16][64][4]
+    float* hpk_new;                               // optional packed copy of h_new (the next step's hpk_prev)
+    float* hmpk_new;                              // optional packed copy of h_masked (the next layer's xpk)
 };
 struct GruFwdBatch { int H; int nprob; int tiles_per_prob; GruFwdProb p[4]; };
 
@@ -106,6 +109,9 @@ struct GruBwdProb {
     float* db_ih; float* db_hh;               // [3H] bias gradients, accumulated with atomics (or null)
     float* dh_out; long ld_dhout;             // [B,H] (only when no pointwise part): gradient wrt the initial hidden
     int dh_out_accumulate;
+    // fragment-major twins (see GruFwdProb): used when given for every problem that has a recurrent term; H % 256 == 0
+    const float* dghpk_next; const float* Wpk_hhT;   // [ceil(B/16)][3H/16][64][4], [H/16][3H/16][64][4]
+    float* dghpk;                                    // optional packed copy of dgh (the next step's dghpk_next)
 };
 struct GruBwdBatch { int H; int nprob; int tiles_per_prob; GruBwdProb p[4]; };
 

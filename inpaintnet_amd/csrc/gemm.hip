@@ -132,7 +132,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int STAGE = TA::WORDS + TB::WORDS;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
-    warm_kernarg(&g, sizeof(GemmArgs));
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;

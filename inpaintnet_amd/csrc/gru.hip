@@ -36,18 +36,46 @@ namespace {
 
 using namespace ksplit;
 
+// Optional in-kernel phase stamps (build with -DINET_STEP_TRACE; tools/trace_steps.py).  Not part of the product build.
+#ifdef INET_STEP_TRACE
+__device__ unsigned long long* g_trace = nullptr;   // [0] = slot counter, records of 8 x u64 from [8]
+#define TRACE_DECL unsigned long long tr_[4] = {0, 0, 0, 0}, tc_[4] = {0, 0, 0, 0}
+#define TRACE(i) do { if (threadIdx.x == 0) { tr_[i] = wall_clock64(); tc_[i] = clock64(); } } while (0)
+#define TRACE_END(kind, ms)                                                                           \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && g_trace) {                                                            \
+            const unsigned long long sl = atomicAdd(g_trace, 1ull);                                   \
+            if (sl < 400000ull) {                                                                     \
+                unsigned long long* r = g_trace + 8 + sl * 8;                                         \
+                r[0] = tr_[0]; r[1] = tr_[1]; r[2] = tr_[2]; r[3] = tr_[3];                           \
+                r[4] = (unsigned long long)blockIdx.x | ((unsigned long long)blockIdx.y << 16) |      \
+                       ((unsigned long long)(kind) << 32) | ((unsigned long long)(ms) << 40) |        \
+                       ((unsigned long long)gridDim.y << 48);                                         \
+                r[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |       \
+                       __builtin_amdgcn_s_getreg((31 << 11) | 4);                                     \
+                r[6] = tc_[1] - tc_[0]; r[7] = tc_[3] - tc_[0];                                       \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+#else
+#define TRACE_DECL
+#define TRACE(i)
+#define TRACE_END(kind, ms)
+#endif
+
 // Row tiles are numbered over the concatenated problems: blockIdx.y = problem * tiles_per_prob + tile.
-template <bool HAS_X, int MS>
+template <bool HAS_X, int MS, bool PK>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 4 * MS * 256];
     const int prob = blockIdx.y / bt.tiles_per_prob;
     const GruFwdProb& P = bt.p[prob];
-    warm_kernarg(&P, sizeof(GruFwdProb));
     const int H = bt.H;
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * TH;
     const int row0 = (blockIdx.y % bt.tiles_per_prob) * (16 * MS);
     if (row0 >= P.B) return;
+    TRACE_DECL;
+    TRACE(0);
 
     f32x4 acc[MS][4];
 #pragma unroll
@@ -55,48 +83,84 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue operands are requested inside the contraction, right after its first group of fragment loads (ksplit.h:
+    // after_first_loads), so their latency hides under the MFMA phase.  Requested after the reduce they cost one
+    // exposed round trip per row group (4.5 of 15.6 us at MS=4, profiles/r01_f).  Rows past the batch are clamped; their
+    // results are never stored.  No arithmetic on the values up there: an add would pull a wait in front of the MFMAs.
+    const int jc = j0 + (t & 15);
+    long tok[MS];
+    float pre_gd[MS][3], pre_gt[MS][3], pre_hp[MS], pre_mask[MS];
+    float pb_hh[3], pb_ih[3] = {0.f, 0.f, 0.f}, pb_v[3] = {0.f, 0.f, 0.f};
+    if (P.gi_table) {                    // the gather needs the token first: that one dependent load goes up front
+#pragma unroll
+        for (int p = 0; p < MS; ++p) tok[p] = P.idx[(long)min(row0 + ((t + 256 * p) >> 4), P.B - 1) * P.idx_stride];
+    }
+    auto prefetch = [&]() {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) pb_hh[g] = P.b_hh[g * H + jc];
+        if (HAS_X && P.b_ih) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pb_ih[g] = P.b_ih[g * H + jc];
+        }
+        if (P.gi_vec) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pb_v[g] = P.gi_vec[g * H + jc];
+        }
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pre_gd[p][g] = P.gi_dense ? P.gi_dense[(long)b * P.ld_gi + g * H + jc] : 0.f;
+            // packed: the same lines the contraction streams (the row-major twin would be a second cold read)
+            pre_hp[p] = PK ? P.hpk_prev[pk_offset(b, jc, H >> 4)] : P.h_prev[(long)b * P.ld_hprev + jc];
+            pre_mask[p] = (P.h_masked && P.mask) ? P.mask[(long)b * P.ld_mask + jc] : 1.f;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pre_gt[p][g] = P.gi_table ? P.gi_table[tok[p] * P.ld_table + g * H + jc] : 0.f;
+        }
+    };
+
     const int brow[3] = {j0, H + j0, 2 * H + j0};
     if (HAS_X) {
         const int slotx[3] = {0, 1, 2};          // r, z, gi_n
-        ksplit_segment<MS, 3>(acc, slotx, P.x, P.ldx, row0, P.B, P.W_ih, P.ld_wih, brow, P.K2, t);
+        if (PK) ksplit_segment<MS, 3, true>(acc, slotx, P.xpk, 0, row0, P.B, P.Wpk_ih, 0, brow, P.K2, t);
+        else ksplit_segment<MS, 3>(acc, slotx, P.x, P.ldx, row0, P.B, P.W_ih, P.ld_wih, brow, P.K2, t);
     }
     const int sloth[3] = {0, 1, 3};              // r, z, gh_n
-    ksplit_segment<MS, 3>(acc, sloth, P.h_prev, P.ld_hprev, row0, P.B, P.W_hh, (long)H, brow, H, t);
+    if (PK) ksplit_segment<MS, 3, true>(acc, sloth, P.hpk_prev, 0, row0, P.B, P.Wpk_hh, 0, brow, H, t, prefetch);
+    else ksplit_segment<MS, 3>(acc, sloth, P.h_prev, P.ld_hprev, row0, P.B, P.W_hh, (long)H, brow, H, t, prefetch);
 
+    TRACE(1);
     float v[MS][4];
     reduce_waves<MS, 4>(acc, lds, t, v);
+    TRACE(2);
 
 #pragma unroll
     for (int p = 0; p < MS; ++p) {
         const int pos = t + 256 * p;
         const int b = row0 + (pos >> 4);
-        const int j = j0 + (pos & 15);
+        const int j = jc;
         if (b >= P.B) continue;
-        float gr = v[p][0], gz = v[p][1], gn = v[p][2], ghn = v[p][3];
-        if (HAS_X && P.b_ih) { gr += P.b_ih[j]; gz += P.b_ih[H + j]; gn += P.b_ih[2 * H + j]; }
-        if (P.gi_dense) {
-            const float* gp = P.gi_dense + (long)b * P.ld_gi;
-            gr += gp[j]; gz += gp[H + j]; gn += gp[2 * H + j];
-        }
-        if (P.gi_table) {
-            const float* gp = P.gi_table + (long)P.idx[(long)b * P.idx_stride] * P.ld_table;
-            gr += gp[j]; gz += gp[H + j]; gn += gp[2 * H + j];
-        }
-        if (P.gi_vec) { gr += P.gi_vec[j]; gz += P.gi_vec[H + j]; gn += P.gi_vec[2 * H + j]; }
-        gr += P.b_hh[j]; gz += P.b_hh[H + j]; ghn += P.b_hh[2 * H + j];
+        const float gr = v[p][0] + pb_ih[0] + pre_gd[p][0] + pre_gt[p][0] + pb_v[0] + pb_hh[0];
+        const float gz = v[p][1] + pb_ih[1] + pre_gd[p][1] + pre_gt[p][1] + pb_v[1] + pb_hh[1];
+        const float gn = v[p][2] + pb_ih[2] + pre_gd[p][2] + pre_gt[p][2] + pb_v[2];
+        const float ghn = v[p][3] + pb_hh[2];
         const float r = sigmoid_f(gr);
         const float z = sigmoid_f(gz);
         const float n = tanh_f(gn + r * ghn);
-        const float hp = P.h_prev[(long)b * P.ld_hprev + j];
+        const float hp = pre_hp[p];
         const float hn = (1.f - z) * n + z * hp;
         P.h_new[(long)b * P.ld_hnew + j] = hn;
         if (P.h_copy) P.h_copy[(long)b * P.ld_hc + j] = hn;
-        if (P.h_masked) P.h_masked[(long)b * P.ld_hm + j] = P.mask ? hn * P.mask[(long)b * P.ld_mask + j] : hn;
+        if (P.h_masked) P.h_masked[(long)b * P.ld_hm + j] = hn * pre_mask[p];
+        if (P.hpk_new) P.hpk_new[pk_offset(b, j, H >> 4)] = hn;
+        if (P.hmpk_new) P.hmpk_new[pk_offset(b, j, H >> 4)] = hn * pre_mask[p];
         if (P.sv_r) {
             const long o = (long)b * H + j;
             P.sv_r[o] = r; P.sv_z[o] = z; P.sv_n[o] = n; P.sv_ghn[o] = ghn; P.sv_hprev[o] = hp;
         }
     }
+    TRACE(3);
+    TRACE_END(HAS_X ? 1 : 0, MS);
 }
 
 // Backward of one step.
@@ -105,17 +169,40 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 //   dn_pre = dn (1-n^2); dz_pre = dz z(1-z); dr_pre = dn_pre ghn r(1-r)
 //   dgi = [dr_pre, dz_pre, dn_pre]      dgh = [dr_pre, dz_pre, dn_pre r]
 //   db_ih += colsum(dgi) ; db_hh += colsum(dgh)               (tile-reduced, one atomic per column per workgroup)
-template <int MS>
+template <int MS, bool PK>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
     __shared__ __attribute__((aligned(16))) float lds[(4 * MS * 256 > 1024) ? 4 * MS * 256 : 1024];
     const int prob = blockIdx.y / bt.tiles_per_prob;
     const GruBwdProb& P = bt.p[prob];
-    warm_kernarg(&P, sizeof(GruBwdProb));
     const int H = bt.H;
     const int t = threadIdx.x;
     const int j0 = blockIdx.x * TH;
     const int row0 = (blockIdx.y % bt.tiles_per_prob) * (16 * MS);
     if (row0 >= P.B) return;
+    TRACE_DECL;
+    TRACE(0);
+
+    // Epilogue operands first: direct gradient terms and the saved gates of this step.  (K = 3H runs as several load
+    // groups here; requested between the groups these 8*MS cold loads would stall the later fragment groups behind
+    // them -- 16.5 vs 13.9 us at MS=4 -- so unlike the forward kernel they go in front.)
+    const int jc = j0 + (t & 15);
+    float pd[MS][3], psv[MS][5];
+#pragma unroll
+    for (int p = 0; p < MS; ++p) {
+        const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
+        const long o = (long)b * H + jc;
+        pd[p][0] = P.dhz_next ? P.dhz_next[o] : 0.f;
+        pd[p][1] = P.dout ? P.dout[(long)b * P.ld_dout + jc] : 0.f;
+        pd[p][2] = P.dout2 ? P.dout2[(long)b * P.ld_dout2 + jc] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) psv[p][a] = 0.f;
+        if (P.sv_r) {
+            psv[p][0] = P.sv_r[o]; psv[p][1] = P.sv_z[o]; psv[p][2] = P.sv_n[o]; psv[p][3] = P.sv_ghn[o];
+            psv[p][4] = P.sv_hprev[o];
+        } else if (P.dh_out_accumulate) {
+            psv[p][0] = P.dh_out[(long)b * P.ld_dhout + jc];
+        }
+    }
 
     float v[MS][1];
 #pragma unroll
@@ -128,27 +215,26 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int brow[1] = {j0};
         const int slot[1] = {0};
-        ksplit_segment<MS, 1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t);
+        if (PK) ksplit_segment<MS, 1, true>(acc, slot, P.dghpk_next, 0, row0, P.B, P.Wpk_hhT, 0, brow, 3 * H, t);
+        else ksplit_segment<MS, 1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t);
+        TRACE(1);
         reduce_waves<MS, 1>(acc, lds, t, v);
     }
+    TRACE(2);
     float bs[4] = {0.f, 0.f, 0.f, 0.f};            // this thread's column partials: dr, dz, dn, dn*r
 #pragma unroll
     for (int p = 0; p < MS; ++p) {
         const int pos = t + 256 * p;
         const int b = row0 + (pos >> 4);
-        const int j = j0 + (pos & 15);
+        const int j = jc;
         if (b >= P.B) continue;
         const long o = (long)b * H + j;
-        float dh = v[p][0];
-        if (P.dhz_next) dh += P.dhz_next[o];
-        if (P.dout) dh += P.dout[(long)b * P.ld_dout + j];
-        if (P.dout2) dh += P.dout2[(long)b * P.ld_dout2 + j];
+        const float dh = v[p][0] + pd[p][0] + pd[p][1] + pd[p][2];
         if (!P.sv_r) {
-            float* d = P.dh_out + (long)b * P.ld_dhout + j;
-            *d = P.dh_out_accumulate ? *d + dh : dh;
+            P.dh_out[(long)b * P.ld_dhout + j] = P.dh_out_accumulate ? psv[p][0] + dh : dh;
             continue;
         }
-        const float r = P.sv_r[o], z = P.sv_z[o], n = P.sv_n[o], ghn = P.sv_ghn[o], hp = P.sv_hprev[o];
+        const float r = psv[p][0], z = psv[p][1], n = psv[p][2], ghn = psv[p][3], hp = psv[p][4];
         const float dn_pre = dh * (1.f - z) * (1.f - n * n);
         const float dz_pre = dh * (hp - n) * z * (1.f - z);
         const float dr_pre = dn_pre * ghn * r * (1.f - r);
@@ -157,6 +243,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
         gi[j] = dr_pre; gi[H + j] = dz_pre; gi[2 * H + j] = dn_pre;
         float* gh = P.dgh + (long)b * P.ld_dghout;
         gh[j] = dr_pre; gh[H + j] = dz_pre; gh[2 * H + j] = dn_pre * r;
+        if (P.dghpk) {
+            const int S3 = (3 * H) >> 4;
+            P.dghpk[pk_offset(b, j, S3)] = dr_pre;
+            P.dghpk[pk_offset(b, H + j, S3)] = dz_pre;
+            P.dghpk[pk_offset(b, 2 * H + j, S3)] = dn_pre * r;
+        }
         bs[0] += dr_pre; bs[1] += dz_pre; bs[2] += dn_pre; bs[3] += dn_pre * r;
     }
     if (P.sv_r && P.db_ih) {
@@ -177,6 +269,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
             else unsafeAtomicAdd(P.db_hh + 2 * H + j, s);
         }
     }
+    TRACE(3);
+    TRACE_END(2, MS);
 }
 
 // Output projection of one decoder tick, fused: weights[:, t, :] = ReLU(h_top[B,H] x W_out[V,H]^T + b) and the
@@ -243,6 +337,13 @@ int pick_ms(int nprob, int maxB, int H, int ms_max) {
 
 }  // namespace
 
+#ifdef INET_STEP_TRACE
+extern "C" int inet_debug_trace_set(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int launch_gru_fwd(const GruFwdBatch& bin, hipStream_t s) {
     GruFwdBatch b = bin;
     if (b.H % TH != 0 || b.nprob < 1 || b.nprob > 4) return -1;
@@ -259,13 +360,20 @@ int launch_gru_fwd(const GruFwdBatch& bin, hipStream_t s) {
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) fl += 2.0 * b.p[i].B * 3.0 * b.H * (b.H + (hasx ? b.p[i].K2 : 0));
     ProfScope prof(PROF_GRU_FWD, fl, s);
-    if (hasx) {
-        if (ms == 2) hipLaunchKernelGGL((gru_step_fwd_kernel<true, 2>), grid, dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((gru_step_fwd_kernel<true, 4>), grid, dim3(256), 0, s, b);
-    } else {
-        if (ms == 2) hipLaunchKernelGGL((gru_step_fwd_kernel<false, 2>), grid, dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((gru_step_fwd_kernel<false, 4>), grid, dim3(256), 0, s, b);
+    bool pk = b.H % 256 == 0;
+    for (int i = 0; i < b.nprob; ++i) {
+        const GruFwdProb& P = b.p[i];
+        if (!P.hpk_prev || !P.Wpk_hh) pk = false;
+        if (hasx && (!P.xpk || !P.Wpk_ih || P.K2 % 256 != 0)) pk = false;
     }
+#define INET_FWD(X, M)                                                                                       \
+    do {                                                                                                     \
+        if (pk) hipLaunchKernelGGL((gru_step_fwd_kernel<X, M, true>), grid, dim3(256), 0, s, b);             \
+        else hipLaunchKernelGGL((gru_step_fwd_kernel<X, M, false>), grid, dim3(256), 0, s, b);               \
+    } while (0)
+    if (hasx) { if (ms == 2) INET_FWD(true, 2); else INET_FWD(true, 4); }
+    else { if (ms == 2) INET_FWD(false, 2); else INET_FWD(false, 4); }
+#undef INET_FWD
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -281,9 +389,16 @@ int launch_gru_bwd(const GruBwdBatch& bin, hipStream_t s) {
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].dgh_next) fl += 2.0 * b.p[i].B * 3.0 * b.H * b.H;
     ProfScope prof(PROF_GRU_BWD, fl, s);
-    if (ms == 2) hipLaunchKernelGGL(gru_step_bwd_kernel<2>, grid, dim3(256), 0, s, b);
-    else if (ms == 4) hipLaunchKernelGGL(gru_step_bwd_kernel<4>, grid, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL(gru_step_bwd_kernel<8>, grid, dim3(256), 0, s, b);
+    bool pk = b.H % 256 == 0;
+    for (int i = 0; i < b.nprob; ++i)
+        if (b.p[i].dgh_next && (!b.p[i].dghpk_next || !b.p[i].Wpk_hhT)) pk = false;
+#define INET_BWD(M)                                                                                          \
+    do {                                                                                                     \
+        if (pk) hipLaunchKernelGGL((gru_step_bwd_kernel<M, true>), grid, dim3(256), 0, s, b);                \
+        else hipLaunchKernelGGL((gru_step_bwd_kernel<M, false>), grid, dim3(256), 0, s, b);                  \
+    } while (0)
+    if (ms == 2) INET_BWD(2); else if (ms == 4) INET_BWD(4); else INET_BWD(8);
+#undef INET_BWD
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -40,7 +40,6 @@ struct LstmBwdArgs {
 template <int MS>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs P) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 4 * MS * 256];
-    warm_kernarg(&P, sizeof(LstmFwdArgs));
     const int H = P.H, t = threadIdx.x;
     const int j0 = blockIdx.x * TH, row0 = blockIdx.y * (16 * MS);
     f32x4 acc[MS][4];
@@ -82,7 +81,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs P) {
 template <int MS>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs P) {
     __shared__ __attribute__((aligned(16))) float lds[(4 * MS * 256 > 1024) ? 4 * MS * 256 : 1024];
-    warm_kernarg(&P, sizeof(LstmBwdArgs));
     const int H = P.H, t = threadIdx.x;
     const int j0 = blockIdx.x * TH, row0 = blockIdx.y * (16 * MS);
     float v[MS][1];

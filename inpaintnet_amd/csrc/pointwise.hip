@@ -43,6 +43,34 @@ __global__ void transpose_kernel(const float* __restrict__ in, long ld_in, float
     }
 }
 
+// Row-major -> fragment-major (ksplit.h): out[row/16][k/16][lane = ((k%16)/4)*16 + row%16][k%4] = Y(row, k) where
+// Y(row,k) = in[row*ld + k] (transposed = 0) or in[k*ld + row] (transposed = 1).  Rows R..ceil16(R) are zero-filled.
+// One thread per 16-byte lane slot; blockIdx.y = batch entry.
+__global__ void pack_frag_kernel(const float* __restrict__ in, long ld, int R, int K, float* __restrict__ out,
+                                 int transposed, long in_bstride, long out_bstride) {
+    const int S = K >> 4;
+    const long slots = (long)((R + 15) >> 4) * S * 64;
+    in += blockIdx.y * in_bstride;
+    out += blockIdx.y * out_bstride;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long blk = i >> 6;
+        const int sb = (int)(blk % S), rb = (int)(blk / S);
+        const int row = 16 * rb + (lane & 15), k = 16 * sb + 4 * (lane >> 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R) {
+            if (!transposed) {
+                const float* q = in + (long)row * ld + k;
+                v = make_float4(q[0], q[1], q[2], q[3]);
+            } else {
+                const float* q = in + (long)k * ld + row;
+                v = make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]);
+            }
+        }
+        *reinterpret_cast<float4*>(out + 4 * i) = v;
+    }
+}
+
 // One wavefront per row of V logits.  loss_sum += lse - w[target];
 // correct += (argmax_first(w) == target); dW = (softmax - onehot) * scale.
 __global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int V,
@@ -328,6 +356,14 @@ inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -2; }
 int pw_transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, hipStream_t s) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, ld_in, out, ld_out, rows, cols);
+    return ok();
+}
+int pw_pack_frag(const float* in, long ld, int R, int K, float* out, int transposed, int nbatch, long in_bstride,
+                 long out_bstride, hipStream_t s) {
+    if (K % 16 != 0 || R <= 0 || nbatch <= 0) return -1;
+    const long slots = (long)((R + 15) / 16) * (K / 16) * 64;
+    dim3 grid(grid_for(slots, 256, 1024), nbatch);
+    hipLaunchKernelGGL(pack_frag_kernel, grid, dim3(256), 0, s, in, ld, R, K, out, transposed, in_bstride, out_bstride);
     return ok();
 }
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,

@@ -36,6 +36,8 @@ struct DirFwd {
     float* hlast; long hlast_ld;                              // extra copy of the final hidden (or null)
     float* sv; long sv_astride;                               // 5 saved arrays (r,z,n,ghn,hprev), each [T][B][H]; or null
     int reverse;
+    // fragment-major fast path (both or neither; H % 256 == 0): packed W_hh and a 2 x pk_floats(B,H) ping-pong buffer
+    const float* Wpk_hh; float* hpk;
 };
 
 struct DirBwd {
@@ -49,7 +51,13 @@ struct DirBwd {
     float* db_ih; float* db_hh;                               // bias gradients (fused into the step kernel), or null
     float* dh0; long dh0_ld; int dh0_acc;                     // dLoss/d initial hidden, or null
     int reverse;
+    // fragment-major fast path (both or neither; H % 256 == 0): packed W_hh^T and a 2 x pk_floats(B,3H) ping-pong buffer
+    const float* Wpk_hhT; float* dghpk;
 };
+
+// floats of a fragment-major [rows,K] operand (rows padded to 16)
+inline size_t pk_floats(int rows, int K) { return (size_t)((rows + 15) / 16) * 16 * (size_t)K; }
+inline bool pk_ok(int H) { return H % 256 == 0; }
 
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
@@ -87,6 +95,7 @@ struct GruDirPtr { const float *w_ih, *w_hh, *b_ih, *b_hh; float *dw_ih, *dw_hh,
 struct BiGru2Ws {
     float *zeros, *x1raw, *x1m, *gi1, *h1, *sv[4];
     float *whhT[4], *dgi1, *dgh[4], *dhz, *dx1, *dgi0;
+    float *wpk[4], *hpk[4], *wpkT[4], *dghpk[4];               // fragment-major twins (null unless pk_ok(H))
 };
 size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w);
 

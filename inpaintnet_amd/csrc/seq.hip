@@ -2,6 +2,11 @@
 
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     const long BH = (long)B * H;
+    const long pkh = (long)pk_floats(B, H);
+    bool pk = pk_ok(H);
+    for (int i = 0; i < nd; ++i) if (!d[i].Wpk_hh || !d[i].hpk) pk = false;
+    if (pk)                                                    // step 0 reads slot 1
+        for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
     for (int step = 0; step < T; ++step) {
         GruFwdBatch bt{};
         bt.H = H; bt.nprob = nd;
@@ -14,6 +19,11 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
             if (step == 0) { P.h_prev = D.h0; P.ld_hprev = D.h0_ld; }
             else { P.h_prev = D.out + (long)tp * D.out_ts; P.ld_hprev = D.out_ld; }
             P.W_hh = D.W_hh; P.b_hh = D.b_hh;
+            if (pk) {
+                P.Wpk_hh = D.Wpk_hh;
+                P.hpk_prev = D.hpk + (long)((step + 1) & 1) * pkh;
+                if (step != T - 1) P.hpk_new = D.hpk + (long)(step & 1) * pkh;
+            }
             if (D.gi) { P.gi_dense = D.gi + (long)t * D.gi_ts; P.ld_gi = D.gi_ld; }
             if (D.table) {
                 P.gi_table = D.table; P.ld_table = D.table_ld;
@@ -39,6 +49,9 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
 
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
     const long BH = (long)B * H, B3H = 3 * BH;
+    const long pkg = (long)pk_floats(B, 3 * H);
+    bool pk = pk_ok(H);
+    for (int i = 0; i < nd; ++i) if (!d[i].Wpk_hhT || !d[i].dghpk) pk = false;
     for (int step = T - 1; step >= 0; --step) {
         GruBwdBatch bt{};
         bt.H = H; bt.nprob = nd;
@@ -51,6 +64,7 @@ int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
             if (step != T - 1) {
                 P.dgh_next = D.dgh + (long)tn * B3H; P.ld_dgh = 3L * H;
                 P.W_hhT = D.W_hhT;
+                if (pk) { P.Wpk_hhT = D.Wpk_hhT; P.dghpk_next = D.dghpk + (long)((step + 1) & 1) * pkg; }
                 P.dhz_next = D.dhz + (long)((step + 1) & 1) * BH;
             } else if (D.dhn) {
                 P.dout2 = D.dhn; P.ld_dout2 = D.dhn_ld;
@@ -62,6 +76,7 @@ int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
             P.dgi = D.dgi + (long)t * D.dgi_ts; P.ld_dgi = D.dgi_ld;
             P.dgh = D.dgh + (long)t * B3H; P.ld_dghout = 3L * H;
             P.dhz = D.dhz + (long)(step & 1) * BH;
+            if (pk) P.dghpk = D.dghpk + (long)(step & 1) * pkg;
             P.db_ih = D.db_ih; P.db_hh = D.db_hh;
         }
         INET_TRY(launch_gru_bwd(bt, s));
@@ -79,6 +94,7 @@ int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
             P.B = B;
             P.dgh_next = D.dgh + (long)t0 * B3H; P.ld_dgh = 3L * H;
             P.W_hhT = D.W_hhT;
+            if (pk) { P.Wpk_hhT = D.Wpk_hhT; P.dghpk_next = D.dghpk; }
             P.dhz_next = D.dhz;                                 // step 0 wrote slot 0
             P.dh_out = D.dh0; P.ld_dhout = D.dh0_ld; P.dh_out_accumulate = D.dh0_acc;
         }
@@ -110,6 +126,13 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
         for (int i = 0; i < 4; ++i) { w.whhT[i] = nullptr; w.dgh[i] = nullptr; }
         w.dgi1 = w.dhz = w.dx1 = w.dgi0 = nullptr;
     }
+    for (int i = 0; i < 4; ++i) {
+        const bool pk = pk_ok(H);
+        w.wpk[i] = pk ? c.take<float>((size_t)3 * H * H) : nullptr;
+        w.hpk[i] = pk ? c.take<float>(2 * pk_floats(B, H)) : nullptr;
+        w.wpkT[i] = pk && save ? c.take<float>((size_t)3 * H * H) : nullptr;
+        w.dghpk[i] = pk && save ? c.take<float>(2 * pk_floats(B, 3 * H)) : nullptr;
+    }
     return c.bytes();
 }
 
@@ -117,6 +140,8 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
                     float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     if (!h0 && hipMemsetAsync(w.zeros, 0, BH * sizeof(float), s) != hipSuccess) return -2;
+    if (w.wpk[0])
+        for (int i = 0; i < 4; ++i) INET_TRY(pw_pack_frag(P[i].w_hh, H, 3 * H, H, w.wpk[i], 0, 1, 0, 0, s));
     DirFwd d[2];
     for (int dir = 0; dir < 2; ++dir) {
         DirFwd& D = d[dir];
@@ -134,6 +159,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (hn && hn[dir]) { D.hlast = hn[dir]; D.hlast_ld = hn_ld; }
         if (save) { D.sv = w.sv[dir]; D.sv_astride = TBH; }
         D.reverse = dir;
+        D.Wpk_hh = w.wpk[dir]; D.hpk = w.hpk[dir];
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     const float* x1 = mask ? w.x1m : w.x1raw;
@@ -150,6 +176,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (hn && hn[2 + dir]) { D.hlast = hn[2 + dir]; D.hlast_ld = hn_ld; }
         if (save) { D.sv = w.sv[2 + dir]; D.sv_astride = TBH; }
         D.reverse = dir;
+        D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir];
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     return 0;
@@ -159,7 +186,10 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
                     const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const bool wg = P[0].dw_hh != nullptr;
-    for (int i = 0; i < 4; ++i) INET_TRY(pw_transpose(P[i].w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+    for (int i = 0; i < 4; ++i) {
+        if (w.wpkT[i]) INET_TRY(pw_pack_frag(P[i].w_hh, H, H, 3 * H, w.wpkT[i], 1, 1, 0, 0, s));
+        else INET_TRY(pw_transpose(P[i].w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+    }
     // ---- layer 1 ----
     DirBwd d[2];
     for (int dir = 0; dir < 2; ++dir) {
@@ -175,6 +205,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.db_ih = P[2 + dir].db_ih; D.db_hh = P[2 + dir].db_hh;
         if (dh0) { D.dh0 = dh0 + (2 + dir) * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
+        D.Wpk_hhT = w.wpkT[2 + dir]; D.dghpk = w.dghpk[2 + dir];
     }
     INET_TRY(gru_layer_bwd(H, B, T, 2, d, s));
     const float* x1 = mask ? w.x1m : w.x1raw;
@@ -207,6 +238,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.db_ih = P[dir].db_ih; D.db_hh = P[dir].db_hh;
         if (dh0) { D.dh0 = dh0 + dir * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
+        D.Wpk_hhT = w.wpkT[dir]; D.dghpk = w.dghpk[dir];
     }
     INET_TRY(gru_layer_bwd(H, B, T, 2, d, s));
     if (wg) {

@@ -145,6 +145,10 @@ struct DecWs {
     // backward
     float *whhT[4], *dlg, *dh1top, *dgi1t, *dgh1t, *dhz, *dht0, *dx1t, *dgi0t, *dgh0t, *dcgi, *dc_all, *onehot, *dtable;
     float *dbeat_out, *dgi1b, *dgh1b, *dxb, *dgi0b, *dgh0b, *dhb0, *tmp3h;
+    // fragment-major twins (ksplit.h), null unless pk_ok(H): packed recurrent / layer-1 input weights, packed initial
+    // tick hiddens [layer][beat], ping-pong packed hiddens [beat][2], packed masked layer-0 output [beat]
+    float *wpk_b[2], *wpk_t0, *wpk_t1hh, *wpk_t1ih, *hpk_b, *ht0pk, *hpk_t0, *hpk_t1, *hm0pk;
+    float *wpkT[4], *dghpk;
 };
 
 size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w) {
@@ -195,7 +199,35 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
         w.dhb0 = cv.take<float>(2 * BH);
         w.tmp3h = cv.take<float>(3 * H);
     }
+    const bool pk = pk_ok((int)H);
+    const size_t pkh = pk_floats(B, (int)H), W3 = 3 * H * H;
+    w.wpk_b[0] = pk ? cv.take<float>(W3) : nullptr;
+    w.wpk_b[1] = pk ? cv.take<float>(W3) : nullptr;
+    w.wpk_t0 = pk ? cv.take<float>(W3) : nullptr;
+    w.wpk_t1hh = pk ? cv.take<float>(W3) : nullptr;
+    w.wpk_t1ih = pk ? cv.take<float>(W3) : nullptr;
+    w.hpk_b = pk ? cv.take<float>(2 * pkh) : nullptr;
+    w.ht0pk = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
+    w.hpk_t0 = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
+    w.hpk_t1 = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
+    w.hm0pk = pk ? cv.take<float>(nb * pkh) : nullptr;
+    for (int i = 0; i < 4; ++i) w.wpkT[i] = pk && save ? cv.take<float>(W3) : nullptr;
+    w.dghpk = pk && save ? cv.take<float>(2 * nb * pk_floats(B, 3 * (int)H)) : nullptr;
     return cv.bytes();
+}
+
+// fragment-major operands of tick j of beat i: layer 0 = P0, layer 1 = P1 (whose x is layer 0's masked output)
+void tick_pk(const DecWs& w, int i, int j, int nb, long pkh, bool masked, GruFwdProb& P0, GruFwdProb& P1) {
+    float* r0 = w.hpk_t0 + (long)i * 2 * pkh;
+    float* r1 = w.hpk_t1 + (long)i * 2 * pkh;
+    P0.Wpk_hh = w.wpk_t0;
+    P0.hpk_prev = j == 0 ? w.ht0pk + (long)i * pkh : r0 + (long)((j + 1) & 1) * pkh;
+    P0.hpk_new = r0 + (long)(j & 1) * pkh;
+    if (masked) P0.hmpk_new = w.hm0pk + (long)i * pkh;
+    P1.Wpk_hh = w.wpk_t1hh; P1.Wpk_ih = w.wpk_t1ih;
+    P1.xpk = masked ? w.hm0pk + (long)i * pkh : P0.hpk_new;
+    P1.hpk_prev = j == 0 ? w.ht0pk + (long)(nb + i) * pkh : r1 + (long)((j + 1) & 1) * pkh;
+    P1.hpk_new = r1 + (long)(j & 1) * pkh;
 }
 
 }  // namespace
@@ -216,6 +248,15 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     DecWs w{};
     dec_carve(c, B, save, ws, w);
     if (save && hipMemcpyAsync(w.zsave, z, (size_t)B * Z * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+    const bool pk = w.wpk_t0 != nullptr;
+    const long pkh = (long)pk_floats(B, H);
+    if (pk) {
+        INET_TRY(pw_pack_frag(p + L.beat[0].w_hh, H, 3 * H, H, w.wpk_b[0], 0, 1, 0, 0, s));
+        INET_TRY(pw_pack_frag(p + L.beat[1].w_hh, H, 3 * H, H, w.wpk_b[1], 0, 1, 0, 0, s));
+        INET_TRY(pw_pack_frag(p + L.tick[0].w_hh, H, 3 * H, H, w.wpk_t0, 0, 1, 0, 0, s));
+        INET_TRY(pw_pack_frag(p + L.tick[1].w_hh, H, 3 * H, H, w.wpk_t1hh, 0, 1, 0, 0, s));
+        INET_TRY(pw_pack_frag(p + L.tick[1].w_ih, H, 3 * H, H, w.wpk_t1ih, 0, 1, 0, 0, s));
+    }
 
     // ---- beat RNN (forward_beat_rnn, decoder.py:455-471) ----
     INET_TRY(linear_fwd(z, Z, p + L.zb_w, Z, p + L.zb_b, w.hb0, 2L * H, B, 2 * H, Z, EPI_SELU, s));
@@ -227,6 +268,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     d.out = w.beat0; d.out_ld = H; d.out_ts = BH;
     if (mask_beat) { d.outm = w.beat0m; d.outm_ld = H; d.outm_ts = BH; d.mask = mask_beat; d.mask_ld = H; d.mask_ts = BH; }
     if (save) { d.sv = w.svb0; d.sv_astride = nb * BH; }
+    d.Wpk_hh = w.wpk_b[0]; d.hpk = w.hpk_b;
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     INET_TRY(linear_fwd(xb, H, p + L.beat[1].w_ih, H, p + L.beat[1].b_ih, w.gi1b, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
@@ -236,10 +278,14 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     d.h0 = w.hb0 + H; d.h0_ld = 2L * H;
     d.out = w.beat_out; d.out_ld = H; d.out_ts = BH;
     if (save) { d.sv = w.svb1; d.sv_astride = nb * BH; }
+    d.Wpk_hh = w.wpk_b[1]; d.hpk = w.hpk_b;
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
 
     // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
     INET_TRY(linear_fwd(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU, s));
+    if (pk)                                                    // packed initial tick hiddens: [layer][beat]
+        for (int l = 0; l < 2; ++l)
+            INET_TRY(pw_pack_frag(w.ht0 + (long)l * H, 2L * H, B, H, w.ht0pk + (long)l * nb * pkh, 0, nb, (long)B * 2 * H, pkh, s));
     INET_TRY(linear_fwd(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU, s));
     const float* wih0 = p + L.tick[0].w_ih;                   // [3H, E+H]
     const long ldw0 = E + H;
@@ -279,6 +325,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
                     P0.sv_r = q; P0.sv_z = q + as; P0.sv_n = q + 2 * as; P0.sv_ghn = q + 3 * as; P0.sv_hprev = q + 4 * as;
                 }
                 GruFwdProb& P1 = b1.p[i];
+                if (pk) tick_pk(w, i, j, nb, pkh, mask_tick != nullptr, P0, P1);
                 P1.B = B;
                 if (j == 0) { P1.h_prev = w.ht0 + (long)i * B * 2 * H + H; P1.ld_hprev = 2L * H; }
                 else { P1.h_prev = w.h1seq + (long)(t - 1) * BH; P1.ld_hprev = H; }
@@ -317,8 +364,6 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
             float* q = w.svt0 + (long)t * BH; const long as = (long)T * BH;
             P0.sv_r = q; P0.sv_z = q + as; P0.sv_n = q + 2 * as; P0.sv_ghn = q + 3 * as; P0.sv_hprev = q + 4 * as;
         }
-        INET_TRY(launch_gru_fwd(b0, s));
-
         GruFwdBatch b1{};
         b1.H = H; b1.nprob = 1;
         GruFwdProb& P1 = b1.p[0];
@@ -333,6 +378,8 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
             float* q = w.svt1 + (long)t * BH; const long as = (long)T * BH;
             P1.sv_r = q; P1.sv_z = q + as; P1.sv_n = q + 2 * as; P1.sv_ghn = q + 3 * as; P1.sv_hprev = q + 4 * as;
         }
+        if (pk) tick_pk(w, i, j, nb, pkh, mask_tick != nullptr, P0, P1);
+        INET_TRY(launch_gru_fwd(b0, s));
         INET_TRY(launch_gru_fwd(b1, s));
 
         // logits = ReLU(h_top . Wo^T + bo) straight into weights[:, t, :], fused with the argmax that feeds tick t+1
@@ -357,7 +404,11 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     DecWs w{};
     dec_carve(c, B, 1, ws, w);
     const GruDirOff* gr[4] = {&L.beat[0], &L.beat[1], &L.tick[0], &L.tick[1]};
-    for (int i = 0; i < 4; ++i) INET_TRY(pw_transpose(p + gr[i]->w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+    for (int i = 0; i < 4; ++i) {
+        if (w.wpkT[i]) INET_TRY(pw_pack_frag(p + gr[i]->w_hh, H, H, 3 * H, w.wpkT[i], 1, 1, 0, 0, s));
+        else INET_TRY(pw_transpose(p + gr[i]->w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+    }
+    const long pkg = (long)pk_floats(B, 3 * H);
 
     // ---- output projection ----
     INET_TRY(pw_dlogits_relayout(dweights, weights, B, T, V, w.dlg, s));
@@ -381,6 +432,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         D.dhz = w.dhz + (long)i * 2 * BH;
         if (g) { D.db_ih = g + L.tick[1].b_ih; D.db_hh = g + L.tick[1].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H + H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
+        D.Wpk_hhT = w.wpkT[3]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
@@ -404,6 +456,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         D.dhz = w.dhz + (long)i * 2 * BH;
         if (g) { D.db_ih = g + L.tick[0].b_ih; D.db_hh = g + L.tick[0].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
+        D.Wpk_hhT = w.wpkT[2]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* wih0 = p + L.tick[0].w_ih;
@@ -451,6 +504,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     b.dgh = w.dgh1b; b.dhz = w.dhz;
     if (g) { b.db_ih = g + L.beat[1].b_ih; b.db_hh = g + L.beat[1].b_hh; }
     b.dh0 = w.dhb0 + H; b.dh0_ld = 2L * H;
+    b.Wpk_hhT = w.wpkT[1]; b.dghpk = w.dghpk;
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     if (g) {
@@ -468,6 +522,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     b.dgh = w.dgh0b; b.dhz = w.dhz;
     if (g) { b.db_ih = g + L.beat[0].b_ih; b.db_hh = g + L.beat[0].b_hh; }
     b.dh0 = w.dhb0; b.dh0_ld = 2L * H;
+    b.Wpk_hhT = w.wpkT[0]; b.dghpk = w.dghpk;
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     if (g) {
         hipStream_t ss = side_fork(s);

@@ -48,10 +48,19 @@ __global__ __launch_bounds__(64 * NW) void step(const float* __restrict__ hp, co
 #else
             const int k = 16 * (s0 + d) + 4 * q;
 #endif
+#ifdef PACKED
+            // fragment-major operands: block (row/16, k-step) is 1 KB contiguous in lane order
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) fa[d][ms] = LD(hp + ((long)((row0 >> 4) + ms) * (H / 16) + s0 + d) * 256 + 4 * lane);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) fb[d][g] = LD(W + ((long)((g * H + j0) >> 4) * (H / 16) + s0 + d) * 256 + 4 * lane);
+            (void)k;
+#else
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms) fa[d][ms] = LD(hp + (long)ROW(row0 + 16 * ms + i16) * H + k);
 #pragma unroll
             for (int g = 0; g < 3; ++g) fb[d][g] = LD(W + (long)(g * H + j0 + i16) * H + k);
+#endif
         }
     } else {
 #pragma unroll
@@ -97,8 +106,14 @@ __global__ __launch_bounds__(64 * NW) void step(const float* __restrict__ hp, co
             float gr = v[0] + gp[j] + bh[j], gz = v[1] + gp[H + j] + bh[H + j], gn = gp[2 * H + j];
             float r = 1.f / (1.f + expf(-gr)), z = 1.f / (1.f + expf(-gz));
             float n = tanhf(gn + r * (v[2] + bh[2 * H + j]));
+#ifdef PACKED
+            const long po = ((long)(b >> 4) * (H / 16) + (j >> 4)) * 256 + (((j & 15) >> 2) * 16 + (b & 15)) * 4 + (j & 3);
+            const float hpv = hp[po];
+            hn[po] = (1.f - z) * n + z * hpv;
+#else
             const float hpv = hp[(long)b * H + j];
             hn[(long)b * H + j] = (1.f - z) * n + z * hpv;
+#endif
             const long o = (long)b * H + j, BH = (long)B * H;
             if (VAR == 5) { sv[o] = r; sv[BH + o] = z; sv[2 * BH + o] = n; sv[3 * BH + o] = v[2]; sv[4 * BH + o] = hpv; }
             if (VAR == 6) { *(f32x4*)(sv + 4 * o) = f32x4{r, z, n, v[2]}; sv[4 * BH + o] = hpv; }
