@@ -71,6 +71,7 @@ def latent_rnn_extra(ds, vae, dev, batch=128, steps=10, warmup=3):
     model = LatentRNN(ds, vae, num_rnn_layers=2, rnn_hidden_size=512, dropout=0.5, rnn_class=torch.nn.GRU,
                       auto_reg=False, teacher_forcing=True)
     trainer = LatentRNNTrainer(ds, model, lr=1e-4)
+    trainer.overlap_backward = True              # as in the epoch loop (Trainer.loss_and_acc_on_epoch)
     model.train()
     score = torch.from_numpy(synthetic.folk_score(batch, NUM_NOTES, seed=9))
     past, future, target = LatentRNNTrainer.split_score(score, 6, 6, 4, 24)
@@ -132,6 +133,7 @@ def arnn_extra(batch=32, steps=8, warmup=2):
                                        linear_hidden_size=256, num_layers=2, dropout_input_prob=0.2, dropout_prob=0.2,
                                        unary_constraint=True, teacher_forcing=True)
     trainer = AnticipationRNNGaussianRegTrainer(ds, model, lr=1e-4)
+    trainer.overlap_backward = True
     model.train()
     score = torch.from_numpy(synthetic.folk_score(batch, NUM_NOTES, seed=21))
     md = torch.from_numpy(synthetic.folk_metadata(batch))
@@ -190,6 +192,7 @@ def main():
     sd = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in model.state_dict().items()}
     model.load_state_dict(sd)                                  # identical initial weights on every rank
     trainer = VAETrainer(ds, model, lr=1e-4)
+    trainer.overlap_backward = True              # as in the epoch loop (Trainer.loss_and_acc_on_epoch)
     model.train()
     set_dropout_seed(1234, rank)                               # per-rank dropout / eps streams
     torch.manual_seed(1000 + rank)

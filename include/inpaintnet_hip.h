@@ -179,6 +179,11 @@ int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const 
 /* ---- runtime options: key 0 = overlap the weight-gradient GEMMs of the backward pass with the BPTT chains on
  * a second, lower-priority HIP stream (default 1; also INET_SIDE_STREAM=0 in the environment) */
 int inet_set_option(int key, int value);
+/* key 1 = deferred joins (default 0).  With 0 every *_bwd entry point makes `stream` wait for the side stream before
+ * it returns.  With 1 it does not: the caller must keep every workspace passed to a *_bwd call alive and call
+ * inet_side_join(stream) before anything reads the gradient arena (optimizer step, all-reduce) or frees those
+ * workspaces.  Lets the leaf GEMMs of one module's backward overlap the next module's BPTT chain. */
+int inet_side_join(void* stream);
 
 /* ---- measurement hooks (bench.py roofline line; not part of the reference surface) --------------- */
 /* class 0 = batched MFMA GEMM, 1 = fused GRU step forward, 2 = fused GRU step backward.  While enabled every

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "inet_relu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "inet_argmax": (C.c_int, [_P, _L, _I, _I, _P, _L, _P]),
     "inet_set_option": (C.c_int, [_I, _I]),
+    "inet_side_join": (C.c_int, [_P]),
     "inet_prof_enable": (C.c_int, [_I]),
     "inet_prof_dump": (C.c_int, [C.c_char_p]),
     "inet_prof_read": (C.c_int, [_I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -290,8 +290,11 @@ int inet_argmax(const float* w, int64_t ld, int rows, int V, int64_t* out, int64
 
 int inet_set_option(int key, int value) {
     if (key == 0) { side_set_enabled(value); return 0; }
+    if (key == 1) { side_set_defer(value); return 0; }
     return -1;
 }
+
+int inet_side_join(void* stream) { return side_join_now((hipStream_t)stream); }
 
 int inet_gru_step(int B, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
                   float* h_new, float* sv5, void* stream) {

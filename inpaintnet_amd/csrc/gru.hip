@@ -28,6 +28,7 @@
 // reduction of the partial accumulators.  (Round-1 profile: the LDS-staged
 // version spent ~0.9 us per 64-deep chunk on load->barrier->ds_read latency,
 // 14.5 us per step; see profiles/.)
+#include <cstdlib>
 #include "common.h"
 #include "ksplit.h"
 #include "prof.h"
@@ -35,6 +36,7 @@
 namespace {
 
 using namespace ksplit;
+
 
 // Optional in-kernel phase stamps (build with -DINET_STEP_TRACE; tools/trace_steps.py).  Not part of the product build.
 #ifdef INET_STEP_TRACE
@@ -326,6 +328,8 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restr
 // Rows per workgroup = 16*MS.  One problem of B=256 fills the chip with MS=2 (256 workgroups).  With 2 or 4 problems
 // per launch (directions, beats) the per-CU L2->L1 load path is the limit (~32 GB/s per CU measured), so bigger row
 // tiles are used to keep ~256 workgroups while loading each W slice once per 64 / 128 rows instead of per 32.
+// (Tried: 32-row tiles capped at 256 registers so that two workgroups share a CU and overlap each other's load and
+// epilogue phases -- 6.14 vs 5.77 ms per teacher-forced step, the doubled W traffic and the longer tail lose.)
 int pick_ms(int nprob, int maxB, int H, int ms_max) {
     int ms = 2;
     for (int cand = 4; cand <= ms_max; cand *= 2) {

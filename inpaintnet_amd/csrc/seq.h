@@ -61,8 +61,10 @@ inline bool pk_ok(int H) { return H % 256 == 0; }
 
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
+int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_hi, int step_lo, hipStream_t s);
 // dW_hh += dgh^T hprev       (rows = T*B, contiguous in t then b; the bias gradients come from the step kernel)
 int gru_dir_wgrad(int H, int B, int T, const float* dgh, const float* sv_hprev, float* dW_hh, hipStream_t s);
+int gru_dir_wgrad_range(int H, int B, int t_lo, int nt, const float* dgh, const float* sv_hprev, float* dW_hh, hipStream_t s);
 
 inline GemmArgs gemm_args(const float* A, long lda, int akm, const float* Bm, long ldb, int bkm, float* C, long ldc,
                           int M, int N, int K, const float* bias = nullptr, int epi = EPI_NONE,

@@ -3,11 +3,16 @@
 // weight-gradient GEMMs and bias column sums have no consumer before the optimizer step.  side_fork() makes
 // the (lower-priority) side stream wait for the main stream's current point and returns it; side_join() makes
 // the main stream wait for everything queued on the side stream.  Every *_bwd entry point joins before it
-// returns, so workspaces never outlive the work that reads them.
+// returns, so workspaces never outlive the work that reads them -- unless the caller has switched joins to
+// "deferred" (inet_set_option(1, 1)): then it keeps the workspaces alive itself and calls inet_side_join() once,
+// before the gradients are consumed (optimizer step / all-reduce), so leaf work of one module's backward can
+// overlap the next module's BPTT chain.
 #pragma once
 #include <hip/hip_runtime.h>
 
 hipStream_t side_fork(hipStream_t main_stream);   // returns main_stream itself when the side stream is disabled
-int side_join(hipStream_t main_stream);
+int side_join(hipStream_t main_stream);            // no-op in deferred mode
+int side_join_now(hipStream_t main_stream);
+void side_set_defer(int on);
 void side_set_enabled(int on);
 int side_enabled();

@@ -7,6 +7,7 @@ hipStream_t g_side = nullptr;
 bool g_init = false;
 int g_enabled = -1;
 bool g_dirty = false;                 // something was queued on the side stream since the last join
+bool g_defer = false;                 // side_join() is a no-op; the caller joins explicitly (side_join_now)
 std::vector<hipEvent_t> g_pool;
 size_t g_next = 0;
 
@@ -47,7 +48,10 @@ hipStream_t side_fork(hipStream_t main_stream) {
     return g_side;
 }
 
-int side_join(hipStream_t main_stream) {
+void side_set_defer(int on) { g_defer = on != 0; }
+int side_join(hipStream_t main_stream) { return g_defer ? 0 : side_join_now(main_stream); }
+
+int side_join_now(hipStream_t main_stream) {
     if (!g_dirty || !g_side) return 0;
     g_dirty = false;
     hipEvent_t e = next_event();

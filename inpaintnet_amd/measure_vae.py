@@ -73,7 +73,9 @@ class _DecoderFn(torch.autograd.Function):
         ctx.ws = None
         if grads is not None:
             # data parallel: the decoder half of the arena is final now -> start its all-reduce under the encoder's backward
-            dp.start_bucket(grads, dec.owner.decoder_arena_start, grads.numel())
+            if dp.world_size() > 1:
+                ops.side_join()                    # deferred joins: the decoder's leaf GEMMs must be in before the exchange
+                dp.start_bucket(grads, dec.owner.decoder_arena_start, grads.numel())
         return dz, None, None, None, None, None, None
 
 
@@ -312,7 +314,9 @@ class MeasureVAE(Model):
         z_tilde = z_dist.rsample(eps=eps)
         prior_dist = distributions.Normal(loc=torch.zeros_like(z_dist.loc), scale=torch.ones_like(z_dist.scale),
                                           validate_args=False)
-        z_prior = prior_dist.sample()
+        # prior_dist.sample() (measure_vae.py:127) for N(0, 1) is a plain standard-normal draw.  torch.normal(mean, std)
+        # would also validate std >= 0 with a device->host read, i.e. stall the host once per forward pass.
+        z_prior = torch.randn_like(z_dist.loc)
         weights, samples = self.decoder(z=z_tilde, score_tensor=measure_score_tensor, train=train,
                                         teacher_forced=teacher_forced)
         return weights, samples, z_dist, prior_dist, z_tilde, z_prior

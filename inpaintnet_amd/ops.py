@@ -77,9 +77,36 @@ def encoder_fwd(cfg, tokens, params, mask=None, save=False, ws=None):
     return mu, ls, ws
 
 
+# ----------------------------------------------------------------------------- deferred side-stream joins
+_DEFER = False
+_HELD = []
+
+
+def side_defer(on):
+    """Deferred joins (include/inpaintnet_hip.h, inet_set_option key 1): the *_bwd calls stop making the current stream
+    wait for the side stream; every tensor they were given is kept alive here until side_join()."""
+    global _DEFER
+    if not on and _DEFER:
+        side_join()
+    _DEFER = bool(on)
+    check(_lib.lib().inet_set_option(1, int(_DEFER)), "inet_set_option")
+
+
+def side_join():
+    """Make the current stream wait for all side-stream work, then release the tensors held for it."""
+    check(_lib.lib().inet_side_join(stream_ptr()), "inet_side_join")
+    _HELD.clear()
+
+
+def _hold(*tensors):
+    if _DEFER:
+        _HELD.append(tensors)
+
+
 def encoder_bwd(cfg, tokens, params, grads, mask, dmu, dls, ws):
     B = tokens.shape[0]
     _f32c(dmu); _f32c(dls); _f32c(grads)
+    _hold(tokens, params, grads, mask, dmu, dls, ws)
     check(_lib.lib().inet_vae_encoder_bwd(C.byref(cfg), B, ptr(tokens), ptr(params), ptr(grads), ptr(mask), ptr(dmu),
                                           ptr(dls), ptr(ws), ws.numel() * 4, stream_ptr()), "inet_vae_encoder_bwd")
 
@@ -113,6 +140,7 @@ def decoder_bwd(cfg, dweights, weights, samples, params, grads, mask_beat, mask_
     B = weights.shape[0]
     _f32c(dweights); _f32c(weights); _i64c(samples)
     dz = torch.empty(B, cfg.z_dim, dtype=torch.float32, device=weights.device) if need_dz else None
+    _hold(dweights, weights, samples, params, grads, mask_beat, mask_tick, ws)
     check(_lib.lib().inet_vae_decoder_bwd(C.byref(cfg), B, ptr(dweights), ptr(weights), ptr(samples), ptr(params),
                                           ptr(grads), ptr(mask_beat), ptr(mask_tick), ptr(dz), ptr(ws), ws.numel() * 4,
                                           stream_ptr()), "inet_vae_decoder_bwd")
@@ -239,6 +267,7 @@ def lstm_bwd(W_hh, out, dout, H, reverse, ws, dW_hh=None, db_ih=None, db_hh=None
     dgi = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
     dh0 = torch.empty(B, H, dtype=torch.float32, device=dev) if want_dstate else None
     dc0 = torch.empty(B, H, dtype=torch.float32, device=dev) if want_dstate else None
+    _hold(W_hh, h0, out, dout, dhT, dcT, dgi, dW_hh, db_ih, db_hh, ws)
     check(_lib.lib().inet_lstm_bwd(B, T, H, ptr(W_hh), ptr(h0), ptr(out), ptr(dout), ptr(dhT), ptr(dcT), int(reverse),
                                    ptr(dgi), ptr(dW_hh), ptr(db_ih), ptr(db_hh), ptr(dh0), ptr(dc0), ptr(ws),
                                    ws.numel() * 4, stream_ptr()), "inet_lstm_bwd")
@@ -309,6 +338,7 @@ def bigru2_bwd(x, x_scalar, weights, grads, H, B, T, K, mask, dout, dhn, ws, wan
     dev = weights.device
     dx = torch.empty(B, T, K, dtype=torch.float32, device=dev) if (want_dx and x is not None) else None
     dh0 = torch.empty(4, B, H, dtype=torch.float32, device=dev) if want_dh0 else None
+    _hold(x, x_scalar, weights, grads, mask, dout, dhn, ws)
     check(_lib.lib().inet_bigru2_bwd(B, T, K, H, ptr(x), ptr(x_scalar), ptr(weights), ptr(grads), ptr(mask),
                                      ptr(dout), ptr(dhn), ptr(dx), ptr(dx_scalar), ptr(dh0), ptr(ws), ws.numel() * 4,
                                      stream_ptr()), "inet_bigru2_bwd")

@@ -84,6 +84,8 @@ class Trainer(ABC):
             self.early_stopping = True
             self.early_stopper = EarlyStopping()
         self.last_epoch_seconds = None
+        # deferred side-stream joins for zero_grad() -> forward -> backward -> step() sequences (see zero_grad)
+        self.overlap_backward = False
 
     # ---- utils/trainer.py:41-124 (plot/log plumbing omitted) -----------------------
     def train_model(self, batch_size, num_epochs, plot=False, log=False):
@@ -116,6 +118,7 @@ class Trainer(ABC):
         sums = torch.zeros(2, dtype=torch.float32, device=dev)
         t0 = time.time()
         n = 0
+        prev_overlap, self.overlap_backward = self.overlap_backward, bool(train)
         for sample_id, batch in enumerate(data_loader):
             batch_data = self.process_batch_data(batch)
             self.zero_grad()
@@ -130,16 +133,23 @@ class Trainer(ABC):
             if accuracy is not None:
                 sums[1] += accuracy.detach()
             n += 1
+        self.overlap_backward = prev_overlap
+        ops.side_defer(False)
         out = (sums / max(n, 1)).tolist()            # the one device->host sync of the epoch
         self.last_epoch_seconds = time.time() - t0
         return out[0], out[1]
 
     def zero_grad(self):
-        """utils/trainer.py:165-170"""
+        """utils/trainer.py:165-170.  With `overlap_backward` set (the epoch loop and bench.py set it) the step that
+        starts here runs with deferred side-stream joins: the gradient arena is only complete after step() (or
+        ops.side_join()), not right after loss.backward()."""
+        if self.overlap_backward:
+            ops.side_defer(True)
         self.model.zero_grad()
 
     def step(self):
         """utils/trainer.py:172-177 (+ the data-parallel gradient exchange)."""
+        ops.side_join()
         gscale = dp.allreduce_grads(self.model.grad)
         self.adam_t += 1
         ops.adam_step(self.model.flat, self.model.grad, self.adam_m, self.adam_v, self.lr, self.adam_t,

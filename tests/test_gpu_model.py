@@ -29,12 +29,15 @@ def build(name, dropout=0.0):
 
 @pytest.mark.parametrize("name", ["small", "full"])
 @pytest.mark.parametrize("mode", ["tf", "fr"])
-def test_trainer_trajectory_matches_reference(name, mode, monkeypatch):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_trainer_trajectory_matches_reference(name, mode, overlap, monkeypatch):
     """The reference's loop body (utils/trainer.py:136-156) verbatim on our classes: the coin comes from
-    random.random, eps from the injected queue; 5 steps of loss / accuracy must follow the reference."""
+    random.random, eps from the injected queue; 5 steps of loss / accuracy must follow the reference.
+    overlap=True runs the steps the way the epoch loop does (deferred side-stream joins, Trainer.zero_grad)."""
     fx = G.load("vae_" + name)
     ds, model = build(name)
     trainer = VAETrainer(ds, model, lr=1e-4)
+    trainer.overlap_backward = overlap
     model.train()
     tok = torch.from_numpy(fx["tokens"]).cuda()
     monkeypatch.setattr(MV.random, "random", lambda: 0.0 if mode == "tf" else 0.9)
@@ -48,6 +51,8 @@ def test_trainer_trajectory_matches_reference(name, mode, monkeypatch):
         trainer.step()
         assert abs(float(loss.detach()) - ref[step][0]) <= 1e-4 * abs(ref[step][0]), (step, float(loss.detach()), ref[step][0])
         assert abs(float(acc.detach()) - ref[step][3]) < 1e-6
+    from inpaintnet_amd import ops
+    ops.side_defer(False)
     if name == "small":
         sd = model.state_dict()
         for k, v in sd.items():

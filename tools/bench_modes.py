@@ -8,6 +8,7 @@ from inpaintnet_amd.measure_vae import MeasureVAE
 from inpaintnet_amd.vae_trainer import VAETrainer
 ds = synthetic.SyntheticFolkDataset(num_notes=48)
 model = MeasureVAE(ds); trainer = VAETrainer(ds, model); model.train()
+trainer.overlap_backward = os.environ.get('OVERLAP', '1') != '0'
 tok = torch.from_numpy(synthetic.det_tokens("prof", (256, 24), 48)).cuda()
 def step(tf):
     trainer.zero_grad()
