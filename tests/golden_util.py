@@ -12,6 +12,8 @@ CFGS = {
     "small": dict(V=12, E=4, H=16, Z=8),
     "mid": dict(V=20, E=6, H=48, Z=24),
     "full": dict(V=48, E=10, H=512, Z=256),
+    # no fixture: H % 256 == 0 turns on the fragment-major operand path of the step kernels; used against the oracle
+    "pk": dict(V=20, E=6, H=256, Z=24),
 }
 
 

@@ -220,11 +220,12 @@ def test_vae_train_steps_golden(name, mode):
                     assert np.abs(pv.reshape(-1)[:64] - r).max() < 1e-5, (pname, step)
 
 
-def test_vae_step_with_dropout_masks_vs_oracle():
-    """Mask-in dropout (encoder l0->l1, beat l0->l1, tick l0->l1): HIP path vs the oracle with identical masks."""
-    name = "mid"
+@pytest.mark.parametrize("name,B", [("mid", 7), ("pk", 37)])
+def test_vae_step_with_dropout_masks_vs_oracle(name, B):
+    """Mask-in dropout (encoder l0->l1, beat l0->l1, tick l0->l1): HIP path vs the oracle with identical masks.
+    "pk" (H=256, ragged batch of 37) runs the fragment-major operand path incl. the masked layer-0 -> layer-1 hand-off."""
     c = G.CFGS[name]
-    B, T, H = 7, 24, c["H"]
+    T, H = 24, c["H"]
     cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
     table, total = ops.vae_param_table(cfg)
     P = G.vae_params(name)
@@ -304,7 +305,10 @@ def test_adam_kernel_matches_torch():
 
 
 # ------------------------------------------------------------------------------- generic bi-GRU (LatentRNN building block)
-@pytest.mark.parametrize("B,T,K,H,scalar", [(3, 5, 8, 16, False), (4, 4, 1, 32, True), (6, 6, 24, 48, False)])
+@pytest.mark.parametrize("B,T,K,H,scalar", [(3, 5, 8, 16, False), (4, 4, 1, 32, True), (6, 6, 24, 48, False),
+                                            # H % 256 == 0: the fragment-major operand path of the step kernels, with
+                                            # ragged batches (last 16-row block partly filled, several row tiles)
+                                            (37, 3, 8, 256, False), (70, 2, 1, 256, True), (133, 2, 4, 512, False)])
 def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
     from inpaintnet_amd import layout
     g = torch.Generator().manual_seed(B * 100 + T * 10 + K)
