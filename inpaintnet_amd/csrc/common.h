@@ -27,8 +27,15 @@ __device__ __forceinline__ void st4u(float* p, f32x4 v) {
 // kernel arguments are global: every access through them becomes flat_load/flat_store, flat operations tick both
 // vmcnt and lgkmcnt, and the waits degrade to vmcnt(0) lgkmcnt(0) -- a two-deep load pipeline silently becomes
 // load -> drain -> compute (profiles/r01_f).
-// (Forcing the field reads to the top of the kernel with typed reads through an empty asm was also tried: the up-front
-// wait on every field cost more than the lazily sunk s_loads it replaced: 40.1k vs 41.0k measures/s, same box.)
+// hipcc sinks every `args.field` read to its first use, so a block of "if (P.ptr) v = P.ptr[i]" statements becomes a
+// chain of s_load -> s_waitcnt lgkmcnt(0) -> branch round trips (3,000 cycles for the forward step's epilogue-operand
+// block, tools/trace_steps.py).  kernarg_touch() names the fields such a block needs right in front of it: the empty
+// asm wants each value in an SGPR, so the s_loads are issued back to back and waited for once.  Typed field reads
+// only -- no punning.  (Touching ALL fields at kernel entry instead was slower: 40.1k vs 41.0k measures/s.)
+template <class T>
+__device__ __forceinline__ void kernarg_touch1(T v) { asm volatile("" ::"s"(v)); }
+template <class... T>
+__device__ __forceinline__ void kernarg_touch(T... v) { (kernarg_touch1(v), ...); }
 
 #define SELU_ALPHA 1.6732632423543772f
 #define SELU_SCALE 1.0507009873554805f
@@ -93,7 +100,7 @@ struct GruFwdProb {
     float* hpk_new;                               // optional packed copy of h_new (the next step's hpk_prev)
     float* hmpk_new;                              // optional packed copy of h_masked (the next layer's xpk)
 };
-struct GruFwdBatch { int H; int nprob; int tiles_per_prob; GruFwdProb p[4]; };
+struct GruFwdBatch { int H; int nprob; int tiles_per_prob; int rows_fastest; GruFwdProb p[4]; };
 
 struct GruBwdProb {
     int B;
@@ -115,7 +122,7 @@ struct GruBwdProb {
     const float* dghpk_next; const float* Wpk_hhT;   // [ceil(B/16)][3H/16][64][4], [H/16][3H/16][64][4]
     float* dghpk;                                    // optional packed copy of dgh (the next step's dghpk_next)
 };
-struct GruBwdBatch { int H; int nprob; int tiles_per_prob; GruBwdProb p[4]; };
+struct GruBwdBatch { int H; int nprob; int tiles_per_prob; int rows_fastest; GruBwdProb p[4]; };
 
 // host-side launchers (defined in the .hip files)
 int launch_gemm(const GemmArgs& g, hipStream_t s);

@@ -41,7 +41,8 @@ using namespace ksplit;
 // Optional in-kernel phase stamps (build with -DINET_STEP_TRACE; tools/trace_steps.py).  Not part of the product build.
 #ifdef INET_STEP_TRACE
 __device__ unsigned long long* g_trace = nullptr;   // [0] = slot counter, records of 8 x u64 from [8]
-#define TRACE_DECL unsigned long long tr_[4] = {0, 0, 0, 0}, tc_[4] = {0, 0, 0, 0}
+#define TRACE_DECL unsigned long long tr_[4] = {0, 0, 0, 0}, tc_[4] = {0, 0, 0, 0}, tx_[3] = {0, 0, 0}
+#define TRACEX(i) do { if (threadIdx.x == 0) tx_[i] = clock64(); } while (0)
 #define TRACE(i) do { if (threadIdx.x == 0) { tr_[i] = wall_clock64(); tc_[i] = clock64(); } } while (0)
 #define TRACE_END(kind, ms)                                                                           \
     do {                                                                                              \
@@ -53,14 +54,15 @@ __device__ unsigned long long* g_trace = nullptr;   // [0] = slot counter, recor
                 r[4] = (unsigned long long)blockIdx.x | ((unsigned long long)blockIdx.y << 16) |      \
                        ((unsigned long long)(kind) << 32) | ((unsigned long long)(ms) << 40) |        \
                        ((unsigned long long)gridDim.y << 48);                                         \
-                r[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |       \
-                       __builtin_amdgcn_s_getreg((31 << 11) | 4);                                     \
+                r[5] = ((tx_[0] - tc_[0]) & 0xfffffull) | (((tx_[1] - tc_[0]) & 0xfffffull) << 20) |      \
+                       (((tx_[2] - tc_[0]) & 0xfffffull) << 40);                                      \
                 r[6] = tc_[1] - tc_[0]; r[7] = tc_[3] - tc_[0];                                       \
             }                                                                                         \
         }                                                                                             \
     } while (0)
 #else
 #define TRACE_DECL
+#define TRACEX(i)
 #define TRACE(i)
 #define TRACE_END(kind, ms)
 #endif
@@ -69,12 +71,13 @@ __device__ unsigned long long* g_trace = nullptr;   // [0] = slot counter, recor
 template <bool HAS_X, int MS, bool PK>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 4 * MS * 256];
-    const int prob = blockIdx.y / bt.tiles_per_prob;
+    const int bcol = bt.rows_fastest ? blockIdx.y : blockIdx.x, brow_t = bt.rows_fastest ? blockIdx.x : blockIdx.y;
+    const int prob = brow_t / bt.tiles_per_prob;
     const GruFwdProb& P = bt.p[prob];
     const int H = bt.H;
     const int t = threadIdx.x;
-    const int j0 = blockIdx.x * TH;
-    const int row0 = (blockIdx.y % bt.tiles_per_prob) * (16 * MS);
+    const int j0 = bcol * TH;
+    const int row0 = (brow_t % bt.tiles_per_prob) * (16 * MS);
     if (row0 >= P.B) return;
     TRACE_DECL;
     TRACE(0);
@@ -98,6 +101,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
         for (int p = 0; p < MS; ++p) tok[p] = P.idx[(long)min(row0 + ((t + 256 * p) >> 4), P.B - 1) * P.idx_stride];
     }
     auto prefetch = [&]() {
+        TRACEX(1);
+        kernarg_touch(P.b_hh, P.b_ih, P.gi_vec, P.gi_dense, P.ld_gi, P.gi_table, P.ld_table, P.h_prev, P.ld_hprev,
+                      P.hpk_prev, P.h_masked, P.mask, P.ld_mask);
 #pragma unroll
         for (int g = 0; g < 3; ++g) pb_hh[g] = P.b_hh[g * H + jc];
         if (HAS_X && P.b_ih) {
@@ -119,6 +125,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 #pragma unroll
             for (int g = 0; g < 3; ++g) pre_gt[p][g] = P.gi_table ? P.gi_table[tok[p] * P.ld_table + g * H + jc] : 0.f;
         }
+        TRACEX(2);
     };
 
     const int brow[3] = {j0, H + j0, 2 * H + j0};
@@ -128,6 +135,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
         else ksplit_segment<MS, 3>(acc, slotx, P.x, P.ldx, row0, P.B, P.W_ih, P.ld_wih, brow, P.K2, t);
     }
     const int sloth[3] = {0, 1, 3};              // r, z, gh_n
+    TRACEX(0);
     if (PK) ksplit_segment<MS, 3, true>(acc, sloth, P.hpk_prev, 0, row0, P.B, P.Wpk_hh, 0, brow, H, t, prefetch);
     else ksplit_segment<MS, 3>(acc, sloth, P.h_prev, P.ld_hprev, row0, P.B, P.W_hh, (long)H, brow, H, t, prefetch);
 
@@ -174,37 +182,41 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 template <int MS, bool PK>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
     __shared__ __attribute__((aligned(16))) float lds[(4 * MS * 256 > 1024) ? 4 * MS * 256 : 1024];
-    const int prob = blockIdx.y / bt.tiles_per_prob;
+    const int bcol = bt.rows_fastest ? blockIdx.y : blockIdx.x, brow_t = bt.rows_fastest ? blockIdx.x : blockIdx.y;
+    const int prob = brow_t / bt.tiles_per_prob;
     const GruBwdProb& P = bt.p[prob];
     const int H = bt.H;
     const int t = threadIdx.x;
-    const int j0 = blockIdx.x * TH;
-    const int row0 = (blockIdx.y % bt.tiles_per_prob) * (16 * MS);
+    const int j0 = bcol * TH;
+    const int row0 = (brow_t % bt.tiles_per_prob) * (16 * MS);
     if (row0 >= P.B) return;
     TRACE_DECL;
     TRACE(0);
 
-    // Epilogue operands first: direct gradient terms and the saved gates of this step.  (K = 3H runs as several load
-    // groups here; requested between the groups these 8*MS cold loads would stall the later fragment groups behind
-    // them -- 16.5 vs 13.9 us at MS=4 -- so unlike the forward kernel they go in front.)
+    // Epilogue operands: direct gradient terms and the saved gates of this step, requested from inside the contraction
+    // (ksplit.h: after_first_loads) like the forward kernel's.
     const int jc = j0 + (t & 15);
     float pd[MS][3], psv[MS][5];
+    auto prefetch = [&]() {
+        kernarg_touch(P.dhz_next, P.dout, P.ld_dout, P.dout2, P.ld_dout2, P.sv_r, P.sv_z, P.sv_n, P.sv_ghn, P.sv_hprev,
+                      P.dh_out, P.ld_dhout, P.dh_out_accumulate);
 #pragma unroll
-    for (int p = 0; p < MS; ++p) {
-        const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
-        const long o = (long)b * H + jc;
-        pd[p][0] = P.dhz_next ? P.dhz_next[o] : 0.f;
-        pd[p][1] = P.dout ? P.dout[(long)b * P.ld_dout + jc] : 0.f;
-        pd[p][2] = P.dout2 ? P.dout2[(long)b * P.ld_dout2 + jc] : 0.f;
+        for (int p = 0; p < MS; ++p) {
+            const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
+            const long o = (long)b * H + jc;
+            pd[p][0] = P.dhz_next ? P.dhz_next[o] : 0.f;
+            pd[p][1] = P.dout ? P.dout[(long)b * P.ld_dout + jc] : 0.f;
+            pd[p][2] = P.dout2 ? P.dout2[(long)b * P.ld_dout2 + jc] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 5; ++a) psv[p][a] = 0.f;
-        if (P.sv_r) {
-            psv[p][0] = P.sv_r[o]; psv[p][1] = P.sv_z[o]; psv[p][2] = P.sv_n[o]; psv[p][3] = P.sv_ghn[o];
-            psv[p][4] = P.sv_hprev[o];
-        } else if (P.dh_out_accumulate) {
-            psv[p][0] = P.dh_out[(long)b * P.ld_dhout + jc];
+            for (int a = 0; a < 5; ++a) psv[p][a] = 0.f;
+            if (P.sv_r) {
+                psv[p][0] = P.sv_r[o]; psv[p][1] = P.sv_z[o]; psv[p][2] = P.sv_n[o]; psv[p][3] = P.sv_ghn[o];
+                psv[p][4] = P.sv_hprev[o];
+            } else if (P.dh_out_accumulate) {
+                psv[p][0] = P.dh_out[(long)b * P.ld_dhout + jc];
+            }
         }
-    }
+    };
 
     float v[MS][1];
 #pragma unroll
@@ -217,10 +229,13 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int brow[1] = {j0};
         const int slot[1] = {0};
-        if (PK) ksplit_segment<MS, 1, true>(acc, slot, P.dghpk_next, 0, row0, P.B, P.Wpk_hhT, 0, brow, 3 * H, t);
-        else ksplit_segment<MS, 1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t);
+        if (PK) ksplit_segment<MS, 1, true>(acc, slot, P.dghpk_next, 0, row0, P.B, P.Wpk_hhT, 0, brow, 3 * H, t, prefetch);
+        else ksplit_segment<MS, 1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t, prefetch);
         TRACE(1);
         reduce_waves<MS, 1>(acc, lds, t, v);
+    }
+    else {
+        prefetch();
     }
     TRACE(2);
     float bs[4] = {0.f, 0.f, 0.f, 0.f};            // this thread's column partials: dr, dz, dn, dn*r
@@ -360,7 +375,12 @@ int launch_gru_fwd(const GruFwdBatch& bin, hipStream_t s) {
     if (maxB <= 0) return 0;
     const int ms = pick_ms(b.nprob, maxB, b.H, 4);
     b.tiles_per_prob = (maxB + 16 * ms - 1) / (16 * ms);
+    // Row tiles on the fastest grid axis: consecutive workgroups go to different XCDs, so each XCD then owns whole
+    // row tiles (one direction's W stays in its 4 MB L2, it reads only its own rows of the fresh hidden state) instead
+    // of column slices of every row.  ~2.5 % on these kernels; not with the extra W_ih (6 MB per XCD would not fit).
+    b.rows_fastest = !hasx;
     dim3 grid(b.H / TH, b.tiles_per_prob * b.nprob, 1);
+    if (b.rows_fastest) grid = dim3(b.tiles_per_prob * b.nprob, b.H / TH, 1);
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) fl += 2.0 * b.p[i].B * 3.0 * b.H * (b.H + (hasx ? b.p[i].K2 : 0));
     ProfScope prof(PROF_GRU_FWD, fl, s);
@@ -389,7 +409,9 @@ int launch_gru_bwd(const GruBwdBatch& bin, hipStream_t s) {
     if (maxB <= 0) return 0;
     const int ms = pick_ms(b.nprob, maxB, b.H, 8);
     b.tiles_per_prob = (maxB + 16 * ms - 1) / (16 * ms);
+    b.rows_fastest = 1;
     dim3 grid(b.H / TH, b.tiles_per_prob * b.nprob, 1);
+    if (b.rows_fastest) grid = dim3(b.tiles_per_prob * b.nprob, b.H / TH, 1);
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].dgh_next) fl += 2.0 * b.p[i].B * 3.0 * b.H * b.H;
     ProfScope prof(PROF_GRU_BWD, fl, s);

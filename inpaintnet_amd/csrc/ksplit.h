@@ -12,6 +12,7 @@
 // The recurrent weights are re-packed once per call (pw_pack_frag), the hidden state / gate gradients are written in
 // this layout by the previous step's epilogue (pk_offset), so the extra cost is a few KB of stores per workgroup.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace ksplit {
@@ -76,6 +77,61 @@ __device__ __forceinline__ void load_step(Frag<MS, NB>& f, const float* __restri
     }
 }
 
+// One fragment of a k-step (unguarded forms only): I < MS -> a[I], else b[I - MS].
+template <int MS, int NB, bool PK, int I>
+__device__ __forceinline__ void load_frag(Frag<MS, NB>& f, const float* __restrict__ A, long lda, int row0, int rowsA,
+                                          const float* __restrict__ Bm, long ldb, const int (&brow)[NB], int K, int s,
+                                          int i16, int q) {
+    if (PK) {
+        const int S = K >> 4, lane4 = (q * 16 + i16) * 4;
+        if (I < MS) {
+            const int last = (rowsA - 1) >> 4;
+            f.a[I < MS ? I : 0] = *reinterpret_cast<const f32x4*>(A + ((long)min((row0 >> 4) + I, last) * S + s) * 256 + lane4);
+        } else {
+            constexpr int g = I < MS ? 0 : I - MS;
+            f.b[g] = *reinterpret_cast<const f32x4*>(Bm + ((long)(brow[g] >> 4) * S + s) * 256 + lane4);
+        }
+    } else {
+        const int k = 16 * s + 4 * q;
+        if (I < MS) {
+            f.a[I < MS ? I : 0] = ld4u(A + (long)min(row0 + 16 * I + i16, rowsA - 1) * lda + k);
+        } else {
+            constexpr int g = I < MS ? 0 : I - MS;
+            f.b[g] = ld4u(Bm + (long)(brow[g] + i16) * ldb + k);
+        }
+    }
+}
+
+// MFMAs [M0, M1) of a k-step in the order e (4) x ms x g
+template <int MS, int NB, int M0, int M1>
+__device__ __forceinline__ void mma_range(f32x4 (&acc)[MS][4], const int (&slot)[NB], const Frag<MS, NB>& f) {
+#pragma unroll
+    for (int m = M0; m < M1; ++m) {
+        const int e = m / (MS * NB), ms = (m % (MS * NB)) / NB, g = m % NB;
+        acc[ms][slot[g]] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ms][e], f.b[g][e], acc[ms][slot[g]], 0, 0, 0);
+    }
+}
+
+// MFMAs of step `cur` with the loads of a later step `nxt` (k-step s_nxt) dealt in between them, one load per
+// ceil(4*MS*NB / (MS+NB)) MFMAs.  Why: a wave issues in order and a vector-memory instruction waits in the issue
+// stage until the CU's address path takes it (~100 cycles per 1 KB instruction with 4 waves streaming, measured:
+// 56 back-to-back loads = 5,500 cycles during which the wave's MFMA pipe idles).  Spread out, the same loads need
+// 18-40 B/clk of the CU's 64 and cost the MFMA stream nothing.  sched_barrier pins the interleave.
+template <int MS, int NB, bool PK, bool LOAD, int I = 0>
+__device__ __forceinline__ void mma_and_prefetch(f32x4 (&acc)[MS][4], const int (&slot)[NB], const Frag<MS, NB>& cur,
+                                                 Frag<MS, NB>& nxt, const float* __restrict__ A, long lda, int row0,
+                                                 int rowsA, const float* __restrict__ Bm, long ldb,
+                                                 const int (&brow)[NB], int K, int s_nxt, int i16, int q) {
+    constexpr int NM = 4 * MS * NB, FR = MS + NB, CH = (NM + FR - 1) / FR;
+    if constexpr (I < FR) {
+        if (LOAD) load_frag<MS, NB, PK, I>(nxt, A, lda, row0, rowsA, Bm, ldb, brow, K, s_nxt, i16, q);
+        constexpr int M0 = I * CH < NM ? I * CH : NM, M1 = (I + 1) * CH < NM ? (I + 1) * CH : NM;
+        mma_range<MS, NB, M0, M1>(acc, slot, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_and_prefetch<MS, NB, PK, LOAD, I + 1>(acc, slot, cur, nxt, A, lda, row0, rowsA, Bm, ldb, brow, K, s_nxt, i16, q);
+    }
+}
+
 template <int MS, int NB>
 __device__ __forceinline__ void mma_step(f32x4 (&acc)[MS][4], const int (&slot)[NB], const Frag<MS, NB>& f) {
 #pragma unroll
@@ -104,29 +160,84 @@ __device__ __forceinline__ void ksplit_fast(f32x4 (&acc)[MS][4], const int (&slo
                                             long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
                                             const int (&brow)[NB], int K, int s_beg, int s_end, int i16, int q,
                                             Hook&& after_first_loads) {
+    // Groups of GDEPTH k-steps, two groups in flight.  The steady-state loop body is branch-free on purpose: a
+    // conditional "load the next group" merges two paths with different numbers of outstanding loads, and the compiler
+    // must then wait for the smaller count -- vmcnt(15) instead of vmcnt(35) here, i.e. for the prefetched group as
+    // well (seen in the ISA of the K = 3H backward contraction).  An odd group count runs one group up front.
     Frag<MS, NB> f0[GDEPTH], f1[GDEPTH];
+    auto load = [&](Frag<MS, NB> (&f)[GDEPTH], int s) {
 #pragma unroll
-    for (int d = 0; d < GDEPTH; ++d)
-        load_step<MS, NB, false, PK>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
+        for (int d = 0; d < GDEPTH; ++d) load_step<MS, NB, false, PK>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + d, i16, q);
+        // keep the group's loads together and ahead of the MFMAs that follow: left alone the scheduler sinks them
+        // between the MFMAs and the waits become vmcnt(0..3).  (An asm memory clobber does not hold them: they are
+        // invariant loads to the compiler.)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma = [&](const Frag<MS, NB> (&f)[GDEPTH]) {
+#pragma unroll
+        for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f[d]);
+    };
+    const int n = (s_end - s_beg) / GDEPTH;                    // wave-uniform
+    int s = s_beg;
+    load(f0, s);
     after_first_loads();
-    for (int s = s_beg; s < s_end; s += 2 * GDEPTH) {
-        const bool more1 = s + GDEPTH < s_end, more2 = s + 2 * GDEPTH < s_end;     // wave-uniform
-        if (more1) {
+    if (n & 1) {
+        mma(f0);
+        s += GDEPTH;
+        if (n == 1) return;
+        load(f0, s);
+    }
+    for (; s + 2 * GDEPTH < s_end; s += 2 * GDEPTH) {
+        load(f1, s + GDEPTH);
+        mma(f0);
+        load(f0, s + 2 * GDEPTH);
+        mma(f1);
+    }
+    load(f1, s + GDEPTH);
+    mma(f0);
+    mma(f1);
+}
+
+// Streamed contraction over k-steps [s_beg, s_end) (count a multiple of R): ring of R step-fragments, R-1 steps of
+// loads requested up front, then every step's MFMAs carry the loads of the step R-1 ahead.  The loop body (R steps,
+// static ring slots) is branch-free; the last R-1 steps run without loads.
+template <int MS, int NB, bool PK, int R, class Hook>
+__device__ __forceinline__ void ksplit_stream(f32x4 (&acc)[MS][4], const int (&slot)[NB], const float* __restrict__ A,
+                                              long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
+                                              const int (&brow)[NB], int K, int s_beg, int s_end, int i16, int q,
+                                              Hook&& after_first_loads) {
+    Frag<MS, NB> f[R];
 #pragma unroll
-            for (int d = 0; d < GDEPTH; ++d)
-                load_step<MS, NB, false, PK>(f1[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + GDEPTH + d, i16, q);
+    for (int d = 0; d < R - 1; ++d) load_step<MS, NB, false, PK>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
+    __builtin_amdgcn_sched_barrier(0);
+    // step j of a body that starts at k-step s: MFMAs of ring slot j, loads of step s+j+R-1 into the slot freed last
+    auto body = [&](int s, auto with_hook) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[j], f[(j + R - 1) % R], A, lda, row0, rowsA, Bm, ldb, brow, K,
+                                               s + j + R - 1, i16, q);
+            if (j == 0 && decltype(with_hook)::value) { after_first_loads(); __builtin_amdgcn_sched_barrier(0); }
         }
+    };
+    auto drain = [&](int s, auto with_hook) {
+        mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[0], f[R - 1], A, lda, row0, rowsA, Bm, ldb, brow, K, s + R - 1, i16, q);
+        if (decltype(with_hook)::value) { after_first_loads(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f0[d]);
-        if (more2) {
-#pragma unroll
-            for (int d = 0; d < GDEPTH; ++d)
-                load_step<MS, NB, false, PK>(f0[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + 2 * GDEPTH + d, i16, q);
-        }
-        if (more1) {
-#pragma unroll
-            for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f1[d]);
-        }
+        for (int j = 1; j < R; ++j)
+            mma_and_prefetch<MS, NB, PK, false>(acc, slot, f[j], f[0], A, lda, row0, rowsA, Bm, ldb, brow, K, 0, i16, q);
+    };
+    // The caller's hook (its epilogue-operand requests) runs after the first step's MFMAs: by then the address path is
+    // down from the prologue burst to the streaming rate, and ~2 dozen small loads issue in a few hundred cycles
+    // instead of ~2,000 right behind the burst.
+    using Yes = std::true_type;
+    using No = std::false_type;
+    int s = s_beg;
+    if (s + R < s_end) {
+        body(s, Yes{});
+        for (s += R; s + R < s_end; s += R) body(s, No{});
+        drain(s, No{});
+    } else {
+        drain(s, Yes{});
     }
 }
 
@@ -155,19 +266,15 @@ __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[MS][4], const int (&
     const int i16 = lane & 15, q = lane >> 4;
     const int S = (K + 15) >> 4;                   // k-steps of 16
     constexpr int FR = MS + NB;                    // float4 fragment registers per k-step
-    if (K == 512 && FR <= 7) {
-        ksplit_once8<MS, NB, PK>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * 8, i16, q, after_first_loads);
-    } else if (PK) {
-        // each wave owns S/4 = multiple of 4 steps
+    if ((K & 255) == 0 && (PK || (K & 511) == 0)) {
+        // each wave owns S/4 steps: a multiple of 4 (of 8 when K % 512 == 0).  Ring of 8 while it fits the registers.
         const int Sq = S >> 2;
-        ksplit_fast<MS, NB, 4, true>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q,
-                                     after_first_loads);
-    } else if ((K & 511) == 0) {
-        // each wave owns S/4 = multiple of 8 steps
-        const int Sq = S >> 2;
-        constexpr int GDEPTH = FR <= 3 ? 8 : 4;
-        ksplit_fast<MS, NB, GDEPTH, false>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q,
-                                           after_first_loads);
+        if ((Sq & 7) == 0 && FR <= 5)
+            ksplit_stream<MS, NB, PK, 8>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q,
+                                         after_first_loads);
+        else
+            ksplit_stream<MS, NB, PK, 4>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q,
+                                         after_first_loads);
     } else {
         // general path (small / odd K): guarded loads, one step at a time
         const int Sq = (S + 3) >> 2;

@@ -1,3 +1,4 @@
+#include <cstdlib>
 #include "seq.h"
 
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
@@ -251,7 +252,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     }
     // The chain can hand its weight gradients to the side stream a chunk of steps at a time (CH < T) so that they do
     // not all queue up behind the last step.  Measured at B=256: the side stream is already the longer of the two
-    // during backward, and four K=1536 chunks cost 408 us against 290 us for one K=6144 product -- so one chunk.
+    // during backward; 2 or 3 chunks measured no faster than one (5.70 / 5.73 vs 5.69 ms per step) -- so one chunk.
     const int CH = T;
     for (int hi = T - 1; hi >= 0; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0;

@@ -90,13 +90,16 @@ for key, idx in launches:
         wgmax=np.max(t[idx, 3] - t[idx, 0]) / 100.0,
         mhz=float(np.median(rec[idx, 7].astype(np.float64) / np.maximum(1, (t[idx, 3] - t[idx, 0])) * 100.0)),
         ccyc=float(np.median(rec[idx, 6].astype(np.float64))),
+        xa=float(np.median((rec[idx, 5] & np.uint64(0xfffff)).astype(np.float64))),
+        xb=float(np.median(((rec[idx, 5] >> np.uint64(20)) & np.uint64(0xfffff)).astype(np.float64))),
+        xc=float(np.median(((rec[idx, 5] >> np.uint64(40)) & np.uint64(0xfffff)).astype(np.float64))),
     ))
 print(f"{n} workgroup records, {len(launches)} launches (one teacher-forced training step, side stream "
       f"{'on' if int(os.environ.get('SIDE', '0')) else 'off'})")
 print(f"{'kernel':<8}{'MS':>3}{'gridY':>6}{'launches':>9}{'WGs':>6} | us: {'start spread':>12}{'contraction':>12}{'reduce':>8}"
-      f"{'epilogue':>9}{'per-WG':>8}{'WG max':>8}{'first->last end':>16}{'clock MHz':>10}{'contr cyc':>10}")
+      f"{'epilogue':>9}{'per-WG':>8}{'WG max':>8}{'first->last end':>16}{'clock MHz':>10}{'contr cyc':>10}{'  cyc: entry->loads':>20}{'->issued':>9}{'->hook end':>11}")
 for key in sorted(agg):
     v = agg[key]
     m = lambda f: float(np.median([x[f] for x in v]))
     print(f"{names[key[0]]:<8}{key[1]:>3}{key[2]:>6}{len(v):>9}{int(m('wgs')):>6} |     {m('spread'):>12.2f}{m('contr'):>12.2f}"
-          f"{m('red'):>8.2f}{m('epi'):>9.2f}{m('wg'):>8.2f}{m('wgmax'):>8.2f}{m('span'):>16.2f}{m('mhz'):>10.0f}{m('ccyc'):>10.0f}")
+          f"{m('red'):>8.2f}{m('epi'):>9.2f}{m('wg'):>8.2f}{m('wgmax'):>8.2f}{m('span'):>16.2f}{m('mhz'):>10.0f}{m('ccyc'):>10.0f}{m('xa'):>20.0f}{m('xb'):>9.0f}{m('xc'):>11.0f}")
