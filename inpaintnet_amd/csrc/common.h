@@ -135,5 +135,7 @@ struct GruBwdBatch { int H; int nprob; int tiles_per_prob; int rows_fastest; Gru
 int launch_gemm(const GemmArgs& g, hipStream_t s);
 int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s);
 int launch_gru_bwd(const GruBwdBatch& b, hipStream_t s);
+// hpk / Wpk: optional fragment-major twins of h and W (used when both are given and H % 256 == 0)
 int launch_logits_argmax(const float* h, long ldh, int B, int H, const float* W, const float* bias, int V, float* out,
-                         long ldo, long long* samples, long sstride, hipStream_t s);
+                         long ldo, long long* samples, long sstride, hipStream_t s, const float* hpk = nullptr,
+                         const float* Wpk = nullptr);

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
 
 // Output projection of one decoder tick, fused: weights[:, t, :] = ReLU(h_top[B,H] x W_out[V,H]^T + b) and the
 // next token = argmax (lowest index on ties).  Same register-streamed K-split as the step kernels; V = 16*NB <= 64.
-template <int NB>
+// PK: h and W are the fragment-major twins (the tick step's packed h ring, W_out packed once per call).
+template <int NB, bool PK>
 __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restrict__ h, long ldh, int B, int H,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
                                                             float* __restrict__ out, long ldo,
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(const float* __restr
     int brow[NB], slot[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) { brow[g] = 16 * g; slot[g] = g; }
-    ksplit_segment<2, NB>(acc, slot, h, ldh, row0, B, W, (long)H, brow, H, t);
+    ksplit_segment<2, NB, PK>(acc, slot, h, ldh, row0, B, W, (long)H, brow, H, t);
     float v[2][NB];
     reduce_waves<2, NB>(acc, lds, t, v);
     constexpr int V = 16 * NB;
@@ -430,15 +431,24 @@ int launch_gru_bwd(const GruBwdBatch& bin, hipStream_t s) {
 
 // returns 1 if the fused path does not apply (caller falls back to GEMM + argmax)
 int launch_logits_argmax(const float* h, long ldh, int B, int H, const float* W, const float* bias, int V, float* out,
-                         long ldo, long long* samples, long sstride, hipStream_t s) {
+                         long ldo, long long* samples, long sstride, hipStream_t s, const float* hpk, const float* Wpk) {
     if (V % 16 != 0 || V > 64 || H % TH != 0) return 1;
     dim3 grid((B + TM_ROWS - 1) / TM_ROWS);
     ProfScope prof(PROF_GEMM, 2.0 * B * V * H, s, "logits_argmax");
+    const bool pk = hpk && Wpk && H % 256 == 0;
+    const float* a = pk ? hpk : h;
+    const float* w = pk ? Wpk : W;
+#define INET_LOGITS(NBV)                                                                                                \
+    do {                                                                                                                \
+        if (pk) hipLaunchKernelGGL((logits_argmax_kernel<NBV, true>), grid, dim3(256), 0, s, a, ldh, B, H, w, bias, out, ldo, samples, sstride);  \
+        else hipLaunchKernelGGL((logits_argmax_kernel<NBV, false>), grid, dim3(256), 0, s, a, ldh, B, H, w, bias, out, ldo, samples, sstride);    \
+    } while (0)
     switch (V / 16) {
-        case 1: hipLaunchKernelGGL(logits_argmax_kernel<1>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
-        case 2: hipLaunchKernelGGL(logits_argmax_kernel<2>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
-        case 3: hipLaunchKernelGGL(logits_argmax_kernel<3>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
-        default: hipLaunchKernelGGL(logits_argmax_kernel<4>, grid, dim3(256), 0, s, h, ldh, B, H, W, bias, out, ldo, samples, sstride); break;
+        case 1: INET_LOGITS(1); break;
+        case 2: INET_LOGITS(2); break;
+        case 3: INET_LOGITS(3); break;
+        default: INET_LOGITS(4); break;
     }
+#undef INET_LOGITS
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -147,7 +147,7 @@ struct DecWs {
     float *dbeat_out, *dgi1b, *dgh1b, *dxb, *dgi0b, *dgh0b, *dhb0, *tmp3h;
     // fragment-major twins (ksplit.h), null unless pk_ok(H): packed recurrent / layer-1 input weights, packed initial
     // tick hiddens [layer][beat], ping-pong packed hiddens [beat][2], packed masked layer-0 output [beat]
-    float *wpk_b[2], *wpk_t0, *wpk_t1hh, *wpk_t1ih, *hpk_b, *ht0pk, *hpk_t0, *hpk_t1, *hm0pk;
+    float *wpk_b[2], *wpk_t0, *wpk_t1hh, *wpk_t1ih, *wpk_out, *hpk_b, *ht0pk, *hpk_t0, *hpk_t1, *hm0pk;
     float *wpkT[4], *dghpk;
 };
 
@@ -206,6 +206,7 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.wpk_t0 = pk ? cv.take<float>(W3) : nullptr;
     w.wpk_t1hh = pk ? cv.take<float>(W3) : nullptr;
     w.wpk_t1ih = pk ? cv.take<float>(W3) : nullptr;
+    w.wpk_out = pk && V % 16 == 0 ? cv.take<float>(V * H) : nullptr;
     w.hpk_b = pk ? cv.take<float>(2 * pkh) : nullptr;
     w.ht0pk = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
     w.hpk_t0 = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
@@ -249,6 +250,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     dec_carve(c, B, save, ws, w);
     if (save && hipMemcpyAsync(w.zsave, z, (size_t)B * Z * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
     const bool pk = w.wpk_t0 != nullptr;
+    static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
     const long pkh = (long)pk_floats(B, H);
     if (pk) {
         INET_TRY(pw_pack_frag(p + L.beat[0].w_hh, H, 3 * H, H, w.wpk_b[0], 0, 1, 0, 0, s));
@@ -256,6 +258,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         INET_TRY(pw_pack_frag(p + L.tick[0].w_hh, H, 3 * H, H, w.wpk_t0, 0, 1, 0, 0, s));
         INET_TRY(pw_pack_frag(p + L.tick[1].w_hh, H, 3 * H, H, w.wpk_t1hh, 0, 1, 0, 0, s));
         INET_TRY(pw_pack_frag(p + L.tick[1].w_ih, H, 3 * H, H, w.wpk_t1ih, 0, 1, 0, 0, s));
+        if (w.wpk_out && !(teacher_forced && tf_batch)) INET_TRY(pw_pack_frag(p + L.out_w, H, V, H, w.wpk_out, 0, 1, 0, 0, s));
     }
 
     // ---- beat RNN (forward_beat_rnn, decoder.py:455-471) ----
@@ -299,7 +302,6 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         return -2;
 
     // ---- tick RNN (forward_tick_rnn, decoder.py:473-529) ----
-    static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
     if (teacher_forced && tf_batch) {
         // Every input token is known, and the tick GRU's hidden state is re-initialised per beat, so the 4 beats are
         // independent: 6 steps x 4 problems per layer instead of 24 dependent steps, and ONE output projection.
@@ -384,7 +386,8 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
 
         // logits = ReLU(h_top . Wo^T + bo) straight into weights[:, t, :], fused with the argmax that feeds tick t+1
         int rc = launch_logits_argmax(w.h1seq + (long)t * BH, H, B, H, p + L.out_w, p + L.out_b, V, weights + (long)t * V,
-                                      (long)T * V, teacher_forced ? nullptr : samples + t, T, s);
+                                      (long)T * V, teacher_forced ? nullptr : samples + t, T, s,
+                                      pk ? P1.hpk_new : nullptr, w.wpk_out);
         if (rc < 0) return rc;
         if (rc == 1) {                                         // V not a multiple of 16 (or > 64): two kernels
             INET_TRY(linear_fwd(w.h1seq + (long)t * BH, H, p + L.out_w, H, p + L.out_b, weights + (long)t * V,
