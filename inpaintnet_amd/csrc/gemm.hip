@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "prof.h"
+#include "side.h"
 
 namespace {
 
@@ -221,11 +222,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 template <int TM, int TN>
-int launch_cfg(const GemmArgs& g, dim3 grid, hipStream_t s) {
-    if (!g.a_kmajor && !g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, dim3(256), 0, s, g);
-    else if (!g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, dim3(256), 0, s, g);
-    else if (g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, dim3(256), 0, s, g);
+int launch_cfg(const GemmArgs& g, dim3 grid, hipStream_t s, unsigned pad) {
+    if (!g.a_kmajor && !g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, dim3(256), pad, s, g);
+    else if (!g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, dim3(256), pad, s, g);
+    else if (g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), grid, dim3(256), pad, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, dim3(256), pad, s, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -316,12 +317,17 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     int rc;
     {
         ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label);
+        // Leaf GEMMs on the side stream: 64x64 tiles would sit 4 to a CU and take 147 of its 160 KB of LDS, so a BPTT
+        // step kernel arriving on the main stream (16-32 KB) has to wait for one of them to retire.  A few KB of unused
+        // dynamic LDS caps them at 3 per CU and leaves the step kernels room to co-reside (5.22 -> 5.18 ms per step;
+        // capping at 2 per CU costs the GEMMs more than it gives: 5.40).
+        const unsigned pad = (bi == 0 && side_is(s)) ? 4608u : 0u;
         switch (bi) {
-            case 0: rc = launch_cfg<1, 1>(g, grid, s); break;
-            case 1: rc = launch_cfg<2, 2>(g, grid, s); break;
-            case 2: rc = launch_cfg<3, 1>(g, grid, s); break;
-            case 3: rc = launch_cfg<3, 2>(g, grid, s); break;
-            default: rc = launch_cfg<3, 3>(g, grid, s); break;
+            case 0: rc = launch_cfg<1, 1>(g, grid, s, pad); break;
+            case 1: rc = launch_cfg<2, 2>(g, grid, s, 0); break;
+            case 2: rc = launch_cfg<3, 1>(g, grid, s, 0); break;
+            case 3: rc = launch_cfg<3, 2>(g, grid, s, 0); break;
+            default: rc = launch_cfg<3, 3>(g, grid, s, 0); break;
         }
         if (rc == 0 && two_pass) {
             long n = (long)g.M * g.N;

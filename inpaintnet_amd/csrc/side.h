@@ -16,3 +16,4 @@ int side_join_now(hipStream_t main_stream);
 void side_set_defer(int on);
 void side_set_enabled(int on);
 int side_enabled();
+bool side_is(hipStream_t s);                         // s is the side stream

@@ -31,6 +31,7 @@ int side_enabled() {
     return g_enabled;
 }
 void side_set_enabled(int on) { g_enabled = on ? 1 : 0; }
+bool side_is(hipStream_t s) { return g_side != nullptr && s == g_side; }
 
 hipStream_t side_fork(hipStream_t main_stream) {
     if (!side_enabled()) return main_stream;
