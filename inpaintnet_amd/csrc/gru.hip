@@ -179,110 +179,125 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 //   dn_pre = dn (1-n^2); dz_pre = dz z(1-z); dr_pre = dn_pre ghn r(1-r)
 //   dgi = [dr_pre, dz_pre, dn_pre]      dgh = [dr_pre, dz_pre, dn_pre r]
 //   db_ih += colsum(dgi) ; db_hh += colsum(dgh)               (tile-reduced, one atomic per column per workgroup)
-template <int MS, bool PK>
+// Tile = 16*MS batch rows x 16*NC hidden columns.  The contraction runs over K = 3H, so the operand traffic per
+// output is (rows + cols) * 3H: squarer tiles (NC = 2) move 20-33 % fewer bytes through the CU's address path than
+// 16-column ones for the same number of outputs (64x16 -> 32x32: 480 -> 384 KB; 128x16 -> 64x32: 864 -> 576 KB).
+template <int MS, int NC, bool PK>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
-    __shared__ __attribute__((aligned(16))) float lds[(4 * MS * 256 > 1024) ? 4 * MS * 256 : 1024];
+    __shared__ __attribute__((aligned(16))) float lds[(4 * MS * NC * 256 > 1024 * NC) ? 4 * MS * NC * 256 : 1024 * NC];
     const int bcol = bt.rows_fastest ? blockIdx.y : blockIdx.x, brow_t = bt.rows_fastest ? blockIdx.x : blockIdx.y;
     const int prob = brow_t / bt.tiles_per_prob;
     const GruBwdProb& P = bt.p[prob];
     const int H = bt.H;
     const int t = threadIdx.x;
-    const int j0 = bcol * TH;
+    const int j0 = bcol * (TH * NC);
     const int row0 = (brow_t % bt.tiles_per_prob) * (16 * MS);
     if (row0 >= P.B) return;
     TRACE_DECL;
     TRACE(0);
 
     // Epilogue operands: direct gradient terms and the saved gates of this step, requested from inside the contraction
-    // (ksplit.h: after_first_loads) like the forward kernel's.
+    // (ksplit.h: after_first_loads) like the forward kernel's.  Output (p, a) of this thread: row (t + 256p) >> 4,
+    // column j0 + 16a + (t & 15).
     const int jc = j0 + (t & 15);
-    float pd[MS][3], psv[MS][5];
+    float pd[MS][NC][3], psv[MS][NC][5];
     auto prefetch = [&]() {
         kernarg_touch(P.dhz_next, P.dout, P.ld_dout, P.dout2, P.ld_dout2, P.sv_r, P.sv_z, P.sv_n, P.sv_ghn, P.sv_hprev,
                       P.dh_out, P.ld_dhout, P.dh_out_accumulate);
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
-            const long o = (long)b * H + jc;
-            pd[p][0] = P.dhz_next ? P.dhz_next[o] : 0.f;
-            pd[p][1] = P.dout ? P.dout[(long)b * P.ld_dout + jc] : 0.f;
-            pd[p][2] = P.dout2 ? P.dout2[(long)b * P.ld_dout2 + jc] : 0.f;
 #pragma unroll
-            for (int a = 0; a < 5; ++a) psv[p][a] = 0.f;
-            if (P.sv_r) {
-                psv[p][0] = P.sv_r[o]; psv[p][1] = P.sv_z[o]; psv[p][2] = P.sv_n[o]; psv[p][3] = P.sv_ghn[o];
-                psv[p][4] = P.sv_hprev[o];
-            } else if (P.dh_out_accumulate) {
-                psv[p][0] = P.dh_out[(long)b * P.ld_dhout + jc];
+            for (int a = 0; a < NC; ++a) {
+                const int j = jc + 16 * a;
+                const long o = (long)b * H + j;
+                pd[p][a][0] = P.dhz_next ? P.dhz_next[o] : 0.f;
+                pd[p][a][1] = P.dout ? P.dout[(long)b * P.ld_dout + j] : 0.f;
+                pd[p][a][2] = P.dout2 ? P.dout2[(long)b * P.ld_dout2 + j] : 0.f;
+                psv[p][a][0] = P.sv_r ? P.sv_r[o] : (P.dh_out_accumulate ? P.dh_out[(long)b * P.ld_dhout + j] : 0.f);
+                psv[p][a][1] = P.sv_r ? P.sv_z[o] : 0.f;
+                psv[p][a][2] = P.sv_r ? P.sv_n[o] : 0.f;
+                psv[p][a][3] = P.sv_r ? P.sv_ghn[o] : 0.f;
+                psv[p][a][4] = P.sv_r ? P.sv_hprev[o] : 0.f;
             }
         }
     };
 
-    float v[MS][1];
+    float v[MS][NC];
 #pragma unroll
-    for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
+    for (int p = 0; p < MS; ++p)
+#pragma unroll
+        for (int a = 0; a < NC; ++a) v[p][a] = 0.f;
     if (P.dgh_next) {
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int brow[1] = {j0};
-        const int slot[1] = {0};
-        if (PK) ksplit_segment<MS, 1, true>(acc, slot, P.dghpk_next, 0, row0, P.B, P.Wpk_hhT, 0, brow, 3 * H, t, prefetch);
-        else ksplit_segment<MS, 1>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t, prefetch);
+        int brow[NC], slot[NC];
+#pragma unroll
+        for (int a = 0; a < NC; ++a) { brow[a] = j0 + 16 * a; slot[a] = a; }
+        if (PK) ksplit_segment<MS, NC, true>(acc, slot, P.dghpk_next, 0, row0, P.B, P.Wpk_hhT, 0, brow, 3 * H, t, prefetch);
+        else ksplit_segment<MS, NC>(acc, slot, P.dgh_next, P.ld_dgh, row0, P.B, P.W_hhT, (long)3 * H, brow, 3 * H, t, prefetch);
         TRACE(1);
-        reduce_waves<MS, 1>(acc, lds, t, v);
+        reduce_waves<MS, NC>(acc, lds, t, v);
     }
     else {
         prefetch();
     }
     TRACE(2);
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};            // this thread's column partials: dr, dz, dn, dn*r
+    float bs[NC][4];                               // this thread's column partials: dr, dz, dn, dn*r
+#pragma unroll
+    for (int a = 0; a < NC; ++a) bs[a][0] = bs[a][1] = bs[a][2] = bs[a][3] = 0.f;
 #pragma unroll
     for (int p = 0; p < MS; ++p) {
         const int pos = t + 256 * p;
         const int b = row0 + (pos >> 4);
-        const int j = jc;
         if (b >= P.B) continue;
-        const long o = (long)b * H + j;
-        const float dh = v[p][0] + pd[p][0] + pd[p][1] + pd[p][2];
-        if (!P.sv_r) {
-            P.dh_out[(long)b * P.ld_dhout + j] = P.dh_out_accumulate ? psv[p][0] + dh : dh;
-            continue;
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            const int j = jc + 16 * a;
+            const long o = (long)b * H + j;
+            const float dh = v[p][a] + pd[p][a][0] + pd[p][a][1] + pd[p][a][2];
+            if (!P.sv_r) {
+                P.dh_out[(long)b * P.ld_dhout + j] = P.dh_out_accumulate ? psv[p][a][0] + dh : dh;
+                continue;
+            }
+            const float r = psv[p][a][0], z = psv[p][a][1], n = psv[p][a][2], ghn = psv[p][a][3], hp = psv[p][a][4];
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hp - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * ghn * r * (1.f - r);
+            P.dhz[o] = dh * z;
+            float* gi = P.dgi + (long)b * P.ld_dgi;
+            gi[j] = dr_pre; gi[H + j] = dz_pre; gi[2 * H + j] = dn_pre;
+            float* gh = P.dgh + (long)b * P.ld_dghout;
+            gh[j] = dr_pre; gh[H + j] = dz_pre; gh[2 * H + j] = dn_pre * r;
+            if (P.dghpk) {
+                const int S3 = (3 * H) >> 4;
+                P.dghpk[pk_offset(b, j, S3)] = dr_pre;
+                P.dghpk[pk_offset(b, H + j, S3)] = dz_pre;
+                P.dghpk[pk_offset(b, 2 * H + j, S3)] = dn_pre * r;
+            }
+            bs[a][0] += dr_pre; bs[a][1] += dz_pre; bs[a][2] += dn_pre; bs[a][3] += dn_pre * r;
         }
-        const float r = psv[p][0], z = psv[p][1], n = psv[p][2], ghn = psv[p][3], hp = psv[p][4];
-        const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-        const float dz_pre = dh * (hp - n) * z * (1.f - z);
-        const float dr_pre = dn_pre * ghn * r * (1.f - r);
-        P.dhz[o] = dh * z;
-        float* gi = P.dgi + (long)b * P.ld_dgi;
-        gi[j] = dr_pre; gi[H + j] = dz_pre; gi[2 * H + j] = dn_pre;
-        float* gh = P.dgh + (long)b * P.ld_dghout;
-        gh[j] = dr_pre; gh[H + j] = dz_pre; gh[2 * H + j] = dn_pre * r;
-        if (P.dghpk) {
-            const int S3 = (3 * H) >> 4;
-            P.dghpk[pk_offset(b, j, S3)] = dr_pre;
-            P.dghpk[pk_offset(b, H + j, S3)] = dz_pre;
-            P.dghpk[pk_offset(b, 2 * H + j, S3)] = dn_pre * r;
-        }
-        bs[0] += dr_pre; bs[1] += dz_pre; bs[2] += dn_pre; bs[3] += dn_pre * r;
     }
     if (P.sv_r && P.db_ih) {
-        // thread t holds column (t & 15) for rows (t >> 4) + 16p: reduce the 16 row-threads per column
+        // thread t holds column (t & 15) of each group for rows (t >> 4) + 16p: reduce the 16 row-threads per column
         __syncthreads();
 #pragma unroll
-        for (int a = 0; a < 4; ++a) lds[a * 256 + t] = bs[a];
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[(a * 4 + e) * 256 + t] = bs[a][e];
         __syncthreads();
-        if (t < 64) {
-            const int a = t >> 4, c = t & 15;
+        if (t < 64 * NC) {
+            const int a = t >> 6, e = (t >> 4) & 3, c = t & 15;
             float s = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) s += lds[a * 256 + rr * 16 + c];
-            const int j = j0 + c;
-            if (a == 0) { unsafeAtomicAdd(P.db_ih + j, s); unsafeAtomicAdd(P.db_hh + j, s); }
-            else if (a == 1) { unsafeAtomicAdd(P.db_ih + H + j, s); unsafeAtomicAdd(P.db_hh + H + j, s); }
-            else if (a == 2) unsafeAtomicAdd(P.db_ih + 2 * H + j, s);
+            for (int rr = 0; rr < 16; ++rr) s += lds[(a * 4 + e) * 256 + rr * 16 + c];
+            const int j = j0 + 16 * a + c;
+            if (e == 0) { unsafeAtomicAdd(P.db_ih + j, s); unsafeAtomicAdd(P.db_hh + j, s); }
+            else if (e == 1) { unsafeAtomicAdd(P.db_ih + H + j, s); unsafeAtomicAdd(P.db_hh + H + j, s); }
+            else if (e == 2) unsafeAtomicAdd(P.db_ih + 2 * H + j, s);
             else unsafeAtomicAdd(P.db_hh + 2 * H + j, s);
         }
     }
@@ -408,23 +423,28 @@ int launch_gru_bwd(const GruBwdBatch& bin, hipStream_t s) {
     int maxB = 0;
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].B > maxB) maxB = b.p[i].B;
     if (maxB <= 0) return 0;
-    const int ms = pick_ms(b.nprob, maxB, b.H, 8);
+    int ms = pick_ms(b.nprob, maxB, b.H, 8);
+    // 128-row tiles (4 problems per launch) become 64 rows x 2 column groups (see the kernel's tile note): 22.5 -> 21.0 us.
+    // 64-row tiles stay 64x16: as 32x32 they measured slower (13.5 vs 11.9 us) despite the smaller traffic.
+    int nc = 1;
+    if (ms >= 8 && b.H % (2 * TH) == 0) { ms /= 2; nc = 2; }
     b.tiles_per_prob = (maxB + 16 * ms - 1) / (16 * ms);
     b.rows_fastest = 1;
-    dim3 grid(b.H / TH, b.tiles_per_prob * b.nprob, 1);
-    if (b.rows_fastest) grid = dim3(b.tiles_per_prob * b.nprob, b.H / TH, 1);
+    dim3 grid(b.tiles_per_prob * b.nprob, b.H / (TH * nc), 1);
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].dgh_next) fl += 2.0 * b.p[i].B * 3.0 * b.H * b.H;
     ProfScope prof(PROF_GRU_BWD, fl, s);
     bool pk = b.H % 256 == 0;
     for (int i = 0; i < b.nprob; ++i)
         if (b.p[i].dgh_next && (!b.p[i].dghpk_next || !b.p[i].Wpk_hhT)) pk = false;
-#define INET_BWD(M)                                                                                          \
+#define INET_BWD(M, C)                                                                                       \
     do {                                                                                                     \
-        if (pk) hipLaunchKernelGGL((gru_step_bwd_kernel<M, true>), grid, dim3(256), 0, s, b);                \
-        else hipLaunchKernelGGL((gru_step_bwd_kernel<M, false>), grid, dim3(256), 0, s, b);                  \
+        if (pk) hipLaunchKernelGGL((gru_step_bwd_kernel<M, C, true>), grid, dim3(256), 0, s, b);             \
+        else hipLaunchKernelGGL((gru_step_bwd_kernel<M, C, false>), grid, dim3(256), 0, s, b);               \
     } while (0)
-    if (ms == 2) INET_BWD(2); else if (ms == 4) INET_BWD(4); else INET_BWD(8);
+    if (nc == 2) INET_BWD(4, 2);
+    else if (ms == 2) INET_BWD(2, 1);
+    else INET_BWD(4, 1);
 #undef INET_BWD
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
