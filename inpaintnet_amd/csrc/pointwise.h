@@ -7,6 +7,9 @@ int pw_transpose(const float* in, long ld_in, float* out, long ld_out, int rows,
 // row-major [R,K] (or its transpose) -> fragment-major [ceil(R/16)][K/16][64][4] (ksplit.h); nbatch strided matrices
 int pw_pack_frag(const float* in, long ld, int R, int K, float* out, int transposed, int nbatch, long in_bstride,
                  long out_bstride, hipStream_t s);
+// the same for up to 8 equally shaped matrices in one launch
+int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long ld, int R, int K, int transposed,
+                       hipStream_t s);
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
                      float scale, float* loss_sum, float* correct, hipStream_t s);
 int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,

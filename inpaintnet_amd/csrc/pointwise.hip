@@ -71,6 +71,32 @@ __global__ void pack_frag_kernel(const float* __restrict__ in, long ld, int R, i
     }
 }
 
+// Up to 8 same-shaped matrices in one launch (the recurrent weights of a module): blockIdx.y = matrix.
+struct PackList { const float* in[8]; float* out[8]; };
+__global__ void pack_frag_multi_kernel(PackList pl, long ld, int R, int K, int transposed) {
+    const int S = K >> 4;
+    const long slots = (long)((R + 15) >> 4) * S * 64;
+    const float* __restrict__ in = pl.in[blockIdx.y];
+    float* __restrict__ out = pl.out[blockIdx.y];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long blk = i >> 6;
+        const int sb = (int)(blk % S), rb = (int)(blk / S);
+        const int row = 16 * rb + (lane & 15), k = 16 * sb + 4 * (lane >> 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R) {
+            if (!transposed) {
+                const float* q = in + (long)row * ld + k;
+                v = make_float4(q[0], q[1], q[2], q[3]);
+            } else {
+                const float* q = in + (long)k * ld + row;
+                v = make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]);
+            }
+        }
+        *reinterpret_cast<float4*>(out + 4 * i) = v;
+    }
+}
+
 // One wavefront per row of V logits.  loss_sum += lse - w[target];
 // correct += (argmax_first(w) == target); dW = (softmax - onehot) * scale.
 __global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int V,
@@ -364,6 +390,16 @@ int pw_pack_frag(const float* in, long ld, int R, int K, float* out, int transpo
     const long slots = (long)((R + 15) / 16) * (K / 16) * 64;
     dim3 grid(grid_for(slots, 256, 1024), nbatch);
     hipLaunchKernelGGL(pack_frag_kernel, grid, dim3(256), 0, s, in, ld, R, K, out, transposed, in_bstride, out_bstride);
+    return ok();
+}
+int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long ld, int R, int K, int transposed,
+                       hipStream_t s) {
+    if (K % 16 != 0 || R <= 0 || n <= 0 || n > 8) return -1;
+    PackList pl{};
+    for (int i = 0; i < n; ++i) { pl.in[i] = ins[i]; pl.out[i] = outs[i]; }
+    const long slots = (long)((R + 15) / 16) * (K / 16) * 64;
+    dim3 grid(grid_for(slots, 256, 1024), n);
+    hipLaunchKernelGGL(pack_frag_multi_kernel, grid, dim3(256), 0, s, pl, ld, R, K, transposed);
     return ok();
 }
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,

@@ -7,7 +7,13 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     bool pk = pk_ok(H);
     for (int i = 0; i < nd; ++i) if (!d[i].Wpk_hh || !d[i].hpk) pk = false;
     if (pk)                                                    // step 0 reads slot 1
-        for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
+    {
+        bool same_ld = true;
+        const float* ins[4]; float* outs[4];
+        for (int i = 0; i < nd; ++i) { ins[i] = d[i].h0; outs[i] = d[i].hpk + pkh; same_ld = same_ld && d[i].h0_ld == d[0].h0_ld; }
+        if (same_ld) INET_TRY(pw_pack_frag_multi(ins, outs, nd, d[0].h0_ld, B, H, 0, s));
+        else for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
+    }
     for (int step = 0; step < T; ++step) {
         GruFwdBatch bt{};
         bt.H = H; bt.nprob = nd;
@@ -151,7 +157,10 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
     const long BH = (long)B * H, TBH = (long)T * BH;
     if (!h0 && hipMemsetAsync(w.zeros, 0, BH * sizeof(float), s) != hipSuccess) return -2;
     if (w.wpk[0])
-        for (int i = 0; i < 4; ++i) INET_TRY(pw_pack_frag(P[i].w_hh, H, 3 * H, H, w.wpk[i], 0, 1, 0, 0, s));
+    {
+        const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
+        INET_TRY(pw_pack_frag_multi(ins, w.wpk, 4, H, 3 * H, H, 0, s));
+    }
     DirFwd d[2];
     for (int dir = 0; dir < 2; ++dir) {
         DirFwd& D = d[dir];
@@ -196,9 +205,11 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
                     const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const bool wg = P[0].dw_hh != nullptr;
-    for (int i = 0; i < 4; ++i) {
-        if (w.wpkT[i]) INET_TRY(pw_pack_frag(P[i].w_hh, H, H, 3 * H, w.wpkT[i], 1, 1, 0, 0, s));
-        else INET_TRY(pw_transpose(P[i].w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+    if (w.wpkT[0]) {
+        const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
+        INET_TRY(pw_pack_frag_multi(ins, w.wpkT, 4, H, H, 3 * H, 1, s));
+    } else {
+        for (int i = 0; i < 4; ++i) INET_TRY(pw_transpose(P[i].w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
     }
     // ---- layer 1 ----
     DirBwd d[2];

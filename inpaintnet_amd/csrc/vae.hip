@@ -253,11 +253,9 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
     const long pkh = (long)pk_floats(B, H);
     if (pk) {
-        INET_TRY(pw_pack_frag(p + L.beat[0].w_hh, H, 3 * H, H, w.wpk_b[0], 0, 1, 0, 0, s));
-        INET_TRY(pw_pack_frag(p + L.beat[1].w_hh, H, 3 * H, H, w.wpk_b[1], 0, 1, 0, 0, s));
-        INET_TRY(pw_pack_frag(p + L.tick[0].w_hh, H, 3 * H, H, w.wpk_t0, 0, 1, 0, 0, s));
-        INET_TRY(pw_pack_frag(p + L.tick[1].w_hh, H, 3 * H, H, w.wpk_t1hh, 0, 1, 0, 0, s));
-        INET_TRY(pw_pack_frag(p + L.tick[1].w_ih, H, 3 * H, H, w.wpk_t1ih, 0, 1, 0, 0, s));
+        const float* ins[5] = {p + L.beat[0].w_hh, p + L.beat[1].w_hh, p + L.tick[0].w_hh, p + L.tick[1].w_hh, p + L.tick[1].w_ih};
+        float* outs[5] = {w.wpk_b[0], w.wpk_b[1], w.wpk_t0, w.wpk_t1hh, w.wpk_t1ih};
+        INET_TRY(pw_pack_frag_multi(ins, outs, 5, H, 3 * H, H, 0, s));
         if (w.wpk_out && !(teacher_forced && tf_batch)) INET_TRY(pw_pack_frag(p + L.out_w, H, V, H, w.wpk_out, 0, 1, 0, 0, s));
     }
 
@@ -407,9 +405,11 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     DecWs w{};
     dec_carve(c, B, 1, ws, w);
     const GruDirOff* gr[4] = {&L.beat[0], &L.beat[1], &L.tick[0], &L.tick[1]};
-    for (int i = 0; i < 4; ++i) {
-        if (w.wpkT[i]) INET_TRY(pw_pack_frag(p + gr[i]->w_hh, H, H, 3 * H, w.wpkT[i], 1, 1, 0, 0, s));
-        else INET_TRY(pw_transpose(p + gr[i]->w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
+    if (w.wpkT[0]) {
+        const float* ins[4] = {p + gr[0]->w_hh, p + gr[1]->w_hh, p + gr[2]->w_hh, p + gr[3]->w_hh};
+        INET_TRY(pw_pack_frag_multi(ins, w.wpkT, 4, H, H, 3 * H, 1, s));
+    } else {
+        for (int i = 0; i < 4; ++i) INET_TRY(pw_transpose(p + gr[i]->w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
     }
     const long pkg = (long)pk_floats(B, 3 * H);
 
