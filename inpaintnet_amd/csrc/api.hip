@@ -216,7 +216,7 @@ int inet_bigru2_bwd(int B, int T, int K, int H, const float* x, const float* x_s
             if (dx) INET_TRY(linear_dgrad(dgi, 6L * H, P[dir].w_ih, K, w.dx_tm, K, T * B, 3 * H, K, EPI_NONE, nullptr, 0,
                                           dir == 0 ? ACC_STORE : ACC_ADD, s));
         } else if (grads) {
-            if (hipMemsetAsync(w.tmp3h, 0, 3 * H * sizeof(float), s) != hipSuccess) return -2;
+            INET_TRY(pw_zero(w.tmp3h, 3L * H, s));
             INET_TRY(pw_colsum(dgi, 6L * H, T * B, 3 * H, w.tmp3h, s));
             if (!dx_scalar) return -1;
             INET_TRY(pw_beat_input_grad(w.tmp3h, P[dir].w_ih, 1, x_scalar, P[dir].dw_ih, dx_scalar, 3 * H, s));

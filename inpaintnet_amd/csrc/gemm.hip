@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include "prof.h"
 #include "side.h"
+#include "pointwise.h"
 
 namespace {
 
@@ -304,8 +305,7 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     const bool two_pass = splits > 1 && nonlinear;
     if (splits > 1) {
         if (g.acc == ACC_STORE) {
-            if (hipMemset2DAsync(g.C, g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, s) != hipSuccess)
-                return -2;
+            if (pw_zero2d(g.C, g.ldc, g.M, g.N, s) != 0) return -2;
         }
         g.acc = ACC_ATOMIC;
         if (two_pass) g.epi = EPI_NONE;

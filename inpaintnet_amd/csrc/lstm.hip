@@ -180,7 +180,7 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
     LstmWs w;
     lstm_carve(B, T, H, save, ws, w);
     const long BH = (long)B * H, TBH = (long)T * BH;
-    if ((!h0 || !c0) && hipMemsetAsync(w.zeros, 0, BH * sizeof(float), s) != hipSuccess) return -2;
+    if ((!h0 || !c0) && pw_zero(w.zeros, BH, s) != 0) return -2;
     for (int step = 0; step < T; ++step) {
         const int t = reverse ? T - 1 - step : step;
         const int tp = reverse ? t + 1 : t - 1;
@@ -195,8 +195,8 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
         INET_TRY(launch_fwd(a, s));
     }
     const int tl = reverse ? 0 : T - 1;
-    if (hT && hipMemcpyAsync(hT, out + (long)tl * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
-    if (cT && hipMemcpyAsync(cT, w.cseq + (long)tl * BH, BH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+    if (hT && pw_copy_bytes(hT, out + (long)tl * BH, BH * sizeof(float), s) != 0) return -2;
+    if (cT && pw_copy_bytes(cT, w.cseq + (long)tl * BH, BH * sizeof(float), s) != 0) return -2;
     return 0;
 }
 
@@ -235,7 +235,7 @@ int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const 
         a.dh_out = dh0;
         INET_TRY(launch_bwd(a, s));
     }
-    if (dc0 && hipMemcpyAsync(dc0, w.dc, BH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+    if (dc0 && pw_copy_bytes(dc0, w.dc, BH * sizeof(float), s) != 0) return -2;
     if (dW_hh) {
         // dW_hh += sum_t dg(t)^T h_prev(t):  h_prev(t) = out(t -/+ 1), and h0 for the first processed step
         hipStream_t ss = side_fork(s);

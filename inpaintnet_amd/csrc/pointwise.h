@@ -24,6 +24,9 @@ int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int r
 int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s);
 int pw_swap01(const float* in, int A, int B, int K, float* out, hipStream_t s);
 int pw_argmax(const float* W, long ld_w, int rows, int V, long long* out, long stride, hipStream_t s);
+int pw_zero2d(float* p, long ld, long rows, int cols, hipStream_t s);
+int pw_zero(float* p, long n, hipStream_t s);
+int pw_copy_bytes(void* dst, const void* src, long nbytes, hipStream_t s);     // nbytes % 4 == 0
 int pw_fill_i64(long long* p, long n, long long v, hipStream_t s);
 int pw_copy2d(float* dst, long ld_d, const float* src, long ld_s, const float* pos, long ld_p, int rows, int cols,
               hipStream_t s);

@@ -265,6 +265,17 @@ __global__ void argmax_kernel(const float* __restrict__ W, long ld_w, int rows, 
     }
 }
 
+// p[r*ld + c] = 0  (plain kernels instead of hipMemsetAsync / hipMemcpyAsync: the runtime's blit path showed 20-40 us
+// bubbles around its fill/copy kernels in the step's timeline)
+__global__ void zero2d_kernel(float* __restrict__ p, long ld, long rows, int cols) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+__global__ void copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 __global__ void fill_i64_kernel(long long* p, long n, long long v) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -434,7 +445,7 @@ int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s) 
 }
 int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
               hipStream_t s) {
-    if (zero_first && hipMemsetAsync(out, 0, (size_t)rows * W * sizeof(float), s) != hipSuccess) return -2;
+    if (zero_first && pw_zero(out, (long)rows * W, s) != 0) return -2;
     hipLaunchKernelGGL(onehot_kernel, dim3(grid_for(rows)), dim3(256), 0, s, idx, inner, s_outer, s_inner, rows, W, out);
     return ok();
 }
@@ -448,6 +459,19 @@ int pw_swap01(const float* in, int A, int B, int K, float* out, hipStream_t s) {
 }
 int pw_argmax(const float* W, long ld_w, int rows, int V, long long* out, long stride, hipStream_t s) {
     hipLaunchKernelGGL(argmax_kernel, dim3(grid_for((long)rows * 64, 256, 1024)), dim3(256), 0, s, W, ld_w, rows, V, out, stride);
+    return ok();
+}
+int pw_zero2d(float* p, long ld, long rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(zero2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, s, p, ld, rows, cols);
+    return ok();
+}
+int pw_zero(float* p, long n, hipStream_t s) { return pw_zero2d(p, n, 1, (int)n, s); }
+int pw_copy_bytes(void* dst, const void* src, long nbytes, hipStream_t s) {
+    if (nbytes <= 0) return 0;
+    if (nbytes % 4 != 0) return -1;
+    hipLaunchKernelGGL(copy_words_kernel, dim3(grid_for(nbytes / 4)), dim3(256), 0, s, (unsigned*)dst, (const unsigned*)src,
+                       nbytes / 4);
     return ok();
 }
 int pw_fill_i64(long long* p, long n, long long v, hipStream_t s) {

@@ -155,7 +155,7 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
 int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in, const float* h0, const float* mask,
                     float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s) {
     const long BH = (long)B * H, TBH = (long)T * BH;
-    if (!h0 && hipMemsetAsync(w.zeros, 0, BH * sizeof(float), s) != hipSuccess) return -2;
+    if (!h0 && pw_zero(w.zeros, BH, s) != 0) return -2;
     if (w.wpk[0])
     {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};

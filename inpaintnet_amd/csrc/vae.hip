@@ -248,7 +248,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     VaeLayout L(c);
     DecWs w{};
     dec_carve(c, B, save, ws, w);
-    if (save && hipMemcpyAsync(w.zsave, z, (size_t)B * Z * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+    if (save && pw_copy_bytes(w.zsave, z, (long)B * Z * sizeof(float), s) != 0) return -2;
     const bool pk = w.wpk_t0 != nullptr;
     static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
     const long pkh = (long)pk_floats(B, H);
@@ -296,7 +296,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     INET_TRY(linear_fwd(p + L.x_0, E, wih0, ldw0, p + L.tick[0].b_ih, w.table + (long)V * 3 * H, 3L * H, 1, 3 * H, E, EPI_NONE, s));
     INET_TRY(pw_fill_i64(w.idxV, B, V, s));
     if (teacher_forced &&
-        hipMemcpyAsync(samples, target, (size_t)B * T * sizeof(long long), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        pw_copy_bytes(samples, target, (long)B * T * sizeof(long long), s) != 0)
         return -2;
 
     // ---- tick RNN (forward_tick_rnn, decoder.py:473-529) ----
@@ -476,7 +476,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         hipStream_t ss = side_fork(s);
         INET_TRY(linear_wgrad(w.dcgi, 3L * H, w.c_all, H, g + L.tick[0].w_ih + E, ldw0, nb * B, 3 * H, H, ss));
         // token-embedding half through the gather table
-        if (hipMemsetAsync(w.onehot, 0, (size_t)T * B * (V + 1) * sizeof(float), ss) != hipSuccess) return -2;
+        INET_TRY(pw_zero(w.onehot, (long)T * B * (V + 1), ss));
         INET_TRY(pw_onehot(w.idxV, B, 0, 1, B, V + 1, w.onehot, 0, ss));                               // t = 0: x_0 row
         INET_TRY(pw_onehot(tokens_in, B, 1, T, (T - 1) * B, V + 1, w.onehot + (long)B * (V + 1), 0, ss));  // t >= 1: token t-1
         INET_TRY(launch_gemm(gemm_args(w.onehot, V + 1, 1, w.dgi0t, 3L * H, 1, w.dtable, 3L * H, V + 1, 3 * H, T * B), ss));
@@ -531,7 +531,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         hipStream_t ss = side_fork(s);
         INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh0b, w.svb0 + 4 * nb * BH, g + L.beat[0].w_hh, ss));
         // gi = b_0 * W_ih[:,0] + b_ih
-        if (hipMemsetAsync(w.tmp3h, 0, 3 * H * sizeof(float), ss) != hipSuccess) return -2;
+        INET_TRY(pw_zero(w.tmp3h, 3L * H, ss));
         INET_TRY(pw_colsum(w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h, ss));
         INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H, ss));
     }
