@@ -100,22 +100,25 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
 #pragma unroll
         for (int p = 0; p < MS; ++p) tok[p] = P.idx[(long)min(row0 + ((t + 256 * p) >> 4), P.B - 1) * P.idx_stride];
     }
-    auto prefetch = [&]() {
-        TRACEX(1);
-        kernarg_touch(P.b_hh, P.b_ih, P.gi_vec, P.gi_dense, P.ld_gi, P.gi_table, P.ld_table, P.h_prev, P.ld_hprev,
-                      P.hpk_prev, P.h_masked, P.mask, P.ld_mask);
+    auto prefetch = [&](auto tag) {
+        constexpr int I = decltype(tag)::value;
+        if constexpr (I == -1) {
+            TRACEX(1);
+            kernarg_touch(P.b_hh, P.b_ih, P.gi_vec, P.gi_dense, P.ld_gi, P.gi_table, P.ld_table, P.h_prev, P.ld_hprev,
+                          P.hpk_prev, P.h_masked, P.mask, P.ld_mask);
+        } else if constexpr (I == 0) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) pb_hh[g] = P.b_hh[g * H + jc];
-        if (HAS_X && P.b_ih) {
+            for (int g = 0; g < 3; ++g) pb_hh[g] = P.b_hh[g * H + jc];
+            if (HAS_X && P.b_ih) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) pb_ih[g] = P.b_ih[g * H + jc];
-        }
-        if (P.gi_vec) {
+                for (int g = 0; g < 3; ++g) pb_ih[g] = P.b_ih[g * H + jc];
+            }
+            if (P.gi_vec) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) pb_v[g] = P.gi_vec[g * H + jc];
-        }
-#pragma unroll
-        for (int p = 0; p < MS; ++p) {
+                for (int g = 0; g < 3; ++g) pb_v[g] = P.gi_vec[g * H + jc];
+            }
+        } else if constexpr (I <= MS) {
+            constexpr int p = I - 1;
             const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
 #pragma unroll
             for (int g = 0; g < 3; ++g) pre_gd[p][g] = P.gi_dense ? P.gi_dense[(long)b * P.ld_gi + g * H + jc] : 0.f;
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdBatch bt) {
             pre_mask[p] = (P.h_masked && P.mask) ? P.mask[(long)b * P.ld_mask + jc] : 1.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g) pre_gt[p][g] = P.gi_table ? P.gi_table[tok[p] * P.ld_table + g * H + jc] : 0.f;
+            if (I == MS) TRACEX(2);
         }
-        TRACEX(2);
     };
 
     const int brow[3] = {j0, H + j0, 2 * H + j0};
@@ -201,11 +204,13 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
     // column j0 + 16a + (t & 15).
     const int jc = j0 + (t & 15);
     float pd[MS][NC][3], psv[MS][NC][5];
-    auto prefetch = [&]() {
-        kernarg_touch(P.dhz_next, P.dout, P.ld_dout, P.dout2, P.ld_dout2, P.sv_r, P.sv_z, P.sv_n, P.sv_ghn, P.sv_hprev,
-                      P.dh_out, P.ld_dhout, P.dh_out_accumulate);
-#pragma unroll
-        for (int p = 0; p < MS; ++p) {
+    auto prefetch = [&](auto tag) {
+        constexpr int I = decltype(tag)::value;
+        if constexpr (I == -1) {
+            kernarg_touch(P.dhz_next, P.dout, P.ld_dout, P.dout2, P.ld_dout2, P.sv_r, P.sv_z, P.sv_n, P.sv_ghn, P.sv_hprev,
+                          P.dh_out, P.ld_dhout, P.dh_out_accumulate);
+        } else if constexpr (I >= 1 && I <= MS) {
+            constexpr int p = I - 1;
             const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
 #pragma unroll
             for (int a = 0; a < NC; ++a) {
@@ -243,7 +248,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdBatch bt) {
         reduce_waves<MS, NC>(acc, lds, t, v);
     }
     else {
-        prefetch();
+        prefetch(HookTag<-1>{});
+        hook_pieces<MS + 1>(prefetch);
     }
     TRACE(2);
     float bs[NC][4];                               // this thread's column partials: dr, dz, dn, dn*r

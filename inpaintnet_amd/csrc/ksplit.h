@@ -77,6 +77,29 @@ __device__ __forceinline__ void load_step(Frag<MS, NB>& f, const float* __restri
     }
 }
 
+// acc[ms][slot[g]] += A[16*MS rows, this wave's K quarter] * Bg[16 rows, same K]^T
+//
+// The caller's hook requests its epilogue operands from inside the contraction, so their latency hides under the MFMA
+// phase.  It is called with a tag std::integral_constant<int, I>:
+//   I = -1  right after the prologue loads are issued -- the place for kernarg_touch(): the wave is about to wait for
+//           its first fragments anyway, the scalar round trip disappears in that shadow;
+//   I >= 0  piece I, dealt out in front of the I-th MFMA chunk of the first k-step (MS + NB chunks per step), so the
+//           requests are spread like the fragment loads instead of stalling the wave in one block.
+struct NoHook {
+    template <class Tag>
+    __device__ __forceinline__ void operator()(Tag) const {}
+};
+template <int I>
+using HookTag = std::integral_constant<int, I>;
+
+template <int N, class Hook, int I = 0>
+__device__ __forceinline__ void hook_pieces(Hook&& h) {
+    if constexpr (I < N) {
+        h(HookTag<I>{});
+        hook_pieces<N, Hook, I + 1>(static_cast<Hook&&>(h));
+    }
+}
+
 // One fragment of a k-step (unguarded forms only): I < MS -> a[I], else b[I - MS].
 template <int MS, int NB, bool PK, int I>
 __device__ __forceinline__ void load_frag(Frag<MS, NB>& f, const float* __restrict__ A, long lda, int row0, int rowsA,
@@ -117,18 +140,21 @@ __device__ __forceinline__ void mma_range(f32x4 (&acc)[MS][4], const int (&slot)
 // stage until the CU's address path takes it (~100 cycles per 1 KB instruction with 4 waves streaming, measured:
 // 56 back-to-back loads = 5,500 cycles during which the wave's MFMA pipe idles).  Spread out, the same loads need
 // 18-40 B/clk of the CU's 64 and cost the MFMA stream nothing.  sched_barrier pins the interleave.
-template <int MS, int NB, bool PK, bool LOAD, int I = 0>
+template <int MS, int NB, bool PK, bool LOAD, int I = 0, class Hook = NoHook>
 __device__ __forceinline__ void mma_and_prefetch(f32x4 (&acc)[MS][4], const int (&slot)[NB], const Frag<MS, NB>& cur,
                                                  Frag<MS, NB>& nxt, const float* __restrict__ A, long lda, int row0,
                                                  int rowsA, const float* __restrict__ Bm, long ldb,
-                                                 const int (&brow)[NB], int K, int s_nxt, int i16, int q) {
+                                                 const int (&brow)[NB], int K, int s_nxt, int i16, int q,
+                                                 Hook&& hook = Hook()) {
     constexpr int NM = 4 * MS * NB, FR = MS + NB, CH = (NM + FR - 1) / FR;
     if constexpr (I < FR) {
+        hook(HookTag<I>{});
         if (LOAD) load_frag<MS, NB, PK, I>(nxt, A, lda, row0, rowsA, Bm, ldb, brow, K, s_nxt, i16, q);
         constexpr int M0 = I * CH < NM ? I * CH : NM, M1 = (I + 1) * CH < NM ? (I + 1) * CH : NM;
         mma_range<MS, NB, M0, M1>(acc, slot, cur);
         __builtin_amdgcn_sched_barrier(0);
-        mma_and_prefetch<MS, NB, PK, LOAD, I + 1>(acc, slot, cur, nxt, A, lda, row0, rowsA, Bm, ldb, brow, K, s_nxt, i16, q);
+        mma_and_prefetch<MS, NB, PK, LOAD, I + 1>(acc, slot, cur, nxt, A, lda, row0, rowsA, Bm, ldb, brow, K, s_nxt, i16, q,
+                                                  static_cast<Hook&&>(hook));
     }
 }
 
@@ -143,61 +169,6 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[MS][4], const int (&slot)[
                 acc[ms][slot[g]] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ms][e], f.b[g][e], acc[ms][slot[g]], 0, 0, 0);
 }
 
-// acc[ms][slot[g]] += A[16*MS rows, this wave's K quarter] * Bg[16 rows, same K]^T
-//
-// Issue order is the whole game here (profiles/r01_c): a wave issues in order, so a load placed behind an MFMA that
-// waits on vmcnt is not even REQUESTED until that data is back.  The paths below therefore request as much of the
-// wave's K range as the register file allows before the first MFMA: all of it when K = 512 (8 k-steps, 40 x 16-byte
-// loads per lane for the forward step), otherwise two groups of GDEPTH k-steps kept in flight.
-//
-// `after_first_loads` is a hook the caller uses to request its epilogue operands: placed AFTER the first group of
-// fragment loads (loads return in order, so cold epilogue operands requested first would hold the L2-warm fragments
-// -- and the first MFMA -- behind them) and BEFORE the first MFMA (so their latency hides under the MFMA phase).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-
-template <int MS, int NB, int GDEPTH, bool PK, class Hook>
-__device__ __forceinline__ void ksplit_fast(f32x4 (&acc)[MS][4], const int (&slot)[NB], const float* __restrict__ A,
-                                            long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
-                                            const int (&brow)[NB], int K, int s_beg, int s_end, int i16, int q,
-                                            Hook&& after_first_loads) {
-    // Groups of GDEPTH k-steps, two groups in flight.  The steady-state loop body is branch-free on purpose: a
-    // conditional "load the next group" merges two paths with different numbers of outstanding loads, and the compiler
-    // must then wait for the smaller count -- vmcnt(15) instead of vmcnt(35) here, i.e. for the prefetched group as
-    // well (seen in the ISA of the K = 3H backward contraction).  An odd group count runs one group up front.
-    Frag<MS, NB> f0[GDEPTH], f1[GDEPTH];
-    auto load = [&](Frag<MS, NB> (&f)[GDEPTH], int s) {
-#pragma unroll
-        for (int d = 0; d < GDEPTH; ++d) load_step<MS, NB, false, PK>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s + d, i16, q);
-        // keep the group's loads together and ahead of the MFMAs that follow: left alone the scheduler sinks them
-        // between the MFMAs and the waits become vmcnt(0..3).  (An asm memory clobber does not hold them: they are
-        // invariant loads to the compiler.)
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto mma = [&](const Frag<MS, NB> (&f)[GDEPTH]) {
-#pragma unroll
-        for (int d = 0; d < GDEPTH; ++d) mma_step<MS, NB>(acc, slot, f[d]);
-    };
-    const int n = (s_end - s_beg) / GDEPTH;                    // wave-uniform
-    int s = s_beg;
-    load(f0, s);
-    after_first_loads();
-    if (n & 1) {
-        mma(f0);
-        s += GDEPTH;
-        if (n == 1) return;
-        load(f0, s);
-    }
-    for (; s + 2 * GDEPTH < s_end; s += 2 * GDEPTH) {
-        load(f1, s + GDEPTH);
-        mma(f0);
-        load(f0, s + 2 * GDEPTH);
-        mma(f1);
-    }
-    load(f1, s + GDEPTH);
-    mma(f0);
-    mma(f1);
-}
-
 // Streamed contraction over k-steps [s_beg, s_end) (count a multiple of R): ring of R step-fragments, R-1 steps of
 // loads requested up front, then every step's MFMAs carry the loads of the step R-1 ahead.  The loop body (R steps,
 // static ring slots) is branch-free; the last R-1 steps run without loads.
@@ -210,25 +181,31 @@ __device__ __forceinline__ void ksplit_stream(f32x4 (&acc)[MS][4], const int (&s
 #pragma unroll
     for (int d = 0; d < R - 1; ++d) load_step<MS, NB, false, PK>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
     __builtin_amdgcn_sched_barrier(0);
-    // step j of a body that starts at k-step s: MFMAs of ring slot j, loads of step s+j+R-1 into the slot freed last
+    after_first_loads(HookTag<-1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    // step j of a body that starts at k-step s: MFMAs of ring slot j, loads of step s+j+R-1 into the slot freed last;
+    // the very first step also carries the caller's hook pieces
     auto body = [&](int s, auto with_hook) {
+        if constexpr (decltype(with_hook)::value)
+            mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[0], f[R - 1], A, lda, row0, rowsA, Bm, ldb, brow, K, s + R - 1, i16,
+                                               q, after_first_loads);
+        else
+            mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[0], f[R - 1], A, lda, row0, rowsA, Bm, ldb, brow, K, s + R - 1, i16, q);
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
+        for (int j = 1; j < R; ++j)
             mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[j], f[(j + R - 1) % R], A, lda, row0, rowsA, Bm, ldb, brow, K,
                                                s + j + R - 1, i16, q);
-            if (j == 0 && decltype(with_hook)::value) { after_first_loads(); __builtin_amdgcn_sched_barrier(0); }
-        }
     };
     auto drain = [&](int s, auto with_hook) {
-        mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[0], f[R - 1], A, lda, row0, rowsA, Bm, ldb, brow, K, s + R - 1, i16, q);
-        if (decltype(with_hook)::value) { after_first_loads(); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (decltype(with_hook)::value)
+            mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[0], f[R - 1], A, lda, row0, rowsA, Bm, ldb, brow, K, s + R - 1, i16,
+                                               q, after_first_loads);
+        else
+            mma_and_prefetch<MS, NB, PK, true>(acc, slot, f[0], f[R - 1], A, lda, row0, rowsA, Bm, ldb, brow, K, s + R - 1, i16, q);
 #pragma unroll
         for (int j = 1; j < R; ++j)
             mma_and_prefetch<MS, NB, PK, false>(acc, slot, f[j], f[0], A, lda, row0, rowsA, Bm, ldb, brow, K, 0, i16, q);
     };
-    // The caller's hook (its epilogue-operand requests) runs after the first step's MFMAs: by then the address path is
-    // down from the prologue burst to the streaming rate, and ~2 dozen small loads issue in a few hundred cycles
-    // instead of ~2,000 right behind the burst.
     using Yes = std::true_type;
     using No = std::false_type;
     int s = s_beg;
@@ -239,20 +216,6 @@ __device__ __forceinline__ void ksplit_stream(f32x4 (&acc)[MS][4], const int (&s
     } else {
         drain(s, Yes{});
     }
-}
-
-// single group: the wave's whole K range (8 k-steps) is requested before the first MFMA
-template <int MS, int NB, bool PK, class Hook>
-__device__ __forceinline__ void ksplit_once8(f32x4 (&acc)[MS][4], const int (&slot)[NB], const float* __restrict__ A,
-                                             long lda, int row0, int rowsA, const float* __restrict__ Bm, long ldb,
-                                             const int (&brow)[NB], int K, int s_beg, int i16, int q,
-                                             Hook&& after_first_loads) {
-    Frag<MS, NB> f[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) load_step<MS, NB, false, PK>(f[d], A, lda, row0, rowsA, Bm, ldb, brow, K, s_beg + d, i16, q);
-    after_first_loads();
-#pragma unroll
-    for (int d = 0; d < 8; ++d) mma_step<MS, NB>(acc, slot, f[d]);
 }
 
 // PK: both operands fragment-major (requires K % 256 == 0; the host only passes packed operands then).
@@ -267,20 +230,18 @@ __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[MS][4], const int (&
     const int S = (K + 15) >> 4;                   // k-steps of 16
     constexpr int FR = MS + NB;                    // float4 fragment registers per k-step
     if ((K & 255) == 0 && (PK || (K & 511) == 0)) {
-        // each wave owns S/4 steps: a multiple of 4 (of 8 when K % 512 == 0).  Ring of 8 while it fits the registers.
+        // each wave owns S/4 steps, a multiple of 4: ring of 4, three steps requested up front.  (A ring of 8 where the
+        // registers allow it measured slower: the 7-step prologue is a longer burst in front of the first MFMA.)
         const int Sq = S >> 2;
-        if ((Sq & 7) == 0 && FR <= 5)
-            ksplit_stream<MS, NB, PK, 8>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q,
-                                         after_first_loads);
-        else
-            ksplit_stream<MS, NB, PK, 4>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q,
-                                         after_first_loads);
+        ksplit_stream<MS, NB, PK, 4>(acc, slot, A, lda, row0, rowsA, Bm, ldb, brow, K, w * Sq, w * Sq + Sq, i16, q,
+                                     after_first_loads);
     } else {
         // general path (small / odd K): guarded loads, one step at a time
         const int Sq = (S + 3) >> 2;
         const int s_beg = w * Sq;
         const int s_end = min(S, s_beg + Sq);
-        after_first_loads();
+        after_first_loads(HookTag<-1>{});
+        hook_pieces<MS + NB>(after_first_loads);
         for (int s = s_beg; s < s_end; ++s) {
             Frag<MS, NB> f;
             load_step<MS, NB, true>(f, A, lda, row0, rowsA, Bm, ldb, brow, K, s, i16, q);
