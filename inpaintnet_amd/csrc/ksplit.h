@@ -229,7 +229,7 @@ __device__ __forceinline__ void ksplit_segment(f32x4 (&acc)[MS][4], const int (&
     const int i16 = lane & 15, q = lane >> 4;
     const int S = (K + 15) >> 4;                   // k-steps of 16
     constexpr int FR = MS + NB;                    // float4 fragment registers per k-step
-    if ((K & 255) == 0 && (PK || (K & 511) == 0)) {
+    if ((K & 255) == 0) {
         // each wave owns S/4 steps, a multiple of 4: ring of 4, three steps requested up front.  (A ring of 8 where the
         // registers allow it measured slower: the 7-step prologue is a longer burst in front of the first MFMA.)
         const int Sq = S >> 2;
