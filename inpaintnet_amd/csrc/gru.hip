@@ -9,25 +9,25 @@
 //
 // Why one launch per step and not one persistent kernel: every step needs the
 // whole previous hidden state (an all-to-all over the 256 CUs).  On MI355X a
-// dependent kernel boundary costs ~1.5 us, an in-kernel grid barrier 4-7 us
-// (MI355X_MICROARCH.md price list), so the boundary IS the cheapest barrier.
+// dependent kernel boundary costs ~2 us (dispatch + L2 write-back), an in-kernel
+// grid barrier 4-7 us (MI355X_MICROARCH.md price list), so the boundary IS the
+// cheapest barrier.
 //
-// Geometry (gfx950): workgroup = 4 wavefronts, output tile = 32 batch rows x 16
-// hidden units x {r,z,n} gates -- all three gate columns of the same hidden units,
-// so the gate math is register-local.  At B=256,H=512 that is 8 x 32 = 256
-// workgroups = one per CU; bidirectional layers / the four beats run as
-// blockIdx.z "problems" of the same launch.
+// Geometry (gfx950): workgroup = 4 wavefronts, output tile = 32 or 64 batch rows
+// x 16 hidden units x {r,z,n} gates -- all three gate columns of the same hidden
+// units, so the gate math is register-local.  At B=256,H=512 one direction is
+// 8 x 32 = 256 workgroups of 32 rows; bidirectional layers / the four beats run
+// as several "problems" of the same launch with 64-row tiles, again ~256
+// workgroups = one per CU.
 //
-// The step is latency-bound (0.4 GFLOP behind a dependency), so the four waves of
-// a workgroup do NOT share a staged tile: each wave owns a contiguous quarter of
-// K and streams its own MFMA fragments straight from L2 into registers
-// (16 B per lane = 4 consecutive k of one row, which IS the operand layout of
-// v_mfma_f32_16x16x4_f32 up to a k-permutation common to A and B), software-
-// pipelined two groups of 4 k-steps deep with counted vmcnt waits.  No LDS, no
-// barrier in the main loop; the only LDS traffic is the final cross-wave
-// reduction of the partial accumulators.  (Round-1 profile: the LDS-staged
-// version spent ~0.9 us per 64-deep chunk on load->barrier->ds_read latency,
-// 14.5 us per step; see profiles/.)
+// The four waves of a workgroup do NOT share a staged tile: each wave owns a
+// contiguous quarter of K and streams its own MFMA fragments straight from L2
+// into registers (ksplit.h: fragment-major operands, one contiguous KB per wave
+// instruction; loads dealt between the MFMAs).  No LDS, no barrier in the main
+// loop; the only LDS traffic is the final cross-wave reduction of the partial
+// accumulators.  (Round-1 history in DESIGN.md section 8: LDS-staged 14.5 us,
+// register-streamed row-major 12.4 us, fragment-major + streamed 10.8 us per
+// two-direction step; 5.2 us of that is MFMA issue.)
 #include <cstdlib>
 #include "common.h"
 #include "ksplit.h"
