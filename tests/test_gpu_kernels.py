@@ -109,6 +109,31 @@ def test_gru_step_matches_cell(B, H):
     assert torch.equal(sv[4].cpu(), h)
 
 
+def test_gru_step_gates_saturate_cleanly():
+    """The gate non-linearities run on v_exp_f32 / v_rcp_f32: pre-activations of +-100 (exp overflows to inf /
+    underflows to 0) must give exactly saturated gates and a finite state, and ordinary inputs must stay within a few
+    ulp of a float64 evaluation."""
+    B, H = 32, 64
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(B, H, generator=g)
+    W = torch.zeros(3 * H, H)
+    b = torch.zeros(3 * H)
+    gi = torch.empty(B, 3 * H)
+    gi[:, :H] = 100.0            # r -> 1
+    gi[:, H:2 * H] = -100.0      # z -> 0  => h' = n
+    gi[:, 2 * H:] = torch.where(torch.arange(H) % 2 == 0, 100.0, -100.0)   # n -> +-1
+    out, sv = ops.gru_step(gi.to(DEV), h.to(DEV), W.to(DEV), b.to(DEV), save=True)
+    out = out.cpu()
+    assert torch.isfinite(out).all()
+    assert torch.equal(sv[0].cpu(), torch.ones(B, H)) and torch.equal(sv[1].cpu(), torch.zeros(B, H))
+    assert torch.equal(out, torch.where(torch.arange(H) % 2 == 0, 1.0, -1.0).expand(B, H))
+    gi2 = torch.randn(B, 3 * H, generator=g) * 3
+    W2 = torch.randn(3 * H, H, generator=g) / np.sqrt(H)
+    ref = O.gru_cell(gi2.double(), h.double(), W2.double(), b.double())
+    out2, _ = ops.gru_step(gi2.to(DEV), h.to(DEV), W2.to(DEV), b.to(DEV), save=False)
+    assert float((out2.cpu().double() - ref).abs().max()) < 2e-6
+
+
 # ------------------------------------------------------------------------------- encoder / decoder vs reference goldens
 @pytest.mark.parametrize("name", ["small", "mid", "full"])
 def test_encoder_forward_golden(name):
