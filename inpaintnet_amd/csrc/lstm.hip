@@ -49,21 +49,38 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs P) {
         for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int brow[4] = {j0, H + j0, 2 * H + j0, 3 * H + j0};
     const int slot[4] = {0, 1, 2, 3};
-    ksplit_segment<MS, 4>(acc, slot, P.h_prev, (long)H, row0, P.B, P.W_hh, (long)H, brow, H, t);
+    // epilogue operands requested from inside the contraction (ksplit.h hook), not after the reduce
+    const int jc = j0 + (t & 15);
+    float pg[MS][4], pcp[MS], pb[4];
+    auto prefetch = [&](auto tag) {
+        constexpr int I = decltype(tag)::value;
+        if constexpr (I == -1) {
+            kernarg_touch(P.gi, P.b_hh, P.c_prev);
+        } else if constexpr (I == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pb[a] = P.b_hh[a * H + jc];
+        } else if constexpr (I <= MS) {
+            constexpr int p = I - 1;
+            const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pg[p][a] = P.gi[(long)b * 4 * H + a * H + jc];
+            pcp[p] = P.c_prev[(long)b * H + jc];
+        }
+    };
+    ksplit_segment<MS, 4>(acc, slot, P.h_prev, (long)H, row0, P.B, P.W_hh, (long)H, brow, H, t, prefetch);
     float v[MS][4];
     reduce_waves<MS, 4>(acc, lds, t, v);
 #pragma unroll
     for (int p = 0; p < MS; ++p) {
         const int pos = t + 256 * p;
-        const int b = row0 + (pos >> 4), j = j0 + (pos & 15);
+        const int b = row0 + (pos >> 4), j = jc;
         if (b >= P.B) continue;
-        const float* gp = P.gi + (long)b * 4 * H;
-        const float i = sigmoid_f(v[p][0] + gp[j] + P.b_hh[j]);
-        const float f = sigmoid_f(v[p][1] + gp[H + j] + P.b_hh[H + j]);
-        const float g = tanh_f(v[p][2] + gp[2 * H + j] + P.b_hh[2 * H + j]);
-        const float o = sigmoid_f(v[p][3] + gp[3 * H + j] + P.b_hh[3 * H + j]);
+        const float i = sigmoid_f(v[p][0] + pg[p][0] + pb[0]);
+        const float f = sigmoid_f(v[p][1] + pg[p][1] + pb[1]);
+        const float g = tanh_f(v[p][2] + pg[p][2] + pb[2]);
+        const float o = sigmoid_f(v[p][3] + pg[p][3] + pb[3]);
         const long q = (long)b * H + j;
-        const float cp = P.c_prev[q];
+        const float cp = pcp[p];
         const float c = f * cp + i * g;
         const float tc = tanh_f(c);
         P.c_new[q] = c;
@@ -83,6 +100,24 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs P) {
     __shared__ __attribute__((aligned(16))) float lds[(4 * MS * 256 > 1024) ? 4 * MS * 256 : 1024];
     const int H = P.H, t = threadIdx.x;
     const int j0 = blockIdx.x * TH, row0 = blockIdx.y * (16 * MS);
+    const int jc = j0 + (t & 15);
+    float pe[MS][4], psv[MS][6];
+    auto prefetch = [&](auto tag) {
+        constexpr int I = decltype(tag)::value;
+        if constexpr (I == -1) {
+            kernarg_touch(P.dout, P.dout2, P.dc_next, P.dc_ext, P.sv, P.sv_stride);
+        } else if constexpr (I >= 1 && I <= MS) {
+            constexpr int p = I - 1;
+            const int b = min(row0 + ((t + 256 * p) >> 4), P.B - 1);
+            const long q = (long)b * H + jc;
+            pe[p][0] = P.dout ? P.dout[q] : 0.f;
+            pe[p][1] = P.dout2 ? P.dout2[q] : 0.f;
+            pe[p][2] = P.dc_next ? P.dc_next[q] : 0.f;
+            pe[p][3] = P.dc_ext ? P.dc_ext[q] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) psv[p][a] = P.sv ? P.sv[q + a * P.sv_stride] : 0.f;
+        }
+    };
     float v[MS][1];
 #pragma unroll
     for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
@@ -94,29 +129,26 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs P) {
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int brow[1] = {j0};
         const int slot[1] = {0};
-        ksplit_segment<MS, 1>(acc, slot, P.dg_next, (long)4 * H, row0, P.B, P.W_hhT, (long)4 * H, brow, 4 * H, t);
+        ksplit_segment<MS, 1>(acc, slot, P.dg_next, (long)4 * H, row0, P.B, P.W_hhT, (long)4 * H, brow, 4 * H, t, prefetch);
         reduce_waves<MS, 1>(acc, lds, t, v);
+    } else {
+        prefetch(HookTag<-1>{});
+        hook_pieces<MS + 1>(prefetch);
     }
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < MS; ++p) {
         const int pos = t + 256 * p;
-        const int b = row0 + (pos >> 4), j = j0 + (pos & 15);
+        const int b = row0 + (pos >> 4), j = jc;
         if (b >= P.B) continue;
         const long q = (long)b * H + j;
-        float dh = v[p][0];
-        if (P.dout) dh += P.dout[q];
-        if (P.dout2) dh += P.dout2[q];
+        const float dh = v[p][0] + pe[p][0] + pe[p][1];
         if (!P.sv) {                       // gradient wrt the initial hidden / cell state
             if (P.dh_out) P.dh_out[q] = dh;
             continue;
         }
-        const float* s = P.sv + q;
-        const long st = P.sv_stride;
-        const float i = s[0], f = s[st], g = s[2 * st], o = s[3 * st], cp = s[4 * st], tc = s[5 * st];
-        float dc = dh * o * (1.f - tc * tc);
-        if (P.dc_next) dc += P.dc_next[q];
-        if (P.dc_ext) dc += P.dc_ext[q];
+        const float i = psv[p][0], f = psv[p][1], g = psv[p][2], o = psv[p][3], cp = psv[p][4], tc = psv[p][5];
+        const float dc = dh * o * (1.f - tc * tc) + pe[p][2] + pe[p][3];
         const float di = dc * g * i * (1.f - i);
         const float df = dc * cp * f * (1.f - f);
         const float dgg = dc * i * (1.f - g * g);
