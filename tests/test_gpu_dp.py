@@ -1,0 +1,106 @@
+"""Data-parallel path on the GPU: two ranks (sharing cuda:0; gloo carries the exchange, since RCCL wants one device per
+rank) run the real HIP training step through VAETrainer with the epoch loop's deferred side-stream joins, the decoder
+bucket started from inside backward and the rest summed in step().  Both ranks must end with identical parameters, equal
+to a single process that takes the same two half-batches as one global batch."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(V=20, E=6, H=256, Z=24)     # H % 256 == 0: fragment-major step kernels
+B, STEPS = 12, 3
+
+
+def _build():
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    from inpaintnet_amd.vae_trainer import VAETrainer
+    ds = synthetic.SyntheticFolkDataset(num_notes=CFG["V"])
+    model = MeasureVAE(ds, note_embedding_dim=CFG["E"], encoder_hidden_size=CFG["H"], latent_space_dim=CFG["Z"],
+                       decoder_hidden_size=CFG["H"], encoder_dropout_prob=0.0, decoder_dropout_prob=0.0)
+    sd = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    trainer = VAETrainer(ds, model, lr=1e-3)
+    trainer.overlap_backward = True
+    model.train()
+    return model, trainer
+
+
+def _first_grad(model, trainer, tokens, eps_all, coins, lo, hi):
+    """Averaged gradient arena of step 0, exchanged exactly as Trainer.step() does it (join, all-reduce, 1/world)."""
+    from inpaintnet_amd import dp, ops
+    from inpaintnet_amd import measure_vae as MV
+    MV.random.random = (lambda c=coins[0]: 0.0 if c else 0.9)
+    trainer.zero_grad()
+    w, smp, zd, pd, z, zp = model(tokens[lo:hi].cuda(), train=True, eps=eps_all[0][lo:hi].cuda())
+    ce, acc = trainer.mean_crossentropy_loss_and_accuracy(w, tokens[lo:hi].cuda())
+    (ce + trainer.compute_kld_loss(zd, pd)).backward()
+    ops.side_join()
+    scale = dp.allreduce_grads(model.grad)
+    g = (model.grad * scale).cpu().numpy()
+    ops.side_defer(False)
+    return g
+
+
+def _run_steps(model, trainer, tokens, eps_all, coins, lo, hi):
+    from inpaintnet_amd import measure_vae as MV
+    losses = []
+    for s in range(STEPS):
+        MV.random.random = (lambda c=coins[s]: 0.0 if c else 0.9)
+        eps = eps_all[s][lo:hi].cuda()
+        trainer.zero_grad()
+        w, smp, zd, pd, z, zp = model(tokens[lo:hi].cuda(), train=True, eps=eps)
+        ce, acc = trainer.mean_crossentropy_loss_and_accuracy(w, tokens[lo:hi].cuda())
+        loss = ce + trainer.compute_kld_loss(zd, pd)
+        loss.backward()
+        trainer.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    return losses
+
+
+def _inputs():
+    from inpaintnet_amd import synthetic
+    tokens = torch.from_numpy(synthetic.det_tokens("dpgpu/tokens", (B, 24), CFG["V"]))
+    eps_all = [torch.from_numpy(synthetic.det_normal(f"dpgpu/eps{s}", (B, CFG["Z"]))) for s in range(STEPS)]
+    return tokens, eps_all, [True, False, True]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from inpaintnet_amd import dp
+    assert dp.init_from_env(backend="gloo") == world
+    torch.cuda.set_device(0)
+    model, trainer = _build()
+    dp.broadcast_params(model.flat)
+    tokens, eps_all, coins = _inputs()
+    lo, hi = dp.shard(B)
+    grad0 = _first_grad(model, trainer, tokens, eps_all, coins, lo, hi)
+    losses = _run_steps(model, trainer, tokens, eps_all, coins, lo, hi)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), flat=model.flat.cpu().numpy(), losses=np.array(losses), grad0=grad0)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_global_batch(tmp_path):
+    port = 29100 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npz")
+    r1 = np.load(tmp_path / "r1.npz")
+    assert np.array_equal(r0["flat"], r1["flat"])                 # ranks stay bit-identical over 3 optimizer steps
+    assert np.array_equal(r0["grad0"], r1["grad0"])
+    # mean of the two half-batch gradients == gradient of the global batch in one process (compared before Adam, which
+    # would turn rounding noise on near-zero entries into lr-sized differences)
+    model, trainer = _build()
+    tokens, eps_all, coins = _inputs()
+    ref = _first_grad(model, trainer, tokens, eps_all, coins, 0, B)
+    err = np.abs(ref - r0["grad0"]).max() / np.abs(ref).max()
+    assert err < 2e-5, err
+    # and the trajectories agree to the extent Adam allows
+    single = _run_steps(model, trainer, tokens, eps_all, coins, 0, B)
+    assert np.isfinite(r0["losses"]).all() and abs(single[0] - 0.5 * (r0["losses"][0] + r1["losses"][0])) < 1e-4 * abs(single[0])
