@@ -134,7 +134,6 @@ class Trainer(ABC):
                 sums[1] += accuracy.detach()
             n += 1
         self.overlap_backward = prev_overlap
-        ops.side_defer(False)
         out = (sums / max(n, 1)).tolist()            # the one device->host sync of the epoch
         self.last_epoch_seconds = time.time() - t0
         return out[0], out[1]
@@ -149,7 +148,7 @@ class Trainer(ABC):
 
     def step(self):
         """utils/trainer.py:172-177 (+ the data-parallel gradient exchange)."""
-        ops.side_join()
+        ops.side_defer(False)                        # joins; deferred mode only lives between zero_grad() and step()
         gscale = dp.allreduce_grads(self.model.grad)
         self.adam_t += 1
         ops.adam_step(self.model.flat, self.model.grad, self.adam_m, self.adam_v, self.lr, self.adam_t,

@@ -3,7 +3,6 @@ rank) run the real HIP training step through VAETrainer with the epoch loop's de
 bucket started from inside backward and the rest summed in step().  Both ranks must end with identical parameters, equal
 to a single process that takes the same two half-batches as one global batch."""
 import os
-import random
 
 import numpy as np
 import pytest
@@ -34,10 +33,8 @@ def _build():
 def _first_grad(model, trainer, tokens, eps_all, coins, lo, hi):
     """Averaged gradient arena of step 0, exchanged exactly as Trainer.step() does it (join, all-reduce, 1/world)."""
     from inpaintnet_amd import dp, ops
-    from inpaintnet_amd import measure_vae as MV
-    MV.random.random = (lambda c=coins[0]: 0.0 if c else 0.9)
     trainer.zero_grad()
-    w, smp, zd, pd, z, zp = model(tokens[lo:hi].cuda(), train=True, eps=eps_all[0][lo:hi].cuda())
+    w, smp, zd, pd, z, zp = model(tokens[lo:hi].cuda(), train=True, eps=eps_all[0][lo:hi].cuda(), teacher_forced=coins[0])
     ce, acc = trainer.mean_crossentropy_loss_and_accuracy(w, tokens[lo:hi].cuda())
     (ce + trainer.compute_kld_loss(zd, pd)).backward()
     ops.side_join()
@@ -48,13 +45,11 @@ def _first_grad(model, trainer, tokens, eps_all, coins, lo, hi):
 
 
 def _run_steps(model, trainer, tokens, eps_all, coins, lo, hi):
-    from inpaintnet_amd import measure_vae as MV
     losses = []
     for s in range(STEPS):
-        MV.random.random = (lambda c=coins[s]: 0.0 if c else 0.9)
         eps = eps_all[s][lo:hi].cuda()
         trainer.zero_grad()
-        w, smp, zd, pd, z, zp = model(tokens[lo:hi].cuda(), train=True, eps=eps)
+        w, smp, zd, pd, z, zp = model(tokens[lo:hi].cuda(), train=True, eps=eps, teacher_forced=coins[s])
         ce, acc = trainer.mean_crossentropy_loss_and_accuracy(w, tokens[lo:hi].cuda())
         loss = ce + trainer.compute_kld_loss(zd, pd)
         loss.backward()
