@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
 """Headline benchmark: measures/sec of full MeasureVAE training steps on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload vae|latent]
 
-One "step" = one pass of the hot path over one batch of synthetic FolkDB-shaped
-tokens: zero_grad -> encoder fwd -> reparameterise -> hierarchical decoder fwd
-(teacher-forcing coin per step, dropout 0.5) -> CE + KL + accuracy -> backward
--> [all-reduce of the flat gradient arena over RCCL when N > 1] -> fused Adam.
-Workload at every N: BASELINE.json configs[1], batch = 256 measures PER GPU
-(weak scaling), V=48, reference default hyper-parameters, random-init weights.
+One "step" = one pass of the hot path over one batch of synthetic FolkDB-shaped tokens:
+  vae    (headline, BASELINE.json configs[1]): zero_grad -> encoder fwd -> reparameterise -> hierarchical decoder
+         fwd (teacher-forcing coin per step, dropout 0.5) -> CE + KL + accuracy -> backward -> [all-reduce of the flat
+         gradient arena over RCCL when N > 1] -> fused Adam.  256 measures PER GPU (weak scaling).
+  latent (BASELINE.json configs[2] on one GPU, configs[3] on N): frozen MeasureVAE encode of 16 measures -> context
+         bi-GRUs -> generator bi-GRU -> Linear -> frozen decode -> CE -> backward -> all-reduce of the 159.6 MB
+         LatentRNN arena -> Adam.  128 sequences PER GPU (1024 global at N = 8).
+
+Launching: with --gpus N > 1 and no WORLD_SIZE in the environment this process only SPAWNS
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` (before anything touches the GPU) and exits with its
+code; under torch.distributed.run it is one rank.  --gpus must equal the world size RCCL reports, and N may not exceed
+the visible devices: a mismatch is an error, never a silent 1-GPU number.
 
 Prints ONE JSON line on rank 0 (contract in the task brief) carrying
-  roofline     : the dominant MFMA kernel class, achieved TFLOP/s = algorithmic
-                 FLOPs per launch / average launch duration measured with HIP
-                 events on the launch stream (separate, un-timed steps), vs the
-                 157.3 TFLOP/s dense fp32 MFMA peak of gfx950
-  cpu_baseline : the oracle's port of the same step on the host cores
-                 (oracle/torch_ref.CpuVaeTrainStep), bounded sample.
+  roofline       the kernel with the largest summed time in the step (per-launch HIP-event timing on the launch
+                 stream during separate un-timed steps), its algorithmic FLOPs and bytes per launch against the
+                 157.3 TFLOP/s fp32-MFMA and 8 TB/s HBM peaks of gfx950, `traffic` = HBM bytes per launch from the
+                 committed rocprofv3 PMC pass (profiles/), and the same table for the top kernels;
+  cpu_baseline   the oracle's CPU port of the same step on the host cores (bounded sample, best thread count);
+  parity_checked one un-timed step at the bench's own batch compared with the oracle (loss, logits, every gradient).
 """
 import argparse
+import csv
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # kernel arguments in device memory (-0.5 ms/step)
@@ -33,73 +43,333 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk
-BATCH_PER_GPU = 256
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E (6.3 TB/s achievable)
 NUM_NOTES = 48
+VAE_BATCH_PER_GPU = 256
+LATENT_SEQ_PER_GPU = 128
+PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
 
 
-def cpu_baseline(batch, max_seconds=25.0):
-    """Reported baseline only: the oracle's CPU port of the same training step."""
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Parent of a multi-GPU run: never initialises the GPU (device_count() does not, on this image)."""
+    have = torch.cuda.device_count()
+    if args.gpus > have:
+        print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to report a "
+              f"{have}-GPU number as a {args.gpus}-GPU result", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU legs (un-timed)
+def _time_steps(fn, max_seconds, max_steps):
+    fn()                                            # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        fn()
+        n += 1
+        if time.time() - t0 > max_seconds or n >= max_steps:
+            break
+    return n, time.time() - t0
+
+
+def cpu_baseline(batch, seconds=20.0):
+    """Reported baseline only: the oracle's CPU port of the same training step, at the best of a few thread counts
+    (64 threads oversubscribe aten::gru at this size: VERDICT r01 weak 7)."""
     from oracle import torch_ref as O
     from inpaintnet_amd import layout, synthetic
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
     shapes = layout.vae_param_shapes(NUM_NOTES)
     P = {k: torch.from_numpy(synthetic.det_param(k, s)) for k, s in shapes.items()}
-    stepper = O.CpuVaeTrainStep(P, dropout=0.5)
     tok = torch.from_numpy(synthetic.det_tokens("bench/cpu", (batch, 24), NUM_NOTES))
-    rng = random.Random(0)
-    stepper.step(tok, True)                         # warm-up
-    n, t0 = 0, time.time()
-    while True:
-        stepper.step(tok, rng.random() < 0.5)
-        n += 1
-        if time.time() - t0 > max_seconds or n >= 8:
-            break
-    dt = time.time() - t0
-    return {"value": round(batch * n / dt, 2), "unit": "measures/s", "cores": threads, "kind": "port",
-            "sample": f"{n} training steps of batch {batch} (oracle/torch_ref.CpuVaeTrainStep, fused aten::gru, "
-                      f"{threads} threads of {cores} host cores)"}
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= cores} | {min(cores, 8)})
+    best = None
+    tried = {}
+    for th in cands:
+        torch.set_num_threads(th)
+        stepper = O.CpuVaeTrainStep(P, dropout=0.5)
+        rng = random.Random(0)
+        n, dt = _time_steps(lambda: stepper.step(tok, rng.random() < 0.5), seconds / len(cands), 4)
+        tried[th] = round(batch * n / dt, 2)
+        if best is None or tried[th] > best[0]:
+            best = (tried[th], th, n)
+    out = {"value": best[0], "unit": "measures/s", "cores": best[1], "kind": "port",
+           "sample": f"{best[2]} training steps of batch {batch} per thread count "
+                     f"(oracle/torch_ref.CpuVaeTrainStep, fused aten::gru, dropout 0.5); best of "
+                     f"{tried} threads on {cores} host cores"}
+    # the other configurations BASELINE.md section 3 promises next to the MI355X numbers (bounded samples)
+    legs = {}
+    torch.set_num_threads(best[1])
+    try:
+        st = O.CpuVaeTrainStep(P, dropout=0.5)
+        tok2 = tok[:2]
+        n, dt = _time_steps(lambda: st.step(tok2, True), 2.0, 10)
+        legs["cfg1_vae_b2"] = {"measures_per_s": round(2 * n / dt, 2), "ms_per_step": round(1e3 * dt / n, 2)}
+        if hasattr(O, "CpuLatentTrainStep"):
+            lat = O.CpuLatentTrainStep(NUM_NOTES, dropout=0.5)
+            n, dt = _time_steps(lambda: lat.step(LATENT_SEQ_PER_GPU), 8.0, 2)
+            legs["cfg3_latent_b128"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * n / dt, 2),
+                                        "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * n / dt, 2),
+                                        "ms_per_step": round(1e3 * dt / n, 1)}
+        if hasattr(O, "CpuArnnTrainStep"):
+            ar = O.CpuArnnTrainStep(NUM_NOTES)
+            n, dt = _time_steps(lambda: ar.step(32), 8.0, 2)
+            legs["cfg5_arnn_b32"] = {"sequences_per_s": round(32 * n / dt, 2), "measures_per_s": round(16 * 32 * n / dt, 2),
+                                     "ms_per_step": round(1e3 * dt / n, 1)}
+    except Exception as e:                           # a baseline leg must never take the headline down with it
+        legs["error"] = repr(e)
+    out["other_configs"] = legs
+    return out
 
 
-def latent_rnn_extra(ds, vae, dev, batch=128, steps=10, warmup=3):
-    """Secondary number (BASELINE.json configs[2]): LatentRNN training with the frozen MeasureVAE, 16-measure
-    sequences, past/target/future = 6/4/6, batch 128 sequences, one GPU.  Not the headline metric."""
-    from inpaintnet_amd import synthetic
-    from inpaintnet_amd.latent_rnn import LatentRNN
-    from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
-    model = LatentRNN(ds, vae, num_rnn_layers=2, rnn_hidden_size=512, dropout=0.5, rnn_class=torch.nn.GRU,
-                      auto_reg=False, teacher_forcing=True)
-    trainer = LatentRNNTrainer(ds, model, lr=1e-4)
-    trainer.overlap_backward = True              # as in the epoch loop (Trainer.loss_and_acc_on_epoch)
-    model.train()
-    score = torch.from_numpy(synthetic.folk_score(batch, NUM_NOTES, seed=9))
-    past, future, target = LatentRNNTrainer.split_score(score, 6, 6, 4, 24)
+def parity_check(model, trainer, tokens_dev):
+    """One un-timed training step at the bench's own batch (both coin values), through the public classes, against
+    the oracle on the same weights, tokens, eps and dropout masks (recorded from the product's own mask stream).
+    The oracle is only the checker here: nothing it computes is timed or reported as throughput."""
+    from oracle import torch_ref as O
+    from inpaintnet_amd import ops
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tok = tokens_dev.cpu()
+    B = tok.shape[0]
+    Z = model.latent_space_dim
+    g = torch.Generator().manual_seed(7)
+    eps = torch.randn(B, Z, generator=g)
+    worst = {}
+    real = ops.dropout_mask
+    try:
+        for tf in (True, False):
+            rec = []
 
-    def step():
-        trainer.zero_grad()
-        loss, acc = trainer.loss_and_acc_for_batch((past, future, target), 0, train=True)
+            def recording(shape, p, seed, offset, device, _rec=rec):
+                m = real(shape, p, seed, offset, device)
+                _rec.append(m)
+                return m
+            ops.dropout_mask = recording
+            trainer.zero_grad()
+            w, s, zd, pd, z, zp = model(tokens_dev, train=True, eps=eps.to(tokens_dev.device), teacher_forced=tf)
+            ce, acc = trainer.mean_crossentropy_loss_and_accuracy(w, tokens_dev)
+            loss = ce + trainer.compute_kld_loss(zd, pd)
+            loss.backward()
+            ops.side_defer(False)
+            ops.dropout_mask = real
+            m_enc, m_beat, m_tick = [m.cpu().permute(1, 0, 2) for m in rec]
+            Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+            wr, sr, mu, ls, zr = O.vae_forward(Pr, tok, eps, tf, {"enc": m_enc, "beat": m_beat, "tick": m_tick},
+                                               feed_tokens=None if tf else s.cpu()[:, 0])
+            lr, cer, klr, accr = O.vae_loss(wr, tok, mu, ls)
+            lr.backward()
+            tag = "tf" if tf else "fr"
+            worst[f"loss_{tag}"] = abs(float(loss.detach()) - lr.item()) / abs(lr.item())
+            worst[f"logits_{tag}"] = float((w.detach().cpu() - wr.detach()).abs().max() / wr.detach().abs().max())
+            gerr = 0.0
+            for k in P:
+                gr = Pr[k].grad
+                gerr = max(gerr, float((model.param_grad(k).cpu() - gr).abs().max() / (gr.abs().max() + 1e-12)))
+            worst[f"grads_{tag}"] = gerr
+            top2 = torch.topk(wr.detach(), 2, dim=-1).values
+            ok = (top2[..., 0] - top2[..., 1]) > 1e-4
+            worst[f"token_mismatch_{tag}"] = int((s.cpu()[:, 0][ok] != sr[:, 0][ok]).sum())
+    finally:
+        ops.dropout_mask = real
+    passed = all(worst[f"loss_{t}"] <= 1e-4 and worst[f"logits_{t}"] <= 1e-4 and worst[f"grads_{t}"] <= 5e-4 and
+                 worst[f"token_mismatch_{t}"] == 0 for t in ("tf", "fr"))
+    return {"parity_checked": bool(passed),
+            "max_rel_err": round(max(v for k, v in worst.items() if not k.startswith("token")), 8),
+            "parity_detail": {k: (round(v, 8) if isinstance(v, float) else v) for k, v in worst.items()},
+            "parity_tolerance": "loss 1e-4 rel, logits 1e-4 of max, every gradient tensor 5e-4 of its max, sampled "
+                                "tokens exact on rows with top-2 margin > 1e-4 (north_star)"}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+class VaeWorkload:
+    name = "vae"
+    units_per_step = VAE_BATCH_PER_GPU
+    unit = "measures/s"
+
+    def __init__(self, dev, rank):
+        from inpaintnet_amd import synthetic
+        from inpaintnet_amd.measure_vae import MeasureVAE
+        from inpaintnet_amd.vae_trainer import VAETrainer
+        self.ds = synthetic.SyntheticFolkDataset(num_notes=NUM_NOTES)
+        self.model = MeasureVAE(self.ds)                       # reference defaults: E=10,H=512,Z=256, dropout 0.5
+        sd = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in self.model.state_dict().items()}
+        self.model.load_state_dict(sd)                         # identical initial weights on every rank
+        self.trainer = VAETrainer(self.ds, self.model, lr=1e-4)
+        self.trainer.overlap_backward = True                   # as in the epoch loop (Trainer.loss_and_acc_on_epoch)
+        self.model.train()
+        self.tokens = torch.from_numpy(synthetic.det_tokens(f"bench/rank{rank}", (VAE_BATCH_PER_GPU, 24), NUM_NOTES)).to(dev)
+        self.arena_mb = self.model.flat.numel() * 4 / 1e6
+
+    def step(self):
+        t = self.trainer
+        t.zero_grad()
+        loss, acc = t.loss_and_acc_for_batch(self.tokens, 0, train=True)
         loss.backward()
-        trainer.step()
+        t.step()
+        return loss
+
+    def describe(self, world):
+        return {"workload": "MeasureVAE training, synthetic FolkDB-shaped tokens, 256 measures per GPU "
+                            "(BASELINE.json configs[1]); V=48,E=10,H=512,Z=256, dropout 0.5, "
+                            "teacher-forcing coin per step, Adam lr=1e-4",
+                "batch_per_gpu": VAE_BATCH_PER_GPU, "global_batch": world * VAE_BATCH_PER_GPU,
+                "parallelism": f"dp{world}"}
+
+
+class LatentWorkload:
+    name = "latent"
+    units_per_step = 16 * LATENT_SEQ_PER_GPU
+    unit = "measures/s"
+
+    def __init__(self, dev, rank, vae=None, ds=None):
+        from inpaintnet_amd import synthetic
+        from inpaintnet_amd.latent_rnn import LatentRNN
+        from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
+        from inpaintnet_amd.measure_vae import MeasureVAE
+        self.ds = ds or synthetic.SyntheticFolkDataset(num_notes=NUM_NOTES)
+        if vae is None:
+            vae = MeasureVAE(self.ds)
+            vae.load_state_dict({k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape)))
+                                 for k, v in vae.state_dict().items()})
+        self.model = LatentRNN(self.ds, vae, num_rnn_layers=2, rnn_hidden_size=512, dropout=0.5, rnn_class=torch.nn.GRU,
+                               auto_reg=False, teacher_forcing=True)
+        own = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in self.model.named_parameters()}
+        for k, v in own.items():
+            self.model.param(k).copy_(v)
+        self.trainer = LatentRNNTrainer(self.ds, self.model, lr=1e-4)
+        self.trainer.overlap_backward = True
+        self.model.train()
+        score = torch.from_numpy(synthetic.folk_score(LATENT_SEQ_PER_GPU, NUM_NOTES, seed=9 + rank))
+        self.batch = LatentRNNTrainer.split_score(score, 6, 6, 4, 24)
+        self.arena_mb = self.model.flat.numel() * 4 / 1e6
+
+    def step(self):
+        t = self.trainer
+        t.zero_grad()
+        loss, acc = t.loss_and_acc_for_batch(self.batch, 0, train=True)
+        loss.backward()
+        t.step()
+        return loss
+
+    def describe(self, world):
+        return {"workload": "LatentRNN (non-AR) training with the frozen MeasureVAE, 128 sequences x 16 measures per "
+                            "GPU, past/target/future 6/4/6, dropout 0.5 (BASELINE.json configs[2]; configs[3] when "
+                            "data-parallel: 1024 sequences global at 8 GPUs)",
+                "batch_per_gpu": LATENT_SEQ_PER_GPU, "global_batch": world * LATENT_SEQ_PER_GPU,
+                "parallelism": f"dp{world}"}
+
+
+def timed(step, steps, warmup, fence):
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(steps):
+        loss = step()
+    fence()
+    return time.perf_counter() - t0, loss
+
+
+def allreduce_ms(grad, iters=10):
+    """Cost of the gradient exchange alone: all-reduce(sum) of the flat arena over RCCL, averaged."""
+    if not torch.distributed.is_initialized():
+        return None
+    buf = torch.zeros_like(grad)
+    for _ in range(2):
+        torch.distributed.all_reduce(buf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        torch.distributed.all_reduce(buf)
+    torch.cuda.synchronize()
+    return round(1e3 * (time.perf_counter() - t0) / iters, 4)
+
+
+# ------------------------------------------------------------------------------------------------ roofline
+def kernel_table(step, nprof=4):
+    """Per-launch HIP-event timing (inet_prof_*) of separate, un-timed steps with the side stream off, so that every
+    duration is the kernel alone; grouped by the label that names the template instantiation and shape."""
+    from inpaintnet_amd import ops
+    ops.set_option(0, 0)
+    step()
+    torch.cuda.synchronize()
+    ops.prof_enable(True)
+    for _ in range(nprof):
         step()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"latent_rnn_train": {"sequences_per_s": round(batch * steps / dt, 1),
-                                 "measures_per_s": round(16 * batch * steps / dt, 1),
-                                 "ms_per_step": round(1e3 * dt / steps, 3),
-                                 "workload": "LatentRNN (non-AR) + frozen MeasureVAE, 128 sequences x 16 measures, "
-                                             "past/target/future 6/4/6, dropout 0.5"}}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "launches.csv")
+        ops.prof_dump(path)
+        rows = list(csv.DictReader(open(path)))
+    ops.prof_enable(False)
+    ops.set_option(0, 1)
+    groups = {}
+    for r in rows:
+        g = groups.setdefault(r["label"] or f"class{r['class']}", {"n": 0, "us": 0.0, "gflop": 0.0, "mb": 0.0})
+        g["n"] += 1
+        g["us"] += float(r["us"])
+        g["gflop"] += float(r["gflop"])
+        g["mb"] += float(r["mbytes"])
+    table = []
+    for label, g in groups.items():
+        us, n = g["us"], g["n"]
+        tflops = g["gflop"] * 1e9 / (us * 1e-6) / 1e12 if us > 0 else 0.0
+        gbps = g["mb"] * 1e6 / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        table.append({"kernel": label, "launches_per_step": round(n / nprof, 2), "avg_us": round(us / n, 3),
+                      "ms_per_step": round(us / nprof / 1e3, 4), "gflop_per_launch": round(g["gflop"] / n, 4),
+                      "mbytes_per_launch": round(g["mb"] / n, 4), "tflops": round(tflops, 2), "gbps": round(gbps, 1),
+                      "frac_mfma": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4)})
+    table.sort(key=lambda r: -r["ms_per_step"])
+    return table
 
 
+def roofline(step):
+    table = kernel_table(step)
+    top = table[0]
+    pmc = {}
+    if os.path.exists(PMC_FILE):
+        try:
+            pmc = json.load(open(PMC_FILE))
+        except Exception:
+            pmc = {}
+    kern = pmc.get("kernels", {})
+    for row in table:
+        hit = next((v for k, v in kern.items() if k in row["kernel"] or row["kernel"].startswith(k)), None)
+        if hit:
+            row["traffic_mbytes_per_launch"] = hit.get("hbm_mbytes_per_launch")
+    mfma_bound = top["frac_mfma"] >= top["frac_hbm"]
+    out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": top["kernel"],
+           "achieved": top["tflops"] if mfma_bound else top["gbps"],
+           "peak": PEAK_F32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBPS,
+           "unit": "TFLOP/s" if mfma_bound else "GB/s",
+           "frac": top["frac_mfma"] if mfma_bound else top["frac_hbm"],
+           "traffic": top.get("traffic_mbytes_per_launch"),
+           "traffic_unit": "MB of HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected; "
+                           f"{os.path.relpath(PMC_FILE, REPO)})",
+           "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_us"],
+           "algorithmic_gflop_per_launch": top["gflop_per_launch"],
+           "algorithmic_mbytes_per_launch": top["mbytes_per_launch"],
+           "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
+           "step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
+           "kernels": table[:8]}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ extras
 def decode_latency_extra(vae, iters=20):
-    """Inference-side number for the fused tick decode (SURVEY 8d 'K7'): full HierarchicalDecoder.forward in eval
-    mode (beat GRU + 24 ticks x [layer-0 step, layer-1 step, projection+argmax]) at small batch.  The HBM figure
-    counts the 26.44 MB of decoder weights ONCE per call, as SURVEY.md section 8d prescribes."""
+    """Inference-side number for the tick decode (SURVEY 8d 'K7'): full HierarchicalDecoder.forward in eval mode at
+    small batch.  The HBM figure counts the 26.44 MB of decoder weights ONCE per call, as SURVEY.md 8d prescribes; the
+    north_star target for this call is 40 % of the 8 TB/s roofline."""
     out = {}
     vae.eval()
     for b in (1, 16, 256):
@@ -114,8 +384,10 @@ def decode_latency_extra(vae, iters=20):
                 vae.decoder(z, dummy, train=False)
             torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / iters
+        gbps = 26.44e6 / (ms * 1e-3) / 1e9
         out[f"b{b}"] = {"ms_per_call": round(ms, 4), "measures_per_s": round(b / ms * 1e3, 1),
-                        "weights_once_GBps": round(26.44e6 / (ms * 1e-3) / 1e9, 2)}
+                        "weights_once_GBps": round(gbps, 2), "frac_hbm_roofline": round(gbps / PEAK_HBM_GBPS, 5)}
+    out["north_star_target_frac"] = 0.40
     vae.train()
     return {"decoder_eval": out}
 
@@ -162,49 +434,52 @@ def arnn_extra(batch=32, steps=8, warmup=2):
                                                    "train step, 32 sequences x 384 ticks"}}
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)         # >= 2 s of timed GPU work at ~5 ms per step
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=("vae", "latent"), default="vae")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))            # nothing above touched the GPU
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a mismatched run",
+              file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)",
+              file=sys.stderr)
+        sys.exit(2)
+
+    from inpaintnet_amd import dp, ops
+    world = dp.init_from_env(backend="nccl") if world_env > 1 else 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+        # what RCCL really connected: one element per rank summed over the ring
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        world = int(ones.item())
+        if world != args.gpus:
+            print(f"bench.py: RCCL reduced over {world} ranks, --gpus says {args.gpus}", file=sys.stderr)
+            sys.exit(2)
 
-    from inpaintnet_amd import ops, synthetic
-    from inpaintnet_amd.measure_vae import MeasureVAE, set_dropout_seed
-    from inpaintnet_amd.vae_trainer import VAETrainer
-
-    ds = synthetic.SyntheticFolkDataset(num_notes=NUM_NOTES)
-    model = MeasureVAE(ds)                                     # reference defaults: E=10,H=512,Z=256, dropout 0.5
-    sd = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in model.state_dict().items()}
-    model.load_state_dict(sd)                                  # identical initial weights on every rank
-    trainer = VAETrainer(ds, model, lr=1e-4)
-    trainer.overlap_backward = True              # as in the epoch loop (Trainer.loss_and_acc_on_epoch)
-    model.train()
-    set_dropout_seed(1234, rank)                               # per-rank dropout / eps streams
-    torch.manual_seed(1000 + rank)
-    random.seed(4321)                                          # the teacher-forcing coin is shared by all ranks
-    tokens = torch.from_numpy(synthetic.det_tokens(f"bench/rank{rank}", (BATCH_PER_GPU, 24), NUM_NOTES)).to(dev)
-
-    def one_step():
-        trainer.zero_grad()
-        loss, acc = trainer.loss_and_acc_for_batch(tokens, 0, train=True)
-        loss.backward()
-        trainer.step()
-        return loss
+    dp.seed_rank(1234, rank)                                   # per-rank eps / dropout streams
+    dp.seed_shared(4321)                                       # the teacher-forcing coin is shared by all ranks
+    wl = (VaeWorkload if args.workload == "vae" else LatentWorkload)(dev, rank)
+    dp.broadcast_params(wl.model.flat)
 
     def fence():
         torch.cuda.synchronize()
@@ -212,61 +487,63 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt, loss = timed(wl.step, args.steps, args.warmup, fence)
+    dt_local = dt
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     final_loss = float(loss.detach())
 
+    per_rank = None
+    ar_ms = None
+    if world > 1:
+        mine = torch.zeros(world, dtype=torch.float64, device=dev)
+        mine[rank] = wl.units_per_step * args.steps / dt_local
+        torch.distributed.all_reduce(mine)
+        per_rank = [round(v, 1) for v in mine.tolist()]
+        ar_ms = allreduce_ms(wl.model.grad)
+
+    extras = {}
     roof = None
-    if not args.no_roofline and rank == 0:
-        # separate, un-timed steps with every MFMA-kernel launch bracketed by HIP events on its stream; the
-        # side-stream overlap is switched off for them so that each duration is the kernel alone
-        from inpaintnet_amd import _lib
-        _lib.lib().inet_set_option(0, 0)
-        one_step()
-        torch.cuda.synchronize()
-        ops.prof_enable(True)
-        nprof = 4
-        for _ in range(nprof):
-            one_step()
-        torch.cuda.synchronize()
-        stats = ops.prof_read()
-        ops.prof_enable(False)
-        _lib.lib().inet_set_option(0, 1)
-        name = max(stats, key=lambda k: stats[k][1])
-        n, ms, fl = stats[name]
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "launches_per_step": n // nprof, "avg_launch_us": round(1e3 * ms / max(n, 1), 3),
-                "classes": {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[1] / nprof, 4),
-                                "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 3) if v[1] > 0 else 0.0}
-                            for k, v in stats.items()}}
+    if rank == 0 and not args.no_roofline:
+        roof = roofline(wl.step)
     if world > 1:
         torch.distributed.barrier()
 
-    extras = None
-    if rank == 0 and world == 1 and not args.no_extras:
-        extras = latent_rnn_extra(ds, model, dev)
-        extras.update(arnn_extra())
-        extras.update(decode_latency_extra(model))
+    if not args.no_extras:
+        if world > 1 and args.workload == "vae":
+            # BASELINE.json configs[3]: the LatentRNN step under the same data-parallel exchange (159.6 MB arena)
+            lw = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds)
+            dp.broadcast_params(lw.model.flat)
+            ldt, _ = timed(lw.step, 10, 3, fence)
+            t = torch.tensor([ldt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            lar = allreduce_ms(lw.model.grad)
+            extras["latent_rnn_train_dp"] = {
+                "sequences_per_s": round(world * LATENT_SEQ_PER_GPU * 10 / float(t.item()), 1),
+                "measures_per_s": round(world * 16 * LATENT_SEQ_PER_GPU * 10 / float(t.item()), 1),
+                "ms_per_step": round(1e3 * float(t.item()) / 10, 3), "allreduce_ms": lar,
+                "arena_mbytes": round(lw.arena_mb, 1), **lw.describe(world)}
+        elif rank == 0 and world == 1:
+            if args.workload == "vae":
+                lw = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds)
+                ldt, _ = timed(lw.step, 10, 3, fence)
+                extras["latent_rnn_train"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * 10 / ldt, 1),
+                                              "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 10 / ldt, 1),
+                                              "ms_per_step": round(1e3 * ldt / 10, 3), **lw.describe(1)}
+                wl.model.trainable = True                      # (LatentRNN froze the shared VAE)
+                wl.model.train()
+            extras.update(arnn_extra())
+            vae = wl.model if args.workload == "vae" else wl.model.vae_model
+            extras.update(decode_latency_extra(vae))
+
     if rank == 0:
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(BATCH_PER_GPU)
         out = {
-            "metric": "measures/sec training (MeasureVAE: fwd + CE/KL + bwd + Adam)",
-            "value": round(world * BATCH_PER_GPU * args.steps / dt, 2),
-            "unit": "measures/s",
+            "metric": "measures/sec training (MeasureVAE: fwd + CE/KL + bwd + Adam)" if args.workload == "vae" else
+                      "measures/sec training (LatentRNN + frozen MeasureVAE: fwd + CE + bwd + Adam)",
+            "value": round(world * wl.units_per_step * args.steps / dt, 2),
+            "unit": wl.unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -276,17 +553,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "MeasureVAE training, synthetic FolkDB-shaped tokens, 256 measures per GPU "
-                                   "(BASELINE.json configs[1]); V=48,E=10,H=512,Z=256, dropout 0.5, "
-                                   "teacher-forcing coin per step, Adam lr=1e-4",
-                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU,
-                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
+            "config": dict(wl.describe(world), final_loss=round(final_loss, 5)),
             "roofline": roof,
-            "cpu_baseline": cpu,
-            "extras": extras,
         }
+        if world > 1:
+            out["per_rank_units_per_s"] = per_rank
+            out["allreduce_ms_per_step"] = ar_ms
+            out["allreduce_mbytes"] = round(wl.arena_mb, 1)
+        cpu = None
+        if world == 1 and args.workload == "vae":
+            if not args.no_parity:
+                wl.model.trainable = True
+                out.update(parity_check(wl.model, wl.trainer, wl.tokens))
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline(VAE_BATCH_PER_GPU)
+        out["cpu_baseline"] = cpu
+        out["extras"] = extras or None
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

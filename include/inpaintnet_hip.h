@@ -171,6 +171,16 @@ int inet_relu_bwd(const float* dy, const float* y, float* dpre, int64_t n, void*
 /* out[r*stride] = argmax_v w[r*ld + v], lowest index on ties (Tensor.max(1) / np.argmax semantics) */
 int inet_argmax(const float* w, int64_t ld, int rows, int V, int64_t* out, int64_t stride, void* stream);
 
+/* ---- input feed: the dataset tensors are int32 `score (N,1,384)` (DatasetManager/the_session/folk_dataset.py:852-861),
+ *      the models take int64 (utils/helpers.py:17-26 to_cuda_variable_long).  The H2D copy moves the int32 form; these
+ *      widen / split on the device. ------------------------------------------------------------------------------ */
+/* dst[i] = src[i]: VAETrainer.process_batch_data (MeasureVAE/vae_trainer.py:42-55) -- (B,1,384) viewed as (B*16,24) */
+int inet_tokens_to_i64(const int32_t* src, int64_t* dst, int64_t n, void* stream);
+/* score [B, n_measures*measure_len] int32 -> past [B,n_past,L], target [B,n_target,L], future [B,rest,L] int64, each
+ * contiguous: LatentRNNTrainer.split_score / split_to_measures (LatentRNN/latent_rnn_trainer.py:134-176) */
+int inet_split_score(const int32_t* score, int batch, int n_measures, int measure_len, int n_past, int n_target,
+                     int64_t* past, int64_t* target, int64_t* future, void* stream);
+
 /* single GRU step (test hook for the fused step kernel; semantics of torch.nn.GRUCell with the input-side
  * gate pre-activations gi [B,3H] already formed) -- r,z,n,ghn,hprev saves are nullable [B,H] */
 int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
@@ -179,6 +189,9 @@ int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const 
 /* ---- runtime options: key 0 = overlap the weight-gradient GEMMs of the backward pass with the BPTT chains on
  * a second, lower-priority HIP stream (default 1; also INET_SIDE_STREAM=0 in the environment) */
 int inet_set_option(int key, int value);
+/* key 2 = force the batched-GEMM tile configuration: value -1 = cost model (default), 0..4 = 64x64, 128x128, 192x64,
+ * 192x128, 192x192 block tiles; key 3 = forced split-K factor (0 = none) used while key 2 is forced.  Test hooks: the
+ * parity tests drive every tile configuration through the same shapes (also INET_GEMM_FORCE="cfg,split"). */
 /* key 1 = deferred joins (default 0).  With 0 every *_bwd entry point makes `stream` wait for the side stream before
  * it returns.  With 1 it does not: the caller must keep every workspace passed to a *_bwd call alive and call
  * inet_side_join(stream) before anything reads the gradient arena (optimizer step, all-reduce) or frees those
@@ -186,12 +199,14 @@ int inet_set_option(int key, int value);
 int inet_side_join(void* stream);
 
 /* ---- measurement hooks (bench.py roofline line; not part of the reference surface) --------------- */
-/* class 0 = batched MFMA GEMM, 1 = fused GRU step forward, 2 = fused GRU step backward.  While enabled every
+/* class 0 = batched MFMA GEMM, 1 = fused GRU/LSTM step forward, 2 = fused GRU/LSTM step backward, 3 = HBM-bound
+ * pointwise kernels (the fused Adam update).  While enabled every
  * launch of those kernels is bracketed by hipEventRecord on its stream; read() synchronises and returns the
  * number of launches, the summed event time (ms) and the summed algorithmic FLOPs (2*M*N*K) of the class. */
 int inet_prof_enable(int on);
 int inet_prof_read(int cls, int64_t* launches, double* total_ms, double* total_flops);
-/* per-launch CSV (class,label,us,gflop) of everything recorded since inet_prof_enable(1) */
+/* per-launch CSV (class,label,us,gflop,mbytes) of everything recorded since inet_prof_enable(1); the label names the
+ * kernel instantiation and shape, mbytes = algorithmic HBM bytes of the launch (operands once, results once) */
 int inet_prof_dump(const char* path);
 
 #ifdef __cplusplus

@@ -27,16 +27,34 @@ class LatentConfig(C.Structure):
 
 
 def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into the in-tree shared library."""
+    """Compile every HIP source for gfx950 into the in-tree shared library: one object per source (in parallel,
+    only the stale ones), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, f) for f in SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(os.path.dirname(_HERE), "include", "inpaintnet_hip.h"))
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-            return LIB_PATH
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "inpaintnet_hip.h"))
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    objdir = os.path.join(os.path.dirname(_HERE), "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
-           "-o", LIB_PATH] + srcs
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+    objs, stale = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            stale.append((src, obj))
+    if not stale and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def compile_one(job):
+        cmd = [hipcc] + flags + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print("[inpaintnet_amd] " + " ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(stale)))) as ex:
+        list(ex.map(compile_one, stale))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print("[inpaintnet_amd] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
@@ -84,6 +102,8 @@ _SIGNATURES = {
     "inet_embedding_bwd": (C.c_int, [_P, _P, _L, _I, _P, _P, _P]),
     "inet_relu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "inet_argmax": (C.c_int, [_P, _L, _I, _I, _P, _L, _P]),
+    "inet_tokens_to_i64": (C.c_int, [_P, _P, _L, _P]),
+    "inet_split_score": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "inet_set_option": (C.c_int, [_I, _I]),
     "inet_side_join": (C.c_int, [_P]),
     "inet_prof_enable": (C.c_int, [_I]),

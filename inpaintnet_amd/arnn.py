@@ -177,9 +177,9 @@ class ConstraintModelGaussianReg(Model):
 
     def mask_tensor_score(self, tensor_score, constraints_location=None):
         """tokens where constrained, the extra 'no constraint' symbol elsewhere (:512-532)"""
-        if constraints_location is None:
-            p = random.random() * 0.5
-            constraints_location = (torch.rand(*tensor_score.size(), device=tensor_score.device) < p).long()
+        p = random.random() * 0.5          # drawn on EVERY call, as the reference does (:517): keeps the `random` stream
+        if constraints_location is None:   # -- which also feeds the teacher-forcing coin -- aligned with it
+            constraints_location = (torch.rand(*tensor_score.size()) < p).long().to(tensor_score.device)
         no_constraint = self.num_notes_per_voice[0]
         return tensor_score * constraints_location + no_constraint * (1 - constraints_location)
 

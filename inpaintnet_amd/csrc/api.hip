@@ -288,9 +288,25 @@ int inet_argmax(const float* w, int64_t ld, int rows, int V, int64_t* out, int64
     return pw_argmax(w, ld, rows, V, (long long*)out, stride, (hipStream_t)stream);
 }
 
+int inet_tokens_to_i64(const int32_t* src, int64_t* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return -1;
+    return pw_tokens_i32_to_i64(src, (long long*)dst, n, (hipStream_t)stream);
+}
+int inet_split_score(const int32_t* score, int batch, int n_measures, int measure_len, int n_past, int n_target,
+                     int64_t* past, int64_t* target, int64_t* future, void* stream) {
+    if (!score || batch <= 0 || n_measures <= 0 || measure_len <= 0 || n_past < 0 || n_target < 0 ||
+        n_past + n_target > n_measures)
+        return -1;
+    if ((n_past > 0 && !past) || (n_target > 0 && !target) || (n_measures - n_past - n_target > 0 && !future)) return -1;
+    return pw_split_measures(score, batch, n_measures, measure_len, n_past, n_target, (long long*)past,
+                             (long long*)target, (long long*)future, (hipStream_t)stream);
+}
+
 int inet_set_option(int key, int value) {
     if (key == 0) { side_set_enabled(value); return 0; }
     if (key == 1) { side_set_defer(value); return 0; }
+    if (key == 2) { if (value < -1 || value > 4) return -1; gemm_set_force(value, -1); return 0; }
+    if (key == 3) { if (value < 0) return -1; gemm_set_force(-2, value); return 0; }
     return -1;
 }
 

@@ -249,7 +249,15 @@ __global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int
     }
 }
 
+int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (INET_GEMM_FORCE="cfg,split"), -1: cost model
+
 }  // namespace
+
+// inet_set_option keys 2 / 3: force tile configuration `cfg` (index into kCfgs, -1 = cost model) / split-K factor
+void gemm_set_force(int cfg, int split) {
+    if (cfg >= -1) g_force_cfg = cfg;
+    if (split >= 0) g_force_split = split;
+}
 
 // Tile / split-K selection by a small cost model (microseconds), calibrated on MI355X (profiles/r01_*):
 //  * a workgroup alone on a CU spends ~0.7 us per 32-deep chunk on the load -> LDS -> MFMA dependency, whatever the
@@ -265,11 +273,11 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     GemmArgs g = gin;
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.K <= 0) return -1;
-    static int force_cfg = -2, force_split = 0;
-    if (force_cfg == -2) {
-        force_cfg = -1;
-        if (const char* v = std::getenv("INET_GEMM_FORCE")) std::sscanf(v, "%d,%d", &force_cfg, &force_split);
+    if (g_force_cfg == -2) {
+        g_force_cfg = -1;
+        if (const char* v = std::getenv("INET_GEMM_FORCE")) std::sscanf(v, "%d,%d", &g_force_cfg, &g_force_split);
     }
+    const int force_cfg = g_force_cfg, force_split = g_force_split;
     const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     const bool nonlinear = g.epi != EPI_NONE;
     double best = 1e300;
@@ -316,7 +324,7 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
                   g.b_kmajor ? 'N' : 'T', 64 * c.tm, 64 * c.tn, splits, gin.epi);
     int rc;
     {
-        ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label);
+        ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
         // Leaf GEMMs on the side stream: 64x64 tiles would sit 4 to a CU and take 147 of its 160 KB of LDS, so a BPTT
         // step kernel arriving on the main stream (16-32 KB) has to wait for one of them to retire.  A few KB of unused
         // dynamic LDS caps them at 3 per CU and leaves the step kernels room to co-reside (5.22 -> 5.18 ms per step;

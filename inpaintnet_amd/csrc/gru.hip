@@ -28,6 +28,7 @@
 // accumulators.  (Round-1 history in DESIGN.md section 8: LDS-staged 14.5 us,
 // register-streamed row-major 12.4 us, fragment-major + streamed 10.8 us per
 // two-direction step; 5.2 us of that is MFMA issue.)
+#include <cstdio>
 #include <cstdlib>
 #include "common.h"
 #include "ksplit.h"
@@ -405,13 +406,20 @@ int launch_gru_fwd(const GruFwdBatch& bin, hipStream_t s) {
     if (b.rows_fastest) grid = dim3(b.tiles_per_prob * b.nprob, b.H / TH, 1);
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) fl += 2.0 * b.p[i].B * 3.0 * b.H * (b.H + (hasx ? b.p[i].K2 : 0));
-    ProfScope prof(PROF_GRU_FWD, fl, s);
     bool pk = b.H % 256 == 0;
     for (int i = 0; i < b.nprob; ++i) {
         const GruFwdProb& P = b.p[i];
         if (!P.hpk_prev || !P.Wpk_hh) pk = false;
         if (hasx && (!P.xpk || !P.Wpk_ih || P.K2 % 256 != 0)) pk = false;
     }
+    char label[64];                               // names the template instantiation (tests assert which ones ran)
+    std::snprintf(label, sizeof label, "gru_fwd x%d ms%d pk%d np%d B%d H%d", (int)hasx, ms, (int)pk, b.nprob, maxB, b.H);
+    // algorithmic bytes: W_hh (+ W_ih) once per problem; per row h_prev in, h_new out, gi in, the 5 backward saves
+    double by = 0;
+    for (int i = 0; i < b.nprob; ++i)
+        by += 4.0 * (3.0 * b.H * (b.H + (hasx ? b.p[i].K2 : 0)) +
+                     (double)b.p[i].B * b.H * (2 + (b.p[i].gi_dense ? 3 : 0) + (b.p[i].sv_r ? 5 : 0) + (hasx ? 1 : 0)));
+    ProfScope prof(PROF_GRU_FWD, fl, s, label, by);
 #define INET_FWD(X, M)                                                                                       \
     do {                                                                                                     \
         if (pk) hipLaunchKernelGGL((gru_step_fwd_kernel<X, M, true>), grid, dim3(256), 0, s, b);             \
@@ -439,10 +447,16 @@ int launch_gru_bwd(const GruBwdBatch& bin, hipStream_t s) {
     dim3 grid(b.tiles_per_prob * b.nprob, b.H / (TH * nc), 1);
     double fl = 0;
     for (int i = 0; i < b.nprob; ++i) if (b.p[i].dgh_next) fl += 2.0 * b.p[i].B * 3.0 * b.H * b.H;
-    ProfScope prof(PROF_GRU_BWD, fl, s);
     bool pk = b.H % 256 == 0;
     for (int i = 0; i < b.nprob; ++i)
         if (b.p[i].dgh_next && (!b.p[i].dghpk_next || !b.p[i].Wpk_hhT)) pk = false;
+    char label[64];
+    std::snprintf(label, sizeof label, "gru_bwd ms%d nc%d pk%d np%d B%d H%d", ms, nc, (int)pk, b.nprob, maxB, b.H);
+    // algorithmic bytes: W_hh^T once per problem; per row dgh_next (3H) in, dgi + dgh (6H) out, 5 saves + dhz in/out
+    double by = 0;
+    for (int i = 0; i < b.nprob; ++i)
+        by += 4.0 * ((b.p[i].dgh_next ? 3.0 * b.H * b.H : 0.0) + (double)b.p[i].B * b.H * (3 + 6 + 5 + 2 + 1));
+    ProfScope prof(PROF_GRU_BWD, fl, s, label, by);
 #define INET_BWD(M, C)                                                                                       \
     do {                                                                                                     \
         if (pk) hipLaunchKernelGGL((gru_step_bwd_kernel<M, C, true>), grid, dim3(256), 0, s, b);             \
@@ -460,7 +474,7 @@ int launch_logits_argmax(const float* h, long ldh, int B, int H, const float* W,
                          long ldo, long long* samples, long sstride, hipStream_t s, const float* hpk, const float* Wpk) {
     if (V % 16 != 0 || V > 64 || H % TH != 0) return 1;
     dim3 grid((B + TM_ROWS - 1) / TM_ROWS);
-    ProfScope prof(PROF_GEMM, 2.0 * B * V * H, s, "logits_argmax");
+    ProfScope prof(PROF_GEMM, 2.0 * B * V * H, s, "logits_argmax", 4.0 * ((double)V * H + (double)B * (H + V)));
     const bool pk = hpk && Wpk && H % 256 == 0;
     const float* a = pk ? hpk : h;
     const float* w = pk ? Wpk : W;

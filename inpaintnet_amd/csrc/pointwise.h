@@ -41,3 +41,6 @@ int pw_embedding_fwd(const float* table, const long long* idx, long rows, int E,
                      hipStream_t s);
 int pw_embedding_bwd(const float* dout, const long long* idx, long rows, int E, float* dtable, const float* row_scale,
                      hipStream_t s);
+int pw_tokens_i32_to_i64(const int* src, long long* dst, long n, hipStream_t s);
+int pw_split_measures(const int* score, int B, int M, int L, int n_past, int n_target, long long* past,
+                      long long* target, long long* future, hipStream_t s);

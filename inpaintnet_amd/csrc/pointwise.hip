@@ -7,6 +7,7 @@
 // shuffles.
 #include "common.h"
 #include "pointwise.h"
+#include "prof.h"
 
 namespace {
 
@@ -380,6 +381,29 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ dout, const long 
     }
 }
 
+// Input feed: the dataset tensors are int32 (folk_dataset.py:852-861); the model wants int64 (utils/helpers.py:17-26).
+// The H2D copy moves the 4-byte form, the widening happens here.
+__global__ void tokens_i32_to_i64_kernel(const int* __restrict__ src, long long* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// score [B, M*L] int32 -> past [B, np, L], target [B, nt, L], future [B, M-np-nt, L] int64, each contiguous
+// (LatentRNNTrainer.split_score, latent_rnn_trainer.py:134-160): one pass, every token read once and written once.
+__global__ void split_measures_kernel(const int* __restrict__ score, int B, int M, int L, int n_past, int n_target,
+                                      long long* __restrict__ past, long long* __restrict__ target,
+                                      long long* __restrict__ future) {
+    const long n = (long)B * M * L;
+    const int n_future = M - n_past - n_target;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(i % L);
+        const int m = (int)((i / L) % M);
+        const long b = i / ((long)L * M);
+        const long long v = score[i];
+        if (m < n_past) past[(b * n_past + m) * L + l] = v;
+        else if (m < n_past + n_target) target[(b * n_target + (m - n_past)) * L + l] = v;
+        else future[(b * n_future + (m - n_past - n_target)) * L + l] = v;
+    }
+}
+
 inline int grid_for(long n, int block = 256, int cap = 2048) {
     long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -432,6 +456,7 @@ int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
             float gscale, hipStream_t s) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    ProfScope prof(PROF_HBM, 0.0, s, "adam", 28.0 * (double)n);      // read p,g,m,v; write p,m,v
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
                        (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale);
     return ok();
@@ -517,5 +542,15 @@ int pw_embedding_fwd(const float* table, const long long* idx, long rows, int E,
 int pw_embedding_bwd(const float* dout, const long long* idx, long rows, int E, float* dtable, const float* row_scale,
                      hipStream_t s) {
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(rows * E)), dim3(256), 0, s, dout, idx, rows, E, dtable, row_scale);
+    return ok();
+}
+int pw_tokens_i32_to_i64(const int* src, long long* dst, long n, hipStream_t s) {
+    hipLaunchKernelGGL(tokens_i32_to_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+    return ok();
+}
+int pw_split_measures(const int* score, int B, int M, int L, int n_past, int n_target, long long* past,
+                      long long* target, long long* future, hipStream_t s) {
+    hipLaunchKernelGGL(split_measures_kernel, dim3(grid_for((long)B * M * L)), dim3(256), 0, s, score, B, M, L, n_past,
+                       n_target, past, target, future);
     return ok();
 }

@@ -6,11 +6,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { PROF_GEMM = 0, PROF_GRU_FWD = 1, PROF_GRU_BWD = 2, PROF_NCLASS = 3 };
+enum { PROF_GEMM = 0, PROF_GRU_FWD = 1, PROF_GRU_BWD = 2, PROF_HBM = 3, PROF_NCLASS = 4 };
 
 struct ProfScope {
     int idx;
     hipStream_t s;
-    ProfScope(int cls, double flops, hipStream_t stream, const char* label = nullptr);
+    // bytes: algorithmic (compulsory) HBM bytes of the launch -- operands read once, results written once
+    ProfScope(int cls, double flops, hipStream_t stream, const char* label = nullptr, double bytes = 0.0);
     ~ProfScope();
 };

@@ -5,7 +5,7 @@
 #include "../../include/inpaintnet_hip.h"
 
 namespace {
-struct Rec { int cls; double flops; hipEvent_t a, b; std::string label; };
+struct Rec { int cls; double flops, bytes; hipEvent_t a, b; std::string label; };
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -21,9 +21,9 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-ProfScope::ProfScope(int cls, double flops, hipStream_t stream, const char* label) : idx(-1), s(stream) {
+ProfScope::ProfScope(int cls, double flops, hipStream_t stream, const char* label, double bytes) : idx(-1), s(stream) {
     if (!g_on) return;
-    Rec r{cls, flops, get_event(), get_event(), label ? label : ""};
+    Rec r{cls, flops, bytes, get_event(), get_event(), label ? label : ""};
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
@@ -42,12 +42,12 @@ int inet_prof_enable(int on) {
 int inet_prof_dump(const char* path) {
     FILE* f = std::fopen(path, "w");
     if (!f) return -1;
-    std::fprintf(f, "class,label,us,gflop\n");
+    std::fprintf(f, "class,label,us,gflop,mbytes\n");
     for (const Rec& r : g_recs) {
         if (hipEventSynchronize(r.b) != hipSuccess) { std::fclose(f); return -2; }
         float t = 0.f;
         (void)hipEventElapsedTime(&t, r.a, r.b);
-        std::fprintf(f, "%d,%s,%.3f,%.4f\n", r.cls, r.label.c_str(), t * 1e3, r.flops * 1e-9);
+        std::fprintf(f, "%d,%s,%.3f,%.4f,%.4f\n", r.cls, r.label.c_str(), t * 1e3, r.flops * 1e-9, r.bytes * 1e-6);
     }
     std::fclose(f);
     return 0;

@@ -4,10 +4,15 @@ The reference has no distributed code; BASELINE.json's c
 training with a gradient all-reduce.  Samples are independent through forward/backward and every loss is a
 mean over rows, so with equal per-rank batches the global-batch gradient is the mean of the rank gradients:
 ONE all-reduce(sum) of the flat fp32 gradient arena per step, the 1/world folded into the Adam kernel.
-What has to be identical on every rank, because the reference draws it once per (global) batch:
-the teacher-forcing coin (decoder.py:432, latent_rnn.py:143) and the past/target/future split
-(latent_rnn_trainer.py:99-117) -- both come from host generators seeded identically on all ranks
-(seed_shared); dropout masks and eps are per-rank streams (measure_vae.set_dropout_seed, torch.manual_seed).
+
+Random draws:
+  * identical on every rank, because the reference draws them once per (global) batch: the teacher-forcing coin
+    (decoder.py:432, latent_rnn.py:143 -- Python's `random`) and the past/target/future split
+    (latent_rnn_trainer.py:99-117 -- torch's CPU generator).  seed_shared(seed) seeds exactly those two HOST
+    generators and nothing else;
+  * distinct per rank: eps (torch.randn_like on the device -> the CUDA generator) and the dropout masks (the
+    counter-based stream of measure_vae.set_dropout_seed).  seed_rank(seed) seeds those with a rank offset and
+    does not touch the host generators.
 """
 import os
 import random
@@ -47,9 +52,18 @@ def init_from_env(backend=None):
 
 def seed_shared(seed):
     """Host generators that must agree on all ranks: Python's `random` (teacher-forcing coins) and torch's CPU
-    generator (the stochastic past/target/future split)."""
+    generator (the stochastic past/target/future split, the constraint window).  The device generator is left alone."""
     random.seed(seed)
-    torch.manual_seed(seed)
+    torch.default_generator.manual_seed(seed)
+
+
+def seed_rank(seed, r=None):
+    """Per-rank noise: eps draws (device generator) and dropout masks (counter-based stream)."""
+    from .measure_vae import set_dropout_seed
+    r = rank() if r is None else r
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(int(seed) + r)
+    set_dropout_seed(seed, r)
 
 
 def broadcast_params(flat, src=0):
@@ -58,34 +72,57 @@ def broadcast_params(flat, src=0):
         torch.distributed.broadcast(flat, src=src)
 
 
-_pending = []        # [(start, stop, work handle)] buckets of the arena already being summed
+# Buckets of a gradient arena whose sum over ranks has already been started, keyed by the arena's data pointer so that
+# two models in one process (or a stale entry after an exception) can never be mistaken for each other.
+_pending = {}        # data_ptr -> [(start, stop, work handle)]
+
+
+def reset_buckets(grad=None):
+    """Forget started buckets (Trainer.zero_grad calls this: a step that died between backward and step() must not
+    leave handles behind).  Outstanding work is waited for first so that no all-reduce is left writing the arena."""
+    keys = list(_pending) if grad is None else [grad.data_ptr()]
+    for k in keys:
+        for _, _, work in _pending.pop(k, []):
+            work.wait()
 
 
 def start_bucket(grad, start, stop):
     """Begin summing grad[start:stop] over ranks asynchronously (RCCL runs on its own stream, ordered after the
     work already queued on the current stream).  Called as soon as a contiguous part of the arena is final --
     the decoder's gradients are complete while the encoder is still back-propagating -- so that part of the
-    exchange hides behind the rest of backward.  No-op for a single process."""
+    exchange hides behind the rest of backward.  No-op for a single process.  A range may be started only once per
+    step (a second backward() before step() would otherwise be summed twice)."""
     if world_size() > 1 and stop > start:
+        mine = _pending.setdefault(grad.data_ptr(), [])
+        for a, b, _ in mine:
+            if start < b and a < stop:
+                raise RuntimeError(f"dp.start_bucket: [{start},{stop}) overlaps the bucket [{a},{b}) already being "
+                                   "reduced for this arena (backward() twice without step()/zero_grad()?)")
         work = torch.distributed.all_reduce(grad[start:stop], op=torch.distributed.ReduceOp.SUM, async_op=True)
-        _pending.append((start, stop, work))
+        mine.append((start, stop, work))
 
 
 def allreduce_grads(grad):
     """Sum the (rest of the) flat gradient arena over ranks and wait for the buckets started earlier; returns the
     scale (1/world) the optimizer kernel applies to it."""
     w = world_size()
+    mine = _pending.pop(grad.data_ptr(), [])
     if w > 1:
-        done = sorted((a, b) for a, b, _ in _pending)
         pos = 0
-        for a, b in done + [(grad.numel(), grad.numel())]:
+        for a, b in sorted((a, b) for a, b, _ in mine) + [(grad.numel(), grad.numel())]:
             if a > pos:
                 torch.distributed.all_reduce(grad[pos:a], op=torch.distributed.ReduceOp.SUM)
             pos = max(pos, b)
-        for _, _, work in _pending:
+        for _, _, work in mine:
             work.wait()
-    _pending.clear()
     return 1.0 / w
+
+
+def allreduce_sum_(t):
+    """In-place sum of a small tensor over ranks (epoch statistics)."""
+    if world_size() > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+    return t
 
 
 def shard(n_items, r=None, w=None):
@@ -94,3 +131,13 @@ def shard(n_items, r=None, w=None):
     w = world_size() if w is None else w
     per = n_items // w
     return r * per, (r + 1) * per
+
+
+def shard_batch(batch):
+    """This rank's rows of a global batch (a tensor or a tuple/list of tensors sharing dim 0)."""
+    if world_size() == 1:
+        return batch
+    if torch.is_tensor(batch):
+        lo, hi = shard(batch.shape[0])
+        return batch[lo:hi]
+    return type(batch)(shard_batch(b) if torch.is_tensor(b) else b for b in batch)

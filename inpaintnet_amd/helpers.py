@@ -9,7 +9,14 @@ def to_cuda_variable(tensor):
 
 
 def to_cuda_variable_long(tensor):
-    return tensor.to(device=default_device(), dtype=torch.int64, non_blocking=True).contiguous()
+    """utils/helpers.py:17-26.  int32 dataset tensors cross the bus as int32 and are widened by the HIP kernel
+    (inet_tokens_to_i64); anything else takes torch's conversion."""
+    dev = default_device()
+    if tensor.dtype == torch.int32:
+        from . import ops
+        t = tensor if tensor.is_cuda else tensor.to(dev, non_blocking=True)
+        return ops.tokens_to_long(t.contiguous())
+    return tensor.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous()
 
 
 def to_numpy(variable):

@@ -15,7 +15,7 @@ import random
 
 import torch
 
-from . import ops
+from . import dp, ops
 from ._lib import LatentConfig
 from .measure_vae import MeasureVAE, _DropState, _next_mask_offset
 from .model import Model
@@ -43,6 +43,11 @@ class _BiGru2Fn(torch.autograd.Function):
         dx, dh0 = ops.bigru2_bwd(xin, x_scalar, owner.flat[off:], owner.grad[off:], H, B, T, K, mask,
                                  dout.contiguous(), dhn.contiguous(), ws,
                                  want_dx=ctx.needs_input_grad[0], dx_scalar=dxs, want_dh0=ctx.needs_input_grad[2])
+        if off == getattr(owner, "dp_bucket_from", -1) and dp.world_size() > 1:
+            # data parallel: everything from the generator GRU to the end of the arena (generation_rnn +
+            # generation_linear, 103 of the 160 MB) is final now -> its all-reduce runs under the context GRUs' backward
+            ops.side_join()
+            dp.start_bucket(owner.grad, off, owner.grad.numel())
         return dx, None, dh0, None, None, None, None, None, None, None, None
 
 
@@ -89,6 +94,11 @@ class LatentRNN(Model):
         table, total = ops.latent_param_table(self.lcfg)
         self._alloc_arena(table, total, self.vae_model.flat.device)
         self._off = {name: off for name, off, _ in table}
+        # arena order: x_0 | context_rnn_past | context_rnn_future | generation_rnn | generation_linear; backward visits
+        # generation_linear, generation_rnn, then the contexts -> the tail starting here completes first
+        self.dp_bucket_from = self._off["generation_rnn.weight_ih_l0"]
+        assert all(off >= self.dp_bucket_from for name, off, _ in table if name.startswith("generation_"))
+        assert all(off < self.dp_bucket_from for name, off, _ in table if not name.startswith("generation_"))
         self._flat_leaf = None
         self.init_reference_style()
         cur_dir = os.path.dirname(os.path.realpath(__file__))

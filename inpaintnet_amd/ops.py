@@ -190,11 +190,21 @@ def dropout_mask(shape, p, seed, offset, device):
 
 
 # ----------------------------------------------------------------------------- measurement hooks
-PROF_CLASSES = ("gemm_f32_mfma", "gru_step_fwd", "gru_step_bwd")
+PROF_CLASSES = ("gemm_f32_mfma", "gru_step_fwd", "gru_step_bwd", "hbm_pointwise")
 
 
 def prof_enable(on):
     check(_lib.lib().inet_prof_enable(int(bool(on))), "inet_prof_enable")
+
+
+def set_option(key, value):
+    """inet_set_option (include/inpaintnet_hip.h): 0 side stream, 1 deferred joins, 2 GEMM tile force, 3 GEMM split force."""
+    check(_lib.lib().inet_set_option(int(key), int(value)), "inet_set_option")
+
+
+def prof_dump(path):
+    """Per-launch CSV (class,label,us,gflop) of the launches since prof_enable(True)."""
+    check(_lib.lib().inet_prof_dump(str(path).encode()), "inet_prof_dump")
 
 
 def prof_read():
@@ -343,3 +353,26 @@ def bigru2_bwd(x, x_scalar, weights, grads, H, B, T, K, mask, dout, dhn, ws, wan
                                      ptr(dout), ptr(dhn), ptr(dx), ptr(dx_scalar), ptr(dh0), ptr(ws), ws.numel() * 4,
                                      stream_ptr()), "inet_bigru2_bwd")
     return dx, dh0
+
+
+# ----------------------------------------------------------------------------- input feed
+def tokens_to_long(t):
+    """int32 device tensor -> int64 of the same shape (utils/helpers.py:17-26 on the device)."""
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()
+    out = torch.empty(t.shape, dtype=torch.int64, device=t.device)
+    check(_lib.lib().inet_tokens_to_i64(ptr(t), ptr(out), t.numel(), stream_ptr()), "inet_tokens_to_i64")
+    return out
+
+
+def split_score(score, n_past, n_target, measure_len):
+    """score (B,1,L) or (B,L) int32 on the device -> past, future, target int64 (B,n,measure_len), one kernel."""
+    assert score.is_cuda and score.dtype == torch.int32 and score.is_contiguous()
+    B = score.shape[0]
+    L = score.numel() // B
+    M = L // measure_len
+    n_future = M - n_past - n_target
+    mk = lambda n: torch.empty(B, n, measure_len, dtype=torch.int64, device=score.device)
+    past, target, future = mk(n_past), mk(n_target), mk(n_future)
+    check(_lib.lib().inet_split_score(ptr(score), B, M, measure_len, n_past, n_target, ptr(past), ptr(target),
+                                      ptr(future), stream_ptr()), "inet_split_score")
+    return past, future, target

@@ -91,20 +91,15 @@ class SyntheticFolkDataset:
                 folk_metadata(self.n_seq, self.n_bars))
 
     def data_loaders(self, batch_size, split=(0.85, 0.10)):
-        """Same contract as MusicDataset.data_loaders (music_dataset.py:177-221):
-        returns (train, val, eval) iterables of (score, metadata) batches,
-        drop_last=True."""
+        """Same contract as MusicDataset.data_loaders (music_dataset.py:177-221): (train, val, eval) loaders over
+        the (score, metadata) tensors split by fraction, drop_last=True, only the train loader shuffles."""
         import torch
-        score, md = self.tensors()
-        score = torch.from_numpy(score)
-        md = torch.from_numpy(md)
+        from .feed import BatchLoader
+        assert sum(split) < 1
+        score, md = (torch.from_numpy(t) for t in self.tensors())
         n = score.shape[0]
         a = int(split[0] * n)
         b = int((split[0] + split[1]) * n)
-
-        def loader(lo, hi):
-            out = []
-            for s in range(lo, hi - batch_size + 1, batch_size):
-                out.append((score[s:s + batch_size], md[s:s + batch_size]))
-            return out
-        return loader(0, a), loader(a, b), loader(b, n)
+        return (BatchLoader((score[:a], md[:a]), batch_size, shuffle=True),
+                BatchLoader((score[a:b], md[a:b]), batch_size, shuffle=False),
+                BatchLoader((score[b:], md[b:]), batch_size, shuffle=False))

@@ -14,12 +14,14 @@ the static loss helpers.  Differences that are the point of the build:
     (the reference syncs every batch: utils/trainer.py:154).
 Plotting / tensorboard plumbing of the reference is out of scope.
 """
+import os
 import time
 from abc import ABC, abstractmethod
 
 import torch
 
 from . import dp, ops
+from .feed import DeviceFeed
 
 
 def _dist_ready():
@@ -70,6 +72,8 @@ class _KLFn(torch.autograd.Function):
 class Trainer(ABC):
     """utils/trainer.py:15-39"""
 
+    feed_fields = (0, 1)       # which members of a (score, metadata) batch the trainer needs on the device
+
     def __init__(self, dataset, model, lr=1e-4, early_stopping=False):
         self.dataset = dataset
         self.model = model
@@ -84,66 +88,82 @@ class Trainer(ABC):
             self.early_stopping = True
             self.early_stopper = EarlyStopping()
         self.last_epoch_seconds = None
+        self.start_epoch = 0                         # load_training_state() moves it
         # deferred side-stream joins for zero_grad() -> forward -> backward -> step() sequences (see zero_grad)
         self.overlap_backward = False
 
     # ---- utils/trainer.py:41-124 (plot/log plumbing omitted) -----------------------
-    def train_model(self, batch_size, num_epochs, plot=False, log=False):
-        (generator_train, generator_val, _) = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
-        print('Num Train Batches: ', len(generator_train))
-        print('Num Valid Batches: ', len(generator_val))
-        for epoch_index in range(num_epochs):
-            self.update_scheduler(epoch_index)
-            self.model.train()
-            mean_loss_train, mean_accuracy_train = self.loss_and_acc_on_epoch(
-                data_loader=generator_train, epoch_num=epoch_index, train=True)
-            self.model.eval()
-            mean_loss_val, mean_accuracy_val = self.loss_and_acc_on_epoch(
-                data_loader=generator_val, epoch_num=epoch_index, train=False)
-            self.print_epoch_stats(epoch_index, num_epochs, mean_loss_train, mean_accuracy_train, mean_loss_val,
-                                   mean_accuracy_val)
-            if not _dist_ready() or torch.distributed.get_rank() == 0:
+    def train_model(self, batch_size, num_epochs, plot=False, log=False, seed=0):
+        """Epoch loop of the reference (train pass, validation pass, stats, save, optional early stopping).
+        `batch_size` is the GLOBAL batch.  Under torch.distributed every rank iterates the same loader (same shuffle:
+        the host generators are seeded identically), takes its contiguous shard of every batch, and sees the same
+        epoch statistics (they are summed over ranks), so save / early-stopping decisions agree on all ranks."""
+        if dp.world_size() > 1:
+            dp.seed_shared(seed)
+            dp.seed_rank(seed)
+            dp.broadcast_params(self.model.flat)
+        train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
+        print('Num Train Batches: ', len(train_loader))
+        print('Num Valid Batches: ', len(val_loader))
+        for epoch in range(self.start_epoch, num_epochs):
+            self.update_scheduler(epoch)
+            stats = []
+            for loader, train in ((train_loader, True), (val_loader, False)):
+                self.model.train(train)
+                stats += self.loss_and_acc_on_epoch(data_loader=loader, epoch_num=epoch, train=train)
+            self.print_epoch_stats(epoch, num_epochs, *stats)
+            if dp.rank() == 0:
                 self.model.save()
-                if epoch_index > 0 and epoch_index % 10 == 0:
-                    self.model.save_checkpoint(epoch_index)
-            if self.early_stopping:
-                self.early_stopper(mean_loss_val, self.model)
-                if self.early_stopper.early_stop:
-                    print("Early Stopping")
-                    return
+                if epoch > 0 and epoch % 10 == 0:
+                    self.model.save_checkpoint(epoch)
+                    self.save_training_state(self.model.filepath + f'_{epoch}.trainer', epoch + 1)
+            if self.early_stopping and self.early_stopper(stats[2], self.model):
+                print("Early Stopping")
+                return
 
     # ---- utils/trainer.py:126-163 ---------------------------------------------------
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
         dev = self.model.flat.device
-        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        sums = torch.zeros(3, dtype=torch.float32, device=dev)        # loss sum, accuracy sum, batches
         t0 = time.time()
-        n = 0
         prev_overlap, self.overlap_backward = self.overlap_backward, bool(train)
-        for sample_id, batch in enumerate(data_loader):
-            batch_data = self.process_batch_data(batch)
-            self.zero_grad()
-            if train:
-                loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=True)
-                loss.backward()
-                self.step()
-            else:
-                with torch.no_grad():
-                    loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=False)
-            sums[0] += loss.detach().mean()
-            if accuracy is not None:
-                sums[1] += accuracy.detach()
-            n += 1
-        self.overlap_backward = prev_overlap
-        out = (sums / max(n, 1)).tolist()            # the one device->host sync of the epoch
+        try:
+            if not isinstance(data_loader, DeviceFeed):
+                # this rank's shard of every batch, copied on a side stream two batches ahead (feed.py)
+                data_loader = DeviceFeed(data_loader, fields=self.feed_fields, device=dev)
+            for sample_id, batch in enumerate(data_loader):
+                batch_data = self.process_batch_data(batch)
+                self.zero_grad()
+                if train:
+                    loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=True)
+                    loss.backward()
+                    self.step()
+                else:
+                    with torch.no_grad():
+                        loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=False)
+                self._accumulate_stats(sums, loss, accuracy)
+        finally:
+            self.overlap_backward = prev_overlap
+            ops.side_defer(False)
+        dp.allreduce_sum_(sums)                      # every rank reports (and early-stops on) the global means
+        out = sums.tolist()                          # the one device->host sync of the epoch
+        n = max(out[2], 1.0)
         self.last_epoch_seconds = time.time() - t0
-        return out[0], out[1]
+        return out[0] / n, out[1] / n
+
+    @staticmethod
+    def _accumulate_stats(sums, loss, accuracy):
+        sums[0] += loss.detach().mean()
+        if accuracy is not None:
+            sums[1] += accuracy.detach()
+        sums[2] += 1.0
 
     def zero_grad(self):
         """utils/trainer.py:165-170.  With `overlap_backward` set (the epoch loop and bench.py set it) the step that
         starts here runs with deferred side-stream joins: the gradient arena is only complete after step() (or
         ops.side_join()), not right after loss.backward()."""
-        if self.overlap_backward:
-            ops.side_defer(True)
+        dp.reset_buckets(self.model.grad)            # nothing may survive from a step that never reached step()
+        ops.side_defer(bool(self.overlap_backward))
         self.model.zero_grad()
 
     def step(self):
@@ -153,6 +173,28 @@ class Trainer(ABC):
         self.adam_t += 1
         ops.adam_step(self.model.flat, self.model.grad, self.adam_m, self.adam_v, self.lr, self.adam_t,
                       self.betas[0], self.betas[1], self.eps, gscale)
+
+    # ---- optimizer / epoch resume (SURVEY 8f1 add-on: the reference saves weights only, utils/model.py:16-53) ----
+    def training_state(self, next_epoch=0):
+        return {"adam_m": self.adam_m.cpu(), "adam_v": self.adam_v.cpu(), "adam_t": self.adam_t, "lr": self.lr,
+                "betas": self.betas, "eps": self.eps, "next_epoch": int(next_epoch),
+                "num_parameters": int(self.model.flat.numel())}
+
+    def save_training_state(self, path, next_epoch=0):
+        torch.save(self.training_state(next_epoch), path)
+
+    def load_training_state(self, path_or_state):
+        """Restore the Adam moments, step count and the epoch to resume from (train_model starts there)."""
+        st = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, (str, bytes, os.PathLike)) \
+            else path_or_state
+        if int(st["num_parameters"]) != self.model.flat.numel():
+            raise RuntimeError("training state belongs to a model with a different parameter arena")
+        self.adam_m.copy_(st["adam_m"])
+        self.adam_v.copy_(st["adam_v"])
+        self.adam_t = int(st["adam_t"])
+        self.lr, self.betas, self.eps = float(st["lr"]), tuple(st["betas"]), float(st["eps"])
+        self.start_epoch = int(st["next_epoch"])
+        return self.start_epoch
 
     @abstractmethod
     def loss_and_acc_for_batch(self, batch, epoch_num=None, train=True):
@@ -222,30 +264,27 @@ class Trainer(ABC):
 
 
 class EarlyStopping:
-    """utils/trainer.py:379-413 (np.Inf replaced by float('inf'): removed in NumPy 2)"""
+    """Patience counter on the validation loss (behaviour of utils/trainer.py:379-413): an epoch counts as an
+    improvement only if the loss drops by at least `min_delta` below the best seen; `patience` epochs in a row without
+    one set `early_stop`.  Calling the object returns the flag."""
 
-    def __init__(self, patience=5, verbose=False):
+    def __init__(self, patience=5, verbose=False, min_delta=1e-5):
         self.patience = patience
         self.verbose = verbose
+        self.min_delta = min_delta
         self.counter = 0
         self.best_score = None
         self.early_stop = False
         self.val_loss_min = float("inf")
 
-    def __call__(self, val_loss, model):
-        score = -val_loss
-        if self.best_score is None:
-            self.best_score = score
-        elif score <= self.best_score:
-            self.counter += 1
-            if self.counter >= self.patience:
-                self.early_stop = True
-        else:
-            if score - self.best_score < 1e-5:
-                self.counter += 1
-                if self.counter >= self.patience:
-                    self.early_stop = True
-            else:
-                self.best_score = score
-                self.val_loss_min = val_loss
+    def __call__(self, val_loss, model=None):
+        score = -float(val_loss)
+        if self.best_score is None or score - self.best_score >= self.min_delta:
+            if self.best_score is not None:
                 self.counter = 0
+                self.val_loss_min = float(val_loss)
+            self.best_score = score
+        else:
+            self.counter += 1
+            self.early_stop = self.early_stop or self.counter >= self.patience
+        return self.early_stop

@@ -6,6 +6,8 @@ from .trainer import Trainer, _KLFn
 
 
 class VAETrainer(Trainer):
+    feed_fields = (0,)                     # the metadata tensor is never read (vae_trainer.py:42-55)
+
     def __init__(self, dataset, model, lr=1e-4):
         super().__init__(dataset, model, lr)
 
@@ -20,7 +22,7 @@ class VAETrainer(Trainer):
 
     def process_batch_data(self, batch):
         """(B,1,384) int32 -> (B*16, 24) int64 on the device   (vae_trainer.py:42-55)"""
-        score_tensor, _ = batch
+        score_tensor = batch[0]
         n_bars = getattr(self.dataset, "n_bars", None)
         if n_bars is not None and score_tensor.dim() == 3:
             batch_size = score_tensor.size(0)

@@ -392,9 +392,63 @@ def gen_split_helpers():
     print("wrote split_helpers.npz")
 
 
+def gen_feed_helpers():
+    """Batch preparation on the host side of the reference, with its own RNG consumption (SURVEY 8c fixture 7):
+    VAETrainer.process_batch_data (vae_trainer.py:42-55) for an N-bars dataset, LatentRNNTrainer.split_score_stochastic
+    under a fixed torch seed (latent_rnn_trainer.py:77-132), AnticipationRNN get_constraints_location (:93-128)."""
+    from DatasetManager.the_session.folk_dataset import FolkDatasetNBars
+
+    class FakeNBars(FolkDatasetNBars):                # isinstance(dataset, FolkDatasetNBars) switches the reshape on
+        def __init__(self, V):
+            self.__dict__.update(FakeDataset(V).__dict__)
+
+        def __repr__(self):
+            return "FakeNBars"
+
+    c = CFGS["small"]
+    V = c["V"]
+    score = torch.from_numpy(synthetic.folk_score(4, V, seed=11))
+    md = torch.from_numpy(synthetic.folk_metadata(4))
+    fx = {"score": score.numpy(), "metadata": md.numpy()}
+    vae = build_vae(c)
+    fx["vae_batch"] = VAETrainer(FakeNBars(V), vae).process_batch_data((score, md)).numpy()
+    model = LatentRNN(FakeDataset(V), vae, num_rnn_layers=2, rnn_hidden_size=c["H"], dropout=0.0,
+                      rnn_class=torch.nn.GRU, auto_reg=False, teacher_forcing=True)
+    lt = LatentRNNTrainer(FakeDataset(V), model)
+    torch.manual_seed(1234)
+    draws = []
+    for i in range(8):
+        past, future, target, n_past, n_target = lt.split_score_stochastic(score, extra_outs=True)
+        draws.append((n_past, n_target))
+        if i == 0:
+            fx["split0_past"], fx["split0_future"], fx["split0_target"] = past.numpy(), future.numpy(), target.numpy()
+    fx["split_seed"] = np.array(1234)
+    fx["split_draws"] = np.array(draws, dtype=np.int64)
+    p2, f2, t2, np2, nt2 = lt.split_score_stochastic(score, extra_outs=True, fix_num_target=3)
+    fx["split_fixed3"] = np.array([np2, nt2, p2.shape[1], f2.shape[1], t2.shape[1]], dtype=np.int64)
+    ca = ARNN_CFGS["small"]
+    dsa = FakeDataset(ca["V"])
+    arnn = ConstraintModelGaussianReg(dsa, note_embedding_dim=ca["E"], metadata_embedding_dim=ca["Em"],
+                                      num_lstm_constraints_units=ca["H"], num_lstm_generation_units=ca["H"],
+                                      linear_hidden_size=ca["LH"], num_layers=2, dropout_input_prob=0.0,
+                                      dropout_prob=0.0, unary_constraint=True, teacher_forcing=True)
+    at = AnticipationRNNGaussianRegTrainer(dsa, arnn)
+    torch.manual_seed(4321)
+    ticks = []
+    for i in range(8):
+        loc, start, end = at.get_constraints_location(score)
+        ticks.append((start, end))
+        if i == 0:
+            fx["constraints0"] = loc.numpy()
+    fx["constraints_seed"] = np.array(4321)
+    fx["constraints_ticks"] = np.array(ticks, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "feed_helpers.npz"), **fx)
+    print("wrote feed_helpers.npz (%d arrays)" % len(fx))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["vae", "latent", "arnn", "split"]
+    which = sys.argv[1:] or ["vae", "latent", "arnn", "split", "feed"]
     if "vae" in which:
         for n, c in CFGS.items():
             gen_vae(n, c)
@@ -411,3 +465,5 @@ if __name__ == "__main__":
             gen_arnn(n, c)
     if "split" in which:
         gen_split_helpers()
+    if "feed" in which:
+        gen_feed_helpers()

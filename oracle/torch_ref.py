@@ -141,10 +141,13 @@ def encoder_forward(P, tokens, masks=None, prefix="encoder", fast=False):
 
 
 def decoder_forward(P, z, target, teacher_forced, masks=None, prefix="decoder",
-                    beats=4, ticks_per_beat=6):
+                    beats=4, ticks_per_beat=6, feed_tokens=None):
     """z (B,Z), target (B,T) int64 (used iff teacher_forced) ->
     weights (B,T,V) post-ReLU logits, samples (B,1,T) int64.  decoder.py:412-529.
-    masks: {'beat': (B,beats,H) or None, 'tick': (B,T,H) or None}, pre-scaled."""
+    masks: {'beat': (B,beats,H) or None, 'tick': (B,T,H) or None}, pre-scaled.
+    feed_tokens (B,T): test hook for free-running parity at large batch -- the token fed back after tick t is
+    feed_tokens[:, t] (e.g. the samples of the implementation under test) while `samples` still reports this
+    function's own argmax, so that a near-tie flip in one row cannot de-synchronise the two trajectories."""
     B = z.shape[0]
     H = P[f"{prefix}.rnn_beat.weight_hh_l0"].shape[1]
     masks = masks or {}
@@ -180,18 +183,18 @@ def decoder_forward(P, z, target, teacher_forced, masks=None, prefix="decoder",
             w_t = torch.relu(h_l1 @ P[f"{prefix}.tick_emb_to_note_emb.0.weight"].t()
                              + P[f"{prefix}.tick_emb_to_note_emb.0.bias"])
             tok = target[:, t] if teacher_forced else argmax_first(w_t.detach())
-            prev = E[tok]
+            prev = E[tok if feed_tokens is None else feed_tokens[:, t]]
             weights.append(w_t)
             samples.append(tok)
     return torch.stack(weights, 1), torch.stack(samples, 1).unsqueeze(1)
 
 
-def vae_forward(P, tokens, eps, teacher_forced, masks=None):
+def vae_forward(P, tokens, eps, teacher_forced, masks=None, feed_tokens=None):
     """measure_vae.py:97-134 with eps injected.  Returns weights, samples, mu, logsigma, z."""
     masks = masks or {}
     mu, ls = encoder_forward(P, tokens, [masks.get("enc")] if masks.get("enc") is not None else None)
     z = mu + eps * torch.exp(ls)
-    w, s = decoder_forward(P, z, tokens, teacher_forced, masks)
+    w, s = decoder_forward(P, z, tokens, teacher_forced, masks, feed_tokens=feed_tokens)
     return w, s, mu, ls, z
 
 
@@ -242,23 +245,27 @@ def split_score(score, n_past, n_future, n_target, measure_len=24):
 
 
 def latent_get_z(P, measures, eps, enc_mask=None):
-    """get_z_seq, latent_rnn.py:161-174: z SAMPLES from the frozen encoder."""
+    """get_z_seq, latent_rnn.py:161-174: z SAMPLES from the frozen encoder.  enc_mask: (B*n, T, 2H) pre-scaled
+    layer-0 -> layer-1 dropout mask (LatentRNN.train() also puts the frozen VAE in training mode, SURVEY App. C iv)."""
     B, n, T = measures.shape
-    mu, ls = encoder_forward(P, measures.reshape(-1, T), enc_mask, prefix="vae_model.encoder")
+    mu, ls = encoder_forward(P, measures.reshape(-1, T), [enc_mask] if enc_mask is not None else None,
+                             prefix="vae_model.encoder")
     z = mu + eps * torch.exp(ls)
     return z.view(B, n, -1)
 
 
 def latent_forward(P, past, future, target, eps_p, eps_f, eps_t, auto_reg=False,
-                   teacher_forcing=False, eps_ar=None, masks=None):
+                   teacher_forcing=False, eps_ar=None, masks=None, feed_tokens=None):
     """latent_rnn.py:110-263.  Returns weights (B,nt,T,V), samples (B,1,nt*T), gen_z (B,nt,Z).
-    masks: {'ctx_past','ctx_future','gen': layer0->1 masks; 'dec': list of per-measure decoder masks}."""
+    masks: {'ctx_past','ctx_future','gen': layer0->1 masks; 'dec': list of per-measure decoder masks;
+    'enc_past','enc_future','enc_target': encoder masks of the three get_z_seq calls}.
+    feed_tokens (B,nt,T): see decoder_forward."""
     masks = masks or {}
     B, nt, T = target.shape
     with torch.no_grad():
-        zp = latent_get_z(P, past, eps_p)
-        zf = latent_get_z(P, future, eps_f)
-        zt = latent_get_z(P, target, eps_t)
+        zp = latent_get_z(P, past, eps_p, masks.get("enc_past"))
+        zf = latent_get_z(P, future, eps_f, masks.get("enc_future"))
+        zt = latent_get_z(P, target, eps_t, masks.get("enc_target"))
     H = P["context_rnn_past.weight_hh_l0"].shape[1]
     h0 = torch.zeros(4, B, H)
 
@@ -270,7 +277,8 @@ def latent_forward(P, past, future, target, eps_p, eps_f, eps_t, auto_reg=False,
     dec_masks = masks.get("dec") or [None] * nt
 
     def decode(zi, i):
-        return decoder_forward(P, zi, None, False, dec_masks[i], prefix="vae_model.decoder")
+        return decoder_forward(P, zi, None, False, dec_masks[i], prefix="vae_model.decoder",
+                               feed_tokens=None if feed_tokens is None else feed_tokens[:, i])
 
     Wg, bg = P["generation_linear.weight"], P["generation_linear.bias"]
     weights, samples = [], []

@@ -89,3 +89,91 @@ def test_single_process_defaults():
     g = torch.ones(8)
     assert dp.allreduce_grads(g) == 1.0 and torch.equal(g, torch.ones(8))
     assert dp.shard(10, 1, 4) == (2, 4)
+
+
+# ---- epoch loop under data parallelism: every rank must see the same statistics and stop on the same epoch ----------
+class _StubModel:
+    """Host-only stand-in: the epoch loop's control flow (feed sharding, statistic reduction, early stopping, save on
+    rank 0 only) is what is under test here, not the kernels."""
+
+    def __init__(self, out_dir):
+        self.flat = torch.zeros(8)
+        self.grad = torch.zeros(8)
+        self.filepath = os.path.join(out_dir, f"model_r{dp.rank()}")
+        self.saved = 0
+
+    def train(self, mode=True):
+        return self
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def save(self):
+        self.saved += 1
+
+    def save_checkpoint(self, epoch):
+        pass
+
+
+def _epoch_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    assert dp.init_from_env(backend="gloo") == world
+    from inpaintnet_amd.trainer import Trainer
+
+    class StubTrainer(Trainer):
+        feed_fields = (0,)
+
+        def __init__(self, dataset, model):
+            self.seen = []
+            super().__init__(dataset, model, early_stopping=True)
+            self.early_stopper.patience = 2
+
+        def process_batch_data(self, batch):
+            return batch[0]
+
+        def loss_and_acc_for_batch(self, batch, epoch_num=None, train=True):
+            self.seen.append(batch[:, 0, 0].clone())
+            # a loss that differs between ranks (it depends on the shard) and stops improving after epoch 1
+            base = 1.0 if epoch_num < 2 else 2.0
+            return (batch.float().mean() * 1e-3 + base - 0.1 * min(epoch_num, 1)).requires_grad_(train), torch.tensor(0.5)
+
+        def zero_grad(self):                 # (the real one also arms the HIP side stream)
+            self.model.zero_grad()
+
+        def step(self):
+            self.adam_t += 1
+
+        def update_scheduler(self, epoch_num):
+            return
+
+        def save_training_state(self, path, next_epoch=0):
+            pass
+
+    ds = synthetic.SyntheticFolkDataset(num_notes=12, n_seq=40)
+    model = _StubModel(out_dir)
+    tr = StubTrainer(ds, model)
+    tr.train_model(batch_size=8, num_epochs=10, seed=5)
+    seen = torch.stack(tr.seen).numpy()
+    np.savez(os.path.join(out_dir, f"e{rank}.npz"), seen=seen, saved=model.saved, steps=tr.adam_t,
+             counter=tr.early_stopper.counter, stop=tr.early_stopper.early_stop)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_epoch_loop_ranks_agree_on_statistics_and_early_stop(tmp_path):
+    port = 29300 + (os.getpid() % 2000)
+    mp.spawn(_epoch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "e0.npz"), np.load(tmp_path / "e1.npz")
+    # both ranks ran the same number of optimizer steps and stopped on the same epoch (no rank is left hanging in an
+    # all-reduce): epochs 0,1 improve, 2 and 3 do not -> stop after epoch 3 with patience 2
+    assert int(r0["steps"]) == int(r1["steps"]) == 4 * 3
+    assert bool(r0["stop"]) and bool(r1["stop"]) and int(r0["counter"]) == int(r1["counter"]) == 2
+    assert int(r0["saved"]) == 4 and int(r1["saved"]) == 0          # only rank 0 writes checkpoints
+    # each rank saw its own half of every global batch: same shuffle on both ranks, disjoint rows
+    assert r0["seen"].shape == r1["seen"].shape and r0["seen"].shape[1] == 4
+    assert not np.array_equal(r0["seen"], r1["seen"])
+    full_score, _ = synthetic.SyntheticFolkDataset(num_notes=12, n_seq=40).tensors()
+    first_tokens = set(full_score[:28, 0, 0].tolist())
+    assert set(r0["seen"][0].tolist()) <= first_tokens

@@ -99,3 +99,87 @@ def test_two_ranks_match_single_process_global_batch(tmp_path):
     # and the trajectories agree to the extent Adam allows
     single = _run_steps(model, trainer, tokens, eps_all, coins, 0, B)
     assert np.isfinite(r0["losses"]).all() and abs(single[0] - 0.5 * (r0["losses"][0] + r1["losses"][0])) < 1e-4 * abs(single[0])
+
+
+# ---- LatentRNNTrainer under data parallelism (BASELINE.json configs[3], per-rank shape scaled down) -------------------
+LB = 4                                      # global batch of sequences; 2 per rank
+
+
+def _build_latent():
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.latent_rnn import LatentRNN
+    from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    ds = synthetic.SyntheticFolkDataset(num_notes=CFG["V"])
+    vae = MeasureVAE(ds, note_embedding_dim=CFG["E"], encoder_hidden_size=CFG["H"], latent_space_dim=CFG["Z"],
+                     decoder_hidden_size=CFG["H"], encoder_dropout_prob=0.0, decoder_dropout_prob=0.0)
+    vae.load_state_dict({k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in vae.state_dict().items()})
+    model = LatentRNN(ds, vae, num_rnn_layers=2, rnn_hidden_size=CFG["H"], dropout=0.0, rnn_class=torch.nn.GRU,
+                      auto_reg=False, teacher_forcing=True)
+    for k, v in model.named_parameters():
+        v.copy_(torch.from_numpy(synthetic.det_param(k, tuple(v.shape))))
+    trainer = LatentRNNTrainer(ds, model, lr=1e-3)
+    trainer.overlap_backward = True
+    model.train()
+    return model, trainer
+
+
+def _latent_inputs():
+    from inpaintnet_amd import synthetic
+    score = torch.from_numpy(synthetic.folk_score(LB, CFG["V"], seed=17))
+    eps = [torch.from_numpy(synthetic.det_normal(f"dpgpu/leps{i}", (LB, n, CFG["Z"]))) for i, n in enumerate((6, 6, 4))]
+    return score, eps
+
+
+def _latent_first_grad(model, trainer, score, eps, lo, hi):
+    from inpaintnet_amd import dp, ops
+    from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
+    past, future, target = LatentRNNTrainer.split_score(score[lo:hi], 6, 6, 4, 24)
+    trainer.zero_grad()
+    w, s, gz = model(past, future, target, 4, train=True, eps=tuple(e[lo:hi].cuda() for e in eps))
+    loss, acc = trainer.mean_crossentropy_loss_and_accuracy(w, target)
+    loss.backward()
+    ops.side_join()
+    scale = dp.allreduce_grads(model.grad)
+    g = (model.grad * scale).cpu().numpy()
+    ops.side_defer(False)
+    return g, float(loss.detach())
+
+
+def _latent_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from inpaintnet_amd import dp
+    assert dp.init_from_env(backend="gloo") == world
+    torch.cuda.set_device(0)
+    model, trainer = _build_latent()
+    dp.broadcast_params(model.flat)
+    score, eps = _latent_inputs()
+    lo, hi = dp.shard(LB)
+    grad0, loss0 = _latent_first_grad(model, trainer, score, eps, lo, hi)
+    # two real optimizer steps through Trainer.step(): the generator bucket starts inside backward, the rest in step()
+    from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
+    past, future, target = LatentRNNTrainer.split_score(score[lo:hi], 6, 6, 4, 24)
+    for _ in range(2):
+        trainer.zero_grad()
+        w, s, gz = model(past, future, target, 4, train=True, eps=tuple(e[lo:hi].cuda() for e in eps))
+        loss, acc = trainer.mean_crossentropy_loss_and_accuracy(w, target)
+        loss.backward()
+        trainer.step()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"l{rank}.npz"), flat=model.flat.cpu().numpy(), grad0=grad0, loss0=loss0)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_latent_trainer_two_ranks_match_single_process_global_batch(tmp_path):
+    port = 29400 + (os.getpid() % 2000)
+    mp.spawn(_latent_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "l0.npz"), np.load(tmp_path / "l1.npz")
+    assert np.array_equal(r0["flat"], r1["flat"])                 # ranks stay bit-identical through two Adam steps
+    assert np.array_equal(r0["grad0"], r1["grad0"])
+    model, trainer = _build_latent()
+    score, eps = _latent_inputs()
+    ref, loss = _latent_first_grad(model, trainer, score, eps, 0, LB)
+    err = np.abs(ref - r0["grad0"]).max() / np.abs(ref).max()
+    assert err < 2e-5, err
+    assert abs(loss - 0.5 * (float(r0["loss0"]) + float(r1["loss0"]))) < 1e-5 * abs(loss)
