@@ -94,6 +94,14 @@ int inet_vae_decoder_bwd(const inet_vae_config* cfg, int batch, const float* dwe
                          const int64_t* tokens_in, const float* params, float* grads, const float* mask_beat,
                          const float* mask_tick, float* dz, void* ws, int64_t ws_bytes, void* stream);
 
+/* Test hook: float offset and element count of a named intermediate inside a workspace written with save=1.
+ * which 0 = encoder workspace: "a_mu", "a_ls" [B,2H] (SELU outputs of linear_mean.0 / linear_log_std.0, encoder.py:36-52);
+ * which 1 = decoder workspace: "hb0" [B,2H] (z_to_beat_rnn_input), "ht0" [beats,B,2H] (beat_emb_to_tick_rnn_hidden),
+ * "c_all" [beats,B,H] (beat_emb_to_tick_rnn_input), decoder.py:335-372.  Parity tests read the sign of these SELU outputs
+ * to align the derivative branch of near-zero pre-activations with the oracle's. */
+int inet_vae_ws_field(const inet_vae_config* cfg, int batch, int which, const char* name, int64_t* offset_floats,
+                      int64_t* count);
+
 /* ---- losses: VAETrainer.loss_and_acc_for_batch, vae_trainer.py:16-40,128-139; utils/trainer.py:271-306 */
 /* rows of V logits (row stride ld_w); out3[0] += sum_rows (lse - w[target]); out3[1] += #correct (argmax_first);
  * dW (nullable, row stride ld_dw) = (softmax - onehot) * scale */

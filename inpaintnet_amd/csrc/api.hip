@@ -130,6 +130,15 @@ int inet_vae_decoder_bwd(const inet_vae_config* cfg, int batch, const float* dwe
                            mask_tick, dz, ws, (hipStream_t)stream);
 }
 
+int inet_vae_ws_field(const inet_vae_config* cfg, int batch, int which, const char* name, int64_t* offset_floats,
+                      int64_t* count) {
+    if (!cfg_ok(cfg) || batch <= 0 || !name) return -1;
+    long long off = 0, n = 0;
+    const int rc = vae_ws_field(*cfg, batch, which, name, &off, &n);
+    if (rc == 0) { if (offset_floats) *offset_floats = off; if (count) *count = n; }
+    return rc;
+}
+
 int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
                        int64_t ld_dw, float scale, float* loss_sum, float* correct, void* stream) {
     if (!weights || !targets || !loss_sum || !correct || rows <= 0 || V <= 0) return -1;

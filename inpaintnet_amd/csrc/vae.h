@@ -14,3 +14,4 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
 int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, const float* weights,
                     const long long* tokens_in, const float* p, float* g, const float* mask_beat,
                     const float* mask_tick, float* dz, void* ws, hipStream_t s);
+int vae_ws_field(const inet_vae_config& c, int B, int which, const char* name, long long* offset_floats, long long* count);

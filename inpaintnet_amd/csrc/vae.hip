@@ -17,6 +17,7 @@
 #include "layout.h"
 #include "vae.h"
 #include <cstdlib>
+#include <string>
 
 namespace {
 
@@ -545,4 +546,33 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         INET_TRY(pw_colsum(w.dhb0, 2L * H, B, 2 * H, g + L.zb_b, ss));
     }
     return side_join(s);
+}
+
+// Test hook (inet_vae_ws_field): where the SELU outputs of the Linear+SELU heads live inside a workspace, so that a
+// parity test can read the branch every element took (SELU's derivative jumps at 0: two fp32 implementations that
+// differ by 1e-7 in a pre-activation next to 0 otherwise disagree by O(1) in that element's derivative).
+int vae_ws_field(const inet_vae_config& c, int B, int which, const char* name, long long* offset_floats, long long* count) {
+    char* const base = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 30);
+    const long long nb = c.beats;
+    const float* p = nullptr;
+    long long n = 0;
+    const std::string f(name ? name : "");
+    if (which == 0) {
+        EncWs w;
+        enc_carve(c, B, 1, base, w);
+        const long long H = c.enc_hidden;
+        if (f == "a_mu") { p = w.a_mu; n = (long long)B * 2 * H; }
+        else if (f == "a_ls") { p = w.a_ls; n = (long long)B * 2 * H; }
+    } else if (which == 1) {
+        DecWs w{};
+        dec_carve(c, B, 1, base, w);
+        const long long H = c.dec_hidden;
+        if (f == "hb0") { p = w.hb0; n = (long long)B * 2 * H; }                 // [B, 2H]
+        else if (f == "ht0") { p = w.ht0; n = nb * B * 2 * H; }                  // [beats, B, 2H]
+        else if (f == "c_all") { p = w.c_all; n = nb * B * H; }                  // [beats, B, H]
+    }
+    if (!p) return -1;
+    if (offset_floats) *offset_floats = (reinterpret_cast<const char*>(p) - base) / (long long)sizeof(float);
+    if (count) *count = n;
+    return 0;
 }

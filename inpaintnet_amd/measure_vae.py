@@ -59,6 +59,8 @@ class _DecoderFn(torch.autograd.Function):
         weights, samples, ws = ops.decoder_fwd(dec.cfg, z.contiguous(), target, teacher_forced, flat, mask_beat,
                                                mask_tick, save=need)
         ctx.dec, ctx.ws, ctx.mb, ctx.mt = dec, ws, mask_beat, mask_tick
+        if getattr(dec, "keep_ws", False):         # test hook: lets a parity test read intermediates (ops.ws_field)
+            dec.last_ws = ws
         ctx.save_for_backward(weights, samples)
         ctx.mark_non_differentiable(samples)
         return weights, samples

@@ -376,3 +376,11 @@ def split_score(score, n_past, n_target, measure_len):
     check(_lib.lib().inet_split_score(ptr(score), B, M, measure_len, n_past, n_target, ptr(past), ptr(target),
                                       ptr(future), stream_ptr()), "inet_split_score")
     return past, future, target
+
+
+def ws_field(cfg, ws, B, which, name):
+    """Test hook: view of a named intermediate (flat) inside an encoder (which=0) / decoder (which=1) workspace."""
+    off, n = C.c_int64(), C.c_int64()
+    check(_lib.lib().inet_vae_ws_field(C.byref(cfg), B, int(which), name.encode(), C.byref(off), C.byref(n)),
+          "inet_vae_ws_field")
+    return ws[off.value:off.value + n.value]

@@ -47,6 +47,24 @@ def selu(x):
     return SELU_SCALE * torch.where(x > 0, x, SELU_ALPHA * (torch.exp(x) - 1.0))
 
 
+# Kink alignment (test hook).  SELU's derivative jumps at 0 (1.0507 -> 1.7581) and ReLU's from 0 to 1: two fp32
+# implementations whose pre-activations differ by 1e-7 disagree by O(1) in the derivative of an element that sits
+# within that distance of 0, and a batch of 256 measures has ~2.7 M such elements, so a handful always do.  The
+# functions below take an optional boolean `pos` = the branch the implementation under test took (its output > 0) and
+# follow it; with pos=None they are the plain functions.  Forward values change by O(|x|) <= 1e-6 at the affected
+# elements only; what is gained is that gradients can then be compared at 1e-5 instead of "5e-4 with luck".
+def selu_k(x, pos=None):
+    if pos is None:
+        return selu(x)
+    return SELU_SCALE * torch.where(pos, x, SELU_ALPHA * (torch.exp(x) - 1.0))
+
+
+def relu_k(x, pos=None):
+    if pos is None:
+        return torch.relu(x)
+    return torch.where(pos, x, torch.zeros_like(x))
+
+
 def argmax_first(w):
     """Lowest index among maxima, last dim."""
     m = w.max(dim=-1, keepdim=True).values
@@ -122,8 +140,10 @@ def gru_stack_fast(x, h0, P, prefix, num_layers, bidirectional):
 # ----------------------------------------------------------------------------
 # MeasureVAE
 # ----------------------------------------------------------------------------
-def encoder_forward(P, tokens, masks=None, prefix="encoder", fast=False):
-    """tokens (B,T) int64 -> (mu, logsigma) each (B,Z).  encoder.py:104-134."""
+def encoder_forward(P, tokens, masks=None, prefix="encoder", fast=False, kinks=None):
+    """tokens (B,T) int64 -> (mu, logsigma) each (B,Z).  encoder.py:104-134.
+    kinks: optional {'a_mu','a_ls': (B,2H) bool} branch of the two heads' SELUs (see selu_k)."""
+    kinks = kinks or {}
     B = tokens.shape[0]
     emb = P[f"{prefix}.note_embedding_layer.weight"][tokens]
     H = P[f"{prefix}.lstm.weight_hh_l0"].shape[1]
@@ -134,25 +154,33 @@ def encoder_forward(P, tokens, masks=None, prefix="encoder", fast=False):
         _, hn = gru_stack(emb, h0, P, f"{prefix}.lstm", 2, True, masks)
     hcat = hn.transpose(0, 1).contiguous().view(B, -1)
 
-    def head(name):
-        a = selu(hcat @ P[f"{prefix}.{name}.0.weight"].t() + P[f"{prefix}.{name}.0.bias"])
+    def head(name, kink):
+        a = selu_k(hcat @ P[f"{prefix}.{name}.0.weight"].t() + P[f"{prefix}.{name}.0.bias"], kinks.get(kink))
         return a @ P[f"{prefix}.{name}.2.weight"].t() + P[f"{prefix}.{name}.2.bias"]
-    return head("linear_mean"), head("linear_log_std")
+    return head("linear_mean", "a_mu"), head("linear_log_std", "a_ls")
 
 
 def decoder_forward(P, z, target, teacher_forced, masks=None, prefix="decoder",
-                    beats=4, ticks_per_beat=6, feed_tokens=None):
+                    beats=4, ticks_per_beat=6, feed_tokens=None, kinks=None):
     """z (B,Z), target (B,T) int64 (used iff teacher_forced) ->
     weights (B,T,V) post-ReLU logits, samples (B,1,T) int64.  decoder.py:412-529.
     masks: {'beat': (B,beats,H) or None, 'tick': (B,T,H) or None}, pre-scaled.
     feed_tokens (B,T): test hook for free-running parity at large batch -- the token fed back after tick t is
     feed_tokens[:, t] (e.g. the samples of the implementation under test) while `samples` still reports this
-    function's own argmax, so that a near-tie flip in one row cannot de-synchronise the two trajectories."""
+    function's own argmax, so that a near-tie flip in one row cannot de-synchronise the two trajectories.
+    kinks: optional {'hb0': (B,2H), 'ht0': (beats,B,2H), 'c_all': (beats,B,H), 'relu': (B,T,V)} bool branches of the
+    three SELU heads and of the output ReLU (see selu_k)."""
     B = z.shape[0]
     H = P[f"{prefix}.rnn_beat.weight_hh_l0"].shape[1]
     masks = masks or {}
+    kinks = kinks or {}
+
+    def kink(name, *idx):
+        k = kinks.get(name)
+        return None if k is None else k[idx]
     # beat rnn (forward_beat_rnn, decoder.py:455-471)
-    hb0 = selu(z @ P[f"{prefix}.z_to_beat_rnn_input.0.weight"].t() + P[f"{prefix}.z_to_beat_rnn_input.0.bias"])
+    hb0 = selu_k(z @ P[f"{prefix}.z_to_beat_rnn_input.0.weight"].t() + P[f"{prefix}.z_to_beat_rnn_input.0.bias"],
+                 kinks.get("hb0"))
     h_beat = hb0.view(B, 2, H).transpose(0, 1).contiguous()
     beat_in = P[f"{prefix}.b_0"].view(1, 1, 1).expand(B, beats, 1)
     bm = masks.get("beat")
@@ -166,12 +194,12 @@ def decoder_forward(P, z, target, teacher_forced, masks=None, prefix="decoder",
     weights, samples = [], []
     for i in range(beats):
         o_i = beat_out[:, i]
-        ht0 = selu(o_i @ P[f"{prefix}.beat_emb_to_tick_rnn_hidden.0.weight"].t()
-                   + P[f"{prefix}.beat_emb_to_tick_rnn_hidden.0.bias"])
+        ht0 = selu_k(o_i @ P[f"{prefix}.beat_emb_to_tick_rnn_hidden.0.weight"].t()
+                     + P[f"{prefix}.beat_emb_to_tick_rnn_hidden.0.bias"], kink("ht0", i))
         hid = ht0.view(B, 2, H).transpose(0, 1)
         h_l0, h_l1 = hid[0], hid[1]
-        c_i = selu(o_i @ P[f"{prefix}.beat_emb_to_tick_rnn_input.0.weight"].t()
-                   + P[f"{prefix}.beat_emb_to_tick_rnn_input.0.bias"])
+        c_i = selu_k(o_i @ P[f"{prefix}.beat_emb_to_tick_rnn_input.0.weight"].t()
+                     + P[f"{prefix}.beat_emb_to_tick_rnn_input.0.bias"], kink("c_all", i))
         for j in range(ticks_per_beat):
             t = i * ticks_per_beat + j
             u = torch.cat((prev, c_i), 1)
@@ -180,8 +208,8 @@ def decoder_forward(P, z, target, teacher_forced, masks=None, prefix="decoder",
             x1 = h_l0 if tm is None else h_l0 * tm[:, t]
             gi1 = x1 @ P[f"{pf}.weight_ih_l1"].t() + P[f"{pf}.bias_ih_l1"]
             h_l1 = gru_cell(gi1, h_l1, P[f"{pf}.weight_hh_l1"], P[f"{pf}.bias_hh_l1"])
-            w_t = torch.relu(h_l1 @ P[f"{prefix}.tick_emb_to_note_emb.0.weight"].t()
-                             + P[f"{prefix}.tick_emb_to_note_emb.0.bias"])
+            w_t = relu_k(h_l1 @ P[f"{prefix}.tick_emb_to_note_emb.0.weight"].t()
+                         + P[f"{prefix}.tick_emb_to_note_emb.0.bias"], kink("relu", slice(None), t))
             tok = target[:, t] if teacher_forced else argmax_first(w_t.detach())
             prev = E[tok if feed_tokens is None else feed_tokens[:, t]]
             weights.append(w_t)
@@ -189,12 +217,12 @@ def decoder_forward(P, z, target, teacher_forced, masks=None, prefix="decoder",
     return torch.stack(weights, 1), torch.stack(samples, 1).unsqueeze(1)
 
 
-def vae_forward(P, tokens, eps, teacher_forced, masks=None, feed_tokens=None):
+def vae_forward(P, tokens, eps, teacher_forced, masks=None, feed_tokens=None, kinks=None):
     """measure_vae.py:97-134 with eps injected.  Returns weights, samples, mu, logsigma, z."""
     masks = masks or {}
-    mu, ls = encoder_forward(P, tokens, [masks.get("enc")] if masks.get("enc") is not None else None)
+    mu, ls = encoder_forward(P, tokens, [masks.get("enc")] if masks.get("enc") is not None else None, kinks=kinks)
     z = mu + eps * torch.exp(ls)
-    w, s = decoder_forward(P, z, tokens, teacher_forced, masks, feed_tokens=feed_tokens)
+    w, s = decoder_forward(P, z, tokens, teacher_forced, masks, feed_tokens=feed_tokens, kinks=kinks)
     return w, s, mu, ls, z
 
 
@@ -255,11 +283,11 @@ def latent_get_z(P, measures, eps, enc_mask=None):
 
 
 def latent_forward(P, past, future, target, eps_p, eps_f, eps_t, auto_reg=False,
-                   teacher_forcing=False, eps_ar=None, masks=None, feed_tokens=None):
+                   teacher_forcing=False, eps_ar=None, masks=None, feed_tokens=None, dec_kinks=None):
     """latent_rnn.py:110-263.  Returns weights (B,nt,T,V), samples (B,1,nt*T), gen_z (B,nt,Z).
     masks: {'ctx_past','ctx_future','gen': layer0->1 masks; 'dec': list of per-measure decoder masks;
     'enc_past','enc_future','enc_target': encoder masks of the three get_z_seq calls}.
-    feed_tokens (B,nt,T): see decoder_forward."""
+    feed_tokens (B,nt,T): see decoder_forward.  dec_kinks: list (one per generated measure) of decoder_forward `kinks`."""
     masks = masks or {}
     B, nt, T = target.shape
     with torch.no_grad():
@@ -278,7 +306,8 @@ def latent_forward(P, past, future, target, eps_p, eps_f, eps_t, auto_reg=False,
 
     def decode(zi, i):
         return decoder_forward(P, zi, None, False, dec_masks[i], prefix="vae_model.decoder",
-                               feed_tokens=None if feed_tokens is None else feed_tokens[:, i])
+                               feed_tokens=None if feed_tokens is None else feed_tokens[:, i],
+                               kinks=None if dec_kinks is None else dec_kinks[i])
 
     Wg, bg = P["generation_linear.weight"], P["generation_linear.bias"]
     weights, samples = [], []

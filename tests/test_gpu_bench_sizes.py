@@ -3,11 +3,18 @@ spends its time in -- gru_step_fwd_kernel<*,4,true>, gru_step_bwd_kernel<4,1,tru
 tiles -- are only selected at B >= 256 (H=512) / big M,K, so they get their own oracle comparisons here:
 
   (i)   one MeasureVAE training step at B=256, H=512, V=48 with mask-in dropout, teacher-forced and free-running,
-        against oracle/torch_ref.py (loss 1e-4 rel, weights 1e-4, every gradient tensor 5e-4 of its max);
+        against oracle/torch_ref.py (loss 1e-4 rel, logits 2e-5, every gradient tensor 1e-4 of its max);
   (ii)  LatentRNN non-auto-regressive step at 128 sequences x 6/4/6 measures (encoder batch 2048, generator H=1024,
         decoder batch 512) with dropout on, masks recorded from the product's own stream and replayed in the oracle;
   (iii) every GEMM tile configuration x split-K forced over the big shapes of the step;
   (iv)  the per-launch profile labels prove that the MS=4 / NC=2 / 192-tile instantiations really ran in (i).
+
+Kink alignment: SELU's derivative jumps at 0 and ReLU's from 0 to 1, and a batch this size always has a few of its
+~2.7 M pre-activations within fp32 noise of 0, where two correct implementations pick different branches and then
+disagree by up to 1e-2 of a small gradient tensor's max (measured: tools/parity_diag.py, profiles/r02_parity_diag.txt).
+The tests therefore read the branch each element took on the GPU (logits > 0; SELU outputs through the
+inet_vae_ws_field test hook) and make the oracle follow it (oracle `kinks`), which changes its forward values by
+<= 1e-6 at those elements and nothing else; the gradient comparison is then asserted at 1e-4, not 5e-4.
 
 Free-running decodes feed the oracle the product's sampled tokens (oracle `feed_tokens`), so a near-tie argmax in one
 of the 6144 rows cannot de-synchronise the two trajectories; the oracle's own argmax is then compared with the
@@ -26,7 +33,7 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     from inpaintnet_amd import ops
-    from tests.test_gpu_kernels import _vae_step_hip, pack, relmax, unpack
+    from tests.test_gpu_kernels import pack, relmax, unpack
 
 DEV = "cuda:0"
 
@@ -59,7 +66,7 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     masks = {"enc": m_enc, "beat": m_beat, "tick": m_tick}
     grads = torch.zeros_like(params)
     ops.prof_enable(True)
-    hl, hce, hkl, hacc, hw, hs, hz = _vae_step_hip(cfg, table, params, grads, tok.to(DEV), eps.to(DEV), tf, masks)
+    hl, hce, hkl, hacc, hw, hs, hz, kinks = _vae_step_with_kinks(cfg, params, grads, tok.to(DEV), eps.to(DEV), tf, masks)
     torch.cuda.synchronize()
     ops.prof_dump(tmp_path / "launches.csv")
     ops.prof_enable(False)
@@ -78,11 +85,11 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     for p in P.values():
         p.requires_grad_(True)
     feed = None if tf else hs.cpu()[:, 0]
-    w, s, mu, ls, z = O.vae_forward(P, tok, eps, tf, om, feed_tokens=feed)
+    w, s, mu, ls, z = O.vae_forward(P, tok, eps, tf, om, feed_tokens=feed, kinks=kinks)
     loss, ce, kl, acc = O.vae_loss(w, tok, mu, ls)
     loss.backward()
-    assert relmax(hz, z) < 1e-4
-    assert relmax(hw, w) < 1e-4
+    assert relmax(hz, z) < 2e-5
+    assert relmax(hw, w) < 2e-5
     ok = _margin(w.detach()) > 1e-4
     assert ok.mean() > 0.4                      # (post-ReLU logits: rows whose top-2 are both 0 have margin 0)
     assert np.array_equal(hs.cpu().numpy()[:, 0][ok], s.numpy()[:, 0][ok])
@@ -90,13 +97,40 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     assert abs(hce - ce.item()) <= 1e-4 * abs(ce.item())
     assert abs(hkl - kl.item()) <= 1e-4 * abs(kl.item())
     assert abs(hacc - acc.item()) <= 2.0 / (B * T)          # a near-tie row may count differently
-    bad = []
+    errs = {}
     for pname, off, shape in table:
         gg = unpack(table, grads, pname).cpu()
-        err = float((gg - P[pname].grad).abs().max() / (P[pname].grad.abs().max() + 1e-12))
-        if not err < 5e-4:
-            bad.append((pname, err))
-    assert not bad, bad
+        errs[pname] = float((gg - P[pname].grad).abs().max() / (P[pname].grad.abs().max() + 1e-12))
+    worst = max(errs, key=errs.get)
+    print(f"worst gradient tensor {worst}: {errs[worst]:.2e} of its max")
+    # with the SELU / ReLU branches aligned (module docstring) every gradient tensor agrees far inside the 5e-4 bar
+    assert errs[worst] < 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+def _vae_step_with_kinks(cfg, params, grads, tok, eps, teacher_forced, masks):
+    """tests.test_gpu_kernels._vae_step_hip plus the branch every SELU / ReLU element took (read from the workspaces
+    through the inet_vae_ws_field test hook and from the logits)."""
+    B, T = tok.shape
+    V, nb = cfg.num_notes, cfg.beats
+    He, Hd = cfg.enc_hidden, cfg.dec_hidden
+    mu, ls, ews = ops.encoder_fwd(cfg, tok, params, mask=masks.get("enc"), save=True)
+    acc3 = torch.zeros(3, device=DEV)
+    z, _ = ops.reparam_kl(mu, ls, eps, kl_sum=acc3[2:3])
+    w, s, dws = ops.decoder_fwd(cfg, z, tok, teacher_forced, params, masks.get("beat"), masks.get("tick"), save=True)
+    kinks = {"a_mu": ops.ws_field(cfg, ews, B, 0, "a_mu").view(B, 2 * He).cpu() > 0,
+             "a_ls": ops.ws_field(cfg, ews, B, 0, "a_ls").view(B, 2 * He).cpu() > 0,
+             "hb0": ops.ws_field(cfg, dws, B, 1, "hb0").view(B, 2 * Hd).cpu() > 0,
+             "ht0": ops.ws_field(cfg, dws, B, 1, "ht0").view(nb, B, 2 * Hd).cpu() > 0,
+             "c_all": ops.ws_field(cfg, dws, B, 1, "c_all").view(nb, B, Hd).cpu() > 0,
+             "relu": w.cpu() > 0}
+    dW = torch.empty_like(w)
+    ops.cross_entropy(w.view(B * T, V), tok.reshape(-1), acc3, dW=dW.view(B * T, V), scale=1.0 / (B * T))
+    dz = ops.decoder_bwd(cfg, dW, w, s, params, grads, masks.get("beat"), masks.get("tick"), dws)
+    dmu, dls = ops.latent_bwd(dz, mu, ls, eps, 1e-3 / B)
+    ops.encoder_bwd(cfg, tok, params, grads, masks.get("enc"), dmu, dls, ews)
+    a = acc3.cpu().double()
+    ce, kl = a[0] / (B * T), 1e-3 * a[2] / B
+    return float(ce + kl), float(ce), float(kl), float(a[1] / (B * T)), w, s, z, kinks
 
 
 def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
@@ -132,9 +166,18 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
         return m
     monkeypatch.setattr(ops, "dropout_mask", recording_mask)
 
+    vae.decoder.keep_ws = True
     trainer.zero_grad()
     ops.prof_enable(True)
     w, s, gz = model(past, future, target, n_target, train=True, eps=tuple(e.cuda() for e in eps))
+    # branch of every SELU / ReLU element of the (frozen) decoder, rows ordered (sequence, measure)
+    dws, R = vae.decoder.last_ws, B * n_target
+    k_hb0 = (ops.ws_field(vae.cfg, dws, R, 1, "hb0").view(B, n_target, 2 * H).cpu() > 0)
+    k_ht0 = (ops.ws_field(vae.cfg, dws, R, 1, "ht0").view(4, B, n_target, 2 * H).cpu() > 0)
+    k_c = (ops.ws_field(vae.cfg, dws, R, 1, "c_all").view(4, B, n_target, H).cpu() > 0)
+    k_relu = w.detach().cpu() > 0
+    dec_kinks = [{"hb0": k_hb0[:, i], "ht0": k_ht0[:, :, i], "c_all": k_c[:, :, i], "relu": k_relu[:, i]}
+                 for i in range(n_target)]
     loss, acc = trainer.mean_crossentropy_loss_and_accuracy(w, target)
     loss.backward()
     ops.side_join()
@@ -170,23 +213,20 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
     hs = s.cpu().view(B, n_target, 24)
     wo, so, gzo = O.latent_forward(P, past.cpu(), future.cpu(), target.cpu(), eps[0].reshape(-1, Z), eps[1].reshape(-1, Z),
                                    eps[2].reshape(-1, Z), auto_reg=False,
-                                   masks=masks, feed_tokens=hs)
+                                   masks=masks, feed_tokens=hs, dec_kinks=dec_kinks)
     lo, ao = O.latent_loss(wo, target.cpu())
     lo.backward()
-    assert G.rel_err(gz.detach().cpu(), gzo.detach()) < 2e-4
-    assert G.rel_err(w.detach().cpu(), wo.detach()) < 2e-4
+    assert G.rel_err(gz.detach().cpu(), gzo.detach()) < 5e-5
+    assert G.rel_err(w.detach().cpu(), wo.detach()) < 5e-5
     ok = _margin(wo.detach()).reshape(B, -1) > 1e-4
     assert ok.mean() > 0.4
     assert np.array_equal(s.cpu().numpy()[:, 0][ok], so.numpy()[:, 0][ok])
     assert abs(float(loss.detach()) - lo.item()) <= 1e-4 * abs(lo.item())
     assert abs(float(acc) - ao.item()) <= 2.0 / (B * n_target * 24)
-    bad = []
-    for k in own:
-        gg = model.param_grad(k).cpu()
-        err = float((gg - P[k].grad).abs().max() / (P[k].grad.abs().max() + 1e-12))
-        if not err < 5e-4:
-            bad.append((k, err))
-    assert not bad, bad
+    errs = {k: float((model.param_grad(k).cpu() - P[k].grad).abs().max() / (P[k].grad.abs().max() + 1e-12)) for k in own}
+    worst = max(errs, key=errs.get)
+    print(f"worst gradient tensor {worst}: {errs[worst]:.2e} of its max")
+    assert errs[worst] < 2e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     assert float(vae.grad.abs().max()) == 0.0
 
 
