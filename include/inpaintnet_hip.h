@@ -204,7 +204,13 @@ int inet_set_option(int key, int value);
  * it returns.  With 1 it does not: the caller must keep every workspace passed to a *_bwd call alive and call
  * inet_side_join(stream) before anything reads the gradient arena (optimizer step, all-reduce) or frees those
  * workspaces.  Lets the leaf GEMMs of one module's backward overlap the next module's BPTT chain. */
+/* key 4 = chain kernels (default 1; INET_CHAIN=0): one persistent launch per recurrent layer, weights resident in
+ * registers, the hidden state exchanged between workgroups once per step (csrc/chain.h).  0 = one launch per step. */
 int inet_side_join(void* stream);
+/* Number of chain-kernel workgroups that gave up waiting for their group since the last reset (0 = healthy; every
+ * in-kernel spin is bounded, so a broken hand-off shows up here instead of hanging the GPU).  Meaningful after the
+ * stream has been synchronised.  -2: the host-mapped counter could not be allocated. */
+int inet_chain_status(int reset);
 
 /* ---- measurement hooks (bench.py roofline line; not part of the reference surface) --------------- */
 /* class 0 = batched MFMA GEMM, 1 = fused GRU/LSTM step forward, 2 = fused GRU/LSTM step backward, 3 = HBM-bound

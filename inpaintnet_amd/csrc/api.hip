@@ -4,6 +4,7 @@
 #include "layout.h"
 #include "vae.h"
 #include "lstm.h"
+#include "chain.h"
 
 namespace {
 
@@ -314,9 +315,18 @@ int inet_split_score(const int32_t* score, int batch, int n_measures, int measur
 int inet_set_option(int key, int value) {
     if (key == 0) { side_set_enabled(value); return 0; }
     if (key == 1) { side_set_defer(value); return 0; }
+    if (key == 4) { chain_set_enabled(value); return 0; }
     if (key == 2) { if (value < -1 || value > 4) return -1; gemm_set_force(value, -1); return 0; }
     if (key == 3) { if (value < 0) return -1; gemm_set_force(-2, value); return 0; }
     return -1;
+}
+
+int inet_chain_status(int reset) {
+    unsigned* p = chain_host_status();
+    if (!p) return -2;
+    const int v = (int)__atomic_load_n(p, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(p, 0u, __ATOMIC_RELAXED);
+    return v;
 }
 
 int inet_side_join(void* stream) { return side_join_now((hipStream_t)stream); }

@@ -1,0 +1,138 @@
+// "Chain kernels": one persistent launch runs ALL time steps of a recurrent layer.
+//
+// Why (measured, profiles/r02_c_*): a per-step launch starts with a cold L2 (kernel boundaries write back AND invalidate
+// the per-XCD L2s), so every step re-fetches its W_hh slice through the fabric -- rocprofv3 counts 37 MB of memory-side
+// reads per two-direction GRU step against 15 MB of algorithmic bytes, 2.4 TB/s for 15 us -- and pays ~2 us of dispatch
+// on top.  The weights never change during a sequence: in a chain kernel every workgroup loads its W slice ONCE into
+// registers (16 hidden units x gates x K/4 per wave = 64-96 VGPRs) and only the hidden state moves per step.
+//
+// Geometry: a GROUP = the workgroups that share one row tile (16*MS batch rows) of one problem (direction): H/16
+// members, one per 16 hidden units.  Each step every member needs the group's whole previous hidden state, so the
+// group synchronises once per step on a monotonic counter.  Groups are independent (no grid barrier).
+//
+// Hand-off protocol (MI355X_MICROARCH.md "inter-workgroup visibility", cdna_hip_programming.md Guideline 16, form R1;
+// measured in tools/exp_chain.hip V1: 4.2 us per step same-XCD incl. moving 128 KB, 0 stale reads):
+//   producer: 16-byte `sc1` (write-through) stores of its [16 rows x 16 k] fragment blocks -> EVERY wave drains
+//             (s_waitcnt vmcnt(0)) -> __syncthreads -> ONE lane adds 1 to the group counter (relaxed, agent scope);
+//   consumer: ONE lane polls the counter (relaxed agent-scope load + s_sleep, bounded) -> __syncthreads -> every wave
+//             reads the fragments with 16-byte `sc1` loads (served by L2, never by this CU's L1).
+// This is correct under ANY workgroup->XCD placement.  For speed only, block b is given group b % 8 so that, with the
+// observed round-robin dispatch, all members of a group share one XCD and the exchange stays inside its L2
+// (cross-XCD the same protocol measures 11 us per step).
+// Every spin is bounded: on timeout the workgroup raises the status word and leaves; the host side reports it.
+// The exchange buffers are fragment-major (ksplit.h pk_offset): a member's 16 hidden units of one 16-row block ARE one
+// contiguous 1 KB block = one 16-byte store per lane of one wave, and a consumer wave's MFMA A-fragment is one 16-byte
+// load per lane.
+#pragma once
+#include "common.h"
+
+namespace chain {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kSpinLimit = 400000;          // polls (~1 us each with s_sleep): ~0.4 s before giving up
+enum { ST_OK = 0, ST_TIMEOUT = 1 };
+
+// buffer resource over a (wave-uniform) base pointer; 2 GB window, raw addressing
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+// 16-byte load / store with sc1: L1-bypassing, write-through -- the agent-coherent forms.  The compiler tracks these in
+// vmcnt like any other buffer access, so they pipeline normally.
+__device__ __forceinline__ f32x4 ld16_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
+}
+
+// Producer side, called by ALL threads after their sc1 stores of the step.
+__device__ __forceinline__ void arrive(unsigned* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Consumer side, called by ALL threads: returns false (for every thread) if the group did not arrive in time.
+// `flag` is one word of LDS.
+// `status` = {device word inside the workspace (aborts the other workgroups of the launch quickly), host-mapped word
+// (chain_host_status(): what inet_chain_status() reports)}.
+struct Status { unsigned* dev; unsigned* host; };
+__device__ __forceinline__ bool wait_group(unsigned* counter, unsigned target, Status status, unsigned* flag) {
+    if (threadIdx.x == 0) {
+        unsigned ok = 1, spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > kSpinLimit || __hip_atomic_load(status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ST_OK) {
+                __hip_atomic_store(status.dev, (unsigned)ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (status.host) __hip_atomic_fetch_add(status.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    __syncthreads();                                            // flag may be rewritten by the next wait
+    return ok;
+}
+
+// block -> (group, member): group = (b % 8) + 8 * (b / (8 * members)), member = (b / 8) % members.  Launch
+// 8 * members * ceil(groups / 8) blocks; blocks whose group >= groups leave at once.
+__host__ __device__ inline int blocks_for(int groups, int members) { return 8 * members * ((groups + 7) / 8); }
+__device__ __forceinline__ void decode_block(int b, int members, int& group, int& member) {
+    group = (b & 7) + 8 * (b / (8 * members));
+    member = (b >> 3) % members;
+}
+
+// acc[ms][slot g] += A[16*MS rows of the group's state, this wave's K quarter] x Wr[g]^T, where the A fragments are
+// read from the exchange buffer `r` (fragment-major, S k-steps per 16-row block) at byte offset `base` with sc1 loads
+// and the B fragments Wr[g][si] (k-step s0 + si) already sit in registers.  Loads run one chunk of 4 k-steps ahead of
+// the MFMAs (double buffer, fully unrolled: all indices are compile-time).
+template <int MS, int NG, int SQ>
+__device__ __forceinline__ void contract(f32x4 (&acc)[MS][4], const f32x4 (&Wr)[NG][SQ], __amdgpu_buffer_rsrc_t r,
+                                         int base, int rb0, int rb_last, int S, int s0, int lane) {
+    constexpr int CH = SQ < 4 ? SQ : 4, NCH = SQ / CH;
+    static_assert(SQ % CH == 0, "k-steps per wave must be a multiple of the chunk");
+    f32x4 A[2][MS][CH];
+    auto load = [&](int c, int buf) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            const int rb = min(rb0 + ms, rb_last);              // row blocks past the batch are clamped, never stored
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                A[buf][ms][i] = ld16_sc1(r, base + ((rb * S + s0 + c * CH + i) * 256 + lane * 4) * 4);
+        }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) load(c + 1, (c + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        acc[ms][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c & 1][ms][i][e], Wr[g][c * CH + i][e], acc[ms][g], 0, 0, 0);
+    }
+}
+
+// One 16x16 block of the group state: rows of sub-tile p held row-major in LDS tile `xt` ([16*MS][16]) -> the member's
+// 1 KB fragment block (row block rb, k-step ks) of the exchange buffer, one 16-byte sc1 store per lane of wave p.
+__device__ __forceinline__ void publish_block(__amdgpu_buffer_rsrc_t r, int base, const float* xt, int p, int lane,
+                                              int rb, int S, int ks) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xt + (p * 16 + (lane & 15)) * 16 + (lane >> 4) * 4);
+    st16_sc1(r, base + ((rb * S + ks) * 256 + lane * 4) * 4, v);
+}
+
+}  // namespace chain
+
+// runtime switch (inet_set_option key 4; INET_CHAIN=0 in the environment): 0 = per-step launches everywhere
+int chain_enabled();
+void chain_set_enabled(int on);
+// host-mapped failure counter shared by every chain launch of the process (null if it could not be allocated)
+unsigned* chain_host_status();

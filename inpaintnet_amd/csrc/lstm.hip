@@ -4,7 +4,9 @@
 // recurrent contraction h_prev[B,H] x W_hh[4H,H]^T streamed from L2 into v_mfma_f32_16x16x4_f32 fragments, gate
 // math / cell update / backward saves in the epilogue.  Input-side pre-activations gi = x W_ih^T + b_ih are formed for
 // all time steps at once by the batched GEMM (gemm.hip).
+#include <cstdio>
 #include "ksplit.h"
+#include "chain.h"
 #include "prof.h"
 #include "seq.h"
 #include "lstm.h"
@@ -174,6 +176,243 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs P) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Chain kernels (chain.h): all T steps of one LSTM layer in ONE launch.  W_hh (fwd) / W_hh^T (bwd) slices live in
+// registers for the whole sequence, the cell state c and its gradient are per-thread registers, and only h (fwd) /
+// the gate gradients (bwd) travel between the H/16 members of a row-tile group, once per step.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LstmChainFwdArgs {
+    int B, H, T, reverse, members;
+    const float* gi;                              // [T,B,4H] input-side pre-activations (x W_ih^T + b_ih)
+    const float* W_hh; const float* b_hh;         // [4H,H], [4H]
+    const float* c0;                              // [B,H]
+    float* out; float* cseq;                      // [T,B,H]
+    float* sv; long sv_stride;                    // 6 x [T,B,H] (i,f,g,o,c_prev,tanh c) or null
+    float* hx;                                    // exchange [2][rows16][H] fragment-major; slot 1 holds h0
+    unsigned* counters; chain::Status status;
+};
+
+template <int MS, int SQ>                          // SQ = H/64: k-steps of 16 per wave
+__global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * MS * 256];
+    __shared__ __attribute__((aligned(16))) float xt[MS * 256];
+    __shared__ unsigned flag;
+    int group, member;
+    chain::decode_block(blockIdx.x, P.members, group, member);
+    const int row0 = group * 16 * MS;
+    if (row0 >= P.B) return;
+    const int H = P.H, B = P.B, S = H >> 4, t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int j0 = member * 16, jc = j0 + (t & 15);
+    const int rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
+    const int slot_bytes = ((B + 15) >> 4) * 16 * H * 4;
+    // this wave's W_hh fragments: 4 gates x SQ k-steps, resident for all T steps
+    f32x4 Wr[4][SQ];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int si = 0; si < SQ; ++si)
+            Wr[g][si] = ld4u(P.W_hh + (long)(g * H + j0 + i16) * H + 16 * (w * SQ + si) + 4 * q);
+    float bh[4], c[MS];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) bh[a] = P.b_hh[a * H + jc];
+#pragma unroll
+    for (int p = 0; p < MS; ++p) c[p] = P.c0[(long)min(row0 + ((t + 256 * p) >> 4), B - 1) * H + jc];
+    const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.hx);
+    for (int step = 0; step < P.T; ++step) {
+        const int tt = P.reverse ? P.T - 1 - step : step;
+        float pg[MS][4];                           // does not depend on h: requested before the wait
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = min(row0 + ((t + 256 * p) >> 4), B - 1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pg[p][a] = P.gi[((long)tt * B + b) * 4 * H + a * H + jc];
+        }
+        if (step > 0 && !chain::wait_group(P.counters + group, (unsigned)(step * P.members), P.status, &flag)) return;
+        f32x4 acc[MS][4];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        chain::contract<MS, 4, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
+        float v[MS][4];
+        reduce_waves<MS, 4>(acc, red, t, v);
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int rl = (t + 256 * p) >> 4;
+            const int b = row0 + rl;
+            const float i = sigmoid_f(v[p][0] + pg[p][0] + bh[0]);
+            const float f = sigmoid_f(v[p][1] + pg[p][1] + bh[1]);
+            const float g = tanh_f(v[p][2] + pg[p][2] + bh[2]);
+            const float o = sigmoid_f(v[p][3] + pg[p][3] + bh[3]);
+            const float cp = c[p];
+            const float cn = f * cp + i * g;
+            const float tc = tanh_f(cn);
+            const float h = o * tc;
+            c[p] = cn;
+            xt[rl * 16 + (t & 15)] = h;
+            if (b < B) {
+                const long qo = ((long)tt * B + b) * H + jc;
+                P.out[qo] = h;
+                P.cseq[qo] = cn;
+                if (P.sv) {
+                    float* sp = P.sv + qo;
+                    const long st = P.sv_stride;
+                    sp[0] = i; sp[st] = f; sp[2 * st] = g; sp[3 * st] = o; sp[4 * st] = cp; sp[5 * st] = tc;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
+            chain::publish_block(rs, (step & 1) * slot_bytes, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
+        chain::arrive(P.counters + group);
+    }
+}
+
+struct LstmChainBwdArgs {
+    int B, H, T, reverse, members;
+    const float* W_hhT;                           // [H,4H]
+    const float* dout;                            // [T,B,H] or null
+    const float* dhT; const float* dcT;           // [B,H] or null: gradients into the final state
+    const float* sv; long sv_stride;              // forward saves
+    float* dg;                                    // [T,B,4H] gate gradients (row-major: the weight-gradient GEMMs read it)
+    float* dh0; float* dc0;                       // [B,H] or null: gradients wrt the initial state
+    float* db_ih; float* db_hh;                   // [4H] accumulated (nullable)
+    float* gx;                                    // exchange [2][rows16][4H] fragment-major
+    unsigned* counters; chain::Status status;
+};
+
+template <int MS, int SQ>                          // SQ = H/16: k-steps of 16 per wave over K = 4H
+__global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P) {
+    __shared__ __attribute__((aligned(16))) float red[4 * MS * 256];
+    __shared__ __attribute__((aligned(16))) float xt[4][MS * 256];
+    __shared__ unsigned flag;
+    int group, member;
+    chain::decode_block(blockIdx.x, P.members, group, member);
+    const int row0 = group * 16 * MS;
+    if (row0 >= P.B) return;
+    const int H = P.H, B = P.B, T = P.T, S4 = (4 * H) >> 4, t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int j0 = member * 16, jc = j0 + (t & 15);
+    const int rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
+    const int slot_bytes = ((B + 15) >> 4) * 16 * 4 * H * 4;
+    f32x4 Wr[1][SQ];                               // rows j0..j0+15 of W_hh^T, this wave's quarter of K = 4H
+#pragma unroll
+    for (int si = 0; si < SQ; ++si) Wr[0][si] = ld4u(P.W_hhT + (long)(j0 + i16) * 4 * H + 16 * (w * SQ + si) + 4 * q);
+    const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.gx);
+    float dc[MS], bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < MS; ++p) dc[p] = 0.f;
+    for (int step = T - 1; step >= -1; --step) {
+        // step == -1: only dh0 = dg(first step) . W_hh
+        const bool tail = step < 0;
+        if (tail && !P.dh0) break;
+        const int tt = tail ? 0 : (P.reverse ? T - 1 - step : step);
+        float pe[MS][2], psv[MS][6];
+        if (!tail) {
+#pragma unroll
+            for (int p = 0; p < MS; ++p) {
+                const int b = min(row0 + ((t + 256 * p) >> 4), B - 1);
+                const long qo = ((long)tt * B + b) * H + jc, q2 = (long)b * H + jc;
+                pe[p][0] = P.dout ? P.dout[qo] : 0.f;
+                pe[p][1] = 0.f;
+                if (step == T - 1) {
+                    if (P.dhT) pe[p][0] += P.dhT[q2];
+                    if (P.dcT) pe[p][1] = P.dcT[q2];
+                }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) psv[p][a] = P.sv[qo + a * P.sv_stride];
+            }
+        }
+        float v[MS][1];
+#pragma unroll
+        for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
+        if (step != T - 1) {
+            if (!chain::wait_group(P.counters + group, (unsigned)((T - 1 - step) * P.members), P.status, &flag)) return;
+            f32x4 acc[MS][4];
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            chain::contract<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S4, w * SQ, lane);
+            reduce_waves<MS, 1>(acc, red, t, v);
+        }
+        if (tail) {
+#pragma unroll
+            for (int p = 0; p < MS; ++p) {
+                const int b = row0 + ((t + 256 * p) >> 4);
+                if (b < B) P.dh0[(long)b * H + jc] = v[p][0];
+            }
+            break;
+        }
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int rl = (t + 256 * p) >> 4;
+            const int b = row0 + rl;
+            const float dh = v[p][0] + pe[p][0];
+            const float i = psv[p][0], f = psv[p][1], g = psv[p][2], o = psv[p][3], cp = psv[p][4], tc = psv[p][5];
+            const float dct = dh * o * (1.f - tc * tc) + dc[p] + pe[p][1];
+            const float di = dct * g * i * (1.f - i);
+            const float df = dct * cp * f * (1.f - f);
+            const float dgg = dct * i * (1.f - g * g);
+            const float dob = dh * tc * o * (1.f - o);
+            dc[p] = dct * f;
+            const int xo = rl * 16 + (t & 15);
+            xt[0][xo] = di; xt[1][xo] = df; xt[2][xo] = dgg; xt[3][xo] = dob;
+            if (b < B) {
+                float* d = P.dg + ((long)tt * B + b) * 4 * H;
+                d[jc] = di; d[H + jc] = df; d[2 * H + jc] = dgg; d[3 * H + jc] = dob;
+                bs[0] += di; bs[1] += df; bs[2] += dgg; bs[3] += dob;
+            }
+        }
+        __syncthreads();
+        // publish the 4 gate blocks of every row sub-tile: (4 * MS) KB, one wave per block round-robin
+        for (int blk = t >> 6; blk < 4 * MS; blk += 4) {
+            const int g = blk / MS, p = blk % MS;
+            if (rb0 + p <= rb_last)
+                chain::publish_block(rs, (step & 1) * slot_bytes, xt[g], p, lane, rb0 + p, S4, g * (H >> 4) + member);
+        }
+        chain::arrive(P.counters + group);
+    }
+    if (P.dc0) {
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = row0 + ((t + 256 * p) >> 4);
+            if (b < B) P.dc0[(long)b * H + jc] = dc[p];
+        }
+    }
+    if (P.db_ih) {                                 // bias gradients: one tile reduction for the whole sequence
+        __syncthreads();
+        float* lb = &xt[0][0];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) lb[a * 256 + t] = bs[a];
+        __syncthreads();
+        if (t < 64) {
+            const int a = t >> 4, cc = t & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) sum += lb[a * 256 + rr * 16 + cc];
+            unsafeAtomicAdd(P.db_ih + a * H + j0 + cc, sum);
+            unsafeAtomicAdd(P.db_hh + a * H + j0 + cc, sum);
+        }
+    }
+}
+
+template <typename K, typename A>
+int launch_chain(K kernel, const A& a, int groups, hipStream_t s) {
+    hipLaunchKernelGGL(kernel, dim3(chain::blocks_for(groups, a.members)), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// rows per group (16 * MS) for a batch: small batches get one group
+inline int chain_ms(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : 4); }
+inline bool lstm_chain_ok(int B, int H) {
+    if (!chain_enabled() || (H != 256 && H != 512)) return false;
+    const int ms = chain_ms(B), groups = (B + 16 * ms - 1) / (16 * ms);
+    return groups * (H / 16) <= 256;              // every workgroup of the launch must be resident at once
+}
+
 int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
     dim3 grid(a.H / TH, (a.B + 31) / 32);
     ProfScope prof(PROF_GRU_FWD, 2.0 * a.B * 4.0 * a.H * a.H, s);
@@ -187,7 +426,8 @@ int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-struct LstmWs { float *zeros, *cseq, *sv, *whhT, *dc; };
+struct LstmWs { float *zeros, *cseq, *sv, *whhT, *dc, *hx, *gx; unsigned* sync; };
+constexpr int kSyncWords = 64;                     // [0..31] forward group counters, [32..62] backward, [63] status
 size_t lstm_carve(int B, int T, int H, int save, void* base, LstmWs& w) {
     Carver cv(base);
     const size_t BH = (size_t)B * H;
@@ -196,6 +436,9 @@ size_t lstm_carve(int B, int T, int H, int save, void* base, LstmWs& w) {
     w.sv = save ? cv.take<float>(6 * (size_t)T * BH) : nullptr;
     w.whhT = save ? cv.take<float>((size_t)4 * H * H) : nullptr;
     w.dc = save ? cv.take<float>(2 * BH) : nullptr;
+    w.hx = cv.take<float>(2 * pk_floats(B, H));
+    w.gx = save ? cv.take<float>(2 * pk_floats(B, 4 * H)) : nullptr;
+    w.sync = cv.take<unsigned>(kSyncWords);
     return cv.bytes();
 }
 
@@ -213,6 +456,29 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
     lstm_carve(B, T, H, save, ws, w);
     const long BH = (long)B * H, TBH = (long)T * BH;
     if ((!h0 || !c0) && pw_zero(w.zeros, BH, s) != 0) return -2;
+    if (lstm_chain_ok(B, H)) {
+        const int ms = chain_ms(B), groups = (B + 16 * ms - 1) / (16 * ms);
+        if (hipMemsetAsync(w.sync, 0, kSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+        INET_TRY(pw_pack_frag(h0 ? h0 : w.zeros, H, B, H, w.hx + pk_floats(B, H), 0, 1, 0, 0, s));   // slot 1 = h0
+        LstmChainFwdArgs a{};
+        a.B = B; a.H = H; a.T = T; a.reverse = reverse; a.members = H / 16;
+        a.gi = gi; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = c0 ? c0 : w.zeros;
+        a.out = out; a.cseq = w.cseq;
+        if (save) { a.sv = w.sv; a.sv_stride = TBH; }
+        a.hx = w.hx; a.counters = w.sync; a.status = chain::Status{w.sync + kSyncWords - 1, chain_host_status()};
+        char label[64];
+        std::snprintf(label, sizeof label, "lstm_chain_fwd ms%d T%d B%d H%d", ms, T, B, H);
+        ProfScope prof(PROF_GRU_FWD, 2.0 * T * B * 4.0 * H * H, s, label,
+                       4.0 * (4.0 * H * H + (double)T * B * H * (4 + 2 + (save ? 6 : 0))));
+        int rc;
+        if (H == 256) rc = ms == 1 ? launch_chain(lstm_chain_fwd_kernel<1, 4>, a, groups, s)
+                           : ms == 2 ? launch_chain(lstm_chain_fwd_kernel<2, 4>, a, groups, s)
+                                     : launch_chain(lstm_chain_fwd_kernel<4, 4>, a, groups, s);
+        else rc = ms == 1 ? launch_chain(lstm_chain_fwd_kernel<1, 8>, a, groups, s)
+                  : ms == 2 ? launch_chain(lstm_chain_fwd_kernel<2, 8>, a, groups, s)
+                            : launch_chain(lstm_chain_fwd_kernel<4, 8>, a, groups, s);
+        INET_TRY(rc);
+    } else
     for (int step = 0; step < T; ++step) {
         const int t = reverse ? T - 1 - step : step;
         const int tp = reverse ? t + 1 : t - 1;
@@ -241,6 +507,30 @@ int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const 
     lstm_carve(B, T, H, 1, ws, w);
     const long BH = (long)B * H, TBH = (long)T * BH, B4H = 4 * BH;
     INET_TRY(pw_transpose(W_hh, H, w.whhT, 4L * H, 4 * H, H, s));
+    const bool use_chain = lstm_chain_ok(B, H);
+    if (use_chain) {
+        const int ms = chain_ms(B), groups = (B + 16 * ms - 1) / (16 * ms);
+        if (hipMemsetAsync(w.sync + 32, 0, 32 * sizeof(unsigned), s) != hipSuccess) return -2;
+        LstmChainBwdArgs a{};
+        a.B = B; a.H = H; a.T = T; a.reverse = reverse; a.members = H / 16;
+        a.W_hhT = w.whhT; a.dout = dout; a.dhT = dhT; a.dcT = dcT;
+        a.sv = w.sv; a.sv_stride = TBH;
+        a.dg = dgi; a.dh0 = dh0; a.dc0 = dc0;
+        a.db_ih = db_ih; a.db_hh = db_hh;
+        a.gx = w.gx; a.counters = w.sync + 32; a.status = chain::Status{w.sync + kSyncWords - 1, chain_host_status()};
+        char label[64];
+        std::snprintf(label, sizeof label, "lstm_chain_bwd ms%d T%d B%d H%d", ms, T, B, H);
+        ProfScope prof(PROF_GRU_BWD, 2.0 * T * B * 4.0 * H * H, s, label,
+                       4.0 * (4.0 * H * H + (double)T * B * H * (6 + 4 + 1)));
+        int rc;
+        if (H == 256) rc = ms == 1 ? launch_chain(lstm_chain_bwd_kernel<1, 16>, a, groups, s)
+                           : ms == 2 ? launch_chain(lstm_chain_bwd_kernel<2, 16>, a, groups, s)
+                                     : launch_chain(lstm_chain_bwd_kernel<4, 16>, a, groups, s);
+        else rc = ms == 1 ? launch_chain(lstm_chain_bwd_kernel<1, 32>, a, groups, s)
+                  : ms == 2 ? launch_chain(lstm_chain_bwd_kernel<2, 32>, a, groups, s)
+                            : launch_chain(lstm_chain_bwd_kernel<4, 32>, a, groups, s);
+        INET_TRY(rc);
+    } else
     for (int step = T - 1; step >= 0; --step) {
         const int t = reverse ? T - 1 - step : step;
         const int tn = reverse ? t - 1 : t + 1;
@@ -260,14 +550,14 @@ int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const 
         INET_TRY(launch_bwd(a, s));
     }
     const int t0 = reverse ? T - 1 : 0;
-    if (dh0) {
+    if (dh0 && !use_chain) {
         LstmBwdArgs a{};
         a.B = B; a.H = H;
         a.dg_next = dgi + (long)t0 * B4H; a.W_hhT = w.whhT;
         a.dh_out = dh0;
         INET_TRY(launch_bwd(a, s));
     }
-    if (dc0 && pw_copy_bytes(dc0, w.dc, BH * sizeof(float), s) != 0) return -2;
+    if (dc0 && !use_chain && pw_copy_bytes(dc0, w.dc, BH * sizeof(float), s) != 0) return -2;
     if (dW_hh) {
         // dW_hh += sum_t dg(t)^T h_prev(t):  h_prev(t) = out(t -/+ 1), and h0 for the first processed step
         hipStream_t ss = side_fork(s);

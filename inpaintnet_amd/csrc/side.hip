@@ -1,6 +1,7 @@
 #include <cstdlib>
 #include <vector>
 #include "side.h"
+#include "chain.h"
 
 namespace {
 hipStream_t g_side = nullptr;
@@ -60,4 +61,25 @@ int side_join_now(hipStream_t main_stream) {
     if (hipEventRecord(e, g_side) != hipSuccess) return -2;
     if (hipStreamWaitEvent(main_stream, e, 0) != hipSuccess) return -2;
     return 0;
+}
+
+// ---- chain kernels on/off (chain.h) ----
+namespace { int g_chain = -1; }
+int chain_enabled() {
+    if (g_chain < 0) {
+        const char* v = std::getenv("INET_CHAIN");
+        g_chain = (v && v[0] == '0') ? 0 : 1;
+    }
+    return g_chain;
+}
+void chain_set_enabled(int on) { g_chain = on ? 1 : 0; }
+unsigned* chain_host_status() {
+    static unsigned* p = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocMapped) == hipSuccess) { p = static_cast<unsigned*>(q); *p = 0; }
+    }
+    return p;
 }

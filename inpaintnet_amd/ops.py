@@ -384,3 +384,9 @@ def ws_field(cfg, ws, B, which, name):
     check(_lib.lib().inet_vae_ws_field(C.byref(cfg), B, int(which), name.encode(), C.byref(off), C.byref(n)),
           "inet_vae_ws_field")
     return ws[off.value:off.value + n.value]
+
+
+def chain_status(reset=False):
+    """Workgroups of chain kernels that timed out waiting for their group since the last reset (0 = healthy).
+    Call after a synchronisation."""
+    return int(_lib.lib().inet_chain_status(int(bool(reset))))

@@ -31,8 +31,14 @@ def build(name):
 
 def test_lstm_layer_kernel_vs_oracle():
     g = torch.Generator().manual_seed(4)
-    for (B, T, K, H, rev) in [(3, 5, 6, 16, False), (33, 7, 20, 32, True), (32, 12, 266, 256, False)]:
-        P = {"l.weight_ih_l0": torch.randn(4 * H, K, generator=g) * 0.2, "l.weight_hh_l0": torch.randn(4 * H, H, generator=g) * 0.2,
+    # H in {256, 512} runs the chain kernels (one persistent launch per layer, csrc/chain.h): one group (B <= 64, ragged
+    # last row block), several groups (B = 70, 130), both directions, both register geometries
+    for (B, T, K, H, rev) in [(3, 5, 6, 16, False), (33, 7, 20, 32, True), (32, 12, 266, 256, False),
+                              (37, 9, 20, 256, True), (70, 5, 8, 256, False), (130, 4, 16, 256, True),
+                              (5, 6, 8, 512, True), (24, 30, 12, 512, False)]:
+        case = (B, T, K, H, rev)
+        whh_scale = 0.2 if H <= 256 and T <= 12 else 1.0 / np.sqrt(H)    # long / wide cases: keep the recurrence contractive
+        P = {"l.weight_ih_l0": torch.randn(4 * H, K, generator=g) * 0.2, "l.weight_hh_l0": torch.randn(4 * H, H, generator=g) * whh_scale,
              "l.bias_ih_l0": torch.randn(4 * H, generator=g) * 0.1, "l.bias_hh_l0": torch.randn(4 * H, generator=g) * 0.1}
         for p in P.values():
             p.requires_grad_(True)
@@ -48,17 +54,43 @@ def test_lstm_layer_kernel_vs_oracle():
         gi = ops.linear_fwd(x_tm.view(T * B, K), d["l.weight_ih_l0"], d["l.bias_ih_l0"]).view(T, B, 4 * H)
         o, h, c, ws = ops.lstm_fwd(gi, d["l.weight_hh_l0"], d["l.bias_hh_l0"], H, reverse=rev, h0=h0.detach().cuda(),
                                    c0=c0.detach().cuda(), save=True, want_state=True)
-        assert G.rel_err(o.permute(1, 0, 2).cpu(), out.detach()) < 5e-5
-        assert G.rel_err(h.cpu(), hT.detach()) < 5e-5 and G.rel_err(c.cpu(), cT.detach()) < 5e-5
+        assert G.rel_err(o.permute(1, 0, 2).cpu(), out.detach()) < 5e-5, case
+        assert G.rel_err(h.cpu(), hT.detach()) < 5e-5 and G.rel_err(c.cpu(), cT.detach()) < 5e-5, case
         dW = torch.zeros(4 * H, H, device="cuda"); dbi = torch.zeros(4 * H, device="cuda"); dbh = torch.zeros(4 * H, device="cuda")
         dgi, dh0, dc0 = ops.lstm_bwd(d["l.weight_hh_l0"], o, wo.permute(1, 0, 2).contiguous().cuda(), H, rev, ws, dW, dbi, dbh,
                                      h0=h0.detach().cuda(), dhT=wh.cuda(), dcT=wc.cuda(), want_dstate=True)
         torch.cuda.synchronize()
-        assert G.rel_err(dW.cpu(), P["l.weight_hh_l0"].grad) < 5e-4
-        assert G.rel_err(dbh.cpu(), P["l.bias_hh_l0"].grad) < 5e-4 and G.rel_err(dbi.cpu(), P["l.bias_ih_l0"].grad) < 5e-4
-        assert G.rel_err(dh0.cpu(), h0.grad) < 5e-4 and G.rel_err(dc0.cpu(), c0.grad) < 5e-4
+        assert G.rel_err(dW.cpu(), P["l.weight_hh_l0"].grad) < 5e-4, case
+        assert G.rel_err(dbh.cpu(), P["l.bias_hh_l0"].grad) < 5e-4 and G.rel_err(dbi.cpu(), P["l.bias_ih_l0"].grad) < 5e-4, case
+        assert G.rel_err(dh0.cpu(), h0.grad) < 5e-4 and G.rel_err(dc0.cpu(), c0.grad) < 5e-4, case
         dx = ops.linear_bwd(dgi.view(T * B, 4 * H), x_tm.view(T * B, K), d["l.weight_ih_l0"], need_dx=True)
-        assert G.rel_err(dx.view(T, B, K).permute(1, 0, 2).cpu(), x.grad) < 5e-4
+        assert G.rel_err(dx.view(T, B, K).permute(1, 0, 2).cpu(), x.grad) < 5e-4, case
+        assert ops.chain_status() == 0, case
+
+
+def test_lstm_chain_matches_per_step_launches():
+    """Chain kernel vs one launch per step on the AnticipationRNN shape (B=32, H=256, 384 ticks): same contraction order per
+    output element; results agree to fp32 round-off over all 384 steps."""
+    g = torch.Generator().manual_seed(8)
+    B, T, H = 32, 384, 256
+    gi = (torch.randn(T, B, 4 * H, generator=g) * 0.5).cuda()
+    W = (torch.randn(4 * H, H, generator=g) / 16).cuda()
+    b = (torch.randn(4 * H, generator=g) * 0.1).cuda()
+    dout = (torch.randn(T, B, H, generator=g) * 0.1).cuda()
+    res = {}
+    for chain in (1, 0):
+        ops.set_option(4, chain)
+        try:
+            o, h, c, ws = ops.lstm_fwd(gi, W, b, H, reverse=False, save=True, want_state=True)
+            dW = torch.zeros(4 * H, H, device="cuda"); dbi = torch.zeros(4 * H, device="cuda"); dbh = torch.zeros(4 * H, device="cuda")
+            dgi, dh0, dc0 = ops.lstm_bwd(W, o, dout, H, False, ws, dW, dbi, dbh, want_dstate=True)
+            torch.cuda.synchronize()
+            res[chain] = [x.cpu() for x in (o, h, c, dgi, dh0, dc0, dW, dbi)]
+        finally:
+            ops.set_option(4, 1)
+    assert ops.chain_status() == 0
+    for i in range(8):          # (not bit-identical: the two kernels' epilogues are FMA-contracted differently)
+        assert G.rel_err(res[1][i], res[0][i]) < 2e-5, i
 
 
 @pytest.mark.parametrize("name", ["small", "full"])

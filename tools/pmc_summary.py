@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs of `bench.py` into the files committed under profiles/.
+
+    python tools/pmc_summary.py stats  <kernel_trace.csv>                     -> per-kernel time table (text, stdout)
+    python tools/pmc_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+PMC conventions (MI355X_MICROARCH.md, section HBM): FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts
+128-byte requests as 64 bytes for wide coalesced reads, so the read side is DOUBLED here; WRITE_SIZE is taken as is.  The two
+counters are collected in separate passes (TCC slots).  Kernels are keyed by short name + launch grid (threads), because
+one template instantiation serves several problem shapes."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    m = re.search(r"((?:gru_step_fwd|gru_step_bwd|gemm|lstm_step_fwd|lstm_step_bwd|logits_argmax|gru_chain\w*|lstm_chain\w*|"
+                  r"decode_\w+)_kernel<[^>]*>)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"\(anonymous namespace\)::(\w+)\(", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"(\w+)<", name)
+    return (m.group(1) if m else name)[:60]
+
+
+def stats(path, top=40):
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            a = agg[k]
+            a[0] += 1; a[1] += us; a[2] = min(a[2], us); a[3] = max(a[3], us)
+    tot = sum(a[1] for a in agg.values())
+    print(f"# {sum(a[0] for a in agg.values())} dispatches, {tot:.1f} us total kernel time")
+    print(f"{'kernel':<58} {'calls':>7} {'total_us':>11} {'pct':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9}")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print(f"{k:<58} {a[0]:>7d} {a[1]:>11.1f} {100 * a[1] / tot:>6.2f} {a[1] / a[0]:>9.2f} {a[2]:>9.2f} {a[3]:>9.2f}")
+
+
+def read_counter(path, counter):
+    out = defaultdict(lambda: [0, 0.0, 0.0])          # key -> [launches, sum counter, sum us]
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            key = f'{short(r["Kernel_Name"])}|g{r["Grid_Size"]}'
+            a = out[key]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return out
+
+
+def pmc(fetch_csv, write_csv, out_json):
+    fe = read_counter(fetch_csv, "FETCH_SIZE")
+    wr = read_counter(write_csv, "WRITE_SIZE")
+    kernels = {}
+    for key in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0, 0])[2])):
+        f, w = fe.get(key), wr.get(key)
+        fetch_kb = f[1] / f[0] if f else 0.0
+        write_kb = w[1] / w[0] if w else 0.0
+        kernels[key] = {"launches": f[0] if f else w[0], "avg_us_profiled": round((f or w)[2] / (f or w)[0], 3),
+                        "fetch_size_kb_raw": round(fetch_kb, 2), "write_size_kb": round(write_kb, 2),
+                        "hbm_mbytes_per_launch": round((2.0 * fetch_kb + write_kb) * 1024 / 1e6, 4)}
+    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 30 "
+                     "--warmup 5 --no-cpu-baseline --no-extras --no-parity --no-roofline",
+           "corrections": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); KB -> bytes x1024",
+           "kernels": kernels}
+    json.dump(doc, open(out_json, "w"), indent=1)
+    print(f"wrote {out_json}: {len(kernels)} kernel/grid keys")
+    for k, v in list(kernels.items())[:14]:
+        print(f"  {k:<62} n={v['launches']:<6} {v['avg_us_profiled']:>9.2f} us  {v['hbm_mbytes_per_launch']:>9.3f} MB/launch")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
