@@ -1,0 +1,51 @@
+// Launch descriptors of the GRU chain kernels (gru_chain.hip; protocol in chain.h).
+#pragma once
+#include "chain.h"
+
+constexpr int kChainMaxGroups = 32;               // group counters per launch; word [kChainMaxGroups] is the status word
+constexpr int kChainSyncWords = kChainMaxGroups + 1;
+
+struct GruChainFwdProb {
+    const float* W_hh; const float* b_hh;         // [3H,H] row-major, [3H]
+    const float* h0; long ld_h0;                  // [B,H] initial hidden (row-major); slot 1 of hx holds it fragment-major
+    const float* gi_dense; long ld_gi, ts_gi;     // gi(t,b) = gi_dense[t*ts + b*ld + g*H + j], or null
+    const float* gi_table; long ld_table;         // gi(t,b) = gi_table[tok*ld + g*H + j], tok = idx[b*idx_bs + t*idx_ts]
+    const long long* idx; long idx_bs, idx_ts;
+    const float* gi_vec;                          // [3H] broadcast, or null
+    float* out; long ld_out, ts_out;              // h(t,b)
+    float* outm; long ld_outm, ts_outm;           // h(t,b) * mask(t,b), or null
+    const float* mask; long ld_mask, ts_mask;
+    float* hlast; long ld_hlast;                  // copy of the final hidden, or null
+    float* sv; long sv_astride;                   // r,z,n,ghn,hprev saves [T][B][H] each, or null
+    float* hx;                                    // exchange: [2][ceil16(B)][H] fragment-major
+    int reverse;
+};
+struct GruChainFwd {
+    int H, B, T, nprob, tiles_per_prob, members;
+    GruChainFwdProb p[4];
+    unsigned* counters;                           // kChainSyncWords words owned by this launch (zeroed by the launcher)
+    chain::Status status;
+};
+
+struct GruChainBwdProb {
+    const float* W_hh;                            // [3H,H] row-major (read transposed, once)
+    const float* dout; long ld_dout, ts_dout;     // dLoss/dh(t,b), or null
+    const float* dhn; long ld_dhn;                // dLoss/d final hidden, or null
+    const float* sv; long sv_astride;
+    float* dgi; long ld_dgi, ts_dgi;              // [.,3H] input-side gate gradients (strided)
+    float* dgh;                                   // [T][B][3H] dense recurrent-side gate gradients
+    float* db_ih; float* db_hh;                   // [3H], accumulated; or null
+    float* dh0; long ld_dh0; int dh0_accumulate;  // dLoss/d initial hidden, or null
+    float* gx;                                    // exchange: [2][ceil16(B)][3H] fragment-major
+    int reverse;
+};
+struct GruChainBwd {
+    int H, B, T, nprob, tiles_per_prob, members;
+    GruChainBwdProb p[4];
+    unsigned* counters;
+    chain::Status status;
+};
+
+bool gru_chain_ok(int H, int B, int T, int nprob);
+int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s);
+int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s);

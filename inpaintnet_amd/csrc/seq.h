@@ -8,6 +8,7 @@
 #include "common.h"
 #include "pointwise.h"
 #include "side.h"
+#include "gru_chain.h"
 
 #define INET_TRY(expr) do { int _rc = (expr); if (_rc != 0) return _rc; } while (0)
 
@@ -38,6 +39,8 @@ struct DirFwd {
     int reverse;
     // fragment-major fast path (both or neither; H % 256 == 0): packed W_hh and a 2 x pk_floats(B,H) ping-pong buffer
     const float* Wpk_hh; float* hpk;
+    // chain kernel (gru_chain.h): kChainSyncWords words for the launch's group counters, given for direction 0 (or null)
+    unsigned* sync;
 };
 
 struct DirBwd {
@@ -53,6 +56,8 @@ struct DirBwd {
     int reverse;
     // fragment-major fast path (both or neither; H % 256 == 0): packed W_hh^T and a 2 x pk_floats(B,3H) ping-pong buffer
     const float* Wpk_hhT; float* dghpk;
+    const float* W_hh;                                        // [3H,H] row-major (chain kernel reads it transposed once)
+    unsigned* sync;                                           // as in DirFwd
 };
 
 // floats of a fragment-major [rows,K] operand (rows padded to 16)
@@ -98,6 +103,7 @@ struct BiGru2Ws {
     float *zeros, *x1raw, *x1m, *gi1, *h1, *sv[4];
     float *whhT[4], *dgi1, *dgh[4], *dhz, *dx1, *dgi0;
     float *wpk[4], *hpk[4], *wpkT[4], *dghpk[4];               // fragment-major twins (null unless pk_ok(H))
+    unsigned* sync;                                            // chain-kernel counters (gru_chain.h)
 };
 size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w);
 

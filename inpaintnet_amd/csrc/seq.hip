@@ -14,6 +14,28 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
         if (same_ld) INET_TRY(pw_pack_frag_multi(ins, outs, nd, d[0].h0_ld, B, H, 0, s));
         else for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
     }
+    if (pk && d[0].sync && gru_chain_ok(H, B, T, nd)) {
+        // one persistent launch for all T steps (gru_chain.hip); the exchange buffer is the hpk ring, slot 1 = h0
+        GruChainFwd a{};
+        a.H = H; a.B = B; a.T = T; a.nprob = nd;
+        for (int i = 0; i < nd; ++i) {
+            const DirFwd& D = d[i];
+            GruChainFwdProb& P = a.p[i];
+            P.W_hh = D.W_hh; P.b_hh = D.b_hh;
+            P.h0 = D.h0; P.ld_h0 = D.h0_ld;
+            P.gi_dense = D.gi; P.ld_gi = D.gi_ld; P.ts_gi = D.gi_ts;
+            P.gi_table = D.table; P.ld_table = D.table_ld; P.idx = D.idx; P.idx_bs = D.idx_bs; P.idx_ts = D.idx_ts;
+            P.gi_vec = D.gvec;
+            P.out = D.out; P.ld_out = D.out_ld; P.ts_out = D.out_ts;
+            P.outm = D.outm; P.ld_outm = D.outm_ld; P.ts_outm = D.outm_ts;
+            P.mask = D.mask; P.ld_mask = D.mask_ld; P.ts_mask = D.mask_ts;
+            P.hlast = D.hlast; P.ld_hlast = D.hlast_ld;
+            P.sv = D.sv; P.sv_astride = D.sv_astride;
+            P.hx = D.hpk; P.reverse = D.reverse;
+        }
+        a.counters = d[0].sync;
+        return launch_gru_chain_fwd(a, s);
+    }
     for (int step = 0; step < T; ++step) {
         GruFwdBatch bt{};
         bt.H = H; bt.nprob = nd;
@@ -64,6 +86,29 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
     const long pkg = (long)pk_floats(B, 3 * H);
     bool pk = pk_ok(H);
     for (int i = 0; i < nd; ++i) if (!d[i].Wpk_hhT || !d[i].dghpk) pk = false;
+    {
+        bool any0 = false, all0 = true, wok = true;
+        for (int i = 0; i < nd; ++i) { if (d[i].dh0) any0 = true; else all0 = false; if (!d[i].W_hh) wok = false; }
+        if (pk && wok && d[0].sync && step_hi == T - 1 && step_lo == 0 && (!any0 || all0) && gru_chain_ok(H, B, T, nd)) {
+            GruChainBwd a{};
+            a.H = H; a.B = B; a.T = T; a.nprob = nd;
+            for (int i = 0; i < nd; ++i) {
+                const DirBwd& D = d[i];
+                GruChainBwdProb& P = a.p[i];
+                P.W_hh = D.W_hh;
+                P.dout = D.dout; P.ld_dout = D.dout_ld; P.ts_dout = D.dout_ts;
+                P.dhn = D.dhn; P.ld_dhn = D.dhn_ld;
+                P.sv = D.sv; P.sv_astride = D.sv_astride;
+                P.dgi = D.dgi; P.ld_dgi = D.dgi_ld; P.ts_dgi = D.dgi_ts;
+                P.dgh = D.dgh;
+                P.db_ih = D.db_ih; P.db_hh = D.db_hh;
+                P.dh0 = D.dh0; P.ld_dh0 = D.dh0_ld; P.dh0_accumulate = D.dh0_acc;
+                P.gx = D.dghpk; P.reverse = D.reverse;
+            }
+            a.counters = d[0].sync;
+            return launch_gru_chain_bwd(a, s);
+        }
+    }
     for (int step = step_hi; step >= step_lo; --step) {
         GruBwdBatch bt{};
         bt.H = H; bt.nprob = nd;
@@ -149,6 +194,7 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
         w.wpkT[i] = pk && save ? c.take<float>((size_t)3 * H * H) : nullptr;
         w.dghpk[i] = pk && save ? c.take<float>(2 * pk_floats(B, 3 * H)) : nullptr;
     }
+    w.sync = c.take<unsigned>(kChainSyncWords);
     return c.bytes();
 }
 
@@ -179,6 +225,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (save) { D.sv = w.sv[dir]; D.sv_astride = TBH; }
         D.reverse = dir;
         D.Wpk_hh = w.wpk[dir]; D.hpk = w.hpk[dir];
+        D.sync = w.sync;
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     const float* x1 = mask ? w.x1m : w.x1raw;
@@ -196,6 +243,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (save) { D.sv = w.sv[2 + dir]; D.sv_astride = TBH; }
         D.reverse = dir;
         D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir];
+        D.sync = w.sync;
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     return 0;
@@ -227,6 +275,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (dh0) { D.dh0 = dh0 + (2 + dir) * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[2 + dir]; D.dghpk = w.dghpk[2 + dir];
+        D.W_hh = P[2 + dir].w_hh; D.sync = w.sync;
     }
     // The chains can hand their weight-gradient products to the side stream a chunk of steps at a time (CH < T) instead
     // of a layer's whole K = T*B product at the end of its chain.  Measured at B=256 with 2, 3, 4 chunks per layer:
@@ -270,6 +319,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (dh0) { D.dh0 = dh0 + dir * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[dir]; D.dghpk = w.dghpk[dir];
+        D.W_hh = P[dir].w_hh; D.sync = w.sync;
     }
     for (int hi = T - 1; hi >= 0; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0;
