@@ -54,7 +54,8 @@ __device__ __forceinline__ void arrive(unsigned* counter) {
 }
 
 // Consumer side, called by ALL threads: returns false (for every thread) if the group did not arrive in time.
-// `flag` is one word of LDS.
+// `flag` is one word of LDS; consecutive waits must use different words (flag[step & 1]): a fast wave may enter the
+// next wait while a slow one still reads this one's word.
 // `status` = {device word inside the workspace (aborts the other workgroups of the launch quickly), host-mapped word
 // (chain_host_status(): what inet_chain_status() reports)}.
 struct Status { unsigned* dev; unsigned* host; };
@@ -62,20 +63,19 @@ __device__ __forceinline__ bool wait_group(unsigned* counter, unsigned target, S
     if (threadIdx.x == 0) {
         unsigned ok = 1, spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > kSpinLimit || __hip_atomic_load(status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ST_OK) {
+            if (++spins > kSpinLimit ||
+                ((spins & 63) == 0 && __hip_atomic_load(status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ST_OK)) {
                 __hip_atomic_store(status.dev, (unsigned)ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (status.host) __hip_atomic_fetch_add(status.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 ok = 0;
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
         *flag = ok;
     }
     __syncthreads();
-    const bool ok = *flag != 0;
-    __syncthreads();                                            // flag may be rewritten by the next wait
-    return ok;
+    return *flag != 0;                                          // callers alternate between two flag words
 }
 
 // block -> (group, member): group = (b % 8) + 8 * (b / (8 * members)), member = (b / 8) % members.  Launch

@@ -2,8 +2,9 @@
 #pragma once
 #include "chain.h"
 
-constexpr int kChainMaxGroups = 32;               // group counters per launch; word [kChainMaxGroups] is the status word
-constexpr int kChainSyncWords = kChainMaxGroups + 1;
+constexpr int kChainMaxGroups = 32;               // group counters per launch; word [kChainMaxGroups] is the status word,
+constexpr int kChainZeroWord = kChainMaxGroups + 2;   // words [+2, +3] stay zero: the target of absent operand pointers
+constexpr int kChainSyncWords = kChainMaxGroups + 4;
 
 struct GruChainFwdProb {
     const float* W_hh; const float* b_hh;         // [3H,H] row-major, [3H]
@@ -21,7 +22,7 @@ struct GruChainFwdProb {
     int reverse;
 };
 struct GruChainFwd {
-    int H, B, T, nprob, tiles_per_prob, members;
+    int H, B, T, nprob, tiles_per_prob, members, prio;
     GruChainFwdProb p[4];
     unsigned* counters;                           // kChainSyncWords words owned by this launch (zeroed by the launcher)
     chain::Status status;
@@ -40,7 +41,7 @@ struct GruChainBwdProb {
     int reverse;
 };
 struct GruChainBwd {
-    int H, B, T, nprob, tiles_per_prob, members;
+    int H, B, T, nprob, tiles_per_prob, members, prio;
     GruChainBwdProb p[4];
     unsigned* counters;
     chain::Status status;

@@ -11,6 +11,7 @@
 // Same arithmetic as gru_step_fwd_kernel / gru_step_bwd_kernel (gru.hip), which remain the path for shapes a chain does
 // not cover (more row tiles than CUs, H other than 256/512, single steps): tests compare the two.
 #include <cstdio>
+#include <cstdlib>
 #include "chain.h"
 #include "ksplit.h"
 #include "prof.h"
@@ -24,10 +25,11 @@ template <int MS, int SQ>                          // SQ = H/64 k-steps per wave
 __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(GruChainFwd A) {
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * MS * 256];
     __shared__ __attribute__((aligned(16))) float xt[MS * 256];
-    __shared__ unsigned flag;
+    __shared__ unsigned flag[2];
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
     if (group >= A.nprob * A.tiles_per_prob) return;
+    if (A.prio) __builtin_amdgcn_s_setprio(3);     // the chain's waves are mostly parked; when they have work they go first
     const GruChainFwdProb& P = A.p[group / A.tiles_per_prob];
     const int row0 = (group % A.tiles_per_prob) * 16 * MS;
     const int H = A.H, B = A.B, T = A.T;
@@ -59,27 +61,44 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(GruChainFwd A) {
     }
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.hx);
     unsigned* counter = A.counters + group;
+    // Operand sources as (pointer, strides) with every field in a register before the loop; an absent source points at a
+    // zero word with zero strides, so the per-step requests are unconditional loads issued back to back (conditional
+    // loads make hipcc wrap each in a branch with its own s_waitcnt vmcnt(0): one exposed round trip per operand).
+    const float* const zf = reinterpret_cast<const float*>(A.counters + kChainZeroWord);
+    const bool has_tab = P.gi_table != nullptr, has_den = P.gi_dense != nullptr, has_mask = P.outm && P.mask;
+    const long long* const idxp = has_tab ? P.idx : reinterpret_cast<const long long*>(zf);
+    const int idx_bs = has_tab ? (int)P.idx_bs : 0, idx_ts = has_tab ? (int)P.idx_ts : 0;
+    const float* const tabp = has_tab ? P.gi_table : zf;
+    const int tab_ld = has_tab ? (int)P.ld_table : 0, tab_g = has_tab ? H : 0, tab_j = has_tab ? jc : 0;
+    const float* const denp = has_den ? P.gi_dense : zf;
+    const int den_ld = has_den ? (int)P.ld_gi : 0, den_ts = has_den ? (int)P.ts_gi : 0, den_g = has_den ? H : 0, den_j = has_den ? jc : 0;
+    const float* const mskp = has_mask ? P.mask : zf;
+    const int msk_ld = has_mask ? (int)P.ld_mask : 0, msk_ts = has_mask ? (int)P.ts_mask : 0, msk_j = has_mask ? jc : 0;
+    float* const outp = P.out; const int out_ld = (int)P.ld_out, out_ts = (int)P.ts_out;
+    float* const outmp = P.outm; const int outm_ld = (int)P.ld_outm, outm_ts = (int)P.ts_outm;
+    float* const svp = P.sv; const int sv_as = (int)P.sv_astride;
+    float* const hlastp = P.hlast; const int hlast_ld = (int)P.ld_hlast;
+    const int rev = P.reverse, members = A.members;
+    const chain::Status status = A.status;
+    // the token of the NEXT step is requested one step ahead (token -> table row is a dependent load)
+    long tok[MS];
+#pragma unroll
+    for (int p = 0; p < MS; ++p) tok[p] = idxp[brow[p] * idx_bs + (rev ? T - 1 : 0) * idx_ts];
     for (int step = 0; step < T; ++step) {
-        const int tt = P.reverse ? T - 1 - step : step;
-        // epilogue operands of this step: none depends on h, so they are requested before the group wait
-        float pg[MS][3], pm[MS];
+        const int tt = rev ? T - 1 - step : step;
+        const int tn = step + 1 < T ? (rev ? tt - 1 : tt + 1) : tt;
+        float pgt[MS][3], pgd[MS][3], pm[MS];
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const int b = brow[p];
-            if (P.gi_table) {
-                const long tok = P.idx[(long)b * P.idx_bs + (long)tt * P.idx_ts];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) pg[p][g] = P.gi_table[tok * P.ld_table + g * H + jc];
-            } else if (P.gi_dense) {
+            for (int g = 0; g < 3; ++g) pgt[p][g] = tabp[(int)tok[p] * tab_ld + g * tab_g + tab_j];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) pg[p][g] = P.gi_dense[(long)tt * P.ts_gi + (long)b * P.ld_gi + g * H + jc];
-            } else {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) pg[p][g] = 0.f;
-            }
-            pm[p] = (P.outm && P.mask) ? P.mask[(long)tt * P.ts_mask + (long)b * P.ld_mask + jc] : 1.f;
+            for (int g = 0; g < 3; ++g) pgd[p][g] = denp[tt * den_ts + b * den_ld + g * den_g + den_j];
+            pm[p] = mskp[tt * msk_ts + b * msk_ld + msk_j];
+            tok[p] = idxp[b * idx_bs + tn * idx_ts];
         }
-        if (step > 0 && !chain::wait_group(counter, (unsigned)(step * A.members), A.status, &flag)) return;
+        if (step > 0 && !chain::wait_group(counter, (unsigned)(step * members), status, &flag[step & 1])) return;
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -88,34 +107,40 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(GruChainFwd A) {
         chain::contract<MS, 3, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
         float v[MS][3];
         reduce_waves<MS, 3>(acc, red, t, v);
+        // gates first, then the hand-off (what the other members wait for), then the stores nobody in the launch reads
+        float er[MS], ez[MS], en[MS], eg[MS], eh[MS], ehp[MS];
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const int rl = (t + 256 * p) >> 4;
-            const int b = row0 + rl;
             const float ghn = v[p][2] + bh[2];
-            const float r = sigmoid_f(v[p][0] + pg[p][0] + bv[0] + bh[0]);
-            const float z = sigmoid_f(v[p][1] + pg[p][1] + bv[1] + bh[1]);
-            const float n = tanh_f(pg[p][2] + bv[2] + r * ghn);
+            const float r = sigmoid_f(v[p][0] + pgd[p][0] + pgt[p][0] + bv[0] + bh[0]);
+            const float z = sigmoid_f(v[p][1] + pgd[p][1] + pgt[p][1] + bv[1] + bh[1]);
+            const float n = tanh_f(pgd[p][2] + pgt[p][2] + bv[2] + r * ghn);
             const float hprev = hp[p];
             const float hn = (1.f - z) * n + z * hprev;
             hp[p] = hn;
             xt[rl * 16 + (t & 15)] = hn;
+            er[p] = r; ez[p] = z; en[p] = n; eg[p] = ghn; eh[p] = hn; ehp[p] = hprev;
+        }
+        if (step != T - 1) {                       // nobody reads the last state from the exchange
+            __syncthreads();
+            if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
+                chain::publish_block(rs, (step & 1) * slot_bytes, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
+            chain::arrive(counter);
+        }
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = row0 + ((t + 256 * p) >> 4);
             if (b < B) {
-                P.out[(long)tt * P.ts_out + (long)b * P.ld_out + jc] = hn;
-                if (P.outm) P.outm[(long)tt * P.ts_outm + (long)b * P.ld_outm + jc] = hn * pm[p];
-                if (P.hlast && step == T - 1) P.hlast[(long)b * P.ld_hlast + jc] = hn;
-                if (P.sv) {
-                    float* sp = P.sv + ((long)tt * B + b) * H + jc;
-                    const long as = P.sv_astride;
-                    sp[0] = r; sp[as] = z; sp[2 * as] = n; sp[3 * as] = ghn; sp[4 * as] = hprev;
+                outp[tt * out_ts + b * out_ld + jc] = eh[p];
+                if (outmp) outmp[tt * outm_ts + b * outm_ld + jc] = has_mask ? eh[p] * pm[p] : eh[p];
+                if (hlastp && step == T - 1) hlastp[b * hlast_ld + jc] = eh[p];
+                if (svp) {
+                    float* sp = svp + (tt * B + b) * H + jc;
+                    sp[0] = er[p]; sp[sv_as] = ez[p]; sp[2 * sv_as] = en[p]; sp[3 * sv_as] = eg[p]; sp[4 * sv_as] = ehp[p];
                 }
             }
         }
-        if (step == T - 1) break;                  // nobody reads the last state from the exchange
-        __syncthreads();
-        if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
-            chain::publish_block(rs, (step & 1) * slot_bytes, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
-        chain::arrive(counter);
     }
 }
 
@@ -123,10 +148,11 @@ template <int MS, int SQ>                          // SQ = 3H/64 k-steps per wav
 __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     __shared__ __attribute__((aligned(16))) float red[4 * MS * 256];
     __shared__ __attribute__((aligned(16))) float xt[3][MS * 256];
-    __shared__ unsigned flag;
+    __shared__ unsigned flag[2];
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
     if (group >= A.nprob * A.tiles_per_prob) return;
+    if (A.prio) __builtin_amdgcn_s_setprio(3);
     const GruChainBwdProb& P = A.p[group / A.tiles_per_prob];
     const int row0 = (group % A.tiles_per_prob) * 16 * MS;
     const int H = A.H, B = A.B, T = A.T;
@@ -151,31 +177,44 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     int brow[MS];
 #pragma unroll
     for (int p = 0; p < MS; ++p) { dhz[p] = 0.f; brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1); }
+    // operand sources in registers, absent ones aimed at a zero word (see the forward kernel)
+    const float* const zf = reinterpret_cast<const float*>(A.counters + kChainZeroWord);
+    const bool has_dout = P.dout != nullptr, has_dhn = P.dhn != nullptr;
+    const float* const doutp = has_dout ? P.dout : zf;
+    const int dout_ld = has_dout ? (int)P.ld_dout : 0, dout_ts = has_dout ? (int)P.ts_dout : 0, dout_j = has_dout ? jc : 0;
+    const float* const dhnp = has_dhn ? P.dhn : zf;
+    const int dhn_ld = has_dhn ? (int)P.ld_dhn : 0, dhn_j = has_dhn ? jc : 0;
+    const float* const svp = P.sv; const int sv_as = (int)P.sv_astride;
+    float* const dgip = P.dgi; const int dgi_ld = (int)P.ld_dgi, dgi_ts = (int)P.ts_dgi;
+    float* const dghp = P.dgh;
+    float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
+    const int rev = P.reverse, members = A.members;
+    const chain::Status status = A.status;
     for (int step = T - 1; step >= -1; --step) {
         const bool tail = step < 0;                // dh0 = dgh(first step) W_hh + dhz
-        if (tail && !P.dh0) break;
-        const int tt = tail ? 0 : (P.reverse ? T - 1 - step : step);
+        if (tail && !dh0p) break;
+        const int tt = tail ? 0 : (rev ? T - 1 - step : step);
         float pd[MS], psv[MS][5];
         if (!tail) {
 #pragma unroll
             for (int p = 0; p < MS; ++p) {
                 const int b = brow[p];
-                float d = P.dout ? P.dout[(long)tt * P.ts_dout + (long)b * P.ld_dout + jc] : 0.f;
-                if (step == T - 1 && P.dhn) d += P.dhn[(long)b * P.ld_dhn + jc];
-                pd[p] = d;
-                const float* sp = P.sv + ((long)tt * B + b) * H + jc;
+                const float d1 = doutp[tt * dout_ts + b * dout_ld + dout_j];
+                const float d2 = dhnp[b * dhn_ld + dhn_j];
+                const float* sp = svp + (tt * B + b) * H + jc;
 #pragma unroll
-                for (int a = 0; a < 5; ++a) psv[p][a] = sp[a * P.sv_astride];
+                for (int a = 0; a < 5; ++a) psv[p][a] = sp[a * sv_as];
+                pd[p] = step == T - 1 ? d1 + d2 : d1;
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < MS; ++p) pd[p] = P.dh0_accumulate ? P.dh0[(long)brow[p] * P.ld_dh0 + jc] : 0.f;
+            for (int p = 0; p < MS; ++p) pd[p] = dh0_acc ? dh0p[brow[p] * dh0_ld + jc] : 0.f;
         }
         float v[MS][1];
 #pragma unroll
         for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
         if (step != T - 1) {
-            if (!chain::wait_group(counter, (unsigned)((T - 1 - step) * A.members), A.status, &flag)) return;
+            if (!chain::wait_group(counter, (unsigned)((T - 1 - step) * members), status, &flag[step & 1])) return;
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -186,14 +225,14 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
 #pragma unroll
             for (int p = 0; p < MS; ++p) {
                 const int b = row0 + ((t + 256 * p) >> 4);
-                if (b < B) P.dh0[(long)b * P.ld_dh0 + jc] = v[p][0] + dhz[p] + pd[p];
+                if (b < B) dh0p[b * dh0_ld + jc] = v[p][0] + dhz[p] + pd[p];
             }
             break;
         }
+        float e_r[MS], e_z[MS], e_n[MS], e_nr[MS];
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const int rl = (t + 256 * p) >> 4;
-            const int b = row0 + rl;
             const float dh = v[p][0] + dhz[p] + pd[p];
             const float r = psv[p][0], z = psv[p][1], n = psv[p][2], ghn = psv[p][3], hprev = psv[p][4];
             const float dn_pre = dh * (1.f - z) * (1.f - n * n);
@@ -203,22 +242,28 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
             dhz[p] = dh * z;
             const int xo = rl * 16 + (t & 15);
             xt[0][xo] = dr_pre; xt[1][xo] = dz_pre; xt[2][xo] = dnr;
+            e_r[p] = dr_pre; e_z[p] = dz_pre; e_n[p] = dn_pre; e_nr[p] = dnr;
+        }
+        if (step != 0 || dh0p) {                   // (nothing reads the last gate gradients unless dh0 is wanted)
+            __syncthreads();
+            for (int blk = t >> 6; blk < 3 * MS; blk += 4) {
+                const int g = blk / MS, p = blk % MS;
+                if (rb0 + p <= rb_last)
+                    chain::publish_block(rs, (step & 1) * slot_bytes, xt[g], p, lane, rb0 + p, S3, g * (H >> 4) + member);
+            }
+            chain::arrive(counter);
+        }
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = row0 + ((t + 256 * p) >> 4);
             if (b < B) {
-                float* gi = P.dgi + (long)tt * P.ts_dgi + (long)b * P.ld_dgi;
-                gi[jc] = dr_pre; gi[H + jc] = dz_pre; gi[2 * H + jc] = dn_pre;
-                float* gh = P.dgh + ((long)tt * B + b) * 3 * H;
-                gh[jc] = dr_pre; gh[H + jc] = dz_pre; gh[2 * H + jc] = dnr;
-                bs[0] += dr_pre; bs[1] += dz_pre; bs[2] += dn_pre; bs[3] += dnr;
+                float* gi = dgip + tt * dgi_ts + b * dgi_ld;
+                gi[jc] = e_r[p]; gi[H + jc] = e_z[p]; gi[2 * H + jc] = e_n[p];
+                float* gh = dghp + (tt * B + b) * 3 * H;
+                gh[jc] = e_r[p]; gh[H + jc] = e_z[p]; gh[2 * H + jc] = e_nr[p];
+                bs[0] += e_r[p]; bs[1] += e_z[p]; bs[2] += e_n[p]; bs[3] += e_nr[p];
             }
         }
-        if (step == 0 && !P.dh0) break;            // nothing reads the last gate gradients from the exchange
-        __syncthreads();
-        for (int blk = t >> 6; blk < 3 * MS; blk += 4) {
-            const int g = blk / MS, p = blk % MS;
-            if (rb0 + p <= rb_last)
-                chain::publish_block(rs, (step & 1) * slot_bytes, xt[g], p, lane, rb0 + p, S3, g * (H >> 4) + member);
-        }
-        chain::arrive(counter);
     }
     if (P.db_ih) {
         __syncthreads();
@@ -241,10 +286,16 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
 }
 
 int rows_ms(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : 4); }
+int chain_prio() {
+    static int v = -1;
+    if (v < 0) { const char* e = std::getenv("INET_CHAIN_PRIO"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
 
 }  // namespace
 
 bool gru_chain_ok(int H, int B, int T, int nprob) {
+    if ((double)T * B * 6.0 * H >= 2.0e9) return false;   // the kernels index with 32-bit element offsets
     if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
     const int ms = rows_ms(B), tiles = (B + 16 * ms - 1) / (16 * ms);
     return nprob * tiles * (H / 16) <= 256;        // every workgroup must be resident at once (one per CU)
@@ -258,7 +309,8 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     const int groups = a.nprob * a.tiles_per_prob;
     if (groups > kChainMaxGroups) return -1;
     a.status.host = chain_host_status();
-    if (hipMemsetAsync(a.counters, 0, (kChainMaxGroups + 1) * sizeof(unsigned), s) != hipSuccess) return -2;
+    a.prio = chain_prio();
+    if (hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status.dev = a.counters + kChainMaxGroups;
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_fwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);
@@ -281,7 +333,8 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
     const int groups = a.nprob * a.tiles_per_prob;
     if (groups > kChainMaxGroups) return -1;
     a.status.host = chain_host_status();
-    if (hipMemsetAsync(a.counters, 0, (kChainMaxGroups + 1) * sizeof(unsigned), s) != hipSuccess) return -2;
+    a.prio = chain_prio();
+    if (hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status.dev = a.counters + kChainMaxGroups;
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_bwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);

@@ -197,7 +197,7 @@ template <int MS, int SQ>                          // SQ = H/64: k-steps of 16 p
 __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * MS * 256];
     __shared__ __attribute__((aligned(16))) float xt[MS * 256];
-    __shared__ unsigned flag;
+    __shared__ unsigned flag[2];
     int group, member;
     chain::decode_block(blockIdx.x, P.members, group, member);
     const int row0 = group * 16 * MS;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
 #pragma unroll
             for (int a = 0; a < 4; ++a) pg[p][a] = P.gi[((long)tt * B + b) * 4 * H + a * H + jc];
         }
-        if (step > 0 && !chain::wait_group(P.counters + group, (unsigned)(step * P.members), P.status, &flag)) return;
+        if (step > 0 && !chain::wait_group(P.counters + group, (unsigned)(step * P.members), P.status, &flag[step & 1])) return;
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -288,7 +288,7 @@ template <int MS, int SQ>                          // SQ = H/16: k-steps of 16 p
 __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P) {
     __shared__ __attribute__((aligned(16))) float red[4 * MS * 256];
     __shared__ __attribute__((aligned(16))) float xt[4][MS * 256];
-    __shared__ unsigned flag;
+    __shared__ unsigned flag[2];
     int group, member;
     chain::decode_block(blockIdx.x, P.members, group, member);
     const int row0 = group * 16 * MS;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
 #pragma unroll
         for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
         if (step != T - 1) {
-            if (!chain::wait_group(P.counters + group, (unsigned)((T - 1 - step) * P.members), P.status, &flag)) return;
+            if (!chain::wait_group(P.counters + group, (unsigned)((T - 1 - step) * P.members), P.status, &flag[step & 1])) return;
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};

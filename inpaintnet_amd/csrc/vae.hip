@@ -117,9 +117,12 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
     // GRU stack
     const float* dhn[4] = {w.dhcat, w.dhcat + H, w.dhcat + 2 * H, w.dhcat + 3 * H};
     INET_TRY(bigru2_core_bwd(B, T, H, P, mask, nullptr, dhn, 4L * H, nullptr, w.g, s));
-    // embedding / layer-0 input weights through the gather table
+    // embedding / layer-0 input weights through the gather table.  On the MAIN stream: these are the last items of the
+    // step's backward pass and the side stream is still busy with the layer-0 dW_hh products (r02 timeline: queued behind
+    // them they delayed the optimizer by ~0.14 ms).
     {
-        hipStream_t ss = side_fork(s);
+        static const bool emb_main = [] { const char* v = std::getenv("INET_EMB_MAIN"); return !(v && v[0] == '0'); }();
+        hipStream_t ss = emb_main ? s : side_fork(s);
         INET_TRY(pw_onehot(tokens, B, 1, T, T * B, V, w.onehot, 1, ss));     // row (t,b) -> tokens[b*T + t]
         for (int dir = 0; dir < 2; ++dir) {
             const float* dgi = w.g.dgi0 + dir * 3L * H;

@@ -47,6 +47,13 @@ def main(path, which=5, gap_us=12.0):
                 small += g
         prev_end = e
     print(f"  (+ {small:.1f} us in gaps below the threshold)")
+    # the end of the step in detail: what the optimizer is waiting for
+    print("last 1200 us of the step, both streams (start, end, stream, kernel, grid):")
+    for r in step:
+        s0 = (int(r["Start_Timestamp"]) - T0) / 1e3
+        e0 = (int(r["End_Timestamp"]) - T0) / 1e3
+        if e0 > (T1 - T0) / 1e3 - 1200 and e0 - s0 > 8:
+            print(f"  {s0:8.1f} {e0:8.1f}  s{r['Stream_Id']}  {short(r['Kernel_Name'])[:44]:<44} g={r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}")
     by = collections.defaultdict(lambda: [0, 0.0])
     for r in step:
         k = short(r["Kernel_Name"])
