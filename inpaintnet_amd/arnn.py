@@ -233,6 +233,46 @@ class ConstraintModelGaussianReg(Model):
             gen.append(prev)
         return [torch.stack(ws, 1)], torch.cat(gen, 0).t().unsqueeze(1).contiguous()
 
+    def forward_inpaint(self, score_tensor, metadata_tensor, constraints_loc, start_tick, end_tick):
+        """Inpainting as the testers use it (:261-346): the generation LSTMs read the ground truth up to start_tick
+        (teacher-forced, one batched pass that leaves their state), then ticks start_tick .. end_tick-1 are generated
+        one at a time -- the argmax of BATCH ELEMENT 0 is written to the whole batch, as in _forward_no_tf.
+        -> [weights (B, end_tick - start_tick, V)], gen_chorale (B, 1, L) with the generated window filled in."""
+        B, _, L = score_tensor.shape
+        if not 0 <= start_tick < end_tick <= L:
+            raise ValueError("need 0 <= start_tick < end_tick <= sequence length")
+        oc = self._constraints(score_tensor, metadata_tensor, constraints_loc)
+        tok_tm = score_tensor[:, 0].t()                                        # [L,B]
+        gen = torch.zeros_like(score_tensor)
+        gen[:, :, :start_tick] = score_tensor[:, :, :start_tick]
+        gen[:, :, end_tick:] = score_tensor[:, :, end_tick:]
+        # teacher-forced prefix: ticks 0 .. start_tick-1 (input = zero vector, then the embedded ground truth shifted by one)
+        if start_tick > 0:
+            shifted = torch.cat((torch.zeros_like(tok_tm[:1]), tok_tm[:start_tick - 1]), 0)
+            scale = torch.ones(start_tick, B, dtype=torch.float32, device=tok_tm.device)
+            if self.training and self.dropout_input_prob > 0:
+                scale = ops.dropout_mask((start_tick, B), self.dropout_input_prob, _DropState.seed,
+                                         _next_mask_offset(start_tick * B), tok_tm.device)
+            scale[0] = 0.0
+        states = [None] * self.num_layers
+        if start_tick > 0:
+            h = torch.cat((self._embed("note_embeddings.0.weight", shifted, scale.view(-1)), oc[:start_tick]), 2)
+            for l in range(self.num_layers):
+                h, hT, cT = self._lstm(f"lstm_generation.{l}", h, False)
+                states[l] = (hT, cT)
+        ws = []
+        for tick in range(start_tick - 1, end_tick - 1):
+            # token at `tick` predicts tick + 1; before the first tick the start symbol 0 is embedded (:308-313)
+            prev = gen[:, 0, tick].reshape(1, B).contiguous() if tick >= 0 else torch.zeros(1, B, dtype=torch.int64, device=gen.device)
+            inp = torch.cat((self._embed("note_embeddings.0.weight", prev), oc[tick + 1:tick + 2]), 2)
+            for l in range(self.num_layers):
+                inp, hT, cT = self._lstm(f"lstm_generation.{l}", inp, False, states[l])
+                states[l] = (hT, cT)
+            w = self._head(inp.view(B, -1))
+            ws.append(w)
+            gen[:, 0, tick + 1] = ops.argmax_rows(w.detach()[0:1]).view(1)     # batch element 0 decides (:340-343)
+        return [torch.stack(ws, 1)], gen
+
     def forward(self, score_tensor, metadata_tensor, constraints_loc, start_tick=None, end_tick=None, train=True,
                 teacher_forcing=None):
         """-> list (one per voice) of (B, n_unconstrained, V) weights, extra   (:406-435)"""
@@ -245,6 +285,14 @@ class ConstraintModelGaussianReg(Model):
         weights, add_args = fwd(score_tensor, metadata_tensor, constraints_loc)
         free = (constraints_loc[0, 0, :] == 0).nonzero().squeeze(-1)
         return [w[:, free, :] for w in weights], add_args
+
+
+class AnticipationRNNBaseline(ConstraintModelGaussianReg):
+    """The unconstrained-position baseline of the reference (:682-726): the same network under another name (its
+    checkpoints live in their own file); what differs is the trainer's constraint sampling."""
+
+    def __repr__(self):
+        return super().__repr__().replace('AnticipationRNNReg(', 'AnticipationRNNBaseline(', 1)
 
 
 class AnticipationRNNGaussianRegTrainer(Trainer):
@@ -300,3 +348,20 @@ class AnticipationRNNGaussianRegTrainer(Trainer):
 
     def update_scheduler(self, epoch_num):
         return
+
+
+class AnticipationRNNBaselineTrainer(AnticipationRNNGaussianRegTrainer):
+    """AnticipationRNN/anticipation_rnn_trainer.py:185-210: constraints are not a contiguous window but an i.i.d. Bernoulli
+    mask over the ticks (rate p ~ U(0, 0.5) per batch, the same mask for every sequence of the batch).  The draws use
+    Python's `random` (p) and torch's CPU generator (the mask), in the reference's order."""
+
+    def __init__(self, dataset, model, lr=1e-4, early_stopping=False):
+        super().__init__(dataset, model, lr, early_stopping)
+        self.constraint_prod = 0.5
+
+    def process_batch_data(self, batch):
+        score_tensor, metadata_tensor = batch
+        p = random.random() * 0.5
+        loc = (torch.rand(*score_tensor[0, :, :].size()) < p).unsqueeze(0).repeat(score_tensor.size(0), 1, 1)
+        return (to_cuda_variable_long(score_tensor), to_cuda_variable_long(metadata_tensor),
+                to_cuda_variable_long(loc.to(torch.int32)), None, None)

@@ -15,7 +15,7 @@ import random
 
 import torch
 
-from . import dp, ops
+from . import dp, layout, ops
 from ._lib import LatentConfig
 from .measure_vae import MeasureVAE, _DropState, _next_mask_offset
 from .model import Model
@@ -91,7 +91,15 @@ class LatentRNN(Model):
         self.gen_rnn_input_dim = self.z_dim if self.auto_reg else 1
         self.trainable = True
         self.lcfg = LatentConfig(self.z_dim, rnn_hidden_size, int(bool(auto_reg)))
-        table, total = ops.latent_param_table(self.lcfg)
+        # which contexts initialise the generator: both (LatentRNN) or one of them (LatentRNNAblations)
+        self.context_mode = getattr(self, "context_mode", "both")
+        self.gen_hidden = 2 * rnn_hidden_size if self.context_mode == "both" else rnn_hidden_size
+        if self.context_mode == "both":
+            table, total = ops.latent_param_table(self.lcfg)
+        else:
+            offs, total = layout.arena_offsets(layout.latent_param_shapes(self.z_dim, rnn_hidden_size, bool(auto_reg),
+                                                                          gen_hidden=self.gen_hidden))
+            table = [(k, off, shp) for k, (off, shp) in offs.items()]
         self._alloc_arena(table, total, self.vae_model.flat.device)
         self._off = {name: off for name, off, _ in table}
         # arena order: x_0 | context_rnn_past | context_rnn_future | generation_rnn | generation_linear; backward visits
@@ -178,26 +186,36 @@ class LatentRNN(Model):
         eps: optional (eps_past (B,np,Z), eps_future, eps_target) injection; eps_ar: list of (B,Z) for the
         free-running auto-regressive path."""
         batch_size, _, measure_seq_len = past_context.size()
-        n_past, n_future, n_target = past_context.size(1), future_context.size(1), target.size(1)
+        n_past, n_future = past_context.size(1), future_context.size(1)
+        n_target = target.size(1) if target is not None else 0        # inference: no target (latent_rnn_tester.py:231-236)
         # one encoder call over all measures of the sequence
-        allm = torch.cat((past_context, target, future_context), 1)
+        parts = (past_context, target, future_context) if target is not None else (past_context, future_context)
+        allm = torch.cat(parts, 1)
         e = None
         if eps is not None:
-            e = torch.cat((eps[0].view(batch_size, n_past, -1), eps[2].view(batch_size, n_target, -1),
-                           eps[1].view(batch_size, n_future, -1)), 1)
+            es = [eps[0].view(batch_size, n_past, -1)]
+            if target is not None:
+                es.append(eps[2].view(batch_size, n_target, -1))
+            es.append(eps[1].view(batch_size, n_future, -1))
+            e = torch.cat(es, 1)
         z_all = self.get_z_seq(allm, e)
         zp = z_all[:, :n_past].contiguous()
         zt = z_all[:, n_past:n_past + n_target].contiguous()
         zf = z_all[:, n_past + n_target:].contiguous()
-        context_past = self.forward_context(zp, type="past")
-        context_future = self.forward_context(zf, type="future")
-        comb_context = torch.cat((context_past, context_future), 2)
+        if self.context_mode == "both":
+            comb_context = torch.cat((self.forward_context(zp, type="past"), self.forward_context(zf, type="future")), 2)
+        elif self.context_mode == "past":                          # latent_rnn_ablations.py:143-146
+            comb_context = self.forward_context(zp, type="past")
+        else:
+            comb_context = self.forward_context(zf, type="future")
         if teacher_forcing is None:
             if self.use_teacher_forcing and train:
                 teacher_forcing = random.random() < self.teacher_forcing_prob
             else:
                 teacher_forcing = False
         if teacher_forcing:
+            if target is None:
+                raise ValueError("teacher forcing needs the target measures")
             seed = torch.cat((zp[:, -1, :].unsqueeze(1), zt[:, :-1, :]), 1)
         else:
             seed = zp[:, -1, :].unsqueeze(1)
@@ -208,7 +226,7 @@ class LatentRNN(Model):
                            eps_ar=None):
         """latent_rnn.py:211-263"""
         batch_size = context_vector.size(1)
-        Hg = 2 * self.rnn_hidden_size
+        Hg = self.gen_hidden
         if teacher_forcing or not self.auto_reg:
             if self.auto_reg:
                 out, _ = self._bigru("generation_rnn", seed.contiguous(), None, context_vector, Hg, self.z_dim)

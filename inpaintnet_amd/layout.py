@@ -59,17 +59,21 @@ def vae_param_shapes(num_notes, emb_dim=10, enc_hidden=512, z_dim=256, dec_hidde
     return OrderedDict(p)
 
 
-def latent_param_shapes(z_dim=256, rnn_hidden=512, auto_reg=False):
+def latent_param_shapes(z_dim=256, rnn_hidden=512, auto_reg=False, gen_hidden=None):
     """Trainable LatentRNN parameters only (the frozen VAE lives in its own
-    arena and appears in state_dict() under 'vae_model.').  latent_rnn.py:53-83."""
+    arena and appears in state_dict() under 'vae_model.').  latent_rnn.py:53-83.
+    gen_hidden: hidden size of the generation GRU -- 2*rnn_hidden for the LatentRNN (its initial state is the
+    concatenation of both contexts), rnn_hidden for the past-only / future-only ablations
+    (latent_rnn_ablations.py:77-85)."""
     Z, H = z_dim, rnn_hidden
+    G = 2 * H if gen_hidden is None else gen_hidden
     p = []
     if not auto_reg:
         p.append(("x_0", (1, 1, 1)))
     p += _gru("context_rnn_past", Z, H, 2, True)
     p += _gru("context_rnn_future", Z, H, 2, True)
-    p += _gru("generation_rnn", Z if auto_reg else 1, 2 * H, 2, True)
-    p.append(("generation_linear.weight", (Z, 4 * H)))
+    p += _gru("generation_rnn", Z if auto_reg else 1, G, 2, True)
+    p.append(("generation_linear.weight", (Z, 2 * G)))
     p.append(("generation_linear.bias", (Z,)))
     return OrderedDict(p)
 

@@ -392,6 +392,147 @@ def gen_split_helpers():
     print("wrote split_helpers.npz")
 
 
+def gen_latent_ablation(kind):
+    """LatentRNNAblations (past-only / future-only context, generator hidden = H): forward + one trainer step (f4)."""
+    from LatentRNN.latent_rnn_ablations import LatentRNNAblations
+    import LatentRNN.latent_rnn_ablations as ref_abl_mod
+    c = dict(CFGS["small"])
+    V, Z, B, H = c["V"], c["Z"], c["B"], c["H"]
+    vae = build_vae(c, dropout=0.0)
+    load_det_weights(vae)
+    model = LatentRNNAblations(FakeDataset(V), vae, num_rnn_layers=2, rnn_hidden_size=H, dropout=0.0,
+                               rnn_class=torch.nn.GRU, auto_reg=False, teacher_forcing=True, type=kind)
+    wts = load_det_weights(model)
+    tag = f"latent_small_abl_{kind}"
+    fx = {"param/" + k: v for k, v in wts.items()}
+    score = torch.from_numpy(synthetic.folk_score(B, V, seed=3))
+    fx["score"] = score.numpy()
+    n_past, n_target, n_future = 6, 4, 6
+    trainer = LatentRNNTrainer(FakeDataset(V), model, lr=1e-4)
+    past, future, target = LatentRNNTrainer.split_score(score, n_past, n_future, n_target, 24)
+    fx["split"] = np.array([n_past, n_target, n_future])
+    model.train()
+    ref_abl_mod.random.random = lambda: 0.9
+    with EpsQueue() as q:
+        e_p = q.push(f"eps_p/{tag}", (B * n_past, Z))
+        e_f = q.push(f"eps_f/{tag}", (B * n_future, Z))
+        e_t = q.push(f"eps_t/{tag}", (B * n_target, Z))
+        fx["eps_past"], fx["eps_future"], fx["eps_target"] = e_p.numpy(), e_f.numpy(), e_t.numpy()
+        trainer.zero_grad()
+        weights, samples, gen_z = model(past, future, target, n_target, train=True)
+    loss = trainer.mean_crossentropy_loss_alt(weights=weights, targets=target)
+    acc = trainer.mean_accuracy_alt(weights=weights, targets=target)
+    loss.backward()
+    fx["weights"], fx["samples"] = weights.detach().numpy(), samples.detach().numpy()
+    fx["margin"] = top2_margin(weights.detach())
+    fx["gen_z"] = gen_z.detach().numpy()
+    fx["loss_acc"] = np.array([loss.item(), acc.item()], dtype=np.float64)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            fx["grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    trainer.step()
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            fx["after1/" + k] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
+    print("wrote %s.npz (%d arrays)" % (tag, len(fx)))
+
+
+def gen_inference():
+    """Inference surface (f3): MeasureVAE.forward_test, VAETester.decode_mid_point, and B = 1 inpainting as
+    LatentRNNTester.generate runs it (eval mode, no teacher forcing) for the non-AR and the auto-regressive model."""
+    from MeasureVAE.vae_tester import VAETester
+    c = dict(CFGS["small"])
+    V, Z, H = c["V"], c["Z"], c["H"]
+    vae = build_vae(c, dropout=0.0)
+    load_det_weights(vae)
+    vae.eval()
+    fx = {}
+    # forward_test: (B, M, 24); one rsample per measure, in measure order
+    B, M = 2, 3
+    tok = torch.from_numpy(synthetic.det_tokens("inf/ft", (B, M, 24), V))
+    fx["ft_tokens"] = tok.numpy()
+    with EpsQueue() as q, torch.no_grad():
+        for i in range(M):
+            fx[f"ft_eps{i}"] = q.push(f"inf/ft_eps{i}", (B, Z)).numpy()
+        w, s = vae.forward_test(tok)
+    fx["ft_weights"], fx["ft_samples"], fx["ft_margin"] = w.numpy(), s.numpy(), top2_margin(w)
+    # decode_mid_point
+    tester = VAETester(FakeDataset(V), vae)
+    z1 = torch.from_numpy(synthetic.det_normal("inf/z1", (1, Z)))
+    z2 = torch.from_numpy(synthetic.det_normal("inf/z2", (1, Z)))
+    with torch.no_grad():
+        mid = tester.decode_mid_point(z1, z2, 3)
+        ws = [vae.decoder(z1 + (z2 - z1) * i / 4, torch.zeros(1, 24), False)[0] for i in range(5)]
+    fx["mid_z1"], fx["mid_z2"], fx["mid_tokens"] = z1.numpy(), z2.numpy(), mid.numpy()
+    fx["mid_margin"] = top2_margin(torch.cat(ws, 0))
+    # generate: B = 1, past 5 / target 3 / future 8 measures
+    for auto_reg in (False, True):
+        model = LatentRNN(FakeDataset(V), vae, num_rnn_layers=2, rnn_hidden_size=H, dropout=0.0,
+                          rnn_class=torch.nn.GRU, auto_reg=auto_reg, teacher_forcing=True)
+        load_det_weights(model)
+        model.eval()
+        tag = "gen_ar" if auto_reg else "gen_nar"
+        score = torch.from_numpy(synthetic.folk_score(1, V, seed=41))
+        past, future, target = LatentRNNTrainer.split_score(score, 5, 8, 3, 24)
+        fx[f"{tag}_score"] = score.numpy()
+        with EpsQueue() as q, torch.no_grad():
+            fx[f"{tag}_eps_past"] = q.push(f"inf/{tag}/p", (5, Z)).numpy()
+            fx[f"{tag}_eps_future"] = q.push(f"inf/{tag}/f", (8, Z)).numpy()
+            fx[f"{tag}_eps_target"] = q.push(f"inf/{tag}/t", (3, Z)).numpy()
+            if auto_reg:
+                for i in range(3):
+                    fx[f"{tag}_eps_ar{i}"] = q.push(f"inf/{tag}/ar{i}", (1, Z)).numpy()
+            w, s, gz = model(past, future, target, 3, train=False)
+        fx[f"{tag}_weights"], fx[f"{tag}_samples"], fx[f"{tag}_gen_z"] = w.numpy(), s.numpy(), gz.numpy()
+        fx[f"{tag}_margin"] = top2_margin(w)
+        fx[f"{tag}_full"] = torch.cat((past, s.view(1, 3, 24), future), 1).numpy()
+    np.savez_compressed(os.path.join(OUT, "inference_small.npz"), **fx)
+    print("wrote inference_small.npz (%d arrays)" % len(fx))
+
+
+def gen_arnn_inpaint():
+    """ConstraintModelGaussianReg.forward_inpaint (eval mode) and the baseline trainer's constraint sampling (f4)."""
+    import random as pyrandom
+    from AnticipationRNN.anticipation_rnn_gauss_reg_model import AnticipationRNNBaseline
+    from AnticipationRNN.anticipation_rnn_trainer import AnticipationRNNBaselineTrainer
+    c = ARNN_CFGS["small"]
+    V, B, L = c["V"], c["B"], 384
+    ds = FakeDataset(V)
+    model = AnticipationRNNBaseline(ds, note_embedding_dim=c["E"], metadata_embedding_dim=c["Em"],
+                                    num_lstm_constraints_units=c["H"], num_lstm_generation_units=c["H"],
+                                    linear_hidden_size=c["LH"], num_layers=2, dropout_input_prob=0.0,
+                                    dropout_prob=0.0, unary_constraint=True, teacher_forcing=True)
+    load_det_weights(model)
+    model.eval()
+    fx = {"repr": np.array(repr(model))}
+    score = torch.from_numpy(synthetic.folk_score(B, V, seed=11)).long()
+    metadata = torch.from_numpy(synthetic.folk_metadata(B)).long()
+    metadata[..., 0] = torch.from_numpy(synthetic.det_tokens("arnn/md0", (B, 1, L), 6))
+    start_tick, end_tick = 7 * 24, 7 * 24 + 2 * 24
+    loc = torch.zeros_like(score)
+    loc[:, :, :start_tick] = 1
+    loc[:, :, end_tick:] = 1
+    fx["score"], fx["metadata"], fx["constraints_loc"] = score.numpy(), metadata.numpy(), loc.numpy()
+    fx["ticks"] = np.array([start_tick, end_tick])
+    with torch.no_grad():
+        w, gen = model.forward_inpaint(score, metadata, loc, start_tick, end_tick)
+    fx["inpaint_weights"], fx["inpaint_gen"] = w[0].numpy(), gen.numpy()
+    fx["inpaint_margin_row0"] = top2_margin(w[0][0])
+    trainer = AnticipationRNNBaselineTrainer(ds, model)
+    pyrandom.seed(99)
+    torch.manual_seed(99)
+    locs = []
+    for _ in range(3):
+        out = trainer.process_batch_data((score.int(), metadata.int()))
+        locs.append(out[2].numpy())
+        assert out[3] is None and out[4] is None
+    fx["baseline_seed"] = np.array(99)
+    fx["baseline_locs"] = np.stack(locs)
+    np.savez_compressed(os.path.join(OUT, "arnn_inpaint_small.npz"), **fx)
+    print("wrote arnn_inpaint_small.npz (%d arrays)" % len(fx))
+
+
 def gen_feed_helpers():
     """Batch preparation on the host side of the reference, with its own RNG consumption (SURVEY 8c fixture 7):
     VAETrainer.process_batch_data (vae_trainer.py:42-55) for an N-bars dataset, LatentRNNTrainer.split_score_stochastic
@@ -448,7 +589,7 @@ def gen_feed_helpers():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["vae", "latent", "arnn", "split", "feed"]
+    which = sys.argv[1:] or ["vae", "latent", "arnn", "split", "feed", "ablation", "inference", "inpaint"]
     if "vae" in which:
         for n, c in CFGS.items():
             gen_vae(n, c)
@@ -467,3 +608,10 @@ if __name__ == "__main__":
         gen_split_helpers()
     if "feed" in which:
         gen_feed_helpers()
+    if "ablation" in which:
+        gen_latent_ablation("past")
+        gen_latent_ablation("future")
+    if "inference" in which:
+        gen_inference()
+    if "inpaint" in which:
+        gen_arnn_inpaint()

@@ -18,7 +18,9 @@ What is restated (reference file:line each function follows):
   vae_forward                       MeasureVAE/measure_vae.py:97-134
   vae_loss                          MeasureVAE/vae_trainer.py:16-40,128-139; utils/trainer.py:271-306
   adam_step                         torch.optim.Adam as built at utils/trainer.py:32-35 (torch 2.10 form)
-  latent_forward                    LatentRNN/latent_rnn.py:110-263
+  latent_forward                    LatentRNN/latent_rnn.py:110-263; context="past"/"future": LatentRNN/latent_rnn_ablations.py
+  vae_forward_test / decode_mid_point  MeasureVAE/measure_vae.py:136-169, MeasureVAE/vae_tester.py:72-93
+  arnn_forward_inpaint              AnticipationRNN/anticipation_rnn_gauss_reg_model.py:261-346
   latent_loss                       LatentRNN/latent_rnn_trainer.py:36-67; utils/trainer.py:344-376
   split_score                       LatentRNN/latent_rnn_trainer.py:134-176
 
@@ -226,6 +228,29 @@ def vae_forward(P, tokens, eps, teacher_forced, masks=None, feed_tokens=None, ki
     return w, s, mu, ls, z
 
 
+def vae_forward_test(P, measures, eps_list):
+    """MeasureVAE.forward_test (measure_vae.py:136-169): measures (B,M,T); one rsample per measure (eps_list[i] (B,Z)),
+    eval-mode decode of every measure.  -> weights (B,M,T,V), samples (B,1,M*T)."""
+    ws, ss = [], []
+    for i in range(measures.shape[1]):
+        mu, ls = encoder_forward(P, measures[:, i])
+        w, smp = decoder_forward(P, mu + eps_list[i] * torch.exp(ls), None, False)
+        ws.append(w.unsqueeze(1))
+        ss.append(smp)
+    return torch.cat(ws, 1), torch.cat(ss, 2)
+
+
+def decode_mid_point(P, z1, z2, n):
+    """VAETester.decode_mid_point (vae_tester.py:72-93): tokens of z1, n interpolated points, z2 -> (1, (n+2)*T);
+    also returns the stacked logits (n+2, T, V)."""
+    toks, ws = [], []
+    for i in range(n + 2):
+        w, smp = decoder_forward(P, z1 + (z2 - z1) * i / (n + 1), None, False)
+        toks.append(smp[:, 0])
+        ws.append(w)
+    return torch.cat(toks, 1).view(1, -1), torch.cat(ws, 0)
+
+
 def cross_entropy_mean(weights, targets):
     V = weights.shape[-1]
     return F.cross_entropy(weights.reshape(-1, V), targets.reshape(-1), reduction="mean")
@@ -283,11 +308,13 @@ def latent_get_z(P, measures, eps, enc_mask=None):
 
 
 def latent_forward(P, past, future, target, eps_p, eps_f, eps_t, auto_reg=False,
-                   teacher_forcing=False, eps_ar=None, masks=None, feed_tokens=None, dec_kinks=None):
+                   teacher_forcing=False, eps_ar=None, masks=None, feed_tokens=None, dec_kinks=None, context="both"):
     """latent_rnn.py:110-263.  Returns weights (B,nt,T,V), samples (B,1,nt*T), gen_z (B,nt,Z).
     masks: {'ctx_past','ctx_future','gen': layer0->1 masks; 'dec': list of per-measure decoder masks;
     'enc_past','enc_future','enc_target': encoder masks of the three get_z_seq calls}.
-    feed_tokens (B,nt,T): see decoder_forward.  dec_kinks: list (one per generated measure) of decoder_forward `kinks`."""
+    feed_tokens (B,nt,T): see decoder_forward.  dec_kinks: list (one per generated measure) of decoder_forward `kinks`.
+    context: "both" (LatentRNN) | "past" | "future" (LatentRNNAblations, latent_rnn_ablations.py:143-146: the generator
+    starts from one context only and has hidden size H instead of 2H)."""
     masks = masks or {}
     B, nt, T = target.shape
     with torch.no_grad():
@@ -301,7 +328,7 @@ def latent_forward(P, past, future, target, eps_p, eps_f, eps_t, auto_reg=False,
         return [masks[k]] if masks.get(k) is not None else None
     _, cp = gru_stack(zp, h0, P, "context_rnn_past", 2, True, m1("ctx_past"))
     _, cf = gru_stack(zf, h0, P, "context_rnn_future", 2, True, m1("ctx_future"))
-    ctx = torch.cat((cp, cf), 2)
+    ctx = torch.cat((cp, cf), 2) if context == "both" else (cp if context == "past" else cf)
     dec_masks = masks.get("dec") or [None] * nt
 
     def decode(zi, i):
@@ -512,6 +539,44 @@ def arnn_forward(P, score, metadata, constraints_loc, teacher_forcing, num_layer
         prev = tok.expand(B).clone()
         gen.append(prev)
     return torch.stack(ws, 1), torch.stack(gen, 1)
+
+
+def arnn_forward_inpaint(P, score, metadata, constraints_loc, start_tick, end_tick, num_layers=2):
+    """forward_inpaint (anticipation_rnn_gauss_reg_model.py:261-346), eval mode: the generation LSTMs consume the ground
+    truth up to start_tick in one pass, then ticks start_tick..end_tick-1 are generated one by one from the argmax of batch
+    element 0.  -> weights (B, end-start, V), gen (B,1,L)."""
+    B, _, L = score.shape
+    x, m = arnn_embed(P, score, metadata, constraints_loc)
+    Hc = P["lstm_constraint.0.weight_hh_l0"].shape[1]
+    z = torch.zeros(B, Hc)
+    oc = m
+    for l in range(num_layers):
+        oc, _ = lstm_layer(oc, z, z, P, f"lstm_constraint.{l}", reverse=True)
+    Hg = P["lstm_generation.0.weight_hh_l0"].shape[1]
+    hs = [torch.zeros(B, Hg) for _ in range(num_layers)]
+    cs = [torch.zeros(B, Hg) for _ in range(num_layers)]
+    gen = torch.zeros_like(score)
+    gen[:, :, :start_tick] = score[:, :, :start_tick]
+    gen[:, :, end_tick:] = score[:, :, end_tick:]
+    if start_tick > 0:
+        off = torch.cat((torch.zeros(B, 1, x.shape[2]), x[:, :L - 1]), 1)
+        h = torch.cat((off, oc), 2)[:, :start_tick]
+        for l in range(num_layers):
+            h, (hs[l], cs[l]) = lstm_layer(h, hs[l], cs[l], P, f"lstm_generation.{l}")
+    E = P["note_embeddings.0.weight"]
+    ws = []
+    for tick in range(start_tick - 1, end_tick - 1):
+        prev = gen[:, 0, tick] if tick >= 0 else torch.zeros(B, dtype=torch.long)
+        inp = torch.cat((E[prev], oc[:, tick + 1]), 1)
+        for l in range(num_layers):
+            pf = f"lstm_generation.{l}"
+            gi = inp @ P[f"{pf}.weight_ih_l0"].t() + P[f"{pf}.bias_ih_l0"]
+            hs[l], cs[l] = lstm_cell(gi, hs[l], cs[l], P[f"{pf}.weight_hh_l0"], P[f"{pf}.bias_hh_l0"])
+            inp = hs[l]
+        w = _arnn_head(P, inp)
+        ws.append(w)
+        gen[:, 0, tick + 1] = argmax_first(w[0].detach())
+    return torch.stack(ws, 1), gen
 
 
 def arnn_loss(weights_free, targets_free):

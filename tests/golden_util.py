@@ -71,3 +71,8 @@ def arnn_params(name, fx=None):
             if "param/" + k in fx.files:
                 assert np.array_equal(fx["param/" + k], P[k].numpy()), k
     return P
+
+
+def latent_params_from_fixture(fx, prefix="param/"):
+    """state_dict of a fixture that stores its full weights (small configs)."""
+    return {k[len(prefix):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(prefix)}

@@ -1,0 +1,170 @@
+"""GPU parity of the widened rows through the public classes, against golden vectors
+captured from the reference: LatentRNNAblations (past-only / future-only), MeasureVAE.forward_test,
+VAETester.decode_mid_point, LatentRNNTester.generate (B = 1 inpainting, non-AR and auto-regressive),
+ConstraintModelGaussianReg.forward_inpaint, AnticipationRNNBaseline(+Trainer)."""
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from inpaintnet_amd import ops, synthetic
+    from inpaintnet_amd.arnn import AnticipationRNNBaseline, AnticipationRNNBaselineTrainer
+    from inpaintnet_amd.latent_rnn import LatentRNN
+    from inpaintnet_amd.latent_rnn_ablations import LatentRNNAblations
+    from inpaintnet_amd.latent_rnn_tester import LatentRNNTester
+    from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    from inpaintnet_amd.vae_tester import VAETester
+
+
+def small_vae():
+    c = G.CFGS["small"]
+    ds = synthetic.SyntheticFolkDataset(num_notes=c["V"])
+    vae = MeasureVAE(ds, note_embedding_dim=c["E"], encoder_hidden_size=c["H"], latent_space_dim=c["Z"],
+                     decoder_hidden_size=c["H"], encoder_dropout_prob=0.0, decoder_dropout_prob=0.0)
+    vae.load_state_dict(G.vae_params("small"))
+    return c, ds, vae
+
+
+@pytest.mark.parametrize("kind", ["past", "future"])
+def test_latent_ablation_matches_reference(kind):
+    fx = G.load(f"latent_small_abl_{kind}")
+    c, ds, vae = small_vae()
+    model = LatentRNNAblations(ds, vae, num_rnn_layers=2, rnn_hidden_size=c["H"], dropout=0.0, rnn_class=torch.nn.GRU,
+                               auto_reg=False, teacher_forcing=True, type=kind)
+    sd = G.latent_params_from_fixture(fx)
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd)
+    assert "LatentRNN(" + kind in repr(model) and model.gen_hidden == c["H"]
+    trainer = LatentRNNTrainer(ds, model, lr=1e-4)
+    model.train()
+    score = torch.from_numpy(fx["score"])
+    n_past, n_target, n_future = [int(x) for x in fx["split"]]
+    past, future, target = LatentRNNTrainer.split_score(score, n_past, n_future, n_target, 24)
+    eps = tuple(torch.from_numpy(fx[k]).cuda() for k in ("eps_past", "eps_future", "eps_target"))
+    trainer.zero_grad()
+    w, s, gz = model(past, future, target, n_target, train=True, eps=eps)
+    assert G.rel_err(gz.detach().cpu(), fx["gen_z"]) < 2e-4 and G.rel_err(w.detach().cpu(), fx["weights"]) < 2e-4
+    ok = G.unique_rows(fx["margin"], 1e-3).reshape(score.shape[0], -1)
+    assert np.array_equal(s.cpu().numpy()[:, 0][ok], fx["samples"][:, 0][ok])
+    loss, acc = trainer.mean_crossentropy_loss_and_accuracy(w, target)
+    loss.backward()
+    assert abs(float(loss.detach()) - fx["loss_acc"][0]) < 1e-4 * abs(fx["loss_acc"][0]) and abs(float(acc) - fx["loss_acc"][1]) < 1e-6
+    bad = []
+    for k, _ in model.named_parameters():
+        g, ref = model.param_grad(k).cpu().numpy(), fx["grad/" + k]
+        err = np.abs(g - ref).max() / (np.abs(ref).max() + 1e-7)
+        if not err < 1e-3:
+            bad.append((k, float(err)))
+    assert not bad, bad
+    trainer.step()
+    for k, _ in model.named_parameters():
+        assert np.abs(model.param(k).cpu().numpy() - fx["after1/" + k]).max() < 1e-5, k
+
+
+def test_forward_test_and_decode_mid_point(monkeypatch):
+    fx = G.load("inference_small")
+    c, ds, vae = small_vae()
+    vae.eval()
+    tok = torch.from_numpy(fx["ft_tokens"]).cuda()
+    B, M = tok.shape[:2]
+    # forward_test encodes all B*M measures in one call, rows ordered (b, measure): interleave the per-measure eps
+    eps = torch.stack([torch.from_numpy(fx[f"ft_eps{i}"]) for i in range(M)], 1).reshape(B * M, -1).cuda()
+    monkeypatch.setattr(torch, "randn_like", lambda t: eps)
+    with torch.no_grad():
+        w, s = vae.forward_test(tok)
+    assert w.shape == fx["ft_weights"].shape and s.shape == fx["ft_samples"].shape and s.dtype == torch.int64
+    assert G.rel_err(w.cpu(), fx["ft_weights"]) < 1e-4
+    ok = G.unique_rows(fx["ft_margin"]).reshape(B, -1)
+    assert np.array_equal(s.cpu().numpy()[:, 0][ok], fx["ft_samples"][:, 0][ok])
+    monkeypatch.undo()
+    tester = VAETester(ds, vae)
+    mid = tester.decode_mid_point(torch.from_numpy(fx["mid_z1"]).cuda(), torch.from_numpy(fx["mid_z2"]).cuda(), 3)
+    okm = G.unique_rows(fx["mid_margin"]).reshape(1, -1)
+    assert mid.shape == fx["mid_tokens"].shape and np.array_equal(mid.cpu().numpy()[okm], fx["mid_tokens"][okm])
+    _, inter = tester.test_interpolation(tok[0, :1], tok[1, :1], n=2)
+    assert inter.shape == (1, 4 * 24)
+
+
+@pytest.mark.parametrize("auto_reg", [False, True])
+def test_generate_inpaints_like_the_reference(auto_reg, monkeypatch):
+    fx = G.load("inference_small")
+    tag = "gen_ar" if auto_reg else "gen_nar"
+    c, ds, vae = small_vae()
+    model = LatentRNN(ds, vae, num_rnn_layers=2, rnn_hidden_size=c["H"], dropout=0.0, rnn_class=torch.nn.GRU,
+                      auto_reg=auto_reg, teacher_forcing=True)
+    model.load_state_dict(G.latent_params("small", auto_reg))
+    tester = LatentRNNTester(ds, model)
+    score = torch.from_numpy(fx[f"{tag}_score"])
+    past, future, target = LatentRNNTrainer.split_score(score, 5, 8, 3, 24)
+    # generate() encodes past | future (no target); the auto-regressive path then re-encodes each generated measure
+    queue = [torch.cat((torch.from_numpy(fx[f"{tag}_eps_past"]), torch.from_numpy(fx[f"{tag}_eps_future"])), 0).cuda()]
+    if auto_reg:
+        queue += [torch.from_numpy(fx[f"{tag}_eps_ar{i}"]).cuda() for i in range(3)]
+    monkeypatch.setattr(torch, "randn_like", lambda t: queue.pop(0))
+    _, full, _ = tester.generate(past, future, target, 3, eval=True)
+    assert full.shape == (1, 16, 24) and full.dtype == torch.int64
+    w = tester.last_weights
+    okg = G.unique_rows(fx[f"{tag}_margin"], 1e-4).reshape(1, 3, 24)
+    got = full.cpu().numpy()
+    assert np.array_equal(got[:, :5], fx[f"{tag}_full"][:, :5]) and np.array_equal(got[:, 8:], fx[f"{tag}_full"][:, 8:])
+    if not auto_reg or np.array_equal(got, fx[f"{tag}_full"]):
+        assert G.rel_err(w.cpu(), fx[f"{tag}_weights"]) < 2e-4
+        assert np.array_equal(got[:, 5:8][okg], fx[f"{tag}_full"][:, 5:8][okg])
+    else:
+        assert G.rel_err(w.cpu()[:, 0], fx[f"{tag}_weights"][:, 0]) < 2e-4
+    assert 0.0 <= tester.last_eval[1] <= 1.0
+    # contexts may be omitted: 3 START measures / 1 END measure are substituted (latent_rnn_tester.py:268-296)
+    ds.note2index_dicts[0].update({"START": 1, "END": 2, "rest": 3})
+    queue[:] = [torch.zeros(4, c["Z"]).cuda()] + [torch.zeros(1, c["Z"]).cuda()] * 3
+    _, full2, orig = tester.generate(None, None, None, 2)
+    assert full2.shape == (1, 3 + 2 + 1, 24) and orig is None
+    assert int(full2[0, 0, 0]) == 1 and int(full2[0, -1, 0]) == 2
+
+
+def test_arnn_forward_inpaint_and_baseline():
+    fx = G.load("arnn_inpaint_small")
+    c = G.ARNN_CFGS["small"]
+    ds = synthetic.SyntheticFolkDataset(num_notes=c["V"])
+    ds.metadatas = [types.SimpleNamespace(num_values=6), types.SimpleNamespace(num_values=6)]
+    model = AnticipationRNNBaseline(ds, note_embedding_dim=c["E"], metadata_embedding_dim=c["Em"],
+                                    num_lstm_constraints_units=c["H"], num_lstm_generation_units=c["H"],
+                                    linear_hidden_size=c["LH"], num_layers=2, dropout_input_prob=0.0, dropout_prob=0.0,
+                                    unary_constraint=True, teacher_forcing=True)
+    model.load_state_dict(G.arnn_params("small"))
+    assert repr(model).startswith("AnticipationRNNBaseline(") and repr(model).endswith(",tf")
+    model.eval()
+    score, md, loc = (torch.from_numpy(fx[k]).cuda() for k in ("score", "metadata", "constraints_loc"))
+    a, b = [int(x) for x in fx["ticks"]]
+    with torch.no_grad():
+        w, gen = model.forward_inpaint(score, md, loc, a, b)
+    assert w[0].shape == fx["inpaint_weights"].shape and gen.shape == fx["inpaint_gen"].shape
+    g = gen.cpu().numpy()
+    if np.array_equal(g, fx["inpaint_gen"]):
+        assert G.rel_err(w[0].cpu(), fx["inpaint_weights"]) < 2e-4
+    else:
+        first = int(np.argmax(g[0, 0] != fx["inpaint_gen"][0, 0]))
+        assert fx["inpaint_margin_row0"][first - a] < 1e-4
+        assert G.rel_err(w[0].cpu()[:, :first - a], fx["inpaint_weights"][:, :first - a]) < 2e-4
+    assert ops.chain_status() == 0
+    # baseline trainer: Bernoulli constraint mask, the reference's draws under the same seeds
+    trainer = AnticipationRNNBaselineTrainer(ds, model)
+    random.seed(int(fx["baseline_seed"]))
+    torch.manual_seed(int(fx["baseline_seed"]))
+    for i in range(3):
+        out = trainer.process_batch_data((score.cpu().int(), md.cpu().int()))
+        assert out[3] is None and out[4] is None and out[2].dtype == torch.int64 and out[2].is_cuda
+        assert np.array_equal(out[2].cpu().numpy(), fx["baseline_locs"][i])
+    model.train()
+    trainer.zero_grad()
+    loss, acc = trainer.loss_and_acc_for_batch(out, 0, train=True)
+    loss.backward()
+    trainer.step()
+    assert np.isfinite(float(loss.detach()))
