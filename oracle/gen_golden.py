@@ -66,6 +66,8 @@ from AnticipationRNN.anticipation_rnn_trainer import AnticipationRNNGaussianRegT
 from inpaintnet_amd import synthetic  # noqa: E402
 
 torch.set_num_threads(8)
+import random as _random_module  # noqa: E402
+_ORIG_RANDOM_RANDOM = _random_module.random
 
 
 class FakeDataset:
@@ -494,6 +496,7 @@ def gen_inference():
 def gen_arnn_inpaint():
     """ConstraintModelGaussianReg.forward_inpaint (eval mode) and the baseline trainer's constraint sampling (f4)."""
     import random as pyrandom
+    pyrandom.random = _ORIG_RANDOM_RANDOM            # set_coin() patches the shared `random` module; undo it here
     from AnticipationRNN.anticipation_rnn_gauss_reg_model import AnticipationRNNBaseline
     from AnticipationRNN.anticipation_rnn_trainer import AnticipationRNNBaselineTrainer
     c = ARNN_CFGS["small"]
