@@ -29,6 +29,7 @@
 namespace chain {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kSpinLimit = 400000;          // polls (~1 us each with s_sleep): ~0.4 s before giving up
 enum { ST_OK = 0, ST_TIMEOUT = 1 };

@@ -1,0 +1,23 @@
+// Fused free-running decode kernel (decode_chain.hip; protocol in chain.h).
+#pragma once
+#include "chain.h"
+
+constexpr int kDecodeSyncWords = 16;              // group counters [0..13], status word [15]
+
+struct DecodeChainArgs {
+    int B, H, T, G, V, members;                   // G = ticks per beat; T = beats * G
+    const float* W_hh0; const float* b_hh0;       // tick layer 0: recurrent weights [3H,H], [3H]
+    const float* cgi;                             // [beats*B, 3H] beat-constant part of the layer-0 input projection
+    const float* table;                           // [(V+1), 3H] token part incl. b_ih(l0); row V = x_0
+    const float* W_ih1; const float* b_ih1; const float* W_hh1; const float* b_hh1;   // tick layer 1
+    const float* W_out; const float* b_out;       // [V,H], [V]
+    const float* ht0;                             // [beats*B, 2H] initial tick hiddens per beat (cols [0,H) layer 0)
+    const float* ht0pk;                           // [2 layers][beats][pk(B,H)] the same, fragment-major
+    float* hx0; float* hx1;                       // exchange rings [2][pk(B,H)]
+    float* amax;                                  // [2][V/16][ceil16(B)] x {idx, max} (8 bytes each)
+    float* weights; long long* samples;           // outputs [B,T,V], [B,1,T]
+    unsigned* counters; chain::Status status;
+};
+
+bool decode_chain_ok(int B, int H, int V, int T, int G);
+int launch_decode_chain(DecodeChainArgs a, hipStream_t s);

@@ -1,0 +1,305 @@
+// Fused free-running decode (SURVEY.md 2.3 "K7", north_star "fused GRU decode kernel"): ALL 24 ticks of
+// HierarchicalDecoder.forward_tick_rnn (MeasureVAE/decoder.py:473-529, sampling = argmax, no teacher forcing) in ONE
+// persistent launch -- tick layer 0, tick layer 1, the output projection, ReLU, argmax and the feedback of the sampled
+// token, for small inference batches (B <= 32: LatentRNNTester.generate, VAETester.decode_mid_point, forward_test).
+//
+// Before: 72 dependent launches per call (24 x [layer-0 step, layer-1 step, logits+argmax]), 0.67 ms at b = 1, every
+// launch re-reading its weights through a cold L2.  Here a group of H/16 workgroups owns one row tile; member m owns
+// hidden units [16m, 16m+16) of BOTH layers for the whole call:
+//   * W_hh(l0) and W_hh(l1) slices live in registers (2 x 96 VGPRs), W_ih(l1)'s slice in LDS (96 KB, fragment-major), the
+//     16 x H slice of W_out of the members that also compute a logits tile in registers: weights are read ONCE per call;
+//   * per tick three hand-offs inside the group (chain.h protocol): h0_t -> everybody (layer 1's input), h1_t ->
+//     the logits tiles, (max, argmax) per 16-column block -> everybody (the token that selects the next gather row);
+//   * the layer-1 recurrent contraction h1_{t-1} W_hh^T does not depend on h0_t and runs while the group is still
+//     handing h0_t over.
+// Arithmetic per element is that of gru_step_fwd_kernel / logits_argmax_kernel (same MFMA contraction order per wave,
+// same gate formulas, lowest index wins ties), so results agree with the per-tick path to fp32 round-off.
+#include <cstdio>
+#include <cstdlib>
+#include "chain.h"
+#include "ksplit.h"
+#include "prof.h"
+#include "decode_chain.h"
+
+using namespace ksplit;
+
+namespace {
+
+// acc[ms][slot[g]] += A x B_g^T with the B fragments supplied by `getB(g, si)` (registers or LDS); see chain::contract
+template <int MS, int NG, int SQ, class GetB>
+__device__ __forceinline__ void contract_b(f32x4 (&acc)[MS][4], const int (&slot)[NG], GetB&& getB,
+                                           __amdgpu_buffer_rsrc_t r, int base, int rb0, int rb_last, int S, int s0, int lane) {
+    constexpr int CH = SQ < 4 ? SQ : 4, NCH = SQ / CH;
+    f32x4 A[2][MS][CH];
+    auto load = [&](int c, int buf) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            const int rb = min(rb0 + ms, rb_last);
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                A[buf][ms][i] = chain::ld16_sc1(r, base + ((rb * S + s0 + c * CH + i) * 256 + lane * 4) * 4);
+        }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) load(c + 1, (c + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            f32x4 Bf[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) Bf[g] = getB(g, c * CH + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        acc[ms][slot[g]] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c & 1][ms][i][e], Bf[g][e], acc[ms][slot[g]], 0, 0, 0);
+        }
+    }
+}
+
+template <int MS, int SQ>                          // SQ = H/64
+__global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
+    constexpr int S = 4 * SQ, H = 64 * SQ;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wih = smem;                                   // [3][S][64][4]  W_ih(l1) slice, fragment-major
+    float* const red = wih + 3 * S * 256;                      // [4 waves][4 acc][MS*256]
+    float* const xt = red + 4 * 4 * MS * 256;                  // [MS*256]
+    unsigned* const flag = reinterpret_cast<unsigned*>(xt + MS * 256);   // [2]
+    int group, member;
+    chain::decode_block(blockIdx.x, P.members, group, member);
+    const int row0 = group * 16 * MS, B = P.B, T = P.T, V = P.V;
+    if (row0 >= B) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int j0 = member * 16, jc = j0 + (t & 15);
+    const int rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
+    const int pkh = ((B + 15) >> 4) * 16 * H;                  // floats of one fragment-major [B,H] state
+    const int NCB = V >> 4;                                    // 16-column blocks of the vocabulary
+    // logits tile of this member (if any): row block lp of the group, column block lcb
+    const bool has_tile = member < NCB * MS;
+    const int lp = member / NCB, lcb = member % NCB;
+
+    // ---- weights, once per call --------------------------------------------------------------------------------
+    f32x4 W0[3][SQ], W1[3][SQ], Wo[1][SQ];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int si = 0; si < SQ; ++si) {
+            const long o = (long)(g * H + j0 + i16) * H + 16 * (w * SQ + si) + 4 * q;
+            W0[g][si] = ld4u(P.W_hh0 + o);
+            W1[g][si] = ld4u(P.W_hh1 + o);
+        }
+#pragma unroll
+    for (int si = 0; si < SQ; ++si)
+        Wo[0][si] = has_tile ? ld4u(P.W_out + (long)(16 * lcb + i16) * H + 16 * (w * SQ + si) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < 3 * S * 64; i += 256) {                // W_ih(l1): slot (g, s, lane) <- 4 consecutive k of row g*H + j0 + lane%16
+        const int ln = i & 63, s = (i >> 6) % S, g = i / (64 * S);
+        *reinterpret_cast<f32x4*>(wih + (long)i * 4) = ld4u(P.W_ih1 + (long)(g * H + j0 + (ln & 15)) * H + 16 * s + 4 * (ln >> 4));
+    }
+    float bh0[3], bi1[3], bh1[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { bh0[g] = P.b_hh0[g * H + jc]; bi1[g] = P.b_ih1[g * H + jc]; bh1[g] = P.b_hh1[g * H + jc]; }
+    const float bo = has_tile ? P.b_out[16 * lcb + (t & 15)] : 0.f;
+    int brow[MS];
+#pragma unroll
+    for (int p = 0; p < MS; ++p) brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1);
+    const __amdgpu_buffer_rsrc_t r_hx0 = chain::make_rsrc(P.hx0), r_hx1 = chain::make_rsrc(P.hx1),
+                                 r_ht0 = chain::make_rsrc(P.ht0pk), r_am = chain::make_rsrc(P.amax);
+    unsigned* const counter = P.counters + group;
+    const chain::Status status = P.status;
+    const int members = P.members, G = P.G, nb = T / G;
+    const int am_slot = NCB * (((B + 15) >> 4) * 16);          // float2 entries per amax slot: [NCB][rows16]
+    unsigned phase = 0;                                        // hand-offs completed so far by this member
+    float hp0[MS], hp1[MS];
+    __syncthreads();                                           // wih is complete
+
+    auto token_of = [&](int tick, int p) -> long {             // argmax over the column-block partials of `tick`
+        float best = -1.f;
+        int bi = 0;
+        for (int cb = 0; cb < NCB; ++cb) {
+            const chain::u32x2 u2 = __builtin_amdgcn_raw_buffer_load_b64(r_am, (((tick & 1) * am_slot + cb * (am_slot / NCB) + brow[p]) * 8), 0, 16);
+            const unsigned long long u = ((unsigned long long)u2.y << 32) | u2.x;
+            const float m = __builtin_bit_cast(float, (unsigned)(u >> 32));
+            if (m > best) { best = m; bi = (int)(unsigned)u; }
+        }
+        return bi;
+    };
+
+    for (int tick = 0; tick < T; ++tick) {
+        const int beat = tick / G, j = tick % G;
+        // ================= layer 0 =================
+        float c0[MS][3];
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) c0[p][g] = P.cgi[((long)beat * B + brow[p]) * 3 * H + g * H + jc];
+            if (j == 0) {                                      // hidden states restart from the beat embedding
+                hp0[p] = P.ht0[((long)beat * B + brow[p]) * 2 * H + jc];
+                hp1[p] = P.ht0[((long)beat * B + brow[p]) * 2 * H + H + jc];
+            }
+        }
+        if (tick > 0 && !chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;   // tokens of tick-1
+        long tok[MS];
+#pragma unroll
+        for (int p = 0; p < MS; ++p) tok[p] = tick == 0 ? V : token_of(tick - 1, p);
+        if (tick > 0 && member == 0 && (t & 15) == 0) {
+#pragma unroll
+            for (int p = 0; p < MS; ++p)
+                if (row0 + ((t + 256 * p) >> 4) < B) P.samples[(long)brow[p] * T + tick - 1] = tok[p];
+        }
+        float g0[MS][3];
+#pragma unroll
+        for (int p = 0; p < MS; ++p)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) g0[p][g] = P.table[tok[p] * 3 * H + g * H + jc];
+        f32x4 acc[MS][4];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const int sl[3] = {0, 1, 2};
+            if (j == 0) contract_b<MS, 3, SQ>(acc, sl, [&](int g, int si) { return W0[g][si]; }, r_ht0, beat * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+            else contract_b<MS, 3, SQ>(acc, sl, [&](int g, int si) { return W0[g][si]; }, r_hx0, ((tick + 1) & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+        }
+        float v[MS][4];
+        reduce_waves<MS, 4>(acc, red, t, v);
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const float ghn = v[p][2] + bh0[2];
+            const float r = sigmoid_f(v[p][0] + c0[p][0] + g0[p][0] + bh0[0]);
+            const float z = sigmoid_f(v[p][1] + c0[p][1] + g0[p][1] + bh0[1]);
+            const float n = tanh_f(c0[p][2] + g0[p][2] + r * ghn);
+            hp0[p] = (1.f - z) * n + z * hp0[p];
+            xt[((t + 256 * p) >> 4) * 16 + (t & 15)] = hp0[p];
+        }
+        __syncthreads();
+        if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
+            chain::publish_block(r_hx0, (tick & 1) * pkh * 4, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
+        chain::arrive(counter);
+        ++phase;
+        // ================= layer 1 =================
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {   // recurrent half first: it needs h1 of the previous tick only, and hides the hand-off of h0
+            const int sh[3] = {0, 1, 3};
+            if (j == 0) contract_b<MS, 3, SQ>(acc, sh, [&](int g, int si) { return W1[g][si]; }, r_ht0, (nb + beat) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+            else contract_b<MS, 3, SQ>(acc, sh, [&](int g, int si) { return W1[g][si]; }, r_hx1, ((tick + 1) & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+        }
+        if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;               // h0 of this tick
+        {
+            const int sx[3] = {0, 1, 2};
+            contract_b<MS, 3, SQ>(acc, sx, [&](int g, int si) { return *reinterpret_cast<const f32x4*>(wih + ((g * S + w * SQ + si) * 64 + lane) * 4); },
+                                  r_hx0, (tick & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+        }
+        reduce_waves<MS, 4>(acc, red, t, v);
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const float ghn = v[p][3] + bh1[2];
+            const float r = sigmoid_f(v[p][0] + bi1[0] + bh1[0]);
+            const float z = sigmoid_f(v[p][1] + bi1[1] + bh1[1]);
+            const float n = tanh_f(v[p][2] + bi1[2] + r * ghn);
+            hp1[p] = (1.f - z) * n + z * hp1[p];
+            xt[((t + 256 * p) >> 4) * 16 + (t & 15)] = hp1[p];
+        }
+        __syncthreads();
+        if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
+            chain::publish_block(r_hx1, (tick & 1) * pkh * 4, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
+        chain::arrive(counter);
+        ++phase;
+        // ================= output projection + partial argmax (members that own a logits tile) =================
+        if (has_tile) {
+            if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;           // h1 of this tick
+            f32x4 la[1][4];
+            la[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int s1[1] = {0};
+            contract_b<1, 1, SQ>(la, s1, [&](int g, int si) { return Wo[0][si]; }, r_hx1, (tick & 1) * pkh * 4, rb0 + lp, rb_last, S,
+                                 w * SQ, lane);
+            float lv[1][1];
+            reduce_waves<1, 1>(la, red, t, lv);
+            const int rl = t >> 4, c = t & 15, b = row0 + 16 * lp + rl;
+            float x = lv[0][0] + bo;
+            x = x > 0.f ? x : 0.f;
+            if (b < B) P.weights[((long)b * T + tick) * V + 16 * lcb + c] = x;
+            // (max, lowest argmax) over the 16 columns of the row: butterfly inside each 16-lane group
+            float m = x;
+            int am = c;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float m2 = __shfl_xor(m, o, 16);
+                const int a2 = __shfl_xor(am, o, 16);
+                if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+            }
+            if (c == 0 && rb0 + lp <= rb_last) {
+                const unsigned long long u = ((unsigned long long)__builtin_bit_cast(unsigned, m) << 32) | (unsigned)(16 * lcb + am);
+                __builtin_amdgcn_raw_buffer_store_b64(chain::u32x2{(unsigned)u, (unsigned)(u >> 32)}, r_am,
+                                                      ((tick & 1) * am_slot + lcb * (am_slot / NCB) + row0 + 16 * lp + rl) * 8, 0, 16);
+            }
+        }
+        chain::arrive(counter);
+        ++phase;
+    }
+    // the last tick's tokens
+    if (member == 0) {
+        if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;
+        if ((t & 15) == 0) {
+#pragma unroll
+            for (int p = 0; p < MS; ++p)
+                if (row0 + ((t + 256 * p) >> 4) < B) P.samples[(long)brow[p] * T + T - 1] = token_of(T - 1, p);
+        }
+    }
+}
+
+int rows_ms(int B) { return B <= 16 ? 1 : 2; }
+
+}  // namespace
+
+bool decode_chain_ok(int B, int H, int V, int T, int G) {
+    if (!chain_enabled() || (H != 256 && H != 512) || B < 1 || B > 32 || V % 16 != 0 || V > 64 || T % G != 0) return false;
+    static const bool off = [] { const char* v = std::getenv("INET_DECODE_CHAIN"); return v && v[0] == '0'; }();
+    if (off) return false;
+    const int ms = rows_ms(B);
+    return (V / 16) * ms <= H / 16;
+}
+
+size_t decode_chain_lds_bytes(int B, int H) {
+    const int ms = rows_ms(B), S = H / 16;
+    return (size_t)(3 * S * 256 + 4 * 4 * ms * 256 + ms * 256 + 4) * sizeof(float);
+}
+
+int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
+    if (!decode_chain_ok(a.B, a.H, a.V, a.T, a.G)) return -1;
+    const int ms = rows_ms(a.B), groups = (a.B + 16 * ms - 1) / (16 * ms);
+    a.members = a.H / 16;
+    a.status.host = chain_host_status();
+    if (hipMemsetAsync(a.counters, 0, kDecodeSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    a.status.dev = a.counters + kDecodeSyncWords - 1;
+    const size_t lds = decode_chain_lds_bytes(a.B, a.H);
+    char label[72];
+    std::snprintf(label, sizeof label, "decode_chain ms%d T%d B%d H%d V%d", ms, a.T, a.B, a.H, a.V);
+    // algorithmic bytes: the tick GRU + output weights once per call, logits out
+    ProfScope prof(PROF_GRU_FWD, 2.0 * a.T * a.B * (9.0 * a.H * a.H + (double)a.V * a.H), s, label,
+                   4.0 * (9.0 * a.H * a.H + (double)a.V * a.H + (double)a.B * a.T * a.V));
+    const dim3 grid(chain::blocks_for(groups, a.members));
+#define INET_DC(M, Q)                                                                                                   \
+    do {                                                                                                                \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chain_kernel<M, Q>),                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((decode_chain_kernel<M, Q>), grid, dim3(256), lds, s, a);                                    \
+    } while (0)
+    if (a.H == 512) { if (ms == 1) INET_DC(1, 8); else INET_DC(2, 8); }
+    else { if (ms == 1) INET_DC(1, 4); else INET_DC(2, 4); }
+#undef INET_DC
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

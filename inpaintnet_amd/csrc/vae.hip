@@ -16,6 +16,7 @@
 #include "seq.h"
 #include "layout.h"
 #include "vae.h"
+#include "decode_chain.h"
 #include <cstdlib>
 #include <string>
 
@@ -153,6 +154,7 @@ struct DecWs {
     // tick hiddens [layer][beat], ping-pong packed hiddens [beat][2], packed masked layer-0 output [beat]
     float *wpk_b[2], *wpk_t0, *wpk_t1hh, *wpk_t1ih, *wpk_out, *hpk_b, *ht0pk, *hpk_t0, *hpk_t1, *hm0pk;
     float *wpkT[4], *dghpk;
+    float* amax; unsigned* sync;                     // fused decode kernel (decode_chain.h): partial argmax, counters
 };
 
 size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w) {
@@ -218,6 +220,8 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.hm0pk = pk ? cv.take<float>(nb * pkh) : nullptr;
     for (int i = 0; i < 4; ++i) w.wpkT[i] = pk && save ? cv.take<float>(W3) : nullptr;
     w.dghpk = pk && save ? cv.take<float>(2 * nb * pk_floats(B, 3 * (int)H)) : nullptr;
+    w.amax = cv.take<float>(2 * 2 * ((V + 15) / 16) * ((B + 15) / 16) * 16);
+    w.sync = cv.take<unsigned>(kDecodeSyncWords > kChainSyncWords ? kDecodeSyncWords : kChainSyncWords);
     return cv.bytes();
 }
 
@@ -348,6 +352,20 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         INET_TRY(linear_fwd(w.h1seq, H, p + L.out_w, H, p + L.out_b, w.wtm, V, T * B, V, H, EPI_RELU, s));
         INET_TRY(pw_swap01(w.wtm, T, B, V, weights, s));             // [T,B,V] -> [B,T,V]
         return 0;
+    }
+    if (pk && !teacher_forced && !save && !mask_tick && w.wpk_out && decode_chain_ok(B, H, V, T, G)) {
+        // small-batch inference: all 24 ticks (layer 0, layer 1, projection, argmax, token feedback) in ONE launch
+        DecodeChainArgs a{};
+        a.B = B; a.H = H; a.T = T; a.G = G; a.V = V;
+        a.W_hh0 = p + L.tick[0].w_hh; a.b_hh0 = p + L.tick[0].b_hh;
+        a.cgi = w.cgi; a.table = w.table;
+        a.W_ih1 = p + L.tick[1].w_ih; a.b_ih1 = p + L.tick[1].b_ih; a.W_hh1 = p + L.tick[1].w_hh; a.b_hh1 = p + L.tick[1].b_hh;
+        a.W_out = p + L.out_w; a.b_out = p + L.out_b;
+        a.ht0 = w.ht0; a.ht0pk = w.ht0pk;
+        a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
+        a.weights = weights; a.samples = samples;
+        a.counters = w.sync;
+        return launch_decode_chain(a, s);
     }
     for (int t = 0; t < T; ++t) {
         const int i = t / G, j = t % G;

@@ -168,3 +168,45 @@ def test_arnn_forward_inpaint_and_baseline():
     loss.backward()
     trainer.step()
     assert np.isfinite(float(loss.detach()))
+
+
+@pytest.mark.parametrize("name,B", [("full", 5), ("full", 1), ("full", 16), ("full", 29), ("pk", 7), ("pk", 32)])
+def test_fused_decode_kernel_matches_per_tick_path(name, B):
+    """The fused free-running decode (csrc/decode_chain.hip: 24 ticks x [layer 0, layer 1, projection + argmax] in one
+    launch) against the per-tick launches and the oracle: logits to fp32 round-off, tokens exact on rows with a margin."""
+    from oracle import torch_ref as O
+    from tests.test_gpu_kernels import pack
+    c = G.CFGS[name]
+    cfg = ops.vae_config(c["V"] if name == "full" else 32, c["E"], c["H"], c["Z"], c["H"])
+    V = cfg.num_notes
+    table, total = ops.vae_param_table(cfg)
+    from inpaintnet_amd import layout
+    shapes = layout.vae_param_shapes(V, c["E"], c["H"], c["Z"], c["H"])
+    P = {k: torch.from_numpy(synthetic.det_param(k, s)) for k, s in shapes.items()}
+    params = pack(table, total, P)
+    z = torch.from_numpy(synthetic.det_normal(f"fused/{name}/{B}", (B, c["Z"]))).cuda()
+    ops.prof_enable(True)
+    w1, s1, _ = ops.decoder_fwd(cfg, z, None, False, params)
+    torch.cuda.synchronize()
+    import csv, tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        ops.prof_dump(os.path.join(td, "l.csv"))
+        labels = [r["label"] for r in csv.DictReader(open(os.path.join(td, "l.csv")))]
+    ops.prof_enable(False)
+    assert any(l.startswith("decode_chain") for l in labels), sorted(set(labels))
+    assert ops.chain_status() == 0
+    ops.set_option(4, 0)
+    try:
+        w0, s0, _ = ops.decoder_fwd(cfg, z, None, False, params)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option(4, 1)
+    with torch.no_grad():
+        wr, sr = O.decoder_forward(P, z.cpu(), None, False, feed_tokens=s1.cpu()[:, 0])
+    top2 = torch.topk(wr, 2, dim=-1).values
+    ok = ((top2[..., 0] - top2[..., 1]) > 1e-4).numpy()
+    assert G.rel_err(w1.cpu(), wr) < 2e-5
+    assert np.array_equal(s1.cpu().numpy()[:, 0][ok], sr.numpy()[:, 0][ok])
+    same = np.array_equal(s1.cpu().numpy(), s0.cpu().numpy())
+    if same:
+        assert G.rel_err(w1.cpu(), w0.cpu()) < 2e-5
