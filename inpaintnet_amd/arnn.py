@@ -58,7 +58,7 @@ class _LinearFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
-class _LstmLayerFn(torch.autograd.Function):
+class _LstmLayerFn(ops.TrackedFunction):
     """One nn.LSTM(num_layers=1) over a time-major sequence x [T,B,K]; optional carried state (single steps of the
     free-running path)."""
 
@@ -67,7 +67,7 @@ class _LstmLayerFn(torch.autograd.Function):
         T, B, K = x.shape
         W_ih, W_hh = owner.param(prefix + ".weight_ih_l0"), owner.param(prefix + ".weight_hh_l0")
         H = W_hh.shape[1]
-        need = any(ctx.needs_input_grad[:4])
+        need = ops.outer_grad() and any(ctx.needs_input_grad[:4])
         x2 = x.contiguous().view(T * B, K)
         gi = ops.linear_fwd(x2, W_ih, owner.param(prefix + ".bias_ih_l0"))
         out, hT, cT, ws = ops.lstm_fwd(gi.view(T, B, 4 * H), W_hh, owner.param(prefix + ".bias_hh_l0"), H,
@@ -168,7 +168,7 @@ class ConstraintModelGaussianReg(Model):
 
     def _lstm(self, prefix, x_tm, reverse, state=None):
         h0, c0 = state if state is not None else (None, None)
-        return _LstmLayerFn.apply(x_tm, h0, c0, self.flat_for_autograd(), self, prefix, reverse)
+        return _LstmLayerFn.call(x_tm, h0, c0, self.flat_for_autograd(), self, prefix, reverse)
 
     def _head(self, h2d):
         a = _LinearFn.apply(h2d, self.flat_for_autograd(), self, "linear_1.weight", "linear_1.bias", True)

@@ -21,12 +21,12 @@ from .measure_vae import MeasureVAE, _DropState, _next_mask_offset
 from .model import Model
 
 
-class _BiGru2Fn(torch.autograd.Function):
+class _BiGru2Fn(ops.TrackedFunction):
     """2-layer bidirectional nn.GRU(batch_first).  x (B,T,K) or the scalar parameter x_0 (K == 1)."""
 
     @staticmethod
     def forward(ctx, x, x_scalar, h0, flat, owner, off, H, B, T, K, mask):
-        need = any(ctx.needs_input_grad[:4])
+        need = ops.outer_grad() and any(ctx.needs_input_grad[:4])
         weights = flat[off:]
         xin = x.contiguous() if x is not None else None
         out, hn, ws = ops.bigru2_fwd(xin, x_scalar, weights, H, B, T, K, h0=h0.contiguous() if h0 is not None else None,
@@ -153,7 +153,7 @@ class LatentRNN(Model):
             B, T, _ = x.shape
         else:
             B = h0.shape[1]
-        return _BiGru2Fn.apply(x, x_scalar, h0, self.flat_for_autograd(), self, self._off[name + ".weight_ih_l0"], H, B,
+        return _BiGru2Fn.call(x, x_scalar, h0, self.flat_for_autograd(), self, self._off[name + ".weight_ih_l0"], H, B,
                                T, K, self._mask(T, B, H))
 
     def get_z_seq(self, measures_tensor, eps=None):

@@ -35,10 +35,10 @@ class _DropState:
     seed = 0x5eed
 
 
-class _EncoderFn(torch.autograd.Function):
+class _EncoderFn(ops.TrackedFunction):
     @staticmethod
     def forward(ctx, flat, enc, tokens, mask):
-        need = ctx.needs_input_grad[0]           # grad mode is off inside forward(): ask the ctx
+        need = ops.outer_grad() and ctx.needs_input_grad[0]     # grad mode is off inside forward(): ask the ctx
         mu, ls, ws = ops.encoder_fwd(enc.cfg, tokens, flat, mask=mask, save=need)
         ctx.enc, ctx.tokens, ctx.mask, ctx.ws = enc, tokens, mask, ws
         return mu, ls
@@ -52,10 +52,10 @@ class _EncoderFn(torch.autograd.Function):
         return None, None, None, None
 
 
-class _DecoderFn(torch.autograd.Function):
+class _DecoderFn(ops.TrackedFunction):
     @staticmethod
     def forward(ctx, z, flat, dec, target, teacher_forced, mask_beat, mask_tick):
-        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need = ops.outer_grad() and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         weights, samples, ws = ops.decoder_fwd(dec.cfg, z.contiguous(), target, teacher_forced, flat, mask_beat,
                                                mask_tick, save=need)
         ctx.dec, ctx.ws, ctx.mb, ctx.mt = dec, ws, mask_beat, mask_tick
@@ -160,7 +160,7 @@ class Encoder(torch.nn.Module):
             n = T * batch_size * 2 * self.rnn_hidden_size
             mask = ops.dropout_mask((T, batch_size, 2 * self.rnn_hidden_size), self.dropout, _DropState.seed,
                                     _next_mask_offset(n), tokens.device)
-        mu, ls = _EncoderFn.apply(self.owner.flat_for_autograd(), self, tokens, mask)
+        mu, ls = _EncoderFn.call(self.owner.flat_for_autograd(), self, tokens, mask)
         return NormalLogScale(mu, ls, _ExpFn.apply(ls))
 
 
@@ -246,7 +246,7 @@ class HierarchicalDecoder(torch.nn.Module):
                                   _next_mask_offset(self.cfg.beats * batch_size * H), dev)
             mt = ops.dropout_mask((T, batch_size, H), self.dropout, _DropState.seed,
                                   _next_mask_offset(T * batch_size * H), dev)
-        weights, samples = _DecoderFn.apply(z, self.owner.flat_for_autograd(), self, target, teacher_forced, mb, mt)
+        weights, samples = _DecoderFn.call(z, self.owner.flat_for_autograd(), self, target, teacher_forced, mb, mt)
         return weights, samples
 
 

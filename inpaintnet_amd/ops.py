@@ -12,6 +12,25 @@ from . import _lib
 from ._lib import VaeConfig, LatentConfig, check, ptr, stream_ptr
 
 
+# Whether autograd is recording OUTSIDE the custom Function whose forward is running (inside Function.forward grad mode is
+# always off, and ctx.needs_input_grad only reflects requires_grad flags -- a trainable model evaluated under
+# torch.no_grad() would otherwise save its backward activations and miss the save-free inference kernels).
+_OUTER_GRAD = [True]
+
+
+class TrackedFunction(torch.autograd.Function):
+    """autograd.Function whose call() records the caller's grad mode first (read it with ops.outer_grad())."""
+
+    @classmethod
+    def call(cls, *args):
+        _OUTER_GRAD[0] = torch.is_grad_enabled()
+        return cls.apply(*args)
+
+
+def outer_grad():
+    return _OUTER_GRAD[0]
+
+
 def _f32c(t):
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
     return t
