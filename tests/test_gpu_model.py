@@ -185,3 +185,32 @@ def test_training_state_resume_continues_the_run(tmp_path):
         st = tb.training_state()
         st["num_parameters"] = 3
         tb.load_training_state(st)
+
+
+def test_reference_style_initialisation_statistics():
+    """a1: Encoder/Decoder.xavier_initialization (encoder.py:71-78, decoder.py:47-54) -- xavier_normal_ on every tensor
+    whose name contains 'weight' (std = sqrt(2 / (fan_in + fan_out))), torch defaults elsewhere: GRU biases
+    U(+-1/sqrt(H)), Linear biases U(+-1/sqrt(fan_in)), b_0 / x_0 zeros (decoder.py:341,360)."""
+    torch.manual_seed(123)
+    ds = synthetic.SyntheticFolkDataset(num_notes=48)
+    model = MeasureVAE(ds)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        v = v.cpu().double()
+        if "weight" in k and v.dim() == 2 and v.numel() >= 4096:
+            want = (2.0 / (v.shape[0] + v.shape[1])) ** 0.5
+            assert abs(float(v.std()) - want) < 0.05 * want, k
+            assert abs(float(v.mean())) < 4 * want / v.numel() ** 0.5 + 1e-4, k
+        elif "bias_ih" in k or "bias_hh" in k:
+            bound = 1.0 / (v.shape[0] // 3) ** 0.5
+            assert float(v.abs().max()) <= bound and abs(float(v.std()) - bound / 3 ** 0.5) < 0.1 * bound, k
+        elif k.endswith(".bias"):
+            fan_in = sd[k[:-4] + "weight"].shape[1]
+            assert float(v.abs().max()) <= 1.0 / fan_in ** 0.5 + 1e-7, k
+        elif k in ("decoder.b_0", "decoder.x_0"):
+            assert float(v.abs().max()) == 0.0
+    # two constructions draw different weights; a seeded one is reproducible
+    torch.manual_seed(123)
+    again = MeasureVAE(ds)
+    assert torch.equal(again.flat, model.flat)
+    assert not torch.equal(MeasureVAE(ds).flat, model.flat)
