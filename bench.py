@@ -368,7 +368,7 @@ def roofline(step):
            "algorithmic_mbytes_per_launch": top["mbytes_per_launch"],
            "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
            "step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
-           "kernels": table[:8]}
+           "kernels": table[:int(os.environ.get("INET_BENCH_TOPK", "8"))]}
     return out
 
 

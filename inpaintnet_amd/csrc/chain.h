@@ -40,8 +40,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
 }
 // 16-byte load / store with sc1: L1-bypassing, write-through -- the agent-coherent forms.  The compiler tracks these in
 // vmcnt like any other buffer access, so they pipeline normally.
-__device__ __forceinline__ f32x4 ld16_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+__device__ __forceinline__ f32x4 ld16_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, int s_off = 0) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, s_off, 16));
+}
+// A VGPR that holds 0 without the compiler knowing: added to a wave-uniform index it keeps the derived addresses in
+// vector registers.  (The A-fragment offsets of a contraction are loop-invariant and uniform; hipcc hoists one SGPR per
+// (row block, k-step) out of the step loop and, past ~100 of them, spills scalars to VGPR lanes.)
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
 }
 __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);

@@ -31,19 +31,22 @@ __device__ __forceinline__ void contract_b(f32x4 (&acc)[MS][4], const int (&slot
                                            __amdgpu_buffer_rsrc_t r, int base, int rb0, int rb_last, int S, int s0, int lane) {
     constexpr int CH = SQ < 4 ? SQ : 4, NCH = SQ / CH;
     f32x4 A[2][MS][CH];
+    int vo[MS];
+    const int oz = chain::opaque_zero();           // offsets in vector registers (chain.h)
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) vo[ms] = (((min(rb0 + ms, rb_last) + oz) * S + s0) * 256 + lane * 4) * 4;
     auto load = [&](int c, int buf) {
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-            const int rb = min(rb0 + ms, rb_last);
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-            for (int i = 0; i < CH; ++i)
-                A[buf][ms][i] = chain::ld16_sc1(r, base + ((rb * S + s0 + c * CH + i) * 256 + lane * 4) * 4);
-        }
+            for (int i = 0; i < CH; ++i) A[buf][ms][i] = chain::ld16_sc1(r, vo[ms] + (c * CH + i) * 1024, base);
     };
     load(0, 0);
+    __builtin_amdgcn_sched_barrier(0);             // keep the prefetch order (chain.h)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) load(c + 1, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             f32x4 Bf[NG];
