@@ -340,6 +340,34 @@ def kernel_table(step, nprof=4):
     return table
 
 
+def pmc_key(label):
+    """Kernel-name|grid key of tools/pmc_summary.py (rocprofv3 PMC pass) for a profile label of the library."""
+    import math
+    import re
+    f = {k: int(v) for k, v in re.findall(r"\b(ms|np|nc|pk|x|T|B|H|M|N|K|s)(\d+)", label)}
+    tf = lambda v: "true" if v else "false"
+    if label.startswith("gru_chain_fwd") or label.startswith("gru_chain_bwd"):
+        fwd = label.startswith("gru_chain_fwd")
+        H, ms = f["H"], f["ms"]
+        groups = f["np"] * math.ceil(f["B"] / (16 * ms))
+        grid = 256 * 8 * (H // 16) * math.ceil(groups / 8)
+        return f"gru_chain_{'fwd' if fwd else 'bwd'}_kernel<{ms}, {H // 64 if fwd else 3 * H // 64}>|g{grid}"
+    if label.startswith("gru_fwd"):
+        grid = 256 * f["np"] * math.ceil(f["B"] / (16 * f["ms"])) * (f["H"] // 16)
+        return f"gru_step_fwd_kernel<{tf(f['x'])}, {f['ms']}, {tf(f['pk'])}>|g{grid}"
+    if label.startswith("gru_bwd"):
+        grid = 256 * f["np"] * math.ceil(f["B"] / (16 * f["ms"])) * (f["H"] // (16 * f["nc"]))
+        return f"gru_step_bwd_kernel<{f['ms']}, {f['nc']}, {tf(f['pk'])}>|g{grid}"
+    if label == "adam":
+        return "adam_kernel|"
+    m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) t(\d+)x(\d+) s(\d+)", label)
+    if m:
+        M, N, K, a, b, bm, bn, sp = m.groups()
+        grid = 256 * math.ceil(int(N) / int(bn)) * math.ceil(int(M) / int(bm)) * int(sp)
+        return f"gemm_kernel<{int(bm) // 64}, {int(bn) // 64}, {tf(a == 'T')}, {tf(b == 'N')}>|g{grid}"
+    return None
+
+
 def roofline(step):
     table = kernel_table(step)
     top = table[0]
@@ -351,9 +379,13 @@ def roofline(step):
             pmc = {}
     kern = pmc.get("kernels", {})
     for row in table:
-        hit = next((v for k, v in kern.items() if k in row["kernel"] or row["kernel"].startswith(k)), None)
+        key = pmc_key(row["kernel"])
+        hit = None
+        if key:
+            hit = kern.get(key) or next((v for k, v in kern.items() if k.startswith(key)), None)
         if hit:
             row["traffic_mbytes_per_launch"] = hit.get("hbm_mbytes_per_launch")
+            row["pmc_key"] = key
     mfma_bound = top["frac_mfma"] >= top["frac_hbm"]
     out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": top["kernel"],
            "achieved": top["tflops"] if mfma_bound else top["gbps"],

@@ -130,6 +130,48 @@ __device__ __forceinline__ void contract(f32x4 (&acc)[MS][4], const f32x4 (&Wr)[
     }
 }
 
+// Streamed variant of contract(): acc[ms][g] += A[16*MS rows of the group's state, this wave's K quarter] x Wr[g]^T, where the A fragments are read from
+// the exchange buffer `r` (fragment-major, S k-steps per 16-row block) at byte offset `base` with sc1 loads and the B
+// fragments Wr[g][si] (k-step s0 + si) already sit in registers.
+//
+// Schedule (the streamed form of ksplit.h, with B in registers): a ring of R k-steps of A fragments; R-1 k-steps are
+// requested up front, then every k-step's MFMAs carry the loads of the k-step R-1 ahead, ONE load dealt in front of
+// each row block's 4*NG MFMAs and pinned there with sched_barrier.  Left to itself hipcc sinks each load to its first
+// use (load 4 -> wait -> 16 MFMAs -> load 4 ...: latency fully exposed, 12 us per backward step); issued as bursts of a
+// whole chunk the loads stall the in-order wave in the issue stage (~100 cycles per 1 KB load while four waves stream)
+// and the MFMA pipe idles behind them (13 us).  Dealt out, the issue stalls hide under MFMA execution.
+template <int MS, int NG, int SQ, int R = 4>
+__device__ __forceinline__ void contract_stream(f32x4 (&acc)[MS][4], const f32x4 (&Wr)[NG][SQ], __amdgpu_buffer_rsrc_t r,
+                                         int base, int rb0, int rb_last, int S, int s0, int lane) {
+    f32x4 A[R][MS];
+    // per-lane byte offset of k-step s0 in row block ms, kept in vector registers on purpose (opaque_zero); k-steps
+    // are 1 KB apart and ride in the instruction's immediate, the slot `base` in its scalar offset
+    int vo[MS];
+    const int oz = opaque_zero();
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) vo[ms] = (((min(rb0 + ms, rb_last) + oz) * S + s0) * 256 + lane * 4) * 4;   // clamped rows are never stored
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d)
+        if (d < SQ) {
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) A[d][ms] = ld16_sc1(r, vo[ms] + d * 1024, base);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int si = 0; si < SQ; ++si) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            if (si + R - 1 < SQ) A[(si + R - 1) % R][ms] = ld16_sc1(r, vo[ms] + (si + R - 1) * 1024, base);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    acc[ms][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[si % R][ms][e], Wr[g][si][e], acc[ms][g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // One 16x16 block of the group state: rows of sub-tile p held row-major in LDS tile `xt` ([16*MS][16]) -> the member's
 // 1 KB fragment block (row block rb, k-step ks) of the exchange buffer, one 16-byte sc1 store per lane of wave p.
 __device__ __forceinline__ void publish_block(__amdgpu_buffer_rsrc_t r, int base, const float* xt, int p, int lane,

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        chain::contract<MS, 4, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
+        chain::contract_stream<MS, 4, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
         float v[MS][4];
         reduce_waves<MS, 4>(acc, red, t, v);
 #pragma unroll
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chain::contract<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S4, w * SQ, lane);
+            chain::contract_stream<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S4, w * SQ, lane);
             reduce_waves<MS, 1>(acc, red, t, v);
         }
         if (tail) {
