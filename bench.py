@@ -431,6 +431,27 @@ def decode_latency_extra(vae, iters=20):
     return {"decoder_eval": out}
 
 
+def epoch_loop_extra(wl, batches=100):
+    """The same step driven by Trainer.loss_and_acc_on_epoch over the input feed (feed.BatchLoader: pinned staging, shuffle;
+    feed.DeviceFeed: copy stream two batches ahead; on-device int32 -> int64 widening): 16 sequences = 256 measures per
+    batch, every batch different.  SURVEY.md section 8 f2: the feed must not cost throughput against the resident batch."""
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.feed import BatchLoader
+    score, md = synthetic.SyntheticFolkDataset(num_notes=NUM_NOTES, n_seq=16 * batches, seed=3).tensors()
+    loader = BatchLoader((torch.from_numpy(score), torch.from_numpy(md)), 16, shuffle=True)
+    wl.trainer.dataset.n_bars = 16
+    wl.model.train()
+    wl.trainer.loss_and_acc_on_epoch(loader, 0, train=True)           # warm-up epoch (allocator, staging ring)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss, acc = wl.trainer.loss_and_acc_on_epoch(loader, 0, train=True)
+    dt = time.perf_counter() - t0                                     # (the epoch ends with its one host sync)
+    return {"epoch_loop": {"measures_per_s": round(256 * batches / dt, 1), "ms_per_step": round(1e3 * dt / batches, 4),
+                           "batches": batches, "mean_loss": round(loss, 4),
+                           "workload": "VAETrainer.loss_and_acc_on_epoch over feed.BatchLoader/DeviceFeed, 256 measures "
+                                       "per batch from pinned host memory, shuffled"}}
+
+
 def arnn_extra(batch=32, steps=8, warmup=2):
     """Secondary number (BASELINE.json configs[4]): AnticipationRNN gauss-reg model, teacher-forced training step,
     batch 32 sequences of 384 ticks, script defaults of train_arnn_reg.py.  Not the headline metric."""
@@ -573,6 +594,8 @@ def main():
                                               "ms_per_step": round(1e3 * ldt / 10, 3), **lw.describe(1)}
                 wl.model.trainable = True                      # (LatentRNN froze the shared VAE)
                 wl.model.train()
+            if args.workload == "vae":
+                extras.update(epoch_loop_extra(wl))
             extras.update(arnn_extra())
             vae = wl.model if args.workload == "vae" else wl.model.vae_model
             extras.update(decode_latency_extra(vae))
