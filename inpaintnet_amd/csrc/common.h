@@ -134,6 +134,7 @@ struct GruBwdBatch { int H; int nprob; int tiles_per_prob; int rows_fastest; Gru
 // host-side launchers (defined in the .hip files)
 int launch_gemm(const GemmArgs& g, hipStream_t s);
 void gemm_set_force(int cfg, int split);      // cfg: -1 cost model, 0..4 tile configuration; split: 0 = 1, else forced
+void gemm_set_direct(int mode);                 // 0 never, 1 cost model, 2 whenever applicable (k-major x k-major products)
 int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s);
 int launch_gru_bwd(const GruBwdBatch& b, hipStream_t s);
 // hpk / Wpk: optional fragment-major twins of h and W (used when both are given and H % 256 == 0)

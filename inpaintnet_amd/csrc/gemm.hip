@@ -222,6 +222,249 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
 }
 
+// ---------------------------------------------------------------------------
+// Weight-gradient products (A and B both k-major: C[m][n] = sum_k A[k][m] * B[k][n], K = T*B rows) without LDS.
+//
+// A k-major operand already has the MFMA register image in memory: lane (c = lane % 32, h = lane / 32) of a
+// v_mfma_f32_32x32x2_f32 step holds X[k + h][r0 + c], i.e. a half-wave reads one aligned 128-byte line.  Each wave
+// therefore feeds its MFMAs straight from global memory, kept D k steps (~3,000 cycles) ahead in registers: no LDS, no
+// barriers, one wave per SIMD that never waits for its neighbours.  The texture addresser spends 16 cycles on every
+// wave-wide load whatever its width, and five dword loads per 6-MFMA step from four waves would keep it 83 % busy
+// (measured: the loop then runs at 76 % of the MFMA rate), so the rows of the A strip are dealt to lanes TA at a time
+// (tile i of the strip holds row TA*c + i): one 8/12-byte load feeds all TA tiles and the addresser is 50 % busy.  B stays
+// in natural order, which keeps every epilogue store / atomic a contiguous 128 bytes per half-wave.  The 2 x 2 waves of a workgroup share their A / B strips through the CU's L1.
+// Buffer loads past the split's last k row return 0 (the resource is sized to the split), so there is no K tail code.
+// Workgroups are renumbered so that one XCD works on one k range: its L2 then streams every A / B row once.
+// ---------------------------------------------------------------------------
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_tn_direct_kernel(GemmArgs g, int tiles_n, int tiles) {
+    constexpr int D = 8;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    int v = blockIdx.x;
+    if ((gridDim.x & 7) == 0) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int split = v / tiles, tile = v - split * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * (64 * TA) + wr * (32 * TA), n0 = tn * (64 * TB) + wc * (32 * TB);
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int lda = (int)g.lda, ldb = (int)g.ldb;
+
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A) + (long)kbeg * lda, 0, (kend - kbeg) * lda * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.B) + (long)kbeg * ldb, 0, (kend - kbeg) * ldb * 4, 0x00020000);
+    int oa[D], ob[D];                                   // byte offsets of this lane's elements in k step s of the block
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        oa[s] = ((2 * s + h) * lda + m0 + TA * l31) * 4;
+        ob[s] = ((2 * s + h) * ldb + n0 + l31) * 4;
+    }
+    const int adv_a = 2 * D * lda * 4, adv_b = 2 * D * ldb * 4;
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float fa[D][TA], fb[D][TB];
+    auto fetch = [&](int s) {
+        if constexpr (TA == 3) {
+            typedef float f32x3 __attribute__((ext_vector_type(3)));
+            const f32x3 x = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(ra_rsrc, oa[s], 0, 0));
+            fa[s][0] = x[0]; fa[s][1] = x[1]; fa[s][2] = x[2];
+        } else {
+            static_assert(TA == 2, "row strip");
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 x = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ra_rsrc, oa[s], 0, 0));
+            fa[s][0] = x[0]; fa[s][1] = x[1];
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+            fb[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, ob[s] + 128 * j, 0, 0));
+        oa[s] += adv_a;
+        ob[s] += adv_b;
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        fetch(s);
+        __builtin_amdgcn_sched_barrier(0);              // same issue order as in the loop: the loop-head wait count is
+    }                                                   // the minimum over both ways in
+    const int nblocks = (kend - kbeg + 2 * D - 1) / (2 * D);
+    for (int b = 0; b < nblocks; ++b) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+            fetch(s);                                   // k step s of the next block (reads 0 past the split)
+            __builtin_amdgcn_sched_barrier(0);          // or hipcc gathers the block's loads behind its last MFMA
+        }
+    }
+
+    const bool add_bias = g.bias != nullptr && split == 0;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int col = n0 + j * 32 + l31;
+            const float bv = add_bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + i + TA * ((r & 3) + 8 * (r >> 2) + 4 * h);
+                float val = acc[i][j][r] + bv;
+                if (g.epi != EPI_NONE) {
+                    const float a = g.aux ? g.aux[(long)row * g.ldaux + col] : 0.f;
+                    val = apply_epi(val, g.epi, a);
+                }
+                float* cp = g.C + (long)row * g.ldc + col;
+                if (g.acc == ACC_STORE) *cp = val;
+                else if (g.acc == ACC_ADD) *cp += val;
+                else unsafeAtomicAdd(cp, val);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// The same idea for the forward / data-gradient products, whose A operand (activations, [M][K]) is k-contiguous:
+// v_mfma_f32_16x16x4_f32 with lane (c = lane % 16, q = lane / 16).  A k-contiguous operand is read with one 16-byte
+// load per (16-row tile, 16-deep k group): lane (c, q) takes row c, k = 4q..4q+3 of the group, element e feeding the
+// group's MFMA e as k slot q (16 rows x 64 bytes per instruction).  B is read to match: k-contiguous the same way,
+// k-major (data gradient: W as stored) as TB consecutive columns of row k = 4q + e.  Columns are dealt to lanes TB at
+// a time (tile j of the strip holds column TB*c + j), so a lane's accumulators for one output row are TB adjacent
+// columns and the epilogue stores 8 / 16 bytes per lane.  D = 4 groups (4 x 16 k) are kept in flight; K % 64 == 0.
+// ---------------------------------------------------------------------------
+template <int NV>
+struct FVec { float v[NV]; };
+
+template <int TB>
+__device__ __forceinline__ FVec<TB> ld_cols(__amdgpu_buffer_rsrc_t r, int off) {
+    FVec<TB> o;
+    if constexpr (TB == 4) {
+        const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        o.v[0] = x[0]; o.v[1] = x[1]; o.v[2] = x[2]; o.v[3] = x[3];
+    } else {
+        static_assert(TB == 2 || TB == 6, "strip width");
+#pragma unroll
+        for (int p = 0; p < TB / 2; ++p) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 x = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off + 8 * p, 0, 0));
+            o.v[2 * p] = x[0]; o.v[2 * p + 1] = x[1];
+        }
+    }
+    return o;
+}
+
+template <int TA, int TB, bool BKM>
+__global__ __launch_bounds__(256) void gemm_kc_direct_kernel(GemmArgs g, int tiles_n) {
+    constexpr int D = 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int c = lane & 15, q = lane >> 4;
+    int v = blockIdx.x;
+    if ((gridDim.x & 7) == 0) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tm = v / tiles_n, tn = v - tm * tiles_n;
+    const int m0 = tm * (32 * TA) + wr * (16 * TA), n0 = tn * (32 * TB) + wc * (16 * TB);
+    const int lda = (int)g.lda, ldb = (int)g.ldb;
+    const __amdgpu_buffer_rsrc_t ra_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.M * lda * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * ldb * 4, 0x00020000);
+
+    int oa[TA];                                          // this lane's 16 bytes of k group 0, row tile i
+#pragma unroll
+    for (int i = 0; i < TA; ++i) oa[i] = ((m0 + 16 * i + c) * lda + 4 * q) * 4;
+    constexpr int NOB = BKM ? 4 : TB;
+    int ob[NOB];                                         // k-major: row 4q + e, columns n0 + TB c ..; else row tile j
+#pragma unroll
+    for (int x = 0; x < NOB; ++x)
+        ob[x] = BKM ? ((4 * q + x) * ldb + n0 + TB * c) * 4 : ((n0 + TB * c + x) * ldb + 4 * q) * 4;
+    const int adv_b = BKM ? 16 * ldb * 4 : 64;           // one k group further
+
+    f32x4 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 fa[D][TA];
+    FVec<4> fbk[D][BKM ? 1 : TB];                        // k-contiguous B: [row tile j] -> elements e
+    FVec<TB> fbm[D][BKM ? 4 : 1];                        // k-major B:      [e] -> columns j
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+            fa[s][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, oa[i], 0, 0));
+            oa[i] += 64;
+        }
+#pragma unroll
+        for (int x = 0; x < NOB; ++x) {
+            if constexpr (BKM) fbm[s][x] = ld_cols<TB>(rb_rsrc, ob[x]);
+            else fbk[s][x] = ld_cols<4>(rb_rsrc, ob[x]);
+            ob[x] += adv_b;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        fetch(s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int nblocks = g.K / (16 * D);
+    for (int b = 0; b < nblocks; ++b) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        float bv;
+                        if constexpr (BKM) bv = fbm[s][e].v[j];
+                        else bv = fbk[s][j].v[e];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][i][e], bv, acc[i][j], 0, 0, 0);
+                    }
+            fetch(s);                                    // same group of the next block; past K the values are never used
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // C/D map of the 16x16 MFMA: row = 4q + r, column slot c  ->  global column n0 + TB c + j
+    const int col0 = n0 + TB * c;
+    float bias[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) bias[j] = g.bias ? g.bias[col0 + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * i + 4 * q + r;
+            float* cp = g.C + (long)row * g.ldc + col0;
+            FVec<TB> o;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) o.v[j] = acc[i][j][r] + bias[j];
+            if (g.epi != EPI_NONE) {
+                const float* ap = g.aux ? g.aux + (long)row * g.ldaux + col0 : nullptr;
+#pragma unroll
+                for (int j = 0; j < TB; ++j) o.v[j] = apply_epi(o.v[j], g.epi, ap ? ap[j] : 0.f);
+            }
+            if (g.acc == ACC_ADD) {
+#pragma unroll
+                for (int j = 0; j < TB; ++j) o.v[j] += cp[j];
+            }
+            struct __attribute__((packed, aligned(4))) Out { float v[TB]; };
+            Out st;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) st.v[j] = o.v[j];
+            *reinterpret_cast<Out*>(cp) = st;
+        }
+}
+
 template <int TM, int TN>
 int launch_cfg(const GemmArgs& g, dim3 grid, hipStream_t s, unsigned pad) {
     if (!g.a_kmajor && !g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, dim3(256), pad, s, g);
@@ -250,6 +493,70 @@ __global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int
 }
 
 int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (INET_GEMM_FORCE="cfg,split"), -1: cost model
+int g_direct = -1;                            // INET_GEMM_DIRECT: 0 never, 1 (default) cost model, 2 whenever applicable
+
+struct DirectCfg { int ta, tb; };
+const DirectCfg kDirect[] = {{3, 2}, {2, 2}, {3, 3}};
+inline long tiles_of(const DirectCfg& c, const GemmArgs& g) { return (long)(g.M / (64 * c.ta)) * (g.N / (64 * c.tb)); }
+
+// Direct (LDS-free) k-major x k-major product: returns 1 when the shape does not qualify, else the launch status.
+// `budget_us`: estimated cost of the best LDS-tiled configuration (the direct kernel is taken when it beats it).
+int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, double budget_us, int force_split) {
+    GemmArgs g = gin;
+    const bool nonlinear = g.epi != EPI_NONE;
+    if (!g.a_kmajor || !g.b_kmajor || (g.M & 63) || (g.N & 63) || g.K < 64) return 1;
+    if ((double)g.K * g.lda * 4 >= 2.0e9 || (double)g.K * g.ldb * 4 >= 2.0e9) return 1;
+    const int kSplits[] = {1, 2, 4, 8, 16, 32};
+    double best = 1e300;
+    int bi = -1, bs = 1;
+    for (int ci = 0; ci < 3; ++ci) {
+        const DirectCfg& c = kDirect[ci];
+        if (g.M % (64 * c.ta) || g.N % (64 * c.tb)) continue;
+        const long tiles = (long)(g.M / (64 * c.ta)) * (g.N / (64 * c.tb));
+        for (int sp : kSplits) {
+            if (sp > 1 && (g.K / sp < 64 || (nonlinear && g.acc != ACC_STORE))) break;
+            if (force_split > 0 && sp != force_split) continue;
+            const long wgs = tiles * sp;
+            const long rounds = (wgs + 255) / 256;
+            const double steps = (double)((g.K + sp - 1) / sp + 1) / 2;
+            double cost = rounds * (steps * c.ta * c.tb * (64.0 / 2400.0) + 4.0);
+            if (sp > 1) cost += 2.0 + (double)g.M * g.N * sp / 6.0e5 + (nonlinear ? 3.0 : 0.0);
+            if (cost < best) { best = cost; bi = ci; bs = sp; }
+        }
+    }
+    if (bi < 0 || (g_direct < 2 && (g.K / bs < 512 || (long)tiles_of(kDirect[bi], g) * bs < 192))) return 1;
+    (void)budget_us;
+    const DirectCfg& c = kDirect[bi];
+    int kps = (g.K + bs - 1) / bs;
+    kps = (kps + 1) / 2 * 2;
+    const int splits = (g.K + kps - 1) / kps;
+    g.k_per_split = kps;
+    const bool two_pass = splits > 1 && nonlinear;
+    if (splits > 1) {
+        if (g.acc == ACC_STORE && pw_zero2d(g.C, g.ldc, g.M, g.N, s) != 0) return -2;
+        g.acc = ACC_ATOMIC;
+        if (two_pass) g.epi = EPI_NONE;
+    }
+    const int tiles_n = g.N / (64 * c.tb), tiles = tiles_n * (g.M / (64 * c.ta));
+    char label[96];
+    std::snprintf(label, sizeof label, "M%d N%d K%d TN d%dx%d s%d e%d", g.M, g.N, g.K, 64 * c.ta, 64 * c.tb, splits,
+                  gin.epi);
+    ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label,
+                   4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    const dim3 grid(tiles * splits);
+    if (bi == 0) hipLaunchKernelGGL((gemm_tn_direct_kernel<3, 2>), grid, dim3(256), 0, s, g, tiles_n, tiles);
+    else if (bi == 1) hipLaunchKernelGGL((gemm_tn_direct_kernel<2, 2>), grid, dim3(256), 0, s, g, tiles_n, tiles);
+    else hipLaunchKernelGGL((gemm_tn_direct_kernel<3, 3>), grid, dim3(256), 0, s, g, tiles_n, tiles);
+    int rc = hipGetLastError() == hipSuccess ? 0 : -2;
+    if (rc == 0 && two_pass) {
+        long n = (long)g.M * g.N;
+        int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(gemm_epilogue_kernel, dim3(blocks), dim3(256), 0, s, g.C, g.ldc, g.M, g.N, gin.aux, gin.ldaux,
+                           gin.epi);
+        rc = hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    return rc;
+}
 
 }  // namespace
 
@@ -258,6 +565,53 @@ void gemm_set_force(int cfg, int split) {
     if (cfg >= -1) g_force_cfg = cfg;
     if (split >= 0) g_force_split = split;
 }
+
+struct KcCfg { int ta, tb; };
+const KcCfg kKc[] = {{6, 6}, {6, 4}, {6, 2}, {4, 4}};
+
+template <int TA, int TB>
+void launch_kc(const GemmArgs& g, dim3 grid, hipStream_t s, int tiles_n) {
+    if (g.b_kmajor) hipLaunchKernelGGL((gemm_kc_direct_kernel<TA, TB, true>), grid, dim3(256), 0, s, g, tiles_n);
+    else hipLaunchKernelGGL((gemm_kc_direct_kernel<TA, TB, false>), grid, dim3(256), 0, s, g, tiles_n);
+}
+
+// Direct kernel for a k-contiguous A (forward and data-gradient products): no split-K, so it needs a tile
+// configuration whose grid fills the chip by itself.  Returns 1 when the shape does not qualify.
+int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s, double budget_us) {
+    if (g.a_kmajor || (g.K & 63) || g.acc == ACC_ATOMIC) return 1;
+    if ((double)g.M * g.lda * 4 >= 2.0e9 || (double)(g.b_kmajor ? g.K : g.N) * g.ldb * 4 >= 2.0e9) return 1;
+    double best = 1e300;
+    int bi = -1;
+    for (int ci = 0; ci < 4; ++ci) {
+        const KcCfg& c = kKc[ci];
+        if (g.M % (32 * c.ta) || g.N % (32 * c.tb)) continue;
+        const long wgs = (long)(g.M / (32 * c.ta)) * (g.N / (32 * c.tb));
+        if (wgs < 192 && g_direct < 2) continue;
+        const long rounds = (wgs + 255) / 256;
+        const double cost = rounds * ((double)g.K / 4 * c.ta * c.tb * (32.0 / 1900.0) + 8.0);
+        if (cost < best) { best = cost; bi = ci; }
+    }
+    if (bi < 0 || (g_direct < 2 && g.K < 512)) return 1;
+    (void)budget_us;
+    const KcCfg& c = kKc[bi];
+    const int tiles_n = g.N / (32 * c.tb);
+    const dim3 grid(tiles_n * (g.M / (32 * c.ta)));
+    char label[96];
+    std::snprintf(label, sizeof label, "M%d N%d K%d N%c d%dx%d s1 e%d", g.M, g.N, g.K, g.b_kmajor ? 'N' : 'T', 32 * c.ta,
+                  32 * c.tb, g.epi);
+    ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label,
+                   4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    switch (bi) {
+        case 0: launch_kc<6, 6>(g, grid, s, tiles_n); break;
+        case 1: launch_kc<6, 4>(g, grid, s, tiles_n); break;
+        case 2: launch_kc<6, 2>(g, grid, s, tiles_n); break;
+        default: launch_kc<4, 4>(g, grid, s, tiles_n); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// inet_set_option key 5: 0 = LDS-tiled kernels only, 1 = cost model (default), 2 = the direct kernel whenever it applies
+void gemm_set_direct(int mode) { g_direct = mode; }
 
 // Tile / split-K selection by a small cost model (microseconds), calibrated on MI355X (profiles/r01_*):
 //  * a workgroup alone on a CU spends ~0.7 us per 32-deep chunk on the load -> LDS -> MFMA dependency, whatever the
@@ -298,6 +652,14 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
             if (sp > 1) cost += 2.0 + (double)g.M * g.N * sp / 6.0e5 + (nonlinear ? 3.0 : 0.0);
             if (cost < best) { best = cost; bi = ci; bs = sp; }
         }
+    }
+    if (g_direct < 0) {
+        const char* v = std::getenv("INET_GEMM_DIRECT");
+        g_direct = v ? std::atoi(v) : 1;
+    }
+    if (g_direct > 0 && force_cfg < 0) {
+        const int rc = gin.a_kmajor ? launch_gemm_direct(gin, s, best, force_split) : launch_gemm_kc_direct(gin, s, best);
+        if (rc != 1) return rc;
     }
     if (force_cfg >= 0 && force_cfg < kNumCfgs) {
         bi = force_cfg;

@@ -217,7 +217,8 @@ def prof_enable(on):
 
 
 def set_option(key, value):
-    """inet_set_option (include/inpaintnet_hip.h): 0 side stream, 1 deferred joins, 2 GEMM tile force, 3 GEMM split force."""
+    """inet_set_option (include/inpaintnet_hip.h): 0 side stream, 1 deferred joins, 2 GEMM tile force, 3 GEMM split force, 4 chain kernels,
+    5 direct k-major GEMM (0 never / 1 cost model / 2 always)."""
     check(_lib.lib().inet_set_option(int(key), int(value)), "inet_set_option")
 
 

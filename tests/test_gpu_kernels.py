@@ -63,6 +63,81 @@ def test_gemm_layouts(akm, bkm, M, N, K):
     assert relmax(C1, ref + C0.double()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 512, 6144), (1536, 1024, 1000), (384, 256, 131), (128, 128, 64),
+                                   (576, 576, 777), (1024, 2048, 256)])
+def test_gemm_direct_kmajor_products(M, N, K):
+    """The LDS-free weight-gradient kernel (csrc/gemm.hip gemm_tn_direct_kernel), forced wherever the shape qualifies:
+    plain, accumulating, biased + non-linear epilogue, strided destination; odd K and K not a multiple of the prefetch
+    block exercise the zero-returning out-of-range buffer loads."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad, Bd = A.t().contiguous().to(DEV), B.t().contiguous().to(DEV)
+    ops.set_option(5, 2)
+    try:
+        ops.prof_enable(True)
+        C = ops.gemm(Ad, Bd, M, N, K, a_kmajor=1, b_kmajor=1)
+        torch.cuda.synchronize()
+        ops.prof_dump("/tmp/_inet_direct.csv")
+        ops.prof_enable(False)
+        assert " d" in open("/tmp/_inet_direct.csv").read().strip().splitlines()[-1].split(",")[1]
+        assert relmax(C, ref) < 2e-5
+        C0 = torch.randn(M, N, generator=g)
+        C1 = C0.to(DEV).clone()
+        ops.gemm(Ad, Bd, M, N, K, a_kmajor=1, b_kmajor=1, out=C1, accumulate=True)
+        assert relmax(C1, ref + C0.double()) < 2e-5
+        out = ops.gemm(Ad, Bd, M, N, K, a_kmajor=1, b_kmajor=1, bias=bias.to(DEV), epi=1)
+        assert relmax(out, O.selu(ref + bias.double())) < 2e-5
+        big = torch.zeros(M, 2, N, device=DEV)
+        ops.gemm(Ad, Bd, M, N, K, a_kmajor=1, b_kmajor=1, out=big[:, 1, :])
+        assert relmax(big[:, 1, :], ref) < 2e-5
+        assert float(big[:, 0, :].abs().max()) == 0.0
+    finally:
+        ops.set_option(5, 1)
+        ops.prof_enable(False)
+
+
+@pytest.mark.parametrize("bkm", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(6144, 1536, 1024), (6144, 1024, 1536), (6144, 512, 1536), (384, 256, 64),
+                                   (192, 64, 192), (1152, 768, 320)])
+def test_gemm_direct_kcontiguous_products(M, N, K, bkm):
+    """The LDS-free forward / data-gradient kernel (csrc/gemm.hip gemm_kc_direct_kernel), forced wherever the shape
+    qualifies: plain, accumulating, bias + non-linear epilogue with an aux operand, strided destination."""
+    g = torch.Generator().manual_seed(M + 3 * N + K + bkm)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad, Bd = A.to(DEV), (B.t().contiguous() if bkm else B).to(DEV)
+    ops.set_option(5, 2)
+    try:
+        ops.prof_enable(True)
+        C = ops.gemm(Ad, Bd, M, N, K, b_kmajor=bkm)
+        torch.cuda.synchronize()
+        ops.prof_dump("/tmp/_inet_direct.csv")
+        ops.prof_enable(False)
+        assert " d" in open("/tmp/_inet_direct.csv").read().strip().splitlines()[-1].split(",")[1]
+        assert relmax(C, ref) < 2e-5
+        C0 = torch.randn(M, N, generator=g)
+        C1 = C0.to(DEV).clone()
+        ops.gemm(Ad, Bd, M, N, K, b_kmajor=bkm, out=C1, accumulate=True)
+        assert relmax(C1, ref + C0.double()) < 2e-5
+        out = ops.gemm(Ad, Bd, M, N, K, b_kmajor=bkm, bias=bias.to(DEV), epi=1)
+        assert relmax(out, O.selu(ref + bias.double())) < 2e-5
+        out = ops.gemm(Ad, Bd, M, N, K, b_kmajor=bkm, epi=4, aux=aux.to(DEV))
+        assert relmax(out, ref * aux.double()) < 2e-5
+        big = torch.zeros(M, 2, N, device=DEV)
+        ops.gemm(Ad, Bd, M, N, K, b_kmajor=bkm, out=big[:, 1, :])
+        assert relmax(big[:, 1, :], ref) < 2e-5
+        assert float(big[:, 0, :].abs().max()) == 0.0
+    finally:
+        ops.set_option(5, 1)
+        ops.prof_enable(False)
+
+
 def test_gemm_strided_unaligned_and_epilogues():
     g = torch.Generator().manual_seed(5)
     M, N, K = 77, 50, 128
