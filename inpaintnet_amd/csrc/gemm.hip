@@ -465,6 +465,134 @@ __global__ __launch_bounds__(256) void gemm_kc_direct_kernel(GemmArgs g, int til
         }
 }
 
+// ---------------------------------------------------------------------------
+// Medium and small products (M or N of a few hundred, K of 256..2048: the Linear heads, the decoder's batched input
+// projections and their gradients): too few output tiles to give every wave its own, so the four waves of a workgroup
+// split K instead.  Wave w runs the 16-deep k groups w, w+4, ... of the WHOLE workgroup tile through the same
+// register-fed v_mfma_f32_16x16x4_f32 loop as above (no sharing between waves, no barriers in the loop), the four partial
+// tiles meet once in LDS, and every wave finishes a quarter of the tile with the full epilogue: bias, non-linearity, aux
+// operand, store or accumulate -- one launch where the LDS-tiled path needs a zero-fill, a split-K launch with f32
+// atomics and (for a non-linear epilogue) a third pass.  Either operand may be k-contiguous (16-byte loads of one row) or
+// k-major (the strip's rows dealt to lanes T at a time, one 4T-byte load per k row).
+// ---------------------------------------------------------------------------
+template <int T, bool KM>
+struct KsOperand {
+    // one 16-deep k group of a 16*T-row strip, as the values this lane feeds to MFMA e (k slot q): v[e][t]
+    float v[4][T];
+    int off[KM ? 4 : T];
+    int adv;
+    __device__ __forceinline__ void init(int r0, int ld, int c, int q, int g0) {
+        if constexpr (KM) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) off[e] = ((16 * g0 + 4 * q + e) * ld + r0 + T * c) * 4;
+            adv = 64 * ld * 4;                          // 4 groups (one per wave) further
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) off[t] = ((r0 + T * c + t) * ld + 16 * g0 + 4 * q) * 4;
+            adv = 64 * 4;
+        }
+    }
+    __device__ __forceinline__ void fetch(__amdgpu_buffer_rsrc_t r) {
+        if constexpr (KM) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const FVec<T> x = ld_cols<T>(r, off[e]);
+#pragma unroll
+                for (int t = 0; t < T; ++t) v[e][t] = x.v[t];
+                off[e] += adv;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const FVec<4> x = ld_cols<4>(r, off[t]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e][t] = x.v[e];
+                off[t] += adv;
+            }
+        }
+    }
+};
+
+template <int TA, int TB, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n) {
+    constexpr int D = 4, NR = TA * TB * 4, QR = NR / 4;
+    __shared__ float red[NR * 4 * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    int v = blockIdx.x;
+    if ((gridDim.x & 7) == 0) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tm = v / tiles_n, tn = v - tm * tiles_n;
+    const int m0 = tm * (16 * TA), n0 = tn * (16 * TB);
+    const int lda = (int)g.lda, ldb = (int)g.ldb;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * lda * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * ldb * 4, 0x00020000);
+
+    KsOperand<TA, AKM> a[D];
+    KsOperand<TB, BKM> b[D];
+    f32x4 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        a[s].init(m0, lda, c, q, w + 4 * s);
+        b[s].init(n0, ldb, c, q, w + 4 * s);
+        a[s].adv *= D;
+        b[s].adv *= D;
+        a[s].fetch(ra_rsrc);
+        b[s].fetch(rb_rsrc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int G = (g.K + 15) >> 4;                       // k groups in all; this wave owns w, w+4, ...
+    for (int g0 = w; g0 < G; g0 += 4 * D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            if (g0 + 4 * s < G) {                        // wave-uniform: past K a k-contiguous operand is not zero
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int j = 0; j < TB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].v[e][i], b[s].v[e][j], acc[i][j], 0, 0, 0);
+            }
+            a[s].fetch(ra_rsrc);
+            b[s].fetch(rb_rsrc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // the four partial tiles meet in LDS: [register][wave][lane]
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((i * TB + j) * 4 + r) * 4 + w) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+    // wave w finishes registers [QR w, QR w + QR): rows and columns dealt like the operands (MFMA row c' = 4q + r of
+    // tile i is strip row TA*c' + i, column c of tile j is strip column TB*c + j)
+#pragma unroll
+    for (int x = 0; x < QR; ++x) {
+        const int reg = QR * w + x;
+        const float* p = red + (reg * 4) * 64 + lane;
+        float val = (p[0] + p[64]) + (p[128] + p[192]);
+        const int r = reg & 3, j = (reg >> 2) % TB, i = (reg >> 2) / TB;
+        const int rr = 4 * q + r;
+        const int row = m0 + TA * rr + i;
+        const int col = n0 + TB * c + j;
+        if (g.bias) val += g.bias[col];
+        if (g.epi != EPI_NONE) val = apply_epi(val, g.epi, g.aux ? g.aux[(long)row * g.ldaux + col] : 0.f);
+        float* cp = g.C + (long)row * g.ldc + col;
+        if (g.acc == ACC_STORE) *cp = val;
+        else if (g.acc == ACC_ADD) *cp += val;
+        else unsafeAtomicAdd(cp, val);
+    }
+}
+
 template <int TM, int TN>
 int launch_cfg(const GemmArgs& g, dim3 grid, hipStream_t s, unsigned pad) {
     if (!g.a_kmajor && !g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, dim3(256), pad, s, g);
@@ -493,7 +621,7 @@ __global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int
 }
 
 int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (INET_GEMM_FORCE="cfg,split"), -1: cost model
-int g_direct = -1;                            // INET_GEMM_DIRECT: 0 never, 1 (default) cost model, 2 whenever applicable
+int g_direct = -1;                            // INET_GEMM_DIRECT: 0 never, 1 (default) by shape, 2 whenever applicable, 3 big shapes only
 
 struct DirectCfg { int ta, tb; };
 const DirectCfg kDirect[] = {{3, 2}, {2, 2}, {3, 3}};
@@ -524,7 +652,7 @@ int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, double budget_us, int
             if (cost < best) { best = cost; bi = ci; bs = sp; }
         }
     }
-    if (bi < 0 || (g_direct < 2 && (g.K / bs < 512 || (long)tiles_of(kDirect[bi], g) * bs < 192))) return 1;
+    if (bi < 0 || (g_direct != 2 && (g.K / bs < 512 || (long)tiles_of(kDirect[bi], g) * bs < 192))) return 1;
     (void)budget_us;
     const DirectCfg& c = kDirect[bi];
     int kps = (g.K + bs - 1) / bs;
@@ -586,12 +714,12 @@ int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s, double budget_us) {
         const KcCfg& c = kKc[ci];
         if (g.M % (32 * c.ta) || g.N % (32 * c.tb)) continue;
         const long wgs = (long)(g.M / (32 * c.ta)) * (g.N / (32 * c.tb));
-        if (wgs < 192 && g_direct < 2) continue;
+        if (wgs < 192 && g_direct != 2) continue;
         const long rounds = (wgs + 255) / 256;
         const double cost = rounds * ((double)g.K / 4 * c.ta * c.tb * (32.0 / 1900.0) + 8.0);
         if (cost < best) { best = cost; bi = ci; }
     }
-    if (bi < 0 || (g_direct < 2 && g.K < 512)) return 1;
+    if (bi < 0 || (g_direct != 2 && g.K < 512)) return 1;
     (void)budget_us;
     const KcCfg& c = kKc[bi];
     const int tiles_n = g.N / (32 * c.tb);
@@ -606,6 +734,50 @@ int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s, double budget_us) {
         case 1: launch_kc<6, 4>(g, grid, s, tiles_n); break;
         case 2: launch_kc<6, 2>(g, grid, s, tiles_n); break;
         default: launch_kc<4, 4>(g, grid, s, tiles_n); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+struct KsCfg { int ta, tb; };
+const KsCfg kKs[] = {{4, 4}, {4, 2}, {2, 2}};
+
+template <int TA, int TB>
+void launch_ks(const GemmArgs& g, dim3 grid, hipStream_t s, int tiles_n) {
+    if (g.a_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, true, true>), grid, dim3(256), 0, s, g, tiles_n);
+    else if (g.b_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, false, true>), grid, dim3(256), 0, s, g, tiles_n);
+    else hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, false, false>), grid, dim3(256), 0, s, g, tiles_n);
+}
+
+// In-workgroup split-K kernel for the medium / small products.  Returns 1 when the shape does not qualify.
+int launch_gemm_ks(const GemmArgs& g, hipStream_t s) {
+    if (g.a_kmajor && !g.b_kmajor) return 1;
+    if (!g.a_kmajor && (g.K & 15)) return 1;             // a k-contiguous operand has no zero-returning K tail
+    if (g.acc == ACC_ATOMIC || g.K < 64) return 1;
+    if ((double)(g.a_kmajor ? g.K : g.M) * g.lda * 4 >= 2.0e9 || (double)(g.b_kmajor ? g.K : g.N) * g.ldb * 4 >= 2.0e9) return 1;
+    // rounds of 256 workgroups x MFMAs per workgroup, the smaller tiles charged for their higher L2 traffic per MFMA
+    const double kL2[] = {1.0, 1.15, 1.5};
+    int bi = -1;
+    double best = 1e300;
+    for (int ci = 0; ci < 3; ++ci) {
+        const KsCfg& c = kKs[ci];
+        if (g.M % (16 * c.ta) || g.N % (16 * c.tb)) continue;
+        const long wgs = (long)(g.M / (16 * c.ta)) * (g.N / (16 * c.tb));
+        const double cost = (double)((wgs + 255) / 256) * c.ta * c.tb * kL2[ci];
+        if (cost < best) { best = cost; bi = ci; }
+    }
+    if (bi < 0) return 1;
+    const KsCfg& c = kKs[bi];
+    const int tiles_n = g.N / (16 * c.tb);
+    const dim3 grid(tiles_n * (g.M / (16 * c.ta)));
+    char label[96];
+    std::snprintf(label, sizeof label, "M%d N%d K%d %c%c k%dx%d s1 e%d", g.M, g.N, g.K, g.a_kmajor ? 'T' : 'N',
+                  g.b_kmajor ? 'N' : 'T', 16 * c.ta, 16 * c.tb, g.epi);
+    ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label,
+                   4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    switch (bi) {
+        case 0: launch_ks<4, 4>(g, grid, s, tiles_n); break;
+        case 1: launch_ks<4, 2>(g, grid, s, tiles_n); break;
+        default: launch_ks<2, 2>(g, grid, s, tiles_n); break;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -658,7 +830,8 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
         g_direct = v ? std::atoi(v) : 1;
     }
     if (g_direct > 0 && force_cfg < 0) {
-        const int rc = gin.a_kmajor ? launch_gemm_direct(gin, s, best, force_split) : launch_gemm_kc_direct(gin, s, best);
+        int rc = gin.a_kmajor ? launch_gemm_direct(gin, s, best, force_split) : launch_gemm_kc_direct(gin, s, best);
+        if (rc == 1 && g_direct != 3 && force_split == 0) rc = launch_gemm_ks(gin, s);
         if (rc != 1) return rc;
     }
     if (force_cfg >= 0 && force_cfg < kNumCfgs) {

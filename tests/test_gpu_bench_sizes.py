@@ -80,8 +80,9 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     # the big products run on the LDS-free direct kernels (forward NT 192x192, data-gradient NN 192x128, weight-gradient
     # TN 192x128 split over the XCDs); the 192-row LDS-tiled instantiations are covered by the forced-tile test below
     big = sorted(set(l for l in labels if l.startswith("M")))
-    for wl in ("M6144 N1536 K1024 NT d192x192 s1 e0", "M6144 N1024 K1536 NN d192x128 s1 e0",
-               "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N1024 K6144 TN d192x128 s4 e0"):
+    for wl in ("M6144 N1536 K1024 NT d192x192 s1 e0", "M6144 N1024 K1536 NN d192x128 s1 e4",   # e4: dropout mask epilogue
+               "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N1024 K6144 TN d192x128 s4 e0",
+               "M256 N1024 K2048 NT k32x32 s1 e1"):                                            # workgroup split-K, SELU head
         assert wl in labels, (wl, big)
     print(sorted(set(l for l in labels if l.startswith("gru"))))
 

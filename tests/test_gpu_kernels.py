@@ -138,6 +138,47 @@ def test_gemm_direct_kcontiguous_products(M, N, K, bkm):
         ops.prof_enable(False)
 
 
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 2048), (1536, 512, 1024), (1024, 2048, 256), (256, 256, 1024),
+                                   (64, 32, 64), (32, 32, 1008), (128, 96, 336)])
+def test_gemm_workgroup_split_k(akm, bkm, M, N, K):
+    """The in-workgroup split-K kernel (csrc/gemm.hip gemm_ks_kernel) on the medium / small shapes of the step, every
+    operand layout it takes: plain, accumulating, bias + SELU, aux epilogues, strided destination; for k-major
+    operands also a K that is not a multiple of the 16-deep group."""
+    for Kx in ([K, K - 6] if akm else [K]):
+        g = torch.Generator().manual_seed(M + 3 * N + Kx + akm + 2 * bkm)
+        A = torch.randn(M, Kx, generator=g)
+        B = torch.randn(N, Kx, generator=g)
+        bias = torch.randn(N, generator=g)
+        aux = torch.randn(M, N, generator=g)
+        ref = A.double() @ B.double().t()
+        Ad = (A.t().contiguous() if akm else A).to(DEV)
+        Bd = (B.t().contiguous() if bkm else B).to(DEV)
+        kw = dict(a_kmajor=akm, b_kmajor=bkm)
+        ops.prof_enable(True)
+        C = ops.gemm(Ad, Bd, M, N, Kx, **kw)
+        torch.cuda.synchronize()
+        ops.prof_dump("/tmp/_inet_ks.csv")
+        ops.prof_enable(False)
+        if Kx >= 64:                                          # shorter products stay on the LDS-tiled kernel
+            assert " k" in open("/tmp/_inet_ks.csv").read().strip().splitlines()[-1].split(",")[1]
+        assert relmax(C, ref) < 2e-5
+        C0 = torch.randn(M, N, generator=g)
+        C1 = C0.to(DEV).clone()
+        ops.gemm(Ad, Bd, M, N, Kx, out=C1, accumulate=True, **kw)
+        assert relmax(C1, ref + C0.double()) < 2e-5
+        out = ops.gemm(Ad, Bd, M, N, Kx, bias=bias.to(DEV), epi=1, **kw)
+        assert relmax(out, O.selu(ref + bias.double())) < 2e-5
+        out = ops.gemm(Ad, Bd, M, N, Kx, epi=4, aux=aux.to(DEV), **kw)
+        assert relmax(out, ref * aux.double()) < 2e-5
+        out = ops.gemm(Ad, Bd, M, N, Kx, epi=5, aux=aux.to(DEV), **kw)
+        assert relmax(out, ref * (aux > 0).double()) < 2e-5
+        big = torch.zeros(M, 2, N, device=DEV)
+        ops.gemm(Ad, Bd, M, N, Kx, out=big[:, 1, :], **kw)
+        assert relmax(big[:, 1, :], ref) < 2e-5
+        assert float(big[:, 0, :].abs().max()) == 0.0
+
+
 def test_gemm_strided_unaligned_and_epilogues():
     g = torch.Generator().manual_seed(5)
     M, N, K = 77, 50, 128

@@ -15,7 +15,7 @@ def short(n):
     return n[:58]
 
 
-def main(path, which=5, gap_us=12.0):
+def main(path, which=5, gap_us=12.0, full=False):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
@@ -54,6 +54,16 @@ def main(path, which=5, gap_us=12.0):
         e0 = (int(r["End_Timestamp"]) - T0) / 1e3
         if e0 > (T1 - T0) / 1e3 - 1200 and e0 - s0 > 8:
             print(f"  {s0:8.1f} {e0:8.1f}  s{r['Stream_Id']}  {short(r['Kernel_Name'])[:44]:<44} g={r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}")
+    if full:
+        print("every kernel of the step (start, end, gap to the previous kernel of the same stream, stream, kernel, grid):")
+        last = {}
+        for r in step:
+            s0 = (int(r["Start_Timestamp"]) - T0) / 1e3
+            e0 = (int(r["End_Timestamp"]) - T0) / 1e3
+            sid = r["Stream_Id"]
+            gap = s0 - last[sid] if sid in last else 0.0
+            last[sid] = e0
+            print(f"  {s0:8.1f} {e0:8.1f} {gap:7.1f}  s{sid}  {short(r['Kernel_Name'])[:50]:<50} g={r['Grid_Size_X']}")
     by = collections.defaultdict(lambda: [0, 0.0])
     for r in step:
         k = short(r["Kernel_Name"])
@@ -65,4 +75,4 @@ def main(path, which=5, gap_us=12.0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 5, full=len(sys.argv) > 3 and sys.argv[3] == "full")

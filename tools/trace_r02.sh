@@ -10,7 +10,7 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -o t -- pyth
 cd $ROOT
 TR=$(find $OUT/tr -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py $TR 5 > $OUT/timeline_step5.txt 2>&1
-python3 tools/timeline.py $TR 6 > $OUT/timeline_step6.txt 2>&1
+python3 tools/timeline.py $TR 6 full > $OUT/timeline_step6.txt 2>&1
 python3 tools/pmc_summary.py stats $TR > $OUT/kernel_stats.txt 2>&1
 rm -rf $OUT/tr
 cat $OUT/timeline_step5.txt; tail -2 $OUT/trace.log
