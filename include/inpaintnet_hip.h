@@ -103,16 +103,18 @@ int inet_vae_ws_field(const inet_vae_config* cfg, int batch, int which, const ch
                       int64_t* count);
 
 /* ---- losses: VAETrainer.loss_and_acc_for_batch, vae_trainer.py:16-40,128-139; utils/trainer.py:271-306 */
-/* rows of V logits (row stride ld_w); out3[0] += sum_rows (lse - w[target]); out3[1] += #correct (argmax_first);
+/* rows of V logits (row stride ld_w); *loss_sum += out_scale * sum_rows (lse - w[target]); *correct += out_scale *
+ * #correct (argmax_first) -- out_scale = 1/rows gives the reference's means without a follow-up kernel;
  * dW (nullable, row stride ld_dw) = (softmax - onehot) * scale */
 int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
-                       int64_t ld_dw, float scale, float* loss_sum, float* correct, void* stream);
+                       int64_t ld_dw, float scale, float out_scale, float* loss_sum, float* correct, void* stream);
 /* z = mu + eps*exp(logsigma) (measure_vae.py:119); sigma out (nullable); kl_sum += sum(0.5(s^2+mu^2-1) - ls) */
 int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, float* z, float* sigma, int64_t n,
                     float* kl_sum, void* stream);
-/* dmu = dz + kscale*mu; dlogsigma = dz*eps*sigma + kscale*(sigma^2-1) */
+/* dmu = dz + k*mu; dlogsigma = dz*eps*sigma + k*(sigma^2-1), k = kscale * (kscale_dev ? *kscale_dev : 1): the gradient of
+ * z (dz, nullable) and of the KL sum (a device scalar from autograd, nullable) in one pass */
 int inet_latent_bwd(const float* dz, const float* mu, const float* logsigma, const float* eps, float kscale,
-                    float* dmu, float* dlogsigma, int64_t n, void* stream);
+                    const float* kscale_dev, float* dmu, float* dlogsigma, int64_t n, void* stream);
 
 /* ---- optimizer: torch.optim.Adam as built at utils/trainer.py:32-35, stepped at :172-177 -------- */
 /* p,g,m,v: arenas of n floats; step is 1-based; grads are multiplied by gscale first (1/world_size for DP) */

@@ -141,10 +141,10 @@ int inet_vae_ws_field(const inet_vae_config* cfg, int batch, int which, const ch
 }
 
 int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
-                       int64_t ld_dw, float scale, float* loss_sum, float* correct, void* stream) {
+                       int64_t ld_dw, float scale, float out_scale, float* loss_sum, float* correct, void* stream) {
     if (!weights || !targets || !loss_sum || !correct || rows <= 0 || V <= 0) return -1;
-    return pw_cross_entropy(weights, ld_w, rows, V, (const long long*)targets, dW, ld_dw, scale, loss_sum, correct,
-                            (hipStream_t)stream);
+    return pw_cross_entropy(weights, ld_w, rows, V, (const long long*)targets, dW, ld_dw, scale, out_scale, loss_sum,
+                            correct, (hipStream_t)stream);
 }
 int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, float* z, float* sigma, int64_t n,
                     float* kl_sum, void* stream) {
@@ -152,9 +152,9 @@ int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, fl
     return pw_reparam_kl(mu, logsigma, eps, z, sigma, n, kl_sum, (hipStream_t)stream);
 }
 int inet_latent_bwd(const float* dz, const float* mu, const float* logsigma, const float* eps, float kscale,
-                    float* dmu, float* dlogsigma, int64_t n, void* stream) {
+                    const float* kscale_dev, float* dmu, float* dlogsigma, int64_t n, void* stream) {
     if (!mu || !logsigma || !dmu || !dlogsigma || n <= 0) return -1;
-    return pw_latent_bwd(dz, mu, logsigma, eps, kscale, dmu, dlogsigma, n, (hipStream_t)stream);
+    return pw_latent_bwd(dz, mu, logsigma, eps, kscale, kscale_dev, dmu, dlogsigma, n, (hipStream_t)stream);
 }
 int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int step, float gscale, void* stream) {

@@ -11,11 +11,11 @@ int pw_pack_frag(const float* in, long ld, int R, int K, float* out, int transpo
 int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long ld, int R, int K, int transposed,
                        hipStream_t s);
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
-                     float scale, float* loss_sum, float* correct, hipStream_t s);
+                     float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s);
 int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,
                   hipStream_t s);
-int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, float* dmu,
-                  float* dls, long n, hipStream_t s);
+int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, const float* kdev,
+                  float* dmu, float* dls, long n, hipStream_t s);
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
             float gscale, hipStream_t s);
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);

@@ -98,11 +98,11 @@ __global__ void pack_frag_multi_kernel(PackList pl, long ld, int R, int K, int t
     }
 }
 
-// One wavefront per row of V logits.  loss_sum += lse - w[target];
-// correct += (argmax_first(w) == target); dW = (softmax - onehot) * scale.
+// One wavefront per row of V logits.  loss_sum += out_scale * (lse - w[target]);
+// correct += out_scale * (argmax_first(w) == target); dW = (softmax - onehot) * scale.
 __global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int V,
                           const long long* __restrict__ tgt, float* __restrict__ dW, long ld_dw, float scale,
-                          float* __restrict__ loss_sum, float* __restrict__ correct) {
+                          float out_scale, float* __restrict__ loss_sum, float* __restrict__ correct) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -138,8 +138,8 @@ __global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int 
     if (lane == 0) { part[0][threadIdx.x >> 6] = lsum; part[1][threadIdx.x >> 6] = csum; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(loss_sum, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        unsafeAtomicAdd(correct, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        unsafeAtomicAdd(loss_sum, (part[0][0] + part[0][1] + part[0][2] + part[0][3]) * out_scale);
+        unsafeAtomicAdd(correct, (part[1][0] + part[1][1] + part[1][2] + part[1][3]) * out_scale);
     }
 }
 
@@ -161,10 +161,12 @@ __global__ void reparam_kl_kernel(const float* __restrict__ mu, const float* __r
     }
 }
 
-// dmu = dz + kscale*mu ;  dls = dz*eps*sigma + kscale*(sigma^2 - 1)      (kscale = beta / B)
+// dmu = dz + k*mu ;  dls = dz*eps*sigma + k*(sigma^2 - 1)      (k = kscale [* *kdev]: beta / B times the upstream gradient
+// of the KL term, which autograd hands over as a device scalar)
 __global__ void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mu,
                                   const float* __restrict__ ls, const float* __restrict__ eps, float kscale,
-                                  float* __restrict__ dmu, float* __restrict__ dls, long n) {
+                                  const float* __restrict__ kdev, float* __restrict__ dmu, float* __restrict__ dls, long n) {
+    if (kdev) kscale *= *kdev;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float s = expf(ls[i]);
         const float g = dz ? dz[i] : 0.f;
@@ -438,9 +440,10 @@ int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long 
     return ok();
 }
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
-                     float scale, float* loss_sum, float* correct, hipStream_t s) {
+                     float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s) {
     const int g = grid_for((long)rows * 64, 256, 256);
-    hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, loss_sum, correct);
+    hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, out_scale, loss_sum,
+                       correct);
     return ok();
 }
 int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,
@@ -448,9 +451,10 @@ int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, 
     hipLaunchKernelGGL(reparam_kl_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, s, mu, ls, eps, z, sigma, n, kl_sum);
     return ok();
 }
-int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, float* dmu,
-                  float* dls, long n, hipStream_t s) {
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, s, dz, mu, ls, eps, kscale, dmu, dls, n);
+int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, const float* kdev,
+                  float* dmu, float* dls, long n, hipStream_t s) {
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, s, dz, mu, ls, eps, kscale, kdev, dmu,
+                       dls, n);
     return ok();
 }
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,

@@ -82,37 +82,57 @@ class _DecoderFn(ops.TrackedFunction):
 
 
 class _ReparamFn(torch.autograd.Function):
-    """z = mu + eps * exp(logsigma), sigma  (measure_vae.py:119 rsample)."""
+    """z = mu + eps * exp(logsigma) (measure_vae.py:119 rsample) and, from the same pass over (mu, logsigma), the sum of
+    the KL terms against N(0, 1) that VAETrainer.compute_kld_loss needs (vae_trainer.py:128-139)."""
 
     @staticmethod
     def forward(ctx, mu, ls, eps):
-        z, sigma = ops.reparam_kl(mu, ls, eps, kl_sum=None, want_sigma=True)
+        kl = torch.zeros(1, dtype=torch.float32, device=mu.device)
+        z, _ = ops.reparam_kl(mu, ls, eps, kl_sum=kl)
         ctx.save_for_backward(mu, ls, eps)
-        ctx.mark_non_differentiable(sigma)
-        return z, sigma
+        ctx.set_materialize_grads(False)
+        return z, kl[0]
 
     @staticmethod
-    def backward(ctx, dz, _ds):
+    def backward(ctx, dz, dkl):
         mu, ls, eps = ctx.saved_tensors
-        dmu, dls = ops.latent_bwd(dz.contiguous(), mu, ls, eps, 0.0)
+        if dz is not None:
+            dz = dz.contiguous()
+        if dkl is not None:
+            dkl = dkl.reshape(1).contiguous()
+        dmu, dls = ops.latent_bwd(dz, mu, ls, eps, 1.0 if dkl is not None else 0.0, kscale_dev=dkl)
         return dmu, dls, None
 
 
 class NormalLogScale(distributions.Normal):
-    """torch Normal whose log-scale (the encoder's actual output) is kept alongside, so
-    the KL kernel needs no log() round trip.  rsample()/sample() draw eps with torch's
-    device generator and combine on the GPU with the reparameterisation kernel."""
+    """torch Normal whose log-scale (the encoder's actual output) is kept alongside, so the KL kernel needs no log()
+    round trip.  `scale` (= exp(log_scale), encoder.py:133) is computed the first time something reads it: the training
+    step never does.  rsample()/sample() draw eps with torch's device generator and combine on the GPU with the
+    reparameterisation kernel, which also leaves the KL sum in `kl_sum`."""
 
-    def __init__(self, loc, log_scale, scale):
-        super().__init__(loc, scale, validate_args=False)
+    def __init__(self, loc, log_scale):
+        self.loc = loc
         self.log_scale = log_scale
+        self._scale = None
+        self.kl_sum = None
+        distributions.Distribution.__init__(self, loc.size(), validate_args=False)
+
+    @property
+    def scale(self):
+        if self._scale is None:
+            self._scale = _ExpFn.apply(self.log_scale)
+        return self._scale
+
+    @scale.setter
+    def scale(self, value):
+        self._scale = value
 
     def rsample(self, sample_shape=torch.Size(), eps=None):
         if len(sample_shape) != 0:
             return super().rsample(sample_shape)
         if eps is None:
             eps = torch.randn_like(self.loc)
-        z, _ = _ReparamFn.apply(self.loc, self.log_scale, eps)
+        z, self.kl_sum = _ReparamFn.apply(self.loc, self.log_scale, eps)
         self.last_eps = eps
         return z
 
@@ -161,7 +181,7 @@ class Encoder(torch.nn.Module):
             mask = ops.dropout_mask((T, batch_size, 2 * self.rnn_hidden_size), self.dropout, _DropState.seed,
                                     _next_mask_offset(n), tokens.device)
         mu, ls = _EncoderFn.call(self.owner.flat_for_autograd(), self, tokens, mask)
-        return NormalLogScale(mu, ls, _ExpFn.apply(ls))
+        return NormalLogScale(mu, ls)
 
 
 class _ExpFn(torch.autograd.Function):
@@ -313,15 +333,28 @@ class MeasureVAE(Model):
         seq_len = measure_score_tensor.size(1)
         assert seq_len == self.num_ticks_per_measure
         z_dist = self.encoder(measure_score_tensor)
+        # prior_dist.sample() (measure_vae.py:127) for N(0, 1) is a plain standard-normal draw (torch.normal(mean, std)
+        # would also validate std >= 0 with a device->host read, i.e. stall the host once per forward pass): eps of the
+        # reparameterisation and z_prior come out of one generator call
+        if eps is None:
+            draws = torch.randn((2,) + tuple(z_dist.loc.shape), dtype=z_dist.loc.dtype, device=z_dist.loc.device)
+            eps, z_prior = draws[0], draws[1]
+        else:
+            z_prior = torch.randn_like(z_dist.loc)
         z_tilde = z_dist.rsample(eps=eps)
-        prior_dist = distributions.Normal(loc=torch.zeros_like(z_dist.loc), scale=torch.ones_like(z_dist.scale),
-                                          validate_args=False)
-        # prior_dist.sample() (measure_vae.py:127) for N(0, 1) is a plain standard-normal draw.  torch.normal(mean, std)
-        # would also validate std >= 0 with a device->host read, i.e. stall the host once per forward pass.
-        z_prior = torch.randn_like(z_dist.loc)
+        prior_dist = self._standard_normal(z_dist.loc)
         weights, samples = self.decoder(z=z_tilde, score_tensor=measure_score_tensor, train=train,
                                         teacher_forced=teacher_forced)
         return weights, samples, z_dist, prior_dist, z_tilde, z_prior
+
+    def _standard_normal(self, like):
+        """N(0, 1) of the latent's shape (measure_vae.py:122-125): the constant loc / scale tensors are built once."""
+        key = (tuple(like.shape), like.device, like.dtype)
+        cache = self.__dict__.setdefault("_prior_cache", {})
+        if key not in cache:
+            cache[key] = (torch.zeros_like(like), torch.ones_like(like))
+        loc, scale = cache[key]
+        return distributions.Normal(loc=loc, scale=scale, validate_args=False)
 
     def forward_test(self, measure_score_tensor):
         """(B,M,24) -> weights (B,M,24,V), samples (B,1,24M)   (measure_vae.py:136-169).  The M measures are

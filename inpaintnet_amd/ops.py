@@ -167,14 +167,14 @@ def decoder_bwd(cfg, dweights, weights, samples, params, grads, mask_beat, mask_
 
 
 # ----------------------------------------------------------------------------- losses
-def cross_entropy(weights2d, targets1d, out2, dW=None, scale=1.0):
-    """weights2d [rows,V] (row stride = stride(0)); out2: 2-float accumulator (loss_sum, correct)."""
+def cross_entropy(weights2d, targets1d, out2, dW=None, scale=1.0, out_scale=1.0):
+    """weights2d [rows,V] (row stride = stride(0)); out2: 2-float accumulator (loss_sum, correct), both times out_scale."""
     rows, V = weights2d.shape
     assert weights2d.stride(1) == 1
     _i64c(targets1d)
     check(_lib.lib().inet_cross_entropy(ptr(weights2d), weights2d.stride(0), rows, V, ptr(targets1d), ptr(dW),
-                                        dW.stride(0) if dW is not None else 0, float(scale), ptr(out2[0:1]),
-                                        ptr(out2[1:2]), stream_ptr()), "inet_cross_entropy")
+                                        dW.stride(0) if dW is not None else 0, float(scale), float(out_scale),
+                                        ptr(out2[0:1]), ptr(out2[1:2]), stream_ptr()), "inet_cross_entropy")
 
 
 def reparam_kl(mu, ls, eps, kl_sum=None, want_sigma=False):
@@ -186,11 +186,14 @@ def reparam_kl(mu, ls, eps, kl_sum=None, want_sigma=False):
     return z, sigma
 
 
-def latent_bwd(dz, mu, ls, eps, kscale):
+def latent_bwd(dz, mu, ls, eps, kscale, kscale_dev=None):
+    """Gradients of (mu, logsigma) from dz (nullable) and from the KL sum, whose upstream gradient is
+    kscale * kscale_dev[0] (kscale_dev: optional device scalar)."""
     dmu = torch.empty_like(mu)
     dls = torch.empty_like(mu)
-    check(_lib.lib().inet_latent_bwd(ptr(dz), ptr(mu), ptr(ls), ptr(eps), float(kscale), ptr(dmu), ptr(dls),
-                                     mu.numel(), stream_ptr()), "inet_latent_bwd")
+    _hold(kscale_dev)
+    check(_lib.lib().inet_latent_bwd(ptr(dz), ptr(mu), ptr(ls), ptr(eps), float(kscale), ptr(kscale_dev), ptr(dmu),
+                                     ptr(dls), mu.numel(), stream_ptr()), "inet_latent_bwd")
     return dmu, dls
 
 

@@ -37,10 +37,9 @@ class _CrossEntropyFn(torch.autograd.Function):
         out = torch.zeros(2, dtype=torch.float32, device=weights2d.device)
         need = ctx.needs_input_grad[0]
         dW = torch.empty_like(weights2d) if need else None
-        ops.cross_entropy(weights2d, targets1d, out, dW=dW, scale=1.0 / rows)
+        ops.cross_entropy(weights2d, targets1d, out, dW=dW, scale=1.0 / rows, out_scale=1.0 / rows)
         ctx.dW = dW
-        res = out / rows
-        loss, acc = res[0], res[1]
+        loss, acc = out[0], out[1]                  # the kernel accumulated the means: no follow-up launch
         ctx.mark_non_differentiable(acc)
         return loss, acc
 

@@ -39,4 +39,9 @@ class VAETrainer(Trainer):
         log_scale = getattr(z_dist, "log_scale", None)
         if log_scale is None:
             raise ValueError("compute_kld_loss expects the encoder's distribution (it carries log_scale)")
+        kl_sum = getattr(z_dist, "kl_sum", None)
+        if kl_sum is not None:
+            # rsample() already summed the KL terms in the reparameterisation kernel; its backward handles dz and the KL
+            # gradient in one pass (no second kernel, no gradient accumulation between two paths into mu / log sigma)
+            return kl_sum * (beta / z_dist.loc.shape[0])
         return _KLFn.apply(z_dist.loc, log_scale, beta)

@@ -44,7 +44,8 @@ def test_trainer_trajectory_matches_reference(name, mode, overlap, monkeypatch):
     ref = fx[f"step_{mode}_losses"]
     for step in range(5):
         eps = torch.from_numpy(fx[f"step_{mode}_eps{step}"]).cuda()
-        monkeypatch.setattr(torch, "randn_like", lambda t, e=eps: e)
+        # MeasureVAE.forward draws eps and z_prior with one torch.randn((2, B, Z)) call: row 0 is eps
+        monkeypatch.setattr(torch, "randn", lambda *a, e=eps, **k: torch.stack([e, torch.zeros_like(e)]))
         trainer.zero_grad()
         loss, acc = trainer.loss_and_acc_for_batch(tok, 0, train=True)
         loss.backward()
