@@ -340,6 +340,37 @@ def kernel_table(step, nprof=4):
     return table
 
 
+def dump_kernel_sequences(step, path, nsteps=6):
+    """For tools/pmc_summary.py: one template instantiation + grid can serve several shapes (the direct weight-gradient
+    kernel runs M1536 N512 and M1536 N1024 with the same 256 workgroups).  The per-step launch ORDER of the labels behind
+    each kernel|grid key lets the PMC summary split such a key by shape.  Only keys whose order is the same in every
+    profiled step are written."""
+    from inpaintnet_amd import ops
+    seqs = []
+    for _ in range(nsteps):
+        torch.cuda.synchronize()
+        ops.prof_enable(True)
+        step()
+        torch.cuda.synchronize()
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "l.csv")
+            ops.prof_dump(f)
+            rows = list(csv.DictReader(open(f)))
+        ops.prof_enable(False)
+        per = {}
+        for r in rows:
+            key = pmc_key(r["label"]) if r["label"] else None
+            if key:
+                per.setdefault(key, []).append(r["label"])
+        seqs.append(per)
+    out = {}
+    for key in seqs[0]:
+        if all(s_.get(key) == seqs[0][key] for s_ in seqs) and len(set(seqs[0][key])) > 1:
+            out[key] = seqs[0][key]
+    json.dump(out, open(path, "w"), indent=1)
+    return out
+
+
 def pmc_key(label):
     """Kernel-name|grid key of tools/pmc_summary.py (rocprofv3 PMC pass) for a profile label of the library."""
     import math
@@ -360,11 +391,17 @@ def pmc_key(label):
         return f"gru_step_bwd_kernel<{f['ms']}, {f['nc']}, {tf(f['pk'])}>|g{grid}"
     if label == "adam":
         return "adam_kernel|"
-    m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) t(\d+)x(\d+) s(\d+)", label)
+    m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) ([tdk])(\d+)x(\d+) s(\d+)", label)
     if m:
-        M, N, K, a, b, bm, bn, sp = m.groups()
+        M, N, K, a, b, kind, bm, bn, sp = m.groups()
         grid = 256 * math.ceil(int(N) / int(bn)) * math.ceil(int(M) / int(bm)) * int(sp)
-        return f"gemm_kernel<{int(bm) // 64}, {int(bn) // 64}, {tf(a == 'T')}, {tf(b == 'N')}>|g{grid}"
+        if kind == "t":                                  # LDS-tiled
+            return f"gemm_kernel<{int(bm) // 64}, {int(bn) // 64}, {tf(a == 'T')}, {tf(b == 'N')}>|g{grid}"
+        if kind == "k":                                  # workgroup split-K
+            return f"gemm_ks_kernel<{int(bm) // 16}, {int(bn) // 16}, {tf(a == 'T')}, {tf(b == 'N')}>|g{grid}"
+        if a == "T":                                     # direct, k-major x k-major
+            return f"gemm_tn_direct_kernel<{int(bm) // 64}, {int(bn) // 64}>|g{grid}"
+        return f"gemm_kc_direct_kernel<{int(bm) // 32}, {int(bn) // 32}, {tf(b == 'N')}>|g{grid}"
     return None
 
 
@@ -382,7 +419,8 @@ def roofline(step):
         key = pmc_key(row["kernel"])
         hit = None
         if key:
-            hit = kern.get(key) or next((v for k, v in kern.items() if k.startswith(key)), None)
+            hit = (kern.get(key + "#" + row["kernel"]) or kern.get(key)
+                   or next((v for k, v in kern.items() if k.startswith(key)), None))
         if hit:
             row["traffic_mbytes_per_launch"] = hit.get("hbm_mbytes_per_launch")
             row["pmc_key"] = key
@@ -566,6 +604,8 @@ def main():
 
     extras = {}
     roof = None
+    if rank == 0 and os.environ.get("INET_BENCH_SEQ"):         # tools/profile_r02.sh: launch order of shape-sharing kernels
+        dump_kernel_sequences(wl.step, os.environ["INET_BENCH_SEQ"])
     if rank == 0 and not args.no_roofline:
         roof = roofline(wl.step)
     if world > 1:

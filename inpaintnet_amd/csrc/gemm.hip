@@ -652,7 +652,7 @@ int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, double budget_us, int
             if (cost < best) { best = cost; bi = ci; bs = sp; }
         }
     }
-    if (bi < 0 || (g_direct != 2 && (g.K / bs < 512 || (long)tiles_of(kDirect[bi], g) * bs < 192))) return 1;
+    if (bi < 0 || (g_direct != 2 && (g.K / bs < 768 || (long)tiles_of(kDirect[bi], g) * bs < 192))) return 1;
     (void)budget_us;
     const DirectCfg& c = kDirect[bi];
     int kps = (g.K + bs - 1) / bs;

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 outputs of `bench.py` into the files committed under profiles/.
 
     python tools/pmc_summary.py stats  <kernel_trace.csv>                     -> per-kernel time table (text, stdout)
-    python tools/pmc_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python tools/pmc_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [seq.json]
 
 PMC conventions (MI355X_MICROARCH.md, section HBM): FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts
 128-byte requests as 64 bytes for wide coalesced reads, so the read side is DOUBLED here; WRITE_SIZE is taken as is.  The two
@@ -18,7 +18,7 @@ csv.field_size_limit(1 << 30)
 
 
 def short(name):
-    m = re.search(r"((?:gru_step_fwd|gru_step_bwd|gemm|lstm_step_fwd|lstm_step_bwd|logits_argmax|gru_chain\w*|lstm_chain\w*|"
+    m = re.search(r"((?:gru_step_fwd|gru_step_bwd|gemm\w*|lstm_step_fwd|lstm_step_bwd|logits_argmax|gru_chain\w*|lstm_chain\w*|"
                   r"decode_\w+)_kernel<[^>]*>)", name)
     if m:
         return m.group(1)
@@ -44,23 +44,36 @@ def stats(path, top=40):
         print(f"{k:<58} {a[0]:>7d} {a[1]:>11.1f} {100 * a[1] / tot:>6.2f} {a[1] / a[0]:>9.2f} {a[2]:>9.2f} {a[3]:>9.2f}")
 
 
-def read_counter(path, counter):
-    out = defaultdict(lambda: [0, 0.0, 0.0])          # key -> [launches, sum counter, sum us]
+def read_counter(path, counter, seqs=None):
+    """key -> [launches, sum counter, sum us].  `seqs` {key: [label of the 1st, 2nd, ... launch of that key in a step]}
+    (bench.py INET_BENCH_SEQ) splits a kernel|grid key that serves several shapes into key#label entries by launch order
+    (dispatch ids are in host launch order; every step launches the same sequence)."""
+    rows = []
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            if r["Counter_Name"] != counter:
-                continue
-            key = f'{short(r["Kernel_Name"])}|g{r["Grid_Size"]}'
-            a = out[key]
+            if r["Counter_Name"] == counter:
+                rows.append((int(r["Dispatch_Id"]), f'{short(r["Kernel_Name"])}|g{r["Grid_Size"]}', float(r["Counter_Value"]),
+                             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    rows.sort()
+    out = defaultdict(lambda: [0, 0.0, 0.0])
+    seen = defaultdict(int)
+    for _, key, val, us in rows:
+        targets = [key]
+        if seqs and key in seqs:
+            targets.append(key + "#" + seqs[key][seen[key] % len(seqs[key])])
+            seen[key] += 1
+        for k in targets:
+            a = out[k]
             a[0] += 1
-            a[1] += float(r["Counter_Value"])
-            a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            a[1] += val
+            a[2] += us
     return out
 
 
-def pmc(fetch_csv, write_csv, out_json):
-    fe = read_counter(fetch_csv, "FETCH_SIZE")
-    wr = read_counter(write_csv, "WRITE_SIZE")
+def pmc(fetch_csv, write_csv, out_json, seq_json=None):
+    seqs = json.load(open(seq_json)) if seq_json else None
+    fe = read_counter(fetch_csv, "FETCH_SIZE", seqs)
+    wr = read_counter(write_csv, "WRITE_SIZE", seqs)
     kernels = {}
     for key in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0, 0])[2])):
         f, w = fe.get(key), wr.get(key)
@@ -83,4 +96,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
