@@ -208,8 +208,10 @@ int inet_set_option(int key, int value);
  * workspaces.  Lets the leaf GEMMs of one module's backward overlap the next module's BPTT chain. */
 /* key 4 = chain kernels (default 1; INET_CHAIN=0): one persistent launch per recurrent layer, weights resident in
  * registers, the hidden state exchanged between workgroups once per step (csrc/chain.h).  0 = one launch per step. */
-/* key 5 = LDS-free direct kernels for the weight-gradient (k-major x k-major) products: 0 = never, 1 = when the cost
- * model prefers them (default; INET_GEMM_DIRECT), 2 = whenever the shape qualifies (test hook). */
+/* key 5 = LDS-free GEMM kernels (csrc/gemm.hip; also INET_GEMM_DIRECT): 0 = LDS-tiled kernels only, 1 = by shape
+ * (default: shared-strip direct kernels for the big products, workgroup split-K for the medium / small ones), 2 = the
+ * direct kernels whenever the shape qualifies (test hook), 3 = direct kernels only (no split-K), 4 = split-K first, also for
+ * the long weight-gradient products. */
 int inet_side_join(void* stream);
 /* Number of chain-kernel workgroups that gave up waiting for their group since the last reset (0 = healthy; every
  * in-kernel spin is bounded, so a broken hand-off shows up here instead of hanging the GPU).  Meaningful after the

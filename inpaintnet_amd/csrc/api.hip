@@ -318,7 +318,7 @@ int inet_set_option(int key, int value) {
     if (key == 4) { chain_set_enabled(value); return 0; }
     if (key == 2) { if (value < -1 || value > 4) return -1; gemm_set_force(value, -1); return 0; }
     if (key == 3) { if (value < 0) return -1; gemm_set_force(-2, value); return 0; }
-    if (key == 5) { if (value < 0 || value > 3) return -1; gemm_set_direct(value); return 0; }
+    if (key == 5) { if (value < 0 || value > 4) return -1; gemm_set_direct(value); return 0; }
     return -1;
 }
 

@@ -514,20 +514,27 @@ struct KsOperand {
 };
 
 template <int TA, int TB, bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n) {
-    constexpr int D = 4, NR = TA * TB * 4, QR = NR / 4;
-    __shared__ float red[NR * 4 * 64];
+__global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n, int tiles) {
+    constexpr int D = 4, NR = TA * TB * 4;
+    constexpr int RR = NR <= 64 ? NR : NR / 2;           // registers per reduction round (64 KB of LDS at most)
+    constexpr int QR = RR / 4;
+    static_assert(NR % RR == 0 && RR % 4 == 0, "reduction rounds");
+    __shared__ float red[RR * 4 * 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     int v = blockIdx.x;
     if ((gridDim.x & 7) == 0) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int tm = v / tiles_n, tn = v - tm * tiles_n;
+    // a k-major x k-major product may also be split over the grid (k range `split`; one XCD then works on one range)
+    const int split = v / tiles, tile = v - split * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * (16 * TA), n0 = tn * (16 * TB);
     const int lda = (int)g.lda, ldb = (int)g.ldb;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
     const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * lda * 4, 0x00020000);
+        const_cast<float*>(g.A) + (AKM ? (long)kbeg * lda : 0), 0, (AKM ? kend - kbeg : g.M) * lda * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * ldb * 4, 0x00020000);
+        const_cast<float*>(g.B) + (BKM ? (long)kbeg * ldb : 0), 0, (BKM ? kend - kbeg : g.N) * ldb * 4, 0x00020000);
 
     KsOperand<TA, AKM> a[D];
     KsOperand<TB, BKM> b[D];
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n) {
         b[s].fetch(rb_rsrc);
         __builtin_amdgcn_sched_barrier(0);
     }
-    const int G = (g.K + 15) >> 4;                       // k groups in all; this wave owns w, w+4, ...
+    const int G = (kend - kbeg + 15) >> 4;               // k groups of this range; this wave owns w, w+4, ...
     for (int g0 = w; g0 < G; g0 += 4 * D) {
 #pragma unroll
         for (int s = 0; s < D; ++s) {
@@ -565,31 +572,38 @@ __global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n) {
         }
     }
 
-    // the four partial tiles meet in LDS: [register][wave][lane]
+    // the four partial tiles meet in LDS, RR registers at a time: [register][wave][lane]; wave w finishes registers
+    // [QR w, QR w + QR) of the round.  Rows and columns are dealt like the operands: MFMA row c' = 4q + r of tile i is
+    // strip row TA*c' + i, column c of tile j is strip column TB*c + j.
+    const bool add_bias = g.bias != nullptr && split == 0;
 #pragma unroll
-    for (int i = 0; i < TA; ++i)
+    for (int round = 0; round < NR / RR; ++round) {
+        if (round) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TB; ++j)
+        for (int i = 0; i < TA; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(((i * TB + j) * 4 + r) * 4 + w) * 64 + lane] = acc[i][j][r];
-    __syncthreads();
-    // wave w finishes registers [QR w, QR w + QR): rows and columns dealt like the operands (MFMA row c' = 4q + r of
-    // tile i is strip row TA*c' + i, column c of tile j is strip column TB*c + j)
+            for (int j = 0; j < TB; ++j)
 #pragma unroll
-    for (int x = 0; x < QR; ++x) {
-        const int reg = QR * w + x;
-        const float* p = red + (reg * 4) * 64 + lane;
-        float val = (p[0] + p[64]) + (p[128] + p[192]);
-        const int r = reg & 3, j = (reg >> 2) % TB, i = (reg >> 2) / TB;
-        const int rr = 4 * q + r;
-        const int row = m0 + TA * rr + i;
-        const int col = n0 + TB * c + j;
-        if (g.bias) val += g.bias[col];
-        if (g.epi != EPI_NONE) val = apply_epi(val, g.epi, g.aux ? g.aux[(long)row * g.ldaux + col] : 0.f);
-        float* cp = g.C + (long)row * g.ldc + col;
-        if (g.acc == ACC_STORE) *cp = val;
-        else if (g.acc == ACC_ADD) *cp += val;
-        else unsafeAtomicAdd(cp, val);
+                for (int r = 0; r < 4; ++r) {
+                    const int reg = (i * TB + j) * 4 + r;
+                    if (reg / RR == round) red[((reg % RR) * 4 + w) * 64 + lane] = acc[i][j][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < QR; ++x) {
+            const int lr = QR * w + x, reg = round * RR + lr;
+            const float* p = red + (lr * 4) * 64 + lane;
+            float val = (p[0] + p[64]) + (p[128] + p[192]);
+            const int r = reg & 3, j = (reg >> 2) % TB, i = (reg >> 2) / TB;
+            const int row = m0 + TA * (4 * q + r) + i;
+            const int col = n0 + TB * c + j;
+            if (add_bias) val += g.bias[col];
+            if (g.epi != EPI_NONE) val = apply_epi(val, g.epi, g.aux ? g.aux[(long)row * g.ldaux + col] : 0.f);
+            float* cp = g.C + (long)row * g.ldc + col;
+            if (g.acc == ACC_STORE) *cp = val;
+            else if (g.acc == ACC_ADD) *cp += val;
+            else unsafeAtomicAdd(cp, val);
+        }
     }
 }
 
@@ -621,7 +635,7 @@ __global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int
 }
 
 int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (INET_GEMM_FORCE="cfg,split"), -1: cost model
-int g_direct = -1;                            // INET_GEMM_DIRECT: 0 never, 1 (default) by shape, 2 whenever applicable, 3 big shapes only
+int g_direct = -1;   // INET_GEMM_DIRECT: 0 never, 1 (default) by shape, 2 direct whenever applicable, 3 big shapes only, 4 split-K first
 
 struct DirectCfg { int ta, tb; };
 const DirectCfg kDirect[] = {{3, 2}, {2, 2}, {3, 3}};
@@ -739,45 +753,69 @@ int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s, double budget_us) {
 }
 
 struct KsCfg { int ta, tb; };
-const KsCfg kKs[] = {{4, 4}, {4, 2}, {2, 2}};
+const KsCfg kKs[] = {{4, 4}, {4, 2}, {2, 2}, {6, 4}};
 
 template <int TA, int TB>
-void launch_ks(const GemmArgs& g, dim3 grid, hipStream_t s, int tiles_n) {
-    if (g.a_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, true, true>), grid, dim3(256), 0, s, g, tiles_n);
-    else if (g.b_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, false, true>), grid, dim3(256), 0, s, g, tiles_n);
-    else hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, false, false>), grid, dim3(256), 0, s, g, tiles_n);
+void launch_ks(const GemmArgs& g, dim3 grid, hipStream_t s, int tiles_n, int tiles) {
+    if (g.a_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, true, true>), grid, dim3(256), 0, s, g, tiles_n, tiles);
+    else if (g.b_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, false, true>), grid, dim3(256), 0, s, g, tiles_n, tiles);
+    else hipLaunchKernelGGL((gemm_ks_kernel<TA, TB, false, false>), grid, dim3(256), 0, s, g, tiles_n, tiles);
 }
 
-// In-workgroup split-K kernel for the medium / small products.  Returns 1 when the shape does not qualify.
-int launch_gemm_ks(const GemmArgs& g, hipStream_t s) {
+// In-workgroup split-K kernel.  Medium / small products: one workgroup per output tile, the largest tile that still
+// fills the chip.  Long weight-gradient products (k-major x k-major, K = T*B): 96x64 tiles, and when those are fewer than
+// the CUs the k range is also split over the grid (2 ranges for M1536 N512: 1/4 of the atomics of an 8-way split).
+// Returns 1 when the shape does not qualify.
+int launch_gemm_ks(const GemmArgs& gin, hipStream_t s, int force_split) {
+    GemmArgs g = gin;
     if (g.a_kmajor && !g.b_kmajor) return 1;
     if (!g.a_kmajor && (g.K & 15)) return 1;             // a k-contiguous operand has no zero-returning K tail
     if (g.acc == ACC_ATOMIC || g.K < 64) return 1;
     if ((double)(g.a_kmajor ? g.K : g.M) * g.lda * 4 >= 2.0e9 || (double)(g.b_kmajor ? g.K : g.N) * g.ldb * 4 >= 2.0e9) return 1;
+    const bool nonlinear = g.epi != EPI_NONE;
     // rounds of 256 workgroups x MFMAs per workgroup, the smaller tiles charged for their higher L2 traffic per MFMA
-    const double kL2[] = {1.0, 1.15, 1.5};
-    int bi = -1;
+    const double kL2[] = {1.0, 1.15, 1.5, 0.95};
+    int bi = -1, bs = 1;
     double best = 1e300;
-    for (int ci = 0; ci < 3; ++ci) {
+    for (int ci = 0; ci < 4; ++ci) {
         const KsCfg& c = kKs[ci];
         if (g.M % (16 * c.ta) || g.N % (16 * c.tb)) continue;
-        const long wgs = (long)(g.M / (16 * c.ta)) * (g.N / (16 * c.tb));
-        const double cost = (double)((wgs + 255) / 256) * c.ta * c.tb * kL2[ci];
-        if (cost < best) { best = cost; bi = ci; }
+        if (ci == 3 && !(g.a_kmajor && g.K >= 2048)) continue;
+        const long tiles = (long)(g.M / (16 * c.ta)) * (g.N / (16 * c.tb));
+        for (int sp = 1; sp <= 8; sp *= 2) {
+            if (sp > 1 && (!g.a_kmajor || g.K / sp < 1024 || nonlinear)) break;
+            if (force_split > 0 && sp != force_split) continue;
+            const long wgs = tiles * sp;
+            double cost = (double)((wgs + 255) / 256) * c.ta * c.tb * kL2[ci] / sp;
+            if (sp > 1) cost *= 1.0 + 0.04 * sp;         // zero-fill + atomics
+            if (cost < best) { best = cost; bi = ci; bs = sp; }
+        }
     }
     if (bi < 0) return 1;
     const KsCfg& c = kKs[bi];
-    const int tiles_n = g.N / (16 * c.tb);
-    const dim3 grid(tiles_n * (g.M / (16 * c.ta)));
+    int kps = (g.K + bs - 1) / bs;
+    kps = (kps + 15) / 16 * 16;
+    const int splits = (g.K + kps - 1) / kps;
+    g.k_per_split = kps;
+    if (splits > 1) {
+        if (g.acc == ACC_STORE && pw_zero2d(g.C, g.ldc, g.M, g.N, s) != 0) return -2;
+        g.acc = ACC_ATOMIC;
+    }
+    const int tiles_n = g.N / (16 * c.tb), tiles = tiles_n * (g.M / (16 * c.ta));
+    const dim3 grid(tiles * splits);
     char label[96];
-    std::snprintf(label, sizeof label, "M%d N%d K%d %c%c k%dx%d s1 e%d", g.M, g.N, g.K, g.a_kmajor ? 'T' : 'N',
-                  g.b_kmajor ? 'N' : 'T', 16 * c.ta, 16 * c.tb, g.epi);
+    std::snprintf(label, sizeof label, "M%d N%d K%d %c%c k%dx%d s%d e%d", g.M, g.N, g.K, g.a_kmajor ? 'T' : 'N',
+                  g.b_kmajor ? 'N' : 'T', 16 * c.ta, 16 * c.tb, splits, g.epi);
     ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label,
                    4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     switch (bi) {
-        case 0: launch_ks<4, 4>(g, grid, s, tiles_n); break;
-        case 1: launch_ks<4, 2>(g, grid, s, tiles_n); break;
-        default: launch_ks<2, 2>(g, grid, s, tiles_n); break;
+        case 0: launch_ks<4, 4>(g, grid, s, tiles_n, tiles); break;
+        case 1: launch_ks<4, 2>(g, grid, s, tiles_n, tiles); break;
+        case 2: launch_ks<2, 2>(g, grid, s, tiles_n, tiles); break;
+        default:
+            if (!g.a_kmajor) return 1;
+            hipLaunchKernelGGL((gemm_ks_kernel<6, 4, true, true>), grid, dim3(256), 0, s, g, tiles_n, tiles);
+            break;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -830,8 +868,14 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
         g_direct = v ? std::atoi(v) : 1;
     }
     if (g_direct > 0 && force_cfg < 0) {
-        int rc = gin.a_kmajor ? launch_gemm_direct(gin, s, best, force_split) : launch_gemm_kc_direct(gin, s, best);
-        if (rc == 1 && g_direct != 3 && force_split == 0) rc = launch_gemm_ks(gin, s);
+        // The long weight-gradient products go to the shared-strip direct kernel first.  Workgroup split-K with 96x64 tiles
+        // (INET_GEMM_DIRECT=4 tries it first) is 8-15 % faster alone (no zero-fill, 1/4 of the atomics) but 1 % slower
+        // in the training step, where its doubled L2 traffic competes with the BPTT chain on the other stream.
+        int rc = 1;
+        if (gin.a_kmajor && g_direct != 4) rc = launch_gemm_direct(gin, s, best, force_split);
+        else if (!gin.a_kmajor) rc = launch_gemm_kc_direct(gin, s, best);
+        if (rc == 1 && g_direct != 3) rc = launch_gemm_ks(gin, s, force_split);
+        if (rc == 1 && gin.a_kmajor) rc = launch_gemm_direct(gin, s, best, force_split);
         if (rc != 1) return rc;
     }
     if (force_cfg >= 0 && force_cfg < kNumCfgs) {

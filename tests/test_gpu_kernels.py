@@ -140,11 +140,14 @@ def test_gemm_direct_kcontiguous_products(M, N, K, bkm):
 
 @pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(256, 1024, 2048), (1536, 512, 1024), (1024, 2048, 256), (256, 256, 1024),
-                                   (64, 32, 64), (32, 32, 1008), (128, 96, 336)])
+                                   (64, 32, 64), (32, 32, 1008), (128, 96, 336),
+                                   (1536, 512, 6144), (1536, 1024, 6144), (192, 128, 2064)])   # TN: 96x64 tiles (+ grid split)
 def test_gemm_workgroup_split_k(akm, bkm, M, N, K):
     """The in-workgroup split-K kernel (csrc/gemm.hip gemm_ks_kernel) on the medium / small shapes of the step, every
     operand layout it takes: plain, accumulating, bias + SELU, aux epilogues, strided destination; for k-major
     operands also a K that is not a multiple of the 16-deep group."""
+    if K >= 2048 and akm:
+        ops.set_option(5, 4)                                # long k-major products: split-K first (default: direct kernel)
     for Kx in ([K, K - 6] if akm else [K]):
         g = torch.Generator().manual_seed(M + 3 * N + Kx + akm + 2 * bkm)
         A = torch.randn(M, Kx, generator=g)
@@ -177,6 +180,7 @@ def test_gemm_workgroup_split_k(akm, bkm, M, N, K):
         ops.gemm(Ad, Bd, M, N, Kx, out=big[:, 1, :], **kw)
         assert relmax(big[:, 1, :], ref) < 2e-5
         assert float(big[:, 0, :].abs().max()) == 0.0
+    ops.set_option(5, 1)
 
 
 def test_gemm_strided_unaligned_and_epilogues():
