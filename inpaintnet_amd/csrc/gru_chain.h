@@ -2,9 +2,14 @@
 #pragma once
 #include "chain.h"
 
-constexpr int kChainMaxGroups = 32;               // group counters per launch; word [kChainMaxGroups] is the status word,
-constexpr int kChainZeroWord = kChainMaxGroups + 2;   // words [+2, +3] stay zero: the target of absent operand pointers
-constexpr int kChainSyncWords = kChainMaxGroups + 4;
+// Sync area of one launch.  Every group counter sits alone in a 256-byte block: the counters are polled (L2-bypassing
+// loads) by all members of their group and bumped with device-scope atomics, and with 8 of them in one line all 256
+// pollers of the launch queued on the same memory channel -- 0.6 us of every step (profiles/r02_i_chain_counters.txt).
+constexpr int kChainMaxGroups = 32;               // group counters per launch
+constexpr int kChainCounterStride = 64;           // words between two group counters
+constexpr int kChainStatusWord = kChainMaxGroups * kChainCounterStride;   // the launch's status word (abort flag)
+constexpr int kChainZeroWord = kChainStatusWord + 64; // words [+0, +1] stay zero: the target of absent operand pointers
+constexpr int kChainSyncWords = kChainZeroWord + 4;
 
 struct GruChainFwdProb {
     const float* W_hh; const float* b_hh;         // [3H,H] row-major, [3H]

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(GruChainFwd A) {
         hp[p] = P.h0[(long)brow[p] * P.ld_h0 + jc];
     }
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.hx);
-    unsigned* counter = A.counters + group;
+    unsigned* counter = A.counters + group * kChainCounterStride;
     // Operand sources as (pointer, strides) with every field in a register before the loop; an absent source points at a
     // zero word with zero strides, so the per-step requests are unconditional loads issued back to back (conditional
     // loads make hipcc wrap each in a branch with its own s_waitcnt vmcnt(0): one exposed round trip per operand).
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
         Wr[0][si] = f32x4{wp[0], wp[H], wp[2 * H], wp[3 * (long)H]};
     }
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.gx);
-    unsigned* counter = A.counters + group;
+    unsigned* counter = A.counters + group * kChainCounterStride;
     float dhz[MS], bs[4] = {0.f, 0.f, 0.f, 0.f};
     int brow[MS];
 #pragma unroll
@@ -311,7 +311,7 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     a.status.host = chain_host_status();
     a.prio = chain_prio();
     if (hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    a.status.dev = a.counters + kChainMaxGroups;
+    a.status.dev = a.counters + kChainStatusWord;
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_fwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;
@@ -335,7 +335,7 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
     a.status.host = chain_host_status();
     a.prio = chain_prio();
     if (hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    a.status.dev = a.counters + kChainMaxGroups;
+    a.status.dev = a.counters + kChainStatusWord;
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_bwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;

@@ -15,28 +15,45 @@
 #include "ksplit.h"
 using namespace ksplit;
 
-constexpr int MS = 4, SQ = 8, H = 512, B = 256, T = 24, MEMBERS = 32, GROUPS = 8;
-struct Args { float* hx; const float* W; const float* gi; float* out; unsigned* counters; unsigned* status; unsigned long long* stamps; };
+#ifndef MS_
+#define MS_ 4
+#endif
+constexpr int MS = MS_, SQ = 8, H = 512, B = 256, T = 24, MEMBERS = 32;
+constexpr int TILES = B / (16 * MS), GROUPS = 2 * TILES, NB = GROUPS * MEMBERS;   // MS_=2: 512 workgroups, two per CU
+struct Args { float* hx; const float* W; const float* gi; float* out; unsigned* counters; unsigned* status; unsigned long long* stamps; unsigned* where; };
 
 template <bool MFMA, bool LOADS, bool SYNC, bool PLAIN>
 __global__ __launch_bounds__(256) void k(Args A) {
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * MS * 256];
     __shared__ __attribute__((aligned(16))) float xt[MS * 256];
     __shared__ unsigned flag[2];
+#ifdef PAD_
+    __shared__ float pad[PAD_];
+    if (threadIdx.x == 0 && A.where == nullptr) pad[0] = 1.f;
+#endif
     int group, member;
     chain::decode_block(blockIdx.x, MEMBERS, group, member);
-    const int row0 = (group % 4) * 64, t = threadIdx.x, lane = t & 63, S = H >> 4;
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        A.where[blockIdx.x] = ((xcc & 0xf) << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf);
+    }
+    const int row0 = (group % TILES) * 16 * MS, t = threadIdx.x, lane = t & 63, S = H >> 4;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), i16 = lane & 15, q = lane >> 4;
     const int j0 = member * 16, jc = j0 + (t & 15), rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
     const int slot_bytes = B * H * 4;
-    float* hx = A.hx + (size_t)(group / 4) * 2 * B * H;
+    float* hx = A.hx + (size_t)(group / TILES) * 2 * B * H;
     f32x4 Wr[3][SQ];
     for (int g = 0; g < 3; ++g) for (int si = 0; si < SQ; ++si)
         Wr[g][si] = ld4u(A.W + (long)(g * H + j0 + i16) * H + 16 * (w * SQ + si) + 4 * q);
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(hx);
-    unsigned* counter = A.counters + group;
+    #ifndef CSTRIDE_
+#define CSTRIDE_ 1
+#endif
+    unsigned* counter = A.counters + group * CSTRIDE_;
     chain::Status st{A.status, nullptr};
-    float hp[MS] = {0, 0, 0, 0};
+    float hp[MS] = {};
     unsigned long long* stamp = A.stamps + (size_t)blockIdx.x * T * 6;
     f32x4 acc[MS][4];
     for (int ms = 0; ms < MS; ++ms) for (int a = 0; a < 3; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -92,28 +109,36 @@ __global__ __launch_bounds__(256) void k(Args A) {
 
 template <bool MFMA, bool LOADS, bool SYNC, bool PLAIN>
 void run(const char* name, Args a) {
-    std::vector<unsigned long long> h((size_t)256 * T * 6);
+    std::vector<unsigned long long> h((size_t)NB * T * 6);
     double best = 1e30; std::vector<double> ph(6, 0);
     unsigned stat = 0;
     for (int rep = 0; rep < 5; ++rep) {
-        (void)hipMemset(a.counters, 0, 64 * 4); (void)hipMemset(a.status, 0, 4);
-        hipLaunchKernelGGL((k<MFMA, LOADS, SYNC, PLAIN>), dim3(256), dim3(256), 0, 0, a);
+        (void)hipMemset(a.counters, 0, 64 * 64 * 4); (void)hipMemset(a.status, 0, 4);
+        hipLaunchKernelGGL((k<MFMA, LOADS, SYNC, PLAIN>), dim3(NB), dim3(256), 0, 0, a);
         if (hipDeviceSynchronize() != hipSuccess) { printf("%s failed\n", name); return; }
         (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipMemcpy(&stat, a.status, 4, hipMemcpyDeviceToHost);
         unsigned long long b0 = ~0ull, e1 = 0;
-        for (int b = 0; b < 256; ++b) { b0 = std::min(b0, h[(size_t)b * T * 6]); e1 = std::max(e1, h[(size_t)b * T * 6 + (T - 1) * 6 + 5]); }
+        for (int b = 0; b < NB; ++b) { b0 = std::min(b0, h[(size_t)b * T * 6]); e1 = std::max(e1, h[(size_t)b * T * 6 + (T - 1) * 6 + 5]); }
         const double us = (e1 - b0) / 100.0 / T;
         if (us < best) {
             best = us;
             std::fill(ph.begin(), ph.end(), 0.0);
-            for (int b = 0; b < 256; ++b) for (int s = 2; s < T; ++s) {        // skip the first two steps
+            for (int b = 0; b < NB; ++b) for (int s = 2; s < T; ++s) {        // skip the first two steps
                 const unsigned long long* p = &h[((size_t)b * T + s) * 6];
                 const unsigned long long prev_end = h[((size_t)b * T + s - 1) * 6 + 5];
                 ph[0] += (p[0] - prev_end); ph[1] += p[1] - p[0]; ph[2] += p[2] - p[1]; ph[3] += p[3] - p[2]; ph[4] += p[4] - p[3]; ph[5] += p[5] - p[4];
             }
-            for (auto& x : ph) x /= 100.0 * 256 * (T - 2);
+            for (auto& x : ph) x /= 100.0 * NB * (T - 2);
         }
+    }
+    {
+        std::vector<unsigned> wh(NB);
+        (void)hipMemcpy(wh.data(), a.where, NB * 4, hipMemcpyDeviceToHost);
+        std::sort(wh.begin(), wh.end());
+        int hist[9] = {0}, cus = 0;
+        for (size_t i = 0; i < wh.size();) { size_t j = i; while (j < wh.size() && wh[j] == wh[i]) ++j; hist[std::min<size_t>(j - i, 8)]++; ++cus; i = j; }
+        printf("  placement: %d CUs; CUs holding 1/2/3/4 workgroups: %d %d %d %d\n", cus, hist[1], hist[2], hist[3], hist[4]);
     }
     printf("%-10s %6.2f us/step | loop %.2f  prefetch+wait %.2f  contract %.2f  reduce %.2f  gates+publish+arrive %.2f  stores %.2f | status %u\n",
            name, best, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], stat);
@@ -125,8 +150,9 @@ int main() {
     float* W; (void)hipMalloc(&W, (size_t)3 * H * H * 4); (void)hipMemset(W, 0, (size_t)3 * H * H * 4); a.W = W;
     float* gi; (void)hipMalloc(&gi, (size_t)T * B * 3 * H * 4); (void)hipMemset(gi, 0, (size_t)T * B * 3 * H * 4); a.gi = gi;
     (void)hipMalloc(&a.out, (size_t)7 * T * B * H * 4);
-    (void)hipMalloc(&a.counters, 64 * 4); (void)hipMalloc(&a.status, 4);
-    (void)hipMalloc(&a.stamps, (size_t)256 * T * 6 * 8);
+    (void)hipMalloc(&a.counters, 64 * 64 * 4); (void)hipMalloc(&a.status, 4);
+    (void)hipMalloc(&a.stamps, (size_t)NB * T * 6 * 8);
+    (void)hipMalloc(&a.where, NB * 4);
     run<true, true, true, false>("full", a);
     run<false, true, true, false>("no_mfma", a);
     run<true, false, true, false>("no_loads", a);
