@@ -67,6 +67,9 @@ __device__ __forceinline__ void arrive(unsigned* counter) {
 // next wait while a slow one still reads this one's word.
 // `status` = {device word inside the workspace (aborts the other workgroups of the launch quickly), host-mapped word
 // (chain_host_status(): what inet_chain_status() reports)}.
+#ifndef INET_CHAIN_POLL_SLEEP
+#define INET_CHAIN_POLL_SLEEP 1                   // s_sleep units (64 clocks) between two polls of the group counter
+#endif
 struct Status { unsigned* dev; unsigned* host; };
 __device__ __forceinline__ bool wait_group(unsigned* counter, unsigned target, Status status, unsigned* flag) {
     if (threadIdx.x == 0) {
@@ -79,7 +82,7 @@ __device__ __forceinline__ bool wait_group(unsigned* counter, unsigned target, S
                 ok = 0;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(INET_CHAIN_POLL_SLEEP);
         }
         *flag = ok;
     }
