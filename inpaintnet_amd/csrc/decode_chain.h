@@ -2,7 +2,10 @@
 #pragma once
 #include "chain.h"
 
-constexpr int kDecodeSyncWords = 16;              // group counters [0..13], status word [15]
+constexpr int kDecodeMaxGroups = 8;               // row tiles of 16*MS rows: B <= 256 at MS = 2
+constexpr int kDecodeCounterStride = 64;          // one 256-byte block per group counter (see gru_chain.h)
+constexpr int kDecodeStatusWord = kDecodeMaxGroups * kDecodeCounterStride;
+constexpr int kDecodeSyncWords = kDecodeStatusWord + 4;
 
 struct DecodeChainArgs {
     int B, H, T, G, V, members;                   // G = ticks per beat; T = beats * G
@@ -17,6 +20,12 @@ struct DecodeChainArgs {
     float* amax;                                  // [2][V/16][ceil16(B)] x {idx, max} (8 bytes each)
     float* weights; long long* samples;           // outputs [B,T,V], [B,1,T]
     unsigned* counters; chain::Status status;
+    // training (free-running forward with backward saves): everything below may be null for inference
+    const float* mask;                            // [T,B,H] dropout mask of the layer-0 output (layer 1 sees h0 * mask)
+    float* hx0m;                                  // [beats][pk(B,H)] exchange buffer of the masked h0 (needed iff mask)
+    float* sv0; float* sv1; long sv_stride;       // saves r,z,n,W_hn h + b_hn,h_prev of layer 0 / 1: [5][T,B,H], stride
+    float* h0out;                                 // [T,B,H] layer-0 output as layer 1 saw it (masked if mask)
+    float* h1seq;                                 // [T,B,H] layer-1 output (input of the output projection's gradients)
 };
 
 bool decode_chain_ok(int B, int H, int V, int T, int G);

@@ -63,14 +63,15 @@ __device__ __forceinline__ void contract_b(f32x4 (&acc)[MS][4], const int (&slot
     }
 }
 
-template <int MS, int SQ>                          // SQ = H/64
+template <int MS, int SQ, bool TRAIN>              // SQ = H/64; TRAIN: dropout mask + backward saves
 __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     constexpr int S = 4 * SQ, H = 64 * SQ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wih = smem;                                   // [3][S][64][4]  W_ih(l1) slice, fragment-major
     float* const red = wih + 3 * S * 256;                      // [4 waves][4 acc][MS*256]
     float* const xt = red + 4 * 4 * MS * 256;                  // [MS*256]
-    unsigned* const flag = reinterpret_cast<unsigned*>(xt + MS * 256);   // [2]
+    float* const xm = xt + MS * 256;                           // [MS*256] masked h0 (TRAIN)
+    unsigned* const flag = reinterpret_cast<unsigned*>(xm + MS * 256);   // [2]
     int group, member;
     chain::decode_block(blockIdx.x, P.members, group, member);
     const int row0 = group * 16 * MS, B = P.B, T = P.T, V = P.V;
@@ -113,7 +114,9 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     for (int p = 0; p < MS; ++p) brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1);
     const __amdgpu_buffer_rsrc_t r_hx0 = chain::make_rsrc(P.hx0), r_hx1 = chain::make_rsrc(P.hx1),
                                  r_ht0 = chain::make_rsrc(P.ht0pk), r_am = chain::make_rsrc(P.amax);
-    unsigned* const counter = P.counters + group;
+    const bool masked = TRAIN && P.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t r_hxm = chain::make_rsrc(masked ? P.hx0m : P.hx0);
+    unsigned* const counter = P.counters + group * kDecodeCounterStride;
     const chain::Status status = P.status;
     const int members = P.members, G = P.G, nb = T / G;
     const int am_slot = NCB * (((B + 15) >> 4) * 16);          // float2 entries per amax slot: [NCB][rows16]
@@ -136,9 +139,10 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     for (int tick = 0; tick < T; ++tick) {
         const int beat = tick / G, j = tick % G;
         // ================= layer 0 =================
-        float c0[MS][3];
+        float c0[MS][3], mk[MS];
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
+            mk[p] = masked ? P.mask[((long)tick * B + brow[p]) * H + jc] : 1.f;
 #pragma unroll
             for (int g = 0; g < 3; ++g) c0[p][g] = P.cgi[((long)beat * B + brow[p]) * 3 * H + g * H + jc];
             if (j == 0) {                                      // hidden states restart from the beat embedding
@@ -172,20 +176,41 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
         }
         float v[MS][4];
         reduce_waves<MS, 4>(acc, red, t, v);
+        float sv[MS][6];                                       // TRAIN: r, z, n, ghn, h_prev, h0 as layer 1 sees it
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const float ghn = v[p][2] + bh0[2];
             const float r = sigmoid_f(v[p][0] + c0[p][0] + g0[p][0] + bh0[0]);
             const float z = sigmoid_f(v[p][1] + c0[p][1] + g0[p][1] + bh0[1]);
             const float n = tanh_f(c0[p][2] + g0[p][2] + r * ghn);
+            if (TRAIN) { sv[p][0] = r; sv[p][1] = z; sv[p][2] = n; sv[p][3] = ghn; sv[p][4] = hp0[p]; }
             hp0[p] = (1.f - z) * n + z * hp0[p];
             xt[((t + 256 * p) >> 4) * 16 + (t & 15)] = hp0[p];
+            if (TRAIN) {
+                sv[p][5] = hp0[p] * mk[p];
+                if (masked) xm[((t + 256 * p) >> 4) * 16 + (t & 15)] = sv[p][5];
+            }
         }
         __syncthreads();
-        if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
+        if (t < 64 * MS && rb0 + (t >> 6) <= rb_last) {
             chain::publish_block(r_hx0, (tick & 1) * pkh * 4, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
+            if (masked) chain::publish_block(r_hxm, beat * pkh * 4, xm, t >> 6, lane, rb0 + (t >> 6), S, member);
+        }
         chain::arrive(counter);
         ++phase;
+        if (TRAIN) {                                           // backward saves: after the hand-off, off the critical path
+#pragma unroll
+            for (int p = 0; p < MS; ++p) {
+                if (row0 + ((t + 256 * p) >> 4) < B) {
+                    const long o = ((long)tick * B + brow[p]) * H + jc;
+                    if (P.sv0) {
+#pragma unroll
+                        for (int a = 0; a < 5; ++a) P.sv0[o + a * P.sv_stride] = sv[p][a];
+                    }
+                    if (P.h0out) P.h0out[o] = sv[p][5];
+                }
+            }
+        }
         // ================= layer 1 =================
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
         {
             const int sx[3] = {0, 1, 2};
             contract_b<MS, 3, SQ>(acc, sx, [&](int g, int si) { return *reinterpret_cast<const f32x4*>(wih + ((g * S + w * SQ + si) * 64 + lane) * 4); },
-                                  r_hx0, (tick & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+                                  r_hxm, (masked ? beat : (tick & 1)) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
         }
         reduce_waves<MS, 4>(acc, red, t, v);
 #pragma unroll
@@ -209,6 +234,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             const float r = sigmoid_f(v[p][0] + bi1[0] + bh1[0]);
             const float z = sigmoid_f(v[p][1] + bi1[1] + bh1[1]);
             const float n = tanh_f(v[p][2] + bi1[2] + r * ghn);
+            if (TRAIN) { sv[p][0] = r; sv[p][1] = z; sv[p][2] = n; sv[p][3] = ghn; sv[p][4] = hp1[p]; }
             hp1[p] = (1.f - z) * n + z * hp1[p];
             xt[((t + 256 * p) >> 4) * 16 + (t & 15)] = hp1[p];
         }
@@ -217,6 +243,19 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             chain::publish_block(r_hx1, (tick & 1) * pkh * 4, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
         chain::arrive(counter);
         ++phase;
+        if (TRAIN) {
+#pragma unroll
+            for (int p = 0; p < MS; ++p) {
+                if (row0 + ((t + 256 * p) >> 4) < B) {
+                    const long o = ((long)tick * B + brow[p]) * H + jc;
+                    if (P.sv1) {
+#pragma unroll
+                        for (int a = 0; a < 5; ++a) P.sv1[o + a * P.sv_stride] = sv[p][a];
+                    }
+                    if (P.h1seq) P.h1seq[o] = hp1[p];
+                }
+            }
+        }
         // ================= output projection + partial argmax (members that own a logits tile) =================
         if (has_tile) {
             if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;           // h1 of this tick
@@ -261,11 +300,13 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
 }
 
 int rows_ms(int B) { return B <= 16 ? 1 : 2; }
+inline int groups_of(int B) { const int ms = rows_ms(B); return (B + 16 * ms - 1) / (16 * ms); }
 
 }  // namespace
 
 bool decode_chain_ok(int B, int H, int V, int T, int G) {
-    if (!chain_enabled() || (H != 256 && H != 512) || B < 1 || B > 32 || V % 16 != 0 || V > 64 || T % G != 0) return false;
+    if (!chain_enabled() || (H != 256 && H != 512) || B < 1 || V % 16 != 0 || V > 64 || T % G != 0) return false;
+    if (groups_of(B) > kDecodeMaxGroups || groups_of(B) * (H / 16) > 256) return false;   // every workgroup resident at once
     static const bool off = [] { const char* v = std::getenv("INET_DECODE_CHAIN"); return v && v[0] == '0'; }();
     if (off) return false;
     const int ms = rows_ms(B);
@@ -274,7 +315,7 @@ bool decode_chain_ok(int B, int H, int V, int T, int G) {
 
 size_t decode_chain_lds_bytes(int B, int H) {
     const int ms = rows_ms(B), S = H / 16;
-    return (size_t)(3 * S * 256 + 4 * 4 * ms * 256 + ms * 256 + 4) * sizeof(float);
+    return (size_t)(3 * S * 256 + 4 * 4 * ms * 256 + 2 * ms * 256 + 4) * sizeof(float);
 }
 
 int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
@@ -283,26 +324,33 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
     a.members = a.H / 16;
     a.status.host = chain_host_status();
     if (hipMemsetAsync(a.counters, 0, kDecodeSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    a.status.dev = a.counters + kDecodeSyncWords - 1;
+    a.status.dev = a.counters + kDecodeStatusWord;
     const size_t lds = decode_chain_lds_bytes(a.B, a.H);
     char label[72];
-    std::snprintf(label, sizeof label, "decode_chain ms%d T%d B%d H%d V%d", ms, a.T, a.B, a.H, a.V);
+    const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;
+    if (a.mask && !a.hx0m) return -1;
+    std::snprintf(label, sizeof label, "decode_chain%s ms%d T%d B%d H%d V%d", train ? "_train" : "", ms, a.T, a.B, a.H, a.V);
     // algorithmic bytes: the tick GRU + output weights once per call, logits out
     ProfScope prof(PROF_GRU_FWD, 2.0 * a.T * a.B * (9.0 * a.H * a.H + (double)a.V * a.H), s, label,
                    4.0 * (9.0 * a.H * a.H + (double)a.V * a.H + (double)a.B * a.T * a.V));
     const dim3 grid(chain::blocks_for(groups, a.members));
-#define INET_DC(M, Q)                                                                                                   \
+#define INET_DC(M, Q, TR)                                                                                               \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chain_kernel<M, Q>),                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chain_kernel<M, Q, TR>),                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((decode_chain_kernel<M, Q>), grid, dim3(256), lds, s, a);                                    \
+        hipLaunchKernelGGL((decode_chain_kernel<M, Q, TR>), grid, dim3(256), lds, s, a);                                \
     } while (0)
-    if (a.H == 512) { if (ms == 1) INET_DC(1, 8); else INET_DC(2, 8); }
-    else { if (ms == 1) INET_DC(1, 4); else INET_DC(2, 4); }
+    if (train) {
+        if (a.H == 512) { if (ms == 1) INET_DC(1, 8, true); else INET_DC(2, 8, true); }
+        else { if (ms == 1) INET_DC(1, 4, true); else INET_DC(2, 4, true); }
+    } else {
+        if (a.H == 512) { if (ms == 1) INET_DC(1, 8, false); else INET_DC(2, 8, false); }
+        else { if (ms == 1) INET_DC(1, 4, false); else INET_DC(2, 4, false); }
+    }
 #undef INET_DC
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

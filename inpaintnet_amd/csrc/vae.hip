@@ -353,8 +353,10 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         INET_TRY(pw_swap01(w.wtm, T, B, V, weights, s));             // [T,B,V] -> [B,T,V]
         return 0;
     }
-    if (pk && !teacher_forced && !save && !mask_tick && w.wpk_out && decode_chain_ok(B, H, V, T, G)) {
-        // small-batch inference: all 24 ticks (layer 0, layer 1, projection, argmax, token feedback) in ONE launch
+    static const bool train_chain = [] { const char* v = std::getenv("INET_DECODE_CHAIN_TRAIN"); return !(v && v[0] == '0'); }();
+    if (pk && !teacher_forced && w.wpk_out && decode_chain_ok(B, H, V, T, G) && ((!save && !mask_tick) || train_chain)) {
+        // all 24 free-running ticks (layer 0, layer 1, projection, argmax, token feedback) in ONE launch: inference, and
+        // the free-running half of the training steps (dropout mask between the layers, backward saves written on the way)
         DecodeChainArgs a{};
         a.B = B; a.H = H; a.T = T; a.G = G; a.V = V;
         a.W_hh0 = p + L.tick[0].w_hh; a.b_hh0 = p + L.tick[0].b_hh;
@@ -365,6 +367,11 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
         a.weights = weights; a.samples = samples;
         a.counters = w.sync;
+        if (mask_tick) { a.mask = mask_tick; a.hx0m = w.hm0pk; }
+        if (save) {
+            a.sv0 = w.svt0; a.sv1 = w.svt1; a.sv_stride = (long)T * BH;
+            a.h0out = mask_tick ? w.h0m : w.h0seq; a.h1seq = w.h1seq;
+        }
         return launch_decode_chain(a, s);
     }
     for (int t = 0; t < T; ++t) {

@@ -84,6 +84,8 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
                "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N1024 K6144 TN d192x128 s4 e0",
                "M256 N1024 K2048 NT k32x32 s1 e1"):                                            # workgroup split-K, SELU head
         assert wl in labels, (wl, big)
+    if not tf:      # the 24 free-running ticks with dropout and backward saves: one launch of the fused decode kernel
+        assert "decode_chain_train ms2 T24 B256 H512 V48" in labels, sorted(set(l for l in labels if l.startswith("dec")))
     print(sorted(set(l for l in labels if l.startswith("gru"))))
 
     om = {"enc": m_enc.cpu().permute(1, 0, 2), "beat": m_beat.cpu().permute(1, 0, 2), "tick": m_tick.cpu().permute(1, 0, 2)}
