@@ -83,10 +83,13 @@ int inet_vae_encoder_bwd(const inet_vae_config* cfg, int batch, const int64_t* t
 /* ---- MeasureVAE decoder: HierarchicalDecoder.forward, MeasureVAE/decoder.py:412-529 -- */
 int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int save);
 /* z [B,Z]; target [B,T] int64 (read iff teacher_forced); mask_beat [beats,B,H], mask_tick [T,B,H] or null;
- * weights [B,T,V] post-ReLU logits; samples [B,1,T] int64 (argmax, lowest index on ties; = target if teacher forced) */
+ * weights [B,T,V] post-ReLU logits; samples [B,1,T] int64 (= target if teacher forced; else argmax, lowest index on
+ * ties, or -- multinomial_seed != 0, decoder.py:506-509 sampling = 'multinomial' -- one draw per tick and row from
+ * softmax(weights) with a counter-based generator keyed (multinomial_seed, tick * B + row)) */
 int inet_vae_decoder_fwd(const inet_vae_config* cfg, int batch, const float* z, const int64_t* target,
                          int teacher_forced, const float* params, const float* mask_beat, const float* mask_tick,
-                         float* weights, int64_t* samples, void* ws, int64_t ws_bytes, int save, void* stream);
+                         float* weights, int64_t* samples, void* ws, int64_t ws_bytes, int save,
+                         uint64_t multinomial_seed, void* stream);
 /* dweights [B,T,V] = dLoss/dweights; weights = the forward output; grads may be null (frozen decoder:
  * LatentRNN/latent_rnn.py:42-43) in which case only dz [B,Z] is produced.  `tokens_in` are the tokens that
  * were fed back (= samples of the forward call). */
@@ -115,6 +118,11 @@ int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, fl
  * z (dz, nullable) and of the KL sum (a device scalar from autograd, nullable) in one pass */
 int inet_latent_bwd(const float* dz, const float* mu, const float* logsigma, const float* eps, float kscale,
                     const float* kscale_dev, float* dmu, float* dlogsigma, int64_t n, void* stream);
+
+/* rows of V (post-ReLU) logits -> out[row*stride] ~ Multinomial(softmax(row))  (decoder.py:506-509): inverse-CDF draw with
+ * one counter-based uniform per row keyed (seed, offset + row) */
+int inet_sample_multinomial(const float* weights, int64_t ld_w, int rows, int V, int64_t* out, int64_t stride,
+                            uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- optimizer: torch.optim.Adam as built at utils/trainer.py:32-35, stepped at :172-177 -------- */
 /* p,g,m,v: arenas of n floats; step is 1-based; grads are multiplied by gscale first (1/world_size for DP) */

@@ -116,11 +116,12 @@ int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int sav
 }
 int inet_vae_decoder_fwd(const inet_vae_config* cfg, int batch, const float* z, const int64_t* target,
                          int teacher_forced, const float* params, const float* mask_beat, const float* mask_tick,
-                         float* weights, int64_t* samples, void* ws, int64_t ws_bytes, int save, void* stream) {
+                         float* weights, int64_t* samples, void* ws, int64_t ws_bytes, int save,
+                         uint64_t multinomial_seed, void* stream) {
     if (!cfg_ok(cfg) || batch <= 0 || !z || !params || !weights || !samples || !ws) return -1;
     if (ws_bytes < (int64_t)vae_decoder_ws_bytes(*cfg, batch, save)) return -1;
     return vae_decoder_fwd(*cfg, batch, z, (const long long*)target, teacher_forced, params, mask_beat, mask_tick,
-                           weights, (long long*)samples, ws, save, (hipStream_t)stream);
+                           weights, (long long*)samples, ws, save, (hipStream_t)stream, multinomial_seed);
 }
 int inet_vae_decoder_bwd(const inet_vae_config* cfg, int batch, const float* dweights, const float* weights,
                          const int64_t* tokens_in, const float* params, float* grads, const float* mask_beat,
@@ -145,6 +146,11 @@ int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, cons
     if (!weights || !targets || !loss_sum || !correct || rows <= 0 || V <= 0) return -1;
     return pw_cross_entropy(weights, ld_w, rows, V, (const long long*)targets, dW, ld_dw, scale, out_scale, loss_sum,
                             correct, (hipStream_t)stream);
+}
+int inet_sample_multinomial(const float* weights, int64_t ld_w, int rows, int V, int64_t* out, int64_t stride,
+                            uint64_t seed, uint64_t offset, void* stream) {
+    if (!weights || !out || rows <= 0 || V <= 0) return -1;
+    return pw_sample_multinomial(weights, ld_w, rows, V, (long long*)out, stride, seed, offset, (hipStream_t)stream);
 }
 int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, float* z, float* sigma, int64_t n,
                     float* kl_sum, void* stream) {

@@ -16,6 +16,8 @@ int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, 
                   hipStream_t s);
 int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, const float* kdev,
                   float* dmu, float* dls, long n, hipStream_t s);
+int pw_sample_multinomial(const float* W, long ld_w, int rows, int V, long long* out, long stride, uint64_t seed,
+                          uint64_t offset, hipStream_t s);
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
             float gscale, hipStream_t s);
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);

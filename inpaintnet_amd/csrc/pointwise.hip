@@ -359,6 +359,43 @@ __global__ void dropout_mask_kernel(float* __restrict__ out, long n, float p, ui
     }
 }
 
+// samples[row*stride] ~ Multinomial(softmax(W[row,:]))  (decoder.py:506-509, sampling = 'multinomial'): one wavefront per
+// row, inverse-CDF draw with one counter-based uniform per row (seed, offset + row): reproducible, rank-offsettable.
+__global__ void sample_multinomial_kernel(const float* __restrict__ W, long ld_w, int rows, int V,
+                                          long long* __restrict__ out, long stride, uint64_t seed, uint64_t offset) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int row = wave; row < rows; row += nwaves) {
+        const float* w = W + (long)row * ld_w;
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, w[v]);
+        m = wave_max(m);
+        float tot = 0.f;
+        for (int v = lane; v < V; v += 64) tot += expf(w[v] - m);
+        tot = wave_sum(tot);
+        const uint64_t h = mix64(mix64(seed) ^ (offset + (uint64_t)row));
+        const float target = (float)((uint32_t)(h >> 40)) * (1.f / 16777216.f) * tot;     // u in [0, 1) times the total mass
+        float base = 0.f;
+        int pick = V - 1;
+        bool found = false;
+        for (int v0 = 0; v0 < V && !found; v0 += 64) {
+            const int v = v0 + lane;
+            const float e = v < V ? expf(w[v] - m) : 0.f;
+            float incl = e;                                     // inclusive prefix sum over the 64 lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const unsigned long long hit = __ballot(v < V && base + incl > target);
+            if (hit) { pick = v0 + __ffsll((long long)hit) - 1; found = true; }
+            base += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) out[(long)row * stride] = pick;
+    }
+}
+
 __global__ void scale_kernel(float* __restrict__ x, long n, float a) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= a;
 }
@@ -531,6 +568,12 @@ int pw_beat_input_grad(const float* sv, const float* w, long incw, const float* 
 }
 int pw_dropout_mask(float* out, long n, float p, uint64_t seed, uint64_t offset, hipStream_t s) {
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, n, p, seed, offset);
+    return ok();
+}
+int pw_sample_multinomial(const float* W, long ld_w, int rows, int V, long long* out, long stride, uint64_t seed,
+                          uint64_t offset, hipStream_t s) {
+    hipLaunchKernelGGL(sample_multinomial_kernel, dim3(grid_for((long)rows * 64, 256, 1024)), dim3(256), 0, s, W, ld_w, rows, V,
+                       out, stride, seed, offset);
     return ok();
 }
 int pw_scale(float* x, long n, float a, hipStream_t s) {

@@ -10,7 +10,7 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
 size_t vae_decoder_ws_bytes(const inet_vae_config& c, int B, int save);
 int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long long* target, int teacher_forced,
                     const float* p, const float* mask_beat, const float* mask_tick, float* weights,
-                    long long* samples, void* ws, int save, hipStream_t s);
+                    long long* samples, void* ws, int save, hipStream_t s, uint64_t multinomial_seed = 0);
 int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, const float* weights,
                     const long long* tokens_in, const float* p, float* g, const float* mask_beat,
                     const float* mask_tick, float* dz, void* ws, hipStream_t s);

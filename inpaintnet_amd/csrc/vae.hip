@@ -248,7 +248,7 @@ size_t vae_decoder_ws_bytes(const inet_vae_config& c, int B, int save) {
 
 int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long long* target, int teacher_forced,
                     const float* p, const float* mask_beat, const float* mask_tick, float* weights,
-                    long long* samples, void* ws, int save, hipStream_t s) {
+                    long long* samples, void* ws, int save, hipStream_t s, uint64_t multinomial_seed) {
     const int nb = c.beats, G = c.ticks_per_beat, T = nb * G, H = c.dec_hidden, V = c.num_notes, E = c.emb_dim, Z = c.z_dim;
     const long BH = (long)B * H;
     if (nb > 4) return -1;
@@ -354,7 +354,8 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         return 0;
     }
     static const bool train_chain = [] { const char* v = std::getenv("INET_DECODE_CHAIN_TRAIN"); return !(v && v[0] == '0'); }();
-    if (pk && !teacher_forced && w.wpk_out && decode_chain_ok(B, H, V, T, G) && ((!save && !mask_tick) || train_chain)) {
+    if (pk && !teacher_forced && !multinomial_seed && w.wpk_out && decode_chain_ok(B, H, V, T, G) &&
+        ((!save && !mask_tick) || train_chain)) {
         // all 24 free-running ticks (layer 0, layer 1, projection, argmax, token feedback) in ONE launch: inference, and
         // the free-running half of the training steps (dropout mask between the layers, backward saves written on the way)
         DecodeChainArgs a{};
@@ -412,14 +413,17 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         INET_TRY(launch_gru_fwd(b1, s));
 
         // logits = ReLU(h_top . Wo^T + bo) straight into weights[:, t, :], fused with the argmax that feeds tick t+1
-        int rc = launch_logits_argmax(w.h1seq + (long)t * BH, H, B, H, p + L.out_w, p + L.out_b, V, weights + (long)t * V,
-                                      (long)T * V, teacher_forced ? nullptr : samples + t, T, s,
-                                      pk ? P1.hpk_new : nullptr, w.wpk_out);
+        const bool draw = multinomial_seed != 0 && !teacher_forced;       // decoder.py:506-509: sample the fed-back token
+        int rc = draw ? 1 : launch_logits_argmax(w.h1seq + (long)t * BH, H, B, H, p + L.out_w, p + L.out_b, V,
+                                                 weights + (long)t * V, (long)T * V, teacher_forced ? nullptr : samples + t,
+                                                 T, s, pk ? P1.hpk_new : nullptr, w.wpk_out);
         if (rc < 0) return rc;
-        if (rc == 1) {                                         // V not a multiple of 16 (or > 64): two kernels
+        if (rc == 1) {                                         // V not a multiple of 16 (or > 64), or sampling: two kernels
             INET_TRY(linear_fwd(w.h1seq + (long)t * BH, H, p + L.out_w, H, p + L.out_b, weights + (long)t * V,
                                 (long)T * V, B, V, H, EPI_RELU, s));
-            if (!teacher_forced) INET_TRY(pw_argmax(weights + (long)t * V, (long)T * V, B, V, samples + t, T, s));
+            if (draw) INET_TRY(pw_sample_multinomial(weights + (long)t * V, (long)T * V, B, V, samples + t, T,
+                                                     multinomial_seed, (uint64_t)t * B, s));
+            else if (!teacher_forced) INET_TRY(pw_argmax(weights + (long)t * V, (long)T * V, B, V, samples + t, T, s));
         }
     }
     return 0;

@@ -54,10 +54,10 @@ class _EncoderFn(ops.TrackedFunction):
 
 class _DecoderFn(ops.TrackedFunction):
     @staticmethod
-    def forward(ctx, z, flat, dec, target, teacher_forced, mask_beat, mask_tick):
+    def forward(ctx, z, flat, dec, target, teacher_forced, mask_beat, mask_tick, multinomial_seed=0):
         need = ops.outer_grad() and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         weights, samples, ws = ops.decoder_fwd(dec.cfg, z.contiguous(), target, teacher_forced, flat, mask_beat,
-                                               mask_tick, save=need)
+                                               mask_tick, save=need, multinomial_seed=multinomial_seed)
         ctx.dec, ctx.ws, ctx.mb, ctx.mt = dec, ws, mask_beat, mask_tick
         if getattr(dec, "keep_ws", False):         # test hook: lets a parity test read intermediates (ops.ws_field)
             dec.last_ws = ws
@@ -78,7 +78,7 @@ class _DecoderFn(ops.TrackedFunction):
             if dp.world_size() > 1:
                 ops.side_join()                    # deferred joins: the decoder's leaf GEMMs must be in before the exchange
                 dp.start_bucket(grads, dec.owner.decoder_arena_start, grads.numel())
-        return dz, None, None, None, None, None, None
+        return dz, None, None, None, None, None, None, None
 
 
 class _ReparamFn(torch.autograd.Function):
@@ -243,8 +243,8 @@ class HierarchicalDecoder(torch.nn.Module):
                 teacher_forced = random.random() < self.teacher_forcing_prob
             else:
                 teacher_forced = False
-        if train and self.sampling != 'argmax':
-            raise NotImplementedError("only argmax sampling (the reference default, decoder.py:376) is implemented")
+        if self.sampling not in ('argmax', 'multinomial'):
+            raise ValueError(f"sampling must be 'argmax' or 'multinomial' (decoder.py:506-516), got {self.sampling!r}")
         batch_size_z, z_dim = z.size()
         assert z_dim == self.z_dim
         batch_size = score_tensor.size(0)
@@ -266,7 +266,11 @@ class HierarchicalDecoder(torch.nn.Module):
                                   _next_mask_offset(self.cfg.beats * batch_size * H), dev)
             mt = ops.dropout_mask((T, batch_size, H), self.dropout, _DropState.seed,
                                   _next_mask_offset(T * batch_size * H), dev)
-        weights, samples = _DecoderFn.call(z, self.owner.flat_for_autograd(), self, target, teacher_forced, mb, mt)
+        seed = 0
+        if self.sampling == 'multinomial' and not teacher_forced:
+            # one counter-based stream per call, derived from the dropout seed (set_dropout_seed) and the call counter
+            seed = ((_DropState.seed * 0x9E3779B97F4A7C15 + _next_mask_offset(T * batch_size) + 1) & (2 ** 64 - 1)) or 1
+        weights, samples = _DecoderFn.call(z, self.owner.flat_for_autograd(), self, target, teacher_forced, mb, mt, seed)
         return weights, samples
 
 

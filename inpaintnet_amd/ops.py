@@ -138,8 +138,10 @@ def decoder_ws(cfg, B, save, device):
     return _ws(n, device)
 
 
-def decoder_fwd(cfg, z, target, teacher_forced, params, mask_beat=None, mask_tick=None, save=False, ws=None):
-    """z [B,Z] -> weights [B,T,V], samples [B,1,T] int64, ws"""
+def decoder_fwd(cfg, z, target, teacher_forced, params, mask_beat=None, mask_tick=None, save=False, ws=None,
+                multinomial_seed=0):
+    """z [B,Z] -> weights [B,T,V], samples [B,1,T] int64, ws.  multinomial_seed != 0: the fed-back tokens are drawn from
+    softmax(weights) (decoder.py:506-509) instead of the argmax."""
     _f32c(z); _f32c(params)
     B = z.shape[0]
     T = cfg.beats * cfg.ticks_per_beat
@@ -151,7 +153,8 @@ def decoder_fwd(cfg, z, target, teacher_forced, params, mask_beat=None, mask_tic
     samples = torch.empty(B, 1, T, dtype=torch.int64, device=z.device)
     check(_lib.lib().inet_vae_decoder_fwd(C.byref(cfg), B, ptr(z), ptr(target), int(bool(teacher_forced)), ptr(params),
                                           ptr(mask_beat), ptr(mask_tick), ptr(weights), ptr(samples), ptr(ws),
-                                          ws.numel() * 4, int(save), stream_ptr()), "inet_vae_decoder_fwd")
+                                          ws.numel() * 4, int(save), int(multinomial_seed) & (2 ** 64 - 1), stream_ptr()),
+          "inet_vae_decoder_fwd")
     return weights, samples, ws
 
 
@@ -175,6 +178,16 @@ def cross_entropy(weights2d, targets1d, out2, dW=None, scale=1.0, out_scale=1.0)
     check(_lib.lib().inet_cross_entropy(ptr(weights2d), weights2d.stride(0), rows, V, ptr(targets1d), ptr(dW),
                                         dW.stride(0) if dW is not None else 0, float(scale), float(out_scale),
                                         ptr(out2[0:1]), ptr(out2[1:2]), stream_ptr()), "inet_cross_entropy")
+
+
+def sample_multinomial(weights2d, seed, offset=0):
+    """One draw per row from softmax(weights2d[row]) (decoder.py:506-509), counter-based generator (seed, offset + row)."""
+    rows, V = weights2d.shape
+    assert weights2d.stride(1) == 1 and weights2d.dtype == torch.float32
+    out = torch.empty(rows, dtype=torch.int64, device=weights2d.device)
+    check(_lib.lib().inet_sample_multinomial(ptr(weights2d), weights2d.stride(0), rows, V, ptr(out), 1,
+                                             int(seed) & (2 ** 64 - 1), int(offset), stream_ptr()), "inet_sample_multinomial")
+    return out
 
 
 def reparam_kl(mu, ls, eps, kl_sum=None, want_sigma=False):

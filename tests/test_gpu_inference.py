@@ -210,3 +210,41 @@ def test_fused_decode_kernel_matches_per_tick_path(name, B):
     same = np.array_equal(s1.cpu().numpy(), s0.cpu().numpy())
     if same:
         assert G.rel_err(w1.cpu(), w0.cpu()) < 2e-5
+
+
+def test_decoder_multinomial_sampling():
+    """HierarchicalDecoder.sampling = 'multinomial' (decoder.py:506-509): the fed-back token of every free-running tick is
+    drawn from softmax(weights).  Tick 0 does not depend on any draw, so its logits equal the argmax run's; the draws are
+    valid tokens, reproducible for one dropout seed / call counter, and follow the model's own softmax on tick 0."""
+    from inpaintnet_amd import measure_vae as MV
+    c, ds, vae = small_vae()
+    vae.eval()
+    B = 512
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, c["Z"], generator=g).cuda()
+    dummy = torch.zeros(B, 24, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        w_arg, s_arg = vae.decoder(z, dummy, train=False)
+        vae.decoder.sampling = 'multinomial'
+        MV.set_dropout_seed(11)
+        w1, s1 = vae.decoder(z, dummy, train=False)
+        MV.set_dropout_seed(11)
+        w2, s2 = vae.decoder(z, dummy, train=False)
+        w3, s3 = vae.decoder(z, dummy, train=False)              # next call: another stream
+        vae.decoder.sampling = 'argmax'
+    assert torch.equal(s1, s2) and torch.equal(w1, w2) and not torch.equal(s1, s3)
+    assert G.rel_err(w1[:, 0].cpu(), w_arg[:, 0].cpu().numpy()) < 1e-6
+    V = w1.shape[-1]
+    assert int(s1.min()) >= 0 and int(s1.max()) < V and s1.shape == s_arg.shape
+    assert not torch.equal(s1, s_arg)
+    # tick 0: the same z in every row -> same distribution in every row -> frequencies follow its softmax
+    zc = z[:1].repeat(4096, 1).contiguous()
+    with torch.no_grad():
+        vae.decoder.sampling = 'multinomial'
+        wc, sc = vae.decoder(zc, torch.zeros(4096, 24, dtype=torch.int64, device="cuda"), train=False)
+        vae.decoder.sampling = 'argmax'
+    p = torch.softmax(wc[0, 0].double(), 0).cpu().numpy()
+    counts = np.bincount(sc[:, 0, 0].cpu().numpy(), minlength=V).astype(np.float64)
+    keep = p * 4096 > 5
+    chi2 = float((((counts - 4096 * p) ** 2) / (4096 * p))[keep].sum())
+    assert chi2 < keep.sum() + 6.0 * np.sqrt(2.0 * keep.sum()), chi2

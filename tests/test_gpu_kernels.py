@@ -497,3 +497,28 @@ def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
         if not err < 5e-4:
             bad.append((k, err))
     assert not bad, bad
+
+
+# ------------------------------------------------------------------------------- multinomial sampling (decoder.py:506-509)
+@pytest.mark.parametrize("V", [48, 10, 130])
+def test_sample_multinomial_follows_softmax(V):
+    """Draws from the sampling kernel follow softmax(row): chi-square against the exact probabilities over 200k draws of
+    one row (different counters), exact reproducibility for a (seed, offset), different draws for another seed."""
+    g = torch.Generator().manual_seed(V)
+    row = torch.relu(torch.randn(V, generator=g) * 2.0)            # post-ReLU logits, as the decoder produces them
+    n = 200_000
+    W = row.repeat(n, 1).to(DEV)
+    a = ops.sample_multinomial(W, seed=1234, offset=7)
+    b = ops.sample_multinomial(W, seed=1234, offset=7)
+    c = ops.sample_multinomial(W, seed=4321, offset=7)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert int(a.min()) >= 0 and int(a.max()) < V
+    p = torch.softmax(row.double(), 0).numpy()
+    counts = np.bincount(a.cpu().numpy(), minlength=V).astype(np.float64)
+    chi2 = float(((counts - n * p) ** 2 / (n * p)).sum())
+    assert chi2 < V + 6.0 * np.sqrt(2.0 * V), (chi2, V)            # mean V-1, sd sqrt(2(V-1)): six sigma
+    # rows with one dominant logit pick it; a strided destination and per-row probabilities
+    Wd = torch.full((64, V), -30.0)
+    idx = torch.arange(64) % V
+    Wd[torch.arange(64), idx] = 30.0
+    assert torch.equal(ops.sample_multinomial(Wd.to(DEV), seed=5).cpu(), idx)
