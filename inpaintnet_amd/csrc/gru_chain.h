@@ -53,5 +53,6 @@ struct GruChainBwd {
 };
 
 bool gru_chain_ok(int H, int B, int T, int nprob);
+bool gru_chain_bwd_ok(int H, int B, int T, int nprob);      // as above, with two row tiles per workgroup when needed
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s);
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s);

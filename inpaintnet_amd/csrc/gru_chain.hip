@@ -16,6 +16,15 @@
 #include "ksplit.h"
 #include "prof.h"
 #include "gru_chain.h"
+// Contraction schedule of the forward / backward kernels (chain.h): the backward kernels (K = 3H, 24 k-steps per wave)
+// stream their A fragments with dealt, pinned loads -- 274 -> 246 us per encoder launch, 4.354 -> 4.340 ms per training
+// step; the forward kernels (8 k-steps per wave) measure the same either way and keep the chunked double buffer.
+#ifndef INET_GRU_CONTRACT
+#define INET_GRU_CONTRACT contract
+#endif
+#ifndef INET_GRU_CONTRACT_B
+#define INET_GRU_CONTRACT_B contract_stream
+#endif
 
 using namespace ksplit;
 
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(GruChainFwd A) {
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int a = 0; a < 3; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        chain::contract<MS, 3, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
+        chain::INET_GRU_CONTRACT<MS, 3, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
         float v[MS][3];
         reduce_waves<MS, 3>(acc, red, t, v);
         // gates first, then the hand-off (what the other members wait for), then the stores nobody in the launch reads
@@ -218,7 +227,14 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chain::contract<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S3, w * SQ, lane);
+            if constexpr (MS == 8) {               // two 64-row tiles against the same register-resident W slice
+                chain::INET_GRU_CONTRACT_B<4, 1, SQ>(reinterpret_cast<f32x4(&)[4][4]>(acc[0]), Wr, rs, ((step + 1) & 1) * slot_bytes, rb0,
+                                          rb_last, S3, w * SQ, lane);
+                chain::INET_GRU_CONTRACT_B<4, 1, SQ>(reinterpret_cast<f32x4(&)[4][4]>(acc[4]), Wr, rs, ((step + 1) & 1) * slot_bytes, rb0 + 4,
+                                          rb_last, S3, w * SQ, lane);
+            } else {
+                chain::INET_GRU_CONTRACT_B<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S3, w * SQ, lane);
+            }
             reduce_waves<MS, 1>(acc, red, t, v);
         }
         if (tail) {
@@ -301,6 +317,21 @@ bool gru_chain_ok(int H, int B, int T, int nprob) {
     return nprob * tiles * (H / 16) <= 256;        // every workgroup must be resident at once (one per CU)
 }
 
+// Backward chains may give a workgroup two 64-row tiles (MS = 8) when one per workgroup would need more than 256
+// workgroups: the decoder's tick layers run their 4 beats as 4 problems x 256 rows.
+int rows_ms_bwd(int H, int B, int nprob) {
+    const int ms = rows_ms(B);
+    static const bool wide = [] { const char* e = std::getenv("INET_CHAIN_WIDE"); return !(e && e[0] == '0'); }();
+    if (wide && ms == 4 && B >= 128 && nprob * ((B + 63) / 64) * (H / 16) > 256) return 8;
+    return ms;
+}
+bool gru_chain_bwd_ok(int H, int B, int T, int nprob) {
+    if ((double)T * B * 6.0 * H >= 2.0e9) return false;
+    if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
+    const int ms = rows_ms_bwd(H, B, nprob), tiles = (B + 16 * ms - 1) / (16 * ms);
+    return nprob * tiles * (H / 16) <= 256;
+}
+
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     if (!gru_chain_ok(a.H, a.B, a.T, a.nprob)) return -1;
     const int ms = rows_ms(a.B);
@@ -326,8 +357,8 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
 }
 
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
-    if (!gru_chain_ok(a.H, a.B, a.T, a.nprob)) return -1;
-    const int ms = rows_ms(a.B);
+    if (!gru_chain_bwd_ok(a.H, a.B, a.T, a.nprob)) return -1;
+    const int ms = rows_ms_bwd(a.H, a.B, a.nprob);
     a.tiles_per_prob = (a.B + 16 * ms - 1) / (16 * ms);
     a.members = a.H / 16;
     const int groups = a.nprob * a.tiles_per_prob;
@@ -343,8 +374,8 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)));
     const dim3 grid(chain::blocks_for(groups, a.members));
 #define INET_CB(M, Q) hipLaunchKernelGGL((gru_chain_bwd_kernel<M, Q>), grid, dim3(256), 0, s, a)
-    if (a.H == 512) { if (ms == 1) INET_CB(1, 24); else if (ms == 2) INET_CB(2, 24); else INET_CB(4, 24); }
-    else { if (ms == 1) INET_CB(1, 12); else if (ms == 2) INET_CB(2, 12); else INET_CB(4, 12); }
+    if (a.H == 512) { if (ms == 1) INET_CB(1, 24); else if (ms == 2) INET_CB(2, 24); else if (ms == 4) INET_CB(4, 24); else INET_CB(8, 24); }
+    else { if (ms == 1) INET_CB(1, 12); else if (ms == 2) INET_CB(2, 12); else if (ms == 4) INET_CB(4, 12); else INET_CB(8, 12); }
 #undef INET_CB
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

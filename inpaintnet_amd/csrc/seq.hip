@@ -89,7 +89,7 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
     {
         bool any0 = false, all0 = true, wok = true;
         for (int i = 0; i < nd; ++i) { if (d[i].dh0) any0 = true; else all0 = false; if (!d[i].W_hh) wok = false; }
-        if (pk && wok && d[0].sync && step_hi == T - 1 && step_lo == 0 && (!any0 || all0) && gru_chain_ok(H, B, T, nd)) {
+        if (pk && wok && d[0].sync && step_hi == T - 1 && step_lo == 0 && (!any0 || all0) && gru_chain_bwd_ok(H, B, T, nd)) {
             GruChainBwd a{};
             a.H = H; a.B = B; a.T = T; a.nprob = nd;
             for (int i = 0; i < nd; ++i) {

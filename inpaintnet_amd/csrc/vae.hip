@@ -469,6 +469,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         if (g) { D.db_ih = g + L.tick[1].b_ih; D.db_hh = g + L.tick[1].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H + H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
         D.Wpk_hhT = w.wpkT[3]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
+        D.W_hh = p + L.tick[1].w_hh; D.sync = w.sync;        // chain kernel: the 4 beats as 4 problems, 2 row tiles per workgroup
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
@@ -493,6 +494,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         if (g) { D.db_ih = g + L.tick[0].b_ih; D.db_hh = g + L.tick[0].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
         D.Wpk_hhT = w.wpkT[2]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
+        D.W_hh = p + L.tick[0].w_hh; D.sync = w.sync;
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* wih0 = p + L.tick[0].w_ih;

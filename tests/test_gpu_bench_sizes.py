@@ -76,7 +76,7 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
             "gru_chain_bwd ms4 np2 T24 B256 H512"]          # encoder BPTT
     for wl in want:
         assert wl in labels, (wl, sorted(set(l for l in labels if l.startswith("gru"))))
-    assert any(l.startswith("gru_bwd ms4 nc2 pk1 np4 B256") or l.startswith("gru_chain_bwd ms4 np") for l in labels)
+    assert "gru_chain_bwd ms8 np4 T6 B256 H512" in labels      # decoder tick layers: 4 beats x 256 rows, two row tiles per workgroup
     # the big products run on the LDS-free direct kernels (forward NT 192x192, data-gradient NN 192x128, weight-gradient
     # TN 192x128 split over the XCDs); the 192-row LDS-tiled instantiations are covered by the forced-tile test below
     big = sorted(set(l for l in labels if l.startswith("M")))
