@@ -44,7 +44,8 @@ struct GruChainBwdProb {
     float* dh0; long ld_dh0; int dh0_accumulate;  // dLoss/d initial hidden, or null
     float* gx;                                    // exchange: [2][ceil16(B)][3H] fragment-major
     int reverse;
-};
+    float* dgi_sum;                               // optional [B,3H]: sum over the T steps of the input-side gate gradients
+};                                                // (the decoder's beat-constant input half: one value per beat)
 struct GruChainBwd {
     int H, B, T, nprob, tiles_per_prob, members, prio;
     GruChainBwdProb p[4];

@@ -182,10 +182,13 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     }
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.gx);
     unsigned* counter = A.counters + group * kChainCounterStride;
-    float dhz[MS], bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float dhz[MS], bs[4] = {0.f, 0.f, 0.f, 0.f}, gs[MS][3];
     int brow[MS];
 #pragma unroll
-    for (int p = 0; p < MS; ++p) { dhz[p] = 0.f; brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1); }
+    for (int p = 0; p < MS; ++p) {
+        dhz[p] = 0.f; brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1);
+        gs[p][0] = gs[p][1] = gs[p][2] = 0.f;
+    }
     // operand sources in registers, absent ones aimed at a zero word (see the forward kernel)
     const float* const zf = reinterpret_cast<const float*>(A.counters + kChainZeroWord);
     const bool has_dout = P.dout != nullptr, has_dhn = P.dhn != nullptr;
@@ -278,6 +281,17 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
                 float* gh = dghp + (tt * B + b) * 3 * H;
                 gh[jc] = e_r[p]; gh[H + jc] = e_z[p]; gh[2 * H + jc] = e_nr[p];
                 bs[0] += e_r[p]; bs[1] += e_z[p]; bs[2] += e_n[p]; bs[3] += e_nr[p];
+                gs[p][0] += e_r[p]; gs[p][1] += e_z[p]; gs[p][2] += e_n[p];
+            }
+        }
+    }
+    if (P.dgi_sum) {
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = row0 + ((t + 256 * p) >> 4);
+            if (b < B) {
+                float* o = P.dgi_sum + (long)b * 3 * H + jc;
+                o[0] = gs[p][0]; o[H] = gs[p][1]; o[2 * H] = gs[p][2];
             }
         }
     }

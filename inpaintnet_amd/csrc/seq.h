@@ -58,6 +58,8 @@ struct DirBwd {
     const float* Wpk_hhT; float* dghpk;
     const float* W_hh;                                        // [3H,H] row-major (chain kernel reads it transposed once)
     unsigned* sync;                                           // as in DirFwd
+    float* dgi_sum;                                           // optional [B,3H] sum_t dgi(t); `*dgi_sum_done` is set to 1 when the
+    int* dgi_sum_done;                                        // layer's launch produced it (chain kernel), else left alone
 };
 
 // floats of a fragment-major [rows,K] operand (rows padded to 16)

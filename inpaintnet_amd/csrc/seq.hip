@@ -104,9 +104,14 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
                 P.db_ih = D.db_ih; P.db_hh = D.db_hh;
                 P.dh0 = D.dh0; P.ld_dh0 = D.dh0_ld; P.dh0_accumulate = D.dh0_acc;
                 P.gx = D.dghpk; P.reverse = D.reverse;
+                P.dgi_sum = D.dgi_sum;
             }
             a.counters = d[0].sync;
-            return launch_gru_chain_bwd(a, s);
+            const int rc = launch_gru_chain_bwd(a, s);
+            if (rc == 0)
+                for (int i = 0; i < nd; ++i)
+                    if (d[i].dgi_sum && d[i].dgi_sum_done) *d[i].dgi_sum_done = 1;
+            return rc;
         }
     }
     for (int step = step_hi; step >= step_lo; --step) {

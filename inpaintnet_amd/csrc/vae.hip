@@ -482,6 +482,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
                           mask_tick ? EPI_MUL_AUX : EPI_NONE, mask_tick, H, ACC_STORE, s));
 
     // ---- tick RNN layer 0 ----
+    int dcgi_done = 0;
     for (int i = 0; i < nb; ++i) {
         DirBwd& D = d[i];
         D = DirBwd{};
@@ -495,6 +496,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
         D.Wpk_hhT = w.wpkT[2]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
         D.W_hh = p + L.tick[0].w_hh; D.sync = w.sync;
+        D.dgi_sum = w.dcgi + (long)i * 3 * BH; D.dgi_sum_done = &dcgi_done;     // beat-constant input half, see below
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* wih0 = p + L.tick[0].w_ih;
@@ -503,8 +505,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         hipStream_t ss = side_fork(s);
         INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, ss));
     }
-    // beat-constant input half:  dcgi[i] = sum_j dgi0[6i+j]
-    INET_TRY(pw_group_sum(w.dgi0t, nb, G, 3 * BH, w.dcgi, s));
+    // beat-constant input half:  dcgi[i] = sum_j dgi0[6i+j]  (summed in registers by the chain kernel when it ran)
+    if (!dcgi_done) INET_TRY(pw_group_sum(w.dgi0t, nb, G, 3 * BH, w.dcgi, s));
     INET_TRY(linear_dgrad(w.dcgi, 3L * H, wih0 + E, ldw0, w.dc_all, H, nb * B, 3 * H, H, EPI_MUL_SELU_GRAD, w.c_all, H,
                           ACC_STORE, s));
     if (g) {
