@@ -592,6 +592,11 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     final_loss = float(loss.detach())
+    from inpaintnet_amd import ops as _ops
+    chain_timeouts = _ops.chain_status(reset=True)
+    if chain_timeouts > 0:
+        print(f"[bench] {chain_timeouts} chain-kernel workgroups timed out in the timed region: result invalid", file=sys.stderr)
+        sys.exit(3)
 
     per_rank = None
     ar_ms = None
@@ -657,6 +662,7 @@ def main():
             "data": "synthetic",
             "config": dict(wl.describe(world), final_loss=round(final_loss, 5)),
             "roofline": roof,
+            "chain_timeouts": chain_timeouts,                      # inet_chain_status after the timed region: 0 = healthy
         }
         if world > 1:
             out["per_rank_units_per_s"] = per_rank

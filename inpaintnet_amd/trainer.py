@@ -146,6 +146,10 @@ class Trainer(ABC):
             ops.side_defer(False)
         dp.allreduce_sum_(sums)                      # every rank reports (and early-stops on) the global means
         out = sums.tolist()                          # the one device->host sync of the epoch
+        timeouts = ops.chain_status(reset=True)      # persistent kernels: bounded spins report here instead of hanging
+        if timeouts > 0:                             # < 0: no chain kernel has run in this process
+            raise RuntimeError(f"{timeouts} chain-kernel workgroups gave up waiting for their group during this epoch "
+                               "(inet_chain_status); its results are not valid")
         n = max(out[2], 1.0)
         self.last_epoch_seconds = time.time() - t0
         return out[0] / n, out[1] / n
