@@ -4,10 +4,16 @@
 #include "chain.h"
 
 namespace {
-hipStream_t g_side = nullptr;
+// Leaf work (weight-gradient products, bias sums) goes to low-priority side streams, one fork "session" per call of
+// side_fork().  Sessions are independent of each other (distinct gradient tensors, scratch private to a session), so
+// they rotate over kMaxSide streams: the tail of one 256-workgroup product (skewed finishers, atomics) overlaps the
+// start of the next (4.345 -> 4.231 ms per training step with two streams instead of one; INET_SIDE_STREAMS=n).
+constexpr int kMaxSide = 3;           // measured: 1 -> 4.35, 2 -> 4.24, 3 -> 4.29 ms per step; 4 -> 7.57 (the queues get multiplexed)
+hipStream_t g_sides[kMaxSide] = {nullptr, nullptr, nullptr};
+bool g_dirty[kMaxSide] = {false, false, false};          // something was queued on stream i since the last join
+int g_nside = 0, g_turn = 0;
 bool g_init = false;
 int g_enabled = -1;
-bool g_dirty = false;                 // something was queued on the side stream since the last join
 bool g_defer = false;                 // side_join() is a no-op; the caller joins explicitly (side_join_now)
 std::vector<hipEvent_t> g_pool;
 size_t g_next = 0;
@@ -32,7 +38,11 @@ int side_enabled() {
     return g_enabled;
 }
 void side_set_enabled(int on) { g_enabled = on ? 1 : 0; }
-bool side_is(hipStream_t s) { return g_side != nullptr && s == g_side; }
+bool side_is(hipStream_t s) {
+    for (int i = 0; i < g_nside; ++i)
+        if (s == g_sides[i]) return true;
+    return false;
+}
 
 hipStream_t side_fork(hipStream_t main_stream) {
     if (!side_enabled()) return main_stream;
@@ -40,26 +50,33 @@ hipStream_t side_fork(hipStream_t main_stream) {
         g_init = true;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) g_side = nullptr;
+        const char* v = std::getenv("INET_SIDE_STREAMS");
+        int want = v ? std::atoi(v) : 2;
+        want = want < 1 ? 1 : (want > kMaxSide ? kMaxSide : want);
+        for (int i = 0; i < want; ++i) {
+            if (hipStreamCreateWithPriority(&g_sides[g_nside], hipStreamNonBlocking, lo) != hipSuccess) break;
+            ++g_nside;
+        }
     }
-    if (!g_side) return main_stream;
+    if (g_nside == 0) return main_stream;
+    const int i = g_turn++ % g_nside;
     hipEvent_t e = next_event();
-    if (!e || hipEventRecord(e, main_stream) != hipSuccess || hipStreamWaitEvent(g_side, e, 0) != hipSuccess)
+    if (!e || hipEventRecord(e, main_stream) != hipSuccess || hipStreamWaitEvent(g_sides[i], e, 0) != hipSuccess)
         return main_stream;
-    g_dirty = true;
-    return g_side;
+    g_dirty[i] = true;
+    return g_sides[i];
 }
 
 void side_set_defer(int on) { g_defer = on != 0; }
 int side_join(hipStream_t main_stream) { return g_defer ? 0 : side_join_now(main_stream); }
 
 int side_join_now(hipStream_t main_stream) {
-    if (!g_dirty || !g_side) return 0;
-    g_dirty = false;
-    hipEvent_t e = next_event();
-    if (!e) return -2;
-    if (hipEventRecord(e, g_side) != hipSuccess) return -2;
-    if (hipStreamWaitEvent(main_stream, e, 0) != hipSuccess) return -2;
+    for (int i = 0; i < g_nside; ++i) {
+        if (!g_dirty[i]) continue;
+        g_dirty[i] = false;
+        hipEvent_t e = next_event();
+        if (!e || hipEventRecord(e, g_sides[i]) != hipSuccess || hipStreamWaitEvent(main_stream, e, 0) != hipSuccess) return -2;
+    }
     return 0;
 }
 
