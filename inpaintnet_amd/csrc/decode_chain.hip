@@ -257,8 +257,12 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             }
         }
         // ================= output projection + partial argmax (members that own a logits tile) =================
+        // EVERY member waits for all of h1 before its third arrival, tile or not: the counter is a plain count, and a
+        // member that skipped this wait could arrive a third time while a slow one has not arrived twice -- the count
+        // then reaches 2 x members too early and a logits tile contracts a k-slice that is not published yet (seen as
+        // one wrong 16 x 16 logits tile at tick 0 in ~5 % of the B = 256 calls before this wait was made unconditional).
+        if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;               // h1 of this tick
         if (has_tile) {
-            if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;           // h1 of this tick
             f32x4 la[1][4];
             la[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int s1[1] = {0};

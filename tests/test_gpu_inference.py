@@ -248,3 +248,38 @@ def test_decoder_multinomial_sampling():
     keep = p * 4096 > 5
     chi2 = float((((counts - 4096 * p) ** 2) / (4096 * p))[keep].sum())
     assert chi2 < keep.sum() + 6.0 * np.sqrt(2.0 * keep.sum()), chi2
+
+
+def test_fused_decode_matches_per_tick_path_repeatedly():
+    """Stress for the fused decode kernel's hand-off protocol: the same free-running decode (inference and training form:
+    backward saves, dropout masks) through the fused kernel and through the per-tick launches, many times, over batch sizes
+    that give 1..8 groups, with the allocator's pool dirtied in between.  A premature release in the third hand-off of
+    a tick (members without a logits tile arriving a third time before slow members had arrived twice) showed up as one
+    wrong 16 x 16 logits tile at tick 0 in ~5 % of the B = 256 calls; the full-size fixtures alone hit it once in ~7
+    suite runs."""
+    from tests.test_gpu_kernels import pack
+    c = G.CFGS["full"]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params("full"))
+    g = torch.Generator().manual_seed(17)
+    rng = np.random.RandomState(3)
+    try:
+        for it in range(240):
+            B = [256, 5, 256, 96, 192, 32][it % 6]
+            junk = torch.empty(int(rng.randint(1, 48)) << 20, device="cuda").uniform_(-100, 100)
+            del junk
+            z = torch.randn(B, c["Z"], generator=g).cuda()
+            train = it % 3 != 0
+            mb = ops.dropout_mask((4, B, c["H"]), 0.5, it, 0, "cuda") if it % 2 and train else None
+            mt = ops.dropout_mask((24, B, c["H"]), 0.5, it, 10 ** 6, "cuda") if it % 2 and train else None
+            outs = []
+            for chain in (1, 0):
+                ops.set_option(4, chain)
+                w, s, _ = ops.decoder_fwd(cfg, z, None, False, params, mb, mt, save=train)
+                outs.append((w, s))
+            err = float((outs[0][0] - outs[1][0]).abs().max() / outs[1][0].abs().max())
+            assert err < 2e-5, (it, B, train, err)
+    finally:
+        ops.set_option(4, 1)
+    assert ops.chain_status() == 0

@@ -331,11 +331,25 @@ def test_vae_train_steps_golden(name, mode):
         assert abs(ce - ref[step][1]) <= 1e-4 * abs(ref[step][1])
         assert abs(kl - ref[step][2]) <= 1e-4 * abs(ref[step][2])
         if step == 0:
+            if relmax(w, fx[f"step_{mode}_weights"]) >= 1e-4:        # diagnostics for an intermittent failure
+                d = (w.cpu().double() - torch.from_numpy(fx[f"step_{mode}_weights"]).double()).abs()
+                per_tick = d.amax(dim=(0, 2)).numpy()
+                per_row = d.amax(dim=(1, 2)).numpy()
+                print("DIAG chain_status", ops.chain_status(), "per_tick", np.round(per_tick, 4), "per_row", np.round(per_row, 4),
+                      "z err", relmax(z, fx[f"step_{mode}_z"]))
             assert relmax(w, fx[f"step_{mode}_weights"]) < 1e-4
             assert relmax(z, fx[f"step_{mode}_z"]) < 1e-4
             ok = G.unique_rows(fx[f"step_{mode}_margin"])
             assert np.array_equal(s.cpu().numpy()[:, 0][ok], fx[f"step_{mode}_samples"][:, 0][ok])
-            assert abs(acc - ref[0][3]) < 1e-6
+            # accuracy: the kernel's count must equal the first-argmax count of its own logits exactly; against the
+            # reference it may differ by the rows whose top-2 margin is inside fp32 round-off (split-K sums upstream
+            # are order-dependent in the last bits, and a free-running tick feeds its argmax back)
+            wh = w.cpu().reshape(-1, w.shape[-1])
+            own = float((wh.argmax(1) == tok.cpu().reshape(-1)).double().mean())
+            assert abs(acc - own) < 1e-6, (acc, own)
+            mg = fx[f"step_{mode}_margin"]
+            near = float(((mg > 0) & (mg <= 1e-4)).mean())          # exact ties (all-zero rows) resolve identically
+            assert abs(acc - ref[0][3]) <= near + 1e-6, (acc, ref[0][3], near)
             bad = []
             for pname, off, shape in table:
                 gg = unpack(table, grads, pname).cpu().numpy()

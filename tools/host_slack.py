@@ -35,5 +35,18 @@ def run(where, delay, n=150):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+# a delay in front of one backward entry point: is the host ahead of the GPU INSIDE the backward pass?
+from inpaintnet_amd import ops as _ops
+for name in ("encoder_bwd", "decoder_bwd", "latent_bwd"):
+    orig = getattr(_ops, name)
+    res = []
+    for d in (0, 100, 300):
+        def wrapped(*a, _o=orig, _d=d, **k):
+            spin(_d)
+            return _o(*a, **k)
+        setattr(_ops, name, wrapped)
+        res.append(f"D={d}us: {run('none', 0):.3f} ms")
+    setattr(_ops, name, orig)
+    print("before", name, " ".join(res), flush=True)
 for where in ("mid", "start", "end"):
     print(where, " ".join(f"D={d}us: {run(where, d):.3f} ms" for d in (0, 100, 300, 1000)), flush=True)
