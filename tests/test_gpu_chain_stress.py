@@ -1,0 +1,62 @@
+"""Repeated-call stress for the persistent (chain) kernels: the same encoder forward + backward and decoder backward
+through the chain kernels and through the per-step launches (inet_set_option(4, 0)), many times, with the allocator's
+pool dirtied in between.  Single-shot parity tests cannot see a hand-off that is released early once in a hundred calls
+(the fused decode kernel had one: tests/test_gpu_inference.py::test_fused_decode_matches_per_tick_path_repeatedly)."""
+import numpy as np
+import pytest
+import torch
+
+from inpaintnet_amd import ops
+from tests import golden_util as G
+from tests.test_gpu_kernels import pack
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_encoder_and_decoder_backward_chains_repeatedly():
+    c = G.CFGS["full"]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params("full"))
+    g = torch.Generator().manual_seed(5)
+    rng = np.random.RandomState(11)
+    T, H, Z, V = 24, c["H"], c["Z"], c["V"]
+    try:
+        for it in range(200):
+            B = [256, 37, 256, 128, 64][it % 5]
+            junk = torch.empty(int(rng.randint(1, 48)) << 20, device="cuda").uniform_(-100, 100)
+            del junk
+            tok = torch.randint(0, V, (B, T), generator=g).cuda()
+            m_enc = ops.dropout_mask((T, B, 2 * H), 0.5, it, 0, "cuda")
+            m_beat = ops.dropout_mask((4, B, H), 0.5, it, 10 ** 7, "cuda")
+            m_tick = ops.dropout_mask((T, B, H), 0.5, it, 2 * 10 ** 7, "cuda")
+            dmu = torch.randn(B, Z, generator=g).cuda() * 1e-2
+            dls = torch.randn(B, Z, generator=g).cuda() * 1e-2
+            z = torch.randn(B, Z, generator=g).cuda()
+            dW = torch.randn(B, T, V, generator=g).cuda() * 1e-3
+            res = []
+            for chain in (1, 0):
+                ops.set_option(4, chain)
+                grads = torch.zeros_like(params)
+                mu, ls, ews = ops.encoder_fwd(cfg, tok, params, mask=m_enc, save=True)
+                ops.encoder_bwd(cfg, tok, params, grads, m_enc, dmu, dls, ews)
+                # teacher-forced decode: identical tokens on both paths, so the backward inputs are identical too
+                w, s, dws = ops.decoder_fwd(cfg, z, tok, True, params, m_beat, m_tick, save=True)
+                dz = ops.decoder_bwd(cfg, dW, w, s, params, grads, m_beat, m_tick, dws)
+                torch.cuda.synchronize()
+                res.append((mu, ls, w, dz, grads))
+            a, b = res
+            assert _rel(a[0], b[0]) < 2e-5 and _rel(a[1], b[1]) < 2e-5, (it, B, "encoder forward")
+            assert _rel(a[2], b[2]) < 2e-5, (it, B, "decoder forward")
+            assert _rel(a[3], b[3]) < 1e-4, (it, B, "dz", _rel(a[3], b[3]))
+            for name, off, shape in table:
+                n = int(np.prod(shape))
+                ga, gb = a[4][off:off + n], b[4][off:off + n]
+                assert _rel(ga, gb) < 2e-4, (it, B, name, _rel(ga, gb))
+    finally:
+        ops.set_option(4, 1)
+    assert ops.chain_status() == 0
