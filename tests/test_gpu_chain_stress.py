@@ -25,6 +25,7 @@ def test_encoder_and_decoder_backward_chains_repeatedly():
     g = torch.Generator().manual_seed(5)
     rng = np.random.RandomState(11)
     T, H, Z, V = 24, c["H"], c["Z"], c["V"]
+    skipped = 0
     try:
         for it in range(200):
             B = [256, 37, 256, 128, 64][it % 5]
@@ -48,10 +49,17 @@ def test_encoder_and_decoder_backward_chains_repeatedly():
                 w, s, dws = ops.decoder_fwd(cfg, z, tok, True, params, m_beat, m_tick, save=True)
                 dz = ops.decoder_bwd(cfg, dW, w, s, params, grads, m_beat, m_tick, dws)
                 torch.cuda.synchronize()
-                res.append((mu, ls, w, dz, grads))
+                # branch taken by every SELU / ReLU element: the derivative jumps at 0, so two correct paths whose
+                # pre-activations differ in the last bit next to 0 disagree by O(1) in that element's gradient
+                kinks = [ops.ws_field(cfg, ews, B, 0, n_) > 0 for n_ in ("a_mu", "a_ls")]
+                kinks += [ops.ws_field(cfg, dws, B, 1, n_) > 0 for n_ in ("hb0", "ht0", "c_all")] + [w > 0]
+                res.append((mu, ls, w, dz, grads, kinks))
             a, b = res
             assert _rel(a[0], b[0]) < 2e-5 and _rel(a[1], b[1]) < 2e-5, (it, B, "encoder forward")
             assert _rel(a[2], b[2]) < 2e-5, (it, B, "decoder forward")
+            if any(not torch.equal(x, y) for x, y in zip(a[5], b[5])):
+                skipped += 1                       # a branch flipped between the two paths: gradients legitimately differ
+                continue
             assert _rel(a[3], b[3]) < 1e-4, (it, B, "dz", _rel(a[3], b[3]))
             for name, off, shape in table:
                 n = int(np.prod(shape))
@@ -60,3 +68,4 @@ def test_encoder_and_decoder_backward_chains_repeatedly():
     finally:
         ops.set_option(4, 1)
     assert ops.chain_status() == 0
+    assert skipped <= 30, skipped
