@@ -125,6 +125,7 @@ class Trainer(ABC):
         dev = self.model.flat.device
         sums = torch.zeros(3, dtype=torch.float32, device=dev)        # loss sum, accuracy sum, batches
         t0 = time.time()
+        batches = 0
         prev_overlap, self.overlap_backward = self.overlap_backward, bool(train)
         try:
             if not isinstance(data_loader, DeviceFeed):
@@ -141,9 +142,11 @@ class Trainer(ABC):
                     with torch.no_grad():
                         loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=False)
                 self._accumulate_stats(sums, loss, accuracy)
+                batches += 1
         finally:
             self.overlap_backward = prev_overlap
             ops.side_defer(False)
+        sums[2] += float(batches)                    # counted on the host, added once
         dp.allreduce_sum_(sums)                      # every rank reports (and early-stops on) the global means
         out = sums.tolist()                          # the one device->host sync of the epoch
         timeouts = ops.chain_status(reset=True)      # persistent kernels: bounded spins report here instead of hanging
@@ -156,10 +159,15 @@ class Trainer(ABC):
 
     @staticmethod
     def _accumulate_stats(sums, loss, accuracy):
-        sums[0] += loss.detach().mean()
-        if accuracy is not None:
-            sums[1] += accuracy.detach()
-        sums[2] += 1.0
+        """sums[:2] += (loss, accuracy) on the device: two launches (stack + add) per batch."""
+        loss = loss.detach()
+        if loss.dim() > 0:
+            loss = loss.mean()
+        loss = loss.reshape(()).to(sums.dtype)
+        if accuracy is None:
+            sums[0] += loss
+        else:
+            sums[:2] += torch.stack((loss, accuracy.detach().reshape(()).to(sums.dtype)))
 
     def zero_grad(self):
         """utils/trainer.py:165-170.  With `overlap_backward` set (the epoch loop and bench.py set it) the step that
