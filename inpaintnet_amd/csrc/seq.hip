@@ -36,6 +36,41 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
         a.counters = d[0].sync;
         return launch_gru_chain_fwd(a, s);
     }
+    // More rows than one resident launch can take (the frozen encoder of LatentRNN runs 2048 measures at once): the rows
+    // are independent, so the chain kernel runs over chunks of 256 rows, one launch after the other, each on a chunk-sized
+    // exchange ring inside the hpk buffer.  Only without backward saves (their time stride is the full batch).
+    constexpr int CH = 256;
+    bool chunked = pk && d[0].sync && B >= 2 * CH && B % CH == 0 && gru_chain_ok(H, CH, T, nd);
+    for (int i = 0; i < nd; ++i) chunked = chunked && !d[i].sv;
+    if (chunked) {
+        const long pkc = (long)pk_floats(CH, H);
+        for (int c = 0; c < B / CH; ++c) {
+            const long r0 = (long)c * CH;
+            GruChainFwd a{};
+            a.H = H; a.B = CH; a.T = T; a.nprob = nd;
+            for (int i = 0; i < nd; ++i) {
+                const DirFwd& D = d[i];
+                GruChainFwdProb& P = a.p[i];
+                P.W_hh = D.W_hh; P.b_hh = D.b_hh;
+                P.h0 = D.h0 + r0 * D.h0_ld; P.ld_h0 = D.h0_ld;
+                P.gi_dense = D.gi ? D.gi + r0 * D.gi_ld : nullptr; P.ld_gi = D.gi_ld; P.ts_gi = D.gi_ts;
+                P.gi_table = D.table; P.ld_table = D.table_ld;
+                P.idx = D.idx ? D.idx + r0 * D.idx_bs : nullptr; P.idx_bs = D.idx_bs; P.idx_ts = D.idx_ts;
+                P.gi_vec = D.gvec;
+                P.out = D.out + r0 * D.out_ld; P.ld_out = D.out_ld; P.ts_out = D.out_ts;
+                P.outm = D.outm ? D.outm + r0 * D.outm_ld : nullptr; P.ld_outm = D.outm_ld; P.ts_outm = D.outm_ts;
+                P.mask = D.mask ? D.mask + r0 * D.mask_ld : nullptr; P.ld_mask = D.mask_ld; P.ts_mask = D.mask_ts;
+                P.hlast = D.hlast ? D.hlast + r0 * D.hlast_ld : nullptr; P.ld_hlast = D.hlast_ld;
+                // slot 1 of the chunk's ring = the chunk's rows of the full-batch h0 pack made above (row blocks are the
+                // outermost index of the fragment-major layout); slot 0 = the 256 rows in front of it: the previous chunk's
+                // slice, already consumed (chunk 0: the unused slot 0 of the full ring)
+                P.hx = D.hpk + pkh + (long)(c - 1) * pkc; P.reverse = D.reverse;
+            }
+            a.counters = d[0].sync;
+            INET_TRY(launch_gru_chain_fwd(a, s));
+        }
+        return 0;
+    }
     for (int step = 0; step < T; ++step) {
         GruFwdBatch bt{};
         bt.H = H; bt.nprob = nd;

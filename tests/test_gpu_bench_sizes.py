@@ -192,7 +192,8 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
     ops.prof_dump(tmp_path / "launches.csv")
     ops.prof_enable(False)
     labels = _labels(tmp_path / "launches.csv")
-    assert "gru_fwd x0 ms4 pk1 np2 B2048 H512" in labels                 # frozen encoder over all 16 measures at once
+    # frozen encoder over all 128 x 16 measures at once: the chain kernel over eight 256-row chunks per layer
+    assert sum(l == "gru_chain_fwd ms4 np2 T24 B256 H512" for l in labels) == 16, sorted(set(l for l in labels if l.startswith("gru")))
     assert "gru_chain_fwd ms4 np2 T6 B128 H512" in labels and "gru_chain_bwd ms4 np2 T6 B128 H512" in labels   # contexts
     assert any(l.startswith("gru_fwd x0") and l.endswith("B128 H1024") for l in labels)      # generator
     assert any(l.startswith("gru_bwd") and l.endswith("B128 H1024") for l in labels)

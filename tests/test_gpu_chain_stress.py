@@ -69,3 +69,33 @@ def test_encoder_and_decoder_backward_chains_repeatedly():
         ops.set_option(4, 1)
     assert ops.chain_status() == 0
     assert skipped <= 30, skipped
+
+
+def test_chunked_chain_forward_for_large_batches():
+    """More rows than one resident chain launch takes (the frozen encoder of LatentRNN: 2048 measures): the forward runs
+    the chain kernel over 256-row chunks; compared with the per-step launches."""
+    c = G.CFGS["full"]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params("full"))
+    g = torch.Generator().manual_seed(9)
+    try:
+        for B in (2048, 512, 768):
+            tok = torch.randint(0, c["V"], (B, 24), generator=g).cuda()
+            res = []
+            for chain in (1, 0):
+                ops.set_option(4, chain)
+                ops.prof_enable(True)
+                mu, ls, _ = ops.encoder_fwd(cfg, tok, params, mask=None, save=False)
+                torch.cuda.synchronize()
+                ops.prof_dump("/tmp/_inet_chunk.csv")
+                ops.prof_enable(False)
+                labels = [l.split(",")[1] for l in open("/tmp/_inet_chunk.csv").read().strip().splitlines()[1:]]
+                if chain:
+                    assert sum(l.startswith("gru_chain_fwd ms4 np2 T24 B256") for l in labels) == 2 * (B // 256), labels[:6]
+                res.append((mu, ls))
+            assert _rel(res[0][0], res[1][0]) < 2e-5 and _rel(res[0][1], res[1][1]) < 2e-5, B
+    finally:
+        ops.set_option(4, 1)
+        ops.prof_enable(False)
+    assert ops.chain_status() == 0
