@@ -642,8 +642,7 @@ const DirectCfg kDirect[] = {{3, 2}, {2, 2}, {3, 3}};
 inline long tiles_of(const DirectCfg& c, const GemmArgs& g) { return (long)(g.M / (64 * c.ta)) * (g.N / (64 * c.tb)); }
 
 // Direct (LDS-free) k-major x k-major product: returns 1 when the shape does not qualify, else the launch status.
-// `budget_us`: estimated cost of the best LDS-tiled configuration (the direct kernel is taken when it beats it).
-int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, double budget_us, int force_split) {
+int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, int force_split) {
     GemmArgs g = gin;
     const bool nonlinear = g.epi != EPI_NONE;
     if (!g.a_kmajor || !g.b_kmajor || (g.M & 63) || (g.N & 63) || g.K < 64) return 1;
@@ -667,7 +666,6 @@ int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, double budget_us, int
         }
     }
     if (bi < 0 || (g_direct != 2 && (g.K / bs < 768 || (long)tiles_of(kDirect[bi], g) * bs < 192))) return 1;
-    (void)budget_us;
     const DirectCfg& c = kDirect[bi];
     int kps = (g.K + bs - 1) / bs;
     kps = (kps + 1) / 2 * 2;
@@ -719,7 +717,7 @@ void launch_kc(const GemmArgs& g, dim3 grid, hipStream_t s, int tiles_n) {
 
 // Direct kernel for a k-contiguous A (forward and data-gradient products): no split-K, so it needs a tile
 // configuration whose grid fills the chip by itself.  Returns 1 when the shape does not qualify.
-int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s, double budget_us) {
+int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s) {
     if (g.a_kmajor || (g.K & 63) || g.acc == ACC_ATOMIC) return 1;
     if ((double)g.M * g.lda * 4 >= 2.0e9 || (double)(g.b_kmajor ? g.K : g.N) * g.ldb * 4 >= 2.0e9) return 1;
     double best = 1e300;
@@ -734,7 +732,6 @@ int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s, double budget_us) {
         if (cost < best) { best = cost; bi = ci; }
     }
     if (bi < 0 || (g_direct != 2 && g.K < 512)) return 1;
-    (void)budget_us;
     const KcCfg& c = kKc[bi];
     const int tiles_n = g.N / (32 * c.tb);
     const dim3 grid(tiles_n * (g.M / (32 * c.ta)));
@@ -872,10 +869,10 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
         // (INET_GEMM_DIRECT=4 tries it first) is 8-15 % faster alone (no zero-fill, 1/4 of the atomics) but 1 % slower
         // in the training step, where its doubled L2 traffic competes with the BPTT chain on the other stream.
         int rc = 1;
-        if (gin.a_kmajor && g_direct != 4) rc = launch_gemm_direct(gin, s, best, force_split);
-        else if (!gin.a_kmajor) rc = launch_gemm_kc_direct(gin, s, best);
+        if (gin.a_kmajor && g_direct != 4) rc = launch_gemm_direct(gin, s, force_split);
+        else if (!gin.a_kmajor) rc = launch_gemm_kc_direct(gin, s);
         if (rc == 1 && g_direct != 3) rc = launch_gemm_ks(gin, s, force_split);
-        if (rc == 1 && gin.a_kmajor) rc = launch_gemm_direct(gin, s, best, force_split);
+        if (rc == 1 && gin.a_kmajor) rc = launch_gemm_direct(gin, s, force_split);
         if (rc != 1) return rc;
     }
     if (force_cfg >= 0 && force_cfg < kNumCfgs) {
