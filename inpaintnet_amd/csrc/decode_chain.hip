@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     }
 }
 
-int rows_ms(int B) { return B <= 16 ? 1 : 2; }
+int rows_ms(int B) { return (B + 15) / 16 <= kDecodeMaxGroups ? 1 : 2; }      // the smallest tile that fits (gru_chain.hip)
 inline int groups_of(int B) { const int ms = rows_ms(B); return (B + 16 * ms - 1) / (16 * ms); }
 
 }  // namespace

@@ -315,7 +315,18 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     }
 }
 
-int rows_ms(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : 4); }
+// Rows per workgroup (16 * MS): the smallest tile whose launch still fits on the chip (every workgroup resident, at most
+// kChainMaxGroups groups).  A chain step is hand-off latency plus the MFMAs of ONE workgroup, so more, smaller groups
+// shorten every step: B = 128 with two directions runs 8 groups of 32 rows instead of 4 of 64.
+int rows_ms(int B, int H, int nprob) {
+    static const int force = [] { const char* e = std::getenv("INET_CHAIN_MS"); return e ? std::atoi(e) : 0; }();
+    if (force > 0) return B <= 16 ? 1 : (B <= 32 ? 2 : 4);                 // the fixed rule of the first chain kernels
+    for (int ms = 1; ms <= 4; ms *= 2) {
+        const int groups = nprob * ((B + 16 * ms - 1) / (16 * ms));
+        if (groups * (H / 16) <= 256 && groups <= kChainMaxGroups) return ms;
+    }
+    return 4;
+}
 int chain_prio() {
     static int v = -1;
     if (v < 0) { const char* e = std::getenv("INET_CHAIN_PRIO"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -327,14 +338,14 @@ int chain_prio() {
 bool gru_chain_ok(int H, int B, int T, int nprob) {
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;   // the kernels index with 32-bit element offsets
     if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
-    const int ms = rows_ms(B), tiles = (B + 16 * ms - 1) / (16 * ms);
-    return nprob * tiles * (H / 16) <= 256;        // every workgroup must be resident at once (one per CU)
+    const int ms = rows_ms(B, H, nprob), tiles = (B + 16 * ms - 1) / (16 * ms);
+    return nprob * tiles * (H / 16) <= 256 && nprob * tiles <= kChainMaxGroups;   // every workgroup resident at once
 }
 
 // Backward chains may give a workgroup two 64-row tiles (MS = 8) when one per workgroup would need more than 256
 // workgroups: the decoder's tick layers run their 4 beats as 4 problems x 256 rows.
 int rows_ms_bwd(int H, int B, int nprob) {
-    const int ms = rows_ms(B);
+    const int ms = rows_ms(B, H, nprob);
     static const bool wide = [] { const char* e = std::getenv("INET_CHAIN_WIDE"); return !(e && e[0] == '0'); }();
     if (wide && ms == 4 && B >= 128 && nprob * ((B + 63) / 64) * (H / 16) > 256) return 8;
     return ms;
@@ -343,12 +354,12 @@ bool gru_chain_bwd_ok(int H, int B, int T, int nprob) {
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;
     if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
     const int ms = rows_ms_bwd(H, B, nprob), tiles = (B + 16 * ms - 1) / (16 * ms);
-    return nprob * tiles * (H / 16) <= 256;
+    return nprob * tiles * (H / 16) <= 256 && nprob * tiles <= kChainMaxGroups;
 }
 
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     if (!gru_chain_ok(a.H, a.B, a.T, a.nprob)) return -1;
-    const int ms = rows_ms(a.B);
+    const int ms = rows_ms(a.B, a.H, a.nprob);
     a.tiles_per_prob = (a.B + 16 * ms - 1) / (16 * ms);
     a.members = a.H / 16;
     const int groups = a.nprob * a.tiles_per_prob;

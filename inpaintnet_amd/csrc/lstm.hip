@@ -15,6 +15,12 @@ using namespace ksplit;
 
 namespace {
 
+// sync area: one 256-byte block per group counter (gru_chain.h): 32 forward counters, 32 backward counters, status word
+constexpr int kCounterStride = 64;
+constexpr int kBwdCounters = 32 * kCounterStride;
+constexpr int kStatusWord = 64 * kCounterStride;
+constexpr int kSyncWords = kStatusWord + 4;
+
 struct LstmFwdArgs {
     int B, H;
     const float* h_prev; const float* c_prev;     // [B,H]
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
 #pragma unroll
             for (int a = 0; a < 4; ++a) pg[p][a] = P.gi[((long)tt * B + b) * 4 * H + a * H + jc];
         }
-        if (step > 0 && !chain::wait_group(P.counters + group, (unsigned)(step * P.members), P.status, &flag[step & 1])) return;
+        if (step > 0 && !chain::wait_group(P.counters + group * kCounterStride, (unsigned)(step * P.members), P.status, &flag[step & 1])) return;
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
         __syncthreads();
         if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
             chain::publish_block(rs, (step & 1) * slot_bytes, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
-        chain::arrive(P.counters + group);
+        chain::arrive(P.counters + group * kCounterStride);
     }
 }
 
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
 #pragma unroll
         for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
         if (step != T - 1) {
-            if (!chain::wait_group(P.counters + group, (unsigned)((T - 1 - step) * P.members), P.status, &flag[step & 1])) return;
+            if (!chain::wait_group(P.counters + group * kCounterStride, (unsigned)((T - 1 - step) * P.members), P.status, &flag[step & 1])) return;
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
             if (rb0 + p <= rb_last)
                 chain::publish_block(rs, (step & 1) * slot_bytes, xt[g], p, lane, rb0 + p, S4, g * (H >> 4) + member);
         }
-        chain::arrive(P.counters + group);
+        chain::arrive(P.counters + group * kCounterStride);
     }
     if (P.dc0) {
 #pragma unroll
@@ -405,12 +411,22 @@ int launch_chain(K kernel, const A& a, int groups, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// rows per group (16 * MS) for a batch: small batches get one group
-inline int chain_ms(int B) { return B <= 16 ? 1 : (B <= 32 ? 2 : 4); }
+// rows per group (16 * MS): the smallest tile that still fits the launch on the chip -- a step of these chains is mostly
+// hand-off latency plus the MFMAs of ONE workgroup (B = 32, H = 256: 1.9 of 4.1 us with 32 rows per workgroup), so more,
+// smaller groups shorten every step (AnticipationRNN: two 16-row groups instead of one 32-row group)
+inline int chain_ms(int B, int H) {
+    static const int force = [] { const char* e = std::getenv("INET_LSTM_MS"); return e ? std::atoi(e) : 0; }();
+    if (force == 1 || force == 2 || force == 4) return force;
+    for (int ms = 1; ms <= 4; ms *= 2) {
+        const int groups = (B + 16 * ms - 1) / (16 * ms);
+        if (groups * (H / 16) <= 256 && groups <= 32) return ms;
+    }
+    return 4;
+}
 inline bool lstm_chain_ok(int B, int H) {
     if (!chain_enabled() || (H != 256 && H != 512)) return false;
-    const int ms = chain_ms(B), groups = (B + 16 * ms - 1) / (16 * ms);
-    return groups * (H / 16) <= 256;              // every workgroup of the launch must be resident at once
+    const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
+    return groups * (H / 16) <= 256 && groups <= 32;   // every workgroup of the launch must be resident at once
 }
 
 int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
@@ -427,7 +443,6 @@ int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
 }
 
 struct LstmWs { float *zeros, *cseq, *sv, *whhT, *dc, *hx, *gx; unsigned* sync; };
-constexpr int kSyncWords = 64;                     // [0..31] forward group counters, [32..62] backward, [63] status
 size_t lstm_carve(int B, int T, int H, int save, void* base, LstmWs& w) {
     Carver cv(base);
     const size_t BH = (size_t)B * H;
@@ -457,7 +472,7 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
     const long BH = (long)B * H, TBH = (long)T * BH;
     if ((!h0 || !c0) && pw_zero(w.zeros, BH, s) != 0) return -2;
     if (lstm_chain_ok(B, H)) {
-        const int ms = chain_ms(B), groups = (B + 16 * ms - 1) / (16 * ms);
+        const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
         if (hipMemsetAsync(w.sync, 0, kSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
         INET_TRY(pw_pack_frag(h0 ? h0 : w.zeros, H, B, H, w.hx + pk_floats(B, H), 0, 1, 0, 0, s));   // slot 1 = h0
         LstmChainFwdArgs a{};
@@ -465,7 +480,7 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
         a.gi = gi; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = c0 ? c0 : w.zeros;
         a.out = out; a.cseq = w.cseq;
         if (save) { a.sv = w.sv; a.sv_stride = TBH; }
-        a.hx = w.hx; a.counters = w.sync; a.status = chain::Status{w.sync + kSyncWords - 1, chain_host_status()};
+        a.hx = w.hx; a.counters = w.sync; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
         char label[64];
         std::snprintf(label, sizeof label, "lstm_chain_fwd ms%d T%d B%d H%d", ms, T, B, H);
         ProfScope prof(PROF_GRU_FWD, 2.0 * T * B * 4.0 * H * H, s, label,
@@ -509,15 +524,15 @@ int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const 
     INET_TRY(pw_transpose(W_hh, H, w.whhT, 4L * H, 4 * H, H, s));
     const bool use_chain = lstm_chain_ok(B, H);
     if (use_chain) {
-        const int ms = chain_ms(B), groups = (B + 16 * ms - 1) / (16 * ms);
-        if (hipMemsetAsync(w.sync + 32, 0, 32 * sizeof(unsigned), s) != hipSuccess) return -2;
+        const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
+        if (hipMemsetAsync(w.sync + kBwdCounters, 0, kBwdCounters * sizeof(unsigned), s) != hipSuccess) return -2;
         LstmChainBwdArgs a{};
         a.B = B; a.H = H; a.T = T; a.reverse = reverse; a.members = H / 16;
         a.W_hhT = w.whhT; a.dout = dout; a.dhT = dhT; a.dcT = dcT;
         a.sv = w.sv; a.sv_stride = TBH;
         a.dg = dgi; a.dh0 = dh0; a.dc0 = dc0;
         a.db_ih = db_ih; a.db_hh = db_hh;
-        a.gx = w.gx; a.counters = w.sync + 32; a.status = chain::Status{w.sync + kSyncWords - 1, chain_host_status()};
+        a.gx = w.gx; a.counters = w.sync + kBwdCounters; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
         char label[64];
         std::snprintf(label, sizeof label, "lstm_chain_bwd ms%d T%d B%d H%d", ms, T, B, H);
         ProfScope prof(PROF_GRU_BWD, 2.0 * T * B * 4.0 * H * H, s, label,
