@@ -278,6 +278,8 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     if (mask_beat) { d.outm = w.beat0m; d.outm_ld = H; d.outm_ts = BH; d.mask = mask_beat; d.mask_ld = H; d.mask_ts = BH; }
     if (save) { d.sv = w.svb0; d.sv_astride = nb * BH; }
     d.Wpk_hh = w.wpk_b[0]; d.hpk = w.hpk_b;
+    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
+    if (beat_chain) d.sync = w.sync;                           // 4 steps in one launch (8 groups of 32 rows at B = 256)
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     INET_TRY(linear_fwd(xb, H, p + L.beat[1].w_ih, H, p + L.beat[1].b_ih, w.gi1b, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
@@ -288,6 +290,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     d.out = w.beat_out; d.out_ld = H; d.out_ts = BH;
     if (save) { d.sv = w.svb1; d.sv_astride = nb * BH; }
     d.Wpk_hh = w.wpk_b[1]; d.hpk = w.hpk_b;
+    if (beat_chain) d.sync = w.sync;
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
 
     // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
@@ -545,6 +548,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (g) { b.db_ih = g + L.beat[1].b_ih; b.db_hh = g + L.beat[1].b_hh; }
     b.dh0 = w.dhb0 + H; b.dh0_ld = 2L * H;
     b.Wpk_hhT = w.wpkT[1]; b.dghpk = w.dghpk;
+    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
+    if (beat_chain) { b.W_hh = p + L.beat[1].w_hh; b.sync = w.sync; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     if (g) {
@@ -563,6 +568,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (g) { b.db_ih = g + L.beat[0].b_ih; b.db_hh = g + L.beat[0].b_hh; }
     b.dh0 = w.dhb0; b.dh0_ld = 2L * H;
     b.Wpk_hhT = w.wpkT[0]; b.dghpk = w.dghpk;
+    if (beat_chain) { b.W_hh = p + L.beat[0].w_hh; b.sync = w.sync; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     if (g) {
         hipStream_t ss = side_fork(s);
