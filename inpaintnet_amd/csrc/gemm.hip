@@ -731,7 +731,7 @@ int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s) {
         const double cost = rounds * ((double)g.K / 4 * c.ta * c.tb * (32.0 / 1900.0) + 8.0);
         if (cost < best) { best = cost; bi = ci; }
     }
-    if (bi < 0 || (g_direct != 2 && g.K < 512)) return 1;
+    if (bi < 0 || (g_direct != 2 && g.K < 256)) return 1;
     const KcCfg& c = kKc[bi];
     const int tiles_n = g.N / (32 * c.tb);
     const dim3 grid(tiles_n * (g.M / (32 * c.ta)));
@@ -790,6 +790,9 @@ int launch_gemm_ks(const GemmArgs& gin, hipStream_t s, int force_split) {
     }
     if (bi < 0) return 1;
     const KsCfg& c = kKs[bi];
+    // many tiles (several rounds of workgroups that share nothing): the LDS-tiled kernel is the better one there
+    // (M12288 N1024 K256: 133 us here, 85 us LDS-tiled)
+    if ((long)(g.M / (16 * c.ta)) * (g.N / (16 * c.tb)) * bs > 1024 && g_direct != 4) return 1;
     int kps = (g.K + bs - 1) / bs;
     kps = (kps + 15) / 16 * 16;
     const int splits = (g.K + kps - 1) / kps;

@@ -47,7 +47,7 @@ def main():
         C = torch.zeros(M, N, device="cuda")
         row = [f"M{M} N{N} K{K} {'T' if akm else 'N'}{'N' if bkm else 'T'}"]
         splits = [int(x) for x in os.environ.get("SPLITS", "0").split(",")]
-        for mode, sp in [(0, 0)] + [(1, x) for x in splits]:
+        for mode, sp in [(0, 0)] + [(1, x) for x in splits] + ([(2, 0)] if os.environ.get('FORCE2') else []):
             ops.set_option(5, mode)
             ops.set_option(3, sp)
             f = lambda: ops.gemm(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, out=C)
@@ -59,7 +59,7 @@ def main():
             ops.prof_dump("/tmp/_gd.csv")
             lab = open("/tmp/_gd.csv").read().strip().splitlines()[-1].split(",")[1]
             ops.prof_enable(False)
-            row.append(f"{'new   ' if mode else 'tiled '} {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF err {err:.1e} [{lab}]")
+            row.append(f"{('forced' if mode == 2 else 'new   ') if mode else 'tiled '} {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF err {err:.1e} [{lab}]")
         ops.set_option(5, 1)
         ops.set_option(3, 0)
         print("\n    ".join(row), flush=True)
