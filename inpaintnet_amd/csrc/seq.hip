@@ -242,7 +242,10 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
                     float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     if (!h0 && pw_zero(w.zeros, BH, s) != 0) return -2;
-    if (w.wpk[0])
+    // fragment-major W_hh twins: only the per-step kernels read them (the chain kernels take W_hh as stored)
+    const bool chained = w.wpk[0] && w.hpk[0] && w.sync && pk_ok(H) &&
+                         (gru_chain_ok(H, B, T, 2) || (!save && B >= 512 && B % 256 == 0 && gru_chain_ok(H, 256, T, 2)));
+    if (w.wpk[0] && !chained)
     {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
         INET_TRY(pw_pack_frag_multi(ins, w.wpk, 4, H, 3 * H, H, 0, s));
@@ -293,7 +296,11 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
                     const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const bool wg = P[0].dw_hh != nullptr;
-    if (w.wpkT[0]) {
+    // both layers run as backward chains (they read W_hh as stored) iff the conditions of gru_layer_bwd_range hold:
+    // the transposed fragment-major twins are then never read
+    const bool chained = w.wpkT[0] && w.dghpk[0] && w.sync && pk_ok(H) && gru_chain_bwd_ok(H, B, T, 2);
+    if (w.wpkT[0] && chained) {
+    } else if (w.wpkT[0]) {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
         INET_TRY(pw_pack_frag_multi(ins, w.wpkT, 4, H, H, 3 * H, 1, s));
     } else {

@@ -260,11 +260,28 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     const bool pk = w.wpk_t0 != nullptr;
     static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
     const long pkh = (long)pk_floats(B, H);
+    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
+    static const bool train_chain = [] { const char* v = std::getenv("INET_DECODE_CHAIN_TRAIN"); return !(v && v[0] == '0'); }();
+    // Which kernels will run: the chain kernels read W_hh / W_ih as stored, only the per-step kernels want the
+    // fragment-major twins -- each is packed only if its consumer runs.
+    const bool beats_chained = pk && beat_chain && gru_chain_ok(H, B, nb, 1);
+    const bool fused_decode = pk && !teacher_forced && !multinomial_seed && w.wpk_out && decode_chain_ok(B, H, V, T, G) &&
+                              ((!save && !mask_tick) || train_chain);
     if (pk) {
-        const float* ins[5] = {p + L.beat[0].w_hh, p + L.beat[1].w_hh, p + L.tick[0].w_hh, p + L.tick[1].w_hh, p + L.tick[1].w_ih};
-        float* outs[5] = {w.wpk_b[0], w.wpk_b[1], w.wpk_t0, w.wpk_t1hh, w.wpk_t1ih};
-        INET_TRY(pw_pack_frag_multi(ins, outs, 5, H, 3 * H, H, 0, s));
-        if (w.wpk_out && !(teacher_forced && tf_batch)) INET_TRY(pw_pack_frag(p + L.out_w, H, V, H, w.wpk_out, 0, 1, 0, 0, s));
+        const float* ins[5]; float* outs[5];
+        int n = 0;
+        if (!beats_chained) {
+            ins[n] = p + L.beat[0].w_hh; outs[n++] = w.wpk_b[0];
+            ins[n] = p + L.beat[1].w_hh; outs[n++] = w.wpk_b[1];
+        }
+        if (!fused_decode) {
+            ins[n] = p + L.tick[0].w_hh; outs[n++] = w.wpk_t0;
+            ins[n] = p + L.tick[1].w_hh; outs[n++] = w.wpk_t1hh;
+            ins[n] = p + L.tick[1].w_ih; outs[n++] = w.wpk_t1ih;
+        }
+        if (n) INET_TRY(pw_pack_frag_multi(ins, outs, n, H, 3 * H, H, 0, s));
+        if (w.wpk_out && !fused_decode && !(teacher_forced && tf_batch))
+            INET_TRY(pw_pack_frag(p + L.out_w, H, V, H, w.wpk_out, 0, 1, 0, 0, s));
     }
 
     // ---- beat RNN (forward_beat_rnn, decoder.py:455-471) ----
@@ -278,8 +295,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     if (mask_beat) { d.outm = w.beat0m; d.outm_ld = H; d.outm_ts = BH; d.mask = mask_beat; d.mask_ld = H; d.mask_ts = BH; }
     if (save) { d.sv = w.svb0; d.sv_astride = nb * BH; }
     d.Wpk_hh = w.wpk_b[0]; d.hpk = w.hpk_b;
-    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
-    if (beat_chain) d.sync = w.sync;                           // 4 steps in one launch (8 groups of 32 rows at B = 256)
+    if (beats_chained) d.sync = w.sync;                        // 4 steps in one launch (8 groups of 32 rows at B = 256)
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     INET_TRY(linear_fwd(xb, H, p + L.beat[1].w_ih, H, p + L.beat[1].b_ih, w.gi1b, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
@@ -290,7 +306,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     d.out = w.beat_out; d.out_ld = H; d.out_ts = BH;
     if (save) { d.sv = w.svb1; d.sv_astride = nb * BH; }
     d.Wpk_hh = w.wpk_b[1]; d.hpk = w.hpk_b;
-    if (beat_chain) d.sync = w.sync;
+    if (beats_chained) d.sync = w.sync;
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
 
     // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
@@ -356,9 +372,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         INET_TRY(pw_swap01(w.wtm, T, B, V, weights, s));             // [T,B,V] -> [B,T,V]
         return 0;
     }
-    static const bool train_chain = [] { const char* v = std::getenv("INET_DECODE_CHAIN_TRAIN"); return !(v && v[0] == '0'); }();
-    if (pk && !teacher_forced && !multinomial_seed && w.wpk_out && decode_chain_ok(B, H, V, T, G) &&
-        ((!save && !mask_tick) || train_chain)) {
+    if (fused_decode) {
         // all 24 free-running ticks (layer 0, layer 1, projection, argmax, token feedback) in ONE launch: inference, and
         // the free-running half of the training steps (dropout mask between the layers, backward saves written on the way)
         DecodeChainArgs a{};
@@ -441,9 +455,17 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     DecWs w{};
     dec_carve(c, B, 1, ws, w);
     const GruDirOff* gr[4] = {&L.beat[0], &L.beat[1], &L.tick[0], &L.tick[1]};
+    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
+    // the backward chain kernels read W_hh as stored (transposed on the fly, once): the fragment-major W_hh^T twins are
+    // only packed for layers that fall back to one launch per step
+    const bool beats_chained = w.wpkT[0] && w.dghpk && beat_chain && gru_chain_bwd_ok(H, B, nb, 1);
+    const bool ticks_chained = w.wpkT[0] && w.dghpk && gru_chain_bwd_ok(H, B, G, nb);
     if (w.wpkT[0]) {
-        const float* ins[4] = {p + gr[0]->w_hh, p + gr[1]->w_hh, p + gr[2]->w_hh, p + gr[3]->w_hh};
-        INET_TRY(pw_pack_frag_multi(ins, w.wpkT, 4, H, H, 3 * H, 1, s));
+        const float* ins[4]; float* outs[4];
+        int n = 0;
+        for (int i = 0; i < 4; ++i)
+            if (!(i < 2 ? beats_chained : ticks_chained)) { ins[n] = p + gr[i]->w_hh; outs[n++] = w.wpkT[i]; }
+        if (n) INET_TRY(pw_pack_frag_multi(ins, outs, n, H, H, 3 * H, 1, s));
     } else {
         for (int i = 0; i < 4; ++i) INET_TRY(pw_transpose(p + gr[i]->w_hh, H, w.whhT[i], 3L * H, 3 * H, H, s));
     }
@@ -472,7 +494,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         if (g) { D.db_ih = g + L.tick[1].b_ih; D.db_hh = g + L.tick[1].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H + H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
         D.Wpk_hhT = w.wpkT[3]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
-        D.W_hh = p + L.tick[1].w_hh; D.sync = w.sync;        // chain kernel: the 4 beats as 4 problems, 2 row tiles per workgroup
+        if (ticks_chained) { D.W_hh = p + L.tick[1].w_hh; D.sync = w.sync; }   // the 4 beats as 4 problems, 2 row tiles per workgroup
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
@@ -498,7 +520,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         if (g) { D.db_ih = g + L.tick[0].b_ih; D.db_hh = g + L.tick[0].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
         D.Wpk_hhT = w.wpkT[2]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
-        D.W_hh = p + L.tick[0].w_hh; D.sync = w.sync;
+        if (ticks_chained) { D.W_hh = p + L.tick[0].w_hh; D.sync = w.sync; }
         D.dgi_sum = w.dcgi + (long)i * 3 * BH; D.dgi_sum_done = &dcgi_done;     // beat-constant input half, see below
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
@@ -548,8 +570,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (g) { b.db_ih = g + L.beat[1].b_ih; b.db_hh = g + L.beat[1].b_hh; }
     b.dh0 = w.dhb0 + H; b.dh0_ld = 2L * H;
     b.Wpk_hhT = w.wpkT[1]; b.dghpk = w.dghpk;
-    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
-    if (beat_chain) { b.W_hh = p + L.beat[1].w_hh; b.sync = w.sync; }
+    if (beats_chained) { b.W_hh = p + L.beat[1].w_hh; b.sync = w.sync; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     if (g) {
@@ -568,7 +589,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (g) { b.db_ih = g + L.beat[0].b_ih; b.db_hh = g + L.beat[0].b_hh; }
     b.dh0 = w.dhb0; b.dh0_ld = 2L * H;
     b.Wpk_hhT = w.wpkT[0]; b.dghpk = w.dghpk;
-    if (beat_chain) { b.W_hh = p + L.beat[0].w_hh; b.sync = w.sync; }
+    if (beats_chained) { b.W_hh = p + L.beat[0].w_hh; b.sync = w.sync; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     if (g) {
         hipStream_t ss = side_fork(s);
