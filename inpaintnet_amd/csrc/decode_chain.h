@@ -20,6 +20,7 @@ struct DecodeChainArgs {
     float* amax;                                  // [2][V/16][ceil16(B)] x {idx, max} (8 bytes each)
     float* weights; long long* samples;           // outputs [B,T,V], [B,1,T]
     unsigned* counters; chain::Status status;
+    int prezeroed;                                // the sync words are already zero (gru_chain.h kSyncAreas)
     // training (free-running forward with backward saves): everything below may be null for inference
     const float* mask;                            // [T,B,H] dropout mask of the layer-0 output (layer 1 sees h0 * mask)
     float* hx0m;                                  // [beats][pk(B,H)] exchange buffer of the masked h0 (needed iff mask)

@@ -327,7 +327,7 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
     const int ms = rows_ms(a.B), groups = (a.B + 16 * ms - 1) / (16 * ms);
     a.members = a.H / 16;
     a.status.host = chain_host_status();
-    if (hipMemsetAsync(a.counters, 0, kDecodeSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kDecodeSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status.dev = a.counters + kDecodeStatusWord;
     const size_t lds = decode_chain_lds_bytes(a.B, a.H);
     char label[72];

@@ -366,7 +366,7 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     if (groups > kChainMaxGroups) return -1;
     a.status.host = chain_host_status();
     a.prio = chain_prio();
-    if (hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status.dev = a.counters + kChainStatusWord;
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_fwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);
@@ -390,7 +390,7 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
     if (groups > kChainMaxGroups) return -1;
     a.status.host = chain_host_status();
     a.prio = chain_prio();
-    if (hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status.dev = a.counters + kChainStatusWord;
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_bwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);

@@ -41,6 +41,7 @@ struct DirFwd {
     const float* Wpk_hh; float* hpk;
     // chain kernel (gru_chain.h): kChainSyncWords words for the launch's group counters, given for direction 0 (or null)
     unsigned* sync;
+    int sync_prezeroed;                                       // those words are zero already (one memset per library call)
 };
 
 struct DirBwd {
@@ -58,6 +59,7 @@ struct DirBwd {
     const float* Wpk_hhT; float* dghpk;
     const float* W_hh;                                        // [3H,H] row-major (chain kernel reads it transposed once)
     unsigned* sync;                                           // as in DirFwd
+    int sync_prezeroed;
     float* dgi_sum;                                           // optional [B,3H] sum_t dgi(t); `*dgi_sum_done` is set to 1 when the
     int* dgi_sum_done;                                        // layer's launch produced it (chain kernel), else left alone
 };
@@ -105,7 +107,7 @@ struct BiGru2Ws {
     float *zeros, *x1raw, *x1m, *gi1, *h1, *sv[4];
     float *whhT[4], *dgi1, *dgh[4], *dhz, *dx1, *dgi0;
     float *wpk[4], *hpk[4], *wpkT[4], *dghpk[4];               // fragment-major twins (null unless pk_ok(H))
-    unsigned* sync;                                            // chain-kernel counters (gru_chain.h)
+    unsigned* sync;                                            // chain-kernel counters: kSyncAreas areas (gru_chain.h)
 };
 size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w);
 

@@ -33,7 +33,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
             P.sv = D.sv; P.sv_astride = D.sv_astride;
             P.hx = D.hpk; P.reverse = D.reverse;
         }
-        a.counters = d[0].sync;
+        a.counters = d[0].sync; a.prezeroed = d[0].sync_prezeroed;
         return launch_gru_chain_fwd(a, s);
     }
     // More rows than one resident launch can take (the frozen encoder of LatentRNN runs 2048 measures at once): the rows
@@ -141,7 +141,7 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
                 P.gx = D.dghpk; P.reverse = D.reverse;
                 P.dgi_sum = D.dgi_sum;
             }
-            a.counters = d[0].sync;
+            a.counters = d[0].sync; a.prezeroed = d[0].sync_prezeroed;
             const int rc = launch_gru_chain_bwd(a, s);
             if (rc == 0)
                 for (int i = 0; i < nd; ++i)
@@ -234,7 +234,7 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
         w.wpkT[i] = pk && save ? c.take<float>((size_t)3 * H * H) : nullptr;
         w.dghpk[i] = pk && save ? c.take<float>(2 * pk_floats(B, 3 * H)) : nullptr;
     }
-    w.sync = c.take<unsigned>(kChainSyncWords);
+    w.sync = c.take<unsigned>(kSyncAreas * kChainSyncWords);
     return c.bytes();
 }
 
@@ -245,6 +245,8 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
     // fragment-major W_hh twins: only the per-step kernels read them (the chain kernels take W_hh as stored)
     const bool chained = w.wpk[0] && w.hpk[0] && w.sync && pk_ok(H) &&
                          (gru_chain_ok(H, B, T, 2) || (!save && B >= 512 && B % 256 == 0 && gru_chain_ok(H, 256, T, 2)));
+    const bool one_launch = chained && gru_chain_ok(H, B, T, 2);      // (not the chunked form: it reuses one area per launch)
+    if (one_launch && hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     if (w.wpk[0] && !chained)
     {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
@@ -268,7 +270,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (save) { D.sv = w.sv[dir]; D.sv_astride = TBH; }
         D.reverse = dir;
         D.Wpk_hh = w.wpk[dir]; D.hpk = w.hpk[dir];
-        D.sync = w.sync;
+        D.sync = w.sync; D.sync_prezeroed = one_launch;
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     const float* x1 = mask ? w.x1m : w.x1raw;
@@ -286,7 +288,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (save) { D.sv = w.sv[2 + dir]; D.sv_astride = TBH; }
         D.reverse = dir;
         D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir];
-        D.sync = w.sync;
+        D.sync = one_launch ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = one_launch;
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     return 0;
@@ -299,6 +301,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     // both layers run as backward chains (they read W_hh as stored) iff the conditions of gru_layer_bwd_range hold:
     // the transposed fragment-major twins are then never read
     const bool chained = w.wpkT[0] && w.dghpk[0] && w.sync && pk_ok(H) && gru_chain_bwd_ok(H, B, T, 2);
+    if (chained && hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     if (w.wpkT[0] && chained) {
     } else if (w.wpkT[0]) {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
@@ -322,7 +325,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (dh0) { D.dh0 = dh0 + (2 + dir) * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[2 + dir]; D.dghpk = w.dghpk[2 + dir];
-        D.W_hh = P[2 + dir].w_hh; D.sync = w.sync;
+        D.W_hh = P[2 + dir].w_hh; D.sync = w.sync; D.sync_prezeroed = chained;
     }
     // The chains can hand their weight-gradient products to the side stream a chunk of steps at a time (CH < T) instead
     // of a layer's whole K = T*B product at the end of its chain.  Measured at B=256 with 2, 3, 4 chunks per layer:
@@ -367,7 +370,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (dh0) { D.dh0 = dh0 + dir * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[dir]; D.dghpk = w.dghpk[dir];
-        D.W_hh = P[dir].w_hh; D.sync = w.sync;
+        D.W_hh = P[dir].w_hh; D.sync = chained ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = chained;
     }
     for (int hi = T - 1; hi >= 0; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0;

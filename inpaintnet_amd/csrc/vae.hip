@@ -221,7 +221,8 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     for (int i = 0; i < 4; ++i) w.wpkT[i] = pk && save ? cv.take<float>(W3) : nullptr;
     w.dghpk = pk && save ? cv.take<float>(2 * nb * pk_floats(B, 3 * (int)H)) : nullptr;
     w.amax = cv.take<float>(2 * 2 * ((V + 15) / 16) * ((B + 15) / 16) * 16);
-    w.sync = cv.take<unsigned>(kDecodeSyncWords > kChainSyncWords ? kDecodeSyncWords : kChainSyncWords);
+    static_assert(kDecodeSyncWords <= kChainSyncWords, "one sync area serves either kind of chain launch");
+    w.sync = cv.take<unsigned>(kSyncAreas * kChainSyncWords);
     return cv.bytes();
 }
 
@@ -267,6 +268,8 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     const bool beats_chained = pk && beat_chain && gru_chain_ok(H, B, nb, 1);
     const bool fused_decode = pk && !teacher_forced && !multinomial_seed && w.wpk_out && decode_chain_ok(B, H, V, T, G) &&
                               ((!save && !mask_tick) || train_chain);
+    if ((beats_chained || fused_decode) &&
+        hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     if (pk) {
         const float* ins[5]; float* outs[5];
         int n = 0;
@@ -295,7 +298,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     if (mask_beat) { d.outm = w.beat0m; d.outm_ld = H; d.outm_ts = BH; d.mask = mask_beat; d.mask_ld = H; d.mask_ts = BH; }
     if (save) { d.sv = w.svb0; d.sv_astride = nb * BH; }
     d.Wpk_hh = w.wpk_b[0]; d.hpk = w.hpk_b;
-    if (beats_chained) d.sync = w.sync;                        // 4 steps in one launch (8 groups of 32 rows at B = 256)
+    if (beats_chained) { d.sync = w.sync; d.sync_prezeroed = 1; }   // 4 steps in one launch (8 groups of 32 rows at B = 256)
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     INET_TRY(linear_fwd(xb, H, p + L.beat[1].w_ih, H, p + L.beat[1].b_ih, w.gi1b, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
@@ -306,7 +309,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     d.out = w.beat_out; d.out_ld = H; d.out_ts = BH;
     if (save) { d.sv = w.svb1; d.sv_astride = nb * BH; }
     d.Wpk_hh = w.wpk_b[1]; d.hpk = w.hpk_b;
-    if (beats_chained) d.sync = w.sync;
+    if (beats_chained) { d.sync = w.sync + kChainSyncWords; d.sync_prezeroed = 1; }
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
 
     // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
@@ -384,7 +387,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         a.ht0 = w.ht0; a.ht0pk = w.ht0pk;
         a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
         a.weights = weights; a.samples = samples;
-        a.counters = w.sync;
+        a.counters = w.sync + 2 * kChainSyncWords; a.prezeroed = 1;
         if (mask_tick) { a.mask = mask_tick; a.hx0m = w.hm0pk; }
         if (save) {
             a.sv0 = w.svt0; a.sv1 = w.svt1; a.sv_stride = (long)T * BH;
@@ -460,6 +463,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     // only packed for layers that fall back to one launch per step
     const bool beats_chained = w.wpkT[0] && w.dghpk && beat_chain && gru_chain_bwd_ok(H, B, nb, 1);
     const bool ticks_chained = w.wpkT[0] && w.dghpk && gru_chain_bwd_ok(H, B, G, nb);
+    if ((beats_chained || ticks_chained) &&
+        hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     if (w.wpkT[0]) {
         const float* ins[4]; float* outs[4];
         int n = 0;
@@ -494,7 +499,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         if (g) { D.db_ih = g + L.tick[1].b_ih; D.db_hh = g + L.tick[1].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H + H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
         D.Wpk_hhT = w.wpkT[3]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
-        if (ticks_chained) { D.W_hh = p + L.tick[1].w_hh; D.sync = w.sync; }   // the 4 beats as 4 problems, 2 row tiles per workgroup
+        if (ticks_chained) { D.W_hh = p + L.tick[1].w_hh; D.sync = w.sync; D.sync_prezeroed = 1; }   // 4 beats = 4 problems, 2 row tiles per workgroup
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
@@ -520,7 +525,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         if (g) { D.db_ih = g + L.tick[0].b_ih; D.db_hh = g + L.tick[0].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
         D.Wpk_hhT = w.wpkT[2]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
-        if (ticks_chained) { D.W_hh = p + L.tick[0].w_hh; D.sync = w.sync; }
+        if (ticks_chained) { D.W_hh = p + L.tick[0].w_hh; D.sync = w.sync + kChainSyncWords; D.sync_prezeroed = 1; }
         D.dgi_sum = w.dcgi + (long)i * 3 * BH; D.dgi_sum_done = &dcgi_done;     // beat-constant input half, see below
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
@@ -570,7 +575,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (g) { b.db_ih = g + L.beat[1].b_ih; b.db_hh = g + L.beat[1].b_hh; }
     b.dh0 = w.dhb0 + H; b.dh0_ld = 2L * H;
     b.Wpk_hhT = w.wpkT[1]; b.dghpk = w.dghpk;
-    if (beats_chained) { b.W_hh = p + L.beat[1].w_hh; b.sync = w.sync; }
+    if (beats_chained) { b.W_hh = p + L.beat[1].w_hh; b.sync = w.sync + 2 * kChainSyncWords; b.sync_prezeroed = 1; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
     if (g) {
@@ -589,7 +594,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (g) { b.db_ih = g + L.beat[0].b_ih; b.db_hh = g + L.beat[0].b_hh; }
     b.dh0 = w.dhb0; b.dh0_ld = 2L * H;
     b.Wpk_hhT = w.wpkT[0]; b.dghpk = w.dghpk;
-    if (beats_chained) { b.W_hh = p + L.beat[0].w_hh; b.sync = w.sync; }
+    if (beats_chained) { b.W_hh = p + L.beat[0].w_hh; b.sync = w.sync + 3 * kChainSyncWords; b.sync_prezeroed = 1; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     if (g) {
         hipStream_t ss = side_fork(s);
