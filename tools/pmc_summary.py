@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 outputs of `bench.py` into the files committed under profiles/.
 
-    python tools/pmc_summary.py stats  <kernel_trace.csv>                     -> per-kernel time table (text, stdout)
+    python tools/pmc_summary.py stats  <kernel_trace.csv> [seq.json]          -> per-kernel time table (text, stdout)
     python tools/pmc_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [seq.json]
 
 PMC conventions (MI355X_MICROARCH.md, section HBM): FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts
@@ -29,16 +29,27 @@ def short(name):
     return (m.group(1) if m else name)[:60]
 
 
-def stats(path, top=40):
+def stats(path, top=40, seq_json=None):
+    """Per-kernel time table of a kernel trace.  With the launch-order sequences of bench.py (INET_BENCH_SEQ) a kernel
+    whose instantiation + grid serves several shapes is also listed per shape (`name #label`)."""
+    seqs = json.load(open(seq_json)) if seq_json else {}
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    seen = defaultdict(int)
     with open(path, newline="") as f:
-        for r in csv.DictReader(f):
-            k = short(r["Kernel_Name"])
-            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-            a = agg[k]
+        rows = sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        keys = [k]
+        gkey = f'{k}|g{int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)}'
+        if gkey in seqs:
+            keys.append(k + " #" + seqs[gkey][seen[gkey] % len(seqs[gkey])])
+            seen[gkey] += 1
+        for kk in keys:
+            a = agg[kk]
             a[0] += 1; a[1] += us; a[2] = min(a[2], us); a[3] = max(a[3], us)
-    tot = sum(a[1] for a in agg.values())
-    print(f"# {sum(a[0] for a in agg.values())} dispatches, {tot:.1f} us total kernel time")
+    tot = sum(a[1] for k, a in agg.items() if " #" not in k)
+    print(f"# {sum(a[0] for k, a in agg.items() if ' #' not in k)} dispatches, {tot:.1f} us total kernel time")
     print(f"{'kernel':<58} {'calls':>7} {'total_us':>11} {'pct':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9}")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print(f"{k:<58} {a[0]:>7d} {a[1]:>11.1f} {100 * a[1] / tot:>6.2f} {a[1] / a[0]:>9.2f} {a[2]:>9.2f} {a[3]:>9.2f}")
@@ -94,6 +105,6 @@ def pmc(fetch_csv, write_csv, out_json, seq_json=None):
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
-        stats(sys.argv[2])
+        stats(sys.argv[2], seq_json=sys.argv[3] if len(sys.argv) > 3 else None)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
