@@ -155,9 +155,12 @@ __global__ void reparam_kl_kernel(const float* __restrict__ mu, const float* __r
         if (sigma) sigma[i] = s;
         acc += 0.5f * (s * s + m * m - 1.f) - l;
     }
-    if (kl_sum) {
+    if (kl_sum) {                                   // one atomic per block: a thousand of them on one address cost ~10 us
+        __shared__ float part[4];
         acc = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(kl_sum, acc);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) unsafeAtomicAdd(kl_sum, (part[0] + part[1]) + (part[2] + part[3]));
     }
 }
 
@@ -485,7 +488,7 @@ int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long
 }
 int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,
                   hipStream_t s) {
-    hipLaunchKernelGGL(reparam_kl_kernel, dim3(grid_for(n, 256, 512)), dim3(256), 0, s, mu, ls, eps, z, sigma, n, kl_sum);
+    hipLaunchKernelGGL(reparam_kl_kernel, dim3(grid_for(n, 256, kl_sum ? 64 : 512)), dim3(256), 0, s, mu, ls, eps, z, sigma, n, kl_sum);
     return ok();
 }
 int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, const float* kdev,
