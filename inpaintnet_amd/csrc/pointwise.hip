@@ -481,7 +481,7 @@ int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long 
 }
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
                      float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s) {
-    const int g = grid_for((long)rows * 64, 256, 256);
+    const int g = grid_for((long)rows * 64, 256, 512);
     hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, out_scale, loss_sum,
                        correct);
     return ok();
