@@ -86,19 +86,39 @@ def reset_buckets(grad=None):
             work.wait()
 
 
-def start_bucket(grad, start, stop):
-    """Begin summing grad[start:stop] over ranks asynchronously (RCCL runs on its own stream, ordered after the
-    work already queued on the current stream).  Called as soon as a contiguous part of the arena is final --
-    the decoder's gradients are complete while the encoder is still back-propagating -- so that part of the
-    exchange hides behind the rest of backward.  No-op for a single process.  A range may be started only once per
-    step (a second backward() before step() would otherwise be summed twice)."""
+_prep_streams = {}   # device index -> the stream the bucket all-reduces are issued from
+
+
+def _prep_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _prep_streams:
+        _prep_streams[key] = torch.cuda.Stream(device=device)
+    return _prep_streams[key]
+
+
+def start_bucket(grad, start, stop, join_side=False):
+    """Begin summing grad[start:stop] over ranks asynchronously.  Called as soon as a contiguous part of the arena is
+    final -- the decoder's gradients are complete while the encoder is still back-propagating -- so that part of the
+    exchange hides behind the rest of backward.  The all-reduce is issued from a dedicated stream that waits for the work
+    queued so far on the current stream and, with `join_side`, for the library's side streams (the leaf weight-gradient
+    GEMMs that fill the bucket): the backward pass itself is not held up.  No-op for a single process.  A range may be
+    started only once per step (a second backward() before step() would otherwise be summed twice)."""
     if world_size() > 1 and stop > start:
         mine = _pending.setdefault(grad.data_ptr(), [])
         for a, b, _ in mine:
             if start < b and a < stop:
                 raise RuntimeError(f"dp.start_bucket: [{start},{stop}) overlaps the bucket [{a},{b}) already being "
                                    "reduced for this arena (backward() twice without step()/zero_grad()?)")
-        work = torch.distributed.all_reduce(grad[start:stop], op=torch.distributed.ReduceOp.SUM, async_op=True)
+        if grad.is_cuda:
+            from . import ops
+            prep = _prep_stream(grad.device)
+            prep.wait_stream(torch.cuda.current_stream(grad.device))
+            if join_side:
+                ops.side_join_on(prep)
+            with torch.cuda.stream(prep):
+                work = torch.distributed.all_reduce(grad[start:stop], op=torch.distributed.ReduceOp.SUM, async_op=True)
+        else:
+            work = torch.distributed.all_reduce(grad[start:stop], op=torch.distributed.ReduceOp.SUM, async_op=True)
         mine.append((start, stop, work))
 
 

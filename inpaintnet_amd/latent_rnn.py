@@ -46,8 +46,7 @@ class _BiGru2Fn(ops.TrackedFunction):
         if off == getattr(owner, "dp_bucket_from", -1) and dp.world_size() > 1:
             # data parallel: everything from the generator GRU to the end of the arena (generation_rnn +
             # generation_linear, 103 of the 160 MB) is final now -> its all-reduce runs under the context GRUs' backward
-            ops.side_join()
-            dp.start_bucket(owner.grad, off, owner.grad.numel())
+            dp.start_bucket(owner.grad, off, owner.grad.numel(), join_side=True)
         return dx, None, dh0, None, None, None, None, None, None, None, None
 
 

@@ -76,8 +76,8 @@ class _DecoderFn(ops.TrackedFunction):
         if grads is not None:
             # data parallel: the decoder half of the arena is final now -> start its all-reduce under the encoder's backward
             if dp.world_size() > 1:
-                ops.side_join()                    # deferred joins: the decoder's leaf GEMMs must be in before the exchange
-                dp.start_bucket(grads, dec.owner.decoder_arena_start, grads.numel())
+                # behind the decoder's leaf GEMMs on the side streams, without holding up the encoder's backward
+                dp.start_bucket(grads, dec.owner.decoder_arena_start, grads.numel(), join_side=True)
         return dz, None, None, None, None, None, None, None
 
 

@@ -117,6 +117,13 @@ def side_join():
     _HELD.clear()
 
 
+def side_join_on(stream):
+    """Make `stream` (a torch.cuda.Stream that is NOT the one the library calls were issued on) wait for all side-stream
+    work queued so far.  Nothing is released: the issuing stream has not been ordered after that work (dp.start_bucket
+    uses this to start an all-reduce behind the leaf GEMMs without stalling the backward pass)."""
+    check(_lib.lib().inet_side_join(C.c_void_p(stream.cuda_stream)), "inet_side_join")
+
+
 def _hold(*tensors):
     if _DEFER:
         _HELD.append(tensors)
