@@ -75,10 +75,13 @@ int64_t inet_vae_encoder_ws_bytes(const inet_vae_config* cfg, int batch, int sav
 int inet_vae_encoder_fwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
                          const float* mask, float* mu, float* logsigma, void* ws, int64_t ws_bytes, int save,
                          void* stream);
-/* autograd of the above (utils/trainer.py:150 loss.backward): accumulates into `grads` (VAE arena layout) */
+/* autograd of the above (utils/trainer.py:150 loss.backward): accumulates into `grads` (VAE arena layout).
+ * stage 0 = the whole pass.  A data-parallel caller may split it: stage 1 = Linear heads + GRU layer 1 (afterwards the
+ * arena ranges [weight_ih_l1, note_embedding) and [linear_mean.0.weight, end of the encoder) are final and their
+ * all-reduce can start), then stage 2 = GRU layer 0 + embedding on the same `ws`. */
 int inet_vae_encoder_bwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
                          float* grads, const float* mask, const float* dmu, const float* dlogsigma, void* ws,
-                         int64_t ws_bytes, void* stream);
+                         int64_t ws_bytes, int stage, void* stream);
 
 /* ---- MeasureVAE decoder: HierarchicalDecoder.forward, MeasureVAE/decoder.py:412-529 -- */
 int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int save);

@@ -79,7 +79,7 @@ _SIGNATURES = {
     "inet_latent_param_info": (C.c_int, [_LCFG, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
     "inet_vae_encoder_ws_bytes": (_L, [_CFG, _I, _I]),
     "inet_vae_encoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
-    "inet_vae_encoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "inet_vae_encoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "inet_vae_decoder_ws_bytes": (_L, [_CFG, _I, _I]),
     "inet_vae_decoder_fwd": (C.c_int, [_CFG, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, C.c_uint64, _P]),
     "inet_vae_decoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),

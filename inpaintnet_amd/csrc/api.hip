@@ -105,10 +105,11 @@ int inet_vae_encoder_fwd(const inet_vae_config* cfg, int batch, const int64_t* t
 }
 int inet_vae_encoder_bwd(const inet_vae_config* cfg, int batch, const int64_t* tokens, const float* params,
                          float* grads, const float* mask, const float* dmu, const float* dlogsigma, void* ws,
-                         int64_t ws_bytes, void* stream) {
+                         int64_t ws_bytes, int stage, void* stream) {
     if (!cfg_ok(cfg) || batch <= 0 || !tokens || !params || !grads || !dmu || !dlogsigma || !ws) return -1;
-    if (ws_bytes < (int64_t)vae_encoder_ws_bytes(*cfg, batch, 1)) return -1;
-    return vae_encoder_bwd(*cfg, batch, (const long long*)tokens, params, grads, mask, dmu, dlogsigma, ws, (hipStream_t)stream);
+    if (stage < 0 || stage > 2 || ws_bytes < (int64_t)vae_encoder_ws_bytes(*cfg, batch, 1)) return -1;
+    return vae_encoder_bwd(*cfg, batch, (const long long*)tokens, params, grads, mask, dmu, dlogsigma, ws,
+                           (hipStream_t)stream, stage);
 }
 int64_t inet_vae_decoder_ws_bytes(const inet_vae_config* cfg, int batch, int save) {
     if (!cfg_ok(cfg) || batch <= 0) return -1;

@@ -126,5 +126,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P /*[4]*/, const BiGru
 // dout1: gradient wrt the top layer outputs [T][B][2H] (or null); dhn[4] (ld) gradients wrt final hiddens (or null each).
 // Produces w.dgi0 [T][B][6H] (layer-0 input-side gate gradients, fwd dir cols 0..3H, reverse 3H..6H), accumulates the
 // recurrent / layer-1 weight gradients into P[*].d* (skipped when P[0].dw_hh is null), dh0 [4][B][H] (or null).
+// stage 0 = the whole backward pass; 1 = layer 1 only (its gradients are final afterwards: a data-parallel bucket can start);
+// 2 = the rest (layer 0), on the state stage 1 left in the workspace
 int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, const float* dout1,
-                    const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s);
+                    const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s, int stage = 0);

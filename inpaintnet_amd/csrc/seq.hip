@@ -295,14 +295,16 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
 }
 
 int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, const float* dout1,
-                    const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s) {
+                    const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s, int stage) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const bool wg = P[0].dw_hh != nullptr;
     // both layers run as backward chains (they read W_hh as stored) iff the conditions of gru_layer_bwd_range hold:
     // the transposed fragment-major twins are then never read
     const bool chained = w.wpkT[0] && w.dghpk[0] && w.sync && pk_ok(H) && gru_chain_bwd_ok(H, B, T, 2);
-    if (chained && hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    if (w.wpkT[0] && chained) {
+    // (stage 2 continues on what stage 1 left in the workspace: zeroed sync areas, packed / transposed weights, dx1)
+    if (stage != 2 && chained &&
+        hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    if (stage == 2 || (w.wpkT[0] && chained)) {
     } else if (w.wpkT[0]) {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
         INET_TRY(pw_pack_frag_multi(ins, w.wpkT, 4, H, H, 3 * H, 1, s));
@@ -333,7 +335,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     // chip busy, and smaller-K products are less efficient -- so one chunk.
     const int CH = T;
     const float* x1 = mask ? w.x1m : w.x1raw;
-    for (int hi = T - 1; hi >= 0; hi -= CH) {
+    for (int hi = T - 1; hi >= 0 && stage != 2; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0, nt = hi - lo + 1;
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
@@ -347,7 +349,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
             }
         }
     }
-    for (int dir = 0; dir < 2; ++dir) {
+    for (int dir = 0; dir < 2 && stage != 2; ++dir) {
         const float* dgi = w.dgi1 + dir * 3L * H;
         // dx1 [TB,2H] (+)= dgi1_dir [TB,3H] . W_ih_l1_dir [3H,2H]
         // the dropout mask of the layer-0 output rides in both epilogues: (a + b) m = a m + b m, exactly for the 0 / 2 of
@@ -355,6 +357,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(linear_dgrad(dgi, 6L * H, P[2 + dir].w_ih, 2L * H, w.dx1, 2L * H, T * B, 3 * H, 2 * H,
                               mask ? EPI_MUL_AUX : EPI_NONE, mask, 2L * H, dir == 0 ? ACC_STORE : ACC_ADD, s));
     }
+    if (stage == 1) return 0;
     // ---- layer 0 ----
     for (int dir = 0; dir < 2; ++dir) {
         DirBwd& D = d[dir];

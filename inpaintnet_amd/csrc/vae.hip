@@ -91,7 +91,7 @@ int vae_encoder_fwd(const inet_vae_config& c, int B, const long long* tokens, co
 }
 
 int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, const float* p, float* g,
-                    const float* mask, const float* dmu, const float* dls, void* ws, hipStream_t s) {
+                    const float* mask, const float* dmu, const float* dls, void* ws, hipStream_t s, int stage) {
     const int T = c.beats * c.ticks_per_beat, H = c.enc_hidden, V = c.num_notes, E = c.emb_dim, Z = c.z_dim;
     if (!g) return -1;
     VaeLayout L(c);
@@ -99,7 +99,8 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
     enc_carve(c, B, 1, ws, w);
     GruDirPtr P[4];
     enc_ptrs(L, p, g, P);
-    // heads
+    // heads  (stage 2 of a staged call starts at the layer-0 BPTT: see vae.h)
+    if (stage != 2) {
     INET_TRY(linear_dgrad(dmu, Z, p + L.mean_w2, 2L * H, w.d_amu, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_mu, 2L * H, ACC_STORE, s));
     INET_TRY(linear_dgrad(dls, Z, p + L.ls_w2, 2L * H, w.d_als, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_ls, 2L * H, ACC_STORE, s));
     INET_TRY(linear_dgrad(w.d_amu, 2L * H, p + L.mean_w0, 4L * H, w.dhcat, 4L * H, B, 2 * H, 4 * H, EPI_NONE, nullptr, 0, ACC_STORE, s));
@@ -115,9 +116,11 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
         INET_TRY(pw_colsum(w.d_amu, 2L * H, B, 2 * H, g + L.mean_b0, ss));
         INET_TRY(pw_colsum(w.d_als, 2L * H, B, 2 * H, g + L.ls_b0, ss));
     }
+    }
     // GRU stack
     const float* dhn[4] = {w.dhcat, w.dhcat + H, w.dhcat + 2 * H, w.dhcat + 3 * H};
-    INET_TRY(bigru2_core_bwd(B, T, H, P, mask, nullptr, dhn, 4L * H, nullptr, w.g, s));
+    INET_TRY(bigru2_core_bwd(B, T, H, P, mask, nullptr, dhn, 4L * H, nullptr, w.g, s, stage));
+    if (stage == 1) return side_join(s);
     // embedding / layer-0 input weights through the gather table.  On the MAIN stream: these are the last items of the
     // step's backward pass and the side stream is still busy with the layer-0 dW_hh products (r02 timeline: queued behind
     // them they delayed the optimizer by ~0.14 ms).

@@ -32,6 +32,8 @@ class _BiGru2Fn(ops.TrackedFunction):
         out, hn, ws = ops.bigru2_fwd(xin, x_scalar, weights, H, B, T, K, h0=h0.contiguous() if h0 is not None else None,
                                      mask=mask, save=need)
         ctx.args = (owner, off, H, B, T, K, mask, ws, xin, x_scalar)
+        if need:                                   # applications of this module awaiting their backward (data-parallel buckets)
+            owner.__dict__.setdefault("_dp_open", {})[off] = owner.__dict__.setdefault("_dp_open", {}).get(off, 0) + 1
         return out, hn
 
     @staticmethod
@@ -43,10 +45,17 @@ class _BiGru2Fn(ops.TrackedFunction):
         dx, dh0 = ops.bigru2_bwd(xin, x_scalar, owner.flat[off:], owner.grad[off:], H, B, T, K, mask,
                                  dout.contiguous(), dhn.contiguous(), ws,
                                  want_dx=ctx.needs_input_grad[0], dx_scalar=dxs, want_dh0=ctx.needs_input_grad[2])
-        if off == getattr(owner, "dp_bucket_from", -1) and dp.world_size() > 1:
-            # data parallel: everything from the generator GRU to the end of the arena (generation_rnn +
-            # generation_linear, 103 of the 160 MB) is final now -> its all-reduce runs under the context GRUs' backward
-            dp.start_bucket(owner.grad, off, owner.grad.numel(), join_side=True)
+        opened = owner.__dict__.setdefault("_dp_open", {})
+        opened[off] = opened.get(off, 1) - 1
+        # a module applied several times in one forward (the auto-regressive generator) is final after its LAST backward
+        if dp.world_size() > 1 and opened[off] <= 0:
+            if off == getattr(owner, "dp_bucket_from", -1):
+                # data parallel: everything from the generator GRU to the end of the arena (generation_rnn +
+                # generation_linear, 103 of the 160 MB) is final now -> its all-reduce runs under the context GRUs' backward
+                dp.start_bucket(owner.grad, off, owner.grad.numel(), join_side=True)
+            elif off in getattr(owner, "dp_module_ranges", {}):
+                # a context GRU: its own 28 MB are final -> reduced under the other context's backward
+                dp.start_bucket(owner.grad, off, owner.dp_module_ranges[off], join_side=True)
         return dx, None, dh0, None, None, None, None, None, None, None, None
 
 
@@ -106,6 +115,14 @@ class LatentRNN(Model):
         self.dp_bucket_from = self._off["generation_rnn.weight_ih_l0"]
         assert all(off >= self.dp_bucket_from for name, off, _ in table if name.startswith("generation_"))
         assert all(off < self.dp_bucket_from for name, off, _ in table if not name.startswith("generation_"))
+        # the context GRUs: [first parameter, first parameter of the next module) -- contiguous by construction of the arena
+        self.dp_module_ranges = {}
+        for prefix in ("context_rnn_past.", "context_rnn_future."):
+            lo = min((off for name, off, _ in table if name.startswith(prefix)), default=None)
+            if lo is not None:
+                hi = min(off for name, off, _ in table if off > lo and not name.startswith(prefix))
+                assert all(lo <= off < hi for name, off, _ in table if name.startswith(prefix))
+                self.dp_module_ranges[lo] = hi
         self._flat_leaf = None
         self.init_reference_style()
         cur_dir = os.path.dirname(os.path.realpath(__file__))

@@ -46,8 +46,18 @@ class _EncoderFn(ops.TrackedFunction):
     @staticmethod
     def backward(ctx, dmu, dls):
         enc = ctx.enc
-        ops.encoder_bwd(enc.cfg, ctx.tokens, enc.owner.flat, enc.owner.grad, ctx.mask, dmu.contiguous(),
-                        dls.contiguous(), ctx.ws)
+        owner = enc.owner
+        dmu, dls = dmu.contiguous(), dls.contiguous()
+        buckets = getattr(owner, "encoder_early_buckets", None) if dp.world_size() > 1 else None
+        if buckets:
+            # data parallel: the heads and GRU layer 1 first -- 38 of the encoder's 44 MB of gradients are final about a
+            # millisecond before the step ends -- their all-reduce runs under the layer-0 BPTT chain
+            ops.encoder_bwd(enc.cfg, ctx.tokens, owner.flat, owner.grad, ctx.mask, dmu, dls, ctx.ws, stage=1)
+            for lo, hi in buckets:
+                dp.start_bucket(owner.grad, lo, hi, join_side=True)
+            ops.encoder_bwd(enc.cfg, ctx.tokens, owner.flat, owner.grad, ctx.mask, dmu, dls, ctx.ws, stage=2)
+        else:
+            ops.encoder_bwd(enc.cfg, ctx.tokens, owner.flat, owner.grad, ctx.mask, dmu, dls, ctx.ws)
         ctx.ws = None
         return None, None, None, None
 
@@ -302,6 +312,11 @@ class MeasureVAE(Model):
         table, total = ops.vae_param_table(self.cfg)
         self._alloc_arena(table, total, device or default_device())
         self.decoder_arena_start = min(off for name, off, _ in table if name.startswith("decoder."))
+        # arena ranges whose gradients are final after stage 1 of the encoder's backward (layer 1; the Linear heads): the
+        # note embedding sits between them and is final only at the very end
+        offs = {name: off for name, off, _ in table}
+        self.encoder_early_buckets = ((offs["encoder.lstm.weight_ih_l1"], offs["encoder.note_embedding_layer.weight"]),
+                                      (offs["encoder.linear_mean.0.weight"], self.decoder_arena_start))
         self._flat_leaf = None
         self.encoder = Encoder(self, "encoder", note_embedding_dim, encoder_hidden_size, num_encoder_layers,
                                self.num_notes, encoder_dropout_prob, True, latent_space_dim, torch.nn.GRU)

@@ -129,12 +129,14 @@ def _hold(*tensors):
         _HELD.append(tensors)
 
 
-def encoder_bwd(cfg, tokens, params, grads, mask, dmu, dls, ws):
+def encoder_bwd(cfg, tokens, params, grads, mask, dmu, dls, ws, stage=0):
+    """stage 0: the whole pass; 1 then 2: heads + layer 1, then layer 0 + embedding (include/inpaintnet_hip.h)."""
     B = tokens.shape[0]
     _f32c(dmu); _f32c(dls); _f32c(grads)
     _hold(tokens, params, grads, mask, dmu, dls, ws)
     check(_lib.lib().inet_vae_encoder_bwd(C.byref(cfg), B, ptr(tokens), ptr(params), ptr(grads), ptr(mask), ptr(dmu),
-                                          ptr(dls), ptr(ws), ws.numel() * 4, stream_ptr()), "inet_vae_encoder_bwd")
+                                          ptr(dls), ptr(ws), ws.numel() * 4, int(stage), stream_ptr()),
+          "inet_vae_encoder_bwd")
 
 
 # ----------------------------------------------------------------------------- decoder

@@ -174,6 +174,7 @@ class Trainer(ABC):
         starts here runs with deferred side-stream joins: the gradient arena is only complete after step() (or
         ops.side_join()), not right after loss.backward()."""
         dp.reset_buckets(self.model.grad)            # nothing may survive from a step that never reached step()
+        self.model.__dict__.pop("_dp_open", None)    # (nor counts of forward passes that never saw their backward)
         ops.side_defer(bool(self.overlap_backward))
         self.model.zero_grad()
 

@@ -99,3 +99,38 @@ def test_chunked_chain_forward_for_large_batches():
         ops.set_option(4, 1)
         ops.prof_enable(False)
     assert ops.chain_status() == 0
+
+
+def test_staged_encoder_backward_equals_one_pass():
+    """inet_vae_encoder_bwd stage 1 (heads + layer 1) then stage 2 (layer 0 + embedding) -- the split a data-parallel
+    step uses to start the all-reduce of the early gradients -- against the one-pass call; after stage 1 the two early
+    ranges of the arena already hold their final values."""
+    c = G.CFGS["full"]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params("full"))
+    offs = {n: o for n, o, _ in table}
+    dec0 = min(o for n, o, _ in table if n.startswith("decoder."))
+    early = [(offs["encoder.lstm.weight_ih_l1"], offs["encoder.note_embedding_layer.weight"]),
+             (offs["encoder.linear_mean.0.weight"], dec0)]
+    g = torch.Generator().manual_seed(21)
+    for B in (256, 37):
+        tok = torch.randint(0, c["V"], (B, 24), generator=g).cuda()
+        mask = ops.dropout_mask((24, B, 2 * c["H"]), 0.5, 3, 0, "cuda")
+        dmu = torch.randn(B, c["Z"], generator=g).cuda() * 1e-2
+        dls = torch.randn(B, c["Z"], generator=g).cuda() * 1e-2
+        g0 = torch.zeros_like(params)
+        mu, ls, ews = ops.encoder_fwd(cfg, tok, params, mask=mask, save=True)
+        ops.encoder_bwd(cfg, tok, params, g0, mask, dmu, dls, ews)
+        g1 = torch.zeros_like(params)
+        mu, ls, ews = ops.encoder_fwd(cfg, tok, params, mask=mask, save=True)
+        ops.encoder_bwd(cfg, tok, params, g1, mask, dmu, dls, ews, stage=1)
+        torch.cuda.synchronize()
+        for lo, hi in early:
+            assert _rel(g1[lo:hi], g0[lo:hi]) < 1e-5, (B, lo, hi)
+        assert float(g1[:early[0][0]].abs().max()) == 0.0            # layer 0 not touched yet
+        ops.encoder_bwd(cfg, tok, params, g1, mask, dmu, dls, ews, stage=2)
+        torch.cuda.synchronize()
+        for name, off, shape in table:
+            n = int(np.prod(shape))
+            assert _rel(g1[off:off + n], g0[off:off + n]) < 1e-5 or float(g0[off:off + n].abs().max()) == 0.0, (B, name)
