@@ -158,6 +158,12 @@ int inet_bigru2_bwd(int batch, int T, int K, int H, const float* x, const float*
 int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
               int64_t ldc, int M, int N, int K, const float* bias, const float* aux, int64_t ldaux, int epi,
               int acc, void* stream);
+/* `nbatch` such products of one shape in one launch where a batched kernel applies (the two directions of a bi-GRU
+ * layer's weight gradients: utils/trainer.py's loss.backward() over encoder.py:53-60), one after the other otherwise:
+ * problem i reads A + i*batchA, B + i*batchB and accumulates (acc is always "add") into C + i*batchC (element strides). */
+int inet_gemm_batched(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+                      int64_t ldc, int M, int N, int K, int nbatch, int64_t batchA, int64_t batchB, int64_t batchC,
+                      void* stream);
 
 /* nn.Linear forward / backward (LatentRNN.generation_linear, latent_rnn.py:83,232,250):
  * y[M,N] = epi(x[M,K] W[N,K]^T + b), epi in {0 none, 1 SELU, 2 ReLU};

@@ -251,6 +251,15 @@ int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t
                        (hipStream_t)stream);
 }
 
+int inet_gemm_batched(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+                      int64_t ldc, int M, int N, int K, int nbatch, int64_t batchA, int64_t batchB, int64_t batchC,
+                      void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || nbatch < 1 || nbatch > 8) return -1;
+    GemmArgs g = gemm_args(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, nullptr, EPI_NONE, nullptr, 0, ACC_ADD);
+    g.nbatch = nbatch; g.batchA = batchA; g.batchB = batchB; g.batchC = batchC;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int inet_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int epi,
                     void* stream) {
     if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2) return -1;

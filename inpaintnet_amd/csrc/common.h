@@ -75,6 +75,9 @@ struct GemmArgs {
     int epi;                                  // EPI_*
     int acc;                                  // ACC_*
     int k_per_split;                          // K range handled by one blockIdx.z
+    // nbatch > 1: that many products of one shape in one launch, problem i on A + i*batchA, B + i*batchB, C + i*batchC
+    // (element strides of either sign; no bias / epilogue).  launch_gemm runs them one by one where no batched kernel applies.
+    int nbatch; long batchA, batchB, batchC;
 };
 
 // ---------------------------------------------------------------------------

@@ -244,7 +244,13 @@ __global__ __launch_bounds__(256) void gemm_tn_direct_kernel(GemmArgs g, int til
     const int h = lane >> 5, l31 = lane & 31;
     int v = blockIdx.x;
     if ((gridDim.x & 7) == 0) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int split = v / tiles, tile = v - split * tiles;
+    const int comb = v / tiles, tile = v - comb * tiles;        // comb = (problem, k range): one per XCD at 8 of them
+    int split = comb;
+    if (g.nbatch > 1) {
+        const int splits = gridDim.x / (tiles * g.nbatch), prob = comb / splits;
+        split = comb - prob * splits;
+        g.A += prob * g.batchA; g.B += prob * g.batchB; g.C += prob * g.batchC;
+    }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * (64 * TA) + wr * (32 * TA), n0 = tn * (64 * TB) + wc * (32 * TB);
     const int kbeg = split * g.k_per_split;
@@ -645,27 +651,31 @@ inline long tiles_of(const DirectCfg& c, const GemmArgs& g) { return (long)(g.M 
 int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, int force_split) {
     GemmArgs g = gin;
     const bool nonlinear = g.epi != EPI_NONE;
+    const int nbt = g.nbatch > 1 ? g.nbatch : 1;
     if (!g.a_kmajor || !g.b_kmajor || (g.M & 63) || (g.N & 63) || g.K < 64) return 1;
     if ((double)g.K * g.lda * 4 >= 2.0e9 || (double)g.K * g.ldb * 4 >= 2.0e9) return 1;
+    if (nbt > 1 && (g.bias || nonlinear || g.acc == ACC_STORE)) return 1;
     const int kSplits[] = {1, 2, 4, 8, 16, 32};
     double best = 1e300;
     int bi = -1, bs = 1;
+    static const int only_cfg = [] { const char* v = std::getenv("INET_TN_CFG"); return v ? std::atoi(v) : -1; }();
     for (int ci = 0; ci < 3; ++ci) {
         const DirectCfg& c = kDirect[ci];
         if (g.M % (64 * c.ta) || g.N % (64 * c.tb)) continue;
+        if (only_cfg >= 0 && ci != only_cfg) continue;
         const long tiles = (long)(g.M / (64 * c.ta)) * (g.N / (64 * c.tb));
         for (int sp : kSplits) {
             if (sp > 1 && (g.K / sp < 64 || (nonlinear && g.acc != ACC_STORE))) break;
             if (force_split > 0 && sp != force_split) continue;
-            const long wgs = tiles * sp;
+            const long wgs = tiles * sp * nbt;
             const long rounds = (wgs + 255) / 256;
             const double steps = (double)((g.K + sp - 1) / sp + 1) / 2;
             double cost = rounds * (steps * c.ta * c.tb * (64.0 / 2400.0) + 4.0);
-            if (sp > 1) cost += 2.0 + (double)g.M * g.N * sp / 6.0e5 + (nonlinear ? 3.0 : 0.0);
+            if (sp > 1) cost += 2.0 + (double)g.M * g.N * sp * nbt / 6.0e5 + (nonlinear ? 3.0 : 0.0);
             if (cost < best) { best = cost; bi = ci; bs = sp; }
         }
     }
-    if (bi < 0 || (g_direct != 2 && (g.K / bs < 768 || (long)tiles_of(kDirect[bi], g) * bs < 192))) return 1;
+    if (bi < 0 || (g_direct != 2 && (g.K / bs < 768 || (long)tiles_of(kDirect[bi], g) * bs * nbt < 192))) return 1;
     const DirectCfg& c = kDirect[bi];
     int kps = (g.K + bs - 1) / bs;
     kps = (kps + 1) / 2 * 2;
@@ -679,11 +689,13 @@ int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, int force_split) {
     }
     const int tiles_n = g.N / (64 * c.tb), tiles = tiles_n * (g.M / (64 * c.ta));
     char label[96];
-    std::snprintf(label, sizeof label, "M%d N%d K%d TN d%dx%d s%d e%d", g.M, g.N, g.K, 64 * c.ta, 64 * c.tb, splits,
-                  gin.epi);
-    ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label,
-                   4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
-    const dim3 grid(tiles * splits);
+    if (nbt > 1 && (g.K + kps - 1) / kps * kps != g.K) return 1;   // (the kernel derives the split count from the grid)
+    if (nbt > 1) std::snprintf(label, sizeof label, "M%d N%d K%d TN d%dx%d s%d e%d x%d", g.M, g.N, g.K, 64 * c.ta, 64 * c.tb,
+                               splits, gin.epi, nbt);
+    else std::snprintf(label, sizeof label, "M%d N%d K%d TN d%dx%d s%d e%d", g.M, g.N, g.K, 64 * c.ta, 64 * c.tb, splits, gin.epi);
+    ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K * nbt, s, label,
+                   4.0 * nbt * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    const dim3 grid(tiles * splits * nbt);
     if (bi == 0) hipLaunchKernelGGL((gemm_tn_direct_kernel<3, 2>), grid, dim3(256), 0, s, g, tiles_n, tiles);
     else if (bi == 1) hipLaunchKernelGGL((gemm_tn_direct_kernel<2, 2>), grid, dim3(256), 0, s, g, tiles_n, tiles);
     else hipLaunchKernelGGL((gemm_tn_direct_kernel<3, 3>), grid, dim3(256), 0, s, g, tiles_n, tiles);
@@ -837,9 +849,28 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     GemmArgs g = gin;
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.K <= 0) return -1;
+    if (g_direct < 0) {
+        const char* v = std::getenv("INET_GEMM_DIRECT");
+        g_direct = v ? std::atoi(v) : 1;
+    }
     if (g_force_cfg == -2) {
         g_force_cfg = -1;
         if (const char* v = std::getenv("INET_GEMM_FORCE")) std::sscanf(v, "%d,%d", &g_force_cfg, &g_force_split);
+    }
+    if (g.nbatch > 1) {
+        // several products of one shape: one launch of the shared-strip direct kernel when it applies (half the split-K
+        // factor of a single product for the same 256 workgroups), else one product after the other
+        static const bool batched = [] { const char* v = std::getenv("INET_GEMM_BATCH"); return !(v && v[0] == '0'); }();
+        int rc = 1;
+        if (batched && g_direct > 0 && g_direct != 4 && g_force_cfg < 0) rc = launch_gemm_direct(gin, s, g_force_split > 0 ? g_force_split : 0);
+        if (rc != 1) return rc;
+        for (int i = 0; i < gin.nbatch; ++i) {
+            GemmArgs one = gin;
+            one.nbatch = 0;
+            one.A += i * gin.batchA; one.B += i * gin.batchB; one.C += i * gin.batchC;
+            if ((rc = launch_gemm(one, s)) != 0) return rc;
+        }
+        return 0;
     }
     const int force_cfg = g_force_cfg, force_split = g_force_split;
     const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
@@ -862,10 +893,6 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
             if (sp > 1) cost += 2.0 + (double)g.M * g.N * sp / 6.0e5 + (nonlinear ? 3.0 : 0.0);
             if (cost < best) { best = cost; bi = ci; bs = sp; }
         }
-    }
-    if (g_direct < 0) {
-        const char* v = std::getenv("INET_GEMM_DIRECT");
-        g_direct = v ? std::atoi(v) : 1;
     }
     if (g_direct > 0 && force_cfg < 0) {
         // The long weight-gradient products go to the shared-strip direct kernel first.  Workgroup split-K with 96x64 tiles

@@ -23,6 +23,12 @@ int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);
 int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
               hipStream_t s);
+// out[v][c] = sum of the rows of X whose token is v (out [W][ncols], W <= 63); row r has token idx[(r/inner)*s_outer + (r%inner)*s_inner]
+int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, long s_outer, long s_inner, int rows, int W,
+                    int ncols, float* out, hipStream_t s);
+// dW[d][N3][E] += dtab[:, d*N3:(d+1)*N3]^T emb ;  demb[W][E] += sum_d dtab[:, d*N3:(d+1)*N3] Wih[d]      (E <= 16, W <= 63)
+int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,
+                  float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s);
 int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s);
 int pw_swap01(const float* in, int A, int B, int K, float* out, hipStream_t s);
 int pw_argmax(const float* W, long ld_w, int rows, int V, long long* out, long stride, hipStream_t s);

@@ -236,6 +236,92 @@ __global__ void onehot_kernel(const long long* __restrict__ idx, int inner, long
     }
 }
 
+// Gradient of a gather table: out[v][c] += sum over rows r with tok(r) == v of X[r][c]   (out [W][ncols], zeroed by the
+// caller).  Row r = (r / inner, r % inner) has token idx[(r/inner)*s_outer + (r%inner)*s_inner].  The one-hot product this
+// replaces read X through the MFMA path; this is one pass over X at HBM rate: a workgroup owns 256 columns x `rows_per`
+// rows, a thread owns one column of the LDS table [W+1][256] (plain read-add-write: nobody else touches its slots; LDS
+// float atomics measured 200 cycles per wave -- 116 us for the encoder's 75 MB; row W takes out-of-range tokens) and the
+// table is flushed with one global atomic per non-zero slot.  Loads go 16 rows deep before the first add.
+constexpr int kSegCols = 256, kSegMaxW = 63, kSegDepth = 16;
+__global__ __launch_bounds__(kSegCols) void token_segsum_kernel(
+    const float* __restrict__ X, long ld, const long long* __restrict__ idx, int inner, long s_outer, long s_inner, int rows,
+    int rows_per, int W, int ncols, float* __restrict__ out) {
+    extern __shared__ float tab[];                            // [W + 1][kSegCols]
+    const int c = threadIdx.x;
+    const int col = blockIdx.x * kSegCols + c;
+    for (int v = 0; v <= W; ++v) tab[v * kSegCols + c] = 0.f;
+    const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+    const int colc = min(col, ncols - 1);
+    for (int rb = r0; rb < r1; rb += kSegDepth) {
+        int v[kSegDepth];
+        float x[kSegDepth];
+#pragma unroll
+        for (int k = 0; k < kSegDepth; ++k) {
+            const int r = min(rb + k, rows - 1);
+            const long long t = idx[(long)(r / inner) * s_outer + (long)(r % inner) * s_inner];
+            v[k] = rb + k < r1 && t >= 0 && t < W ? (int)t : W;
+            x[k] = X[(long)r * ld + colc];
+        }
+#pragma unroll
+        for (int k = 0; k < kSegDepth; ++k) tab[v[k] * kSegCols + c] += x[k];
+    }
+    if (col < ncols)
+        for (int v = 0; v < W; ++v) {
+            const float x = tab[v * kSegCols + c];
+            if (x != 0.f) unsafeAtomicAdd(out + (long)v * ncols + col, x);
+        }
+}
+
+// The two small products behind a gather table of input-side gate gradients dtab [W][ndir*N3] (ld = ndir*N3), E <= 16:
+//   dW[d][j][e] (ld ldw) += sum_v dtab[v][d*N3 + j] * emb[v][e]          (blocks 0 .. nblk_a-1: a thread per (d, j, e))
+//   demb[v][e]           += sum_d sum_j dtab[v][d*N3 + j] * Wih[d][j][e]  (then a block per (table row v, 512 columns))
+struct TableGradArgs {
+    const float* dtab; int W, N3, ndir, E;
+    const float* emb; long ld_emb;                            // [W][E]
+    const float* Wih[2]; float* dW[2]; long ldw;              // [N3][E] (row stride ldw)
+    float* demb; long ld_demb;                                // [W][E], accumulated (or null)
+    int nblk_a, chunks;
+};
+__global__ __launch_bounds__(256) void table_grad_kernel(TableGradArgs a) {
+    const int ncols = a.ndir * a.N3;
+    __shared__ float sh[64 * 16];
+    if ((int)blockIdx.x < a.nblk_a) {
+        for (int i = threadIdx.x; i < a.W * a.E; i += 256) sh[i] = a.emb[(long)(i / a.E) * a.ld_emb + i % a.E];
+        __syncthreads();
+        const int o = blockIdx.x * 256 + threadIdx.x;         // (col, e), e fastest
+        if (o >= ncols * a.E) return;
+        const int col = o / a.E, e = o - col * a.E;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int v = 0; v < a.W; ++v) acc += a.dtab[(long)v * ncols + col] * sh[v * a.E + e];
+        const int d = col / a.N3, j = col - d * a.N3;
+        a.dW[d][(long)j * a.ldw + e] += acc;
+        return;
+    }
+    const int bb = blockIdx.x - a.nblk_a, v = bb / a.chunks, ch = bb - v * a.chunks;
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int col = ch * 512 + threadIdx.x; col < min(ncols, (ch + 1) * 512); col += 256) {
+        const int d = col / a.N3, j = col - d * a.N3;
+        const float t = a.dtab[(long)v * ncols + col];
+        const float* wr = a.Wih[d] + (long)j * a.ldw;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) if (e < a.E) acc[e] += t * wr[e];
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float x = acc[e];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        if (lane == 0) sh[wv * 16 + e] = x;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.E)
+        unsafeAtomicAdd(a.demb + (long)v * a.ld_demb + threadIdx.x,
+                        sh[threadIdx.x] + sh[16 + threadIdx.x] + sh[32 + threadIdx.x] + sh[48 + threadIdx.x]);
+}
+
 // x *= m      or      x *= selu'(a)  (a = SELU output)
 __global__ void mul_kernel(float* __restrict__ x, const float* __restrict__ m, long n, int selu_grad) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -516,6 +602,29 @@ int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int r
               hipStream_t s) {
     if (zero_first && pw_zero(out, (long)rows * W, s) != 0) return -2;
     hipLaunchKernelGGL(onehot_kernel, dim3(grid_for(rows)), dim3(256), 0, s, idx, inner, s_outer, s_inner, rows, W, out);
+    return ok();
+}
+int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, long s_outer, long s_inner, int rows, int W,
+                    int ncols, float* out, hipStream_t s) {
+    if (W > kSegMaxW) return -1;
+    if (pw_zero(out, (long)W * ncols, s) != 0) return -2;
+    const int col_blocks = (ncols + kSegCols - 1) / kSegCols;
+    int row_blocks = 1;                                       // >= 384 workgroups (1.5 per CU, 3 fit), at least 64 rows each
+    while (col_blocks * row_blocks < 384 && rows / (row_blocks * 2) >= 64) row_blocks *= 2;
+    const int rows_per = (rows + row_blocks - 1) / row_blocks;
+    hipLaunchKernelGGL(token_segsum_kernel, dim3(col_blocks, row_blocks), dim3(kSegCols),
+                       (size_t)(W + 1) * kSegCols * sizeof(float), s, X, ld, idx, inner, s_outer, s_inner, rows, rows_per, W, ncols, out);
+    return ok();
+}
+int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,
+                  float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s) {
+    if (E > 16 || W > 63 || ndir < 1 || ndir > 2) return -1;
+    TableGradArgs a{};
+    a.dtab = dtab; a.W = W; a.N3 = N3; a.ndir = ndir; a.E = E; a.emb = emb; a.ld_emb = ld_emb; a.ldw = ldw;
+    for (int d = 0; d < ndir; ++d) { a.Wih[d] = Wih[d]; a.dW[d] = dW[d]; }
+    a.demb = demb; a.ld_demb = ld_demb;
+    a.nblk_a = (ndir * N3 * E + 255) / 256; a.chunks = (ndir * N3 + 511) / 512;
+    hipLaunchKernelGGL(table_grad_kernel, dim3(a.nblk_a + (demb ? W * a.chunks : 0)), dim3(256), 0, s, a);
     return ok();
 }
 int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s) {

@@ -99,6 +99,13 @@ inline int linear_wgrad(const float* dy, long lddy, const float* x, long ldx, fl
                         hipStream_t s) {
     return launch_gemm(gemm_args(dy, lddy, 1, x, ldx, 1, dW, lddw, N, K, M, nullptr, EPI_NONE, nullptr, 0, ACC_ADD), s);
 }
+// two weight gradients of one shape in one launch: dW_i[N,K] += dy_i[M,N]^T x_i[M,K], i = 0, 1
+inline int linear_wgrad2(const float* dy0, const float* dy1, long lddy, const float* x0, const float* x1, long ldx,
+                         float* dW0, float* dW1, long lddw, int M, int N, int K, hipStream_t s) {
+    GemmArgs g = gemm_args(dy0, lddy, 1, x0, ldx, 1, dW0, lddw, N, K, M, nullptr, EPI_NONE, nullptr, 0, ACC_ADD);
+    g.nbatch = 2; g.batchA = dy1 - dy0; g.batchB = x1 - x0; g.batchC = dW1 - dW0;
+    return launch_gemm(g, s);
+}
 
 // ---- 2-layer bidirectional GRU core --------------------------------------------------
 struct GruDirPtr { const float *w_ih, *w_hh, *b_ih, *b_hh; float *dw_ih, *dw_hh, *db_ih, *db_hh; int K; };

@@ -340,6 +340,12 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
+            if (nt == T) {                                   // both directions of a product in one launch
+                INET_TRY(linear_wgrad2(w.dgh[2], w.dgh[3], 3L * H, w.sv[2] + 4 * TBH, w.sv[3] + 4 * TBH, H, P[2].dw_hh,
+                                       P[3].dw_hh, H, T * B, 3 * H, H, ss));
+                INET_TRY(linear_wgrad2(w.dgi1, w.dgi1 + 3L * H, 6L * H, x1, x1, 2L * H, P[2].dw_ih, P[3].dw_ih, 2L * H,
+                                       T * B, 3 * H, 2 * H, ss));
+            } else
             for (int dir = 0; dir < 2; ++dir) {
                 const int t_lo = dir ? T - 1 - hi : lo;       // the reverse direction walks time forwards
                 const float* dgi = w.dgi1 + dir * 3L * H + (long)t_lo * B * 6 * H;
@@ -380,6 +386,10 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
             hipStream_t ss = side_fork(s);
+            if (hi - lo + 1 == T)
+                INET_TRY(linear_wgrad2(w.dgh[0], w.dgh[1], 3L * H, w.sv[0] + 4 * TBH, w.sv[1] + 4 * TBH, H, P[0].dw_hh,
+                                       P[1].dw_hh, H, T * B, 3 * H, H, ss));
+            else
             for (int dir = 0; dir < 2; ++dir) {
                 const int t_lo = dir ? T - 1 - hi : lo;         // the reverse direction walks time forwards
                 INET_TRY(gru_dir_wgrad_range(H, B, t_lo, hi - lo + 1, w.dgh[dir], w.sv[dir] + 4 * TBH, P[dir].dw_hh, ss));

@@ -30,7 +30,7 @@ struct EncWs {
 
 size_t enc_carve(const inet_vae_config& c, int B, int save, void* base, EncWs& w) {
     Carver cv(base);
-    const int T = c.beats * c.ticks_per_beat, H = c.enc_hidden, V = c.num_notes;
+    const int T = c.beats * c.ticks_per_beat, H = c.enc_hidden, V = c.num_notes, E = c.emb_dim;
     w.tabF = cv.take<float>((size_t)V * 3 * H);
     w.tabR = cv.take<float>((size_t)V * 3 * H);
     w.hcat = cv.take<float>((size_t)B * 4 * H);
@@ -41,8 +41,9 @@ size_t enc_carve(const inet_vae_config& c, int B, int save, void* base, EncWs& w
         w.d_amu = cv.take<float>((size_t)B * 2 * H);
         w.d_als = cv.take<float>((size_t)B * 2 * H);
         w.dhcat = cv.take<float>((size_t)B * 4 * H);
-        w.onehot = cv.take<float>((size_t)T * B * V);
-        w.dtab = cv.take<float>((size_t)V * 3 * H);
+        const bool seg = V <= 63 && E <= 16;                 // token_segsum / table_grad kernels (pointwise.hip); else one-hot products
+        w.onehot = seg ? nullptr : cv.take<float>((size_t)T * B * V);
+        w.dtab = cv.take<float>((size_t)V * 6 * H);
     } else {
         w.d_amu = w.d_als = w.dhcat = w.onehot = w.dtab = nullptr;
     }
@@ -127,14 +128,22 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
     {
         static const bool emb_main = [] { const char* v = std::getenv("INET_EMB_MAIN"); return !(v && v[0] == '0'); }();
         hipStream_t ss = emb_main ? s : side_fork(s);
-        INET_TRY(pw_onehot(tokens, B, 1, T, T * B, V, w.onehot, 1, ss));     // row (t,b) -> tokens[b*T + t]
-        for (int dir = 0; dir < 2; ++dir) {
-            const float* dgi = w.g.dgi0 + dir * 3L * H;
-            // dTable [V,3H] = onehot^T [V,TB] . dgi0 [TB,3H]
-            INET_TRY(launch_gemm(gemm_args(w.onehot, V, 1, dgi, 6L * H, 1, w.dtab, 3L * H, V, 3 * H, T * B), ss));
-            // dW_ih_l0 [3H,E] += dTable^T . E_enc ;  dE_enc [V,E] += dTable . W_ih_l0
-            INET_TRY(linear_wgrad(w.dtab, 3L * H, p + L.enc_emb, E, P[dir].dw_ih, E, V, 3 * H, E, ss));
-            INET_TRY(linear_dgrad(w.dtab, 3L * H, P[dir].w_ih, E, g + L.enc_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, ss));
+        // dTable [V, 6H] (both directions side by side, as dgi0 holds them): the rows of dgi0 summed by token -- one pass over
+        // dgi0 at HBM rate (it shares the chip with the layer-0 dW_hh products, which own the MFMA pipes); then
+        // dW_ih_l0[dir] [3H,E] += dTable_dir^T . E_enc and dE_enc [V,E] += dTable_dir . W_ih_l0[dir] in one small launch
+        if (!w.onehot) {
+            INET_TRY(pw_token_segsum(w.g.dgi0, 6L * H, tokens, B, 1, T, T * B, V, 6 * H, w.dtab, ss));   // row (t,b) -> tokens[b*T + t]
+            const float* wih[2] = {P[0].w_ih, P[1].w_ih};
+            float* dwih[2] = {P[0].dw_ih, P[1].dw_ih};
+            INET_TRY(pw_table_grad(w.dtab, V, 3 * H, 2, E, p + L.enc_emb, E, wih, dwih, E, g + L.enc_emb, E, ss));
+        } else {                                             // large vocabularies: dTable = onehot^T . dgi0 on the GEMM path
+            INET_TRY(pw_onehot(tokens, B, 1, T, T * B, V, w.onehot, 1, ss));
+            for (int dir = 0; dir < 2; ++dir) {
+                const float* dgi = w.g.dgi0 + dir * 3L * H;
+                INET_TRY(launch_gemm(gemm_args(w.onehot, V, 1, dgi, 6L * H, 1, w.dtab, 3L * H, V, 3 * H, T * B), ss));
+                INET_TRY(linear_wgrad(w.dtab, 3L * H, p + L.enc_emb, E, P[dir].dw_ih, E, V, 3 * H, E, ss));
+                INET_TRY(linear_dgrad(w.dtab, 3L * H, P[dir].w_ih, E, g + L.enc_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, ss));
+            }
         }
     }
     return side_join(s);
@@ -508,8 +517,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
     if (g) {
         hipStream_t ss = side_fork(s);                       // overlaps the layer-0 BPTT chain below
-        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh1t, w.svt1 + 4 * TBH, g + L.tick[1].w_hh, ss));
-        INET_TRY(linear_wgrad(w.dgi1t, 3L * H, x1, H, g + L.tick[1].w_ih, H, T * B, 3 * H, H, ss));
+        INET_TRY(linear_wgrad2(w.dgh1t, w.dgi1t, 3L * H, w.svt1 + 4 * TBH, x1, H, g + L.tick[1].w_hh, g + L.tick[1].w_ih, H,
+                               T * B, 3 * H, H, ss));      // recurrent and input weights of layer 1 in one launch
     }
     INET_TRY(linear_dgrad(w.dgi1t, 3L * H, p + L.tick[1].w_ih, H, w.dx1t, H, T * B, 3 * H, H,
                           mask_tick ? EPI_MUL_AUX : EPI_NONE, mask_tick, H, ACC_STORE, s));

@@ -276,6 +276,16 @@ def gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, epi=0, aux=No
     return out
 
 
+def gemm_batched(A, B, out, M, N, K, nbatch, batchA, batchB, batchC, a_kmajor=True, b_kmajor=True):
+    """out_i[M,N] += A_i . B_i^T for nbatch problems of one shape (element strides between problems), one launch where
+    a batched kernel applies.  A, B, out: the 2-D views of problem 0."""
+    assert A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+    check(_lib.lib().inet_gemm_batched(ptr(A), A.stride(0), int(a_kmajor), ptr(B), B.stride(0), int(b_kmajor), ptr(out),
+                                       out.stride(0), M, N, K, int(nbatch), int(batchA), int(batchB), int(batchC),
+                                       stream_ptr()), "inet_gemm_batched")
+    return out
+
+
 def linear_fwd(x, W, b, epi=0):
     M, K = x.shape
     N = W.shape[0]

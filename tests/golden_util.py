@@ -14,6 +14,8 @@ CFGS = {
     "full": dict(V=48, E=10, H=512, Z=256),
     # no fixture: H % 256 == 0 turns on the fragment-major operand path of the step kernels; used against the oracle
     "pk": dict(V=20, E=6, H=256, Z=24),
+    # no fixture: a vocabulary / embedding wider than the token-sum kernels take (V > 64, E > 16): one-hot GEMM path
+    "wide": dict(V=70, E=20, H=48, Z=24),
 }
 
 

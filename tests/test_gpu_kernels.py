@@ -99,6 +99,35 @@ def test_gemm_direct_kmajor_products(M, N, K):
         ops.prof_enable(False)
 
 
+@pytest.mark.parametrize("M,N,K,nb,label", [(1536, 512, 6144, 2, "s4 e0 x2"), (1536, 1024, 6144, 2, "s2 e0 x2"),
+                                            (1536, 512, 1536, 2, None), (1536, 512, 6144, 3, None), (96, 40, 300, 2, None)])
+def test_gemm_batched_weight_gradients(M, N, K, nb, label):
+    """Several k-major x k-major products of one shape in one launch (the two directions of a bi-GRU layer's weight
+    gradients share 256 workgroups at half the split-K factor), accumulating into live destinations; interleaved
+    operands (direction d at column offset d*M of a [K, nb*M] buffer) and separately allocated ones; shapes the batched
+    kernel does not take run one product after the other."""
+    g = torch.Generator().manual_seed(M + N + K + nb)
+    A = torch.randn(K, nb * M, generator=g)                  # problem i: columns i*M .. (i+1)*M (ld = nb*M)
+    B = torch.randn(nb, K, N, generator=g)
+    C0 = torch.randn(nb, M, N, generator=g)
+    ref = torch.stack([A[:, i * M:(i + 1) * M].double().t() @ B[i].double() for i in range(nb)]) + C0.double()
+    Ad, Bd, Cd = A.to(DEV), B.to(DEV), C0.to(DEV).clone()
+    ops.prof_enable(True)
+    try:
+        ops.gemm_batched(Ad[:, :M], Bd[0], Cd[0], M, N, K, nb, M, K * N, M * N)
+        torch.cuda.synchronize()
+        ops.prof_dump("/tmp/_inet_batched.csv")
+    finally:
+        ops.prof_enable(False)
+    assert relmax(Cd, ref) < 2e-5
+    if label:
+        assert open("/tmp/_inet_batched.csv").read().strip().splitlines()[-1].split(",")[1].endswith(label)
+    # a negative stride: the same problems listed backwards
+    Cd2 = C0.to(DEV).clone()
+    ops.gemm_batched(Ad[:, (nb - 1) * M:], Bd[nb - 1], Cd2[nb - 1], M, N, K, nb, -M, -K * N, -M * N)
+    assert relmax(Cd2, ref) < 2e-5
+
+
 @pytest.mark.parametrize("bkm", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(6144, 1536, 1024), (6144, 1024, 1536), (6144, 512, 1536), (384, 256, 64),
                                    (192, 64, 192), (1152, 768, 320)])
@@ -379,7 +408,7 @@ def test_vae_train_steps_golden(name, mode):
                     assert np.abs(pv.reshape(-1)[:64] - r).max() < 1e-5, (pname, step)
 
 
-@pytest.mark.parametrize("name,B", [("mid", 7), ("pk", 37)])
+@pytest.mark.parametrize("name,B", [("mid", 7), ("pk", 37), ("wide", 5)])
 def test_vae_step_with_dropout_masks_vs_oracle(name, B):
     """Mask-in dropout (encoder l0->l1, beat l0->l1, tick l0->l1): HIP path vs the oracle with identical masks.
     "pk" (H=256, ragged batch of 37) runs the fragment-major operand path incl. the masked layer-0 -> layer-1 hand-off."""
