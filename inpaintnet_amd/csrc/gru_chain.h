@@ -12,7 +12,7 @@ constexpr int kChainZeroWord = kChainStatusWord + 64; // words [+0, +1] stay zer
 constexpr int kChainSyncWords = kChainZeroWord + 4;
 // A workspace holds kSyncAreas such areas: a library call zeroes all of them with ONE memset and gives each of its chain
 // launches its own (`prezeroed`), instead of one 5 us fill kernel in front of every launch (11 per training step).
-constexpr int kSyncAreas = 4;
+constexpr int kSyncAreas = 6;
 
 struct GruChainFwdProb {
     const float* W_hh; const float* b_hh;         // [3H,H] row-major, [3H]

@@ -29,6 +29,8 @@ int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, lo
 // dW[d][N3][E] += dtab[:, d*N3:(d+1)*N3]^T emb ;  demb[W][E] += sum_d dtab[:, d*N3:(d+1)*N3] Wih[d]      (E <= 16, W <= 63)
 int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,
                   float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s);
+// teacher-forced input tokens of a [B,T] target: out[b][0] = first, out[b][t] = target[b][t-1]
+int pw_shift_tokens(const long long* target, int B, int T, long long first, long long* out, hipStream_t s);
 int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s);
 int pw_swap01(const float* in, int A, int B, int K, float* out, hipStream_t s);
 int pw_argmax(const float* W, long ld_w, int rows, int V, long long* out, long stride, hipStream_t s);

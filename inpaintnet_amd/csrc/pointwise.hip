@@ -322,6 +322,12 @@ __global__ __launch_bounds__(256) void table_grad_kernel(TableGradArgs a) {
                         sh[threadIdx.x] + sh[16 + threadIdx.x] + sh[32 + threadIdx.x] + sh[48 + threadIdx.x]);
 }
 
+__global__ void shift_tokens_kernel(const long long* __restrict__ target, int B, int T, long long first,
+                                    long long* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * T; i += gridDim.x * blockDim.x)
+        out[i] = i % T == 0 ? first : target[i - 1];
+}
+
 // x *= m      or      x *= selu'(a)  (a = SELU output)
 __global__ void mul_kernel(float* __restrict__ x, const float* __restrict__ m, long n, int selu_grad) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -625,6 +631,10 @@ int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float
     a.demb = demb; a.ld_demb = ld_demb;
     a.nblk_a = (ndir * N3 * E + 255) / 256; a.chunks = (ndir * N3 + 511) / 512;
     hipLaunchKernelGGL(table_grad_kernel, dim3(a.nblk_a + (demb ? W * a.chunks : 0)), dim3(256), 0, s, a);
+    return ok();
+}
+int pw_shift_tokens(const long long* target, int B, int T, long long first, long long* out, hipStream_t s) {
+    hipLaunchKernelGGL(shift_tokens_kernel, dim3(grid_for((long)B * T)), dim3(256), 0, s, target, B, T, first, out);
     return ok();
 }
 int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s) {

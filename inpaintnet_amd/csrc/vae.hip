@@ -158,7 +158,8 @@ struct DecWs {
     float *zsave, *hb0, *gvec0, *beat0, *beat0m, *svb0, *gi1b, *beat_out, *svb1;
     float *ht0, *c_all, *cgi, *table;
     long long* idxV;
-    float *h0seq, *h0m, *svt0, *h1seq, *svt1, *wtm;
+    float *h0seq, *h0m, *svt0, *h1seq, *svt1, *wtm, *gi1t;
+    long long* tokin;                                // teacher-forced input tokens [B,T] (start symbol, then target shifted)
     // backward
     float *whhT[4], *dlg, *dh1top, *dgi1t, *dgh1t, *dhz, *dht0, *dx1t, *dgi0t, *dgh0t, *dcgi, *dc_all, *onehot, *dtable;
     float *dbeat_out, *dgi1b, *dgh1b, *dxb, *dgi0b, *dgh0b, *dhb0, *tmp3h;
@@ -193,6 +194,8 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.h1seq = cv.take<float>(T * BH);
     w.svt1 = save ? cv.take<float>(5 * T * BH) : nullptr;
     w.wtm = cv.take<float>(T * B * V);
+    w.gi1t = cv.take<float>(3 * T * BH);
+    w.tokin = cv.take<long long>((size_t)B * T);
     if (save) {
         for (int i = 0; i < 4; ++i) w.whhT[i] = cv.take<float>(3 * H * H);
         w.dlg = cv.take<float>(T * B * V);
@@ -280,7 +283,15 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     const bool beats_chained = pk && beat_chain && gru_chain_ok(H, B, nb, 1);
     const bool fused_decode = pk && !teacher_forced && !multinomial_seed && w.wpk_out && decode_chain_ok(B, H, V, T, G) &&
                               ((!save && !mask_tick) || train_chain);
-    if ((beats_chained || fused_decode) &&
+    // teacher-forced ticks: every input token is known and the 4 beats are independent, so each tick layer is a chain of
+    // G steps over the beats as problems -- `npl` beats per launch, as many as fit the chip at once (2 at B = 256)
+    static const bool tf_chain = [] { const char* v = std::getenv("INET_TF_CHAIN"); return !(v && v[0] == '0'); }();
+    int npl = 0;
+    if (pk && teacher_forced && tf_batch && tf_chain)
+        for (int n = nb; n >= 1 && !npl; --n)
+            if (nb % n == 0 && 2 + 2 * (nb / n) <= kSyncAreas && gru_chain_ok(H, B, G, n)) npl = n;
+    const bool ticks_chained = npl > 0;
+    if ((beats_chained || fused_decode || ticks_chained) &&
         hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     if (pk) {
         const float* ins[5]; float* outs[5];
@@ -289,7 +300,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
             ins[n] = p + L.beat[0].w_hh; outs[n++] = w.wpk_b[0];
             ins[n] = p + L.beat[1].w_hh; outs[n++] = w.wpk_b[1];
         }
-        if (!fused_decode) {
+        if (!fused_decode && !ticks_chained) {
             ins[n] = p + L.tick[0].w_hh; outs[n++] = w.wpk_t0;
             ins[n] = p + L.tick[1].w_hh; outs[n++] = w.wpk_t1hh;
             ins[n] = p + L.tick[1].w_ih; outs[n++] = w.wpk_t1ih;
@@ -326,7 +337,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
 
     // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
     INET_TRY(linear_fwd(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU, s));
-    if (pk)                                                    // packed initial tick hiddens: [layer][beat]
+    if (pk && !ticks_chained)                                  // packed initial tick hiddens: [layer][beat]
         for (int l = 0; l < 2; ++l)
             INET_TRY(pw_pack_frag(w.ht0 + (long)l * H, 2L * H, B, H, w.ht0pk + (long)l * nb * pkh, 0, nb, (long)B * 2 * H, pkh, s));
     INET_TRY(linear_fwd(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU, s));
@@ -342,6 +353,48 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         return -2;
 
     // ---- tick RNN (forward_tick_rnn, decoder.py:473-529) ----
+    if (ticks_chained) {
+        INET_TRY(pw_shift_tokens(target, B, T, V, w.tokin, s));
+        const float* x1 = mask_tick ? w.h0m : w.h0seq;
+        for (int layer = 0; layer < 2; ++layer) {
+            if (layer == 1)                                    // layer 1's input-side pre-activations for all 24 ticks at once
+                INET_TRY(linear_fwd(x1, H, p + L.tick[1].w_ih, H, p + L.tick[1].b_ih, w.gi1t, 3L * H, T * B, 3 * H, H, EPI_NONE, s));
+            for (int i0 = 0; i0 < nb; i0 += npl) {
+                DirFwd dd[4];
+                for (int k = 0; k < npl; ++k) {
+                    const int i = i0 + k;
+                    DirFwd& D = dd[k];
+                    D = DirFwd{};
+                    D.W_hh = p + L.tick[layer].w_hh; D.b_hh = p + L.tick[layer].b_hh;
+                    D.h0 = w.ht0 + (long)i * B * 2 * H + layer * H; D.h0_ld = 2L * H;
+                    D.out_ld = H; D.out_ts = BH;
+                    if (layer == 0) {
+                        D.gi = w.cgi + (long)i * B * 3 * H; D.gi_ld = 3L * H; D.gi_ts = 0;   // the beat's constant half
+                        D.table = w.table; D.table_ld = 3L * H;                              // the token half
+                        D.idx = w.tokin + (long)i * G; D.idx_bs = T; D.idx_ts = 1;
+                        D.out = w.h0seq + (long)i * G * BH;
+                        if (mask_tick) {
+                            D.outm = w.h0m + (long)i * G * BH; D.outm_ld = H; D.outm_ts = BH;
+                            D.mask = mask_tick + (long)i * G * BH; D.mask_ld = H; D.mask_ts = BH;
+                        }
+                        if (save) { D.sv = w.svt0 + (long)i * G * BH; D.sv_astride = (long)T * BH; }
+                        D.Wpk_hh = w.wpk_t0; D.hpk = w.hpk_t0 + (long)i * 2 * pkh;
+                    } else {
+                        D.gi = w.gi1t + (long)i * G * 3 * BH; D.gi_ld = 3L * H; D.gi_ts = 3 * BH;
+                        D.out = w.h1seq + (long)i * G * BH;
+                        if (save) { D.sv = w.svt1 + (long)i * G * BH; D.sv_astride = (long)T * BH; }
+                        D.Wpk_hh = w.wpk_t1hh; D.hpk = w.hpk_t1 + (long)i * 2 * pkh;
+                    }
+                }
+                dd[0].sync = w.sync + (long)(2 + layer * (nb / npl) + i0 / npl) * kChainSyncWords;
+                dd[0].sync_prezeroed = 1;
+                INET_TRY(gru_layer_fwd(H, B, G, npl, dd, s));
+            }
+        }
+        INET_TRY(linear_fwd(w.h1seq, H, p + L.out_w, H, p + L.out_b, w.wtm, V, T * B, V, H, EPI_RELU, s));
+        INET_TRY(pw_swap01(w.wtm, T, B, V, weights, s));             // [T,B,V] -> [B,T,V]
+        return 0;
+    }
     if (teacher_forced && tf_batch) {
         // Every input token is known, and the tick GRU's hidden state is re-initialised per beat, so the 4 beats are
         // independent: 6 steps x 4 problems per layer instead of 24 dependent steps, and ONE output projection.

@@ -77,6 +77,9 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     for wl in want:
         assert wl in labels, (wl, sorted(set(l for l in labels if l.startswith("gru"))))
     assert "gru_chain_bwd ms8 np4 T6 B256 H512" in labels      # decoder tick layers: 4 beats x 256 rows, two row tiles per workgroup
+    if tf:          # teacher-forced ticks: each tick layer = two chain launches of two beats (6 steps), no per-tick launches
+        assert sum(l == "gru_chain_fwd ms4 np2 T6 B256 H512" for l in labels) == 4, sorted(set(l for l in labels if l.startswith("gru")))
+        assert not any(l.startswith("gru_fwd") for l in labels)
     # the big products run on the LDS-free direct kernels (forward NT 192x192, data-gradient NN 192x128, weight-gradient
     # TN 192x128 split over the XCDs); the 192-row LDS-tiled instantiations are covered by the forced-tile test below
     big = sorted(set(l for l in labels if l.startswith("M")))
