@@ -28,9 +28,12 @@ struct GruChainFwdProb {
     float* sv; long sv_astride;                   // r,z,n,ghn,hprev saves [T][B][H] each, or null
     float* hx;                                    // exchange: [2][ceil16(B)][H] fragment-major
     int reverse;
+    int hx_slot_bytes;                            // distance between the two slots of hx (0: adjacent)
 };
 struct GruChainFwd {
     int H, B, T, nprob, tiles_per_prob, members, prio;
+    int shared_chip;                              // this launch runs beside another chain launch (two workgroups per CU):
+                                                  // the 256-register build of the kernel
     GruChainFwdProb p[4];
     unsigned* counters;                           // kChainSyncWords words owned by this launch (zeroed by the launcher
     int prezeroed;                                // unless the caller says they already are)

@@ -30,8 +30,10 @@ using namespace ksplit;
 
 namespace {
 
-template <int MS, int SQ>                          // SQ = H/64 k-steps per wave
-__global__ __launch_bounds__(256) void gru_chain_fwd_kernel(GruChainFwd A) {
+// OCC = 2: built for two waves per SIMD (256 registers, a few spilled), so that two launches over independent row
+// chunks share the chip and each one's hand-off latency (a third of a step) is filled by the other's MFMAs.
+template <int MS, int SQ, int OCC>                 // SQ = H/64 k-steps per wave
+__global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) {
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * MS * 256];
     __shared__ __attribute__((aligned(16))) float xt[MS * 256];
     __shared__ unsigned flag[2];
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(GruChainFwd A) {
     const int i16 = lane & 15, q = lane >> 4;
     const int j0 = member * 16, jc = j0 + (t & 15);
     const int rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
-    const int slot_bytes = ((B + 15) >> 4) * 16 * H * 4;
+    const int slot_bytes = P.hx_slot_bytes ? P.hx_slot_bytes : ((B + 15) >> 4) * 16 * H * 4;
     f32x4 Wr[3][SQ];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -369,14 +371,15 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status.dev = a.counters + kChainStatusWord;
     char label[72];
-    std::snprintf(label, sizeof label, "gru_chain_fwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);
+    std::snprintf(label, sizeof label, "gru_chain_fwd ms%d%s np%d T%d B%d H%d", ms, a.shared_chip && ms == 4 ? "x2" : "", a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;
     ProfScope prof(PROF_GRU_FWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))));
     const dim3 grid(chain::blocks_for(groups, a.members));
-#define INET_CF(M, Q) hipLaunchKernelGGL((gru_chain_fwd_kernel<M, Q>), grid, dim3(256), 0, s, a)
-    if (a.H == 512) { if (ms == 1) INET_CF(1, 8); else if (ms == 2) INET_CF(2, 8); else INET_CF(4, 8); }
-    else { if (ms == 1) INET_CF(1, 4); else if (ms == 2) INET_CF(2, 4); else INET_CF(4, 4); }
+#define INET_CF(M, Q, O) hipLaunchKernelGGL((gru_chain_fwd_kernel<M, Q, O>), grid, dim3(256), 0, s, a)
+    if (a.shared_chip && ms == 4) { if (a.H == 512) INET_CF(4, 8, 2); else INET_CF(4, 4, 2); }
+    else if (a.H == 512) { if (ms == 1) INET_CF(1, 8, 1); else if (ms == 2) INET_CF(2, 8, 1); else INET_CF(4, 8, 1); }
+    else { if (ms == 1) INET_CF(1, 4, 1); else if (ms == 2) INET_CF(2, 4, 1); else INET_CF(4, 4, 1); }
 #undef INET_CF
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -43,11 +43,19 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     bool chunked = pk && d[0].sync && B >= 2 * CH && B % CH == 0 && gru_chain_ok(H, CH, T, nd);
     for (int i = 0; i < nd; ++i) chunked = chunked && !d[i].sv;
     if (chunked) {
+        // Two chunks at a time, on two streams: the kernel's 256-register build lets two launches share every CU, and one
+        // chunk's hand-off latency (a third of each step) is filled by the other chunk's MFMAs.  Chunk c works on slot 1 =
+        // its rows of the full-batch h0 pack made above (row blocks are the outermost index of the fragment-major layout)
+        // and slot 0 = the same rows of the (otherwise unused) slot 0 of the full ring; even / odd chunks count on
+        // different sync areas.
+        static const bool twin = [] { const char* v = std::getenv("INET_CHUNK_TWIN"); return !(v && v[0] == '0'); }();
         const long pkc = (long)pk_floats(CH, H);
+        hipStream_t s2 = twin ? twin_fork(s) : s;
         for (int c = 0; c < B / CH; ++c) {
             const long r0 = (long)c * CH;
             GruChainFwd a{};
             a.H = H; a.B = CH; a.T = T; a.nprob = nd;
+            a.shared_chip = s2 != s;
             for (int i = 0; i < nd; ++i) {
                 const DirFwd& D = d[i];
                 GruChainFwdProb& P = a.p[i];
@@ -61,15 +69,12 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
                 P.outm = D.outm ? D.outm + r0 * D.outm_ld : nullptr; P.ld_outm = D.outm_ld; P.ts_outm = D.outm_ts;
                 P.mask = D.mask ? D.mask + r0 * D.mask_ld : nullptr; P.ld_mask = D.mask_ld; P.ts_mask = D.mask_ts;
                 P.hlast = D.hlast ? D.hlast + r0 * D.hlast_ld : nullptr; P.ld_hlast = D.hlast_ld;
-                // slot 1 of the chunk's ring = the chunk's rows of the full-batch h0 pack made above (row blocks are the
-                // outermost index of the fragment-major layout); slot 0 = the 256 rows in front of it: the previous chunk's
-                // slice, already consumed (chunk 0: the unused slot 0 of the full ring)
-                P.hx = D.hpk + pkh + (long)(c - 1) * pkc; P.reverse = D.reverse;
+                P.hx = D.hpk + (long)c * pkc; P.hx_slot_bytes = (int)(pkh * sizeof(float)); P.reverse = D.reverse;
             }
-            a.counters = d[0].sync;
-            INET_TRY(launch_gru_chain_fwd(a, s));
+            a.counters = d[0].sync + (c & 1) * kChainSyncWords;
+            INET_TRY(launch_gru_chain_fwd(a, (c & 1) ? s2 : s));
         }
-        return 0;
+        return s2 != s ? twin_join(s) : 0;
     }
     for (int step = 0; step < T; ++step) {
         GruFwdBatch bt{};

@@ -17,3 +17,7 @@ void side_set_defer(int on);
 void side_set_enabled(int on);
 int side_enabled();
 bool side_is(hipStream_t s);                         // s is the side stream
+// A second stream of the main stream's kind for work that is split over two queues on purpose (row chunks of the frozen
+// encoder's chain launches): twin_fork() makes it wait for the main stream's current point, twin_join() the reverse.
+hipStream_t twin_fork(hipStream_t main_stream);      // returns main_stream itself if no stream could be created
+int twin_join(hipStream_t main_stream);

@@ -80,6 +80,25 @@ int side_join_now(hipStream_t main_stream) {
     return 0;
 }
 
+namespace { hipStream_t g_twin = nullptr; bool g_twin_tried = false, g_twin_dirty = false; }
+hipStream_t twin_fork(hipStream_t main_stream) {
+    if (!g_twin_tried) {
+        g_twin_tried = true;
+        if (hipStreamCreateWithFlags(&g_twin, hipStreamNonBlocking) != hipSuccess) g_twin = nullptr;
+    }
+    hipEvent_t e = g_twin ? next_event() : nullptr;
+    if (!e || hipEventRecord(e, main_stream) != hipSuccess || hipStreamWaitEvent(g_twin, e, 0) != hipSuccess) return main_stream;
+    g_twin_dirty = true;
+    return g_twin;
+}
+int twin_join(hipStream_t main_stream) {
+    if (!g_twin_dirty) return 0;
+    g_twin_dirty = false;
+    hipEvent_t e = next_event();
+    if (!e || hipEventRecord(e, g_twin) != hipSuccess || hipStreamWaitEvent(main_stream, e, 0) != hipSuccess) return -2;
+    return 0;
+}
+
 // ---- chain kernels on/off (chain.h) ----
 namespace { int g_chain = -1; }
 int chain_enabled() {

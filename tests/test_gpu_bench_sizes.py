@@ -196,7 +196,7 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
     ops.prof_enable(False)
     labels = _labels(tmp_path / "launches.csv")
     # frozen encoder over all 128 x 16 measures at once: the chain kernel over eight 256-row chunks per layer
-    assert sum(l == "gru_chain_fwd ms4 np2 T24 B256 H512" for l in labels) == 16, sorted(set(l for l in labels if l.startswith("gru")))
+    assert sum(l == "gru_chain_fwd ms4x2 np2 T24 B256 H512" for l in labels) == 16, sorted(set(l for l in labels if l.startswith("gru")))
     assert "gru_chain_fwd ms2 np2 T6 B128 H512" in labels and "gru_chain_bwd ms2 np2 T6 B128 H512" in labels   # contexts: 8 groups of 32 rows
     assert any(l.startswith("gru_fwd x0") and l.endswith("B128 H1024") for l in labels)      # generator
     assert any(l.startswith("gru_bwd") and l.endswith("B128 H1024") for l in labels)
