@@ -167,7 +167,8 @@ int inet_gemm_batched(const float* A, int64_t lda, int a_kmajor, const float* B,
 
 /* nn.Linear forward / backward (LatentRNN.generation_linear, latent_rnn.py:83,232,250):
  * y[M,N] = epi(x[M,K] W[N,K]^T + b), epi in {0 none, 1 SELU, 2 ReLU};
- * backward (no activation): dx[M,K] = dy W (nullable), dW += dy^T x (nullable), db += colsum(dy) (nullable) */
+ * backward (no activation): dx[M,K] = dy W (nullable), dW += dy^T x (nullable), db += colsum(dy) (nullable); dW and db are
+ * leaf work: they run on the library's side stream (joined before return unless joins are deferred, inet_set_option 1) */
 int inet_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int epi,
                     void* stream);
 int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N,
@@ -186,13 +187,29 @@ int inet_lstm_fwd(int batch, int T, int H, const float* gi, const float* W_hh, c
 int inet_lstm_bwd(int batch, int T, int H, const float* W_hh, const float* h0, const float* out, const float* dout,
                   const float* dhT, const float* dcT, int reverse, float* dgi, float* dW_hh, float* db_ih, float* db_hh,
                   float* dh0, float* dc0, void* ws, int64_t ws_bytes, void* stream);
+/* Two stacked LSTM layers with zero initial states (the loop of lstm_with_activations over lstm_list,
+ * anticipation_rnn_gauss_reg_model.py:14-39) as a pipeline over chunks of time steps: layer 1 runs chunk c on a second
+ * stream while layer 0 runs chunk c+1.  gi0 [T,B,4H] (x W_ih0^T + b_ih0); out0/out1 [T,B,H]; gi1 [T,B,4H] scratch;
+ * ws0/ws1: one inet_lstm_ws_bytes workspace per layer.  Backward: dout1 [T,B,H] -> dgi0, dgi1 [T,B,4H] (the caller forms
+ * dx and dW_ih0 from dgi0 with inet_linear_bwd); dout0 [T,B,H] scratch; the weight / bias gradients (all given or all
+ * null) are accumulated.  Both return 1 (and do nothing) when the shape does not qualify for the pipeline: the caller
+ * then runs inet_lstm_fwd / inet_lstm_bwd layer by layer. */
+int inet_lstm2_ok(int batch, int T, int H);       /* 1 when inet_lstm2_fwd / _bwd will take the shape */
+int inet_lstm2_fwd(int batch, int T, int H, const float* gi0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
+                   const float* b_ih1, const float* W_hh1, const float* b_hh1, int reverse, float* out0, float* gi1,
+                   float* out1, void* ws0, void* ws1, int64_t ws_bytes, int save, void* stream);
+int inet_lstm2_bwd(int batch, int T, int H, const float* W_hh0, const float* W_ih1, const float* W_hh1,
+                   const float* out0, const float* out1, const float* dout1, int reverse, float* dgi0, float* dgi1,
+                   float* dout0, float* dW_hh0, float* db_ih0, float* db_hh0, float* dW_ih1, float* dW_hh1,
+                   float* db_ih1, float* db_hh1, void* ws0, void* ws1, int64_t ws_bytes, void* stream);
 /* nn.Embedding forward / backward (rows of E floats gathered by int64 index; backward accumulates with atomics).
  * row_scale (nullable, [rows]) multiplies each gathered row: the Dropout2d on the shifted note embeddings
  * (drop_input, anticipation_rnn_gauss_reg_model.py:437-442) and the all-zero first time step (:373-376). */
 int inet_embedding_fwd(const float* table, const int64_t* idx, int64_t rows, int E, float* out, const float* row_scale,
                        void* stream);
+/* num_embeddings: rows of the table (0 = not told): small tables take a segment-sum kernel instead of per-element atomics */
 int inet_embedding_bwd(const float* dout, const int64_t* idx, int64_t rows, int E, float* dtable, const float* row_scale,
-                       void* stream);
+                       int num_embeddings, void* stream);
 /* dpre = dy where y > 0 else 0   (backward of the ReLU fused into inet_linear_fwd epi=2) */
 int inet_relu_bwd(const float* dy, const float* y, float* dpre, int64_t n, void* stream);
 /* out[r*stride] = argmax_v w[r*ld + v], lowest index on ties (Tensor.max(1) / np.argmax semantics) */

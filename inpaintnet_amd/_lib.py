@@ -101,8 +101,11 @@ _SIGNATURES = {
     "inet_lstm_ws_bytes": (_L, [_I, _I, _I, _I]),
     "inet_lstm_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
     "inet_lstm_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "inet_lstm2_ok": (C.c_int, [_I, _I, _I]),
+    "inet_lstm2_fwd": (C.c_int, [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 5 + [_L, _I, _P]),
+    "inet_lstm2_bwd": (C.c_int, [_I, _I, _I] + [_P] * 6 + [_I] + [_P] * 12 + [_L, _P]),
     "inet_embedding_fwd": (C.c_int, [_P, _P, _L, _I, _P, _P, _P]),
-    "inet_embedding_bwd": (C.c_int, [_P, _P, _L, _I, _P, _P, _P]),
+    "inet_embedding_bwd": (C.c_int, [_P, _P, _L, _I, _P, _P, _I, _P]),
     "inet_relu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "inet_argmax": (C.c_int, [_P, _L, _I, _I, _P, _L, _P]),
     "inet_tokens_to_i64": (C.c_int, [_P, _P, _L, _P]),

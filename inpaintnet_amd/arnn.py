@@ -92,6 +92,44 @@ class _LstmLayerFn(ops.TrackedFunction):
         return (dx.view(T, B, -1) if dx is not None else None), dh0, dc0, None, None, None, None
 
 
+class _Lstm2Fn(ops.TrackedFunction):
+    """Two stacked nn.LSTM(num_layers=1) modules with zero initial states over x [T,B,K] (lstm_with_activations,
+    anticipation_rnn_gauss_reg_model.py:14-39), the layers pipelined over chunks of time steps (ops.lstm2_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x, flat, owner, prefix0, prefix1, reverse):
+        T, B, K = x.shape
+        pr = owner.param
+        W_hh0 = pr(prefix0 + ".weight_hh_l0")
+        H = W_hh0.shape[1]
+        need = ops.outer_grad() and any(ctx.needs_input_grad[:2])
+        x2 = x.contiguous().view(T * B, K)
+        gi0 = ops.linear_fwd(x2, pr(prefix0 + ".weight_ih_l0"), pr(prefix0 + ".bias_ih_l0"))
+        out0, out1, ws0, ws1 = ops.lstm2_fwd(gi0.view(T, B, 4 * H), W_hh0, pr(prefix0 + ".bias_hh_l0"),
+                                             pr(prefix1 + ".weight_ih_l0"), pr(prefix1 + ".bias_ih_l0"),
+                                             pr(prefix1 + ".weight_hh_l0"), pr(prefix1 + ".bias_hh_l0"), H,
+                                             reverse=reverse, save=need)
+        ctx.args = (owner, prefix0, prefix1, reverse, H, ws0, ws1)
+        ctx.save_for_backward(x2, out0, out1)
+        return out1
+
+    @staticmethod
+    def backward(ctx, dout1):
+        owner, p0, p1, reverse, H, ws0, ws1 = ctx.args
+        ctx.args = None
+        x2, out0, out1 = ctx.saved_tensors
+        T, B, _ = out1.shape
+        pr, g = owner.param, owner.param_grad
+        dgi0 = ops.lstm2_bwd(pr(p0 + ".weight_hh_l0"), pr(p1 + ".weight_ih_l0"), pr(p1 + ".weight_hh_l0"), out0, out1,
+                             dout1.contiguous(), H, reverse, ws0, ws1,
+                             grads=(g(p0 + ".weight_hh_l0"), g(p0 + ".bias_ih_l0"), g(p0 + ".bias_hh_l0"),
+                                    g(p1 + ".weight_ih_l0"), g(p1 + ".weight_hh_l0"), g(p1 + ".bias_ih_l0"),
+                                    g(p1 + ".bias_hh_l0")))
+        dx = ops.linear_bwd(dgi0.view(T * B, 4 * H), x2, pr(p0 + ".weight_ih_l0"), g(p0 + ".weight_ih_l0"), None,
+                            need_dx=ctx.needs_input_grad[0])
+        return (dx.view(T, B, -1) if dx is not None else None), None, None, None, None, None
+
+
 class ConstraintModelGaussianReg(Model):
     def __init__(self, dataset, note_embedding_dim=20, metadata_embedding_dim=30, num_lstm_constraints_units=256,
                  num_lstm_generation_units=256, linear_hidden_size=128, num_layers=1, dropout_input_prob=0.2,
@@ -170,6 +208,15 @@ class ConstraintModelGaussianReg(Model):
         h0, c0 = state if state is not None else (None, None)
         return _LstmLayerFn.call(x_tm, h0, c0, self.flat_for_autograd(), self, prefix, reverse)
 
+    def _lstm_stack(self, base, x_tm, reverse):
+        """All layers of one nn.ModuleList of LSTMs with zero initial states (lstm_with_activations, :14-39)."""
+        T, B, _ = x_tm.shape
+        if self.num_layers == 2 and ops.lstm2_ok(B, T, self.num_lstm_generation_units):
+            return _Lstm2Fn.call(x_tm, self.flat_for_autograd(), self, f"{base}.0", f"{base}.1", reverse)
+        for l in range(self.num_layers):
+            x_tm, _, _ = self._lstm(f"{base}.{l}", x_tm, reverse)
+        return x_tm
+
     def _head(self, h2d):
         a = _LinearFn.apply(h2d, self.flat_for_autograd(), self, "linear_1.weight", "linear_1.bias", True)
         return _LinearFn.apply(a, self.flat_for_autograd(), self, "linear_ouput_notes.0.weight",
@@ -190,9 +237,7 @@ class ConstraintModelGaussianReg(Model):
         masked = self.mask_tensor_score(score_tensor, constraints_loc)[:, 0].t()  # [L,B]
         parts.append(self._embed("note_embeddings.0.weight", masked))
         oc = torch.cat(parts, 2)
-        for l in range(self.num_layers):
-            oc, _, _ = self._lstm(f"lstm_constraint.{l}", oc, True)
-        return oc
+        return self._lstm_stack("lstm_constraint", oc, True)
 
     def _forward_tf(self, score_tensor, metadata_tensor, constraints_loc):
         """-> [weights (B,L,V)], None   (:348-404)"""
@@ -207,8 +252,7 @@ class ConstraintModelGaussianReg(Model):
         scale[0] = 0.0                                                         # the sequence is offset by a zero vector
         off = self._embed("note_embeddings.0.weight", shifted, scale.view(-1))
         h = torch.cat((off, oc), 2)
-        for l in range(self.num_layers):
-            h, _, _ = self._lstm(f"lstm_generation.{l}", h, False)
+        h = self._lstm_stack("lstm_generation", h, False)
         w = self._head(h.view(L * B, -1)).view(L, B, -1).permute(1, 0, 2)
         return [w], None
 

@@ -269,9 +269,22 @@ int inet_linear_bwd(const float* dy, const float* x, const float* W, float* dx, 
                     int K, void* stream) {
     if (!dy || M <= 0 || N <= 0 || K <= 0) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (dx) { if (!W) return -1; INET_TRY(linear_dgrad(dy, N, W, K, dx, K, M, N, K, EPI_NONE, nullptr, 0, ACC_STORE, s)); }
-    if (dW) { if (!x) return -1; INET_TRY(linear_wgrad(dy, N, x, K, dW, K, M, N, K, s)); }
-    if (db) INET_TRY(pw_colsum(dy, N, M, N, db, s));
+    if (dx) {
+        if (!W) return -1;
+        // an input width that is not a multiple of 64 (AnticipationRNN: 20 embedding + 256 constraint columns) would send the
+        // whole product to the LDS-tiled fallback: the leading K % 64 columns go there alone, the rest to the direct kernels
+        const int r = K % 64;
+        if (r && K - r >= 128 && M >= 1024) {
+            INET_TRY(launch_gemm(gemm_args(dy, N, 0, W, K, 1, dx, K, M, r, N), s));
+            INET_TRY(launch_gemm(gemm_args(dy, N, 0, W + r, K, 1, dx + r, K, M, K - r, N), s));
+        } else INET_TRY(linear_dgrad(dy, N, W, K, dx, K, M, N, K, EPI_NONE, nullptr, 0, ACC_STORE, s));
+    }
+    if (dW || db) {
+        hipStream_t ss = side_fork(s);                       // leaf work
+        if (dW) { if (!x) return -1; INET_TRY(linear_wgrad(dy, N, x, K, dW, K, M, N, K, ss)); }
+        if (db) INET_TRY(pw_colsum(dy, N, M, N, db, ss));
+        return side_join(s);
+    }
     return 0;
 }
 
@@ -295,15 +308,42 @@ int inet_lstm_bwd(int B, int T, int H, const float* W_hh, const float* h0, const
     return lstm_seq_bwd(B, T, H, W_hh, h0, out, dout, dhT, dcT, reverse, dgi, dW_hh, db_ih, db_hh, dh0, dc0, ws,
                         (hipStream_t)stream);
 }
+int inet_lstm2_ok(int B, int T, int H) { return B > 0 && T > 0 && H > 0 && H % 16 == 0 && lstm2_ok(B, T, H) ? 1 : 0; }
+int inet_lstm2_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
+                   const float* b_ih1, const float* W_hh1, const float* b_hh1, int reverse, float* out0, float* gi1,
+                   float* out1, void* ws0, void* ws1, int64_t ws_bytes, int save, void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || H % 16 || !gi0 || !W_hh0 || !b_hh0 || !W_ih1 || !b_ih1 || !W_hh1 || !b_hh1 || !out0 ||
+        !gi1 || !out1 || !ws0 || !ws1 || ws0 == ws1)
+        return -1;
+    if (ws_bytes < (int64_t)lstm_ws_bytes(B, T, H, save)) return -1;
+    return lstm2_seq_fwd(B, T, H, gi0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, reverse, out0, gi1, out1, ws0, ws1, save,
+                         (hipStream_t)stream);
+}
+int inet_lstm2_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, const float* W_hh1, const float* out0,
+                   const float* out1, const float* dout1, int reverse, float* dgi0, float* dgi1, float* dout0,
+                   float* dW_hh0, float* db_ih0, float* db_hh0, float* dW_ih1, float* dW_hh1, float* db_ih1, float* db_hh1,
+                   void* ws0, void* ws1, int64_t ws_bytes, void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || H % 16 || !W_hh0 || !W_ih1 || !W_hh1 || !out0 || !out1 || !dout1 || !dgi0 || !dgi1 ||
+        !dout0 || !ws0 || !ws1 || ws0 == ws1)
+        return -1;
+    const int given = (dW_hh0 != nullptr) + (db_ih0 != nullptr) + (db_hh0 != nullptr) + (dW_ih1 != nullptr) +
+                      (dW_hh1 != nullptr) + (db_ih1 != nullptr) + (db_hh1 != nullptr);
+    if (given != 0 && given != 7) return -1;
+    if (ws_bytes < (int64_t)lstm_ws_bytes(B, T, H, 1)) return -1;
+    return lstm2_seq_bwd(B, T, H, W_hh0, W_ih1, W_hh1, out0, out1, dout1, reverse, dgi0, dgi1, dout0, dW_hh0, db_ih0, db_hh0,
+                         dW_ih1, dW_hh1, db_ih1, db_hh1, ws0, ws1, (hipStream_t)stream);
+}
 int inet_embedding_fwd(const float* table, const int64_t* idx, int64_t rows, int E, float* out, const float* row_scale,
                        void* stream) {
     if (!table || !idx || !out || rows <= 0 || E <= 0) return -1;
     return pw_embedding_fwd(table, (const long long*)idx, rows, E, out, row_scale, (hipStream_t)stream);
 }
 int inet_embedding_bwd(const float* dout, const int64_t* idx, int64_t rows, int E, float* dtable, const float* row_scale,
-                       void* stream) {
-    if (!dout || !idx || !dtable || rows <= 0 || E <= 0) return -1;
-    return pw_embedding_bwd(dout, (const long long*)idx, rows, E, dtable, row_scale, (hipStream_t)stream);
+                       int num_embeddings, void* stream) {
+    if (!dout || !idx || !dtable || rows <= 0 || E <= 0 || num_embeddings < 0) return -1;
+    hipStream_t ss = side_fork((hipStream_t)stream);        // leaf work: nothing downstream reads an embedding's gradient
+    INET_TRY(pw_embedding_bwd(dout, (const long long*)idx, rows, E, dtable, row_scale, ss, num_embeddings));
+    return side_join((hipStream_t)stream);
 }
 int inet_relu_bwd(const float* dy, const float* y, float* dpre, int64_t n, void* stream) {
     if (!dy || !y || !dpre || n <= 0) return -1;

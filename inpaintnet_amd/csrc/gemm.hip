@@ -846,6 +846,13 @@ void gemm_set_direct(int mode) { g_direct = mode; }
 // Big shapes (M or K = T*B = 6144) end up on 192-wide tiles with exactly 256 workgroups; small ones on 64x64
 // tiles split until every CU holds several workgroups.
 int launch_gemm(const GemmArgs& gin, hipStream_t s) {
+    // Accumulations issued on the rotating side streams (leaf weight gradients): when a module is applied more than once per
+    // step (a per-tick free-running pass) two of them may target the same tensor from different streams -- the second one is
+    // ordered behind the first (side.hip side_order_dest; no cost when every tensor has one writer per step).
+    if (gin.acc == ACC_ADD && side_is(s)) {
+        for (int i = 0; i < (gin.nbatch > 1 ? gin.nbatch : 1); ++i)
+            if (side_order_dest(gin.C + i * gin.batchC, s) != 0) return -2;
+    }
     GemmArgs g = gin;
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.K <= 0) return -1;

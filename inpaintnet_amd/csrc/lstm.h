@@ -6,3 +6,12 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
 int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const float* out, const float* dout,
                  const float* dhT, const float* dcT, int reverse, float* dgi, float* dW_hh, float* db_ih, float* db_hh,
                  float* dh0, float* dc0, void* ws, hipStream_t s);
+bool lstm2_ok(int B, int T, int H);
+// two stacked layers, pipelined over chunks of time steps on two streams (lstm.hip); return 1 = shape does not qualify
+int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
+                  const float* b_ih1, const float* W_hh1, const float* b_hh1, int reverse, float* out0, float* gi1,
+                  float* out1, void* ws0, void* ws1, int save, hipStream_t s);
+int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, const float* W_hh1, const float* out0,
+                  const float* out1, const float* dout1, int reverse, float* dgi0, float* dgi1, float* dout0, float* dW_hh0,
+                  float* db_ih0, float* db_hh0, float* dW_ih1, float* dW_hh1, float* db_ih1, float* db_hh1, void* ws0,
+                  void* ws1, hipStream_t s);

@@ -442,7 +442,7 @@ int launch_bwd(const LstmBwdArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-struct LstmWs { float *zeros, *cseq, *sv, *whhT, *dc, *hx, *gx; unsigned* sync; };
+struct LstmWs { float *zeros, *cseq, *sv, *whhT, *dc, *hx, *gx, *carry; unsigned* sync; };
 size_t lstm_carve(int B, int T, int H, int save, void* base, LstmWs& w) {
     Carver cv(base);
     const size_t BH = (size_t)B * H;
@@ -453,6 +453,7 @@ size_t lstm_carve(int B, int T, int H, int save, void* base, LstmWs& w) {
     w.dc = save ? cv.take<float>(2 * BH) : nullptr;
     w.hx = cv.take<float>(2 * pk_floats(B, H));
     w.gx = save ? cv.take<float>(2 * pk_floats(B, 4 * H)) : nullptr;
+    w.carry = save ? cv.take<float>(4 * BH) : nullptr;        // (dh, dc) handed from one chunk of a chunked backward to the next, x2
     w.sync = cv.take<unsigned>(kSyncWords);
     return cv.bytes();
 }
@@ -511,6 +512,151 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
     if (hT && pw_copy_bytes(hT, out + (long)tl * BH, BH * sizeof(float), s) != 0) return -2;
     if (cT && pw_copy_bytes(cT, w.cseq + (long)tl * BH, BH * sizeof(float), s) != 0) return -2;
     return 0;
+}
+
+namespace {
+
+// Forward steps [s_lo, s_lo + nt) of a T-step layer as ONE chain launch that continues from (hprev, cprev) [B,H]
+// (the state after step s_lo - 1: rows of `out` / `cseq`, or zeros).  The kernel sees a sequence of nt steps whose
+// buffers start at the chunk's lowest time index; the saves keep the full sequence's array stride.
+int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, const float* b_hh, const float* hprev,
+                   const float* cprev, int reverse, float* out, LstmWs& w, int save, int s_lo, int nt, hipStream_t s) {
+    const long BH = (long)B * H, TBH = (long)T * BH;
+    const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
+    const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
+    if (hipMemsetAsync(w.sync, 0, kSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    INET_TRY(pw_pack_frag(hprev, H, B, H, w.hx + pk_floats(B, H), 0, 1, 0, 0, s));   // slot 1 = the previous step's h
+    LstmChainFwdArgs a{};
+    a.B = B; a.H = H; a.T = nt; a.reverse = reverse; a.members = H / 16;
+    a.gi = gi + t_lo * B * 4 * H; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = cprev;
+    a.out = out + t_lo * BH; a.cseq = w.cseq + t_lo * BH;
+    if (save) { a.sv = w.sv + t_lo * BH; a.sv_stride = TBH; }
+    a.hx = w.hx; a.counters = w.sync; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
+    char label[64];
+    std::snprintf(label, sizeof label, "lstm_chain_fwd ms%d T%d B%d H%d", ms, nt, B, H);
+    ProfScope prof(PROF_GRU_FWD, 2.0 * nt * B * 4.0 * H * H, s, label,
+                   4.0 * (4.0 * H * H + (double)nt * B * H * (4 + 2 + (save ? 6 : 0))));
+    if (H == 256) return ms == 1 ? launch_chain(lstm_chain_fwd_kernel<1, 4>, a, groups, s)
+                       : ms == 2 ? launch_chain(lstm_chain_fwd_kernel<2, 4>, a, groups, s)
+                                 : launch_chain(lstm_chain_fwd_kernel<4, 4>, a, groups, s);
+    return ms == 1 ? launch_chain(lstm_chain_fwd_kernel<1, 8>, a, groups, s)
+           : ms == 2 ? launch_chain(lstm_chain_fwd_kernel<2, 8>, a, groups, s)
+                     : launch_chain(lstm_chain_fwd_kernel<4, 8>, a, groups, s);
+}
+
+// Backward through forward steps [s_lo, s_lo + nt) as one chain launch: (dhT, dcT) = the gradient into the state after
+// the chunk's last step (from the chunk that ran before this one, or null), (dh0, dc0) = the gradient into the state in
+// front of its first step (for the next chunk, or null).  w.whhT must hold W_hh^T.
+int lstm_chunk_bwd(int B, int T, int H, const float* dout, const float* dhT, const float* dcT, int reverse, float* dgi,
+                   float* db_ih, float* db_hh, float* dh0, float* dc0, LstmWs& w, int s_lo, int nt, hipStream_t s) {
+    const long BH = (long)B * H, TBH = (long)T * BH;
+    const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
+    const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
+    if (hipMemsetAsync(w.sync + kBwdCounters, 0, kBwdCounters * sizeof(unsigned), s) != hipSuccess) return -2;
+    LstmChainBwdArgs a{};
+    a.B = B; a.H = H; a.T = nt; a.reverse = reverse; a.members = H / 16;
+    a.W_hhT = w.whhT; a.dout = dout ? dout + t_lo * BH : nullptr; a.dhT = dhT; a.dcT = dcT;
+    a.sv = w.sv + t_lo * BH; a.sv_stride = TBH;
+    a.dg = dgi + t_lo * B * 4 * H; a.dh0 = dh0; a.dc0 = dc0;
+    a.db_ih = db_ih; a.db_hh = db_hh;
+    a.gx = w.gx; a.counters = w.sync + kBwdCounters; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
+    char label[64];
+    std::snprintf(label, sizeof label, "lstm_chain_bwd ms%d T%d B%d H%d", ms, nt, B, H);
+    ProfScope prof(PROF_GRU_BWD, 2.0 * nt * B * 4.0 * H * H, s, label,
+                   4.0 * (4.0 * H * H + (double)nt * B * H * (6 + 4 + 1)));
+    if (H == 256) return ms == 1 ? launch_chain(lstm_chain_bwd_kernel<1, 16>, a, groups, s)
+                       : ms == 2 ? launch_chain(lstm_chain_bwd_kernel<2, 16>, a, groups, s)
+                                 : launch_chain(lstm_chain_bwd_kernel<4, 16>, a, groups, s);
+    return ms == 1 ? launch_chain(lstm_chain_bwd_kernel<1, 32>, a, groups, s)
+           : ms == 2 ? launch_chain(lstm_chain_bwd_kernel<2, 32>, a, groups, s)
+                     : launch_chain(lstm_chain_bwd_kernel<4, 32>, a, groups, s);
+}
+
+int lstm_chunk_steps() {
+    static const int v = [] { const char* e = std::getenv("INET_LSTM_CHUNK"); return e ? std::atoi(e) : 48; }();
+    return v;
+}
+
+}  // namespace
+
+bool lstm2_ok(int B, int T, int H) {
+    const int CH = lstm_chunk_steps();
+    return lstm_chain_ok(B, H) && CH >= 2 && T >= 2 * CH;
+}
+
+// Two stacked LSTM layers (zero initial states) as a pipeline over chunks of time steps: layer 1 needs layer 0's output of
+// step t only, so while layer 0's chain runs chunk c + 1 on the caller's stream, a second stream projects chunk c
+// (gi1 = out0 W_ih1^T + b_ih1) and runs layer 1's chain over it.  A B = 32 chain uses a few dozen CUs and every step of it
+// is hand-off latency: the two layers side by side cost little more than one.  gi0 [T,B,4H] (includes b_ih0);
+// out0 / out1 [T,B,H]; gi1 [T,B,4H] scratch that the backward pass does not need.
+// Returns 1 when the shape does not qualify (caller runs the layers one after the other).
+int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
+                  const float* b_ih1, const float* W_hh1, const float* b_hh1, int reverse, float* out0, float* gi1,
+                  float* out1, void* ws0, void* ws1, int save, hipStream_t s) {
+    const int CH = lstm_chunk_steps();
+    if (!lstm2_ok(B, T, H)) return 1;
+    LstmWs w0, w1;
+    lstm_carve(B, T, H, save, ws0, w0);
+    lstm_carve(B, T, H, save, ws1, w1);
+    const long BH = (long)B * H;
+    if (pw_zero(w0.zeros, BH, s) != 0 || pw_zero(w1.zeros, BH, s) != 0) return -2;
+    hipStream_t s2 = twin_fork(s);
+    for (int s_lo = 0; s_lo < T; s_lo += CH) {
+        const int nt = T - s_lo < CH ? T - s_lo : CH;
+        const long t_lo = reverse ? T - (s_lo + nt) : s_lo, tp = reverse ? t_lo + nt : t_lo - 1;
+        INET_TRY(lstm_chunk_fwd(B, T, H, gi0, W_hh0, b_hh0, s_lo ? out0 + tp * BH : w0.zeros, s_lo ? w0.cseq + tp * BH : w0.zeros,
+                                reverse, out0, w0, save, s_lo, nt, s));
+        INET_TRY(stream_wait(s2, s));
+        INET_TRY(linear_fwd(out0 + t_lo * BH, H, W_ih1, H, b_ih1, gi1 + t_lo * B * 4 * H, 4L * H, nt * B, 4 * H, H, EPI_NONE, s2));
+        INET_TRY(lstm_chunk_fwd(B, T, H, gi1, W_hh1, b_hh1, s_lo ? out1 + tp * BH : w1.zeros, s_lo ? w1.cseq + tp * BH : w1.zeros,
+                                reverse, out1, w1, save, s_lo, nt, s2));
+    }
+    return s2 != s ? twin_join(s) : 0;
+}
+
+// Backward of lstm2_seq_fwd, pipelined the other way round: layer 1's BPTT chain runs chunk c on the caller's stream, the
+// second stream turns its gate gradients into layer 0's output gradient (dout0 = dgi1 W_ih1) and runs layer 0's chain over
+// the chunk.  dout1 [T,B,H]; dgi0 / dgi1 [T,B,4H] out; dout0 [T,B,H] scratch; weight / bias gradients accumulated.
+int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, const float* W_hh1, const float* out0,
+                  const float* out1, const float* dout1, int reverse, float* dgi0, float* dgi1, float* dout0, float* dW_hh0,
+                  float* db_ih0, float* db_hh0, float* dW_ih1, float* dW_hh1, float* db_ih1, float* db_hh1, void* ws0,
+                  void* ws1, hipStream_t s) {
+    const int CH = lstm_chunk_steps();
+    if (!lstm2_ok(B, T, H)) return 1;
+    LstmWs w0, w1;
+    lstm_carve(B, T, H, 1, ws0, w0);
+    lstm_carve(B, T, H, 1, ws1, w1);
+    const long BH = (long)B * H, B4H = 4 * BH;
+    INET_TRY(pw_transpose(W_hh0, H, w0.whhT, 4L * H, 4 * H, H, s));
+    INET_TRY(pw_transpose(W_hh1, H, w1.whhT, 4L * H, 4 * H, H, s));
+    hipStream_t s2 = twin_fork(s);
+    int c = 0;
+    for (int s_end = T; s_end > 0; s_end -= CH, ++c) {
+        const int nt = s_end < CH ? s_end : CH, s_lo = s_end - nt;
+        const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
+        float* in1 = w1.carry + (long)((c + 1) & 1) * 2 * BH;   // written by the previous chunk of this layer
+        float* ou1 = w1.carry + (long)(c & 1) * 2 * BH;
+        float* in0 = w0.carry + (long)((c + 1) & 1) * 2 * BH;
+        float* ou0 = w0.carry + (long)(c & 1) * 2 * BH;
+        INET_TRY(lstm_chunk_bwd(B, T, H, dout1, c ? in1 : nullptr, c ? in1 + BH : nullptr, reverse, dgi1, db_ih1, db_hh1,
+                                s_lo ? ou1 : nullptr, s_lo ? ou1 + BH : nullptr, w1, s_lo, nt, s));
+        INET_TRY(stream_wait(s2, s));
+        INET_TRY(linear_dgrad(dgi1 + t_lo * B4H, 4L * H, W_ih1, H, dout0 + t_lo * BH, H, nt * B, 4 * H, H, EPI_NONE, nullptr, 0,
+                              ACC_STORE, s2));
+        INET_TRY(lstm_chunk_bwd(B, T, H, dout0, c ? in0 : nullptr, c ? in0 + BH : nullptr, reverse, dgi0, db_ih0, db_hh0,
+                                s_lo ? ou0 : nullptr, s_lo ? ou0 + BH : nullptr, w0, s_lo, nt, s2));
+    }
+    if (s2 != s) INET_TRY(twin_join(s));
+    if (dW_hh0) {
+        // (handing each chunk's products to an in-order stream as soon as its gate gradients exist was slower -- 9.2 -> 10.5
+        // ms per AnticipationRNN step: beside the chains they slow every hand-off -- so they run once, after the pipeline)
+        // dW_hh += sum_t dg(t)^T h_prev(t) with h_prev(t) = out(t -/+ 1) (zero initial state); dW_ih1 += dgi1^T out0
+        hipStream_t ss = side_fork(s);
+        INET_TRY(linear_wgrad(reverse ? dgi1 : dgi1 + B4H, 4L * H, reverse ? out1 + BH : out1, H, dW_hh1, H, (T - 1) * B, 4 * H, H, ss));
+        INET_TRY(linear_wgrad(dgi1, 4L * H, out0, H, dW_ih1, H, T * B, 4 * H, H, ss));
+        INET_TRY(linear_wgrad(reverse ? dgi0 : dgi0 + B4H, 4L * H, reverse ? out0 + BH : out0, H, dW_hh0, H, (T - 1) * B, 4 * H, H, ss));
+    }
+    return side_join(s);
 }
 
 // dout [T,B,H] (nullable), dhT/dcT [B,H] (nullable) -> dgi [T,B,4H]; dW_hh / db_ih / db_hh accumulated (nullable as a

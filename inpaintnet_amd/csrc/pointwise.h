@@ -24,8 +24,9 @@ int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);
 int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
               hipStream_t s);
 // out[v][c] = sum of the rows of X whose token is v (out [W][ncols], W <= 63); row r has token idx[(r/inner)*s_outer + (r%inner)*s_inner]
+// (+= into `out` unless zero_first; row_scale [rows] optional factor per row)
 int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, long s_outer, long s_inner, int rows, int W,
-                    int ncols, float* out, hipStream_t s);
+                    int ncols, float* out, hipStream_t s, const float* row_scale = nullptr, int zero_first = 1);
 // dW[d][N3][E] += dtab[:, d*N3:(d+1)*N3]^T emb ;  demb[W][E] += sum_d dtab[:, d*N3:(d+1)*N3] Wih[d]      (E <= 16, W <= 63)
 int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,
                   float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s);
@@ -50,7 +51,7 @@ int pw_scale(float* x, long n, float a, hipStream_t s);
 int pw_embedding_fwd(const float* table, const long long* idx, long rows, int E, float* out, const float* row_scale,
                      hipStream_t s);
 int pw_embedding_bwd(const float* dout, const long long* idx, long rows, int E, float* dtable, const float* row_scale,
-                     hipStream_t s);
+                     hipStream_t s, int num_embeddings = 0);
 int pw_tokens_i32_to_i64(const int* src, long long* dst, long n, hipStream_t s);
 int pw_split_measures(const int* score, int B, int M, int L, int n_past, int n_target, long long* past,
                       long long* target, long long* future, hipStream_t s);

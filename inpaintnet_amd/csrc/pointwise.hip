@@ -242,32 +242,38 @@ __global__ void onehot_kernel(const long long* __restrict__ idx, int inner, long
 // rows, a thread owns one column of the LDS table [W+1][256] (plain read-add-write: nobody else touches its slots; LDS
 // float atomics measured 200 cycles per wave -- 116 us for the encoder's 75 MB; row W takes out-of-range tokens) and the
 // table is flushed with one global atomic per non-zero slot.  Loads go 16 rows deep before the first add.
-constexpr int kSegCols = 256, kSegMaxW = 63, kSegDepth = 16;
-__global__ __launch_bounds__(kSegCols) void token_segsum_kernel(
+constexpr int kSegMaxW = 63, kSegDepth = 16;
+// CW columns per workgroup, 256 / CW row groups with a table each (narrow inputs -- embedding gradients with E = 20..30
+// columns -- keep all 256 lanes busy); optional per-row factor (the Dropout2d scale of an embedded sequence).
+template <int CW>
+__global__ __launch_bounds__(256) void token_segsum_kernel(
     const float* __restrict__ X, long ld, const long long* __restrict__ idx, int inner, long s_outer, long s_inner, int rows,
-    int rows_per, int W, int ncols, float* __restrict__ out) {
-    extern __shared__ float tab[];                            // [W + 1][kSegCols]
-    const int c = threadIdx.x;
-    const int col = blockIdx.x * kSegCols + c;
-    for (int v = 0; v <= W; ++v) tab[v * kSegCols + c] = 0.f;
+    int rows_per, int W, int ncols, float* __restrict__ out, const float* __restrict__ row_scale) {
+    constexpr int RG = 256 / CW;
+    extern __shared__ float tab[];                            // [RG][W + 1][CW]
+    const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
+    const int col = blockIdx.x * CW + c;
+    float* const mine = tab + rg * (W + 1) * CW + c;
+    for (int v = 0; v <= W; ++v) mine[v * CW] = 0.f;
     const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
     const int colc = min(col, ncols - 1);
-    for (int rb = r0; rb < r1; rb += kSegDepth) {
+    for (int rb = r0 + rg; rb < r1; rb += RG * kSegDepth) {
         int v[kSegDepth];
         float x[kSegDepth];
 #pragma unroll
         for (int k = 0; k < kSegDepth; ++k) {
-            const int r = min(rb + k, rows - 1);
+            const int r = min(rb + k * RG, rows - 1);
             const long long t = idx[(long)(r / inner) * s_outer + (long)(r % inner) * s_inner];
-            v[k] = rb + k < r1 && t >= 0 && t < W ? (int)t : W;
+            v[k] = rb + k * RG < r1 && t >= 0 && t < W ? (int)t : W;
             x[k] = X[(long)r * ld + colc];
+            if (row_scale) x[k] *= row_scale[r];
         }
 #pragma unroll
-        for (int k = 0; k < kSegDepth; ++k) tab[v[k] * kSegCols + c] += x[k];
+        for (int k = 0; k < kSegDepth; ++k) mine[v[k] * CW] += x[k];
     }
     if (col < ncols)
         for (int v = 0; v < W; ++v) {
-            const float x = tab[v * kSegCols + c];
+            const float x = mine[v * CW];
             if (x != 0.f) unsafeAtomicAdd(out + (long)v * ncols + col, x);
         }
 }
@@ -611,15 +617,20 @@ int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int r
     return ok();
 }
 int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, long s_outer, long s_inner, int rows, int W,
-                    int ncols, float* out, hipStream_t s) {
+                    int ncols, float* out, hipStream_t s, const float* row_scale, int zero_first) {
     if (W > kSegMaxW) return -1;
-    if (pw_zero(out, (long)W * ncols, s) != 0) return -2;
-    const int col_blocks = (ncols + kSegCols - 1) / kSegCols;
-    int row_blocks = 1;                                       // >= 384 workgroups (1.5 per CU, 3 fit), at least 64 rows each
-    while (col_blocks * row_blocks < 384 && rows / (row_blocks * 2) >= 64) row_blocks *= 2;
+    if (zero_first && pw_zero(out, (long)W * ncols, s) != 0) return -2;
+    const int cw = ncols <= 32 ? 32 : (ncols <= 64 ? 64 : 256), rg = 256 / cw;
+    const int col_blocks = (ncols + cw - 1) / cw;
+    int row_blocks = 1;                                       // >= 384 workgroups (1.5 per CU, 3 fit), at least 64 rows per row group
+    while (col_blocks * row_blocks < 384 && rows / (row_blocks * 2) >= 64 * rg) row_blocks *= 2;
     const int rows_per = (rows + row_blocks - 1) / row_blocks;
-    hipLaunchKernelGGL(token_segsum_kernel, dim3(col_blocks, row_blocks), dim3(kSegCols),
-                       (size_t)(W + 1) * kSegCols * sizeof(float), s, X, ld, idx, inner, s_outer, s_inner, rows, rows_per, W, ncols, out);
+    const dim3 grid(col_blocks, row_blocks);
+    const size_t lds = (size_t)(W + 1) * 256 * sizeof(float);
+#define INET_SEG(C) hipLaunchKernelGGL(token_segsum_kernel<C>, grid, dim3(256), lds, s, X, ld, idx, inner, s_outer, s_inner, rows, \
+                                       rows_per, W, ncols, out, row_scale)
+    if (cw == 32) INET_SEG(32); else if (cw == 64) INET_SEG(64); else INET_SEG(256);
+#undef INET_SEG
     return ok();
 }
 int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,
@@ -709,7 +720,11 @@ int pw_embedding_fwd(const float* table, const long long* idx, long rows, int E,
     return ok();
 }
 int pw_embedding_bwd(const float* dout, const long long* idx, long rows, int E, float* dtable, const float* row_scale,
-                     hipStream_t s) {
+                     hipStream_t s, int num_embeddings) {
+    // a small table: thousands of rows land on a handful of table rows and the per-element atomics serialise (100-160 us for
+    // the metadata embeddings of AnticipationRNN); the segment-sum kernel adds them up in LDS first
+    if (num_embeddings > 0 && num_embeddings <= kSegMaxW && rows >= 1024 && rows < (1L << 31))
+        return pw_token_segsum(dout, E, idx, (int)rows, 0, 1, (int)rows, num_embeddings, E, dtable, s, row_scale, 0);
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(rows * E)), dim3(256), 0, s, dout, idx, rows, E, dtable, row_scale);
     return ok();
 }

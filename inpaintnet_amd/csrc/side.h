@@ -21,3 +21,8 @@ bool side_is(hipStream_t s);                         // s is the side stream
 // encoder's chain launches): twin_fork() makes it wait for the main stream's current point, twin_join() the reverse.
 hipStream_t twin_fork(hipStream_t main_stream);      // returns main_stream itself if no stream could be created
 int twin_join(hipStream_t main_stream);
+// `waiter` waits for everything queued on `on` so far (one event)
+int stream_wait(hipStream_t waiter, hipStream_t on);
+// A non-atomic accumulation into `dest` is about to be queued on side stream `s`: if another side stream has queued one into
+// the same tensor since the last join, `s` first waits for that stream (two applications of one module in a step).
+int side_order_dest(const void* dest, hipStream_t s);

@@ -1,4 +1,5 @@
 #include <cstdlib>
+#include <utility>
 #include <vector>
 #include "side.h"
 #include "chain.h"
@@ -16,6 +17,7 @@ bool g_init = false;
 int g_enabled = -1;
 bool g_defer = false;                 // side_join() is a no-op; the caller joins explicitly (side_join_now)
 std::vector<hipEvent_t> g_pool;
+std::vector<std::pair<const void*, int>> g_dests;         // (tensor, side stream) accumulations queued since the last join
 size_t g_next = 0;
 
 hipEvent_t next_event() {
@@ -67,8 +69,15 @@ hipStream_t side_fork(hipStream_t main_stream) {
     return g_sides[i];
 }
 
-void side_set_defer(int on) { g_defer = on != 0; }
-int side_join(hipStream_t main_stream) { return g_defer ? 0 : side_join_now(main_stream); }
+// (g_dests is forgotten where the CALLER's stream has just been ordered behind all side work -- the join at the end of a
+// *_bwd call, the trainer's switch of the join mode around a step -- not in side_join_now, which data-parallel training
+// also uses to order a third stream)
+void side_set_defer(int on) { g_defer = on != 0; g_dests.clear(); }
+int side_join(hipStream_t main_stream) {
+    if (g_defer) return 0;
+    g_dests.clear();
+    return side_join_now(main_stream);
+}
 
 int side_join_now(hipStream_t main_stream) {
     for (int i = 0; i < g_nside; ++i) {
@@ -96,6 +105,31 @@ int twin_join(hipStream_t main_stream) {
     g_twin_dirty = false;
     hipEvent_t e = next_event();
     if (!e || hipEventRecord(e, g_twin) != hipSuccess || hipStreamWaitEvent(main_stream, e, 0) != hipSuccess) return -2;
+    return 0;
+}
+
+int stream_wait(hipStream_t waiter, hipStream_t on) {
+    if (waiter == on) return 0;
+    hipEvent_t e = next_event();
+    return e && hipEventRecord(e, on) == hipSuccess && hipStreamWaitEvent(waiter, e, 0) == hipSuccess ? 0 : -2;
+}
+
+int side_order_dest(const void* dest, hipStream_t s) {
+    int me = -1;
+    for (int i = 0; i < g_nside; ++i)
+        if (s == g_sides[i]) me = i;
+    if (me < 0) return 0;
+    bool known = false;
+    unsigned waited = 0;
+    for (const auto& d : g_dests) {
+        if (d.first != dest) continue;
+        if (d.second == me) known = true;
+        else if (!(waited & (1u << d.second))) {
+            waited |= 1u << d.second;
+            if (stream_wait(s, g_sides[d.second]) != 0) return -2;
+        }
+    }
+    if (!known) g_dests.emplace_back(dest, me);
     return 0;
 }
 

@@ -299,6 +299,7 @@ def linear_bwd(dy, x, W, dW=None, db=None, need_dx=True):
     M, N = dy.shape
     K = W.shape[1]
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device) if need_dx else None
+    _hold(dy, x, W, dW, db)                                  # dW / db run on the side stream
     check(_lib.lib().inet_linear_bwd(ptr(_f32c(dy)), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), M, N, K,
                                      stream_ptr()), "inet_linear_bwd")
     return dx
@@ -339,6 +340,44 @@ def lstm_bwd(W_hh, out, dout, H, reverse, ws, dW_hh=None, db_ih=None, db_hh=None
     return dgi, dh0, dc0
 
 
+def lstm2_ok(B, T, H):
+    return bool(_lib.lib().inet_lstm2_ok(int(B), int(T), int(H)))
+
+
+def lstm2_fwd(gi0_tm, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, H, reverse=False, save=False):
+    """Two stacked layers, zero initial states, pipelined over chunks of time steps (csrc/lstm.hip lstm2_seq_fwd).
+    gi0_tm [T,B,4H] -> (out0, out1 [T,B,H], ws0, ws1), or None when the shape does not qualify."""
+    T, B, _ = gi0_tm.shape
+    dev = gi0_tm.device
+    ws0, ws1 = lstm_ws(B, T, H, save, dev), lstm_ws(B, T, H, save, dev)
+    out0 = torch.empty(T, B, H, dtype=torch.float32, device=dev)
+    out1 = torch.empty(T, B, H, dtype=torch.float32, device=dev)
+    gi1 = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
+    _hold(gi0_tm, gi1, out0, out1, ws0, ws1)                 # the second stream's work is not ordered by the allocator
+    rc = _lib.lib().inet_lstm2_fwd(B, T, H, ptr(_f32c(gi0_tm)), ptr(W_hh0), ptr(b_hh0), ptr(W_ih1), ptr(b_ih1), ptr(W_hh1),
+                                   ptr(b_hh1), int(reverse), ptr(out0), ptr(gi1), ptr(out1), ptr(ws0), ptr(ws1),
+                                   ws0.numel() * 4, int(save), stream_ptr())
+    if rc == 1:
+        return None
+    check(rc, "inet_lstm2_fwd")
+    return out0, out1, ws0, ws1
+
+
+def lstm2_bwd(W_hh0, W_ih1, W_hh1, out0, out1, dout1, H, reverse, ws0, ws1, grads=None):
+    """-> dgi0 [T,B,4H] (dgi1 is consumed inside).  grads: (dW_hh0, db_ih0, db_hh0, dW_ih1, dW_hh1, db_ih1, db_hh1) or None."""
+    T, B, _ = out1.shape
+    dev = out1.device
+    dgi0 = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
+    dgi1 = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
+    dout0 = torch.empty(T, B, H, dtype=torch.float32, device=dev)
+    g = tuple(grads) if grads is not None else (None,) * 7
+    _hold(W_hh0, W_ih1, W_hh1, out0, out1, dout1, dgi0, dgi1, dout0, ws0, ws1, *g)
+    check(_lib.lib().inet_lstm2_bwd(B, T, H, ptr(W_hh0), ptr(W_ih1), ptr(W_hh1), ptr(out0), ptr(out1), ptr(_f32c(dout1)),
+                                    int(reverse), ptr(dgi0), ptr(dgi1), ptr(dout0), *[ptr(x) for x in g], ptr(ws0), ptr(ws1),
+                                    ws0.numel() * 4, stream_ptr()), "inet_lstm2_bwd")
+    return dgi0
+
+
 def embedding_fwd(table, idx, row_scale=None):
     rows = idx.numel()
     E = table.shape[1]
@@ -350,8 +389,9 @@ def embedding_fwd(table, idx, row_scale=None):
 
 def embedding_bwd(dout, idx, dtable, row_scale=None):
     rows = idx.numel()
+    _hold(dout, idx, dtable, row_scale)                      # runs on the side stream
     check(_lib.lib().inet_embedding_bwd(ptr(_f32c(dout)), ptr(_i64c(idx)), rows, dtable.shape[1], ptr(dtable),
-                                        ptr(row_scale), stream_ptr()), "inet_embedding_bwd")
+                                        ptr(row_scale), int(dtable.shape[0]), stream_ptr()), "inet_embedding_bwd")
 
 
 def relu_bwd(dy, y):

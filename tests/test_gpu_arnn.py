@@ -93,6 +93,40 @@ def test_lstm_chain_matches_per_step_launches():
         assert G.rel_err(res[1][i], res[0][i]) < 2e-5, i
 
 
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("B,T", [(32, 200), (7, 97)])
+def test_lstm_two_layer_pipeline_matches_layer_by_layer(B, T, reverse):
+    """inet_lstm2_fwd / _bwd (layer 1 one chunk of time steps behind layer 0 on a second stream, the backward pass the other
+    way round) against the same two layers run one after the other through inet_lstm_fwd / _bwd: outputs, input-side gate
+    gradients and all seven weight / bias gradients; T not a multiple of the chunk, both time directions, a ragged batch."""
+    g = torch.Generator().manual_seed(B * 1000 + T + int(reverse))
+    H = 256
+    assert ops.lstm2_ok(B, T, H)
+    gi0 = (torch.randn(T, B, 4 * H, generator=g) * 0.5).cuda()
+    Wh0, Wi1, Wh1 = [(torch.randn(4 * H, H, generator=g) / 16).cuda() for _ in range(3)]
+    bh0, bi1, bh1 = [(torch.randn(4 * H, generator=g) * 0.1).cuda() for _ in range(3)]
+    dout1 = (torch.randn(T, B, H, generator=g) * 0.1).cuda()
+    # layer by layer
+    o0, _, _, ws0 = ops.lstm_fwd(gi0, Wh0, bh0, H, reverse=reverse, save=True)
+    gi1 = ops.linear_fwd(o0.view(T * B, H), Wi1, bi1).view(T, B, 4 * H)
+    o1, _, _, ws1 = ops.lstm_fwd(gi1, Wh1, bh1, H, reverse=reverse, save=True)
+    ref_g = [torch.zeros_like(x) for x in (Wh0, bh0, bh0, Wi1, Wh1, bh1, bh1)]
+    dgi1, _, _ = ops.lstm_bwd(Wh1, o1, dout1, H, reverse, ws1, ref_g[4], ref_g[5], ref_g[6])
+    do0 = ops.linear_bwd(dgi1.view(T * B, 4 * H), o0.view(T * B, H), Wi1, ref_g[3], None, need_dx=True).view(T, B, H)
+    dgi0, _, _ = ops.lstm_bwd(Wh0, o0, do0.contiguous(), H, reverse, ws0, ref_g[0], ref_g[1], ref_g[2])
+    torch.cuda.synchronize()
+    # pipelined
+    p0, p1, pw0, pw1 = ops.lstm2_fwd(gi0, Wh0, bh0, Wi1, bi1, Wh1, bh1, H, reverse=reverse, save=True)
+    got_g = [torch.zeros_like(x) for x in ref_g]
+    pdgi0 = ops.lstm2_bwd(Wh0, Wi1, Wh1, p0, p1, dout1, H, reverse, pw0, pw1, grads=got_g)
+    torch.cuda.synchronize()
+    assert ops.chain_status() == 0
+    assert G.rel_err(p0.cpu(), o0.cpu()) < 2e-5 and G.rel_err(p1.cpu(), o1.cpu()) < 2e-5
+    assert G.rel_err(pdgi0.cpu(), dgi0.cpu()) < 1e-4
+    for i, (a, b) in enumerate(zip(got_g, ref_g)):
+        assert G.rel_err(a.cpu(), b.cpu()) < 1e-4, i
+
+
 @pytest.mark.parametrize("name", ["small", "full"])
 def test_arnn_teacher_forced_step_golden(name):
     fx = G.load("arnn_" + name)

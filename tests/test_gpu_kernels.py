@@ -128,6 +128,31 @@ def test_gemm_batched_weight_gradients(M, N, K, nb, label):
     assert relmax(Cd2, ref) < 2e-5
 
 
+def test_repeated_weight_gradient_accumulation_across_side_streams():
+    """A module applied many times in one step (a per-tick free-running pass): every application's weight-gradient product
+    is leaf work on one of the rotating side streams and adds (not atomically) into the same tensor -- the library orders
+    them (side_order_dest).  60 products into one dW with deferred joins, against the sum formed in float64."""
+    g = torch.Generator().manual_seed(99)
+    M, N, K, reps = 2048, 512, 256, 60
+    W = torch.randn(N, K, generator=g).to(DEV)
+    dys = [(torch.randn(M, N, generator=g) * 0.1).to(DEV) for _ in range(4)]
+    xs = [torch.randn(M, K, generator=g).to(DEV) for _ in range(4)]
+    ref = sum(dys[i % 4].double().t() @ xs[i % 4].double() for i in range(reps)).cpu()
+    refb = sum(dys[i % 4].double().sum(0) for i in range(reps)).cpu()
+    for trial in range(3):
+        dW = torch.zeros(N, K, device=DEV)
+        db = torch.zeros(N, device=DEV)
+        ops.side_defer(True)
+        try:
+            for i in range(reps):
+                ops.linear_bwd(dys[i % 4], xs[i % 4], W, dW, db, need_dx=(i % 5 == 0))
+        finally:
+            ops.side_defer(False)
+        torch.cuda.synchronize()
+        assert relmax(dW, ref) < 2e-5, trial
+        assert relmax(db, refb) < 2e-5, trial
+
+
 @pytest.mark.parametrize("bkm", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(6144, 1536, 1024), (6144, 1024, 1536), (6144, 512, 1536), (384, 256, 64),
                                    (192, 64, 192), (1152, 768, 320)])

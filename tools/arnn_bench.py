@@ -1,12 +1,10 @@
-"""AnticipationRNN training-step time with and without chain kernels (bench.py arnn_extra)."""
-import os, sys, time
+#!/usr/bin/env python3
+"""AnticipationRNN training step alone (bench.py's `anticipation_rnn_train` extra): python tools/arnn_bench.py [steps]"""
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import bench
-from inpaintnet_amd import ops
-for chain in (1, 0, 1):
-    ops.set_option(4, chain)
-    t0 = time.time()
-    r = bench.arnn_extra(steps=6, warmup=2)
-    torch.cuda.synchronize()
-    print("chain", chain, r["anticipation_rnn_train"]["ms_per_step"], "ms/step", "status", ops.chain_status(), "wall %.1fs" % (time.time() - t0), flush=True)
+import bench  # noqa: E402
+
+print(json.dumps(bench.arnn_extra(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20, warmup=3)))
