@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 (contract in the task brief) carrying
   parity_checked one un-timed step at the bench's own batch compared with the oracle (loss, logits, every gradient).
 """
 import argparse
+import collections
 import csv
 import json
 import os
@@ -382,7 +383,9 @@ def pmc_key(label):
         H, ms = f["H"], f["ms"]
         groups = f["np"] * math.ceil(f["B"] / (16 * ms))
         grid = 256 * 8 * (H // 16) * math.ceil(groups / 8)
-        return f"gru_chain_{'fwd' if fwd else 'bwd'}_kernel<{ms}, {H // 64 if fwd else 3 * H // 64}>|g{grid}"
+        if fwd:                                          # third parameter: the build for two launches per CU ("ms4x2")
+            return f"gru_chain_fwd_kernel<{ms}, {H // 64}, {2 if re.search(r'ms[0-9]+x2', label) else 1}>|g{grid}"
+        return f"gru_chain_bwd_kernel<{ms}, {3 * H // 64}>|g{grid}"
     if label.startswith("gru_fwd"):
         grid = 256 * f["np"] * math.ceil(f["B"] / (16 * f["ms"])) * (f["H"] // 16)
         return f"gru_step_fwd_kernel<{tf(f['x'])}, {f['ms']}, {tf(f['pk'])}>|g{grid}"
@@ -391,10 +394,10 @@ def pmc_key(label):
         return f"gru_step_bwd_kernel<{f['ms']}, {f['nc']}, {tf(f['pk'])}>|g{grid}"
     if label == "adam":
         return "adam_kernel|"
-    m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) ([tdk])(\d+)x(\d+) s(\d+)", label)
+    m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) ([tdk])(\d+)x(\d+) s(\d+)(?: e\d+)?(?: x(\d+))?", label)
     if m:
-        M, N, K, a, b, kind, bm, bn, sp = m.groups()
-        grid = 256 * math.ceil(int(N) / int(bn)) * math.ceil(int(M) / int(bm)) * int(sp)
+        M, N, K, a, b, kind, bm, bn, sp, nb = m.groups()
+        grid = 256 * math.ceil(int(N) / int(bn)) * math.ceil(int(M) / int(bm)) * int(sp) * int(nb or 1)   # xN: N products per launch
         if kind == "t":                                  # LDS-tiled
             return f"gemm_kernel<{int(bm) // 64}, {int(bn) // 64}, {tf(a == 'T')}, {tf(b == 'N')}>|g{grid}"
         if kind == "k":                                  # workgroup split-K
@@ -415,12 +418,16 @@ def roofline(step):
         except Exception:
             pmc = {}
     kern = pmc.get("kernels", {})
+    shared = collections.Counter(pmc_key(row["kernel"]) for row in table)
     for row in table:
         key = pmc_key(row["kernel"])
         hit = None
         if key:
-            hit = (kern.get(key + "#" + row["kernel"]) or kern.get(key)
-                   or next((v for k, v in kern.items() if k.startswith(key)), None))
+            hit = kern.get(key + "#" + row["kernel"])
+            # a kernel|grid key behind several shapes whose launch order differs between steps (teacher-forced steps add
+            # T = 6 launches of the forward chain kernel) has no per-shape PMC figure: null rather than the mixture
+            if hit is None and shared[key] == 1:
+                hit = kern.get(key) or next((v for k, v in kern.items() if k.startswith(key)), None)
         if hit:
             row["traffic_mbytes_per_launch"] = hit.get("hbm_mbytes_per_launch")
             row["pmc_key"] = key
