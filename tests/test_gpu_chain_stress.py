@@ -134,3 +134,29 @@ def test_staged_encoder_backward_equals_one_pass():
         for name, off, shape in table:
             n = int(np.prod(shape))
             assert _rel(g1[off:off + n], g0[off:off + n]) < 1e-5 or float(g0[off:off + n].abs().max()) == 0.0, (B, name)
+
+
+def test_lstm_tagged_handoff_repeated():
+    """The LSTM forward chain of the two-layer pipeline hands the state over without a counter (members poll the exchanged
+    fragments for a sentinel, csrc/lstm.hip lstm_chain_fwd_tag_kernel).  60 runs of the AnticipationRNN shape (32 x 384, two
+    layers, both directions) must reproduce the first run bit for bit and agree with the counter-based single-layer chain."""
+    g = torch.Generator().manual_seed(31)
+    B, T, H = 32, 384, 256
+    gi0 = (torch.randn(T, B, 4 * H, generator=g) * 0.5).cuda()
+    Wh0, Wi1, Wh1 = [(torch.randn(4 * H, H, generator=g) / 16).cuda() for _ in range(3)]
+    bh0, bi1, bh1 = [(torch.randn(4 * H, generator=g) * 0.1).cuda() for _ in range(3)]
+    for reverse in (False, True):
+        o0, _, _, _ = ops.lstm_fwd(gi0, Wh0, bh0, H, reverse=reverse)
+        gi1 = ops.linear_fwd(o0.view(T * B, H), Wi1, bi1).view(T, B, 4 * H)
+        o1, _, _, _ = ops.lstm_fwd(gi1, Wh1, bh1, H, reverse=reverse)
+        torch.cuda.synchronize()
+        first = None
+        for it in range(30):
+            p0, p1, _, _ = ops.lstm2_fwd(gi0, Wh0, bh0, Wi1, bi1, Wh1, bh1, H, reverse=reverse)
+            torch.cuda.synchronize()
+            assert ops.chain_status() == 0, it
+            if first is None:
+                first = (p0.clone(), p1.clone())
+                assert float((p0 - o0).abs().max()) < 2e-5 and float((p1 - o1).abs().max()) < 2e-5
+            else:
+                assert torch.equal(p0, first[0]) and torch.equal(p1, first[1]), (reverse, it)
