@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
 // has read all of step t - 1, so all members have finished step t - 2's consumers).  Per step this drops the producer's
 // store drain + barrier + atomic and the consumer's counter round trip + barrier: what is left is one store -> load
 // latency through L2.  The host arms slots 0 and 1 (memset 0xFF) and packs the initial state into slot 3.
-// A lane's 16-byte element comes from ONE 16-byte store of one producer lane, so it is either old (sentinel) or complete.
+// A lane's 16-byte element comes from ONE 16-byte store of one producer lane; all four words are checked, so a torn view of
+// that store would only delay the consumer, never feed it a sentinel.
 template <int MS, int SQ>                          // SQ = H/64: k-steps of 16 per wave
 __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArgs P) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * MS * 256];
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
                 for (int si = 0; si < SQ; ++si) {
                     A[ms][si] = chain::ld16_sc1(rs, fo[ms] + si * 1024, in_base);
                     const chain::u32x4 bits = __builtin_bit_cast(chain::u32x4, A[ms][si]);
-                    ok = ok && bits[0] != 0xffffffffu && bits[3] != 0xffffffffu;
+                    ok = ok && bits[0] != 0xffffffffu && bits[1] != 0xffffffffu && bits[2] != 0xffffffffu && bits[3] != 0xffffffffu;
                 }
             if (__all(ok)) break;
             if (spins > chain::kSpinLimit ||
