@@ -21,6 +21,8 @@ struct DecodeChainArgs {
     float* weights; long long* samples;           // outputs [B,T,V], [B,1,T]
     unsigned* counters; chain::Status status;
     int prezeroed;                                // the sync words are already zero (gru_chain.h kSyncAreas)
+    int Bs;                                       // rows of the FULL batch when this launch covers a chunk of its rows (0: B):
+                                                  // the stride of the [T,.,H] / [beats,.,.] buffers (cgi, ht0, mask, saves, outputs)
     // training (free-running forward with backward saves): everything below may be null for inference
     const float* mask;                            // [T,B,H] dropout mask of the layer-0 output (layer 1 sees h0 * mask)
     float* hx0m;                                  // [beats][pk(B,H)] exchange buffer of the masked h0 (needed iff mask)

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     int group, member;
     chain::decode_block(blockIdx.x, P.members, group, member);
     const int row0 = group * 16 * MS, B = P.B, T = P.T, V = P.V;
+    const int Bs = P.Bs ? P.Bs : B;                            // row stride of the time / beat-major buffers (a row chunk of a larger batch)
     if (row0 >= B) return;
     __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x, lane = t & 63;
@@ -142,12 +143,12 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
         float c0[MS][3], mk[MS];
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
-            mk[p] = masked ? P.mask[((long)tick * B + brow[p]) * H + jc] : 1.f;
+            mk[p] = masked ? P.mask[((long)tick * Bs + brow[p]) * H + jc] : 1.f;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) c0[p][g] = P.cgi[((long)beat * B + brow[p]) * 3 * H + g * H + jc];
+            for (int g = 0; g < 3; ++g) c0[p][g] = P.cgi[((long)beat * Bs + brow[p]) * 3 * H + g * H + jc];
             if (j == 0) {                                      // hidden states restart from the beat embedding
-                hp0[p] = P.ht0[((long)beat * B + brow[p]) * 2 * H + jc];
-                hp1[p] = P.ht0[((long)beat * B + brow[p]) * 2 * H + H + jc];
+                hp0[p] = P.ht0[((long)beat * Bs + brow[p]) * 2 * H + jc];
+                hp1[p] = P.ht0[((long)beat * Bs + brow[p]) * 2 * H + H + jc];
             }
         }
         if (tick > 0 && !chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;   // tokens of tick-1
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
 #pragma unroll
             for (int p = 0; p < MS; ++p) {
                 if (row0 + ((t + 256 * p) >> 4) < B) {
-                    const long o = ((long)tick * B + brow[p]) * H + jc;
+                    const long o = ((long)tick * Bs + brow[p]) * H + jc;
                     if (P.sv0) {
 #pragma unroll
                         for (int a = 0; a < 5; ++a) P.sv0[o + a * P.sv_stride] = sv[p][a];
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
 #pragma unroll
             for (int p = 0; p < MS; ++p) {
                 if (row0 + ((t + 256 * p) >> 4) < B) {
-                    const long o = ((long)tick * B + brow[p]) * H + jc;
+                    const long o = ((long)tick * Bs + brow[p]) * H + jc;
                     if (P.sv1) {
 #pragma unroll
                         for (int a = 0; a < 5; ++a) P.sv1[o + a * P.sv_stride] = sv[p][a];

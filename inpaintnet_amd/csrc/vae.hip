@@ -281,8 +281,15 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     // Which kernels will run: the chain kernels read W_hh / W_ih as stored, only the per-step kernels want the
     // fragment-major twins -- each is packed only if its consumer runs.
     const bool beats_chained = pk && beat_chain && gru_chain_ok(H, B, nb, 1);
-    const bool fused_decode = pk && !teacher_forced && !multinomial_seed && w.wpk_out && decode_chain_ok(B, H, V, T, G) &&
-                              ((!save && !mask_tick) || train_chain);
+    const bool fused_shape = pk && !teacher_forced && !multinomial_seed && w.wpk_out && ((!save && !mask_tick) || train_chain);
+    // batches beyond one resident launch (LatentRNN decodes 512 measures per step): the rows are independent, so the fused
+    // kernel runs over chunks of 256 rows, one launch after the other (INET_DECODE_CHUNKS=0: per-tick launches)
+    constexpr int kDecodeChunk = 256;
+    static const bool dec_chunks = [] { const char* v = std::getenv("INET_DECODE_CHUNKS"); return !(v && v[0] == '0'); }();
+    const bool fused_whole = fused_shape && decode_chain_ok(B, H, V, T, G);
+    const bool fused_chunked = fused_shape && !fused_whole && dec_chunks && B > kDecodeChunk && B % kDecodeChunk == 0 &&
+                               decode_chain_ok(kDecodeChunk, H, V, T, G);
+    const bool fused_decode = fused_whole || fused_chunked;
     // teacher-forced ticks: every input token is known and the 4 beats are independent, so each tick layer is a chain of
     // G steps over the beats as problems -- `npl` beats per launch, as many as fit the chip at once (2 at B = 256)
     static const bool tf_chain = [] { const char* v = std::getenv("INET_TF_CHAIN"); return !(v && v[0] == '0'); }();
@@ -337,7 +344,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
 
     // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
     INET_TRY(linear_fwd(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU, s));
-    if (pk && !ticks_chained)                                  // packed initial tick hiddens: [layer][beat]
+    if (pk && !ticks_chained && !fused_chunked)                // packed initial tick hiddens: [layer][beat]
         for (int l = 0; l < 2; ++l)
             INET_TRY(pw_pack_frag(w.ht0 + (long)l * H, 2L * H, B, H, w.ht0pk + (long)l * nb * pkh, 0, nb, (long)B * 2 * H, pkh, s));
     INET_TRY(linear_fwd(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU, s));
@@ -443,22 +450,31 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     if (fused_decode) {
         // all 24 free-running ticks (layer 0, layer 1, projection, argmax, token feedback) in ONE launch: inference, and
         // the free-running half of the training steps (dropout mask between the layers, backward saves written on the way)
-        DecodeChainArgs a{};
-        a.B = B; a.H = H; a.T = T; a.G = G; a.V = V;
-        a.W_hh0 = p + L.tick[0].w_hh; a.b_hh0 = p + L.tick[0].b_hh;
-        a.cgi = w.cgi; a.table = w.table;
-        a.W_ih1 = p + L.tick[1].w_ih; a.b_ih1 = p + L.tick[1].b_ih; a.W_hh1 = p + L.tick[1].w_hh; a.b_hh1 = p + L.tick[1].b_hh;
-        a.W_out = p + L.out_w; a.b_out = p + L.out_b;
-        a.ht0 = w.ht0; a.ht0pk = w.ht0pk;
-        a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
-        a.weights = weights; a.samples = samples;
-        a.counters = w.sync + 2 * kChainSyncWords; a.prezeroed = 1;
-        if (mask_tick) { a.mask = mask_tick; a.hx0m = w.hm0pk; }
-        if (save) {
-            a.sv0 = w.svt0; a.sv1 = w.svt1; a.sv_stride = (long)T * BH;
-            a.h0out = mask_tick ? w.h0m : w.h0seq; a.h1seq = w.h1seq;
+        const int Bc = fused_whole ? B : kDecodeChunk;
+        const long pkc = (long)pk_floats(Bc, H);
+        for (int r0 = 0; r0 < B; r0 += Bc) {
+            if (fused_chunked)                                 // the chunk's initial tick hiddens, fragment-major [layer][beat]
+                for (int l = 0; l < 2; ++l)
+                    INET_TRY(pw_pack_frag(w.ht0 + (long)r0 * 2 * H + (long)l * H, 2L * H, Bc, H, w.ht0pk + (long)l * nb * pkc, 0, nb,
+                                          (long)B * 2 * H, pkc, s));
+            DecodeChainArgs a{};
+            a.B = Bc; a.Bs = B; a.H = H; a.T = T; a.G = G; a.V = V;
+            a.W_hh0 = p + L.tick[0].w_hh; a.b_hh0 = p + L.tick[0].b_hh;
+            a.cgi = w.cgi + (long)r0 * 3 * H; a.table = w.table;
+            a.W_ih1 = p + L.tick[1].w_ih; a.b_ih1 = p + L.tick[1].b_ih; a.W_hh1 = p + L.tick[1].w_hh; a.b_hh1 = p + L.tick[1].b_hh;
+            a.W_out = p + L.out_w; a.b_out = p + L.out_b;
+            a.ht0 = w.ht0 + (long)r0 * 2 * H; a.ht0pk = w.ht0pk;
+            a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
+            a.weights = weights + (long)r0 * T * V; a.samples = samples + (long)r0 * T;
+            a.counters = w.sync + 2 * kChainSyncWords; a.prezeroed = r0 == 0;   // (later chunks: the launcher zeroes the area)
+            if (mask_tick) { a.mask = mask_tick + (long)r0 * H; a.hx0m = w.hm0pk; }
+            if (save) {
+                a.sv0 = w.svt0 + (long)r0 * H; a.sv1 = w.svt1 + (long)r0 * H; a.sv_stride = (long)T * BH;
+                a.h0out = (mask_tick ? w.h0m : w.h0seq) + (long)r0 * H; a.h1seq = w.h1seq + (long)r0 * H;
+            }
+            INET_TRY(launch_decode_chain(a, s));
         }
-        return launch_decode_chain(a, s);
+        return 0;
     }
     for (int t = 0; t < T; ++t) {
         const int i = t / G, j = t % G;

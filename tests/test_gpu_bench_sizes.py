@@ -199,6 +199,8 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
     assert sum(l == "gru_chain_fwd ms4x2 np2 T24 B256 H512" for l in labels) == 16, sorted(set(l for l in labels if l.startswith("gru")))
     assert "gru_chain_fwd ms2 np2 T6 B128 H512" in labels and "gru_chain_bwd ms2 np2 T6 B128 H512" in labels   # contexts: 8 groups of 32 rows
     assert any(l.startswith("gru_fwd x0") and l.endswith("B128 H1024") for l in labels)      # generator
+    # the frozen decoder's 512 free-running rows: the fused decode kernel over two chunks of 256 rows (with backward saves)
+    assert sum(l == "decode_chain_train ms2 T24 B256 H512 V48" for l in labels) == 2, sorted(set(l for l in labels if l.startswith("dec")))
     assert any(l.startswith("gru_bwd") and l.endswith("B128 H1024") for l in labels)
 
     # masks in call order: encoder (T, 16B, 2H); context past (np, B, 2H); context future; generator (nt, B, 4H);
