@@ -1,0 +1,45 @@
+"""bench.py's mapping from the library's per-launch profile labels to the kernel|grid keys of the rocprofv3 PMC summary
+(tools/pmc_summary.py): the `traffic` figure of the bench line is looked up through it, so a label the launchers change
+must keep resolving to the kernel instantiation and grid that really ran."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("label,key", [
+    ("M1536 N512 K6144 TN d192x128 s8 e0", "gemm_tn_direct_kernel<3, 2>|g65536"),
+    ("M1536 N512 K6144 TN d192x128 s4 e0 x2", "gemm_tn_direct_kernel<3, 2>|g65536"),          # two products, half the split
+    ("M1536 N1024 K6144 TN d192x128 s2 e0 x2", "gemm_tn_direct_kernel<3, 2>|g65536"),
+    ("M6144 N1536 K1024 NT d192x192 s1 e0", "gemm_kc_direct_kernel<6, 6, false>|g65536"),
+    ("M6144 N1024 K1536 NN d192x128 s1 e4", "gemm_kc_direct_kernel<6, 4, true>|g65536"),
+    ("M256 N1024 K2048 NT k32x32 s1 e1", "gemm_ks_kernel<2, 2, false, false>|g65536"),
+    ("M48 N1536 K10 NT t64x64 s1 e0", "gemm_kernel<1, 1, false, false>|g6144"),
+    ("gru_chain_fwd ms4 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 1>|g65536"),
+    ("gru_chain_fwd ms4x2 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 2>|g65536"),         # two launches per CU
+    ("gru_chain_bwd ms8 np4 T6 B256 H512", "gru_chain_bwd_kernel<8, 24>|g65536"),
+    ("gru_chain_bwd ms2 np2 T6 B128 H512", "gru_chain_bwd_kernel<2, 24>|g65536"),
+    ("adam", "adam_kernel|"),
+])
+def test_profile_label_to_pmc_key(bench, label, key):
+    assert bench.pmc_key(label) == key
+
+
+def test_committed_pmc_file_has_the_dominant_kernel(bench):
+    """The traffic figure the bench line quotes for its dominant kernel comes from this committed file."""
+    import json
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
+    label = "M1536 N512 K6144 TN d192x128 s4 e0 x2"
+    hit = pmc[bench.pmc_key(label) + "#" + label]
+    assert 100.0 < hit["hbm_mbytes_per_launch"] < 200.0      # 107 MB algorithmic (two 53.5 MB products)
+    assert pmc["adam_kernel|g1048576"]["hbm_mbytes_per_launch"] == pytest.approx(494.7, rel=0.01)   # the calibration point
