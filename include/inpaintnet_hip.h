@@ -246,10 +246,20 @@ int inet_set_option(int key, int value);
  * (default: shared-strip direct kernels for the big products, workgroup split-K for the medium / small ones), 2 = the
  * direct kernels whenever the shape qualifies (test hook), 3 = direct kernels only (no split-K), 4 = split-K first, also for
  * the long weight-gradient products. */
+/* key 6 = test hook: value 1 arms ONE injected fault -- the next forward GRU chain launch loses a workgroup, its group runs
+ * into the bounded spin (~0.4 s) and inet_chain_status() turns non-zero: lets the failure path (optimizer skip, fallback to
+ * per-step kernels) be tested on a healthy GPU. */
 int inet_side_join(void* stream);
+/* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.
+ * Unlike inet_side_join nothing is consumed: the issuing stream still joins the same work at its own next join (a
+ * data-parallel bucket's all-reduce stream orders itself behind the leaf GEMMs this way without the backward pass waiting). */
+int inet_side_wait(void* stream);
 /* Number of chain-kernel workgroups that gave up waiting for their group since the last reset (0 = healthy; every
- * in-kernel spin is bounded, so a broken hand-off shows up here instead of hanging the GPU).  Meaningful after the
- * stream has been synchronised.  -2: the host-mapped counter could not be allocated. */
+ * in-kernel spin is bounded, so a broken hand-off shows up here instead of hanging the GPU).  Complete after the
+ * stream has been synchronised; a non-zero value read earlier is already a definite failure (the counter lives in
+ * host-mapped memory: reading it costs nothing and needs no synchronisation).  While it is non-zero inet_adam_step
+ * leaves parameters and moments untouched (a device-side twin of the counter is read by the kernel), so a failed step
+ * can never reach the weights.  reset != 0 clears both (synchronises the device).  -2: the counter could not be allocated. */
 int inet_chain_status(int reset);
 
 /* ---- measurement hooks (bench.py roofline line; not part of the reference surface) --------------- */

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "inet_split_score": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "inet_set_option": (C.c_int, [_I, _I]),
     "inet_side_join": (C.c_int, [_P]),
+    "inet_side_wait": (C.c_int, [_P]),
     "inet_chain_status": (C.c_int, [_I]),
     "inet_prof_enable": (C.c_int, [_I]),
     "inet_prof_dump": (C.c_int, [C.c_char_p]),

@@ -375,6 +375,7 @@ int inet_set_option(int key, int value) {
     if (key == 2) { if (value < -1 || value > 4) return -1; gemm_set_force(value, -1); return 0; }
     if (key == 3) { if (value < 0) return -1; gemm_set_force(-2, value); return 0; }
     if (key == 5) { if (value < 0 || value > 4) return -1; gemm_set_direct(value); return 0; }
+    if (key == 6) { chain_arm_fault(value); return 0; }
     return -1;
 }
 
@@ -382,11 +383,12 @@ int inet_chain_status(int reset) {
     unsigned* p = chain_host_status();
     if (!p) return -2;
     const int v = (int)__atomic_load_n(p, __ATOMIC_RELAXED);
-    if (reset) __atomic_store_n(p, 0u, __ATOMIC_RELAXED);
+    if (reset && v != 0 && chain_status_reset() != 0) return -2;   // (device-side twin too: needs the device idle)
     return v;
 }
 
 int inet_side_join(void* stream) { return side_join_now((hipStream_t)stream); }
+int inet_side_wait(void* stream) { return side_wait_on((hipStream_t)stream); }
 
 int inet_gru_step(int B, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
                   float* h_new, float* sv5, void* stream) {

@@ -66,19 +66,24 @@ __device__ __forceinline__ void arrive(unsigned* counter) {
 // `flag` is one word of LDS; consecutive waits must use different words (flag[step & 1]): a fast wave may enter the
 // next wait while a slow one still reads this one's word.
 // `status` = {device word inside the workspace (aborts the other workgroups of the launch quickly), host-mapped word
-// (chain_host_status(): what inet_chain_status() reports)}.
+// (chain_host_status(): what inet_chain_status() reports), process-wide device word (chain_dev_status(): what the
+// optimizer kernel reads -- a step whose chain launch timed out never updates the weights)}.
 #ifndef INET_CHAIN_POLL_SLEEP
 #define INET_CHAIN_POLL_SLEEP 1                   // s_sleep units (64 clocks) between two polls of the group counter
 #endif
-struct Status { unsigned* dev; unsigned* host; };
+struct Status { unsigned* dev; unsigned* host; unsigned* gdev; };
+__device__ __forceinline__ void raise_timeout(Status status) {
+    __hip_atomic_store(status.dev, (unsigned)ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (status.gdev) __hip_atomic_store(status.gdev, (unsigned)ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (status.host) __hip_atomic_fetch_add(status.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ bool wait_group(unsigned* counter, unsigned target, Status status, unsigned* flag) {
     if (threadIdx.x == 0) {
         unsigned ok = 1, spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (++spins > kSpinLimit ||
                 ((spins & 63) == 0 && __hip_atomic_load(status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ST_OK)) {
-                __hip_atomic_store(status.dev, (unsigned)ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (status.host) __hip_atomic_fetch_add(status.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                raise_timeout(status);
                 ok = 0;
                 break;
             }
@@ -190,3 +195,18 @@ int chain_enabled();
 void chain_set_enabled(int on);
 // host-mapped failure counter shared by every chain launch of the process (null if it could not be allocated)
 unsigned* chain_host_status();
+// process-wide device-memory twin of that counter (null if it could not be allocated): non-zero after any timeout, read by
+// the Adam kernel (pw_adam) so that a failed step leaves the parameters untouched; inet_chain_status(reset) clears both
+unsigned* chain_dev_status();
+int chain_status_reset();
+inline chain::Status chain_status_for(unsigned* dev_word) { return chain::Status{dev_word, chain_host_status(), chain_dev_status()}; }
+// Workgroups of ONE chain launch that are guaranteed to be resident at the same time on the current device: its compute
+// units (hipDeviceAttributeMultiprocessorCount, cached per device) x one workgroup -- the chain kernels are built for one
+// wave per SIMD (264..512 registers), so a CU never holds two of them.  A launch with more workgroups than this would
+// leave members queued behind spinning ones: the *_chain_ok() predicates refuse it and the caller takes the per-step
+// path.  (MI355X: 256.  A partition, a smaller part or INET_CHAIN_CUS=n gives n.)  What the query cannot see -- a CU
+// mask, another process on the same GPU -- is caught by the bounded spin and reported through inet_chain_status().
+int chain_capacity();
+// test hook (inet_set_option key 6): arm a fault for the next forward GRU chain launch; chain_take_fault() returns and clears it
+void chain_arm_fault(int on);
+int chain_take_fault();

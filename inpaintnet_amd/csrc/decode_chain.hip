@@ -311,7 +311,7 @@ inline int groups_of(int B) { const int ms = rows_ms(B); return (B + 16 * ms - 1
 
 bool decode_chain_ok(int B, int H, int V, int T, int G) {
     if (!chain_enabled() || (H != 256 && H != 512) || B < 1 || V % 16 != 0 || V > 64 || T % G != 0) return false;
-    if (groups_of(B) > kDecodeMaxGroups || groups_of(B) * (H / 16) > 256) return false;   // every workgroup resident at once
+    if (groups_of(B) > kDecodeMaxGroups || groups_of(B) * (H / 16) > chain_capacity()) return false;   // every workgroup resident at once
     static const bool off = [] { const char* v = std::getenv("INET_DECODE_CHAIN"); return v && v[0] == '0'; }();
     if (off) return false;
     const int ms = rows_ms(B);
@@ -327,9 +327,8 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
     if (!decode_chain_ok(a.B, a.H, a.V, a.T, a.G)) return -1;
     const int ms = rows_ms(a.B), groups = (a.B + 16 * ms - 1) / (16 * ms);
     a.members = a.H / 16;
-    a.status.host = chain_host_status();
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kDecodeSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    a.status.dev = a.counters + kDecodeStatusWord;
+    a.status = chain_status_for(a.counters + kDecodeStatusWord);
     const size_t lds = decode_chain_lds_bytes(a.B, a.H);
     char label[72];
     const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;

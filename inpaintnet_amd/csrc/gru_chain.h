@@ -32,6 +32,8 @@ struct GruChainFwdProb {
 };
 struct GruChainFwd {
     int H, B, T, nprob, tiles_per_prob, members, prio;
+    int fault;                                    // test hook (inet_set_option key 6): workgroup 0 leaves at once, so its
+                                                  // group runs into the bounded spin and the failure path can be tested
     int shared_chip;                              // this launch runs beside another chain launch (two workgroups per CU):
                                                   // the 256-register build of the kernel
     GruChainFwdProb p[4];

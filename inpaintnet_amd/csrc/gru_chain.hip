@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
     if (group >= A.nprob * A.tiles_per_prob) return;
+    if (A.fault && blockIdx.x == 0) return;        // injected fault (test hook)
     if (A.prio) __builtin_amdgcn_s_setprio(3);     // the chain's waves are mostly parked; when they have work they go first
     const GruChainFwdProb& P = A.p[group / A.tiles_per_prob];
     const int row0 = (group % A.tiles_per_prob) * 16 * MS;
@@ -325,7 +326,7 @@ int rows_ms(int B, int H, int nprob) {
     if (force > 0) return B <= 16 ? 1 : (B <= 32 ? 2 : 4);                 // the fixed rule of the first chain kernels
     for (int ms = 1; ms <= 4; ms *= 2) {
         const int groups = nprob * ((B + 16 * ms - 1) / (16 * ms));
-        if (groups * (H / 16) <= 256 && groups <= kChainMaxGroups) return ms;
+        if (groups * (H / 16) <= chain_capacity() && groups <= kChainMaxGroups) return ms;
     }
     return 4;
 }
@@ -341,7 +342,7 @@ bool gru_chain_ok(int H, int B, int T, int nprob) {
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;   // the kernels index with 32-bit element offsets
     if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
     const int ms = rows_ms(B, H, nprob), tiles = (B + 16 * ms - 1) / (16 * ms);
-    return nprob * tiles * (H / 16) <= 256 && nprob * tiles <= kChainMaxGroups;   // every workgroup resident at once
+    return nprob * tiles * (H / 16) <= chain_capacity() && nprob * tiles <= kChainMaxGroups;   // every workgroup resident at once
 }
 
 // Backward chains may give a workgroup two 64-row tiles (MS = 8) when one per workgroup would need more than 256
@@ -349,14 +350,14 @@ bool gru_chain_ok(int H, int B, int T, int nprob) {
 int rows_ms_bwd(int H, int B, int nprob) {
     const int ms = rows_ms(B, H, nprob);
     static const bool wide = [] { const char* e = std::getenv("INET_CHAIN_WIDE"); return !(e && e[0] == '0'); }();
-    if (wide && ms == 4 && B >= 128 && nprob * ((B + 63) / 64) * (H / 16) > 256) return 8;
+    if (wide && ms == 4 && B >= 128 && nprob * ((B + 63) / 64) * (H / 16) > chain_capacity()) return 8;
     return ms;
 }
 bool gru_chain_bwd_ok(int H, int B, int T, int nprob) {
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;
     if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
     const int ms = rows_ms_bwd(H, B, nprob), tiles = (B + 16 * ms - 1) / (16 * ms);
-    return nprob * tiles * (H / 16) <= 256 && nprob * tiles <= kChainMaxGroups;
+    return nprob * tiles * (H / 16) <= chain_capacity() && nprob * tiles <= kChainMaxGroups;
 }
 
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
@@ -366,10 +367,10 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     a.members = a.H / 16;
     const int groups = a.nprob * a.tiles_per_prob;
     if (groups > kChainMaxGroups) return -1;
-    a.status.host = chain_host_status();
     a.prio = chain_prio();
+    a.fault = chain_take_fault();
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    a.status.dev = a.counters + kChainStatusWord;
+    a.status = chain_status_for(a.counters + kChainStatusWord);
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_fwd ms%d%s np%d T%d B%d H%d", ms, a.shared_chip && ms == 4 ? "x2" : "", a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;
@@ -391,10 +392,9 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
     a.members = a.H / 16;
     const int groups = a.nprob * a.tiles_per_prob;
     if (groups > kChainMaxGroups) return -1;
-    a.status.host = chain_host_status();
     a.prio = chain_prio();
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    a.status.dev = a.counters + kChainStatusWord;
+    a.status = chain_status_for(a.counters + kChainStatusWord);
     char label[72];
     std::snprintf(label, sizeof label, "gru_chain_bwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;

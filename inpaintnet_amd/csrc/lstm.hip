@@ -341,10 +341,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
             if (__all(ok)) break;
             if (spins > chain::kSpinLimit ||
                 ((spins & 63) == 63 && __hip_atomic_load(P.status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK)) {
-                if (lane == 0) {
-                    __hip_atomic_store(P.status.dev, (unsigned)chain::ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (P.status.host) __hip_atomic_fetch_add(P.status.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
+                if (lane == 0) chain::raise_timeout(P.status);
                 break;                             // carry on with what is there: the host reports the launch as failed
             }
             __builtin_amdgcn_s_sleep(1);
@@ -543,14 +540,14 @@ inline int chain_ms(int B, int H) {
     if (force == 1 || force == 2 || force == 4) return force;
     for (int ms = 1; ms <= 4; ms *= 2) {
         const int groups = (B + 16 * ms - 1) / (16 * ms);
-        if (groups * (H / 16) <= 256 && groups <= 32) return ms;
+        if (groups * (H / 16) <= chain_capacity() && groups <= 32) return ms;
     }
     return 4;
 }
 inline bool lstm_chain_ok(int B, int H) {
     if (!chain_enabled() || (H != 256 && H != 512)) return false;
     const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
-    return groups * (H / 16) <= 256 && groups <= 32;   // every workgroup of the launch must be resident at once
+    return groups * (H / 16) <= chain_capacity() && groups <= 32;   // every workgroup of the launch must be resident at once
 }
 
 int launch_fwd(const LstmFwdArgs& a, hipStream_t s) {
@@ -605,7 +602,7 @@ int lstm_seq_fwd(int B, int T, int H, const float* gi, const float* W_hh, const 
         a.gi = gi; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = c0 ? c0 : w.zeros;
         a.out = out; a.cseq = w.cseq;
         if (save) { a.sv = w.sv; a.sv_stride = TBH; }
-        a.hx = w.hx; a.counters = w.sync; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
+        a.hx = w.hx; a.counters = w.sync; a.status = chain_status_for(w.sync + kStatusWord);
         char label[64];
         std::snprintf(label, sizeof label, "lstm_chain_fwd ms%d T%d B%d H%d", ms, T, B, H);
         ProfScope prof(PROF_GRU_FWD, 2.0 * T * B * 4.0 * H * H, s, label,
@@ -664,7 +661,7 @@ int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, cons
     a.gi = gi + t_lo * B * 4 * H; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = cprev;
     a.out = out + t_lo * BH; a.cseq = w.cseq + t_lo * BH;
     if (save) { a.sv = w.sv + t_lo * BH; a.sv_stride = TBH; }
-    a.hx = w.hx; a.counters = w.sync; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
+    a.hx = w.hx; a.counters = w.sync; a.status = chain_status_for(w.sync + kStatusWord);
     char label[64];
     std::snprintf(label, sizeof label, "lstm_chain_fwd ms%d T%d B%d H%d", ms, nt, B, H);
     ProfScope prof(PROF_GRU_FWD, 2.0 * nt * B * 4.0 * H * H, s, label,
@@ -694,7 +691,7 @@ int lstm_chunk_bwd(int B, int T, int H, const float* dout, const float* dhT, con
     a.sv = w.sv + t_lo * BH; a.sv_stride = TBH;
     a.dg = dgi + t_lo * B * 4 * H; a.dh0 = dh0; a.dc0 = dc0;
     a.db_ih = db_ih; a.db_hh = db_hh;
-    a.gx = w.gx; a.counters = w.sync + kBwdCounters; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
+    a.gx = w.gx; a.counters = w.sync + kBwdCounters; a.status = chain_status_for(w.sync + kStatusWord);
     char label[64];
     std::snprintf(label, sizeof label, "lstm_chain_bwd ms%d T%d B%d H%d", ms, nt, B, H);
     ProfScope prof(PROF_GRU_BWD, 2.0 * nt * B * 4.0 * H * H, s, label,
@@ -813,7 +810,7 @@ int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const 
         a.sv = w.sv; a.sv_stride = TBH;
         a.dg = dgi; a.dh0 = dh0; a.dc0 = dc0;
         a.db_ih = db_ih; a.db_hh = db_hh;
-        a.gx = w.gx; a.counters = w.sync + kBwdCounters; a.status = chain::Status{w.sync + kStatusWord, chain_host_status()};
+        a.gx = w.gx; a.counters = w.sync + kBwdCounters; a.status = chain_status_for(w.sync + kStatusWord);
         char label[64];
         std::snprintf(label, sizeof label, "lstm_chain_bwd ms%d T%d B%d H%d", ms, T, B, H);
         ProfScope prof(PROF_GRU_BWD, 2.0 * T * B * 4.0 * H * H, s, label,

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "pointwise.h"
 #include "prof.h"
+#include "chain.h"
 
 namespace {
 
@@ -181,7 +182,10 @@ __global__ void latent_bwd_kernel(const float* __restrict__ dz, const float* __r
 // torch.optim.Adam (2.x single-tensor form): denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2,
-                            float eps, float gscale) {
+                            float eps, float gscale, const unsigned* __restrict__ abort_word) {
+    // a chain kernel of this process gave up waiting for its group (chain.h): the gradients of the step are not valid,
+    // so the step leaves parameters and moments as they are; the host sees inet_chain_status() != 0 and decides
+    if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const long n4 = n >> 2;
     f32x4* p4 = reinterpret_cast<f32x4*>(p);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
@@ -600,7 +604,8 @@ int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     ProfScope prof(PROF_HBM, 0.0, s, "adam", 28.0 * (double)n);      // read p,g,m,v; write p,m,v
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
-                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale);
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale,
+                       (const unsigned*)chain_dev_status());
     return ok();
 }
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s) {

@@ -13,6 +13,9 @@
 hipStream_t side_fork(hipStream_t main_stream);   // returns main_stream itself when the side stream is disabled
 int side_join(hipStream_t main_stream);            // no-op in deferred mode
 int side_join_now(hipStream_t main_stream);
+// `other` (not the issuing stream) waits for everything queued on the side streams so far; the dirty flags stay set, so
+// the issuing stream still joins that work at its own next join
+int side_wait_on(hipStream_t other);
 void side_set_defer(int on);
 void side_set_enabled(int on);
 int side_enabled();

@@ -89,6 +89,15 @@ int side_join_now(hipStream_t main_stream) {
     return 0;
 }
 
+int side_wait_on(hipStream_t other) {
+    for (int i = 0; i < g_nside; ++i) {
+        if (!g_dirty[i]) continue;
+        hipEvent_t e = next_event();
+        if (!e || hipEventRecord(e, g_sides[i]) != hipSuccess || hipStreamWaitEvent(other, e, 0) != hipSuccess) return -2;
+    }
+    return 0;
+}
+
 namespace { hipStream_t g_twin = nullptr; bool g_twin_tried = false, g_twin_dirty = false; }
 hipStream_t twin_fork(hipStream_t main_stream) {
     if (!g_twin_tried) {
@@ -143,6 +152,38 @@ int chain_enabled() {
     return g_chain;
 }
 void chain_set_enabled(int on) { g_chain = on ? 1 : 0; }
+unsigned* chain_dev_status() {
+    static unsigned* p = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* q = nullptr;
+        if (hipMalloc(&q, 256) == hipSuccess && hipMemset(q, 0, 256) == hipSuccess) p = static_cast<unsigned*>(q);
+    }
+    return p;
+}
+int chain_status_reset() {
+    if (unsigned* h = chain_host_status()) __atomic_store_n(h, 0u, __ATOMIC_RELAXED);
+    unsigned* d = chain_dev_status();
+    if (d && (hipDeviceSynchronize() != hipSuccess || hipMemset(d, 0, 4) != hipSuccess)) return -2;
+    return 0;
+}
+namespace { int g_fault = 0; }
+void chain_arm_fault(int on) { g_fault = on ? 1 : 0; }
+int chain_take_fault() { const int f = g_fault; g_fault = 0; return f; }
+int chain_capacity() {
+    static const int forced = [] { const char* v = std::getenv("INET_CHAIN_CUS"); return v ? std::atoi(v) : 0; }();
+    if (forced > 0) return forced;
+    static int cached[64];                         // per device ordinal; 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;   // no device here (CPU-side size queries)
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus;
+    }
+    return cached[dev];
+}
 unsigned* chain_host_status() {
     static unsigned* p = nullptr;
     static bool tried = false;

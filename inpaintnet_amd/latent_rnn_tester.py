@@ -11,6 +11,7 @@ import os
 
 import torch
 
+from . import ops
 from .helpers import to_cuda_variable_long
 from .trainer import Trainer
 
@@ -48,6 +49,8 @@ class LatentRNNTester(object):
             weights, gen_target, _ = self.model(past_context=tensor_past, future_context=tensor_future, target=None,
                                                 measures_to_generate=num_target_measures, train=False)
         self.last_weights = weights
+        torch.cuda.synchronize()
+        ops.check_chains("LatentRNNTester.generate")                   # persistent kernels: never hand back results of a failed launch
         if tensor_target is not None and eval:
             loss, accuracy = Trainer.mean_crossentropy_loss_and_accuracy(weights, tensor_target)
             self.last_eval = (float(loss), float(accuracy))
@@ -87,5 +90,6 @@ class LatentRNNTester(object):
                 w, _, _ = self.model(past, future, target, fix_num_target, train=False)
                 loss, acc = Trainer.mean_crossentropy_loss_and_accuracy(w, target)
             tot += torch.tensor([float(loss), float(acc), 1.0])
+            ops.check_chains("LatentRNNTester.loss_and_acc_test")
         n = max(float(tot[2]), 1.0)
         return float(tot[0]) / n, float(tot[1]) / n

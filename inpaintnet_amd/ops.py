@@ -101,27 +101,35 @@ _DEFER = False
 _HELD = []
 
 
-def side_defer(on):
+def side_defer(on, release=True):
     """Deferred joins (include/inpaintnet_hip.h, inet_set_option key 1): the *_bwd calls stop making the current stream
-    wait for the side stream; every tensor they were given is kept alive here until side_join()."""
+    wait for the side stream; every tensor they were given is kept alive here until side_join().  release=False when
+    leaving deferred mode: the current stream joins, the held tensors stay until release_held() (Trainer.step keeps
+    them across the gradient exchange)."""
     global _DEFER
     if not on and _DEFER:
-        side_join()
+        side_join(release=release)
     _DEFER = bool(on)
     check(_lib.lib().inet_set_option(1, int(_DEFER)), "inet_set_option")
 
 
-def side_join():
+def side_join(release=True):
     """Make the current stream wait for all side-stream work, then release the tensors held for it."""
     check(_lib.lib().inet_side_join(stream_ptr()), "inet_side_join")
+    if release:
+        _HELD.clear()
+
+
+def release_held():
     _HELD.clear()
 
 
 def side_join_on(stream):
     """Make `stream` (a torch.cuda.Stream that is NOT the one the library calls were issued on) wait for all side-stream
-    work queued so far.  Nothing is released: the issuing stream has not been ordered after that work (dp.start_bucket
-    uses this to start an all-reduce behind the leaf GEMMs without stalling the backward pass)."""
-    check(_lib.lib().inet_side_join(C.c_void_p(stream.cuda_stream)), "inet_side_join")
+    work queued so far.  Nothing is consumed or released (inet_side_wait): the issuing stream has not been ordered after
+    that work and still joins it at its own next join (dp.start_bucket uses this to start an all-reduce behind the leaf
+    GEMMs without stalling the backward pass)."""
+    check(_lib.lib().inet_side_wait(C.c_void_p(stream.cuda_stream)), "inet_side_wait")
 
 
 def _hold(*tensors):
@@ -483,5 +491,20 @@ def ws_field(cfg, ws, B, which, name):
 
 def chain_status(reset=False):
     """Workgroups of chain kernels that timed out waiting for their group since the last reset (0 = healthy).
-    Call after a synchronisation."""
+    Complete after a synchronisation; a non-zero value read earlier is already a failure (host-mapped counter)."""
     return int(_lib.lib().inet_chain_status(int(bool(reset))))
+
+
+class ChainTimeoutError(RuntimeError):
+    """A persistent (chain) kernel gave up waiting for its group: results computed since are not valid."""
+
+
+def check_chains(what=""):
+    """Raise if any chain-kernel workgroup has timed out (reads the host-mapped counter: no synchronisation, ~1 us).
+    The inference wrappers call it after their device->host reads, Trainer.step() after queueing the optimizer."""
+    n = chain_status()
+    if n > 0:
+        raise ChainTimeoutError(f"{n} chain-kernel workgroups gave up waiting for their group ({what or 'inet_chain_status'}): "
+                                "the results are not valid.  All workgroups of such a launch must be resident at once -- "
+                                "is the GPU shared, partitioned or CU-masked?  INET_CHAIN=0 (or ops.set_option(4, 0)) "
+                                "selects the per-step kernels.")

@@ -88,6 +88,8 @@ class Trainer(ABC):
             self.early_stopper = EarlyStopping()
         self.last_epoch_seconds = None
         self.start_epoch = 0                         # load_training_state() moves it
+        self.chain_fallback = True                   # on a chain-kernel timeout: per-step kernels + retry (else raise)
+        self.chain_fallbacks = 0
         # deferred side-stream joins for zero_grad() -> forward -> backward -> step() sequences (see zero_grad)
         self.overlap_backward = False
 
@@ -133,14 +135,25 @@ class Trainer(ABC):
                 data_loader = DeviceFeed(data_loader, fields=self.feed_fields, device=dev)
             for sample_id, batch in enumerate(data_loader):
                 batch_data = self.process_batch_data(batch)
-                self.zero_grad()
-                if train:
-                    loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=True)
-                    loss.backward()
-                    self.step()
-                else:
-                    with torch.no_grad():
-                        loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=False)
+                for attempt in (0, 1):
+                    try:
+                        self.zero_grad()
+                        if train:
+                            loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=True)
+                            loss.backward()
+                            self.step()
+                        else:
+                            with torch.no_grad():
+                                loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=False)
+                        break
+                    except ops.ChainTimeoutError:
+                        # A persistent kernel of an earlier step (the check does not synchronise) gave up waiting for its
+                        # group.  The optimizer kernel has left the weights alone since then (inet_adam_step reads the same
+                        # flag on the device), so nothing is corrupted: switch to the per-step kernels for the rest of the
+                        # process, and run this batch again.  Batches between the failure and its detection were not applied.
+                        if attempt or not self.chain_fallback:
+                            raise
+                        self._fall_back_from_chains()
                 self._accumulate_stats(sums, loss, accuracy)
                 batches += 1
         finally:
@@ -180,11 +193,24 @@ class Trainer(ABC):
 
     def step(self):
         """utils/trainer.py:172-177 (+ the data-parallel gradient exchange)."""
-        ops.side_defer(False)                        # joins; deferred mode only lives between zero_grad() and step()
+        ops.side_defer(False, release=False)         # joins; deferred mode only lives between zero_grad() and step()
         gscale = dp.allreduce_grads(self.model.grad)
+        ops.release_held()                           # (after the exchange: the buckets' streams were ordered behind side work)
         self.adam_t += 1
         ops.adam_step(self.model.flat, self.model.grad, self.adam_m, self.adam_v, self.lr, self.adam_t,
                       self.betas[0], self.betas[1], self.eps, gscale)
+        # persistent kernels: a bounded spin that ran out raises here, at the latest a few steps after it happened (the
+        # host-mapped counter is read without synchronising); the Adam kernel itself skips its update while the flag is up
+        ops.check_chains("Trainer.step")
+
+    def _fall_back_from_chains(self):
+        torch.cuda.synchronize()
+        n = ops.chain_status(reset=True)
+        ops.set_option(4, 0)                          # per-step kernels from here on (INET_CHAIN=0 semantics, in-process)
+        self.chain_fallbacks += 1
+        self.adam_t = max(self.adam_t - 1, 0)         # the step that raised did not update anything
+        print(f"[inpaintnet_amd] {n} chain-kernel workgroups timed out; chain kernels are now OFF for this process and the "
+              "batch is run again (is the GPU shared, partitioned or CU-masked?)")
 
     # ---- optimizer / epoch resume (SURVEY 8f1 add-on: the reference saves weights only, utils/model.py:16-53) ----
     def training_state(self, next_epoch=0):

@@ -8,6 +8,7 @@ import os
 
 import torch
 
+from . import ops
 from .helpers import to_cuda_variable_long
 from .trainer import Trainer
 
@@ -27,11 +28,15 @@ class VAETester(object):
     def decode_mid_point(self, z1, z2, n):
         """z1, z2 (1, z_dim) -> token tensor (1, (n + 2) * 24): z1 | n interpolated | z2   (vae_tester.py:72-93)"""
         assert n >= 1 and isinstance(n, int)
-        steps = torch.arange(n + 2, device=z1.device, dtype=z1.dtype).view(-1, 1) / (n + 1)
-        z = z1 + (z2 - z1) * steps                                   # row 0 = z1, row n+1 = z2
+        # z1 and z2 themselves are decoded at the ends (vae_tester.py:82-91), not z1 + (z2 - z1) * 1.0, which is not
+        # bit-equal to z2 in fp32 and could flip a near-tie argmax of the last measure
+        ks = torch.arange(1, n + 1, device=z1.device, dtype=z1.dtype).view(-1, 1)
+        z = torch.cat((z1, z1 + (z2 - z1) * ks / (n + 1), z2), 0)      # same operation order as the reference's loop
         dummy = torch.zeros(n + 2, self.measure_seq_len, device=z1.device)
         with torch.no_grad():
             _, samples = self.decoder(z.contiguous(), dummy, self.train)
+        torch.cuda.synchronize()
+        ops.check_chains("VAETester.decode_mid_point")             # never hand back tokens of a failed persistent launch
         return samples.reshape(1, -1)
 
     def test_interpolation(self, tensor_score1, tensor_score2, n=1):
@@ -56,5 +61,6 @@ class VAETester(object):
                 weights = self.model(measure_score_tensor=score, train=False)[0]
                 loss, acc = Trainer.mean_crossentropy_loss_and_accuracy(weights, score)
             tot += torch.tensor([float(loss), float(acc), 1.0])
+            ops.check_chains("VAETester.loss_and_acc_test")
         n = max(float(tot[2]), 1.0)
         return float(tot[0]) / n, float(tot[1]) / n

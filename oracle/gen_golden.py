@@ -296,6 +296,15 @@ def gen_latent(name, c, auto_reg, coin):
     for k, v in grads_of(model, full_tensors).items():
         fx[k] = v
     assert all(p.grad is None for p in vae.parameters())
+    # latent-space diagnostics of the reference (utils/trainer.py:308-342; north_star "latent-MSE"): the generated latents
+    # against the frozen encoder's z of the target measures (same eps as the forward pass used)
+    with EpsQueue() as q2:
+        q2.q.append(e_t)
+        with torch.no_grad():
+            z_target = model.get_z_seq(target)
+    fx["z_target"] = z_target.numpy()
+    fx["mse_gen_target"] = np.float64(trainer.mean_mse_loss_rnn(gen_z.detach(), z_target).item())
+    fx["l1_gen_target"] = np.float64(trainer.mean_l1_loss_rnn(gen_z.detach(), z_target).item())
     trainer.step()
     for k, p in model.named_parameters():
         if p.requires_grad:

@@ -157,9 +157,19 @@ def test_arnn_teacher_forced_step_golden(name):
             ref = fx[key] if key in fx.files else np.zeros_like(g)
             err = np.abs(g - ref).max() / (np.abs(ref).max() + 1e-7)
         else:
+            # full-size fixture: per-tensor element slices (first / last 64 elements against the tensor's own scale:
+            # norm / sqrt(n) = its rms), the signed sum, and the norm
             key = "tf_gradnorm/" + k
             rn = float(fx[key]) if key in fx.files else 0.0
-            err = abs(float(np.sqrt((g.astype(np.float64) ** 2).sum())) - rn) / (rn + 1e-9)
+            flat = g.reshape(-1).astype(np.float64)
+            err = abs(float(np.sqrt((flat ** 2).sum())) - rn) / (rn + 1e-9)
+            if key in fx.files:
+                rms = rn / np.sqrt(flat.size) + 1e-12
+                scale = max(float(np.abs(fx["tf_gradhead/" + k]).max()), float(np.abs(fx["tf_gradtail/" + k]).max()), rms)
+                e_head = float(np.abs(flat[:64] - fx["tf_gradhead/" + k]).max()) / scale
+                e_tail = float(np.abs(flat[-64:] - fx["tf_gradtail/" + k]).max()) / scale
+                e_sum = abs(float(flat.sum()) - float(fx["tf_gradsum/" + k])) / (rn * np.sqrt(flat.size) + 1e-12)
+                err = max(err, e_head, e_tail, e_sum)
         if not err < 1e-3:
             bad.append((k, float(err)))
     assert not bad, bad
@@ -224,3 +234,73 @@ def test_arnn_free_running_backward_vs_oracle():
             if not err < 2e-3:
                 bad.append((k, err))
         assert not bad, bad
+
+
+def test_arnn_bench_shape_step_with_input_dropout_vs_oracle(tmp_path, monkeypatch):
+    """The shape bench.py times (BASELINE.json configs[4]): 32 sequences x 384 ticks, H = 256, 2 + 2 LSTM layers, teacher
+    forced, Dropout2d(0.2) on the shifted note embeddings -- the mask the product drew is recorded and replayed in the
+    oracle (`input_mask`), every gradient tensor is compared element-wise, and the profile labels prove that both LSTM
+    stacks ran as the two-layer chunk pipeline (inet_lstm2_*: chain launches of 48 steps)."""
+    import csv
+    name = "full"
+    c = G.ARNN_CFGS[name]
+    B, L, V = 32, 384, c["V"]
+    ds = synthetic.SyntheticFolkDataset(num_notes=V)
+    ds.metadatas = [types.SimpleNamespace(num_values=6), types.SimpleNamespace(num_values=6)]
+    model = ConstraintModelGaussianReg(ds, note_embedding_dim=c["E"], metadata_embedding_dim=c["Em"],
+                                       num_lstm_constraints_units=c["H"], num_lstm_generation_units=c["H"],
+                                       linear_hidden_size=c["LH"], num_layers=2, dropout_input_prob=0.2,
+                                       dropout_prob=0.2, unary_constraint=True, teacher_forcing=True)
+    model.load_state_dict(G.arnn_params(name))
+    trainer = AnticipationRNNGaussianRegTrainer(ds, model, lr=1e-4)
+    model.train()
+    score = torch.from_numpy(synthetic.folk_score(B, V, seed=21)).long()
+    md = torch.from_numpy(synthetic.folk_metadata(B)).long()
+    a, b = 7 * 24, 11 * 24
+    loc = torch.zeros_like(score)
+    loc[:, :, :a] = 1
+    loc[:, :, b:] = 1
+    rec = []
+    real_mask = ops.dropout_mask
+
+    def recording_mask(shape, p, seed, offset, device):
+        m = real_mask(shape, p, seed, offset, device)
+        rec.append((tuple(shape), float(p), m.clone()))
+        return m
+    monkeypatch.setattr(ops, "dropout_mask", recording_mask)
+    trainer.zero_grad()
+    ops.prof_enable(True)
+    weights, _ = model(score.cuda(), md.cuda(), loc.cuda(), a, b, train=True, teacher_forcing=True)
+    loss, acc = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, score.cuda()[:, :, a:b].transpose(0, 1))
+    loss.backward()
+    ops.side_join()
+    torch.cuda.synchronize()
+    ops.prof_dump(tmp_path / "l.csv")
+    ops.prof_enable(False)
+    assert ops.chain_status() == 0
+    with open(tmp_path / "l.csv") as f:
+        labels = [r["label"] for r in csv.DictReader(f)]
+    # two stacks x two layers x 8 chunks of 48 steps, forward and backward
+    nf = sum(l.startswith("lstm_chain_fwd") and " T48 B32 H256" in l for l in labels)
+    nb_ = sum(l.startswith("lstm_chain_bwd") and " T48 B32 H256" in l for l in labels)
+    assert nf == 32 and nb_ == 32, sorted(set(l for l in labels if l.startswith("lstm")))
+    assert [(sh, p) for sh, p, _ in rec] == [((L, B), 0.2)], [(sh, p) for sh, p, _ in rec]
+    m = rec[0][2].cpu()                                            # [L,B], pre-scaled {0, 1/0.8}
+    assert set(np.unique(m.numpy()).round(4)) <= {0.0, 1.25}
+    assert 0.1 < float((m == 0).float().mean()) < 0.3
+    P = G.arnn_params(name)
+    for p in P.values():
+        p.requires_grad_(True)
+    w_all, _ = O.arnn_forward(P, score, md, loc, teacher_forcing=True, input_mask=m.t().unsqueeze(-1))
+    lo, ao = O.arnn_loss(w_all[:, a:b], score[:, 0, a:b])
+    lo.backward()
+    assert G.rel_err(weights[0].detach().cpu(), w_all[:, a:b].detach()) < 1e-4
+    assert abs(float(loss.detach()) - lo.item()) < 1e-4 * abs(lo.item())
+    assert abs(float(acc) - ao.item()) <= 2.0 / (B * (b - a))
+    errs = {}
+    for k in P:
+        gr = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        errs[k] = float((model.param_grad(k).cpu() - gr).abs().max() / (gr.abs().max() + 1e-9))
+    worst = max(errs, key=errs.get)
+    print(f"worst ARNN gradient tensor {worst}: {errs[worst]:.2e} of its max")
+    assert errs[worst] < 5e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]

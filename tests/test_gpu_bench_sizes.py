@@ -95,7 +95,9 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     for p in P.values():
         p.requires_grad_(True)
     feed = None if tf else hs.cpu()[:, 0]
+    O.kink_stats_reset()
     w, s, mu, ls, z = O.vae_forward(P, tok, eps, tf, om, feed_tokens=feed, kinks=kinks)
+    _assert_kinks("vae step")
     loss, ce, kl, acc = O.vae_loss(w, tok, mu, ls)
     loss.backward()
     assert relmax(hz, z) < 2e-5
@@ -113,8 +115,26 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
         errs[pname] = float((gg - P[pname].grad).abs().max() / (P[pname].grad.abs().max() + 1e-12))
     worst = max(errs, key=errs.get)
     print(f"worst gradient tensor {worst}: {errs[worst]:.2e} of its max")
-    # with the SELU / ReLU branches aligned (module docstring) every gradient tensor agrees far inside the 5e-4 bar
-    assert errs[worst] < 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # with the SELU / ReLU branches aligned (module docstring) every gradient tensor agrees far inside the 5e-4 bar.
+    # decoder.b_0 is ONE scalar: a 1536-term sum of both signs (sum_n colsum(dgi0_beat)[n] * W_ih[n]) whose terms are
+    # themselves atomically accumulated column sums -- its "max" is the cancelled result, so run-to-run summation order
+    # alone moves it by up to 2e-4 of itself; it keeps the north_star's 5e-4 bound, every tensor
+    # with more than one element is held to 1e-4
+    bound = {k: 1e-4 for k in errs}
+    bound["decoder.b_0"] = 5e-4
+    bad = {k: v for k, v in errs.items() if v >= bound[k]}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
+
+
+def _assert_kinks(what):
+    """The oracle followed the GPU's SELU / ReLU branch only inside |x| < O.KINK_TOL (oracle/torch_ref.py): nothing may
+    disagree outside that band, and inside it only the handful of elements fp32 noise explains."""
+    st = dict(O.KINK_STATS)
+    print(f"kinks ({what}): {st}")
+    assert st["elements"] > 0
+    assert st["violations"] == 0, st                     # a branch taken wrongly on a clearly non-zero pre-activation
+    assert st["flips"] <= 8 + 1e-5 * st["elements"], st
+    assert st["max_abs_flip"] <= O.KINK_TOL, st
 
 
 def _vae_step_with_kinks(cfg, params, grads, tok, eps, teacher_forced, masks):
@@ -143,21 +163,27 @@ def _vae_step_with_kinks(cfg, params, grads, tok, eps, teacher_forced, masks):
     return float(ce + kl), float(ce), float(kl), float(a[1] / (B * T)), w, s, z, kinks
 
 
-def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
-    """BASELINE.json configs[2] (and the per-rank workload of configs[3]): 128 sequences x 16 measures, split 6/4/6."""
+@pytest.mark.parametrize("variant", ["nar", "ar_tf", "ar_fr"])
+def test_latent_step_at_bench_batch_vs_oracle(variant, tmp_path, monkeypatch):
+    """BASELINE.json configs[2] (and the per-rank workload of configs[3]): 128 sequences x 16 measures, split 6/4/6.
+    `nar` = the benched non-auto-regressive model; `ar_tf` / `ar_fr` = auto_reg=True (the reference script's default,
+    train_inpaintnet.py:53) teacher-forced and free-running -- the free-running path re-encodes its own samples after
+    every generated measure (latent_rnn.py:246-259), with one generator / decoder / encoder dropout mask per measure."""
     from inpaintnet_amd import synthetic
     from inpaintnet_amd import measure_vae as MV
     from inpaintnet_amd.latent_rnn import LatentRNN
     from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
     from inpaintnet_amd.measure_vae import MeasureVAE
     B, n_past, n_target, n_future = 128, 6, 4, 6
+    auto_reg, tf = variant != "nar", variant == "ar_tf"
+    free_ar = variant == "ar_fr"
     c = G.CFGS["full"]
     H, Z, V = c["H"], c["Z"], c["V"]
     ds = synthetic.SyntheticFolkDataset(num_notes=V)
     vae = MeasureVAE(ds)                                            # reference defaults: dropout 0.5 everywhere
     model = LatentRNN(ds, vae, num_rnn_layers=2, rnn_hidden_size=H, dropout=0.5, rnn_class=torch.nn.GRU,
-                      auto_reg=False, teacher_forcing=True)
-    P = G.latent_params("full", False)
+                      auto_reg=auto_reg, teacher_forcing=True)
+    P = G.latent_params("full", auto_reg)
     model.load_state_dict(P)
     trainer = LatentRNNTrainer(ds, model, lr=1e-4)
     model.train()
@@ -166,6 +192,7 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
     past, future, target = LatentRNNTrainer.split_score(score, n_past, n_future, n_target, 24)
     g = torch.Generator().manual_seed(5)
     eps = tuple(torch.randn(B, n, Z, generator=g) for n in (n_past, n_future, n_target))
+    eps_ar = [torch.randn(B, Z, generator=g) for _ in range(n_target)] if free_ar else None
 
     rec = []
     real_mask = ops.dropout_mask
@@ -176,58 +203,94 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
         return m
     monkeypatch.setattr(ops, "dropout_mask", recording_mask)
 
-    vae.decoder.keep_ws = True
+    # branch of every SELU / ReLU element of the (frozen) decoder: one workspace per decoder call
+    wss = []
+    real_dec = ops.decoder_fwd
+
+    def recording_dec(*a, **k):
+        out = real_dec(*a, **k)
+        wss.append(out[2])
+        return out
+    monkeypatch.setattr(ops, "decoder_fwd", recording_dec)
+
     trainer.zero_grad()
     ops.prof_enable(True)
-    w, s, gz = model(past, future, target, n_target, train=True, eps=tuple(e.cuda() for e in eps))
-    # branch of every SELU / ReLU element of the (frozen) decoder, rows ordered (sequence, measure)
-    dws, R = vae.decoder.last_ws, B * n_target
-    k_hb0 = (ops.ws_field(vae.cfg, dws, R, 1, "hb0").view(B, n_target, 2 * H).cpu() > 0)
-    k_ht0 = (ops.ws_field(vae.cfg, dws, R, 1, "ht0").view(4, B, n_target, 2 * H).cpu() > 0)
-    k_c = (ops.ws_field(vae.cfg, dws, R, 1, "c_all").view(4, B, n_target, H).cpu() > 0)
+    w, s, gz = model(past, future, target, n_target, train=True, eps=tuple(e.cuda() for e in eps), teacher_forcing=tf,
+                     eps_ar=[e.cuda() for e in eps_ar] if free_ar else None)
     k_relu = w.detach().cpu() > 0
-    dec_kinks = [{"hb0": k_hb0[:, i], "ht0": k_ht0[:, :, i], "c_all": k_c[:, :, i], "relu": k_relu[:, i]}
-                 for i in range(n_target)]
+    if not free_ar:                                                 # one decoder call, rows ordered (sequence, measure)
+        assert len(wss) == 1
+        dws, R = wss[0], B * n_target
+        k_hb0 = (ops.ws_field(vae.cfg, dws, R, 1, "hb0").view(B, n_target, 2 * H).cpu() > 0)
+        k_ht0 = (ops.ws_field(vae.cfg, dws, R, 1, "ht0").view(4, B, n_target, 2 * H).cpu() > 0)
+        k_c = (ops.ws_field(vae.cfg, dws, R, 1, "c_all").view(4, B, n_target, H).cpu() > 0)
+        dec_kinks = [{"hb0": k_hb0[:, i], "ht0": k_ht0[:, :, i], "c_all": k_c[:, :, i], "relu": k_relu[:, i]}
+                     for i in range(n_target)]
+    else:                                                           # one decoder call of B rows per generated measure
+        assert len(wss) == n_target
+        dec_kinks = [{"hb0": ops.ws_field(vae.cfg, wss[i], B, 1, "hb0").view(B, 2 * H).cpu() > 0,
+                      "ht0": ops.ws_field(vae.cfg, wss[i], B, 1, "ht0").view(4, B, 2 * H).cpu() > 0,
+                      "c_all": ops.ws_field(vae.cfg, wss[i], B, 1, "c_all").view(4, B, H).cpu() > 0,
+                      "relu": k_relu[:, i]} for i in range(n_target)]
     loss, acc = trainer.mean_crossentropy_loss_and_accuracy(w, target)
     loss.backward()
     ops.side_join()
     torch.cuda.synchronize()
     ops.prof_dump(tmp_path / "launches.csv")
     ops.prof_enable(False)
+    assert ops.chain_status() == 0
     labels = _labels(tmp_path / "launches.csv")
     # frozen encoder over all 128 x 16 measures at once: the chain kernel over eight 256-row chunks per layer
     assert sum(l == "gru_chain_fwd ms4x2 np2 T24 B256 H512" for l in labels) == 16, sorted(set(l for l in labels if l.startswith("gru")))
     assert "gru_chain_fwd ms2 np2 T6 B128 H512" in labels and "gru_chain_bwd ms2 np2 T6 B128 H512" in labels   # contexts: 8 groups of 32 rows
-    assert any(l.startswith("gru_fwd x0") and l.endswith("B128 H1024") for l in labels)      # generator
-    # the frozen decoder's 512 free-running rows: the fused decode kernel over two chunks of 256 rows (with backward saves)
-    assert sum(l == "decode_chain_train ms2 T24 B256 H512 V48" for l in labels) == 2, sorted(set(l for l in labels if l.startswith("dec")))
-    assert any(l.startswith("gru_bwd") and l.endswith("B128 H1024") for l in labels)
+    if variant == "nar":
+        assert any(l.startswith("gru_fwd x0") and l.endswith("B128 H1024") for l in labels)      # generator
+        # the frozen decoder's 512 free-running rows: the fused decode kernel over two chunks of 256 rows (with backward saves)
+        assert sum(l == "decode_chain_train ms2 T24 B256 H512 V48" for l in labels) == 2, sorted(set(l for l in labels if l.startswith("dec")))
+        assert any(l.startswith("gru_bwd") and l.endswith("B128 H1024") for l in labels)
+    if free_ar:                                                     # one fused decode launch of 128 rows per generated measure
+        assert sum(l.startswith("decode_chain_train") for l in labels) == n_target, sorted(set(l for l in labels if l.startswith("dec")))
 
-    # masks in call order: encoder (T, 16B, 2H); context past (np, B, 2H); context future; generator (nt, B, 4H);
-    # decoder beat (4, nt*B, H); decoder tick (24, nt*B, H)
+    # masks in call order: encoder (T, 16B, 2H); context past (np, B, 2H); context future; then
+    #   nar / ar_tf: generator (nt, B, 4H); decoder beat (4, nt*B, H); decoder tick (24, nt*B, H)
+    #   ar_fr, per generated measure: generator (1, B, 4H); decoder beat (4, B, H); tick (24, B, H); re-encoding (24, B, 2H)
     shapes = [sh for sh, _ in rec]
-    assert shapes == [(24, 16 * B, 2 * H), (n_past, B, 2 * H), (n_future, B, 2 * H), (n_target, B, 4 * H),
-                      (4, n_target * B, H), (24, n_target * B, H)], shapes
-    m_enc, m_cp, m_cf, m_gen, m_beat, m_tick = [m.cpu() for _, m in rec]
+    head = [(24, 16 * B, 2 * H), (n_past, B, 2 * H), (n_future, B, 2 * H)]
+    if not free_ar:
+        assert shapes == head + [(n_target, B, 4 * H), (4, n_target * B, H), (24, n_target * B, H)], shapes
+    else:
+        assert shapes == head + [(1, B, 4 * H), (4, B, H), (24, B, H), (24, B, 2 * H)] * n_target, shapes
+    ms = [m.cpu() for _, m in rec]
+    m_enc, m_cp, m_cf = ms[:3]
     # encoder rows are ordered (sequence, measure) with measures = past | target | future
     me = m_enc.permute(1, 0, 2).reshape(B, 16, 24, 2 * H)
 
     def enc_rows(lo, hi):
         return me[:, lo:hi].reshape(B * (hi - lo), 24, 2 * H)
-    # decoder rows are ordered (sequence, measure)
-    mb = m_beat.permute(1, 0, 2).reshape(B, n_target, 4, H)
-    mt = m_tick.permute(1, 0, 2).reshape(B, n_target, 24, H)
     masks = {"enc_past": enc_rows(0, n_past), "enc_target": enc_rows(n_past, n_past + n_target),
              "enc_future": enc_rows(n_past + n_target, 16),
-             "ctx_past": m_cp.permute(1, 0, 2), "ctx_future": m_cf.permute(1, 0, 2), "gen": m_gen.permute(1, 0, 2),
-             "dec": [{"beat": mb[:, i], "tick": mt[:, i]} for i in range(n_target)]}
+             "ctx_past": m_cp.permute(1, 0, 2), "ctx_future": m_cf.permute(1, 0, 2)}
+    if not free_ar:
+        m_gen, m_beat, m_tick = ms[3:6]
+        # decoder rows are ordered (sequence, measure)
+        mb = m_beat.permute(1, 0, 2).reshape(B, n_target, 4, H)
+        mt = m_tick.permute(1, 0, 2).reshape(B, n_target, 24, H)
+        masks["gen"] = m_gen.permute(1, 0, 2)
+        masks["dec"] = [{"beat": mb[:, i], "tick": mt[:, i]} for i in range(n_target)]
+    else:
+        per = [ms[3 + 4 * i: 7 + 4 * i] for i in range(n_target)]
+        masks["gen"] = [q[0].permute(1, 0, 2) for q in per]
+        masks["dec"] = [{"beat": q[1].permute(1, 0, 2), "tick": q[2].permute(1, 0, 2)} for q in per]
+        masks["enc_ar"] = [q[3].permute(1, 0, 2) for q in per]
     own = [k for k in P if not k.startswith("vae_model.")]
     for k in own:
         P[k].requires_grad_(True)
     hs = s.cpu().view(B, n_target, 24)
+    O.kink_stats_reset()
     wo, so, gzo = O.latent_forward(P, past.cpu(), future.cpu(), target.cpu(), eps[0].reshape(-1, Z), eps[1].reshape(-1, Z),
-                                   eps[2].reshape(-1, Z), auto_reg=False,
+                                   eps[2].reshape(-1, Z), auto_reg=auto_reg, teacher_forcing=tf, eps_ar=eps_ar,
                                    masks=masks, feed_tokens=hs, dec_kinks=dec_kinks)
+    _assert_kinks(f"latent step {variant}")
     lo, ao = O.latent_loss(wo, target.cpu())
     lo.backward()
     assert G.rel_err(gz.detach().cpu(), gzo.detach()) < 5e-5
@@ -237,7 +300,8 @@ def test_latent_step_at_bench_batch_vs_oracle(tmp_path, monkeypatch):
     assert np.array_equal(s.cpu().numpy()[:, 0][ok], so.numpy()[:, 0][ok])
     assert abs(float(loss.detach()) - lo.item()) <= 1e-4 * abs(lo.item())
     assert abs(float(acc) - ao.item()) <= 2.0 / (B * n_target * 24)
-    errs = {k: float((model.param_grad(k).cpu() - P[k].grad).abs().max() / (P[k].grad.abs().max() + 1e-12)) for k in own}
+    errs = {k: float((model.param_grad(k).cpu() - P[k].grad).abs().max() / (P[k].grad.abs().max() + 1e-12)) for k in own
+            if P[k].grad is not None}
     worst = max(errs, key=errs.get)
     print(f"worst gradient tensor {worst}: {errs[worst]:.2e} of its max")
     assert errs[worst] < 2e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]

@@ -160,3 +160,50 @@ def test_lstm_tagged_handoff_repeated():
                 assert float((p0 - o0).abs().max()) < 2e-5 and float((p1 - o1).abs().max()) < 2e-5
             else:
                 assert torch.equal(p0, first[0]) and torch.equal(p1, first[1]), (reverse, it)
+
+
+def test_injected_chain_timeout_skips_adam_and_trainer_falls_back():
+    """Failure path of the persistent kernels on a healthy GPU (inet_set_option key 6 drops one workgroup of the next forward
+    chain launch): the bounded spin runs out, inet_chain_status() reports it, the optimizer kernel leaves the weights
+    alone while the flag is up, Trainer.step() raises, and the epoch loop switches to the per-step kernels and runs the
+    batch again (Trainer._fall_back_from_chains)."""
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    from inpaintnet_amd.vae_trainer import VAETrainer
+    class SyncTrainer(VAETrainer):                   # detection lags the failure by design (no synchronisation in step());
+        def process_batch_data(self, batch):         # a sync per batch makes WHERE it is detected deterministic for the test
+            torch.cuda.synchronize()
+            return super().process_batch_data(batch)
+    ds = synthetic.SyntheticFolkDataset(num_notes=48)
+    model = MeasureVAE(ds)
+    trainer = SyncTrainer(ds, model, lr=1e-4)
+    model.train()
+    tok = torch.from_numpy(synthetic.det_tokens("fault", (64, 24), 48)).cuda()
+    assert ops.chain_status(reset=True) >= 0
+    try:
+        # (a) direct: a failed step never reaches the weights
+        before = model.flat.clone()
+        trainer.zero_grad()
+        ops.set_option(6, 1)
+        loss, acc = trainer.loss_and_acc_for_batch(tok, 0, train=True)
+        loss.backward()
+        with pytest.raises(ops.ChainTimeoutError):
+            torch.cuda.synchronize()                 # (make the check deterministic: the spin takes ~0.4 s)
+            trainer.step()
+        torch.cuda.synchronize()
+        assert ops.chain_status() > 0
+        assert torch.equal(model.flat, before)       # Adam was queued and skipped itself
+        assert ops.chain_status(reset=True) > 0 and ops.chain_status() == 0
+        # (b) the epoch loop: falls back to per-step kernels, repeats the batch, finishes the epoch
+        score, md = synthetic.SyntheticFolkDataset(num_notes=48, n_seq=8, seed=1).tensors()
+        loader = [(torch.from_numpy(score[:4]), torch.from_numpy(md[:4]))] * 3
+        trainer.dataset.n_bars = 16
+        ops.set_option(6, 1)
+        l, a = trainer.loss_and_acc_on_epoch(loader, 0, train=True)
+        assert np.isfinite(l) and trainer.chain_fallbacks == 1
+        assert not torch.equal(model.flat, before)
+        assert ops.chain_status() == 0
+    finally:
+        ops.set_option(6, 0)
+        ops.set_option(4, 1)
+        ops.chain_status(reset=True)

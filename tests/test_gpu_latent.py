@@ -58,6 +58,15 @@ def test_latent_rnn_forward_loss_grads_step(name, variant):
     else:
         # the first generated measure does not depend on sampled tokens
         assert G.rel_err(gz.detach().cpu()[:, 0], fx["gen_z"][:, 0]) < 2e-4
+    # north_star "latent-MSE within 1e-4 rel": Trainer.mean_mse_loss_rnn / mean_l1_loss_rnn (utils/trainer.py:308-342) of the
+    # generated latents against the frozen encoder's z of the target measures, vs the values the reference computed
+    z_t = model.get_z_seq(target, eps[2])
+    assert G.rel_err(z_t.cpu(), fx["z_target"]) < 1e-4
+    if not free_ar or same_tokens:
+        mse = float(trainer.mean_mse_loss_rnn(gz.detach(), z_t))
+        l1 = float(trainer.mean_l1_loss_rnn(gz.detach(), z_t))
+        assert abs(mse - float(fx["mse_gen_target"])) <= 1e-4 * float(fx["mse_gen_target"]), (mse, float(fx["mse_gen_target"]))
+        assert abs(l1 - float(fx["l1_gen_target"])) <= 1e-4 * float(fx["l1_gen_target"]), (l1, float(fx["l1_gen_target"]))
     loss, acc = trainer.mean_crossentropy_loss_and_accuracy(w, target)
     loss.backward()
     if not free_ar or same_tokens:

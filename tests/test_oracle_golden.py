@@ -122,6 +122,16 @@ def test_latent_rnn(name, variant):
         # free-running AR feeds sampled tokens back through the encoder: one near-tie flips everything after
         assert G.rel_err(w.detach(), fx["weights"]) < 1e-4
         assert np.array_equal(s.numpy()[:, 0][ok], fx["samples"][:, 0][ok])
+    # latent-MSE / L1 of the generated latents against the encoder's z of the target measures, as the reference's
+    # Trainer.mean_mse_loss_rnn / mean_l1_loss_rnn computed them (utils/trainer.py:308-342; north_star: within 1e-4 rel)
+    with torch.no_grad():
+        z_t = O.latent_get_z(P, target, torch.from_numpy(fx["eps_target"]))
+    assert G.rel_err(z_t, fx["z_target"]) < 1e-4
+    if not (auto_reg and not tf) or np.array_equal(s.numpy(), fx["samples"]):
+        mse = float(((gz.detach() - z_t) ** 2).mean())
+        l1 = float((gz.detach() - z_t).abs().mean())
+        assert abs(mse - float(fx["mse_gen_target"])) <= 1e-4 * float(fx["mse_gen_target"])
+        assert abs(l1 - float(fx["l1_gen_target"])) <= 1e-4 * float(fx["l1_gen_target"])
     loss, acc = O.latent_loss(w, target)
     loss.backward()
     if not (auto_reg and not tf) or np.array_equal(s.numpy(), fx["samples"]):
