@@ -114,6 +114,15 @@ int inet_vae_ws_field(const inet_vae_config* cfg, int batch, int which, const ch
  * dW (nullable, row stride ld_dw) = (softmax - onehot) * scale */
 int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
                        int64_t ld_dw, float scale, float out_scale, float* loss_sum, float* correct, void* stream);
+/* The same with the glue of VAETrainer.loss_and_acc_for_batch (vae_trainer.py:29-40) folded in: loss_sum / correct may be
+ * null (gradient-only call); dW is additionally multiplied by the device scalar scale_dev[0] when given (the upstream
+ * gradient of the loss, so that autograd's backward needs no elementwise pass over dW); *loss_sum also receives
+ * add_scale * add_term[0] once when add_term is given (the KL term: loss = CE + beta/B * KL complete in one launch);
+ * fwd_out[0] = fwd_scale * scale_dev[0] when given (the gradient to hand on to the producer of add_term). */
+int inet_cross_entropy_ex(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
+                          int64_t ld_dw, float scale, const float* scale_dev, float out_scale, float* loss_sum,
+                          float* correct, const float* add_term, float add_scale, float* fwd_out, float fwd_scale,
+                          void* stream);
 /* z = mu + eps*exp(logsigma) (measure_vae.py:119); sigma out (nullable); kl_sum += sum(0.5(s^2+mu^2-1) - ls) */
 int inet_reparam_kl(const float* mu, const float* logsigma, const float* eps, float* z, float* sigma, int64_t n,
                     float* kl_sum, void* stream);

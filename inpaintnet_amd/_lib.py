@@ -85,6 +85,7 @@ _SIGNATURES = {
     "inet_vae_decoder_bwd": (C.c_int, [_CFG, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "inet_vae_ws_field": (C.c_int, [_CFG, _I, _I, C.c_char_p, C.POINTER(_L), C.POINTER(_L)]),
     "inet_cross_entropy": (C.c_int, [_P, _L, _I, _I, _P, _P, _L, _F, _F, _P, _P, _P]),
+    "inet_cross_entropy_ex": (C.c_int, [_P, _L, _I, _I, _P, _P, _L, _F, _P, _F, _P, _P, _P, _F, _P, _F, _P]),
     "inet_reparam_kl": (C.c_int, [_P, _P, _P, _P, _P, _L, _P, _P]),
     "inet_sample_multinomial": (C.c_int, [_P, _L, _I, _I, _P, _L, C.c_uint64, C.c_uint64, _P]),
     "inet_latent_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _P, _P, _L, _P]),

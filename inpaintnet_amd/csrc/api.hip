@@ -148,6 +148,14 @@ int inet_cross_entropy(const float* weights, int64_t ld_w, int rows, int V, cons
     return pw_cross_entropy(weights, ld_w, rows, V, (const long long*)targets, dW, ld_dw, scale, out_scale, loss_sum,
                             correct, (hipStream_t)stream);
 }
+int inet_cross_entropy_ex(const float* weights, int64_t ld_w, int rows, int V, const int64_t* targets, float* dW,
+                          int64_t ld_dw, float scale, const float* scale_dev, float out_scale, float* loss_sum,
+                          float* correct, const float* add_term, float add_scale, float* fwd_out, float fwd_scale,
+                          void* stream) {
+    if (!weights || !targets || rows <= 0 || V <= 0 || (!dW && !loss_sum && !correct) || (fwd_out && !scale_dev)) return -1;
+    return pw_cross_entropy(weights, ld_w, rows, V, (const long long*)targets, dW, ld_dw, scale, out_scale, loss_sum,
+                            correct, (hipStream_t)stream, scale_dev, add_term, add_scale, fwd_out, fwd_scale);
+}
 int inet_sample_multinomial(const float* weights, int64_t ld_w, int rows, int V, int64_t* out, int64_t stride,
                             uint64_t seed, uint64_t offset, void* stream) {
     if (!weights || !out || rows <= 0 || V <= 0) return -1;

@@ -136,6 +136,9 @@ struct GruBwdBatch { int H; int nprob; int tiles_per_prob; int rows_fastest; Gru
 
 // host-side launchers (defined in the .hip files)
 int launch_gemm(const GemmArgs& g, hipStream_t s);
+constexpr int kGemmGroupMax = 4;
+// n independent products: one launch when a grouped kernel applies (gemm.hip), else one after the other
+int launch_gemm_group(const GemmArgs* list, int n, hipStream_t s);
 void gemm_set_force(int cfg, int split);      // cfg: -1 cost model, 0..4 tile configuration; split: 0 = 1, else forced
 void gemm_set_direct(int mode);                 // 0 never, 1 cost model, 2 whenever applicable (k-major x k-major products)
 int launch_gru_fwd(const GruFwdBatch& b, hipStream_t s);

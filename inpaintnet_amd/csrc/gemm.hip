@@ -519,8 +519,9 @@ struct KsOperand {
     }
 };
 
+// v = this workgroup's index among the tiles * splits workgroups of the product `g`
 template <int TA, int TB, bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n, int tiles) {
+__device__ __forceinline__ void gemm_ks_body(const GemmArgs& g, int v, int tiles_n, int tiles) {
     constexpr int D = 4, NR = TA * TB * 4;
     constexpr int RR = NR <= 64 ? NR : NR / 2;           // registers per reduction round (64 KB of LDS at most)
     constexpr int QR = RR / 4;
@@ -528,8 +529,6 @@ __global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n, i
     __shared__ float red[RR * 4 * 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    int v = blockIdx.x;
-    if ((gridDim.x & 7) == 0) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // a k-major x k-major product may also be split over the grid (k range `split`; one XCD then works on one range)
     const int split = v / tiles, tile = v - split * tiles;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -611,6 +610,29 @@ __global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n, i
             else unsafeAtomicAdd(cp, val);
         }
     }
+}
+
+template <int TA, int TB, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n, int tiles) {
+    int v = blockIdx.x;
+    if ((gridDim.x & 7) == 0) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    gemm_ks_body<TA, TB, AKM, BKM>(g, v, tiles_n, tiles);
+}
+
+// Up to kGemmGroupMax INDEPENDENT products of one operand layout in one launch (the two Linear heads of the encoder, the two
+// beat -> tick projections of the decoder, a module's leaf weight gradients): each is too small to fill the chip, and a
+// launch of its own costs >= 5 us start to start whatever it does.  Workgroup v belongs to the product whose tile range
+// [first[i], first[i+1]) holds it; every product keeps its own shape, bias, epilogue and accumulation mode.
+struct GemmGroupArgs { int n; int first[kGemmGroupMax + 1]; int tiles_n[kGemmGroupMax]; GemmArgs g[kGemmGroupMax]; };
+
+template <int TA, int TB, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_ks_group_kernel(GemmGroupArgs a) {
+    const int v = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kGemmGroupMax; ++k)
+        if (k < a.n && v >= a.first[k]) i = k;
+    gemm_ks_body<TA, TB, AKM, BKM>(a.g[i], v - a.first[i], a.tiles_n[i], a.first[i + 1] - a.first[i]);
 }
 
 template <int TM, int TN>
@@ -834,6 +856,75 @@ int launch_gemm_ks(const GemmArgs& gin, hipStream_t s, int force_split) {
 
 // inet_set_option key 5: 0 = LDS-tiled kernels only, 1 = cost model (default), 2 = the direct kernel whenever it applies
 void gemm_set_direct(int mode) { g_direct = mode; }
+
+template <int TA, int TB>
+void launch_ks_group(const GemmGroupArgs& a, bool akm, bool bkm, dim3 grid, hipStream_t s) {
+    if (akm) hipLaunchKernelGGL((gemm_ks_group_kernel<TA, TB, true, true>), grid, dim3(256), 0, s, a);
+    else if (bkm) hipLaunchKernelGGL((gemm_ks_group_kernel<TA, TB, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_ks_group_kernel<TA, TB, false, false>), grid, dim3(256), 0, s, a);
+}
+
+// Independent products in ONE launch of the workgroup split-K kernel when all of them have the same operand layout and a
+// common tile shape divides them (INET_GEMM_GROUP=0: always one after the other); else one launch each.
+int launch_gemm_group(const GemmArgs* list, int n, hipStream_t s) {
+    static const bool grouped = [] { const char* v = std::getenv("INET_GEMM_GROUP"); return !(v && v[0] == '0'); }();
+    if (g_direct < 0) { const char* v = std::getenv("INET_GEMM_DIRECT"); g_direct = v ? std::atoi(v) : 1; }
+    bool ok = grouped && n >= 2 && n <= kGemmGroupMax && g_direct > 0 && g_direct != 3 && g_force_cfg < 0;
+    for (int i = 0; i < n && ok; ++i) {
+        const GemmArgs& g = list[i];
+        ok = g.M > 0 && g.N > 0 && g.K >= 64 && g.nbatch <= 1 && g.acc != ACC_ATOMIC && !(g.a_kmajor && !g.b_kmajor) &&
+             (g.a_kmajor || (g.K & 15) == 0) && g.a_kmajor == list[0].a_kmajor && g.b_kmajor == list[0].b_kmajor &&
+             (double)(g.a_kmajor ? g.K : g.M) * g.lda * 4 < 2.0e9 && (double)(g.b_kmajor ? g.K : g.N) * g.ldb * 4 < 2.0e9;
+    }
+    int bi = -1;
+    long total = 0;
+    if (ok) {
+        // the largest tile that divides every product and still gives the launch >= 192 workgroups; else the smallest that divides
+        for (int ci = 0; ci < 3; ++ci) {
+            const KsCfg& c = kKs[ci];
+            bool div = true;
+            long wgs = 0;
+            for (int i = 0; i < n; ++i) {
+                if (list[i].M % (16 * c.ta) || list[i].N % (16 * c.tb)) div = false;
+                else wgs += (long)(list[i].M / (16 * c.ta)) * (list[i].N / (16 * c.tb));
+            }
+            if (!div) continue;
+            bi = ci; total = wgs;
+            if (wgs >= 192) break;
+        }
+        if (bi < 0 || total > 2048) ok = false;
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i) { const int rc = launch_gemm(list[i], s); if (rc != 0) return rc; }
+        return 0;
+    }
+    const KsCfg& c = kKs[bi];
+    GemmGroupArgs a{};
+    a.n = n;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs g = list[i];
+        if (g.acc == ACC_ADD && side_is(s) && side_order_dest(g.C, s) != 0) return -2;
+        g.k_per_split = (g.K + 15) / 16 * 16;
+        a.g[i] = g;
+        a.tiles_n[i] = g.N / (16 * c.tb);
+        a.first[i + 1] = a.first[i] + a.tiles_n[i] * (g.M / (16 * c.ta));
+        flops += 2.0 * g.M * g.N * g.K;
+        bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+    }
+    char label[96];
+    std::snprintf(label, sizeof label, "group%d M%d N%d K%d %c%c k%dx%d e%d", n, list[0].M, list[0].N, list[0].K,
+                  list[0].a_kmajor ? 'T' : 'N', list[0].b_kmajor ? 'N' : 'T', 16 * c.ta, 16 * c.tb, list[0].epi);
+    ProfScope prof(PROF_GEMM, flops, s, label, bytes);
+    const dim3 grid(a.first[n]);
+    const bool akm = list[0].a_kmajor, bkm = list[0].b_kmajor;
+    switch (bi) {
+        case 0: launch_ks_group<4, 4>(a, akm, bkm, grid, s); break;
+        case 1: launch_ks_group<4, 2>(a, akm, bkm, grid, s); break;
+        default: launch_ks_group<2, 2>(a, akm, bkm, grid, s); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 // Tile / split-K selection by a small cost model (microseconds), calibrated on MI355X (profiles/r01_*):
 //  * a workgroup alone on a CU spends ~0.7 us per 32-deep chunk on the load -> LDS -> MFMA dependency, whatever the

@@ -66,13 +66,25 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
 #pragma unroll
         for (int g = 0; g < 3; ++g) bv[g] = P.gi_vec[g * H + jc];
     }
+    const bool has_h0 = P.h0 != nullptr;          // null: an all-zero initial state (never exchanged, step 0 contracts nothing)
 #pragma unroll
     for (int p = 0; p < MS; ++p) {
         brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1);
-        hp[p] = P.h0[(long)brow[p] * P.ld_h0 + jc];
+        hp[p] = has_h0 ? P.h0[(long)brow[p] * P.ld_h0 + jc] : 0.f;
     }
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.hx);
     unsigned* counter = A.counters + group * kChainCounterStride;
+    // The initial state enters the exchange like any later one: every member publishes its own 16 columns of h0 into
+    // slot 1 and arrives (a pack launch in front of every chain used to do this: 8 launches per training step).
+    if (has_h0) {
+#pragma unroll
+        for (int p = 0; p < MS; ++p) xt[((t + 256 * p) >> 4) * 16 + (t & 15)] = hp[p];
+        __syncthreads();
+        if (t < 64 * MS && rb0 + (t >> 6) <= rb_last)
+            chain::publish_block(rs, slot_bytes, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
+        chain::arrive(counter);
+    }
+    const int arrivals0 = has_h0 ? 1 : 0;
     // Operand sources as (pointer, strides) with every field in a register before the loop; an absent source points at a
     // zero word with zero strides, so the per-step requests are unconditional loads issued back to back (conditional
     // loads make hipcc wrap each in a branch with its own s_waitcnt vmcnt(0): one exposed round trip per operand).
@@ -110,13 +122,14 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
             pm[p] = mskp[tt * msk_ts + b * msk_ld + msk_j];
             tok[p] = idxp[b * idx_bs + tn * idx_ts];
         }
-        if (step > 0 && !chain::wait_group(counter, (unsigned)(step * members), status, &flag[step & 1])) return;
+        const bool recur = step > 0 || has_h0;
+        if (recur && !chain::wait_group(counter, (unsigned)((step + arrivals0) * members), status, &flag[step & 1])) return;
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int a = 0; a < 3; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        chain::INET_GRU_CONTRACT<MS, 3, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
+        if (recur) chain::INET_GRU_CONTRACT<MS, 3, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
         float v[MS][3];
         reduce_waves<MS, 3>(acc, red, t, v);
         // gates first, then the hand-off (what the other members wait for), then the stores nobody in the launch reads

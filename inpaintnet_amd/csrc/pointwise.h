@@ -11,7 +11,9 @@ int pw_pack_frag(const float* in, long ld, int R, int K, float* out, int transpo
 int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long ld, int R, int K, int transposed,
                        hipStream_t s);
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
-                     float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s);
+                     float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s,
+                     const float* scale_dev = nullptr, const float* add_term = nullptr, float add_scale = 0.f,
+                     float* fwd_out = nullptr, float fwd_scale = 0.f);
 int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,
                   hipStream_t s);
 int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float* eps, float kscale, const float* kdev,
@@ -21,6 +23,9 @@ int pw_sample_multinomial(const float* W, long ld_w, int rows, int V, long long*
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
             float gscale, hipStream_t s);
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);
+// up to 8 column sums (bias gradients of one module) in one launch: out_i[n] += sum_m X_i[m*ld_i + n]
+struct PwColsumJob { const float* X; long ld; int M, N; float* out; };
+int pw_colsum_multi(const PwColsumJob* jobs, int n, hipStream_t s);
 int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
               hipStream_t s);
 // out[v][c] = sum of the rows of X whose token is v (out [W][ncols], W <= 63); row r has token idx[(r/inner)*s_outer + (r%inner)*s_inner]
@@ -55,3 +60,18 @@ int pw_embedding_bwd(const float* dout, const long long* idx, long rows, int E, 
 int pw_tokens_i32_to_i64(const int* src, long long* dst, long n, hipStream_t s);
 int pw_split_measures(const int* score, int B, int M, int L, int n_past, int n_target, long long* past,
                       long long* target, long long* future, hipStream_t s);
+
+// ---- one launch for the scattered little jobs in front of a module's forward pass (each used to be its own launch of
+// 5 us): gather tables  out[r][n] = emb[r,:E] . W[n,:E] + bias[n]  (the embedding -> layer-0 input projection folded
+// into a table, K = E ~ 10: not MFMA work), the zero-fill of the chain kernels' sync areas, a word copy, y = a*x + b,
+// an int64 fill, and the teacher-forced token copy / shift.  Absent jobs have null pointers / zero counts.
+struct PwTableJob { const float* emb; long ld_emb; int rows; const float* W; long ldw; const float* bias; float* out; long ld_out; int N; int E; };
+struct PwPrologue {
+    PwTableJob tab[4]; int ntab;
+    unsigned* zero_words; long nzero;
+    const unsigned* copy_src; unsigned* copy_dst; long ncopy;
+    const float* axpb_a; const float* axpb_x; long axpb_incx; const float* axpb_b; float* axpb_y; int axpb_n;
+    long long* fill_ptr; long nfill; long long fill_val;
+    const long long* tok_src; long long* tok_copy; long long* tok_shift; int tok_B, tok_T; long long tok_first;
+};
+int pw_prologue(const PwPrologue& p, hipStream_t s);

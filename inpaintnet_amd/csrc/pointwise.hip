@@ -103,7 +103,18 @@ __global__ void pack_frag_multi_kernel(PackList pl, long ld, int R, int K, int t
 // correct += out_scale * (argmax_first(w) == target); dW = (softmax - onehot) * scale.
 __global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int V,
                           const long long* __restrict__ tgt, float* __restrict__ dW, long ld_dw, float scale,
-                          float out_scale, float* __restrict__ loss_sum, float* __restrict__ correct) {
+                          float out_scale, float* __restrict__ loss_sum, float* __restrict__ correct,
+                          const float* __restrict__ scale_dev, const float* __restrict__ add_term, float add_scale,
+                          float* __restrict__ fwd_out, float fwd_scale) {
+    // scale_dev: dW is also multiplied by this device scalar (the upstream gradient of the mean loss, read on the device:
+    // no elementwise pass over dW afterwards); add_term: *loss_sum also receives add_scale * add_term[0], once (the KL
+    // term of the ELBO: loss = CE + beta/B * KL leaves this kernel complete)
+    // fwd_out: receives fwd_scale * scale_dev[0] (the gradient handed on to the producer of add_term, e.g. the KL sum)
+    if (scale_dev) {
+        if (fwd_out && blockIdx.x == 0 && threadIdx.x == 0) *fwd_out = fwd_scale * *scale_dev;
+        scale *= *scale_dev;
+    }
+    if (add_term && loss_sum && blockIdx.x == 0 && threadIdx.x == 0) unsafeAtomicAdd(loss_sum, add_scale * *add_term);
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -139,8 +150,8 @@ __global__ void ce_kernel(const float* __restrict__ W, long ld_w, int rows, int 
     if (lane == 0) { part[0][threadIdx.x >> 6] = lsum; part[1][threadIdx.x >> 6] = csum; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(loss_sum, (part[0][0] + part[0][1] + part[0][2] + part[0][3]) * out_scale);
-        unsafeAtomicAdd(correct, (part[1][0] + part[1][1] + part[1][2] + part[1][3]) * out_scale);
+        if (loss_sum) unsafeAtomicAdd(loss_sum, (part[0][0] + part[0][1] + part[0][2] + part[0][3]) * out_scale);
+        if (correct) unsafeAtomicAdd(correct, (part[1][0] + part[1][1] + part[1][2] + part[1][3]) * out_scale);
     }
 }
 
@@ -228,6 +239,29 @@ __global__ void colsum_kernel(const float* __restrict__ X, long ld, int M, int N
     if (rl == 0 && c < N) {
         s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
         unsafeAtomicAdd(out + c, s);
+    }
+}
+
+// several column sums in one launch: blockIdx.z picks the job (blocks outside its extent leave at once)
+struct ColsumList { int n; PwColsumJob j[8]; };
+__global__ void colsum_multi_kernel(ColsumList L) {
+    __shared__ float part[4][64];
+    const PwColsumJob& J = L.j[blockIdx.z];
+    const int M = J.M, N = J.N;
+    if ((int)blockIdx.x * 64 >= N) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    if (r0 >= M) return;
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0 + rl; r < r1; r += 4) s += J.X[(long)r * J.ld + c];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        unsafeAtomicAdd(J.out + c, s);
     }
 }
 
@@ -331,6 +365,43 @@ __global__ __launch_bounds__(256) void table_grad_kernel(TableGradArgs a) {
         unsafeAtomicAdd(a.demb + (long)v * a.ld_demb + threadIdx.x,
                         sh[threadIdx.x] + sh[16 + threadIdx.x] + sh[32 + threadIdx.x] + sh[48 + threadIdx.x]);
 }
+
+// pw_prologue (pointwise.h): blockIdx.y picks the job, blockIdx.x strides over it
+__global__ void prologue_kernel(PwPrologue a) {
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+    const int job = blockIdx.y;
+    if (job < 4) {
+        if (job >= a.ntab) return;
+        const PwTableJob& t = a.tab[job];
+        const long n = (long)t.rows * t.N;
+        for (long i = i0; i < n; i += step) {
+            const int r = (int)(i / t.N), c = (int)(i - (long)r * t.N);
+            const float* e = t.emb + r * t.ld_emb;
+            const float* w = t.W + c * t.ldw;
+            float acc = t.bias ? t.bias[c] : 0.f;
+            for (int k = 0; k < t.E; ++k) acc = fmaf(e[k], w[k], acc);
+            t.out[r * t.ld_out + c] = acc;
+        }
+    } else if (job == 4) {
+        for (long i = i0; i < a.nzero; i += step) a.zero_words[i] = 0u;
+        for (long i = i0; i < a.ncopy; i += step) a.copy_dst[i] = a.copy_src[i];
+    } else if (job == 5) {
+        if (a.axpb_n > 0) {
+            const float av = *a.axpb_a;
+            for (long i = i0; i < a.axpb_n; i += step) a.axpb_y[i] = av * a.axpb_x[i * a.axpb_incx] + a.axpb_b[i];
+        }
+        for (long i = i0; i < a.nfill; i += step) a.fill_ptr[i] = a.fill_val;
+    } else {
+        if (!a.tok_src) return;
+        const long n = (long)a.tok_B * a.tok_T;
+        for (long i = i0; i < n; i += step) {
+            const long long v = a.tok_src[i];
+            if (a.tok_copy) a.tok_copy[i] = v;
+            if (a.tok_shift) a.tok_shift[i] = (i % a.tok_T) == 0 ? a.tok_first : a.tok_src[i - 1];
+        }
+    }
+}
+
 
 __global__ void shift_tokens_kernel(const long long* __restrict__ target, int B, int T, long long first,
                                     long long* __restrict__ out) {
@@ -582,10 +653,11 @@ int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long 
     return ok();
 }
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
-                     float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s) {
+                     float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s, const float* scale_dev,
+                     const float* add_term, float add_scale, float* fwd_out, float fwd_scale) {
     const int g = grid_for((long)rows * 64, 256, 512);
     hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, out_scale, loss_sum,
-                       correct);
+                       correct, scale_dev, add_term, add_scale, fwd_out, fwd_scale);
     return ok();
 }
 int pw_reparam_kl(const float* mu, const float* ls, const float* eps, float* z, float* sigma, long n, float* kl_sum,
@@ -613,6 +685,23 @@ int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s) 
     if (gy > 64) gy = 64;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, gy), dim3(256), 0, s, X, ld, M, N, out);
+    return ok();
+}
+int pw_colsum_multi(const PwColsumJob* jobs, int n, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (n > 8) return -1;
+    ColsumList L{};
+    L.n = n;
+    int maxN = 0, maxM = 0;
+    for (int i = 0; i < n; ++i) {
+        L.j[i] = jobs[i];
+        if (jobs[i].N > maxN) maxN = jobs[i].N;
+        if (jobs[i].M > maxM) maxM = jobs[i].M;
+    }
+    int gy = (maxM + 255) / 256;
+    if (gy > 64) gy = 64;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((maxN + 63) / 64, gy, n), dim3(256), 0, s, L);
     return ok();
 }
 int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
@@ -741,5 +830,9 @@ int pw_split_measures(const int* score, int B, int M, int L, int n_past, int n_t
                       long long* target, long long* future, hipStream_t s) {
     hipLaunchKernelGGL(split_measures_kernel, dim3(grid_for((long)B * M * L)), dim3(256), 0, s, score, B, M, L, n_past,
                        n_target, past, target, future);
+    return ok();
+}
+int pw_prologue(const PwPrologue& p, hipStream_t s) {
+    hipLaunchKernelGGL(prologue_kernel, dim3(48, 7), dim3(256), 0, s, p);
     return ok();
 }

@@ -89,6 +89,18 @@ inline int linear_fwd(const float* x, long ldx, const float* W, long ldw, const 
                       int N, int K, int epi, hipStream_t s) {
     return launch_gemm(gemm_args(x, ldx, 0, W, ldw, 0, y, ldy, M, N, K, b, epi), s);
 }
+inline GemmArgs linear_fwd_args(const float* x, long ldx, const float* W, long ldw, const float* b, float* y, long ldy,
+                                int M, int N, int K, int epi) {
+    return gemm_args(x, ldx, 0, W, ldw, 0, y, ldy, M, N, K, b, epi);
+}
+inline GemmArgs linear_dgrad_args(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N,
+                                  int K, int epi, const float* aux, long ldaux, int acc) {
+    return gemm_args(dy, lddy, 0, W, ldw, 1, dx, lddx, M, K, N, nullptr, epi, aux, ldaux, acc);
+}
+inline GemmArgs linear_wgrad_args(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M, int N,
+                                  int K) {
+    return gemm_args(dy, lddy, 1, x, ldx, 1, dW, lddw, N, K, M, nullptr, EPI_NONE, nullptr, 0, ACC_ADD);
+}
 // dx[M,K] (op)= epi(dy[M,N] W[N,K])                        (dgrad)
 inline int linear_dgrad(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N, int K,
                         int epi, const float* aux, long ldaux, int acc, hipStream_t s) {
@@ -128,8 +140,10 @@ struct BiGru2In {
     const float* gvec[2];
 };
 // h0: [4][B][H] or null.  mask: [T][B][2H] or null.  hn4: 4 destinations (ld given) for final hiddens or null.
+// sync_prezeroed: the caller has zeroed w.sync (all kSyncAreas areas) on `s` already (the encoder's prologue launch does)
 int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P /*[4]*/, const BiGru2In& in, const float* h0,
-                    const float* mask, float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s);
+                    const float* mask, float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s,
+                    int sync_prezeroed = 0);
 // dout1: gradient wrt the top layer outputs [T][B][2H] (or null); dhn[4] (ld) gradients wrt final hiddens (or null each).
 // Produces w.dgi0 [T][B][6H] (layer-0 input-side gate gradients, fwd dir cols 0..3H, reverse 3H..6H), accumulates the
 // recurrent / layer-1 weight gradients into P[*].d* (skipped when P[0].dw_hh is null), dh0 [4][B][H] (or null).

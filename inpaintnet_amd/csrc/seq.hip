@@ -6,16 +6,9 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     const long pkh = (long)pk_floats(B, H);
     bool pk = pk_ok(H);
     for (int i = 0; i < nd; ++i) if (!d[i].Wpk_hh || !d[i].hpk) pk = false;
-    if (pk)                                                    // step 0 reads slot 1
-    {
-        bool same_ld = true;
-        const float* ins[4]; float* outs[4];
-        for (int i = 0; i < nd; ++i) { ins[i] = d[i].h0; outs[i] = d[i].hpk + pkh; same_ld = same_ld && d[i].h0_ld == d[0].h0_ld; }
-        if (same_ld) INET_TRY(pw_pack_frag_multi(ins, outs, nd, d[0].h0_ld, B, H, 0, s));
-        else for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
-    }
     if (pk && d[0].sync && gru_chain_ok(H, B, T, nd)) {
-        // one persistent launch for all T steps (gru_chain.hip); the exchange buffer is the hpk ring, slot 1 = h0
+        // one persistent launch for all T steps (gru_chain.hip); the exchange buffer is the hpk ring, slot 1 = h0 (published
+        // by the kernel itself; a null h0 = zeros)
         GruChainFwd a{};
         a.H = H; a.B = B; a.T = T; a.nprob = nd;
         for (int i = 0; i < nd; ++i) {
@@ -44,10 +37,9 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     for (int i = 0; i < nd; ++i) chunked = chunked && !d[i].sv;
     if (chunked) {
         // Two chunks at a time, on two streams: the kernel's 256-register build lets two launches share every CU, and one
-        // chunk's hand-off latency (a third of each step) is filled by the other chunk's MFMAs.  Chunk c works on slot 1 =
-        // its rows of the full-batch h0 pack made above (row blocks are the outermost index of the fragment-major layout)
-        // and slot 0 = the same rows of the (otherwise unused) slot 0 of the full ring; even / odd chunks count on
-        // different sync areas.
+        // chunk's hand-off latency (a third of each step) is filled by the other chunk's MFMAs.  Chunk c works on its rows
+        // of the two slots of the full-batch ring (row blocks are the outermost index of the fragment-major layout); even /
+        // odd chunks count on different sync areas.
         static const bool twin = [] { const char* v = std::getenv("INET_CHUNK_TWIN"); return !(v && v[0] == '0'); }();
         const long pkc = (long)pk_floats(CH, H);
         hipStream_t s2 = twin ? twin_fork(s) : s;
@@ -60,7 +52,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
                 const DirFwd& D = d[i];
                 GruChainFwdProb& P = a.p[i];
                 P.W_hh = D.W_hh; P.b_hh = D.b_hh;
-                P.h0 = D.h0 + r0 * D.h0_ld; P.ld_h0 = D.h0_ld;
+                P.h0 = D.h0 ? D.h0 + r0 * D.h0_ld : nullptr; P.ld_h0 = D.h0_ld;
                 P.gi_dense = D.gi ? D.gi + r0 * D.gi_ld : nullptr; P.ld_gi = D.gi_ld; P.ts_gi = D.gi_ts;
                 P.gi_table = D.table; P.ld_table = D.table_ld;
                 P.idx = D.idx ? D.idx + r0 * D.idx_bs : nullptr; P.idx_bs = D.idx_bs; P.idx_ts = D.idx_ts;
@@ -75,6 +67,15 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
             INET_TRY(launch_gru_chain_fwd(a, (c & 1) ? s2 : s));
         }
         return s2 != s ? twin_join(s) : 0;
+    }
+    // one launch per step (gru.hip): the fragment-major ring's slot 1 is packed from h0 here (step 0 reads it)
+    for (int i = 0; i < nd; ++i) if (!d[i].h0) return -1;     // (a null h0 is the chain kernels' shorthand for zeros)
+    if (pk) {
+        bool same_ld = true;
+        const float* ins[4]; float* outs[4];
+        for (int i = 0; i < nd; ++i) { ins[i] = d[i].h0; outs[i] = d[i].hpk + pkh; same_ld = same_ld && d[i].h0_ld == d[0].h0_ld; }
+        if (same_ld) INET_TRY(pw_pack_frag_multi(ins, outs, nd, d[0].h0_ld, B, H, 0, s));
+        else for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
     }
     for (int step = 0; step < T; ++step) {
         GruFwdBatch bt{};
@@ -244,14 +245,17 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
 }
 
 int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in, const float* h0, const float* mask,
-                    float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s) {
+                    float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s, int sync_prezeroed) {
     const long BH = (long)B * H, TBH = (long)T * BH;
-    if (!h0 && pw_zero(w.zeros, BH, s) != 0) return -2;
     // fragment-major W_hh twins: only the per-step kernels read them (the chain kernels take W_hh as stored)
     const bool chained = w.wpk[0] && w.hpk[0] && w.sync && pk_ok(H) &&
                          (gru_chain_ok(H, B, T, 2) || (!save && B >= 512 && B % 256 == 0 && gru_chain_ok(H, 256, T, 2)));
+    // zero initial state: the chain kernels take a null pointer (and skip step 0's contraction), the per-step kernels a buffer
+    const float* const hzero = chained ? nullptr : w.zeros;
+    if (!h0 && !chained && pw_zero(w.zeros, BH, s) != 0) return -2;
     const bool one_launch = chained && gru_chain_ok(H, B, T, 2);      // (not the chunked form: it reuses one area per launch)
-    if (one_launch && hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    if (one_launch && !sync_prezeroed &&
+        hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     if (w.wpk[0] && !chained)
     {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
@@ -265,7 +269,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (in.gi0[dir]) { D.gi = in.gi0[dir]; D.gi_ld = in.gi0_ld; D.gi_ts = in.gi0_ts; }
         if (in.tab[dir]) { D.table = in.tab[dir]; D.table_ld = in.tab_ld; D.idx = in.idx; D.idx_bs = in.idx_bs; D.idx_ts = in.idx_ts; }
         D.gvec = in.gvec[dir];
-        D.h0 = h0 ? h0 + dir * BH : w.zeros; D.h0_ld = H;
+        D.h0 = h0 ? h0 + dir * BH : hzero; D.h0_ld = H;
         D.out = w.x1raw + dir * H; D.out_ld = 2L * H; D.out_ts = 2 * BH;
         if (mask) {
             D.outm = w.x1m + dir * H; D.outm_ld = 2L * H; D.outm_ts = 2 * BH;
@@ -287,7 +291,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         D = DirFwd{};
         D.W_hh = P[2 + dir].w_hh; D.b_hh = P[2 + dir].b_hh;
         D.gi = w.gi1 + dir * 3L * H; D.gi_ld = 6L * H; D.gi_ts = 6 * BH;
-        D.h0 = h0 ? h0 + (2 + dir) * BH : w.zeros; D.h0_ld = H;
+        D.h0 = h0 ? h0 + (2 + dir) * BH : hzero; D.h0_ld = H;
         D.out = w.h1 + dir * H; D.out_ld = 2L * H; D.out_ts = 2 * BH;
         if (hn && hn[2 + dir]) { D.hlast = hn[2 + dir]; D.hlast_ld = hn_ld; }
         if (save) { D.sv = w.sv[2 + dir]; D.sv_astride = TBH; }

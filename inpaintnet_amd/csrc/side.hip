@@ -22,9 +22,14 @@ size_t g_next = 0;
 
 hipEvent_t next_event() {
     if (g_pool.empty()) {
+        // These events only order streams of ONE device against each other: the system-scope fence an event performs by
+        // default when it completes (cache write-back + invalidate, ~7 us of bubble on the recording stream per fork,
+        // profiles/r02_v_timeline_full_step.txt) buys nothing here.  INET_EVENT_FENCE=1 restores the default.
+        static const bool fence = [] { const char* v = std::getenv("INET_EVENT_FENCE"); return v && v[0] == '1'; }();
         g_pool.resize(64);
         for (auto& e : g_pool)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (fence ? 0u : hipEventDisableSystemFence)) != hipSuccess &&
+                hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
     }
     hipEvent_t e = g_pool[g_next];
     g_next = (g_next + 1) % g_pool.size();

@@ -75,19 +75,28 @@ int vae_encoder_fwd(const inet_vae_config& c, int B, const long long* tokens, co
     enc_carve(c, B, save, ws, w);
     GruDirPtr P[4];
     enc_ptrs(L, p, nullptr, P);
-    // gather tables: E_enc [V,E] x W_ih_l0[dir] [3H,E]^T + b_ih
-    INET_TRY(linear_fwd(p + L.enc_emb, E, P[0].w_ih, E, P[0].b_ih, w.tabF, 3L * H, V, 3 * H, E, EPI_NONE, s));
-    INET_TRY(linear_fwd(p + L.enc_emb, E, P[1].w_ih, E, P[1].b_ih, w.tabR, 3L * H, V, 3 * H, E, EPI_NONE, s));
+    // gather tables: E_enc [V,E] x W_ih_l0[dir] [3H,E]^T + b_ih -- and the chain kernels' sync areas zeroed -- in one launch
+    {
+        PwPrologue pr{};
+        for (int dir = 0; dir < 2; ++dir)
+            pr.tab[dir] = PwTableJob{p + L.enc_emb, E, V, P[dir].w_ih, E, P[dir].b_ih, dir ? w.tabR : w.tabF, 3L * H, 3 * H, E};
+        pr.ntab = 2;
+        pr.zero_words = w.g.sync; pr.nzero = (long)kSyncAreas * kChainSyncWords;
+        INET_TRY(pw_prologue(pr, s));
+    }
     BiGru2In in{};
     in.tab[0] = w.tabF; in.tab[1] = w.tabR; in.tab_ld = 3L * H;
     in.idx = tokens; in.idx_bs = T; in.idx_ts = 1;
     // final hiddens land directly in hcat = [l0f | l0b | l1f | l1b]   (encoder.py:126-127)
     float* hn[4] = {w.hcat, w.hcat + H, w.hcat + 2 * H, w.hcat + 3 * H};
-    INET_TRY(bigru2_core_fwd(B, T, H, P, in, nullptr, mask, hn, 4L * H, w.g, save, s));
-    INET_TRY(linear_fwd(w.hcat, 4L * H, p + L.mean_w0, 4L * H, p + L.mean_b0, w.a_mu, 2L * H, B, 2 * H, 4 * H, EPI_SELU, s));
-    INET_TRY(linear_fwd(w.a_mu, 2L * H, p + L.mean_w2, 2L * H, p + L.mean_b2, mu, Z, B, Z, 2 * H, EPI_NONE, s));
-    INET_TRY(linear_fwd(w.hcat, 4L * H, p + L.ls_w0, 4L * H, p + L.ls_b0, w.a_ls, 2L * H, B, 2 * H, 4 * H, EPI_SELU, s));
-    INET_TRY(linear_fwd(w.a_ls, 2L * H, p + L.ls_w2, 2L * H, p + L.ls_b2, logsigma, Z, B, Z, 2 * H, EPI_NONE, s));
+    INET_TRY(bigru2_core_fwd(B, T, H, P, in, nullptr, mask, hn, 4L * H, w.g, save, s, 1));
+    // the two heads (encoder.py:130-133) side by side: two launches of two products instead of four launches
+    const GemmArgs l1[2] = {linear_fwd_args(w.hcat, 4L * H, p + L.mean_w0, 4L * H, p + L.mean_b0, w.a_mu, 2L * H, B, 2 * H, 4 * H, EPI_SELU),
+                            linear_fwd_args(w.hcat, 4L * H, p + L.ls_w0, 4L * H, p + L.ls_b0, w.a_ls, 2L * H, B, 2 * H, 4 * H, EPI_SELU)};
+    INET_TRY(launch_gemm_group(l1, 2, s));
+    const GemmArgs l2[2] = {linear_fwd_args(w.a_mu, 2L * H, p + L.mean_w2, 2L * H, p + L.mean_b2, mu, Z, B, Z, 2 * H, EPI_NONE),
+                            linear_fwd_args(w.a_ls, 2L * H, p + L.ls_w2, 2L * H, p + L.ls_b2, logsigma, Z, B, Z, 2 * H, EPI_NONE)};
+    INET_TRY(launch_gemm_group(l2, 2, s));
     return 0;
 }
 
@@ -102,20 +111,24 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
     enc_ptrs(L, p, g, P);
     // heads  (stage 2 of a staged call starts at the layer-0 BPTT: see vae.h)
     if (stage != 2) {
-    INET_TRY(linear_dgrad(dmu, Z, p + L.mean_w2, 2L * H, w.d_amu, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_mu, 2L * H, ACC_STORE, s));
-    INET_TRY(linear_dgrad(dls, Z, p + L.ls_w2, 2L * H, w.d_als, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_ls, 2L * H, ACC_STORE, s));
+    {
+        const GemmArgs d2[2] = {linear_dgrad_args(dmu, Z, p + L.mean_w2, 2L * H, w.d_amu, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_mu, 2L * H, ACC_STORE),
+                                linear_dgrad_args(dls, Z, p + L.ls_w2, 2L * H, w.d_als, 2L * H, B, Z, 2 * H, EPI_MUL_SELU_GRAD, w.a_ls, 2L * H, ACC_STORE)};
+        INET_TRY(launch_gemm_group(d2, 2, s));
+    }
     INET_TRY(linear_dgrad(w.d_amu, 2L * H, p + L.mean_w0, 4L * H, w.dhcat, 4L * H, B, 2 * H, 4 * H, EPI_NONE, nullptr, 0, ACC_STORE, s));
     INET_TRY(linear_dgrad(w.d_als, 2L * H, p + L.ls_w0, 4L * H, w.dhcat, 4L * H, B, 2 * H, 4 * H, EPI_NONE, nullptr, 0, ACC_ADD, s));
     {   // leaf work (weight / bias gradients of the heads) on the side stream
         hipStream_t ss = side_fork(s);
-        INET_TRY(linear_wgrad(dmu, Z, w.a_mu, 2L * H, g + L.mean_w2, 2L * H, B, Z, 2 * H, ss));
-        INET_TRY(linear_wgrad(dls, Z, w.a_ls, 2L * H, g + L.ls_w2, 2L * H, B, Z, 2 * H, ss));
-        INET_TRY(pw_colsum(dmu, Z, B, Z, g + L.mean_b2, ss));
-        INET_TRY(pw_colsum(dls, Z, B, Z, g + L.ls_b2, ss));
-        INET_TRY(linear_wgrad(w.d_amu, 2L * H, w.hcat, 4L * H, g + L.mean_w0, 4L * H, B, 2 * H, 4 * H, ss));
-        INET_TRY(linear_wgrad(w.d_als, 2L * H, w.hcat, 4L * H, g + L.ls_w0, 4L * H, B, 2 * H, 4 * H, ss));
-        INET_TRY(pw_colsum(w.d_amu, 2L * H, B, 2 * H, g + L.mean_b0, ss));
-        INET_TRY(pw_colsum(w.d_als, 2L * H, B, 2 * H, g + L.ls_b0, ss));
+        const GemmArgs w2[2] = {linear_wgrad_args(dmu, Z, w.a_mu, 2L * H, g + L.mean_w2, 2L * H, B, Z, 2 * H),
+                                linear_wgrad_args(dls, Z, w.a_ls, 2L * H, g + L.ls_w2, 2L * H, B, Z, 2 * H)};
+        INET_TRY(launch_gemm_group(w2, 2, ss));
+        const GemmArgs w0[2] = {linear_wgrad_args(w.d_amu, 2L * H, w.hcat, 4L * H, g + L.mean_w0, 4L * H, B, 2 * H, 4 * H),
+                                linear_wgrad_args(w.d_als, 2L * H, w.hcat, 4L * H, g + L.ls_w0, 4L * H, B, 2 * H, 4 * H)};
+        INET_TRY(launch_gemm_group(w0, 2, ss));
+        const PwColsumJob cs[4] = {{dmu, Z, B, Z, g + L.mean_b2}, {dls, Z, B, Z, g + L.ls_b2},
+                                   {w.d_amu, 2L * H, B, 2 * H, g + L.mean_b0}, {w.d_als, 2L * H, B, 2 * H, g + L.ls_b0}};
+        INET_TRY(pw_colsum_multi(cs, 4, ss));
     }
     }
     // GRU stack
@@ -218,7 +231,6 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
         w.dgi0b = cv.take<float>(3 * nb * BH);
         w.dgh0b = cv.take<float>(3 * nb * BH);
         w.dhb0 = cv.take<float>(2 * BH);
-        w.tmp3h = cv.take<float>(3 * H);
     }
     const bool pk = pk_ok((int)H);
     const size_t pkh = pk_floats(B, (int)H), W3 = 3 * H * H;
@@ -238,6 +250,7 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.amax = cv.take<float>(2 * 2 * ((V + 15) / 16) * ((B + 15) / 16) * 16);
     static_assert(kDecodeSyncWords <= kChainSyncWords, "one sync area serves either kind of chain launch");
     w.sync = cv.take<unsigned>(kSyncAreas * kChainSyncWords);
+    w.tmp3h = save ? cv.take<float>(3 * H) : nullptr;          // right behind the sync areas: one memset zeroes both
     return cv.bytes();
 }
 
@@ -272,7 +285,6 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     VaeLayout L(c);
     DecWs w{};
     dec_carve(c, B, save, ws, w);
-    if (save && pw_copy_bytes(w.zsave, z, (long)B * Z * sizeof(float), s) != 0) return -2;
     const bool pk = w.wpk_t0 != nullptr;
     static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
     const long pkh = (long)pk_floats(B, H);
@@ -298,8 +310,28 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         for (int n = nb; n >= 1 && !npl; --n)
             if (nb % n == 0 && 2 + 2 * (nb / n) <= kSyncAreas && gru_chain_ok(H, B, G, n)) npl = n;
     const bool ticks_chained = npl > 0;
-    if ((beats_chained || fused_decode || ticks_chained) &&
-        hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    const float* wih0 = p + L.tick[0].w_ih;                   // [3H, E+H]
+    const long ldw0 = E + H;
+    {
+        // One launch for the scattered little jobs (each used to be its own ~5 us launch): z saved for the backward pass, the
+        // chain kernels' sync areas zeroed, the beat GRU's constant input gates gvec0 = b_0 W_ih[:,0] + b_ih, the tick
+        // GRU's gather table (rows 0..V-1 = E_dec . W_ih[:, :E]^T + b_ih; row V = x_0 . W_ih[:, :E]^T + b_ih), the start
+        // token index, and the teacher-forced token copy / shift.
+        PwPrologue pr{};
+        pr.tab[0] = PwTableJob{p + L.dec_emb, E, V, wih0, ldw0, p + L.tick[0].b_ih, w.table, 3L * H, 3 * H, E};
+        pr.tab[1] = PwTableJob{p + L.x_0, E, 1, wih0, ldw0, p + L.tick[0].b_ih, w.table + (long)V * 3 * H, 3L * H, 3 * H, E};
+        pr.ntab = 2;
+        if (beats_chained || fused_decode || ticks_chained) { pr.zero_words = w.sync; pr.nzero = (long)kSyncAreas * kChainSyncWords; }
+        if (save) { pr.copy_src = reinterpret_cast<const unsigned*>(z); pr.copy_dst = reinterpret_cast<unsigned*>(w.zsave); pr.ncopy = (long)B * Z; }
+        pr.axpb_a = p + L.b_0; pr.axpb_x = p + L.beat[0].w_ih; pr.axpb_incx = 1; pr.axpb_b = p + L.beat[0].b_ih;
+        pr.axpb_y = w.gvec0; pr.axpb_n = 3 * H;
+        pr.fill_ptr = w.idxV; pr.nfill = B; pr.fill_val = V;
+        if (teacher_forced) {
+            pr.tok_src = target; pr.tok_copy = samples; pr.tok_B = B; pr.tok_T = T; pr.tok_first = V;
+            if (ticks_chained) pr.tok_shift = w.tokin;
+        }
+        INET_TRY(pw_prologue(pr, s));
+    }
     if (pk) {
         const float* ins[5]; float* outs[5];
         int n = 0;
@@ -319,7 +351,6 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
 
     // ---- beat RNN (forward_beat_rnn, decoder.py:455-471) ----
     INET_TRY(linear_fwd(z, Z, p + L.zb_w, Z, p + L.zb_b, w.hb0, 2L * H, B, 2 * H, Z, EPI_SELU, s));
-    INET_TRY(pw_axpb(p + L.b_0, p + L.beat[0].w_ih, 1, p + L.beat[0].b_ih, w.gvec0, 3 * H, s));
     DirFwd d{};
     d.W_hh = p + L.beat[0].w_hh; d.b_hh = p + L.beat[0].b_hh;
     d.gvec = w.gvec0;
@@ -343,25 +374,18 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
 
     // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
-    INET_TRY(linear_fwd(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU, s));
+    {
+        const GemmArgs bt[2] = {linear_fwd_args(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU),
+                                linear_fwd_args(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU)};
+        INET_TRY(launch_gemm_group(bt, 2, s));
+    }
     if (pk && !ticks_chained && !fused_chunked)                // packed initial tick hiddens: [layer][beat]
         for (int l = 0; l < 2; ++l)
             INET_TRY(pw_pack_frag(w.ht0 + (long)l * H, 2L * H, B, H, w.ht0pk + (long)l * nb * pkh, 0, nb, (long)B * 2 * H, pkh, s));
-    INET_TRY(linear_fwd(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU, s));
-    const float* wih0 = p + L.tick[0].w_ih;                   // [3H, E+H]
-    const long ldw0 = E + H;
     INET_TRY(linear_fwd(w.c_all, H, wih0 + E, ldw0, nullptr, w.cgi, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
-    // gather table: rows 0..V-1 = E_dec . W_ih[:, :E]^T + b_ih ; row V = x_0 . W_ih[:, :E]^T + b_ih
-    INET_TRY(linear_fwd(p + L.dec_emb, E, wih0, ldw0, p + L.tick[0].b_ih, w.table, 3L * H, V, 3 * H, E, EPI_NONE, s));
-    INET_TRY(linear_fwd(p + L.x_0, E, wih0, ldw0, p + L.tick[0].b_ih, w.table + (long)V * 3 * H, 3L * H, 1, 3 * H, E, EPI_NONE, s));
-    INET_TRY(pw_fill_i64(w.idxV, B, V, s));
-    if (teacher_forced &&
-        pw_copy_bytes(samples, target, (long)B * T * sizeof(long long), s) != 0)
-        return -2;
 
     // ---- tick RNN (forward_tick_rnn, decoder.py:473-529) ----
     if (ticks_chained) {
-        INET_TRY(pw_shift_tokens(target, B, T, V, w.tokin, s));
         const float* x1 = mask_tick ? w.h0m : w.h0seq;
         for (int layer = 0; layer < 2; ++layer) {
             if (layer == 1)                                    // layer 1's input-side pre-activations for all 24 ticks at once
@@ -544,8 +568,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     // only packed for layers that fall back to one launch per step
     const bool beats_chained = w.wpkT[0] && w.dghpk && beat_chain && gru_chain_bwd_ok(H, B, nb, 1);
     const bool ticks_chained = w.wpkT[0] && w.dghpk && gru_chain_bwd_ok(H, B, G, nb);
-    if ((beats_chained || ticks_chained) &&
-        hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    // one memset: the chain kernels' sync areas and, right behind them, the accumulator of the beat GRU's input-gate column sum
+    if (hipMemsetAsync(w.sync, 0, (size_t)((char*)(w.tmp3h + 3 * H) - (char*)w.sync), s) != hipSuccess) return -2;
     if (w.wpkT[0]) {
         const float* ins[4]; float* outs[4];
         int n = 0;
@@ -558,12 +582,10 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     const long pkg = (long)pk_floats(B, 3 * H);
 
     // ---- output projection ----
+    // Leaf work (weight / bias gradients: nothing downstream reads them before the optimizer) goes to the side streams in
+    // THREE fork sessions -- after the layer-1 tick chain, after the layer-0 tick chain, at the end -- instead of one per
+    // module: every fork is an event on the main stream, and the small products of one session share a grouped launch.
     INET_TRY(pw_dlogits_relayout(dweights, weights, B, T, V, w.dlg, s));
-    if (g) {
-        hipStream_t ss = side_fork(s);
-        INET_TRY(linear_wgrad(w.dlg, V, w.h1seq, H, g + L.out_w, H, T * B, V, H, ss));
-        INET_TRY(pw_colsum(w.dlg, V, T * B, V, g + L.out_b, ss));
-    }
     INET_TRY(linear_dgrad(w.dlg, V, p + L.out_w, H, w.dh1top, H, T * B, V, H, EPI_NONE, nullptr, 0, ACC_STORE, s));
 
     // ---- tick RNN layer 1: 6 steps x 4 beats ----
@@ -588,6 +610,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         hipStream_t ss = side_fork(s);                       // overlaps the layer-0 BPTT chain below
         INET_TRY(linear_wgrad2(w.dgh1t, w.dgi1t, 3L * H, w.svt1 + 4 * TBH, x1, H, g + L.tick[1].w_hh, g + L.tick[1].w_ih, H,
                                T * B, 3 * H, H, ss));      // recurrent and input weights of layer 1 in one launch
+        INET_TRY(linear_wgrad(w.dlg, V, w.h1seq, H, g + L.out_w, H, T * B, V, H, ss));
+        INET_TRY(pw_colsum(w.dlg, V, T * B, V, g + L.out_b, ss));
     }
     INET_TRY(linear_dgrad(w.dgi1t, 3L * H, p + L.tick[1].w_ih, H, w.dx1t, H, T * B, 3 * H, H,
                           mask_tick ? EPI_MUL_AUX : EPI_NONE, mask_tick, H, ACC_STORE, s));
@@ -612,16 +636,13 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* wih0 = p + L.tick[0].w_ih;
     const long ldw0 = E + H;
-    if (g) {
-        hipStream_t ss = side_fork(s);
-        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, ss));
-    }
     // beat-constant input half:  dcgi[i] = sum_j dgi0[6i+j]  (summed in registers by the chain kernel when it ran)
     if (!dcgi_done) INET_TRY(pw_group_sum(w.dgi0t, nb, G, 3 * BH, w.dcgi, s));
     INET_TRY(linear_dgrad(w.dcgi, 3L * H, wih0 + E, ldw0, w.dc_all, H, nb * B, 3 * H, H, EPI_MUL_SELU_GRAD, w.c_all, H,
                           ACC_STORE, s));
     if (g) {
         hipStream_t ss = side_fork(s);
+        INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, ss));
         INET_TRY(linear_wgrad(w.dcgi, 3L * H, w.c_all, H, g + L.tick[0].w_ih + E, ldw0, nb * B, 3 * H, H, ss));
         // token-embedding half through the gather table
         INET_TRY(pw_zero(w.onehot, (long)T * B * (V + 1), ss));
@@ -638,13 +659,6 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     INET_TRY(pw_mul(w.dht0, w.ht0, 2L * nb * BH, 1, s));
     INET_TRY(linear_dgrad(w.dht0, 2L * H, p + L.bh_w, H, w.dbeat_out, H, nb * B, 2 * H, H, EPI_NONE, nullptr, 0, ACC_STORE, s));
     INET_TRY(linear_dgrad(w.dc_all, H, p + L.bi_w, H, w.dbeat_out, H, nb * B, H, H, EPI_NONE, nullptr, 0, ACC_ADD, s));
-    if (g) {
-        hipStream_t ss = side_fork(s);
-        INET_TRY(linear_wgrad(w.dht0, 2L * H, w.beat_out, H, g + L.bh_w, H, nb * B, 2 * H, H, ss));
-        INET_TRY(pw_colsum(w.dht0, 2L * H, nb * B, 2 * H, g + L.bh_b, ss));
-        INET_TRY(linear_wgrad(w.dc_all, H, w.beat_out, H, g + L.bi_w, H, nb * B, H, H, ss));
-        INET_TRY(pw_colsum(w.dc_all, H, nb * B, H, g + L.bi_b, ss));
-    }
 
     // ---- beat RNN ----
     DirBwd b{};
@@ -659,11 +673,6 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (beats_chained) { b.W_hh = p + L.beat[1].w_hh; b.sync = w.sync + 2 * kChainSyncWords; b.sync_prezeroed = 1; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
     const float* xb = mask_beat ? w.beat0m : w.beat0;
-    if (g) {
-        hipStream_t ss = side_fork(s);
-        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh1b, w.svb1 + 4 * nb * BH, g + L.beat[1].w_hh, ss));
-        INET_TRY(linear_wgrad(w.dgi1b, 3L * H, xb, H, g + L.beat[1].w_ih, H, nb * B, 3 * H, H, ss));
-    }
     INET_TRY(linear_dgrad(w.dgi1b, 3L * H, p + L.beat[1].w_ih, H, w.dxb, H, nb * B, 3 * H, H,
                           mask_beat ? EPI_MUL_AUX : EPI_NONE, mask_beat, H, ACC_STORE, s));
     b = DirBwd{};
@@ -677,22 +686,26 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     b.Wpk_hhT = w.wpkT[0]; b.dghpk = w.dghpk;
     if (beats_chained) { b.W_hh = p + L.beat[0].w_hh; b.sync = w.sync + 3 * kChainSyncWords; b.sync_prezeroed = 1; }
     INET_TRY(gru_layer_bwd(H, B, nb, 1, &b, s));
-    if (g) {
-        hipStream_t ss = side_fork(s);
-        INET_TRY(gru_dir_wgrad(H, B, nb, w.dgh0b, w.svb0 + 4 * nb * BH, g + L.beat[0].w_hh, ss));
-        // gi = b_0 * W_ih[:,0] + b_ih
-        INET_TRY(pw_zero(w.tmp3h, 3L * H, ss));
-        INET_TRY(pw_colsum(w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h, ss));
-        INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H, ss));
-    }
 
     // ---- z -> beat hidden ----
     INET_TRY(pw_mul(w.dhb0, w.hb0, 2 * BH, 1, s));
     if (dz) INET_TRY(linear_dgrad(w.dhb0, 2L * H, p + L.zb_w, Z, dz, Z, B, 2 * H, Z, EPI_NONE, nullptr, 0, ACC_STORE, s));
     if (g) {
+        // the beat path's leaf work in one session: six weight gradients in two grouped launches, four column sums in one
         hipStream_t ss = side_fork(s);
-        INET_TRY(linear_wgrad(w.dhb0, 2L * H, w.zsave, Z, g + L.zb_w, Z, B, 2 * H, Z, ss));
-        INET_TRY(pw_colsum(w.dhb0, 2L * H, B, 2 * H, g + L.zb_b, ss));
+        const GemmArgs ga[4] = {linear_wgrad_args(w.dht0, 2L * H, w.beat_out, H, g + L.bh_w, H, nb * B, 2 * H, H),
+                                linear_wgrad_args(w.dc_all, H, w.beat_out, H, g + L.bi_w, H, nb * B, H, H),
+                                linear_wgrad_args(w.dgh1b, 3L * H, w.svb1 + 4 * nb * BH, H, g + L.beat[1].w_hh, H, nb * B, 3 * H, H),
+                                linear_wgrad_args(w.dgi1b, 3L * H, xb, H, g + L.beat[1].w_ih, H, nb * B, 3 * H, H)};
+        INET_TRY(launch_gemm_group(ga, 4, ss));
+        const GemmArgs gb[2] = {linear_wgrad_args(w.dgh0b, 3L * H, w.svb0 + 4 * nb * BH, H, g + L.beat[0].w_hh, H, nb * B, 3 * H, H),
+                                linear_wgrad_args(w.dhb0, 2L * H, w.zsave, Z, g + L.zb_w, Z, B, 2 * H, Z)};
+        INET_TRY(launch_gemm_group(gb, 2, ss));
+        // bias gradients; gi(beat layer 0) = b_0 * W_ih[:,0] + b_ih: its column sum lands in tmp3h (zeroed with the sync areas)
+        const PwColsumJob cs[4] = {{w.dht0, 2L * H, nb * B, 2 * H, g + L.bh_b}, {w.dc_all, H, nb * B, H, g + L.bi_b},
+                                   {w.dhb0, 2L * H, B, 2 * H, g + L.zb_b}, {w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h}};
+        INET_TRY(pw_colsum_multi(cs, 4, ss));
+        INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H, ss));
     }
     return side_join(s);
 }

@@ -96,8 +96,9 @@ class _ReparamFn(torch.autograd.Function):
     the KL terms against N(0, 1) that VAETrainer.compute_kld_loss needs (vae_trainer.py:128-139)."""
 
     @staticmethod
-    def forward(ctx, mu, ls, eps):
-        kl = torch.zeros(1, dtype=torch.float32, device=mu.device)
+    def forward(ctx, mu, ls, eps, kl=None):
+        if kl is None:
+            kl = torch.zeros(1, dtype=torch.float32, device=mu.device)
         z, _ = ops.reparam_kl(mu, ls, eps, kl_sum=kl)
         ctx.save_for_backward(mu, ls, eps)
         ctx.set_materialize_grads(False)
@@ -111,7 +112,7 @@ class _ReparamFn(torch.autograd.Function):
         if dkl is not None:
             dkl = dkl.reshape(1).contiguous()
         dmu, dls = ops.latent_bwd(dz, mu, ls, eps, 1.0 if dkl is not None else 0.0, kscale_dev=dkl)
-        return dmu, dls, None
+        return dmu, dls, None, None
 
 
 class NormalLogScale(distributions.Normal):
@@ -120,11 +121,12 @@ class NormalLogScale(distributions.Normal):
     step never does.  rsample()/sample() draw eps with torch's device generator and combine on the GPU with the
     reparameterisation kernel, which also leaves the KL sum in `kl_sum`."""
 
-    def __init__(self, loc, log_scale):
+    def __init__(self, loc, log_scale, owner=None):
         self.loc = loc
         self.log_scale = log_scale
         self._scale = None
         self.kl_sum = None
+        self._owner = owner                      # the model whose arena tail holds the per-step accumulators (or None)
         distributions.Distribution.__init__(self, loc.size(), validate_args=False)
 
     @property
@@ -142,7 +144,8 @@ class NormalLogScale(distributions.Normal):
             return super().rsample(sample_shape)
         if eps is None:
             eps = torch.randn_like(self.loc)
-        z, self.kl_sum = _ReparamFn.apply(self.loc, self.log_scale, eps)
+        kl = self._owner.take_stats(1) if self._owner is not None else None
+        z, self.kl_sum = _ReparamFn.apply(self.loc, self.log_scale, eps, kl)
         self.last_eps = eps
         return z
 
@@ -191,7 +194,7 @@ class Encoder(torch.nn.Module):
             mask = ops.dropout_mask((T, batch_size, 2 * self.rnn_hidden_size), self.dropout, _DropState.seed,
                                     _next_mask_offset(n), tokens.device)
         mu, ls = _EncoderFn.call(self.owner.flat_for_autograd(), self, tokens, mask)
-        return NormalLogScale(mu, ls)
+        return NormalLogScale(mu, ls, self.owner)
 
 
 class _ExpFn(torch.autograd.Function):
@@ -351,7 +354,20 @@ class MeasureVAE(Model):
         """(B,24) int64 -> (weights, samples, z_dist, prior_dist, z_tilde, z_prior)   (measure_vae.py:97-134)"""
         seq_len = measure_score_tensor.size(1)
         assert seq_len == self.num_ticks_per_measure
-        z_dist = self.encoder(measure_score_tensor)
+        enc_mask = dec_masks = None
+        pe, pd = self.encoder.dropout, self.decoder.dropout
+        if self.training and pe > 0 and pe == pd:
+            # the three dropout masks of a step (encoder layer 0 -> 1, decoder beat and tick layers) in ONE launch: the mask
+            # stream is a pure function of (seed, offset + index), and the three would have taken consecutive offsets
+            B, T, nb = measure_score_tensor.size(0), seq_len, self.num_beats_per_measure
+            He, Hd = self.encoder_hidden_size, self.decoder_hidden_size
+            sizes = (T * B * 2 * He, nb * B * Hd, T * B * Hd)
+            buf = ops.dropout_mask((sum(sizes),), pe, _DropState.seed, _next_mask_offset(sum(sizes)),
+                                   measure_score_tensor.device)
+            m0, m1, m2 = torch.split(buf, sizes)
+            enc_mask = m0.view(T, B, 2 * He)
+            dec_masks = (m1.view(nb, B, Hd), m2.view(T, B, Hd))
+        z_dist = self.encoder(measure_score_tensor, mask=enc_mask)
         # prior_dist.sample() (measure_vae.py:127) for N(0, 1) is a plain standard-normal draw (torch.normal(mean, std)
         # would also validate std >= 0 with a device->host read, i.e. stall the host once per forward pass): eps of the
         # reparameterisation and z_prior come out of one generator call
@@ -363,7 +379,7 @@ class MeasureVAE(Model):
         z_tilde = z_dist.rsample(eps=eps)
         prior_dist = self._standard_normal(z_dist.loc)
         weights, samples = self.decoder(z=z_tilde, score_tensor=measure_score_tensor, train=train,
-                                        teacher_forced=teacher_forced)
+                                        teacher_forced=teacher_forced, masks=dec_masks)
         return weights, samples, z_dist, prior_dist, z_tilde, z_prior
 
     def _standard_normal(self, like):

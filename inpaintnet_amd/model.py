@@ -35,7 +35,12 @@ class Model(torch.nn.Module):
     def _alloc_arena(self, table, total, device):
         self._table = list(table)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        # the gradient arena carries a tail of _STATS floats: per-step accumulators of the loss kernels (KL sum, loss,
+        # accuracy) live there, so that zero_grad()'s ONE fill also zeroes them (each used to cost a torch.zeros launch)
+        self._grad_store = torch.zeros(total + self._STATS, dtype=torch.float32, device=device)
+        self.grad = self._grad_store[:total]
+        self._stats = self._grad_store[total:]
+        self._stats_used = 0
         self._views = OrderedDict()
         self._gviews = OrderedDict()
         for name, off, shape in self._table:
@@ -124,7 +129,19 @@ class Model(torch.nn.Module):
         return self          # the arena is allocated on the GPU at construction
 
     def zero_grad(self, set_to_none=False):
-        self.grad.zero_()
+        self._grad_store.zero_()
+        self._stats_used = 0
+
+    _STATS = 64
+
+    def take_stats(self, n):
+        """n zeroed floats for a kernel to accumulate into: a fresh slice of the arena's tail (zeroed by the last zero_grad();
+        every call hands out another slice, so nothing is ever accumulated twice), torch.zeros once the tail is used up."""
+        lo = self._stats_used
+        if lo + n > self._STATS or not torch.is_grad_enabled():
+            return torch.zeros(n, dtype=torch.float32, device=self.flat.device)
+        self._stats_used = lo + n
+        return self._stats[lo:lo + n]
 
     # ---- utils/model.py:16-53 ------------------------------------------------------
     def save(self):

@@ -197,6 +197,19 @@ def cross_entropy(weights2d, targets1d, out2, dW=None, scale=1.0, out_scale=1.0)
                                         ptr(out2[0:1]), ptr(out2[1:2]), stream_ptr()), "inet_cross_entropy")
 
 
+def cross_entropy_ex(weights2d, targets1d, loss_sum=None, correct=None, dW=None, scale=1.0, scale_dev=None, out_scale=1.0,
+                     add_term=None, add_scale=0.0, fwd_out=None, fwd_scale=0.0):
+    """inet_cross_entropy_ex: cross_entropy() with nullable outputs, a device-scalar factor on dW and an extra term added to
+    the loss (loss_sum / correct / add_term / scale_dev: 1-element float tensors or None)."""
+    rows, V = weights2d.shape
+    assert weights2d.stride(1) == 1
+    _i64c(targets1d)
+    check(_lib.lib().inet_cross_entropy_ex(ptr(weights2d), weights2d.stride(0), rows, V, ptr(targets1d), ptr(dW),
+                                           dW.stride(0) if dW is not None else 0, float(scale), ptr(scale_dev),
+                                           float(out_scale), ptr(loss_sum), ptr(correct), ptr(add_term), float(add_scale),
+                                           ptr(fwd_out), float(fwd_scale), stream_ptr()), "inet_cross_entropy_ex")
+
+
 def sample_multinomial(weights2d, seed, offset=0):
     """One draw per row from softmax(weights2d[row]) (decoder.py:506-509), counter-based generator (seed, offset + row)."""
     rows, V = weights2d.shape

@@ -50,6 +50,33 @@ class _CrossEntropyFn(torch.autograd.Function):
         return dW * gloss, None
 
 
+class _ElboFn(torch.autograd.Function):
+    """loss = mean CE + kscale * kl_sum, accuracy -- VAETrainer.loss_and_acc_for_batch (vae_trainer.py:29-40) in ONE launch
+    forward (the CE kernel also adds the KL term) and ONE launch backward (the same kernel writes dW already multiplied
+    by the upstream gradient, read on the device, and hands kscale * gradient on to the KL sum's producer): the dozen
+    one-element torch kernels of the unfused expression (zeros, mul, add, select-backward, dW * g) are gone."""
+
+    @staticmethod
+    def forward(ctx, weights2d, targets1d, kl_sum, kscale, out2):
+        rows, V = weights2d.shape
+        ops.cross_entropy_ex(weights2d, targets1d, loss_sum=out2[0:1], correct=out2[1:2], out_scale=1.0 / rows,
+                             add_term=kl_sum.reshape(1), add_scale=kscale)
+        ctx.save_for_backward(weights2d, targets1d)
+        ctx.kscale = kscale
+        loss, acc = out2[0], out2[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, gloss, _gacc):
+        w, t = ctx.saved_tensors
+        dW = torch.empty_like(w)
+        gkl = torch.empty((), dtype=torch.float32, device=w.device)
+        ops.cross_entropy_ex(w, t, dW=dW, scale=1.0 / w.shape[0], scale_dev=gloss.reshape(1).contiguous(),
+                             fwd_out=gkl.reshape(1), fwd_scale=ctx.kscale)
+        return dW, None, gkl, None, None
+
+
 class _KLFn(torch.autograd.Function):
     """beta * mean_b sum_d KL(N(mu, sigma) || N(0,1))   (vae_trainer.py:128-139)."""
 

@@ -2,7 +2,7 @@
 import torch
 
 from .helpers import to_cuda_variable_long
-from .trainer import Trainer, _KLFn
+from .trainer import Trainer, _ElboFn, _KLFn
 
 
 class VAETrainer(Trainer):
@@ -15,6 +15,16 @@ class VAETrainer(Trainer):
         """loss = CE_mean + 1e-3 * mean_b KL ; accuracy   (vae_trainer.py:16-40)"""
         score = batch
         weights, samples, z_dist, prior_dist, z_tilde, z_prior = self.model(measure_score_tensor=score, train=train)
+        kl_sum = getattr(z_dist, "kl_sum", None)
+        if kl_sum is not None and type(self).compute_kld_loss is VAETrainer.compute_kld_loss and \
+                type(self).mean_crossentropy_loss_and_accuracy is Trainer.mean_crossentropy_loss_and_accuracy:
+            # the same three lines (vae_trainer.py:29-40: recons + 1e-3 * mean KL, accuracy) as one kernel each way
+            V = weights.size(-1)
+            t1 = score.contiguous().view(-1)
+            if t1.dtype != torch.int64:
+                t1 = t1.long()
+            return _ElboFn.apply(weights.contiguous().view(-1, V), t1, kl_sum, 0.001 / z_dist.loc.shape[0],
+                                 self.model.take_stats(2))
         recons_loss, accuracy = self.mean_crossentropy_loss_and_accuracy(weights, score)
         dist_loss = self.compute_kld_loss(z_dist, prior_dist)
         loss = recons_loss + dist_loss
