@@ -52,20 +52,8 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
     const int j0 = member * 16, jc = j0 + (t & 15);
     const int rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
     const int slot_bytes = P.hx_slot_bytes ? P.hx_slot_bytes : ((B + 15) >> 4) * 16 * H * 4;
-    f32x4 Wr[3][SQ];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int si = 0; si < SQ; ++si)
-            Wr[g][si] = ld4u(P.W_hh + (long)(g * H + j0 + i16) * H + 16 * (w * SQ + si) + 4 * q);
-    float bh[3], bv[3] = {0.f, 0.f, 0.f}, hp[MS];
+    float hp[MS];
     int brow[MS];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) bh[g] = P.b_hh[g * H + jc];
-    if (P.gi_vec) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) bv[g] = P.gi_vec[g * H + jc];
-    }
     const bool has_h0 = P.h0 != nullptr;          // null: an all-zero initial state (never exchanged, step 0 contracts nothing)
 #pragma unroll
     for (int p = 0; p < MS; ++p) {
@@ -76,7 +64,8 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
     unsigned* counter = A.counters + group * kChainCounterStride;
     // The initial state enters the exchange like any later one: every member publishes its own 16 columns of h0 into
     // slot 1 and arrives (a pack launch in front of every chain used to do this: 8 launches per training step).
-    if (has_h0) {
+    const bool publish_h0 = has_h0 && !A.h0_packed;
+    if (publish_h0) {
 #pragma unroll
         for (int p = 0; p < MS; ++p) xt[((t + 256 * p) >> 4) * 16 + (t & 15)] = hp[p];
         __syncthreads();
@@ -84,7 +73,22 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
             chain::publish_block(rs, slot_bytes, xt, t >> 6, lane, rb0 + (t >> 6), S, member);
         chain::arrive(counter);
     }
-    const int arrivals0 = has_h0 ? 1 : 0;
+    const int arrivals0 = publish_h0 ? 1 : 0;
+    // (the weights are requested AFTER the initial state is out: arrive() drains every outstanding load of the wave, and the
+    // W slice is the one load here that comes from HBM -- the other members' wait should not include it)
+    f32x4 Wr[3][SQ];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int si = 0; si < SQ; ++si)
+            Wr[g][si] = ld4u(P.W_hh + (long)(g * H + j0 + i16) * H + 16 * (w * SQ + si) + 4 * q);
+    float bh[3], bv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = P.b_hh[g * H + jc];
+    if (P.gi_vec) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bv[g] = P.gi_vec[g * H + jc];
+    }
     // Operand sources as (pointer, strides) with every field in a register before the loop; an absent source points at a
     // zero word with zero strides, so the per-step requests are unconditional loads issued back to back (conditional
     // loads make hipcc wrap each in a branch with its own s_waitcnt vmcnt(0): one exposed round trip per operand).
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
             tok[p] = idxp[b * idx_bs + tn * idx_ts];
         }
         const bool recur = step > 0 || has_h0;
-        if (recur && !chain::wait_group(counter, (unsigned)((step + arrivals0) * members), status, &flag[step & 1])) return;
+        if ((step > 0 || publish_h0) &&
+            !chain::wait_group(counter, (unsigned)((step + arrivals0) * members), status, &flag[step & 1])) return;
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)

@@ -6,11 +6,24 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     const long pkh = (long)pk_floats(B, H);
     bool pk = pk_ok(H);
     for (int i = 0; i < nd; ++i) if (!d[i].Wpk_hh || !d[i].hpk) pk = false;
+    // A/B switch: INET_CHAIN_H0PACK=1 packs the initial state into slot 1 with a launch in front of the chain (round 2)
+    static const bool h0pack = [] { const char* v = std::getenv("INET_CHAIN_H0PACK"); return v && v[0] == '1'; }();
+    bool all_h0 = true;
+    for (int i = 0; i < nd; ++i) all_h0 = all_h0 && d[i].h0;
+    auto pack_h0 = [&]() -> int {
+        bool same_ld = true;
+        const float* ins[4]; float* outs[4];
+        for (int i = 0; i < nd; ++i) { ins[i] = d[i].h0; outs[i] = d[i].hpk + pkh; same_ld = same_ld && d[i].h0_ld == d[0].h0_ld; }
+        if (same_ld) return pw_pack_frag_multi(ins, outs, nd, d[0].h0_ld, B, H, 0, s);
+        for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
+        return 0;
+    };
     if (pk && d[0].sync && gru_chain_ok(H, B, T, nd)) {
         // one persistent launch for all T steps (gru_chain.hip); the exchange buffer is the hpk ring, slot 1 = h0 (published
         // by the kernel itself; a null h0 = zeros)
         GruChainFwd a{};
         a.H = H; a.B = B; a.T = T; a.nprob = nd;
+        if (h0pack && all_h0) { INET_TRY(pack_h0()); a.h0_packed = 1; }
         for (int i = 0; i < nd; ++i) {
             const DirFwd& D = d[i];
             GruChainFwdProb& P = a.p[i];
@@ -70,13 +83,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     }
     // one launch per step (gru.hip): the fragment-major ring's slot 1 is packed from h0 here (step 0 reads it)
     for (int i = 0; i < nd; ++i) if (!d[i].h0) return -1;     // (a null h0 is the chain kernels' shorthand for zeros)
-    if (pk) {
-        bool same_ld = true;
-        const float* ins[4]; float* outs[4];
-        for (int i = 0; i < nd; ++i) { ins[i] = d[i].h0; outs[i] = d[i].hpk + pkh; same_ld = same_ld && d[i].h0_ld == d[0].h0_ld; }
-        if (same_ld) INET_TRY(pw_pack_frag_multi(ins, outs, nd, d[0].h0_ld, B, H, 0, s));
-        else for (int i = 0; i < nd; ++i) INET_TRY(pw_pack_frag(d[i].h0, d[i].h0_ld, B, H, d[i].hpk + pkh, 0, 1, 0, 0, s));
-    }
+    if (pk) INET_TRY(pack_h0());
     for (int step = 0; step < T; ++step) {
         GruFwdBatch bt{};
         bt.H = H; bt.nprob = nd;

@@ -85,7 +85,7 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     big = sorted(set(l for l in labels if l.startswith("M")))
     for wl in ("M6144 N1536 K1024 NT d192x192 s1 e0", "M6144 N1024 K1536 NN d192x128 s1 e4",   # e4: dropout mask epilogue
                "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N512 K6144 TN d192x128 s4 e0 x2", "M1536 N1024 K6144 TN d192x128 s2 e0 x2",
-               "M256 N1024 K2048 NT k32x32 s1 e1"):                                            # workgroup split-K, SELU head
+               "group2 M256 N1024 K2048 NT k64x32 e1"):                                        # both SELU heads in one grouped split-K launch
         assert wl in labels, (wl, big)
     if not tf:      # the 24 free-running ticks with dropout and backward saves: one launch of the fused decode kernel
         assert "decode_chain_train ms2 T24 B256 H512 V48" in labels, sorted(set(l for l in labels if l.startswith("dec")))

@@ -52,11 +52,21 @@ __global__ __launch_bounds__(256) void k(Args A) {
 #define CSTRIDE_ 1
 #endif
     unsigned* counter = A.counters + group * CSTRIDE_;
-    chain::Status st{A.status, nullptr};
+    chain::Status st{A.status, nullptr, nullptr};
     float hp[MS] = {};
     unsigned long long* stamp = A.stamps + (size_t)blockIdx.x * T * 6;
     f32x4 acc[MS][4];
     for (int ms = 0; ms < MS; ++ms) for (int a = 0; a < 3; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef PRIO_
+    // the two workgroups of a CU at different wave priorities: when both are in their MFMA phase the pipe goes to the
+    // high-priority one, the other falls behind and ends up computing while the first one hands off
+    if (group >= GROUPS / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(PRIO_);
+#endif
+#ifdef SKEW_
+    // de-phase the two workgroups that share a CU: the second half of the groups (dispatched onto the same CUs as the first
+    // half) starts SKEW_ x 10 ns late, so that its MFMA phase falls into the other's hand-off / epilogue phase
+    if (group >= GROUPS / 2) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < SKEW_) __builtin_amdgcn_s_sleep(8); }
+#endif
     for (int step = 0; step < T; ++step) {
         if (t == 0) stamp[step * 6 + 0] = wall_clock64();
         float pg[MS][3];
@@ -147,17 +157,33 @@ void run(const char* name, Args a) {
 int main() {
     Args a;
     (void)hipMalloc(&a.hx, (size_t)2 * 2 * B * H * 4); (void)hipMemset(a.hx, 0, (size_t)2 * 2 * B * H * 4);
-    float* W; (void)hipMalloc(&W, (size_t)3 * H * H * 4); (void)hipMemset(W, 0, (size_t)3 * H * H * 4); a.W = W;
-    float* gi; (void)hipMalloc(&gi, (size_t)T * B * 3 * H * 4); (void)hipMemset(gi, 0, (size_t)T * B * 3 * H * 4); a.gi = gi;
+    float* W; (void)hipMalloc(&W, (size_t)3 * H * H * 4); a.W = W;
+    float* gi; (void)hipMalloc(&gi, (size_t)T * B * 3 * H * 4); a.gi = gi;
+    {   // random operands: zero-filled ones let the chip clock higher (DVFS) than real data does
+        std::vector<float> hw((size_t)3 * H * H), hg((size_t)T * B * 3 * H);
+        unsigned x = 12345u;
+        auto rnd = [&] { x = x * 1664525u + 1013904223u; return ((x >> 8) & 0xffff) / 32768.f - 1.f; };
+        for (auto& v : hw) v = rnd() * 0.05f;
+        for (auto& v : hg) v = rnd();
+        (void)hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(gi, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);
+    }
     (void)hipMalloc(&a.out, (size_t)7 * T * B * H * 4);
     (void)hipMalloc(&a.counters, 64 * 64 * 4); (void)hipMalloc(&a.status, 4);
     (void)hipMalloc(&a.stamps, (size_t)NB * T * 6 * 8);
     (void)hipMalloc(&a.where, NB * 4);
     run<true, true, true, false>("full", a);
+#ifdef ALSO_NOSYNC_
+    run<true, true, false, false>("no_sync", a);
+    run<false, true, true, false>("no_mfma", a);
+    run<true, false, true, false>("no_loads", a);
+#endif
+#ifndef ONLY_FULL_
     run<false, true, true, false>("no_mfma", a);
     run<true, false, true, false>("no_loads", a);
     run<true, true, false, false>("no_sync", a);
     run<false, false, true, false>("sync_only", a);
     run<true, true, true, true>("plain_st", a);
+#endif
     return 0;
 }
