@@ -508,6 +508,47 @@ def epoch_loop_extra(wl, batches=100):
                                        "per batch from pinned host memory, shuffled"}}
 
 
+def vae4096_extra(wl, batch=4096, steps=6, warmup=2):
+    """The reference's default MeasureVAE step (train_measure_vae.py:33: batch_size 256 sequences x 16 bars = 4096 measures,
+    vae_trainer.py:49-52) on the same model: more rows than one resident chain launch holds, so every recurrent layer runs
+    as chain launches over row chunks (csrc/seq.hip chain_chunk_rows), forward and backward.  Secondary number; the
+    headline stays BASELINE.json's configs[1] (256 measures per GPU)."""
+    from inpaintnet_amd import ops, synthetic
+    dev = wl.tokens.device
+    tok = torch.from_numpy(synthetic.det_tokens("bench/4096", (batch, 24), NUM_NOTES)).to(dev)
+    t = wl.trainer
+
+    def step():
+        t.zero_grad()
+        loss, acc = t.loss_and_acc_for_batch(tok, 0, train=True)
+        loss.backward()
+        t.step()
+        return loss
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    # which kernels ran: per-step launches of the H = 512 layers would mean the chunked chain path was not taken
+    ops.prof_enable(True)
+    step()
+    torch.cuda.synchronize()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "l.csv")
+        ops.prof_dump(path)
+        labels = [r["label"] for r in csv.DictReader(open(path))]
+    ops.prof_enable(False)
+    per_step = sum(1 for l in labels if l.startswith("gru_fwd") or l.startswith("gru_bwd"))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"vae_train_4096": {"measures_per_s": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
+                               "batch": batch, "launches_per_step": len(labels), "per_step_gru_launches": per_step,
+                               "final_loss": round(float(loss.detach()), 5),
+                               "workload": "MeasureVAE training at the reference's default batch: 256 sequences x 16 bars = "
+                                           "4096 measures per step (train_measure_vae.py:33), chain kernels over 256-row chunks"}}
+
+
 def arnn_extra(batch=32, steps=8, warmup=2):
     """Secondary number (BASELINE.json configs[4]): AnticipationRNN gauss-reg model, teacher-forced training step,
     batch 32 sequences of 384 ticks, script defaults of train_arnn_reg.py.  Not the headline metric."""
@@ -659,6 +700,10 @@ def main():
                 wl.model.train()
             if args.workload == "vae":
                 extras.update(epoch_loop_extra(wl))
+                try:
+                    extras.update(vae4096_extra(wl))
+                except Exception as e:                       # a secondary number must never take the headline down
+                    extras["vae_train_4096"] = {"error": repr(e)}
             extras.update(arnn_extra())
             vae = wl.model if args.workload == "vae" else wl.model.vae_model
             extras.update(decode_latency_extra(vae))

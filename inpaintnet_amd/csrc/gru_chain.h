@@ -12,7 +12,7 @@ constexpr int kChainZeroWord = kChainStatusWord + 64; // words [+0, +1] stay zer
 constexpr int kChainSyncWords = kChainZeroWord + 4;
 // A workspace holds kSyncAreas such areas: a library call zeroes all of them with ONE memset and gives each of its chain
 // launches its own (`prezeroed`), instead of one 5 us fill kernel in front of every launch (11 per training step).
-constexpr int kSyncAreas = 6;
+constexpr int kSyncAreas = 8;
 
 struct GruChainFwdProb {
     const float* W_hh; const float* b_hh;         // [3H,H] row-major, [3H]
@@ -26,6 +26,8 @@ struct GruChainFwdProb {
     const float* mask; long ld_mask, ts_mask;
     float* hlast; long ld_hlast;                  // copy of the final hidden, or null
     float* sv; long sv_astride;                   // r,z,n,ghn,hprev saves [T][B][H] each, or null
+    long sv_ts;                                   // time stride of the saves in floats (0: B*H; a row chunk of a larger batch
+                                                  // passes the full batch's)
     float* hx;                                    // exchange: [2][ceil16(B)][H] fragment-major
     int reverse;
     int hx_slot_bytes;                            // distance between the two slots of hx (0: adjacent)
@@ -48,8 +50,11 @@ struct GruChainBwdProb {
     const float* dout; long ld_dout, ts_dout;     // dLoss/dh(t,b), or null
     const float* dhn; long ld_dhn;                // dLoss/d final hidden, or null
     const float* sv; long sv_astride;
+    long sv_ts;                                   // time stride of the saves in floats (0: B*H)
     float* dgi; long ld_dgi, ts_dgi;              // [.,3H] input-side gate gradients (strided)
     float* dgh;                                   // [T][B][3H] dense recurrent-side gate gradients
+    long dgh_ts;                                  // time stride of dgh in floats (0: B*3H)
+    int gx_slot_bytes;                            // distance between the two slots of gx (0: adjacent)
     float* db_ih; float* db_hh;                   // [3H], accumulated; or null
     float* dh0; long ld_dh0; int dh0_accumulate;  // dLoss/d initial hidden, or null
     float* gx;                                    // exchange: [2][ceil16(B)][3H] fragment-major

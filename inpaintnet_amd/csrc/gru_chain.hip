@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
     const int msk_ld = has_mask ? (int)P.ld_mask : 0, msk_ts = has_mask ? (int)P.ts_mask : 0, msk_j = has_mask ? jc : 0;
     float* const outp = P.out; const int out_ld = (int)P.ld_out, out_ts = (int)P.ts_out;
     float* const outmp = P.outm; const int outm_ld = (int)P.ld_outm, outm_ts = (int)P.ts_outm;
-    float* const svp = P.sv; const int sv_as = (int)P.sv_astride;
+    float* const svp = P.sv; const int sv_as = (int)P.sv_astride, sv_ts = P.sv_ts ? (int)P.sv_ts : B * H;
     float* const hlastp = P.hlast; const int hlast_ld = (int)P.ld_hlast;
     const int rev = P.reverse, members = A.members;
     const chain::Status status = A.status;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
                 if (outmp) outmp[tt * outm_ts + b * outm_ld + jc] = has_mask ? eh[p] * pm[p] : eh[p];
                 if (hlastp && step == T - 1) hlastp[b * hlast_ld + jc] = eh[p];
                 if (svp) {
-                    float* sp = svp + (tt * B + b) * H + jc;
+                    float* sp = svp + tt * sv_ts + b * H + jc;
                     sp[0] = er[p]; sp[sv_as] = ez[p]; sp[2 * sv_as] = en[p]; sp[3 * sv_as] = eg[p]; sp[4 * sv_as] = ehp[p];
                 }
             }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     const int i16 = lane & 15, q = lane >> 4;
     const int j0 = member * 16, jc = j0 + (t & 15);
     const int rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
-    const int slot_bytes = ((B + 15) >> 4) * 16 * 3 * H * 4;
+    const int slot_bytes = P.gx_slot_bytes ? P.gx_slot_bytes : ((B + 15) >> 4) * 16 * 3 * H * 4;
     // B operand = W_hh^T rows j0..j0+15, k over the 3H gate rows: element (j, k) = W_hh[k][j]; read once, strided
     f32x4 Wr[1][SQ];
 #pragma unroll
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     const int dout_ld = has_dout ? (int)P.ld_dout : 0, dout_ts = has_dout ? (int)P.ts_dout : 0, dout_j = has_dout ? jc : 0;
     const float* const dhnp = has_dhn ? P.dhn : zf;
     const int dhn_ld = has_dhn ? (int)P.ld_dhn : 0, dhn_j = has_dhn ? jc : 0;
-    const float* const svp = P.sv; const int sv_as = (int)P.sv_astride;
+    const float* const svp = P.sv; const int sv_as = (int)P.sv_astride, sv_ts = P.sv_ts ? (int)P.sv_ts : B * H;
     float* const dgip = P.dgi; const int dgi_ld = (int)P.ld_dgi, dgi_ts = (int)P.ts_dgi;
-    float* const dghp = P.dgh;
+    float* const dghp = P.dgh; const int dgh_ts = P.dgh_ts ? (int)P.dgh_ts : B * 3 * H;
     float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
     const int rev = P.reverse, members = A.members;
     const chain::Status status = A.status;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
                 const int b = brow[p];
                 const float d1 = doutp[tt * dout_ts + b * dout_ld + dout_j];
                 const float d2 = dhnp[b * dhn_ld + dhn_j];
-                const float* sp = svp + (tt * B + b) * H + jc;
+                const float* sp = svp + tt * sv_ts + b * H + jc;
 #pragma unroll
                 for (int a = 0; a < 5; ++a) psv[p][a] = sp[a * sv_as];
                 pd[p] = step == T - 1 ? d1 + d2 : d1;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
             if (b < B) {
                 float* gi = dgip + tt * dgi_ts + b * dgi_ld;
                 gi[jc] = e_r[p]; gi[H + jc] = e_z[p]; gi[2 * H + jc] = e_n[p];
-                float* gh = dghp + (tt * B + b) * 3 * H;
+                float* gh = dghp + tt * dgh_ts + b * 3 * H;
                 gh[jc] = e_r[p]; gh[H + jc] = e_z[p]; gh[2 * H + jc] = e_nr[p];
                 bs[0] += e_r[p]; bs[1] += e_z[p]; bs[2] += e_n[p]; bs[3] += e_nr[p];
                 gs[p][0] += e_r[p]; gs[p][1] += e_z[p]; gs[p][2] += e_n[p];

@@ -68,6 +68,9 @@ struct DirBwd {
 inline size_t pk_floats(int rows, int K) { return (size_t)((rows + 15) / 16) * 16 * (size_t)K; }
 inline bool pk_ok(int H) { return H % 256 == 0; }
 
+// rows per chain launch for a batch of B rows (B itself when one launch holds it; 0: no chain kernel applies)
+int chain_chunk_rows(int H, int B, int T, int nd, int save = 1);
+int chain_chunk_rows_bwd(int H, int B, int T, int nd);
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
 int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_hi, int step_lo, hipStream_t s);

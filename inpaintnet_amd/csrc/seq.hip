@@ -1,6 +1,32 @@
 #include <cstdlib>
 #include "seq.h"
 
+// Rows per launch when a batch is too large for one resident chain launch: the largest of 1024 / 512 / 256 / 128 / 64 that
+// divides B and fits the chip (B itself when it fits; 0: no chain launch applies).
+// Chunking pays only while the batch is a few launches' worth: a chain launch is latency-bound (about 57 % of the MFMA
+// rate at 256 rows), a per-step launch over thousands of rows is not -- at the reference's default 4096 measures per step
+// the per-step kernels are 1.5x faster than sixteen chunk launches per layer (profiles/r03_e_*).  INET_CHAIN_CHUNK_MAX
+// = largest batch that is still chunked.
+static int chunk_max_rows() {
+    static const int v = [] { const char* e = std::getenv("INET_CHAIN_CHUNK_MAX"); return e ? std::atoi(e) : 1024; }();
+    return v;
+}
+int chain_chunk_rows(int H, int B, int T, int nd, int save) {
+    if (gru_chain_ok(H, B, T, nd)) return B;
+    if (save && B > chunk_max_rows()) return 0;      // (forward-only passes -- LatentRNN's frozen encoder -- chunk at any size:
+                                                     //  two chunks run side by side there, measured in round 2)
+    for (int ch = 1024; ch >= 64; ch >>= 1)
+        if (ch < B && B % ch == 0 && gru_chain_ok(H, ch, T, nd)) return ch;
+    return 0;
+}
+int chain_chunk_rows_bwd(int H, int B, int T, int nd) {
+    if (gru_chain_bwd_ok(H, B, T, nd)) return B;
+    if (B > chunk_max_rows()) return 0;
+    for (int ch = 1024; ch >= 64; ch >>= 1)
+        if (ch < B && B % ch == 0 && gru_chain_bwd_ok(H, ch, T, nd)) return ch;
+    return 0;
+}
+
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     const long BH = (long)B * H;
     const long pkh = (long)pk_floats(B, H);
@@ -42,17 +68,19 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
         a.counters = d[0].sync; a.prezeroed = d[0].sync_prezeroed;
         return launch_gru_chain_fwd(a, s);
     }
-    // More rows than one resident launch can take (the frozen encoder of LatentRNN runs 2048 measures at once): the rows
-    // are independent, so the chain kernel runs over chunks of 256 rows, one launch after the other, each on a chunk-sized
-    // exchange ring inside the hpk buffer.  Only without backward saves (their time stride is the full batch).
-    constexpr int CH = 256;
-    bool chunked = pk && d[0].sync && B >= 2 * CH && B % CH == 0 && gru_chain_ok(H, CH, T, nd);
-    for (int i = 0; i < nd; ++i) chunked = chunked && !d[i].sv;
+    // More rows than one resident launch can take (the frozen encoder of LatentRNN runs 2048 measures at once, the
+    // reference's default VAE batch is 4096 measures): the rows are independent, so the chain kernel runs over chunks of
+    // rows, one launch after the other, each on a chunk-sized exchange ring inside the hpk buffer; backward saves keep the
+    // full batch's time stride.
+    bool any_sv = false;
+    for (int i = 0; i < nd; ++i) any_sv = any_sv || d[i].sv;
+    const int CH = chain_chunk_rows(H, B, T, nd, any_sv);
+    const bool chunked = pk && d[0].sync && CH > 0 && CH < B;
     if (chunked) {
         // Two chunks at a time, on two streams: the kernel's 256-register build lets two launches share every CU, and one
         // chunk's hand-off latency (a third of each step) is filled by the other chunk's MFMAs.  Chunk c works on its rows
         // of the two slots of the full-batch ring (row blocks are the outermost index of the fragment-major layout); even /
-        // odd chunks count on different sync areas.
+        // odd chunks count on different sync areas (the caller's and the one behind it).
         static const bool twin = [] { const char* v = std::getenv("INET_CHUNK_TWIN"); return !(v && v[0] == '0'); }();
         const long pkc = (long)pk_floats(CH, H);
         hipStream_t s2 = twin ? twin_fork(s) : s;
@@ -74,6 +102,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
                 P.outm = D.outm ? D.outm + r0 * D.outm_ld : nullptr; P.ld_outm = D.outm_ld; P.ts_outm = D.outm_ts;
                 P.mask = D.mask ? D.mask + r0 * D.mask_ld : nullptr; P.ld_mask = D.mask_ld; P.ts_mask = D.mask_ts;
                 P.hlast = D.hlast ? D.hlast + r0 * D.hlast_ld : nullptr; P.ld_hlast = D.hlast_ld;
+                if (D.sv) { P.sv = D.sv + r0 * H; P.sv_astride = D.sv_astride; P.sv_ts = BH; }
                 P.hx = D.hpk + (long)c * pkc; P.hx_slot_bytes = (int)(pkh * sizeof(float)); P.reverse = D.reverse;
             }
             a.counters = d[0].sync + (c & 1) * kChainSyncWords;
@@ -137,29 +166,35 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
     {
         bool any0 = false, all0 = true, wok = true;
         for (int i = 0; i < nd; ++i) { if (d[i].dh0) any0 = true; else all0 = false; if (!d[i].W_hh) wok = false; }
-        if (pk && wok && d[0].sync && step_hi == T - 1 && step_lo == 0 && (!any0 || all0) && gru_chain_bwd_ok(H, B, T, nd)) {
-            GruChainBwd a{};
-            a.H = H; a.B = B; a.T = T; a.nprob = nd;
-            for (int i = 0; i < nd; ++i) {
-                const DirBwd& D = d[i];
-                GruChainBwdProb& P = a.p[i];
-                P.W_hh = D.W_hh;
-                P.dout = D.dout; P.ld_dout = D.dout_ld; P.ts_dout = D.dout_ts;
-                P.dhn = D.dhn; P.ld_dhn = D.dhn_ld;
-                P.sv = D.sv; P.sv_astride = D.sv_astride;
-                P.dgi = D.dgi; P.ld_dgi = D.dgi_ld; P.ts_dgi = D.dgi_ts;
-                P.dgh = D.dgh;
-                P.db_ih = D.db_ih; P.db_hh = D.db_hh;
-                P.dh0 = D.dh0; P.ld_dh0 = D.dh0_ld; P.dh0_accumulate = D.dh0_acc;
-                P.gx = D.dghpk; P.reverse = D.reverse;
-                P.dgi_sum = D.dgi_sum;
+        const int CHB = chain_chunk_rows_bwd(H, B, T, nd);
+        if (pk && wok && d[0].sync && step_hi == T - 1 && step_lo == 0 && (!any0 || all0) && CHB > 0) {
+            // one persistent launch -- or, for a batch beyond one resident launch, one launch per chunk of CHB rows (the rows
+            // are independent; saves / dgh keep the full batch's time stride; bias gradients accumulate with atomics)
+            const long pkc = (long)pk_floats(CHB, 3 * H);
+            for (int c = 0; c < B / CHB; ++c) {
+                const long r0 = (long)c * CHB;
+                GruChainBwd a{};
+                a.H = H; a.B = CHB; a.T = T; a.nprob = nd;
+                for (int i = 0; i < nd; ++i) {
+                    const DirBwd& D = d[i];
+                    GruChainBwdProb& P = a.p[i];
+                    P.W_hh = D.W_hh;
+                    P.dout = D.dout ? D.dout + r0 * D.dout_ld : nullptr; P.ld_dout = D.dout_ld; P.ts_dout = D.dout_ts;
+                    P.dhn = D.dhn ? D.dhn + r0 * D.dhn_ld : nullptr; P.ld_dhn = D.dhn_ld;
+                    P.sv = D.sv + r0 * H; P.sv_astride = D.sv_astride; P.sv_ts = BH;
+                    P.dgi = D.dgi + r0 * D.dgi_ld; P.ld_dgi = D.dgi_ld; P.ts_dgi = D.dgi_ts;
+                    P.dgh = D.dgh + r0 * 3 * H; P.dgh_ts = B3H;
+                    P.db_ih = D.db_ih; P.db_hh = D.db_hh;
+                    P.dh0 = D.dh0 ? D.dh0 + r0 * D.dh0_ld : nullptr; P.ld_dh0 = D.dh0_ld; P.dh0_accumulate = D.dh0_acc;
+                    P.gx = D.dghpk + (long)c * pkc; P.gx_slot_bytes = (int)(pkg * sizeof(float)); P.reverse = D.reverse;
+                    P.dgi_sum = D.dgi_sum ? D.dgi_sum + r0 * 3 * H : nullptr;
+                }
+                a.counters = d[0].sync; a.prezeroed = (c == 0 && CHB == B) ? d[0].sync_prezeroed : 0;
+                INET_TRY(launch_gru_chain_bwd(a, s));
             }
-            a.counters = d[0].sync; a.prezeroed = d[0].sync_prezeroed;
-            const int rc = launch_gru_chain_bwd(a, s);
-            if (rc == 0)
-                for (int i = 0; i < nd; ++i)
-                    if (d[i].dgi_sum && d[i].dgi_sum_done) *d[i].dgi_sum_done = 1;
-            return rc;
+            for (int i = 0; i < nd; ++i)
+                if (d[i].dgi_sum && d[i].dgi_sum_done) *d[i].dgi_sum_done = 1;
+            return 0;
         }
     }
     for (int step = step_hi; step >= step_lo; --step) {
@@ -255,8 +290,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
                     float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s, int sync_prezeroed) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     // fragment-major W_hh twins: only the per-step kernels read them (the chain kernels take W_hh as stored)
-    const bool chained = w.wpk[0] && w.hpk[0] && w.sync && pk_ok(H) &&
-                         (gru_chain_ok(H, B, T, 2) || (!save && B >= 512 && B % 256 == 0 && gru_chain_ok(H, 256, T, 2)));
+    const bool chained = w.wpk[0] && w.hpk[0] && w.sync && pk_ok(H) && chain_chunk_rows(H, B, T, 2, save) > 0;   // (one launch or row chunks)
     // zero initial state: the chain kernels take a null pointer (and skip step 0's contraction), the per-step kernels a buffer
     const float* const hzero = chained ? nullptr : w.zeros;
     if (!h0 && !chained && pw_zero(w.zeros, BH, s) != 0) return -2;
@@ -316,7 +350,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     const bool wg = P[0].dw_hh != nullptr;
     // both layers run as backward chains (they read W_hh as stored) iff the conditions of gru_layer_bwd_range hold:
     // the transposed fragment-major twins are then never read
-    const bool chained = w.wpkT[0] && w.dghpk[0] && w.sync && pk_ok(H) && gru_chain_bwd_ok(H, B, T, 2);
+    const bool chained = w.wpkT[0] && w.dghpk[0] && w.sync && pk_ok(H) && chain_chunk_rows_bwd(H, B, T, 2) > 0;
     // (stage 2 continues on what stage 1 left in the workspace: zeroed sync areas, packed / transposed weights, dx1)
     if (stage != 2 && chained &&
         hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;

@@ -292,7 +292,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     static const bool train_chain = [] { const char* v = std::getenv("INET_DECODE_CHAIN_TRAIN"); return !(v && v[0] == '0'); }();
     // Which kernels will run: the chain kernels read W_hh / W_ih as stored, only the per-step kernels want the
     // fragment-major twins -- each is packed only if its consumer runs.
-    const bool beats_chained = pk && beat_chain && gru_chain_ok(H, B, nb, 1);
+    const bool beats_chained = pk && beat_chain && chain_chunk_rows(H, B, nb, 1, save) > 0;   // (one launch, or one per row chunk)
     const bool fused_shape = pk && !teacher_forced && !multinomial_seed && w.wpk_out && ((!save && !mask_tick) || train_chain);
     // batches beyond one resident launch (LatentRNN decodes 512 measures per step): the rows are independent, so the fused
     // kernel runs over chunks of 256 rows, one launch after the other (INET_DECODE_CHUNKS=0: per-tick launches)
@@ -306,9 +306,12 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     // G steps over the beats as problems -- `npl` beats per launch, as many as fit the chip at once (2 at B = 256)
     static const bool tf_chain = [] { const char* v = std::getenv("INET_TF_CHAIN"); return !(v && v[0] == '0'); }();
     int npl = 0;
-    if (pk && teacher_forced && tf_batch && tf_chain)
-        for (int n = nb; n >= 1 && !npl; --n)
-            if (nb % n == 0 && 2 + 2 * (nb / n) <= kSyncAreas && gru_chain_ok(H, B, G, n)) npl = n;
+    if (pk && teacher_forced && tf_batch && tf_chain) {
+        for (int n = nb; n >= 1 && !npl; --n)                  // whole batch in one launch per `n` beats ...
+            if (nb % n == 0 && 3 + 2 * (nb / n) <= kSyncAreas && gru_chain_ok(H, B, G, n)) npl = n;
+        for (int n = nb; n >= 1 && !npl; --n)                  // ... else row chunks
+            if (nb % n == 0 && 3 + 2 * (nb / n) <= kSyncAreas && chain_chunk_rows(H, B, G, n, save) > 0) npl = n;
+    }
     const bool ticks_chained = npl > 0;
     const float* wih0 = p + L.tick[0].w_ih;                   // [3H, E+H]
     const long ldw0 = E + H;
@@ -566,8 +569,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
     // the backward chain kernels read W_hh as stored (transposed on the fly, once): the fragment-major W_hh^T twins are
     // only packed for layers that fall back to one launch per step
-    const bool beats_chained = w.wpkT[0] && w.dghpk && beat_chain && gru_chain_bwd_ok(H, B, nb, 1);
-    const bool ticks_chained = w.wpkT[0] && w.dghpk && gru_chain_bwd_ok(H, B, G, nb);
+    const bool beats_chained = w.wpkT[0] && w.dghpk && beat_chain && chain_chunk_rows_bwd(H, B, nb, 1) > 0;
+    const bool ticks_chained = w.wpkT[0] && w.dghpk && chain_chunk_rows_bwd(H, B, G, nb) > 0;
     // one memset: the chain kernels' sync areas and, right behind them, the accumulator of the beat GRU's input-gate column sum
     if (hipMemsetAsync(w.sync, 0, (size_t)((char*)(w.tmp3h + 3 * H) - (char*)w.sync), s) != hipSuccess) return -2;
     if (w.wpkT[0]) {

@@ -48,9 +48,15 @@ def _labels(path):
         return [row["label"] for row in csv.DictReader(f)]
 
 
-@pytest.mark.parametrize("tf", [True, False], ids=["tf", "fr"])
-def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
-    B, T = 256, 24
+@pytest.mark.parametrize("tf,B", [(True, 256), (False, 256), (True, 512), (False, 512), (True, 2048)],
+                         ids=["tf-256", "fr-256", "tf-512", "fr-512", "tf-2048"])
+def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
+    """B = 256: the bench batch, every recurrent layer one resident chain launch.  B = 512: more rows than one launch holds
+    (the reference's default VAE batch is 4096 measures, train_measure_vae.py:33): every layer runs as chain launches over
+    256-row chunks WITH backward saves, forward and backward -- no per-step launches for the H = 512 layers.  B = 2048: beyond
+    INET_CHAIN_CHUNK_MAX (1024 rows) the per-step kernels take over -- at that size one launch per step over all rows is
+    the faster form (profiles/r03_e_batch_crossover.txt) -- and the same parity bar holds."""
+    T = 24
     c = G.CFGS["full"]
     H = c["H"]
     cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
@@ -71,23 +77,36 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, tmp_path):
     ops.prof_dump(tmp_path / "launches.csv")
     ops.prof_enable(False)
     labels = _labels(tmp_path / "launches.csv")
+    if B == 512:
+        gl = sorted(set(l for l in labels if l.startswith("gru") or l.startswith("dec")))
+        assert not any(l.startswith("gru_fwd") or l.startswith("gru_bwd") for l in labels), gl      # no per-step launches
+        # every H = 512 layer ran as chain launches: row chunks (two 256-row chunks side by side in the encoder's forward pass,
+        # 128-row chunks of all four beats in the teacher-forced tick layers) or one launch with two row tiles per workgroup
+        assert sum(l == "gru_chain_fwd ms4x2 np2 T24 B256 H512" for l in labels) == 4, gl
+        assert sum(l.startswith("gru_chain_bwd") and " T24 " in l for l in labels) in (2, 4), gl
+        assert sum(l.startswith("gru_chain_bwd") and " T6 " in l for l in labels) in (2, 4), gl
+        if not tf:
+            assert sum(l == "decode_chain_train ms2 T24 B256 H512 V48" for l in labels) == 2, gl
+    if B == 2048:
+        assert any(l.startswith("gru_fwd") for l in labels) and any(l.startswith("gru_bwd") for l in labels)
+        assert not any(l.startswith("gru_chain") for l in labels), sorted(set(l for l in labels if l.startswith("gru")))
     # (iv) the instantiations the bench spends its time in were the ones that ran
-    want = ["gru_chain_fwd ms4 np2 T24 B256 H512",          # encoder layers, two directions, one launch per layer
+    want = [] if B != 256 else ["gru_chain_fwd ms4 np2 T24 B256 H512",          # encoder layers, two directions, one launch per layer
             "gru_chain_bwd ms4 np2 T24 B256 H512"]          # encoder BPTT
     for wl in want:
         assert wl in labels, (wl, sorted(set(l for l in labels if l.startswith("gru"))))
-    assert "gru_chain_bwd ms8 np4 T6 B256 H512" in labels      # decoder tick layers: 4 beats x 256 rows, two row tiles per workgroup
-    if tf:          # teacher-forced ticks: each tick layer = two chain launches of two beats (6 steps), no per-tick launches
+    assert B == 2048 or "gru_chain_bwd ms8 np4 T6 B256 H512" in labels   # decoder tick layers: 4 beats x 256 rows, two row tiles per workgroup
+    if tf and B == 256:   # teacher-forced ticks: each tick layer = two chain launches of two beats (6 steps), no per-tick launches
         assert sum(l == "gru_chain_fwd ms4 np2 T6 B256 H512" for l in labels) == 4, sorted(set(l for l in labels if l.startswith("gru")))
         assert not any(l.startswith("gru_fwd") for l in labels)
     # the big products run on the LDS-free direct kernels (forward NT 192x192, data-gradient NN 192x128, weight-gradient
     # TN 192x128 split over the XCDs); the 192-row LDS-tiled instantiations are covered by the forced-tile test below
     big = sorted(set(l for l in labels if l.startswith("M")))
-    for wl in ("M6144 N1536 K1024 NT d192x192 s1 e0", "M6144 N1024 K1536 NN d192x128 s1 e4",   # e4: dropout mask epilogue
+    for wl in () if B != 256 else ("M6144 N1536 K1024 NT d192x192 s1 e0", "M6144 N1024 K1536 NN d192x128 s1 e4",   # e4: dropout mask epilogue
                "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N512 K6144 TN d192x128 s4 e0 x2", "M1536 N1024 K6144 TN d192x128 s2 e0 x2",
                "group2 M256 N1024 K2048 NT k64x32 e1"):                                        # both SELU heads in one grouped split-K launch
         assert wl in labels, (wl, big)
-    if not tf:      # the 24 free-running ticks with dropout and backward saves: one launch of the fused decode kernel
+    if not tf and B == 256:      # the 24 free-running ticks with dropout and backward saves: one launch of the fused decode kernel
         assert "decode_chain_train ms2 T24 B256 H512 V48" in labels, sorted(set(l for l in labels if l.startswith("dec")))
     print(sorted(set(l for l in labels if l.startswith("gru"))))
 
