@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     const int j0 = member * 16, jc = j0 + (t & 15);
     const int rb0 = row0 >> 4, rb_last = (B - 1) >> 4;
     const int pkh = ((B + 15) >> 4) * 16 * H;                  // floats of one fragment-major [B,H] state
-    const int NCB = V >> 4;                                    // 16-column blocks of the vocabulary
+    const int NCB = (V + 15) >> 4;                             // 16-column blocks of the vocabulary; the last one may be ragged:
+                                                               // its columns >= V carry zero weights, are never stored and
+                                                               // never win the argmax (their logit is forced below ReLU's 0)
     // logits tile of this member (if any): row block lp of the group, column block lcb
     const bool has_tile = member < NCB * MS;
     const int lp = member / NCB, lcb = member % NCB;
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
         }
 #pragma unroll
     for (int si = 0; si < SQ; ++si)
-        Wo[0][si] = has_tile ? ld4u(P.W_out + (long)(16 * lcb + i16) * H + 16 * (w * SQ + si) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        Wo[0][si] = has_tile && 16 * lcb + i16 < V ? ld4u(P.W_out + (long)(16 * lcb + i16) * H + 16 * (w * SQ + si) + 4 * q)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = t; i < 3 * S * 64; i += 256) {                // W_ih(l1): slot (g, s, lane) <- 4 consecutive k of row g*H + j0 + lane%16
         const int ln = i & 63, s = (i >> 6) % S, g = i / (64 * S);
         *reinterpret_cast<f32x4*>(wih + (long)i * 4) = ld4u(P.W_ih1 + (long)(g * H + j0 + (ln & 15)) * H + 16 * s + 4 * (ln >> 4));
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     float bh0[3], bi1[3], bh1[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) { bh0[g] = P.b_hh0[g * H + jc]; bi1[g] = P.b_ih1[g * H + jc]; bh1[g] = P.b_hh1[g * H + jc]; }
-    const float bo = has_tile ? P.b_out[16 * lcb + (t & 15)] : 0.f;
+    const bool col_ok = has_tile && 16 * lcb + (t & 15) < V;
+    const float bo = col_ok ? P.b_out[16 * lcb + (t & 15)] : 0.f;
     int brow[MS];
 #pragma unroll
     for (int p = 0; p < MS; ++p) brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1);
@@ -274,7 +278,8 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             const int rl = t >> 4, c = t & 15, b = row0 + 16 * lp + rl;
             float x = lv[0][0] + bo;
             x = x > 0.f ? x : 0.f;
-            if (b < B) P.weights[((long)b * T + tick) * V + 16 * lcb + c] = x;
+            if (b < B && col_ok) P.weights[((long)b * T + tick) * V + 16 * lcb + c] = x;
+            if (!col_ok) x = -1.f;                             // a padded column: below every real (post-ReLU) logit
             // (max, lowest argmax) over the 16 columns of the row: butterfly inside each 16-lane group
             float m = x;
             int am = c;
@@ -310,12 +315,12 @@ inline int groups_of(int B) { const int ms = rows_ms(B); return (B + 16 * ms - 1
 }  // namespace
 
 bool decode_chain_ok(int B, int H, int V, int T, int G) {
-    if (!chain_enabled() || (H != 256 && H != 512) || B < 1 || V % 16 != 0 || V > 64 || T % G != 0) return false;
+    if (!chain_enabled() || (H != 256 && H != 512) || B < 1 || V < 1 || V > 128 || T % G != 0) return false;
     if (groups_of(B) > kDecodeMaxGroups || groups_of(B) * (H / 16) > chain_capacity()) return false;   // every workgroup resident at once
     static const bool off = [] { const char* v = std::getenv("INET_DECODE_CHAIN"); return v && v[0] == '0'; }();
     if (off) return false;
     const int ms = rows_ms(B);
-    return (V / 16) * ms <= H / 16;
+    return ((V + 15) / 16) * ms <= H / 16;                   // one member per (row block, 16-column block) logits tile
 }
 
 size_t decode_chain_lds_bytes(int B, int H) {

@@ -28,13 +28,15 @@ struct PwColsumJob { const float* X; long ld; int M, N; float* out; };
 int pw_colsum_multi(const PwColsumJob* jobs, int n, hipStream_t s);
 int pw_onehot(const long long* idx, int inner, long s_outer, long s_inner, int rows, int W, float* out, int zero_first,
               hipStream_t s);
-// out[v][c] = sum of the rows of X whose token is v (out [W][ncols], W <= 63); row r has token idx[(r/inner)*s_outer + (r%inner)*s_inner]
+// out[v][c] = sum of the rows of X whose token is v (out [W][ncols], W <= 128); row r has token idx[(r/inner)*s_outer + (r%inner)*s_inner]
 // (+= into `out` unless zero_first; row_scale [rows] optional factor per row)
 int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, long s_outer, long s_inner, int rows, int W,
                     int ncols, float* out, hipStream_t s, const float* row_scale = nullptr, int zero_first = 1);
-// dW[d][N3][E] += dtab[:, d*N3:(d+1)*N3]^T emb ;  demb[W][E] += sum_d dtab[:, d*N3:(d+1)*N3] Wih[d]      (E <= 16, W <= 63)
+// dW[d][N3][E] += dtab[:, d*N3:(d+1)*N3]^T emb ;  demb[W][E] += sum_d dtab[:, d*N3:(d+1)*N3] Wih[d]      (E <= 16, W <= 128)
+// emb_last / demb_last (optional): row W-1 of emb / demb is a separate E-vector (the decoder's start symbol behind its V rows)
 int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,
-                  float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s);
+                  float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s, const float* emb_last = nullptr,
+                  float* demb_last = nullptr);
 // teacher-forced input tokens of a [B,T] target: out[b][0] = first, out[b][t] = target[b][t-1]
 int pw_shift_tokens(const long long* target, int B, int T, long long first, long long* out, hipStream_t s);
 int pw_mul(float* x, const float* m, long n, int selu_grad, hipStream_t s);

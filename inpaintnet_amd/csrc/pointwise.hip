@@ -280,7 +280,7 @@ __global__ void onehot_kernel(const long long* __restrict__ idx, int inner, long
 // rows, a thread owns one column of the LDS table [W+1][256] (plain read-add-write: nobody else touches its slots; LDS
 // float atomics measured 200 cycles per wave -- 116 us for the encoder's 75 MB; row W takes out-of-range tokens) and the
 // table is flushed with one global atomic per non-zero slot.  Loads go 16 rows deep before the first add.
-constexpr int kSegMaxW = 63, kSegDepth = 16;
+constexpr int kSegMaxW = 128, kSegDepth = 16;        // (W + 1) KB of LDS per workgroup: 129 KB of the CU's 160
 // CW columns per workgroup, 256 / CW row groups with a table each (narrow inputs -- embedding gradients with E = 20..30
 // columns -- keep all 256 lanes busy); optional per-row factor (the Dropout2d scale of an embedded sequence).
 template <int CW>
@@ -322,15 +322,20 @@ __global__ __launch_bounds__(256) void token_segsum_kernel(
 struct TableGradArgs {
     const float* dtab; int W, N3, ndir, E;
     const float* emb; long ld_emb;                            // [W][E]
+    const float* emb_last; float* demb_last;                  // optional: row W-1 of emb / demb lives elsewhere (the decoder's
+                                                              // start symbol x_0 behind its V embedding rows)
     const float* Wih[2]; float* dW[2]; long ldw;              // [N3][E] (row stride ldw)
     float* demb; long ld_demb;                                // [W][E], accumulated (or null)
     int nblk_a, chunks;
 };
 __global__ __launch_bounds__(256) void table_grad_kernel(TableGradArgs a) {
     const int ncols = a.ndir * a.N3;
-    __shared__ float sh[64 * 16];
+    __shared__ float sh[kSegMaxW * 16];
     if ((int)blockIdx.x < a.nblk_a) {
-        for (int i = threadIdx.x; i < a.W * a.E; i += 256) sh[i] = a.emb[(long)(i / a.E) * a.ld_emb + i % a.E];
+        for (int i = threadIdx.x; i < a.W * a.E; i += 256) {
+            const int v = i / a.E, e = i % a.E;
+            sh[i] = (v == a.W - 1 && a.emb_last) ? a.emb_last[e] : a.emb[(long)v * a.ld_emb + e];
+        }
         __syncthreads();
         const int o = blockIdx.x * 256 + threadIdx.x;         // (col, e), e fastest
         if (o >= ncols * a.E) return;
@@ -361,9 +366,10 @@ __global__ __launch_bounds__(256) void table_grad_kernel(TableGradArgs a) {
         if (lane == 0) sh[wv * 16 + e] = x;
     }
     __syncthreads();
-    if ((int)threadIdx.x < a.E)
-        unsafeAtomicAdd(a.demb + (long)v * a.ld_demb + threadIdx.x,
-                        sh[threadIdx.x] + sh[16 + threadIdx.x] + sh[32 + threadIdx.x] + sh[48 + threadIdx.x]);
+    if ((int)threadIdx.x < a.E) {
+        float* dst = (v == a.W - 1 && a.demb_last) ? a.demb_last : a.demb + (long)v * a.ld_demb;
+        unsafeAtomicAdd(dst + threadIdx.x, sh[threadIdx.x] + sh[16 + threadIdx.x] + sh[32 + threadIdx.x] + sh[48 + threadIdx.x]);
+    }
 }
 
 // pw_prologue (pointwise.h): blockIdx.y picks the job, blockIdx.x strides over it
@@ -721,16 +727,27 @@ int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, lo
     const int rows_per = (rows + row_blocks - 1) / row_blocks;
     const dim3 grid(col_blocks, row_blocks);
     const size_t lds = (size_t)(W + 1) * 256 * sizeof(float);
-#define INET_SEG(C) hipLaunchKernelGGL(token_segsum_kernel<C>, grid, dim3(256), lds, s, X, ld, idx, inner, s_outer, s_inner, rows, \
-                                       rows_per, W, ncols, out, row_scale)
+#define INET_SEG(C)                                                                                                        \
+    do {                                                                                                                   \
+        static bool attr = false;                              /* more than 64 KB of dynamic LDS needs the opt-in */        \
+        if (!attr) {                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&token_segsum_kernel<C>),                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(token_segsum_kernel<C>, grid, dim3(256), lds, s, X, ld, idx, inner, s_outer, s_inner, rows,     \
+                           rows_per, W, ncols, out, row_scale);                                                            \
+    } while (0)
     if (cw == 32) INET_SEG(32); else if (cw == 64) INET_SEG(64); else INET_SEG(256);
 #undef INET_SEG
     return ok();
 }
 int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,
-                  float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s) {
-    if (E > 16 || W > 63 || ndir < 1 || ndir > 2) return -1;
+                  float* const* dW, long ldw, float* demb, long ld_demb, hipStream_t s, const float* emb_last,
+                  float* demb_last) {
+    if (E > 16 || W > kSegMaxW || ndir < 1 || ndir > 2) return -1;
     TableGradArgs a{};
+    a.emb_last = emb_last; a.demb_last = demb_last;
     a.dtab = dtab; a.W = W; a.N3 = N3; a.ndir = ndir; a.E = E; a.emb = emb; a.ld_emb = ld_emb; a.ldw = ldw;
     for (int d = 0; d < ndir; ++d) { a.Wih[d] = Wih[d]; a.dW[d] = dW[d]; }
     a.demb = demb; a.ld_demb = ld_demb;

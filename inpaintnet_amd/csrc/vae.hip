@@ -41,7 +41,7 @@ size_t enc_carve(const inet_vae_config& c, int B, int save, void* base, EncWs& w
         w.d_amu = cv.take<float>((size_t)B * 2 * H);
         w.d_als = cv.take<float>((size_t)B * 2 * H);
         w.dhcat = cv.take<float>((size_t)B * 4 * H);
-        const bool seg = V <= 63 && E <= 16;                 // token_segsum / table_grad kernels (pointwise.hip); else one-hot products
+        const bool seg = V <= 128 && E <= 16;                // token_segsum / table_grad kernels (pointwise.hip); else one-hot products
         w.onehot = seg ? nullptr : cv.take<float>((size_t)T * B * V);
         w.dtab = cv.take<float>((size_t)V * 6 * H);
     } else {
@@ -222,7 +222,7 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
         w.dgh0t = cv.take<float>(3 * T * BH);
         w.dcgi = cv.take<float>(3 * nb * BH);
         w.dc_all = cv.take<float>(nb * BH);
-        w.onehot = cv.take<float>(T * B * (V + 1));
+        w.onehot = (V + 1 <= 128 && c.emb_dim <= 16) ? nullptr : cv.take<float>(T * B * (V + 1));   // (token_segsum path needs none)
         w.dtable = cv.take<float>((V + 1) * 3 * H);
         w.dbeat_out = cv.take<float>(nb * BH);
         w.dgi1b = cv.take<float>(3 * nb * BH);
@@ -293,7 +293,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     // Which kernels will run: the chain kernels read W_hh / W_ih as stored, only the per-step kernels want the
     // fragment-major twins -- each is packed only if its consumer runs.
     const bool beats_chained = pk && beat_chain && chain_chunk_rows(H, B, nb, 1, save) > 0;   // (one launch, or one per row chunk)
-    const bool fused_shape = pk && !teacher_forced && !multinomial_seed && w.wpk_out && ((!save && !mask_tick) || train_chain);
+    const bool fused_shape = pk && !teacher_forced && !multinomial_seed && ((!save && !mask_tick) || train_chain);
     // batches beyond one resident launch (LatentRNN decodes 512 measures per step): the rows are independent, so the fused
     // kernel runs over chunks of 256 rows, one launch after the other (INET_DECODE_CHUNKS=0: per-tick launches)
     constexpr int kDecodeChunk = 256;
@@ -647,7 +647,17 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         hipStream_t ss = side_fork(s);
         INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, ss));
         INET_TRY(linear_wgrad(w.dcgi, 3L * H, w.c_all, H, g + L.tick[0].w_ih + E, ldw0, nb * B, 3 * H, H, ss));
-        // token-embedding half through the gather table
+        // token-embedding half through the gather table (rows 0..V-1 = the embeddings, row V = the start symbol x_0)
+        if (!w.onehot) {
+            // dTable [V+1, 3H] = the rows of dgi0 summed by the token that selected them -- one pass over dgi0 at HBM rate --
+            // then dW_ih[:, :E] += dTable^T . [E_dec; x_0] and d[E_dec; x_0] += dTable . W_ih[:, :E] in one small launch
+            INET_TRY(pw_shift_tokens(tokens_in, B, T, V, w.tokin, ss));                      // row (t,b) -> token fed at tick t
+            INET_TRY(pw_token_segsum(w.dgi0t, 3L * H, w.tokin, B, 1, T, T * B, V + 1, 3 * H, w.dtable, ss));
+            const float* wih[1] = {wih0};
+            float* dwih[1] = {g + L.tick[0].w_ih};
+            INET_TRY(pw_table_grad(w.dtable, V + 1, 3 * H, 1, E, p + L.dec_emb, E, wih, dwih, ldw0, g + L.dec_emb, E, ss,
+                                   p + L.x_0, g + L.x_0));
+        } else {
         INET_TRY(pw_zero(w.onehot, (long)T * B * (V + 1), ss));
         INET_TRY(pw_onehot(w.idxV, B, 0, 1, B, V + 1, w.onehot, 0, ss));                               // t = 0: x_0 row
         INET_TRY(pw_onehot(tokens_in, B, 1, T, (T - 1) * B, V + 1, w.onehot + (long)B * (V + 1), 0, ss));  // t >= 1: token t-1
@@ -656,6 +666,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         INET_TRY(linear_wgrad(w.dtable + (long)V * 3 * H, 3L * H, p + L.x_0, E, g + L.tick[0].w_ih, ldw0, 1, 3 * H, E, ss));
         INET_TRY(linear_dgrad(w.dtable, 3L * H, wih0, ldw0, g + L.dec_emb, E, V, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, ss));
         INET_TRY(linear_dgrad(w.dtable + (long)V * 3 * H, 3L * H, wih0, ldw0, g + L.x_0, E, 1, 3 * H, E, EPI_NONE, nullptr, 0, ACC_ADD, ss));
+        }
     }
 
     // ---- beat -> tick linears (decoder.py:494-495) ----

@@ -16,6 +16,12 @@ CFGS = {
     "pk": dict(V=20, E=6, H=256, Z=24),
     # no fixture: a vocabulary / embedding wider than the token-sum kernels take (V > 64, E > 16): one-hot GEMM path
     "wide": dict(V=70, E=20, H=48, Z=24),
+    # no fixture: vocabularies that are not a multiple of 16 (the real one is data-derived: MeasureVAE/measure_vae.py:56) on the
+    # fragment-major path: the fused decode kernel pads its last 16-column block, the token segment-sum takes up to 128 rows
+    "v61": dict(V=61, E=10, H=256, Z=24),
+    "v93": dict(V=93, E=10, H=256, Z=24),
+    # no fixture: beyond every fast path's limit (V > 128): per-tick decode, one-hot products for the embedding gradients
+    "v140": dict(V=140, E=10, H=256, Z=24),
 }
 
 

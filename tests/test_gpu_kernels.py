@@ -433,7 +433,7 @@ def test_vae_train_steps_golden(name, mode):
                     assert np.abs(pv.reshape(-1)[:64] - r).max() < 1e-5, (pname, step)
 
 
-@pytest.mark.parametrize("name,B", [("mid", 7), ("pk", 37), ("wide", 5)])
+@pytest.mark.parametrize("name,B", [("mid", 7), ("pk", 37), ("wide", 5), ("v61", 37), ("v93", 20), ("v140", 9)])
 def test_vae_step_with_dropout_masks_vs_oracle(name, B):
     """Mask-in dropout (encoder l0->l1, beat l0->l1, tick l0->l1): HIP path vs the oracle with identical masks.
     "pk" (H=256, ragged batch of 37) runs the fragment-major operand path incl. the masked layer-0 -> layer-1 hand-off."""

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r03e
-python -m pytest tests -m gpu -q -x > gpurun_out/r03e/gpu_tests.log 2>&1; tail -8 gpurun_out/r03e/gpu_tests.log
+python -m pytest tests -m gpu -q -x > gpurun_out/r03e/gpu_tests.log 2>&1; tail -12 gpurun_out/r03e/gpu_tests.log
