@@ -48,7 +48,7 @@ PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E (6.3 TB/s 
 NUM_NOTES = 48
 VAE_BATCH_PER_GPU = 256
 LATENT_SEQ_PER_GPU = 128
-PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -403,6 +403,11 @@ def pmc_key(label):
     if label.startswith("gru_bwd"):
         grid = 256 * f["np"] * math.ceil(f["B"] / (16 * f["ms"])) * (f["H"] // (16 * f["nc"]))
         return f"gru_step_bwd_kernel<{f['ms']}, {f['nc']}, {tf(f['pk'])}>|g{grid}"
+    if label.startswith("decode_chain"):
+        H, ms = f["H"], f["ms"]
+        grid = 256 * 8 * (H // 16) * math.ceil(math.ceil(f["B"] / (16 * ms)) / 8)
+        train = label.startswith("decode_chain_train")
+        return f"decode_chain_kernel<{ms}, {H // 64}, {tf(train)}, 0>|g{grid}"
     if label == "adam":
         return "adam_kernel|"
     m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) ([tdk])(\d+)x(\d+) s(\d+)(?: e\d+)?(?: x(\d+))?", label)
@@ -678,6 +683,9 @@ def main():
             print(f"bench.py: RCCL reduced over {world} ranks, --gpus says {args.gpus}", file=sys.stderr)
             sys.exit(2)
 
+    coin = os.environ.get("INET_BENCH_COIN")                   # profiling aid (tools/profile_r03.sh): every step teacher-forced
+    if coin in ("tf", "fr"):                                   # ("tf") or free-running ("fr") instead of the per-step coin, so that
+        random.random = (lambda: 0.0) if coin == "tf" else (lambda: 0.99)   # every step launches the same kernel sequence
     dp.seed_rank(1234, rank)                                   # per-rank eps / dropout streams
     dp.seed_shared(4321)                                       # the teacher-forcing coin is shared by all ranks
     wl = (VaeWorkload if args.workload == "vae" else LatentWorkload)(dev, rank)

@@ -63,8 +63,13 @@ __device__ __forceinline__ void contract_b(f32x4 (&acc)[MS][4], const int (&slot
     }
 }
 
-template <int MS, int SQ, bool TRAIN>              // SQ = H/64; TRAIN: dropout mask + backward saves
+// NV > 0 (inference, one row block per group): EVERY member computes all NV 16-column blocks of the logits of its rows and
+// takes the argmax itself -- the same arithmetic in the same order everywhere, so all members agree on the token bit for
+// bit -- instead of NV members computing one block each and handing (max, argmax) partials over: two hand-offs per tick
+// instead of three (a hand-off costs more than the 64 extra MFMAs per wave at these batch sizes).
+template <int MS, int SQ, bool TRAIN, int NV = 0>  // SQ = H/64; TRAIN: dropout mask + backward saves
 __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
+    static_assert(NV == 0 || (MS == 1 && !TRAIN && NV <= 4), "redundant logits: small-batch inference only");
     constexpr int S = 4 * SQ, H = 64 * SQ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wih = smem;                                   // [3][S][64][4]  W_ih(l1) slice, fragment-major
@@ -92,7 +97,8 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     const int lp = member / NCB, lcb = member % NCB;
 
     // ---- weights, once per call --------------------------------------------------------------------------------
-    f32x4 W0[3][SQ], W1[3][SQ], Wo[1][SQ];
+    constexpr int NWO = NV > 0 ? NV : 1;
+    f32x4 W0[3][SQ], W1[3][SQ], Wo[NWO][SQ];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -101,10 +107,19 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             W0[g][si] = ld4u(P.W_hh0 + o);
             W1[g][si] = ld4u(P.W_hh1 + o);
         }
+    if constexpr (NV > 0) {
 #pragma unroll
-    for (int si = 0; si < SQ; ++si)
-        Wo[0][si] = has_tile && 16 * lcb + i16 < V ? ld4u(P.W_out + (long)(16 * lcb + i16) * H + 16 * (w * SQ + si) + 4 * q)
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < NV; ++cb)
+#pragma unroll
+            for (int si = 0; si < SQ; ++si)
+                Wo[cb][si] = 16 * cb + i16 < V ? ld4u(P.W_out + (long)(16 * cb + i16) * H + 16 * (w * SQ + si) + 4 * q)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int si = 0; si < SQ; ++si)
+            Wo[0][si] = has_tile && 16 * lcb + i16 < V ? ld4u(P.W_out + (long)(16 * lcb + i16) * H + 16 * (w * SQ + si) + 4 * q)
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int i = t; i < 3 * S * 64; i += 256) {                // W_ih(l1): slot (g, s, lane) <- 4 consecutive k of row g*H + j0 + lane%16
         const int ln = i & 63, s = (i >> 6) % S, g = i / (64 * S);
         *reinterpret_cast<f32x4*>(wih + (long)i * 4) = ld4u(P.W_ih1 + (long)(g * H + j0 + (ln & 15)) * H + 16 * s + 4 * (ln >> 4));
@@ -114,6 +129,10 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     for (int g = 0; g < 3; ++g) { bh0[g] = P.b_hh0[g * H + jc]; bi1[g] = P.b_ih1[g * H + jc]; bh1[g] = P.b_hh1[g * H + jc]; }
     const bool col_ok = has_tile && 16 * lcb + (t & 15) < V;
     const float bo = col_ok ? P.b_out[16 * lcb + (t & 15)] : 0.f;
+    float bov[NWO];                                            // (NV > 0) bias of column 16 cb + (t & 15)
+#pragma unroll
+    for (int cb = 0; cb < NWO; ++cb) bov[cb] = NV > 0 && 16 * cb + (t & 15) < V ? P.b_out[16 * cb + (t & 15)] : 0.f;
+    long own_tok = 0;                                          // (NV > 0) token of row t >> 4 from the previous tick
     int brow[MS];
 #pragma unroll
     for (int p = 0; p < MS; ++p) brow[p] = min(row0 + ((t + 256 * p) >> 4), B - 1);
@@ -155,11 +174,11 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
                 hp1[p] = P.ht0[((long)beat * Bs + brow[p]) * 2 * H + H + jc];
             }
         }
-        if (tick > 0 && !chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;   // tokens of tick-1
+        if (NV == 0 && tick > 0 && !chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;   // tokens of tick-1
         long tok[MS];
 #pragma unroll
-        for (int p = 0; p < MS; ++p) tok[p] = tick == 0 ? V : token_of(tick - 1, p);
-        if (tick > 0 && member == 0 && (t & 15) == 0) {
+        for (int p = 0; p < MS; ++p) tok[p] = tick == 0 ? V : (NV > 0 ? own_tok : token_of(tick - 1, p));
+        if (NV == 0 && tick > 0 && member == 0 && (t & 15) == 0) {
 #pragma unroll
             for (int p = 0; p < MS; ++p)
                 if (row0 + ((t + 256 * p) >> 4) < B) P.samples[(long)brow[p] * T + tick - 1] = tok[p];
@@ -267,6 +286,39 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
         // then reaches 2 x members too early and a logits tile contracts a k-slice that is not published yet (seen as
         // one wrong 16 x 16 logits tile at tick 0 in ~5 % of the B = 256 calls before this wait was made unconditional).
         if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;               // h1 of this tick
+        if constexpr (NV > 0) {
+            f32x4 la[1][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) la[0][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int sl[NV];
+#pragma unroll
+            for (int cb = 0; cb < NV; ++cb) sl[cb] = cb;
+            contract_b<1, NV, SQ>(la, sl, [&](int g, int si) { return Wo[g][si]; }, r_hx1, (tick & 1) * pkh * 4, rb0, rb_last, S,
+                                  w * SQ, lane);
+            float lv[1][NV];
+            reduce_waves<1, NV>(la, red, t, lv);
+            const int rl = t >> 4, c = t & 15, b = row0 + rl;
+            float m = -1.f;
+            int am = 0;
+#pragma unroll
+            for (int cb = 0; cb < NV; ++cb) {
+                const bool okc = 16 * cb + c < V;
+                float x = lv[0][cb] + bov[cb];
+                x = x > 0.f ? x : 0.f;
+                if (member == cb % members && b < B && okc) P.weights[((long)b * T + tick) * V + 16 * cb + c] = x;
+                if (!okc) x = -1.f;                            // a padded column never wins
+                if (x > m) { m = x; am = 16 * cb + c; }        // (ascending cb: the lowest index wins ties)
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {                  // (max, lowest argmax) over the 16 lanes of the row
+                const float m2 = __shfl_xor(m, o, 16);
+                const int a2 = __shfl_xor(am, o, 16);
+                if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+            }
+            own_tok = am;
+            if (member == 0 && c == 0 && b < B) P.samples[(long)b * T + tick] = am;
+            continue;                                          // no third hand-off
+        }
         if (has_tile) {
             f32x4 la[1][4];
             la[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -299,7 +351,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
         ++phase;
     }
     // the last tick's tokens
-    if (member == 0) {
+    if (NV == 0 && member == 0) {
         if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;
         if ((t & 15) == 0) {
 #pragma unroll
@@ -339,27 +391,36 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
     const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;
     if (a.mask && !a.hx0m) return -1;
     std::snprintf(label, sizeof label, "decode_chain%s ms%d T%d B%d H%d V%d", train ? "_train" : "", ms, a.T, a.B, a.H, a.V);
-    // algorithmic bytes: the tick GRU + output weights once per call, logits out
+    // algorithmic bytes: the tick GRU + output weights once per call, logits out; training: the dropout mask in, the 2 x 5
+    // backward saves and the two layer outputs out (13 arrays of [T,B,H])
     ProfScope prof(PROF_GRU_FWD, 2.0 * a.T * a.B * (9.0 * a.H * a.H + (double)a.V * a.H), s, label,
-                   4.0 * (9.0 * a.H * a.H + (double)a.V * a.H + (double)a.B * a.T * a.V));
+                   4.0 * (9.0 * a.H * a.H + (double)a.V * a.H + (double)a.B * a.T * a.V +
+                          (train ? 13.0 * a.T * a.B * a.H : 0.0)));
     const dim3 grid(chain::blocks_for(groups, a.members));
-#define INET_DC(M, Q, TR)                                                                                               \
+#define INET_DC4(M, Q, TR, NVV)                                                                                         \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chain_kernel<M, Q, TR>),                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chain_kernel<M, Q, TR, NVV>),                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((decode_chain_kernel<M, Q, TR>), grid, dim3(256), lds, s, a);                                \
+        hipLaunchKernelGGL((decode_chain_kernel<M, Q, TR, NVV>), grid, dim3(256), lds, s, a);                           \
     } while (0)
+#define INET_DC(M, Q, TR) INET_DC4(M, Q, TR, 0)
     if (train) {
         if (a.H == 512) { if (ms == 1) INET_DC(1, 8, true); else INET_DC(2, 8, true); }
         else { if (ms == 1) INET_DC(1, 4, true); else INET_DC(2, 4, true); }
     } else {
-        if (a.H == 512) { if (ms == 1) INET_DC(1, 8, false); else INET_DC(2, 8, false); }
+        // small-batch inference (one row block per group, V <= 64): every member computes the whole logits row itself
+        static const bool fullv = [] { const char* v = std::getenv("INET_DECODE_FULLV"); return !(v && v[0] == '0'); }();
+        const int nv = (fullv && ms == 1 && a.V <= 64) ? (a.V <= 48 ? 3 : 4) : 0;
+        if (nv == 3) { if (a.H == 512) INET_DC4(1, 8, false, 3); else INET_DC4(1, 4, false, 3); }
+        else if (nv == 4) { if (a.H == 512) INET_DC4(1, 8, false, 4); else INET_DC4(1, 4, false, 4); }
+        else if (a.H == 512) { if (ms == 1) INET_DC(1, 8, false); else INET_DC(2, 8, false); }
         else { if (ms == 1) INET_DC(1, 4, false); else INET_DC(2, 4, false); }
     }
 #undef INET_DC
+#undef INET_DC4
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -103,8 +103,26 @@ def pmc(fetch_csv, write_csv, out_json, seq_json=None):
         print(f"  {k:<62} n={v['launches']:<6} {v['avg_us_profiled']:>9.2f} us  {v['hbm_mbytes_per_launch']:>9.3f} MB/launch")
 
 
+def merge(out_json, *parts):
+    """Union of several pmc() outputs (teacher-forced and free-running passes): a key keeps the entry of the first file that
+    has it, per-shape entries (key#label) of every file are kept."""
+    doc = None
+    for p in parts:
+        d = json.load(open(p))
+        if doc is None:
+            doc = d
+            continue
+        for k, v in d["kernels"].items():
+            doc["kernels"].setdefault(k, v)
+    doc["source"] += " ; passes with INET_BENCH_COIN=tf and =fr merged (every step of a pass launches the same kernel sequence)"
+    json.dump(doc, open(out_json, "w"), indent=1)
+    print(f"wrote {out_json}: {len(doc['kernels'])} kernel/grid keys")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "merge":
+        merge(sys.argv[2], *sys.argv[3:])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], seq_json=sys.argv[3] if len(sys.argv) > 3 else None)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
