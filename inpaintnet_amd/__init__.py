@@ -11,7 +11,8 @@ import os as _os
 
 # Kernel arguments in device memory instead of host-coherent memory: every launch of the step reads its kernarg segment
 # once per wave, and the persistent chain kernels re-read parts of it per time step; with the default placement that read
-# crosses PCIe.  Measured on the B=256 MeasureVAE step: 4.6 -> 4.1 ms (profiles/r03_*kernarg*).  The HIP runtime reads the
+# crosses PCIe.  Measured on the B=256 MeasureVAE step: 4.25 -> 4.20 ms (profiles/r03_i_kernarg_ab.txt; 0.5 ms in round 2,
+# when a step had 124 launches).  The HIP runtime reads the
 # variable when it initialises, i.e. at the first HIP call of the process -- importing this package before touching the
 # GPU is enough; a value the user has set is respected.  
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
