@@ -661,7 +661,8 @@ int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long 
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
                      float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s, const float* scale_dev,
                      const float* add_term, float add_scale, float* fwd_out, float fwd_scale) {
-    const int g = grid_for((long)rows * 64, 256, 512);
+    const int g = grid_for((long)rows * 64, 256, 512);        // (2048 blocks = one row per wave measured SLOWER: 77 vs 54 us for the
+                                                              // loss glue of the B = 256 step -- one atomic pair per block on one word)
     hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, out_scale, loss_sum,
                        correct, scale_dev, add_term, add_scale, fwd_out, fwd_scale);
     return ok();

@@ -13,8 +13,10 @@ static int chunk_max_rows() {
 }
 int chain_chunk_rows(int H, int B, int T, int nd, int save) {
     if (gru_chain_ok(H, B, T, nd)) return B;
-    if (save && B > chunk_max_rows()) return 0;      // (forward-only passes -- LatentRNN's frozen encoder -- chunk at any size:
-                                                     //  two chunks run side by side there, measured in round 2)
+    // (forward-only passes -- LatentRNN's frozen encoder, 2048 rows -- chunk at any size: two chunks run side by side there;
+    //  INET_CHAIN_CHUNK_MAX_FWD caps them too)
+    static const int fwd_cap = [] { const char* e = std::getenv("INET_CHAIN_CHUNK_MAX_FWD"); return e ? std::atoi(e) : (1 << 30); }();
+    if (B > (save ? chunk_max_rows() : fwd_cap)) return 0;
     for (int ch = 1024; ch >= 64; ch >>= 1)
         if (ch < B && B % ch == 0 && gru_chain_ok(H, ch, T, nd)) return ch;
     return 0;
