@@ -407,7 +407,7 @@ def pmc_key(label):
         H, ms = f["H"], f["ms"]
         grid = 256 * 8 * (H // 16) * math.ceil(math.ceil(f["B"] / (16 * ms)) / 8)
         train = label.startswith("decode_chain_train")
-        return f"decode_chain_kernel<{ms}, {H // 64}, {tf(train)}, 0>|g{grid}"
+        return f"decode_chain_kernel<{ms}, {H // 64}, {tf(train)}, 0, 0>|g{grid}"
     if label == "adam":
         return "adam_kernel|"
     m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) ([tdk])(\d+)x(\d+) s(\d+)(?: e\d+)?(?: x(\d+))?", label)

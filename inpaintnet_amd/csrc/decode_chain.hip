@@ -67,9 +67,56 @@ __device__ __forceinline__ void contract_b(f32x4 (&acc)[MS][4], const int (&slot
 // takes the argmax itself -- the same arithmetic in the same order everywhere, so all members agree on the token bit for
 // bit -- instead of NV members computing one block each and handing (max, argmax) partials over: two hand-offs per tick
 // instead of three (a hand-off costs more than the 64 extra MFMAs per wave at these batch sizes).
-template <int MS, int SQ, bool TRAIN, int NV = 0>  // SQ = H/64; TRAIN: dropout mask + backward saves
+// The same contraction for at most VR <= 4 valid rows on the VALU (b = 1 inpainting: LatentRNNTester.generate).  An MFMA
+// contracts a 16-row tile whether one row is valid or sixteen (96 x 32 cycles per gate triple and wave); here lane (unit i16, k
+// group q) multiplies ITS OWN register-resident W fragments with the row's values -- fetched as the usual A fragment and
+// broadcast from lane (q, row) with one shuffle per component -- and the four k groups are summed with two shuffles: ~130 issue
+// slots per row instead of 3,072 cycles of matrix pipe.  The result lands in the C layout of the MFMA path (rows 0..3 = the
+// registers of lanes 0..15), so everything downstream is shared.
+template <int NG, int SQ, int VR, class GetB>
+__device__ __forceinline__ void contract_valu(f32x4 (&acc)[1][4], const int (&slot)[NG], GetB&& getB, __amdgpu_buffer_rsrc_t r,
+                                              int base, int rb0, int S, int s0, int lane) {
+    const int vo = ((rb0 * S + s0) * 256 + lane * 4) * 4;
+    f32x4 A[SQ];
+#pragma unroll
+    for (int si = 0; si < SQ; ++si) A[si] = chain::ld16_sc1(r, vo + si * 1024, base);
+    float p[VR][NG];
+#pragma unroll
+    for (int rr = 0; rr < VR; ++rr)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) p[rr][g] = 0.f;
+    const int src0 = lane & 48;
+#pragma unroll
+    for (int si = 0; si < SQ; ++si) {
+        f32x4 Bf[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) Bf[g] = getB(g, si);
+#pragma unroll
+        for (int rr = 0; rr < VR; ++rr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = __shfl(A[si][e], src0 | rr, 64);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) p[rr][g] = fmaf(a, Bf[g][e], p[rr][g]);
+            }
+        }
+    }
+    const bool q0 = lane < 16;
+#pragma unroll
+    for (int rr = 0; rr < VR; ++rr)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float v = p[rr][g];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[0][slot[g]][rr] += q0 ? v : 0.f;
+        }
+}
+
+template <int MS, int SQ, bool TRAIN, int NV = 0, int VR = 0>  // SQ = H/64; TRAIN: dropout mask + backward saves; VR: VALU rows
 __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     static_assert(NV == 0 || (MS == 1 && !TRAIN && NV <= 4), "redundant logits: small-batch inference only");
+    static_assert(VR == 0 || (NV > 0 && VR <= 4), "VALU contraction: the smallest inference batches only");
     constexpr int S = 4 * SQ, H = 64 * SQ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wih = smem;                                   // [3][S][64][4]  W_ih(l1) slice, fragment-major
@@ -195,8 +242,14 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
             const int sl[3] = {0, 1, 2};
-            if (j == 0) contract_b<MS, 3, SQ>(acc, sl, [&](int g, int si) { return W0[g][si]; }, r_ht0, beat * pkh * 4, rb0, rb_last, S, w * SQ, lane);
-            else contract_b<MS, 3, SQ>(acc, sl, [&](int g, int si) { return W0[g][si]; }, r_hx0, ((tick + 1) & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+            auto gb = [&](int g, int si) { return W0[g][si]; };
+            if constexpr (VR > 0) {
+                if (j == 0) contract_valu<3, SQ, VR>(acc, sl, gb, r_ht0, beat * pkh * 4, rb0, S, w * SQ, lane);
+                else contract_valu<3, SQ, VR>(acc, sl, gb, r_hx0, ((tick + 1) & 1) * pkh * 4, rb0, S, w * SQ, lane);
+            } else {
+                if (j == 0) contract_b<MS, 3, SQ>(acc, sl, gb, r_ht0, beat * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+                else contract_b<MS, 3, SQ>(acc, sl, gb, r_hx0, ((tick + 1) & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+            }
         }
         float v[MS][4];
         reduce_waves<MS, 4>(acc, red, t, v);
@@ -242,14 +295,21 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             for (int a = 0; a < 4; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
         {   // recurrent half first: it needs h1 of the previous tick only, and hides the hand-off of h0
             const int sh[3] = {0, 1, 3};
-            if (j == 0) contract_b<MS, 3, SQ>(acc, sh, [&](int g, int si) { return W1[g][si]; }, r_ht0, (nb + beat) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
-            else contract_b<MS, 3, SQ>(acc, sh, [&](int g, int si) { return W1[g][si]; }, r_hx1, ((tick + 1) & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+            auto gb = [&](int g, int si) { return W1[g][si]; };
+            if constexpr (VR > 0) {
+                if (j == 0) contract_valu<3, SQ, VR>(acc, sh, gb, r_ht0, (nb + beat) * pkh * 4, rb0, S, w * SQ, lane);
+                else contract_valu<3, SQ, VR>(acc, sh, gb, r_hx1, ((tick + 1) & 1) * pkh * 4, rb0, S, w * SQ, lane);
+            } else {
+                if (j == 0) contract_b<MS, 3, SQ>(acc, sh, gb, r_ht0, (nb + beat) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+                else contract_b<MS, 3, SQ>(acc, sh, gb, r_hx1, ((tick + 1) & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+            }
         }
         if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;               // h0 of this tick
         {
             const int sx[3] = {0, 1, 2};
-            contract_b<MS, 3, SQ>(acc, sx, [&](int g, int si) { return *reinterpret_cast<const f32x4*>(wih + ((g * S + w * SQ + si) * 64 + lane) * 4); },
-                                  r_hxm, (masked ? beat : (tick & 1)) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
+            auto gb = [&](int g, int si) { return *reinterpret_cast<const f32x4*>(wih + ((g * S + w * SQ + si) * 64 + lane) * 4); };
+            if constexpr (VR > 0) contract_valu<3, SQ, VR>(acc, sx, gb, r_hxm, (tick & 1) * pkh * 4, rb0, S, w * SQ, lane);
+            else contract_b<MS, 3, SQ>(acc, sx, gb, r_hxm, (masked ? beat : (tick & 1)) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
         }
         reduce_waves<MS, 4>(acc, red, t, v);
 #pragma unroll
@@ -293,8 +353,10 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             int sl[NV];
 #pragma unroll
             for (int cb = 0; cb < NV; ++cb) sl[cb] = cb;
-            contract_b<1, NV, SQ>(la, sl, [&](int g, int si) { return Wo[g][si]; }, r_hx1, (tick & 1) * pkh * 4, rb0, rb_last, S,
-                                  w * SQ, lane);
+            if constexpr (VR > 0) contract_valu<NV, SQ, VR>(la, sl, [&](int g, int si) { return Wo[g][si]; }, r_hx1, (tick & 1) * pkh * 4, rb0,
+                                                            S, w * SQ, lane);
+            else contract_b<1, NV, SQ>(la, sl, [&](int g, int si) { return Wo[g][si]; }, r_hx1, (tick & 1) * pkh * 4, rb0, rb_last, S,
+                                       w * SQ, lane);
             float lv[1][NV];
             reduce_waves<1, NV>(la, red, t, lv);
             const int rl = t >> 4, c = t & 15, b = row0 + rl;
@@ -390,23 +452,24 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
     char label[72];
     const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;
     if (a.mask && !a.hx0m) return -1;
-    std::snprintf(label, sizeof label, "decode_chain%s ms%d T%d B%d H%d V%d", train ? "_train" : "", ms, a.T, a.B, a.H, a.V);
+    std::snprintf(label, sizeof label, "decode_chain%s ms%d T%d B%d H%d V%d", train ? "_train" : (a.B == 1 ? "_valu" : ""), ms, a.T, a.B, a.H, a.V);
     // algorithmic bytes: the tick GRU + output weights once per call, logits out; training: the dropout mask in, the 2 x 5
     // backward saves and the two layer outputs out (13 arrays of [T,B,H])
     ProfScope prof(PROF_GRU_FWD, 2.0 * a.T * a.B * (9.0 * a.H * a.H + (double)a.V * a.H), s, label,
                    4.0 * (9.0 * a.H * a.H + (double)a.V * a.H + (double)a.B * a.T * a.V +
                           (train ? 13.0 * a.T * a.B * a.H : 0.0)));
     const dim3 grid(chain::blocks_for(groups, a.members));
-#define INET_DC4(M, Q, TR, NVV)                                                                                         \
+#define INET_DC5(M, Q, TR, NVV, VRR)                                                                                    \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chain_kernel<M, Q, TR, NVV>),                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chain_kernel<M, Q, TR, NVV, VRR>),            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((decode_chain_kernel<M, Q, TR, NVV>), grid, dim3(256), lds, s, a);                           \
+        hipLaunchKernelGGL((decode_chain_kernel<M, Q, TR, NVV, VRR>), grid, dim3(256), lds, s, a);                      \
     } while (0)
+#define INET_DC4(M, Q, TR, NVV) INET_DC5(M, Q, TR, NVV, 0)
 #define INET_DC(M, Q, TR) INET_DC4(M, Q, TR, 0)
     if (train) {
         if (a.H == 512) { if (ms == 1) INET_DC(1, 8, true); else INET_DC(2, 8, true); }
@@ -415,12 +478,19 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
         // small-batch inference (one row block per group, V <= 64): every member computes the whole logits row itself
         static const bool fullv = [] { const char* v = std::getenv("INET_DECODE_FULLV"); return !(v && v[0] == '0'); }();
         const int nv = (fullv && ms == 1 && a.V <= 64) ? (a.V <= 48 ? 3 : 4) : 0;
-        if (nv == 3) { if (a.H == 512) INET_DC4(1, 8, false, 3); else INET_DC4(1, 4, false, 3); }
+        // one row (b = 1 inpainting): the contractions on the VALU instead of one-sixteenth-full MFMA tiles
+        static const bool valu = [] { const char* v = std::getenv("INET_DECODE_VALU"); return !(v && v[0] == '0'); }();
+        // (one row only: the four-row build of the H = 512 kernel spills ~300 registers)
+        const int vr = (valu && nv > 0 && a.B == 1) ? 1 : 0;
+        if (nv == 3 && vr == 1) { if (a.H == 512) INET_DC5(1, 8, false, 3, 1); else INET_DC5(1, 4, false, 3, 1); }
+        else if (nv == 4 && vr == 1) { if (a.H == 512) INET_DC5(1, 8, false, 4, 1); else INET_DC5(1, 4, false, 4, 1); }
+        else if (nv == 3) { if (a.H == 512) INET_DC4(1, 8, false, 3); else INET_DC4(1, 4, false, 3); }
         else if (nv == 4) { if (a.H == 512) INET_DC4(1, 8, false, 4); else INET_DC4(1, 4, false, 4); }
         else if (a.H == 512) { if (ms == 1) INET_DC(1, 8, false); else INET_DC(2, 8, false); }
         else { if (ms == 1) INET_DC(1, 4, false); else INET_DC(2, 4, false); }
     }
 #undef INET_DC
 #undef INET_DC4
+#undef INET_DC5
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -14,28 +14,32 @@
 #include "ksplit.h"
 using namespace ksplit;
 
-constexpr int H = 512, B = 256, T = 24, MEMBERS = 32, S = H / 16, NRB = B / 16;
-constexpr int TILES = B / 64, GROUPS = 2 * TILES, NB = GROUPS * MEMBERS;
+#ifndef WAVES_
+#define WAVES_ 4                                   // waves (= row blocks) per workgroup; 8: two per SIMD, B = 512
+#endif
+constexpr int WV = WAVES_;
+constexpr int H = 512, B = 64 * WV, T = 24, MEMBERS = 32, S = H / 16, NRB = B / 16;
+constexpr int TILES = 4, GROUPS = 2 * TILES, NB = GROUPS * MEMBERS;     // a tile = WV row blocks
 #ifndef RING_
 #define RING_ 8
 #endif
 struct Args { float* hx; const float* W; const float* gi; float* out; unsigned* counters; unsigned* status; unsigned long long* stamps; };
 
 template <bool MFMA, bool SYNC>
-__global__ __launch_bounds__(256) void k(Args A) {
+__global__ __launch_bounds__(64 * WV) void k(Args A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wl = smem;                                  // [3][S][64][4]
-    float* const xt = smem + 3 * S * 256;                    // [4 waves][256]
+    float* const xt = smem + 3 * S * 256;                    // [WV waves][256]
     int group, member;
     chain::decode_block(blockIdx.x, MEMBERS, group, member);
     const int dir = group / TILES, tile = group % TILES;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c = lane & 15, q = lane >> 4;
-    const int rb = tile * 4 + w;                             // this wave's row block
+    const int rb = tile * WV + w;                            // this wave's row block
     const int j0 = member * 16;
     const int slot_bytes = B * H * 4;
     float* hx = A.hx + (size_t)dir * 2 * B * H;
-    for (int i = t; i < 3 * S * 64; i += 256) {
+    for (int i = t; i < 3 * S * 64; i += 64 * WV) {
         const int ln = i & 63, s = (i >> 6) % S, g = i / (64 * S);
         *reinterpret_cast<f32x4*>(wl + (long)i * 4) = ld4u(A.W + (long)(g * H + j0 + (ln & 15)) * H + 16 * s + 4 * (ln >> 4));
     }
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void k(Args A) {
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(hx);
     unsigned* counter = A.counters + (dir * NRB + rb) * 64;
     float hp[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned long long* stamp = A.stamps + ((size_t)blockIdx.x * 4 + w) * T * 4;
+    unsigned long long* stamp = A.stamps + ((size_t)blockIdx.x * WV + w) * T * 4;
     float* myxt = xt + w * 256;
     const int abase = (rb * S * 256 + lane * 4) * 4;         // byte offset of k-step 0 of this row block
     for (int step = 0; step < T; ++step) {
@@ -113,30 +117,30 @@ __global__ __launch_bounds__(256) void k(Args A) {
 
 template <bool MFMA, bool SYNC>
 void run(const char* name, Args a) {
-    const size_t ns = (size_t)NB * 4 * T * 4;
+    const size_t ns = (size_t)NB * WV * T * 4;
     std::vector<unsigned long long> h(ns);
     double best = 1e30; double ph[4] = {0, 0, 0, 0};
     unsigned stat = 0;
-    const size_t lds = (size_t)(3 * S * 256 + 4 * 256) * 4;
+    const size_t lds = (size_t)(3 * S * 256 + WV * 256) * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MFMA, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int rep = 0; rep < 5; ++rep) {
-        (void)hipMemset(a.counters, 0, 64 * 64 * 4); (void)hipMemset(a.status, 0, 4);
-        hipLaunchKernelGGL((k<MFMA, SYNC>), dim3(NB), dim3(256), lds, 0, a);
+        (void)hipMemset(a.counters, 0, 128 * 64 * 4); (void)hipMemset(a.status, 0, 4);
+        hipLaunchKernelGGL((k<MFMA, SYNC>), dim3(NB), dim3(64 * WV), lds, 0, a);
         if (hipDeviceSynchronize() != hipSuccess) { printf("%s failed\n", name); return; }
         (void)hipMemcpy(h.data(), a.stamps, ns * 8, hipMemcpyDeviceToHost);
         (void)hipMemcpy(&stat, a.status, 4, hipMemcpyDeviceToHost);
         unsigned long long b0 = ~0ull, e1 = 0;
-        for (size_t wv = 0; wv < (size_t)NB * 4; ++wv) { b0 = std::min(b0, h[wv * T * 4]); e1 = std::max(e1, h[wv * T * 4 + (T - 1) * 4 + 3]); }
+        for (size_t wv = 0; wv < (size_t)NB * WV; ++wv) { b0 = std::min(b0, h[wv * T * 4]); e1 = std::max(e1, h[wv * T * 4 + (T - 1) * 4 + 3]); }
         const double us = (e1 - b0) / 100.0 / T;
         if (us < best) {
             best = us;
             for (auto& x : ph) x = 0;
-            for (size_t wv = 0; wv < (size_t)NB * 4; ++wv) for (int s = 2; s < T; ++s) {
+            for (size_t wv = 0; wv < (size_t)NB * WV; ++wv) for (int s = 2; s < T; ++s) {
                 const unsigned long long* p = &h[(wv * T + s) * 4];
                 const unsigned long long prev_end = h[(wv * T + s - 1) * 4 + 3];
                 ph[0] += p[0] - prev_end; ph[1] += p[1] - p[0]; ph[2] += p[2] - p[1]; ph[3] += p[3] - p[2];
             }
-            for (auto& x : ph) x /= 100.0 * NB * 4 * (T - 2);
+            for (auto& x : ph) x /= 100.0 * NB * WV * (T - 2);
         }
     }
     printf("%-10s %6.2f us/step | stores+loop %.2f  prefetch+wait %.2f  contract %.2f  gates+publish+arrive %.2f | status %u\n",
@@ -158,8 +162,8 @@ int main() {
         (void)hipMemcpy(gi, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);
     }
     (void)hipMalloc(&a.out, (size_t)7 * T * B * H * 4);
-    (void)hipMalloc(&a.counters, 64 * 64 * 4); (void)hipMalloc(&a.status, 4);
-    (void)hipMalloc(&a.stamps, (size_t)NB * 4 * T * 4 * 8);
+    (void)hipMalloc(&a.counters, 128 * 64 * 4); (void)hipMalloc(&a.status, 4);
+    (void)hipMalloc(&a.stamps, (size_t)NB * WV * T * 4 * 8);
     run<true, true>("full", a);
     run<true, false>("no_sync", a);
     run<false, true>("no_mfma", a);
