@@ -389,6 +389,13 @@ def pmc_key(label):
     import re
     f = {k: int(v) for k, v in re.findall(r"\b(ms|np|nc|pk|x|T|B|H|M|N|K|s)(\d+)", label)}
     tf = lambda v: "true" if v else "false"
+    m2 = re.match(r"gru_chain_(fwd|bwd) v2w(\d+) p(\d+) np(\d+) T(\d+) B(\d+) H(\d+)", label)
+    if m2:                                               # second generation (csrc/gru_chain2.hip): waves per workgroup, piece products
+        kind, wv, npp, nprob, _, B_, H = m2.group(1), *[int(x) for x in m2.groups()[1:]]
+        groups = nprob * math.ceil(math.ceil(B_ / 16) / wv)
+        grid = 64 * wv * 8 * (H // 16) * math.ceil(groups / 8)
+        s32 = H // 32 if kind == "fwd" else 3 * H // 32
+        return f"gru_chain2_{kind}_kernel<{wv}, {s32}, {npp}>|g{grid}"
     if label.startswith("gru_chain_fwd") or label.startswith("gru_chain_bwd"):
         fwd = label.startswith("gru_chain_fwd")
         H, ms = f["H"], f["ms"]
@@ -599,6 +606,28 @@ def vocab_extra(num_notes=61, steps=40, warmup=8):
                                         "workload": f"the headline step with V = {num_notes} (not a multiple of 16)"}}
 
 
+def chain_generations_extra(wl, steps=60, warmup=10):
+    """The headline step under the other forms of the recurrent contraction (inet_set_option key 7): 0 = first-generation
+    chain kernels (f32-input MFMA), 6 = second generation with the three piece products below 2^-24 |ab| dropped."""
+    from inpaintnet_amd import ops
+    out = {}
+    try:
+        for mode, key in ((0, "f32_input_mfma"), (6, "bf16_split_6_products")):
+            ops.set_option(7, mode)
+            for _ in range(warmup):
+                wl.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                wl.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[key] = {"measures_per_s": round(wl.units_per_step * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4)}
+    finally:
+        ops.set_option(7, 9)
+    return {"chain_generations": out}
+
+
 def arnn_extra(batch=32, steps=8, warmup=2):
     """Secondary number (BASELINE.json configs[4]): AnticipationRNN gauss-reg model, teacher-forced training step,
     batch 32 sequences of 384 ticks, script defaults of train_arnn_reg.py.  Not the headline metric."""
@@ -753,7 +782,8 @@ def main():
                 wl.model.train()
             if args.workload == "vae":
                 extras.update(epoch_loop_extra(wl))
-                for fn, key in ((lambda: vae4096_extra(wl), "vae_train_4096"), (vocab_extra, "vae_train_v61")):
+                for fn, key in ((lambda: chain_generations_extra(wl), "chain_generations"),
+                                (lambda: vae4096_extra(wl), "vae_train_4096"), (vocab_extra, "vae_train_v61")):
                     try:
                         extras.update(fn())
                     except Exception as e:                   # a secondary number must never take the headline down
@@ -776,6 +806,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "arithmetic": "f32 throughout; products on the f32-input MFMA (v_mfma_f32_*_f32) except the recurrent contractions of "
+                          "the GRU chain kernels, which split every f32 operand EXACTLY into three bf16 pieces and accumulate all "
+                          "nine piece products in f32 on the bf16 MFMA: the products of fp32 arithmetic (csrc/gru_chain2.hip; "
+                          "error against float64 equal to the f32-input form, tests/test_gpu_kernels.py::"
+                          "test_chain_generations_against_float64; INET_CHAIN2=0 selects the f32-input form)",
             "data": "synthetic",
             "config": dict(wl.describe(world), final_loss=round(final_loss, 5)),
             "roofline": roof,

@@ -258,6 +258,10 @@ int inet_set_option(int key, int value);
 /* key 6 = test hook: value 1 arms ONE injected fault -- the next forward GRU chain launch loses a workgroup, its group runs
  * into the bounded spin (~0.4 s) and inet_chain_status() turns non-zero: lets the failure path (optimizer skip, fallback to
  * per-step kernels) be tested on a healthy GPU. */
+/* key 7 = generation of the GRU chain kernels: 9 (default; INET_CHAIN2) = second generation (csrc/gru_chain2.hip: one row block
+ * per wave, W in LDS, the contraction on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces
+ * and all nine piece products accumulated in f32 -- the products of fp32 arithmetic), 6 = the same with the three terms below
+ * 2^-24 |ab| dropped, 0 = first generation (f32-input MFMA, W in registers). */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.
  * Unlike inet_side_join nothing is consumed: the issuing stream still joins the same work at its own next join (a

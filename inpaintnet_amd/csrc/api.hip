@@ -384,6 +384,7 @@ int inet_set_option(int key, int value) {
     if (key == 3) { if (value < 0) return -1; gemm_set_force(-2, value); return 0; }
     if (key == 5) { if (value < 0 || value > 4) return -1; gemm_set_direct(value); return 0; }
     if (key == 6) { chain_arm_fault(value); return 0; }
+    if (key == 7) { if (value != 0 && value != 6 && value != 9) return -1; chain2_set_mode(value); return 0; }
     return -1;
 }
 

@@ -5,7 +5,7 @@
 // Sync area of one launch.  Every group counter sits alone in a 256-byte block: the counters are polled (L2-bypassing
 // loads) by all members of their group and bumped with device-scope atomics, and with 8 of them in one line all 256
 // pollers of the launch queued on the same memory channel -- 0.6 us of every step (profiles/r02_i_chain_counters.txt).
-constexpr int kChainMaxGroups = 32;               // group counters per launch
+constexpr int kChainMaxGroups = 64;               // group counters per launch (second generation: one per problem and row block)
 constexpr int kChainCounterStride = 64;           // words between two group counters
 constexpr int kChainStatusWord = kChainMaxGroups * kChainCounterStride;   // the launch's status word (abort flag)
 constexpr int kChainZeroWord = kChainStatusWord + 64; // words [+0, +1] stay zero: the target of absent operand pointers
@@ -71,5 +71,13 @@ struct GruChainBwd {
 
 bool gru_chain_ok(int H, int B, int T, int nprob);
 bool gru_chain_bwd_ok(int H, int B, int T, int nprob);      // as above, with two row tiles per workgroup when needed
-int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s);
+int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s);     // (dispatches to the second generation where it applies)
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s);
+// Second generation (gru_chain2.hip): one row block per wave, W in LDS, contraction on the bf16 matrix cores at fp32
+// accuracy (three-way exact split, 9 or 6 piece products).  Its exchange holds three bf16 pieces per state: rings must be
+// sized 3 * pk_floats(B, K) floats (seq.h chain_ring_floats) instead of 2 * pk_floats.
+int chain2_mode();                                          // 0 = off (INET_CHAIN2=0), 6 or 9 piece products (default 9)
+void chain2_set_mode(int np);
+bool gru_chain2_ok(int H, int B, int T, int nprob);
+int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s);
+int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s);

@@ -379,6 +379,8 @@ bool gru_chain_bwd_ok(int H, int B, int T, int nprob) {
 }
 
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
+    static const bool v2f = [] { const char* v = std::getenv("INET_CHAIN2_FWD"); return !(v && v[0] == '0'); }();   // (debug switch)
+    if (v2f && !a.h0_packed && gru_chain2_ok(a.H, a.B, a.T, a.nprob)) return launch_gru_chain2_fwd(a, s);
     if (!gru_chain_ok(a.H, a.B, a.T, a.nprob)) return -1;
     const int ms = rows_ms(a.B, a.H, a.nprob);
     a.tiles_per_prob = (a.B + 16 * ms - 1) / (16 * ms);
@@ -404,6 +406,8 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
 }
 
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
+    static const bool v2b = [] { const char* v = std::getenv("INET_CHAIN2_BWD"); return !(v && v[0] == '0'); }();   // (debug switch)
+    if (v2b && gru_chain2_ok(a.H, a.B, a.T, a.nprob)) return launch_gru_chain2_bwd(a, s);
     if (!gru_chain_bwd_ok(a.H, a.B, a.T, a.nprob)) return -1;
     const int ms = rows_ms_bwd(a.H, a.B, a.nprob);
     a.tiles_per_prob = (a.B + 16 * ms - 1) / (16 * ms);

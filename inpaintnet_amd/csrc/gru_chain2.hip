@@ -1,0 +1,547 @@
+// Chain kernels, second generation (round 3): the same persistent-launch protocol as gru_chain.hip (chain.h), with
+//   * one ROW BLOCK (16 batch rows) per wave over the whole K instead of one K quarter of four row blocks: no cross-wave
+//     reduction, no __syncthreads inside a step, the gates come straight out of the accumulators (C layout: 4 rows x 1 unit
+//     per lane); a "group" -- the unit of the hand-off -- is one row block x H/16 members, every wave polls the counter of
+//     its own row block;
+//   * the member's W_hh slice in LDS instead of registers, and
+//   * the contraction on the bf16 matrix cores AT FP32 ACCURACY: every fp32 operand is split exactly into three bf16 pieces,
+//     x = x0 + x1 + x2 (3 x 8 mantissa bits: nothing is lost), and a product a*b is the sum of the piece products a_i*b_j --
+//     each exact in the f32 accumulation --, accumulated in f32 by v_mfma_f32_16x16x32_bf16.  NP = 9: all nine terms, i.e. the
+//     products are exactly those of fp32 arithmetic and only the order of the f32 summation differs from the f32-input MFMA
+//     (itself different from any CPU's); NP = 6 drops the three terms below 2^-24 |ab| (a1*b2, a2*b1, a2*b2: less than the
+//     rounding of the f32 accumulation itself).  The bf16 MFMA issues 16x the MACs per cycle of the f32-input one, so the
+//     matrix phase of a step shrinks from 5.7 us to 3.2 (NP = 9) / 2.1 us (NP = 6): 9.5 -> 7.7 / 6.6 us per step
+//     (tools/exp_chain4.hip, profiles/r03_k_chain_bf16_split.txt).
+// The W slice is split once per launch (into LDS: 3 pieces x 48 KB at H = 512), a state element once by the wave that
+// produces it; the exchange carries the three pieces in the MFMA's A-fragment order (6 bytes per element instead of 4):
+//   piece p of a [rows, K] state: [row/16][K/32][lane = (k%32)/8 * 16 + row%16][8 bf16 = k%8]   (1 KB per fragment)
+// Semantics (operand sources, masks, saves, h0 / hlast / dh0, reverse, row chunks) are those of the first-generation kernels;
+// tests run both against the oracle (INET_CHAIN2=0 selects the first generation).
+#include <cstdio>
+#include <cstdlib>
+#include "chain.h"
+#include "prof.h"
+#include "gru_chain.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using chain::u32x4;
+
+__device__ __forceinline__ void split3(float x, __bf16& a0, __bf16& a1, __bf16& a2) {
+    a0 = (__bf16)x;                                  // round to nearest: |x - a0| <= 2^-9 |x|
+    const float r1 = x - (float)a0;                  // exact
+    a1 = (__bf16)r1;
+    a2 = (__bf16)(r1 - (float)a1);                   // exact, and fits 8 bits
+}
+
+// 8 consecutive floats -> the three pieces; store them at byte offset `off` of each piece (piece stride `pb`)
+__device__ __forceinline__ void publish8(__amdgpu_buffer_rsrc_t rs, int off, int pb, const float* src) {
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, c;
+        split3(src[j], a, b, c);
+        p0[j] = a; p1[j] = b; p2[j] = c;
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p0), rs, off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p1), rs, off + pb, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p2), rs, off + 2 * pb, 0, 16);
+}
+
+// acc[g] += A[row block, all K] x W_g^T for NG B-operands held as pieces in LDS: wl + ((p * NG + g) * S32 + s) * 1024
+template <int NG, int S32, int NP>
+__device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char* wl, __amdgpu_buffer_rsrc_t rs, int abase,
+                                          int base, int pb, int lane) {
+    constexpr int R = 4;
+    bf16x8 Ar[R][3];
+    auto ldA = [&](int s, int slot) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            Ar[slot][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, abase + s * 1024 + p * pb, base, 16));
+    };
+#pragma unroll
+    for (int d = 0; d < R - 1; ++d)
+        if (d < S32) ldA(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+    // Consecutive MFMAs never share an accumulator: with NG >= 3 operands the piece products are issued operand-innermost
+    // (distance NG between two updates of one accumulator); a single operand (the backward kernel) accumulates into three
+    // partial sums, product k of a block into partial k % 3 (432 back-to-back dependent MFMAs measured 216 us per
+    // 24-step launch against 187 for the forward kernel's three-gate form).
+    constexpr int NPART = NG >= 3 ? 1 : 3;
+    f32x4 part[NPART][NG];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) part[k][g] = k == 0 ? acc[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int PI[9] = {0, 0, 1, 0, 1, 2, 1, 2, 2}, PJ[9] = {0, 1, 0, 2, 1, 0, 2, 1, 2};   // largest terms first; 6: the first six
+#pragma unroll
+    for (int s = 0; s < S32; ++s) {
+        if (s + R - 1 < S32) ldA(s + R - 1, (s + R - 1) % R);
+        bf16x8 Bf[NG][3];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Bf[g][p] = *reinterpret_cast<const bf16x8*>(wl + ((p * NG + g) * S32 + s) * 1024 + lane * 16);
+        const bf16x8* a = Ar[s % R];
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                part[k % NPART][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PI[k]], Bf[g][PJ[k]], part[k % NPART][g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        acc[g] = part[0][g];
+#pragma unroll
+        for (int k = 1; k < NPART; ++k) acc[g] += part[k][g];
+    }
+}
+
+// bounded poll of one row block's counter by a whole wave (all lanes read the same word: one request)
+__device__ __forceinline__ bool wait_rows(unsigned* counter, unsigned target, chain::Status status, int lane) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > chain::kSpinLimit ||
+            ((spins & 63) == 0 && __hip_atomic_load(status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK)) {
+            if (lane == 0) chain::raise_timeout(status);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(INET_CHAIN_POLL_SLEEP);
+    }
+    return true;
+}
+
+__device__ __forceinline__ void arrive_rows(unsigned* counter, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through stores are out
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// forward:  h_t = GRUCell(gi_t, h_{t-1})
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WV, int S32, int NP>                   // WV waves (= row blocks) per workgroup; S32 = H / 32
+__global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) {
+    constexpr int H = 32 * S32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wl = smem;                             // [3 pieces][3 gates][S32][64][16 B]
+    float* const xt = reinterpret_cast<float*>(smem + 3 * 3 * S32 * 1024);   // [WV][256]
+    int group, member;
+    chain::decode_block(blockIdx.x, A.members, group, member);
+    if (group >= A.nprob * A.tiles_per_prob) return;
+    if (A.fault && blockIdx.x == 0) return;                    // injected fault (test hook)
+    if (A.prio) __builtin_amdgcn_s_setprio(3);
+    const int prob = group / A.tiles_per_prob, tile = group % A.tiles_per_prob;
+    const GruChainFwdProb& P = A.p[prob];
+    const int B = A.B, T = A.T;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int j0 = member * 16, jc = j0 + c;
+    const int nrb = (B + 15) >> 4;
+    const int rb = tile * WV + w;
+    // W slice -> three bf16 pieces in B-fragment order: fragment (g, s): lane (unit = lane % 16, k group = lane / 16) holds
+    // W[g*H + j0 + unit][32 s + 8 (lane / 16) + 0..7]
+    for (int i = t; i < 3 * S32 * 64; i += 64 * WV) {
+        const int ln = i & 63, s = (i >> 6) % S32, g = i / (64 * S32);
+        const float* src = P.W_hh + (long)(g * H + j0 + (ln & 15)) * H + 32 * s + 8 * (ln >> 4);
+        const f32x4 x0 = ld4u(src), x1 = ld4u(src + 4);
+        bf16x8 p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 a, b, cc;
+            split3(j < 4 ? x0[j & 3] : x1[j & 3], a, b, cc);
+            p0[j] = a; p1[j] = b; p2[j] = cc;
+        }
+        *reinterpret_cast<bf16x8*>(wl + ((0 * 3 + g) * S32 + s) * 1024 + ln * 16) = p0;
+        *reinterpret_cast<bf16x8*>(wl + ((1 * 3 + g) * S32 + s) * 1024 + ln * 16) = p1;
+        *reinterpret_cast<bf16x8*>(wl + ((2 * 3 + g) * S32 + s) * 1024 + ln * 16) = p2;
+    }
+    __syncthreads();
+    if (rb >= nrb) return;                                     // (a ragged last tile: this wave has no row block)
+    const int pb = nrb * 16 * H * 2;                           // bytes of one piece of the [B,H] state
+    const int slot_bytes = 3 * pb;
+    const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.hx);
+    unsigned* counter = A.counters + (prob * nrb + rb) * kChainCounterStride;
+    const chain::Status status = A.status;
+    float* myxt = xt + w * 256;
+    const int abase = (rb * S32 * 64 + lane) * 16;
+    // this wave's 16 columns inside a fragment: k block member / 2, k groups 2 (member % 2) + {0, 1}
+    const int pub_off = ((rb * S32 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
+    int brow[4];
+    float hp[4];
+    const bool has_h0 = P.h0 != nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        brow[r] = min(rb * 16 + 4 * q + r, B - 1);
+        hp[r] = has_h0 ? P.h0[(long)brow[r] * P.ld_h0 + jc] : 0.f;
+    }
+    const bool publish_h0 = has_h0 && !A.h0_packed;
+    if (publish_h0) {                                          // the initial state enters the exchange like any later one
+#pragma unroll
+        for (int r = 0; r < 4; ++r) myxt[(4 * q + r) * 16 + c] = hp[r];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) publish8(rs, slot_bytes + pub_off, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
+        __builtin_amdgcn_wave_barrier();
+        arrive_rows(counter, lane);
+    }
+    const int arrivals0 = publish_h0 ? 1 : 0;
+    float bh[3], bv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = P.b_hh[g * H + jc];
+    if (P.gi_vec) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bv[g] = P.gi_vec[g * H + jc];
+    }
+    // operand sources in registers, absent ones aimed at a zero word (gru_chain.hip)
+    const float* const zf = reinterpret_cast<const float*>(A.counters + kChainZeroWord);
+    const bool has_tab = P.gi_table != nullptr, has_den = P.gi_dense != nullptr, has_mask = P.outm && P.mask;
+    const long long* const idxp = has_tab ? P.idx : reinterpret_cast<const long long*>(zf);
+    const int idx_bs = has_tab ? (int)P.idx_bs : 0, idx_ts = has_tab ? (int)P.idx_ts : 0;
+    const float* const tabp = has_tab ? P.gi_table : zf;
+    const int tab_ld = has_tab ? (int)P.ld_table : 0, tab_g = has_tab ? H : 0, tab_j = has_tab ? jc : 0;
+    const float* const denp = has_den ? P.gi_dense : zf;
+    const int den_ld = has_den ? (int)P.ld_gi : 0, den_ts = has_den ? (int)P.ts_gi : 0, den_g = has_den ? H : 0, den_j = has_den ? jc : 0;
+    const float* const mskp = has_mask ? P.mask : zf;
+    const int msk_ld = has_mask ? (int)P.ld_mask : 0, msk_ts = has_mask ? (int)P.ts_mask : 0, msk_j = has_mask ? jc : 0;
+    float* const outp = P.out; const int out_ld = (int)P.ld_out, out_ts = (int)P.ts_out;
+    float* const outmp = P.outm; const int outm_ld = (int)P.ld_outm, outm_ts = (int)P.ts_outm;
+    float* const svp = P.sv; const int sv_as = (int)P.sv_astride, sv_ts = P.sv_ts ? (int)P.sv_ts : B * H;
+    float* const hlastp = P.hlast; const int hlast_ld = (int)P.ld_hlast;
+    const int rev = P.reverse, members = A.members;
+    long tok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tok[r] = idxp[brow[r] * idx_bs + (rev ? T - 1 : 0) * idx_ts];
+    for (int step = 0; step < T; ++step) {
+        const int tt = rev ? T - 1 - step : step;
+        const int tn = step + 1 < T ? (rev ? tt - 1 : tt + 1) : tt;
+        float pgt[4][3], pgd[4][3], pm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = brow[r];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pgt[r][g] = tabp[(int)tok[r] * tab_ld + g * tab_g + tab_j];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pgd[r][g] = denp[tt * den_ts + b * den_ld + g * den_g + den_j];
+            pm[r] = mskp[tt * msk_ts + b * msk_ld + msk_j];
+            tok[r] = idxp[b * idx_bs + tn * idx_ts];
+        }
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step > 0 || has_h0) {
+            if ((step > 0 || publish_h0) && !wait_rows(counter, (unsigned)((step + arrivals0) * members), status, lane)) return;
+            contract2<3, S32, NP>(acc, wl, rs, abase, ((step + 1) & 1) * slot_bytes, pb, lane);
+        }
+        float er[4], ez[4], en[4], eg[4], eh[4], ehp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ghn = acc[2][r] + bh[2];
+            const float rr = sigmoid_f(acc[0][r] + pgd[r][0] + pgt[r][0] + bv[0] + bh[0]);
+            const float z = sigmoid_f(acc[1][r] + pgd[r][1] + pgt[r][1] + bv[1] + bh[1]);
+            const float n = tanh_f(pgd[r][2] + pgt[r][2] + bv[2] + rr * ghn);
+            const float hprev = hp[r];
+            const float hn = (1.f - z) * n + z * hprev;
+            hp[r] = hn;
+            myxt[(4 * q + r) * 16 + c] = hn;
+            er[r] = rr; ez[r] = z; en[r] = n; eg[r] = ghn; eh[r] = hn; ehp[r] = hprev;
+        }
+        if (step != T - 1) {                                   // nobody reads the last state from the exchange
+            __builtin_amdgcn_wave_barrier();                   // (the tile is exchanged between lanes: see the backward kernel)
+            if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
+            __builtin_amdgcn_wave_barrier();
+            arrive_rows(counter, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = rb * 16 + 4 * q + r;
+            if (b < B) {
+                outp[tt * out_ts + b * out_ld + jc] = eh[r];
+                if (outmp) outmp[tt * outm_ts + b * outm_ld + jc] = has_mask ? eh[r] * pm[r] : eh[r];
+                if (hlastp && step == T - 1) hlastp[b * hlast_ld + jc] = eh[r];
+                if (svp) {
+                    float* sp = svp + tt * sv_ts + b * H + jc;
+                    sp[0] = er[r]; sp[sv_as] = ez[r]; sp[2 * sv_as] = en[r]; sp[3 * sv_as] = eg[r]; sp[4 * sv_as] = ehp[r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// backward:  dh_t = dgh_{t+1} W_hh + dh_{t+1} z_{t+1} + dout_t ; gate derivatives; the exchange carries dgh (K = 3H)
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WV, int S32, int NP>                   // S32 = 3H / 32 k blocks of the exchange
+__global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) {
+    constexpr int H = 32 * S32 / 3, SH = H / 32;     // SH: k blocks per gate
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wl = smem;                             // [3 pieces][S32][64][16 B]: W_hh^T columns j0..j0+15
+    float* const xt = reinterpret_cast<float*>(smem + 3 * S32 * 1024);   // [WV][256]: one transpose tile per wave
+    int group, member;
+    chain::decode_block(blockIdx.x, A.members, group, member);
+    if (group >= A.nprob * A.tiles_per_prob) return;
+    if (A.prio) __builtin_amdgcn_s_setprio(3);
+    const int prob = group / A.tiles_per_prob, tile = group % A.tiles_per_prob;
+    const GruChainBwdProb& P = A.p[prob];
+    const int B = A.B, T = A.T;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int j0 = member * 16, jc = j0 + c;
+    const int nrb = (B + 15) >> 4;
+    const int rb = tile * WV + w;
+    // B operand = W_hh^T: fragment s: lane (unit = lane % 16, k group = lane / 16) holds W_hh[32 s + 8 (lane / 16) + i][j0 + unit]
+    for (int i = t; i < S32 * 64; i += 64 * WV) {
+        const int ln = i & 63, s = i >> 6;
+        const float* src = P.W_hh + (long)(32 * s + 8 * (ln >> 4)) * H + j0 + (ln & 15);
+        bf16x8 p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 a, b, cc;
+            split3(src[(long)j * H], a, b, cc);
+            p0[j] = a; p1[j] = b; p2[j] = cc;
+        }
+        *reinterpret_cast<bf16x8*>(wl + (0 * S32 + s) * 1024 + ln * 16) = p0;
+        *reinterpret_cast<bf16x8*>(wl + (1 * S32 + s) * 1024 + ln * 16) = p1;
+        *reinterpret_cast<bf16x8*>(wl + (2 * S32 + s) * 1024 + ln * 16) = p2;
+    }
+    __syncthreads();
+    if (rb >= nrb) return;
+    const int pb = nrb * 16 * 3 * H * 2;                       // bytes of one piece of the [B,3H] exchange
+    const int slot_bytes = 3 * pb;
+    const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.gx);
+    unsigned* counter = A.counters + (prob * nrb + rb) * kChainCounterStride;
+    const chain::Status status = A.status;
+    float* myxt = xt + w * 256;
+    const int abase = (rb * S32 * 64 + lane) * 16;
+    // gate g's 16 columns of this member: k block g * SH + member / 2
+    const int pub_off = ((rb * S32 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
+    int brow[4];
+    float dhz[4], bs[4] = {0.f, 0.f, 0.f, 0.f}, gs[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        brow[r] = min(rb * 16 + 4 * q + r, B - 1);
+        dhz[r] = 0.f;
+        gs[r][0] = gs[r][1] = gs[r][2] = 0.f;
+    }
+    const float* const zf = reinterpret_cast<const float*>(A.counters + kChainZeroWord);
+    const bool has_dout = P.dout != nullptr, has_dhn = P.dhn != nullptr;
+    const float* const doutp = has_dout ? P.dout : zf;
+    const int dout_ld = has_dout ? (int)P.ld_dout : 0, dout_ts = has_dout ? (int)P.ts_dout : 0, dout_j = has_dout ? jc : 0;
+    const float* const dhnp = has_dhn ? P.dhn : zf;
+    const int dhn_ld = has_dhn ? (int)P.ld_dhn : 0, dhn_j = has_dhn ? jc : 0;
+    const float* const svp = P.sv; const int sv_as = (int)P.sv_astride, sv_ts = P.sv_ts ? (int)P.sv_ts : B * H;
+    float* const dgip = P.dgi; const int dgi_ld = (int)P.ld_dgi, dgi_ts = (int)P.ts_dgi;
+    float* const dghp = P.dgh; const int dgh_ts = P.dgh_ts ? (int)P.dgh_ts : B * 3 * H;
+    float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
+    const int rev = P.reverse, members = A.members;
+    for (int step = T - 1; step >= -1; --step) {
+        const bool tail = step < 0;                            // dh0 = dgh(first step) W_hh + dhz
+        if (tail && !dh0p) break;
+        const int tt = tail ? 0 : (rev ? T - 1 - step : step);
+        float pd[4], psv[4][5];
+        if (!tail) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = brow[r];
+                const float d1 = doutp[tt * dout_ts + b * dout_ld + dout_j];
+                const float d2 = dhnp[b * dhn_ld + dhn_j];
+                const float* sp = svp + tt * sv_ts + b * H + jc;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) psv[r][a] = sp[a * sv_as];
+                pd[r] = step == T - 1 ? d1 + d2 : d1;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pd[r] = dh0_acc ? dh0p[brow[r] * dh0_ld + jc] : 0.f;
+        }
+        f32x4 acc[1];
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step != T - 1) {
+            if (!wait_rows(counter, (unsigned)((T - 1 - step) * members), status, lane)) return;
+            contract2<1, S32, NP>(acc, wl, rs, abase, ((step + 1) & 1) * slot_bytes, pb, lane);
+        }
+        if (tail) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = rb * 16 + 4 * q + r;
+                if (b < B) dh0p[b * dh0_ld + jc] = acc[0][r] + dhz[r] + pd[r];
+            }
+            break;
+        }
+        float e_r[4], e_z[4], e_n[4], e_nr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dh = acc[0][r] + dhz[r] + pd[r];
+            const float rr = psv[r][0], z = psv[r][1], n = psv[r][2], ghn = psv[r][3], hprev = psv[r][4];
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hprev - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * ghn * rr * (1.f - rr);
+            const float dnr = dn_pre * rr;
+            dhz[r] = dh * z;
+            e_r[r] = dr_pre; e_z[r] = dz_pre; e_n[r] = dn_pre; e_nr[r] = dnr;
+        }
+        if (step != 0 || dh0p) {                               // (nothing reads the last gate gradients unless dh0 is wanted)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {                      // gate by gate through the wave's transpose tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r) myxt[(4 * q + r) * 16 + c] = g == 0 ? e_r[r] : (g == 1 ? e_z[r] : e_nr[r]);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32)
+                    publish8(rs, (step & 1) * slot_bytes + pub_off + g * SH * 1024, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
+                // The tile is exchanged BETWEEN lanes: lanes 32..63 must not run ahead into the next gate's writes while
+                // lanes 0..31 still have this gate's reads in front of them.  The compiler reasons per thread and did exactly
+                // that (it hoisted the next tile's writes of the upper half-wave over the branch); the convergent wave barrier
+                // pins the order for the whole wave (the LDS itself executes one wave's operations in issue order).
+                __builtin_amdgcn_wave_barrier();
+            }
+            arrive_rows(counter, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = rb * 16 + 4 * q + r;
+            if (b < B) {
+                float* gi = dgip + tt * dgi_ts + b * dgi_ld;
+                gi[jc] = e_r[r]; gi[H + jc] = e_z[r]; gi[2 * H + jc] = e_n[r];
+                float* gh = dghp + tt * dgh_ts + b * 3 * H;
+                gh[jc] = e_r[r]; gh[H + jc] = e_z[r]; gh[2 * H + jc] = e_nr[r];
+                bs[0] += e_r[r]; bs[1] += e_z[r]; bs[2] += e_n[r]; bs[3] += e_nr[r];
+                gs[r][0] += e_r[r]; gs[r][1] += e_z[r]; gs[r][2] += e_n[r];
+            }
+        }
+    }
+    if (P.dgi_sum) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = rb * 16 + 4 * q + r;
+            if (b < B) {
+                float* o = P.dgi_sum + (long)b * 3 * H + jc;
+                o[0] = gs[r][0]; o[H] = gs[r][1]; o[2 * H] = gs[r][2];
+            }
+        }
+    }
+    if (P.db_ih) {                                             // column sums of this wave's 16 rows: over the four row groups
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bs[a] += __shfl_xor(bs[a], 16, 64);
+            bs[a] += __shfl_xor(bs[a], 32, 64);
+        }
+        if (lane < 16) {
+            unsafeAtomicAdd(P.db_ih + jc, bs[0]); unsafeAtomicAdd(P.db_hh + jc, bs[0]);
+            unsafeAtomicAdd(P.db_ih + H + jc, bs[1]); unsafeAtomicAdd(P.db_hh + H + jc, bs[1]);
+            unsafeAtomicAdd(P.db_ih + 2 * H + jc, bs[2]);
+            unsafeAtomicAdd(P.db_hh + 2 * H + jc, bs[3]);
+        }
+    }
+}
+
+int g_chain2 = -1;   // piece products per fp32 product: 0 = first-generation kernels, 6 or 9
+
+}  // namespace
+
+int chain2_mode() {
+    if (g_chain2 < 0) {
+        const char* e = std::getenv("INET_CHAIN2");
+        const int v = e ? std::atoi(e) : 9;
+        g_chain2 = (v == 6 || v == 9) ? v : 0;
+    }
+    return g_chain2;
+}
+void chain2_set_mode(int np) { g_chain2 = (np == 6 || np == 9) ? np : 0; }
+
+// waves per workgroup (4 or 8) with which the launch fits the chip and the sync area, or 0
+static int chain2_waves(int H, int B, int T, int nprob) {
+    // (T >= 6: a launch first splits its 96 KB W slice into 144 KB of bf16 pieces in LDS; over the beat GRU's four steps that
+    //  costs more than the faster steps give back: 31 -> 43 us per launch)
+    if (!chain_enabled() || chain2_mode() == 0 || (H != 256 && H != 512) || T < 6 || nprob < 1 || nprob > 4 || B < 1) return 0;
+    if ((double)T * B * 6.0 * H >= 2.0e9) return 0;
+    const int nrb = (B + 15) / 16;
+    if (nprob * nrb > kChainMaxGroups) return 0;               // one counter per (problem, row block)
+    // Four waves per workgroup (one per SIMD).  Eight -- two row blocks per SIMD -- fit the decoder's four-beat tick BPTT into
+    // one launch, but two waves of a SIMD do not overlap (tools/exp_chain3.hip WAVES_=8) and that launch measured 128 us against
+    // 127 for the first generation's two-tiles-per-workgroup form: INET_CHAIN2_W8=1 enables it, the default leaves those shapes
+    // to the first generation.
+    static const bool w8 = [] { const char* v = std::getenv("INET_CHAIN2_W8"); return v && v[0] == '1'; }();
+    for (int wv = 4; wv <= (w8 ? 8 : 4); wv *= 2)
+        if (nprob * ((nrb + wv - 1) / wv) * (H / 16) <= chain_capacity()) return wv;
+    return 0;
+}
+bool gru_chain2_ok(int H, int B, int T, int nprob) { return chain2_waves(H, B, T, nprob) > 0; }
+
+int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
+    const int wv = chain2_waves(a.H, a.B, a.T, a.nprob);
+    if (!wv) return -1;
+    const int nrb = (a.B + 15) / 16;
+    a.tiles_per_prob = (nrb + wv - 1) / wv;
+    a.members = a.H / 16;
+    const int groups = a.nprob * a.tiles_per_prob;
+    a.prio = 1;
+    a.fault = chain_take_fault();
+    if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    a.status = chain_status_for(a.counters + kChainStatusWord);
+    const int np = chain2_mode();
+    char label[72];
+    std::snprintf(label, sizeof label, "gru_chain_fwd v2w%d p%d np%d T%d B%d H%d", wv, np, a.nprob, a.T, a.B, a.H);
+    const double rows = (double)a.nprob * a.T * a.B;
+    ProfScope prof(PROF_GRU_FWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
+                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))));
+    const dim3 grid(chain::blocks_for(groups, a.members));
+    const size_t lds = (size_t)3 * 3 * (a.H / 32) * 1024 + (size_t)wv * 256 * 4;
+#define INET_C2F(W, S, N)                                                                                               \
+    do {                                                                                                                \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_chain2_fwd_kernel<W, S, N>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((gru_chain2_fwd_kernel<W, S, N>), grid, dim3(64 * W), lds, s, a);                            \
+    } while (0)
+    if (a.H == 512) {
+        if (wv == 4) { if (np == 9) INET_C2F(4, 16, 9); else INET_C2F(4, 16, 6); }
+        else { if (np == 9) INET_C2F(8, 16, 9); else INET_C2F(8, 16, 6); }
+    } else {
+        if (wv == 4) { if (np == 9) INET_C2F(4, 8, 9); else INET_C2F(4, 8, 6); }
+        else { if (np == 9) INET_C2F(8, 8, 9); else INET_C2F(8, 8, 6); }
+    }
+#undef INET_C2F
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s) {
+    const int wv = chain2_waves(a.H, a.B, a.T, a.nprob);
+    if (!wv) return -1;
+    const int nrb = (a.B + 15) / 16;
+    a.tiles_per_prob = (nrb + wv - 1) / wv;
+    a.members = a.H / 16;
+    const int groups = a.nprob * a.tiles_per_prob;
+    a.prio = 1;
+    if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
+    a.status = chain_status_for(a.counters + kChainStatusWord);
+    const int np = chain2_mode();
+    char label[72];
+    std::snprintf(label, sizeof label, "gru_chain_bwd v2w%d p%d np%d T%d B%d H%d", wv, np, a.nprob, a.T, a.B, a.H);
+    const double rows = (double)a.nprob * a.T * a.B;
+    ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
+                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)));
+    const dim3 grid(chain::blocks_for(groups, a.members));
+    const size_t lds = (size_t)3 * (3 * a.H / 32) * 1024 + (size_t)wv * 256 * 4;
+#define INET_C2B(W, S, N)                                                                                               \
+    do {                                                                                                                \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_chain2_bwd_kernel<W, S, N>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((gru_chain2_bwd_kernel<W, S, N>), grid, dim3(64 * W), lds, s, a);                            \
+    } while (0)
+    if (a.H == 512) {
+        if (wv == 4) { if (np == 9) INET_C2B(4, 48, 9); else INET_C2B(4, 48, 6); }
+        else { if (np == 9) INET_C2B(8, 48, 9); else INET_C2B(8, 48, 6); }
+    } else {
+        if (wv == 4) { if (np == 9) INET_C2B(4, 24, 9); else INET_C2B(4, 24, 6); }
+        else { if (np == 9) INET_C2B(8, 24, 9); else INET_C2B(8, 24, 6); }
+    }
+#undef INET_C2B
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -67,6 +67,9 @@ struct DirBwd {
 // floats of a fragment-major [rows,K] operand (rows padded to 16)
 inline size_t pk_floats(int rows, int K) { return (size_t)((rows + 15) / 16) * 16 * (size_t)K; }
 inline bool pk_ok(int H) { return H % 256 == 0; }
+// floats of a chain kernel's exchange ring over a [rows, K] state: two slots of fp32 fragments (first generation) or two slots
+// of three bf16 pieces (second generation: 12 bytes per element) -- sized for the larger
+inline size_t chain_ring_floats(int rows, int K) { return 3 * pk_floats(rows, K); }
 
 // rows per chain launch for a batch of B rows (B itself when one launch holds it; 0: no chain kernel applies)
 int chain_chunk_rows(int H, int B, int T, int nd, int save = 1);

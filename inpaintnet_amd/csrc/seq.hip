@@ -51,7 +51,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
         // by the kernel itself; a null h0 = zeros)
         GruChainFwd a{};
         a.H = H; a.B = B; a.T = T; a.nprob = nd;
-        if (h0pack && all_h0) { INET_TRY(pack_h0()); a.h0_packed = 1; }
+        if (h0pack && all_h0 && !gru_chain2_ok(H, B, T, nd)) { INET_TRY(pack_h0()); a.h0_packed = 1; }
         for (int i = 0; i < nd; ++i) {
             const DirFwd& D = d[i];
             GruChainFwdProb& P = a.p[i];
@@ -85,7 +85,10 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
         // odd chunks count on different sync areas (the caller's and the one behind it).
         static const bool twin = [] { const char* v = std::getenv("INET_CHUNK_TWIN"); return !(v && v[0] == '0'); }();
         const long pkc = (long)pk_floats(CH, H);
-        hipStream_t s2 = twin ? twin_fork(s) : s;
+        // (the second-generation kernel keeps its W slice in 144 KB of LDS: one workgroup per CU, nothing to gain from two
+        // streams; every chunk gets its own contiguous ring of three-piece slots)
+        const bool v2 = gru_chain2_ok(H, CH, T, nd);
+        hipStream_t s2 = twin && !v2 ? twin_fork(s) : s;
         for (int c = 0; c < B / CH; ++c) {
             const long r0 = (long)c * CH;
             GruChainFwd a{};
@@ -105,7 +108,9 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
                 P.mask = D.mask ? D.mask + r0 * D.mask_ld : nullptr; P.ld_mask = D.mask_ld; P.ts_mask = D.mask_ts;
                 P.hlast = D.hlast ? D.hlast + r0 * D.hlast_ld : nullptr; P.ld_hlast = D.hlast_ld;
                 if (D.sv) { P.sv = D.sv + r0 * H; P.sv_astride = D.sv_astride; P.sv_ts = BH; }
-                P.hx = D.hpk + (long)c * pkc; P.hx_slot_bytes = (int)(pkh * sizeof(float)); P.reverse = D.reverse;
+                if (v2) P.hx = D.hpk + (long)c * 3 * pkc;
+                else { P.hx = D.hpk + (long)c * pkc; P.hx_slot_bytes = (int)(pkh * sizeof(float)); }
+                P.reverse = D.reverse;
             }
             a.counters = d[0].sync + (c & 1) * kChainSyncWords;
             INET_TRY(launch_gru_chain_fwd(a, (c & 1) ? s2 : s));
@@ -173,6 +178,7 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
             // one persistent launch -- or, for a batch beyond one resident launch, one launch per chunk of CHB rows (the rows
             // are independent; saves / dgh keep the full batch's time stride; bias gradients accumulate with atomics)
             const long pkc = (long)pk_floats(CHB, 3 * H);
+            const bool v2b = gru_chain2_ok(H, CHB, T, nd);
             for (int c = 0; c < B / CHB; ++c) {
                 const long r0 = (long)c * CHB;
                 GruChainBwd a{};
@@ -188,7 +194,9 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
                     P.dgh = D.dgh + r0 * 3 * H; P.dgh_ts = B3H;
                     P.db_ih = D.db_ih; P.db_hh = D.db_hh;
                     P.dh0 = D.dh0 ? D.dh0 + r0 * D.dh0_ld : nullptr; P.ld_dh0 = D.dh0_ld; P.dh0_accumulate = D.dh0_acc;
-                    P.gx = D.dghpk + (long)c * pkc; P.gx_slot_bytes = (int)(pkg * sizeof(float)); P.reverse = D.reverse;
+                    if (v2b) P.gx = D.dghpk + (long)c * 3 * pkc;
+                    else { P.gx = D.dghpk + (long)c * pkc; P.gx_slot_bytes = (int)(pkg * sizeof(float)); }
+                    P.reverse = D.reverse;
                     P.dgi_sum = D.dgi_sum ? D.dgi_sum + r0 * 3 * H : nullptr;
                 }
                 a.counters = d[0].sync; a.prezeroed = (c == 0 && CHB == B) ? d[0].sync_prezeroed : 0;
@@ -280,9 +288,9 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
     for (int i = 0; i < 4; ++i) {
         const bool pk = pk_ok(H);
         w.wpk[i] = pk ? c.take<float>((size_t)3 * H * H) : nullptr;
-        w.hpk[i] = pk ? c.take<float>(2 * pk_floats(B, H)) : nullptr;
+        w.hpk[i] = pk ? c.take<float>(chain_ring_floats(B, H)) : nullptr;
         w.wpkT[i] = pk && save ? c.take<float>((size_t)3 * H * H) : nullptr;
-        w.dghpk[i] = pk && save ? c.take<float>(2 * pk_floats(B, 3 * H)) : nullptr;
+        w.dghpk[i] = pk && save ? c.take<float>(chain_ring_floats(B, 3 * H)) : nullptr;
     }
     w.sync = c.take<unsigned>(kSyncAreas * kChainSyncWords);
     return c.bytes();

@@ -240,13 +240,13 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.wpk_t1hh = pk ? cv.take<float>(W3) : nullptr;
     w.wpk_t1ih = pk ? cv.take<float>(W3) : nullptr;
     w.wpk_out = pk && V % 16 == 0 ? cv.take<float>(V * H) : nullptr;
-    w.hpk_b = pk ? cv.take<float>(2 * pkh) : nullptr;
+    w.hpk_b = pk ? cv.take<float>(chain_ring_floats(B, (int)H)) : nullptr;
     w.ht0pk = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
-    w.hpk_t0 = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
-    w.hpk_t1 = pk ? cv.take<float>(2 * nb * pkh) : nullptr;
+    w.hpk_t0 = pk ? cv.take<float>(nb * chain_ring_floats(B, (int)H)) : nullptr;   // per beat: a chain ring (3 pkh) or two fp32 slots
+    w.hpk_t1 = pk ? cv.take<float>(nb * chain_ring_floats(B, (int)H)) : nullptr;
     w.hm0pk = pk ? cv.take<float>(nb * pkh) : nullptr;
     for (int i = 0; i < 4; ++i) w.wpkT[i] = pk && save ? cv.take<float>(W3) : nullptr;
-    w.dghpk = pk && save ? cv.take<float>(2 * nb * pk_floats(B, 3 * (int)H)) : nullptr;
+    w.dghpk = pk && save ? cv.take<float>(nb * chain_ring_floats(B, 3 * (int)H)) : nullptr;
     w.amax = cv.take<float>(2 * 2 * ((V + 15) / 16) * ((B + 15) / 16) * 16);
     static_assert(kDecodeSyncWords <= kChainSyncWords, "one sync area serves either kind of chain launch");
     w.sync = cv.take<unsigned>(kSyncAreas * kChainSyncWords);
@@ -412,12 +412,12 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
                             D.mask = mask_tick + (long)i * G * BH; D.mask_ld = H; D.mask_ts = BH;
                         }
                         if (save) { D.sv = w.svt0 + (long)i * G * BH; D.sv_astride = (long)T * BH; }
-                        D.Wpk_hh = w.wpk_t0; D.hpk = w.hpk_t0 + (long)i * 2 * pkh;
+                        D.Wpk_hh = w.wpk_t0; D.hpk = w.hpk_t0 + (long)i * 3 * pkh;
                     } else {
                         D.gi = w.gi1t + (long)i * G * 3 * BH; D.gi_ld = 3L * H; D.gi_ts = 3 * BH;
                         D.out = w.h1seq + (long)i * G * BH;
                         if (save) { D.sv = w.svt1 + (long)i * G * BH; D.sv_astride = (long)T * BH; }
-                        D.Wpk_hh = w.wpk_t1hh; D.hpk = w.hpk_t1 + (long)i * 2 * pkh;
+                        D.Wpk_hh = w.wpk_t1hh; D.hpk = w.hpk_t1 + (long)i * 3 * pkh;
                     }
                 }
                 dd[0].sync = w.sync + (long)(2 + layer * (nb / npl) + i0 / npl) * kChainSyncWords;
@@ -604,7 +604,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         D.dhz = w.dhz + (long)i * 2 * BH;
         if (g) { D.db_ih = g + L.tick[1].b_ih; D.db_hh = g + L.tick[1].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H + H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
-        D.Wpk_hhT = w.wpkT[3]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
+        D.Wpk_hhT = w.wpkT[3]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 3 * pkg : nullptr;
         if (ticks_chained) { D.W_hh = p + L.tick[1].w_hh; D.sync = w.sync; D.sync_prezeroed = 1; }   // 4 beats = 4 problems, 2 row tiles per workgroup
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
@@ -632,7 +632,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         D.dhz = w.dhz + (long)i * 2 * BH;
         if (g) { D.db_ih = g + L.tick[0].b_ih; D.db_hh = g + L.tick[0].b_hh; }
         D.dh0 = w.dht0 + (long)i * B * 2 * H; D.dh0_ld = 2L * H; D.dh0_acc = 0;
-        D.Wpk_hhT = w.wpkT[2]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 2 * pkg : nullptr;
+        D.Wpk_hhT = w.wpkT[2]; D.dghpk = w.dghpk ? w.dghpk + (long)i * 3 * pkg : nullptr;
         if (ticks_chained) { D.W_hh = p + L.tick[0].w_hh; D.sync = w.sync + kChainSyncWords; D.sync_prezeroed = 1; }
         D.dgi_sum = w.dcgi + (long)i * 3 * BH; D.dgi_sum_done = &dcgi_done;     // beat-constant input half, see below
     }

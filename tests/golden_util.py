@@ -84,3 +84,10 @@ def arnn_params(name, fx=None):
 def latent_params_from_fixture(fx, prefix="param/"):
     """state_dict of a fixture that stores its full weights (small configs)."""
     return {k[len(prefix):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(prefix)}
+
+
+def is_chain(label, kind, nprob, T, B, H=512):
+    """A chain-kernel profile label of either generation: 'gru_chain_fwd ms4 np2 T24 B256 H512' (first: csrc/gru_chain.hip; 'ms4x2'
+    = the build for two launches per CU) or 'gru_chain_fwd v2w4 p9 np2 T24 B256 H512' (second: csrc/gru_chain2.hip, waves per
+    workgroup and piece products)."""
+    return label.startswith(f"gru_chain_{kind} ") and label.endswith(f" np{nprob} T{T} B{B} H{H}")

@@ -28,6 +28,9 @@ def bench():
     ("gru_chain_fwd ms4 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 1>|g65536"),
     ("gru_chain_fwd ms4x2 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 2>|g65536"),         # two launches per CU
     ("gru_chain_bwd ms8 np4 T6 B256 H512", "gru_chain_bwd_kernel<8, 24>|g65536"),
+    ("gru_chain_fwd v2w4 p9 np2 T24 B256 H512", "gru_chain2_fwd_kernel<4, 16, 9>|g65536"),      # second generation
+    ("gru_chain_bwd v2w4 p6 np2 T24 B256 H512", "gru_chain2_bwd_kernel<4, 48, 6>|g65536"),
+    ("gru_chain_fwd v2w4 p9 np2 T6 B128 H256", "gru_chain2_fwd_kernel<4, 8, 9>|g32768"),
     ("gru_chain_bwd ms2 np2 T6 B128 H512", "gru_chain_bwd_kernel<2, 24>|g65536"),
     ("adam", "adam_kernel|"),
 ])

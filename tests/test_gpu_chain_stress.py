@@ -92,7 +92,7 @@ def test_chunked_chain_forward_for_large_batches():
                 ops.prof_enable(False)
                 labels = [l.split(",")[1] for l in open("/tmp/_inet_chunk.csv").read().strip().splitlines()[1:]]
                 if chain:
-                    assert sum(l.startswith("gru_chain_fwd ms4x2 np2 T24 B256") for l in labels) == 2 * (B // 256), labels[:6]   # x2: two chunks share the chip
+                    assert sum(G.is_chain(l, "fwd", 2, 24, 256) for l in labels) == 2 * (B // 256), labels[:6]   # x2: two chunks share the chip
                 res.append((mu, ls))
             assert _rel(res[0][0], res[1][0]) < 2e-5 and _rel(res[0][1], res[1][1]) < 2e-5, B
     finally:

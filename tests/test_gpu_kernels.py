@@ -521,13 +521,19 @@ def test_adam_kernel_matches_torch():
 @pytest.mark.parametrize("B,T,K,H,scalar", [(3, 5, 8, 16, False), (4, 4, 1, 32, True), (6, 6, 24, 48, False),
                                             # H % 256 == 0: the fragment-major operand path of the step kernels, with
                                             # ragged batches (last 16-row block partly filled, several row tiles)
-                                            (37, 3, 8, 256, False), (70, 2, 1, 256, True), (133, 2, 4, 512, False)])
+                                            (37, 3, 8, 256, False), (70, 2, 1, 256, True), (133, 2, 4, 512, False),
+                                            # T >= 6: the second-generation chain kernels (csrc/gru_chain2.hip), ragged batches
+                                            (37, 7, 8, 256, False), (133, 6, 4, 512, False)])
 def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
     from inpaintnet_amd import layout
     g = torch.Generator().manual_seed(B * 100 + T * 10 + K)
     shapes = layout._gru("g", K, H, 2, True)
     offs, total = layout.arena_offsets(dict(shapes))
-    P = {k: (torch.randn(*s, generator=g) * (0.3 if "weight" in k else 0.1)) for k, s in shapes}
+    # (long sequences of wide layers: weights scaled so that the recurrence is not chaotic -- at std 0.3 and H = 512 six
+    #  steps amplify one ulp to 1e-3 and two correct fp32 evaluations, this kernel and the CPU oracle alike, differ from a
+    #  float64 one and from each other by that much: tools/dbg2.py)
+    wstd = 0.3 if T < 6 else 1.0 / np.sqrt(H)
+    P = {k: (torch.randn(*s, generator=g) * (wstd if "weight" in k else 0.1)) for k, s in shapes}
     flat = torch.zeros(total)
     for k, (off, s) in offs.items():
         flat[off:off + P[k].numel()] = P[k].reshape(-1)
@@ -565,6 +571,67 @@ def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
         if not err < 5e-4:
             bad.append((k, err))
     assert not bad, bad
+
+
+def test_chain_generations_against_float64():
+    """The three forms of the recurrent contraction against a float64 evaluation of the same two-layer bi-GRU (forward and
+    backward, 12 steps, H = 512): first generation (f32-input MFMA), second generation with all nine bf16 piece products (the
+    products of fp32 arithmetic; only the f32 summation order differs) and with six (terms below 2^-24 |ab| dropped).  The
+    second generation must be as close to float64 as the first: its error may not exceed twice the first's (nine products) /
+    four times (six), on every output."""
+    import csv
+    import tempfile
+    from inpaintnet_amd import layout
+    B, T, K, H = 96, 12, 16, 512
+    g = torch.Generator().manual_seed(77)
+    shapes = layout._gru("g", K, H, 2, True)
+    offs, total = layout.arena_offsets(dict(shapes))
+    P = {k: (torch.randn(*s, generator=g) * (0.06 if "weight_hh" in k else (0.1 if "weight" in k else 0.05))) for k, s in shapes}
+    flat = torch.zeros(total)
+    for k, (off, s) in offs.items():
+        flat[off:off + P[k].numel()] = P[k].reshape(-1)
+    flat = flat.to(DEV)
+    x = torch.randn(B, T, K, generator=g)
+    wo = torch.randn(B, T, 2 * H, generator=g)
+    wh = torch.randn(4, B, H, generator=g)
+    P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    x64 = x.double().requires_grad_(True)
+    out, hn = O.gru_stack(x64, torch.zeros(4, B, H, dtype=torch.float64), P64, "g", 2, True, None)
+    ((out * wo.double()).sum() + (hn * wh.double()).sum()).backward()
+    ref = {"out": out.detach(), "hn": hn.detach(), "dx": x64.grad}
+    for k in P:
+        ref["d" + k] = P64[k].grad
+    errs = {}
+    try:
+        for mode in (0, 9, 6):
+            ops.set_option(7, mode)
+            ops.prof_enable(True)
+            o, h, ws = ops.bigru2_fwd(x.to(DEV), None, flat, H, B, T, K, save=True)
+            grads = torch.zeros_like(flat)
+            dx, _ = ops.bigru2_bwd(x.to(DEV), None, flat, grads, H, B, T, K, None, wo.to(DEV), wh.to(DEV), ws, want_dx=True)
+            ops.side_join()
+            torch.cuda.synchronize()
+            with tempfile.TemporaryDirectory() as td:
+                ops.prof_dump(td + "/l.csv")
+                labels = [r["label"] for r in csv.DictReader(open(td + "/l.csv"))]
+            ops.prof_enable(False)
+            tag = "gru_chain_fwd ms" if mode == 0 else f"gru_chain_fwd v2w4 p{mode}"
+            assert any(l.startswith(tag) for l in labels), (mode, sorted(set(l for l in labels if l.startswith("gru"))))
+            got = {"out": o.cpu(), "hn": h.cpu(), "dx": dx.cpu()}
+            for k, (off, sh) in offs.items():
+                got["d" + k] = grads[off:off + P[k].numel()].reshape(sh).cpu()
+            errs[mode] = {k: float((got[k].double() - ref[k]).abs().max() / ref[k].abs().max()) for k in ref}
+    finally:
+        ops.prof_enable(False)
+        ops.set_option(7, 9)
+    assert ops.chain_status() == 0
+    worst = {m: max(e.values()) for m, e in errs.items()}
+    print("max error vs float64 (relative to each tensor's max):", {m: f"{v:.2e}" for m, v in worst.items()})
+    for k in ref:
+        floor = 3e-7                                               # (a few f32 ulp: both generations sit at this level)
+        assert errs[9][k] <= 2.0 * errs[0][k] + floor, (k, errs[0][k], errs[9][k])
+        assert errs[6][k] <= 4.0 * errs[0][k] + floor, (k, errs[0][k], errs[6][k])
+        assert errs[0][k] < 2e-5 and errs[9][k] < 2e-5 and errs[6][k] < 2e-5, k
 
 
 # ------------------------------------------------------------------------------- multinomial sampling (decoder.py:506-509)
