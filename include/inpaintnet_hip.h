@@ -174,6 +174,14 @@ int inet_gemm_batched(const float* A, int64_t lda, int a_kmajor, const float* B,
                       int64_t ldc, int M, int N, int K, int nbatch, int64_t batchA, int64_t batchB, int64_t batchC,
                       void* stream);
 
+/* The same product on the bf16 matrix cores at fp32 accuracy (csrc/gemm_bf3.hip): both operands are split exactly into three
+ * bf16 pieces in MFMA fragment order (a scratch allocated for the call: this entry exists for tests and benchmarks; inside the
+ * library the pieces live in the callers' workspaces), then C (op)= A . B^T + bias with nine (six) piece products per
+ * element product accumulated in f32.  M % 192 == 0, N % 128 == 0, K % 32 == 0 (k-major operands: rows % 64 == 0), else -1.
+ * ksplit: 0 = chosen by the library, else the k range is split that many ways over the grid (f32 atomics).  acc: 0 store, 1 add. */
+int inet_gemm_bf3(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+                  int64_t ldc, int M, int N, int K, const float* bias, int acc, int ksplit, void* stream);
+
 /* nn.Linear forward / backward (LatentRNN.generation_linear, latent_rnn.py:83,232,250):
  * y[M,N] = epi(x[M,K] W[N,K]^T + b), epi in {0 none, 1 SELU, 2 ReLU};
  * backward (no activation): dx[M,K] = dy W (nullable), dW += dy^T x (nullable), db += colsum(dy) (nullable); dW and db are

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INET_LIB_PATH") or os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip"]
+SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip", "gemm_bf3.hip"]
 
 _lib = None
 
@@ -95,6 +95,7 @@ _SIGNATURES = {
     "inet_bigru2_fwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "inet_bigru2_bwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "inet_gemm": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _P]),
+    "inet_gemm_bf3": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _I, _P]),
     "inet_gemm_batched": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _L, _L, _L, _P]),
     "inet_gru_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "inet_linear_fwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

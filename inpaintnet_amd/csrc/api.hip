@@ -5,6 +5,7 @@
 #include "vae.h"
 #include "lstm.h"
 #include "chain.h"
+#include "gemm_bf3.h"
 
 namespace {
 
@@ -259,6 +260,28 @@ int inet_gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t
                        (hipStream_t)stream);
 }
 
+int inet_gemm_bf3(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+                  int64_t ldc, int M, int N, int K, const float* bias, int acc, int ksplit, void* stream) {
+    if (!A || !B || !C || acc < 0 || acc > 1 || ksplit < 0 || !gemm_bf3_ok(M, N, K)) return -1;
+    if ((a_kmajor && M % 64) || (b_kmajor && N % 64)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* scratch = nullptr;
+    const size_t ab = bf3_bytes(M, K), bb = bf3_bytes(N, K);
+    if (hipMalloc(&scratch, ab + bb) != hipSuccess) return -2;
+    int rc = bf3_split(A, lda, a_kmajor, M, K, nullptr, 0, scratch, (long)bf3_piece_bytes(M, K), K / 32, 0, 0, s);
+    if (rc == 0) rc = bf3_split(B, ldb, b_kmajor, N, K, nullptr, 0, scratch + ab, (long)bf3_piece_bytes(N, K), K / 32, 0, 0, s);
+    if (rc == 0) {
+        Bf3Gemm g{};
+        g.A = scratch; g.a_piece = (long)bf3_piece_bytes(M, K); g.a_kb = K / 32;
+        g.B = scratch + ab; g.b_piece = (long)bf3_piece_bytes(N, K); g.b_kb = K / 32;
+        g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.epi = EPI_NONE; g.acc = acc; g.ksplit = ksplit;
+        rc = launch_gemm_bf3(g, s);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) rc = -2;
+    (void)hipFree(scratch);
+    return rc;
+}
+
 int inet_gemm_batched(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
                       int64_t ldc, int M, int N, int K, int nbatch, int64_t batchA, int64_t batchB, int64_t batchC,
                       void* stream) {
@@ -385,6 +408,7 @@ int inet_set_option(int key, int value) {
     if (key == 5) { if (value < 0 || value > 4) return -1; gemm_set_direct(value); return 0; }
     if (key == 6) { chain_arm_fault(value); return 0; }
     if (key == 7) { if (value != 0 && value != 6 && value != 9) return -1; chain2_set_mode(value); return 0; }
+    if (key == 8) { if (value != 0 && value != 6 && value != 9) return -1; bf3_set_mode(value); return 0; }
     return -1;
 }
 

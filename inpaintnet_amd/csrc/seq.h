@@ -133,6 +133,13 @@ struct BiGru2Ws {
     float *whhT[4], *dgi1, *dgh[4], *dhz, *dx1, *dgi0;
     float *wpk[4], *hpk[4], *wpkT[4], *dghpk[4];               // fragment-major twins (null unless pk_ok(H))
     unsigned* sync;                                            // chain-kernel counters: kSyncAreas areas (gru_chain.h)
+    // piece buffers of the layer-1 input products (gemm_bf3.h; null unless the shapes tile): x1 [TB, 2H], W_ih of both
+    // layer-1 directions stacked [6H, 2H]; backward: dgi1 [TB, 6H], the same weights k-major [2H, 6H]
+    unsigned char *x1pk, *wih1pk, *dgi1pk, *wih1Tpk;
+    // weight-gradient operands, contraction over the T*B rows (k-major sources): per layer the gate gradients transposed,
+    // gT[l] [6H = dir x (r, z, n), TB] (= dgi^T; dgh^T shares its r and z blocks and takes n*r from nrT[2l + dir] [H, TB]),
+    // the layer-0 output x1T [2H, TB] and the previous hidden states hpT[2l + dir] [H, TB]
+    unsigned char *gT[2], *nrT[4], *x1T, *hpT[4];
 };
 size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w);
 

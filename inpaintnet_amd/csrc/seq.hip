@@ -1,5 +1,6 @@
 #include <cstdlib>
 #include "seq.h"
+#include "gemm_bf3.h"
 
 // Rows per launch when a batch is too large for one resident chain launch: the largest of 1024 / 512 / 256 / 128 / 64 that
 // divides B and fits the chip (B itself when it fits; 0: no chain launch applies).
@@ -293,6 +294,19 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
         w.dghpk[i] = pk && save ? c.take<float>(chain_ring_floats(B, 3 * H)) : nullptr;
     }
     w.sync = c.take<unsigned>(kSyncAreas * kChainSyncWords);
+    const bool bf3 = gemm_bf3_ok(T * B, 6 * H, 2 * H);
+    w.x1pk = bf3 ? c.take<unsigned char>(bf3_bytes((long)T * B, 2 * H)) : nullptr;
+    w.wih1pk = bf3 ? c.take<unsigned char>(bf3_bytes(6 * H, 2 * H)) : nullptr;
+    const bool bf3b = bf3 && save && gemm_bf3_ok(T * B, 2 * H, 6 * H);
+    w.dgi1pk = bf3b ? c.take<unsigned char>(bf3_bytes((long)T * B, 6 * H)) : nullptr;
+    w.wih1Tpk = bf3b ? c.take<unsigned char>(bf3_bytes(2 * H, 6 * H)) : nullptr;
+    const bool bf3w = bf3b && gemm_bf3_ok(3 * H, H, T * B) && gemm_bf3_ok(3 * H, 2 * H, T * B) && (T * B) % 64 == 0;
+    for (int l = 0; l < 2; ++l) w.gT[l] = bf3w ? c.take<unsigned char>(bf3_bytes(6 * H, (long)T * B)) : nullptr;
+    w.x1T = bf3w ? c.take<unsigned char>(bf3_bytes(2 * H, (long)T * B)) : nullptr;
+    for (int i = 0; i < 4; ++i) {
+        w.nrT[i] = bf3w ? c.take<unsigned char>(bf3_bytes(H, (long)T * B)) : nullptr;
+        w.hpT[i] = bf3w ? c.take<unsigned char>(bf3_bytes(H, (long)T * B)) : nullptr;
+    }
     return c.bytes();
 }
 
@@ -334,6 +348,21 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     const float* x1 = mask ? w.x1m : w.x1raw;
+    if (w.x1pk && w.wih1pk && bf3_mode() != 0 && gemm_bf3_ok(T * B, 6 * H, 2 * H)) {
+        // both directions' input products as ONE product on the bf16 matrix cores (gemm_bf3.hip): gi1 [TB, 6H] =
+        // x1 [TB, 2H] . [W_ih_fwd; W_ih_bwd]^T + [b_fwd | b_bwd]
+        const long xp = (long)bf3_piece_bytes((long)T * B, 2 * H), wp = (long)bf3_piece_bytes(6 * H, 2 * H);
+        const int KB = 2 * H / 32;
+        INET_TRY(bf3_split(x1, 2L * H, 0, T * B, 2 * H, nullptr, 0, w.x1pk, xp, KB, 0, 0, s));
+        for (int dir = 0; dir < 2; ++dir)
+            INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 0, 3 * H, 2 * H, nullptr, 0, w.wih1pk, wp, KB, dir * 3 * H / 16, 0, s));
+        Bf3Gemm g{};
+        g.A = w.x1pk; g.a_piece = xp; g.a_kb = KB; g.B = w.wih1pk; g.b_piece = wp; g.b_kb = KB;
+        g.C = w.gi1; g.ldc = 6L * H; g.M = T * B; g.N = 6 * H; g.K = 2 * H;
+        g.bias = P[2].b_ih; g.bias2 = P[3].b_ih; g.bias2_from = 3 * H;
+        g.epi = EPI_NONE; g.acc = ACC_STORE; g.ksplit = 1;
+        INET_TRY(launch_gemm_bf3(g, s));
+    } else
     for (int dir = 0; dir < 2; ++dir)
         INET_TRY(linear_fwd(x1, 2L * H, P[2 + dir].w_ih, 2L * H, P[2 + dir].b_ih, w.gi1 + dir * 3L * H, 6L * H,
                             T * B, 3 * H, 2 * H, EPI_NONE, s));
@@ -352,6 +381,31 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     return 0;
+}
+
+// Weight gradients of one layer's recurrent weights, both directions in one launch on the bf16 matrix cores:
+// dW_hh_d [3H, H] += dgh_d^T hprev_d.  The transposed gate gradients gT (r, z of both directions; with `n_too` the n block as
+// well: the layer's dgi^T) and n*r (nrT) are split here from the chain's dgi / dgh arrays.
+static int bigru2_wgrad_hh_bf3(int B, int T, int H, int layer, const GruDirPtr* P, BiGru2Ws& w, const float* dgi, bool n_too,
+                               hipStream_t ss) {
+    const long TB = (long)T * B, TBH = TB * H;
+    const long gp = (long)bf3_piece_bytes(6 * H, TB), hp = (long)bf3_piece_bytes(H, TB);
+    const int KB = (int)(TB / 32);
+    for (int dir = 0; dir < 2; ++dir) {
+        const int i = 2 * layer + dir;
+        // r, z (, n) of dgi_d [TB, 3H] at column dir * 3H of the [TB, 6H] array -> row blocks dir * 3H / 16 ..
+        INET_TRY(bf3_split(dgi + dir * 3L * H, 6L * H, 1, (n_too ? 3 : 2) * H, (int)TB, nullptr, 0, w.gT[layer], gp, KB, dir * 3 * H / 16, 0, ss));
+        INET_TRY(bf3_split(w.dgh[i] + 2L * H, 3L * H, 1, H, (int)TB, nullptr, 0, w.nrT[i], hp, KB, 0, 0, ss));
+        INET_TRY(bf3_split(w.sv[i] + 4 * TBH, H, 1, H, (int)TB, nullptr, 0, w.hpT[i], hp, KB, 0, 0, ss));
+    }
+    const int i0 = 2 * layer;
+    Bf3Gemm g{};
+    g.A = w.gT[layer]; g.A2 = w.gT[layer] + (long)(3 * H / 16) * KB * 1024; g.a_piece = gp; g.a_kb = KB;
+    g.a_alt_from = 2 * H / 16; g.A_alt = w.nrT[i0]; g.A2_alt = w.nrT[i0 + 1]; g.a_alt_piece = hp;
+    g.B = w.hpT[i0]; g.B2 = w.hpT[i0 + 1]; g.b_piece = hp; g.b_kb = KB;
+    g.C = P[i0].dw_hh; g.C2 = P[i0 + 1].dw_hh; g.ldc = H;
+    g.M = 3 * H; g.N = H; g.K = (int)TB; g.epi = EPI_NONE; g.acc = ACC_ADD; g.nbatch = 2;
+    return launch_gemm_bf3(g, ss);
 }
 
 int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, const float* dout1,
@@ -395,12 +449,27 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     // chip busy, and smaller-K products are less efficient -- so one chunk.
     const int CH = T;
     const float* x1 = mask ? w.x1m : w.x1raw;
+    const bool bf3d = bf3_mode() != 0 && w.dgi1pk && w.wih1Tpk && gemm_bf3_ok(T * B, 2 * H, 6 * H);
+    const bool bf3w = bf3_mode() != 0 && w.gT[0] && w.hpT[0] && wg;
     for (int hi = T - 1; hi >= 0 && stage != 2; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0, nt = hi - lo + 1;
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
-            if (nt == T) {                                   // both directions of a product in one launch
+            if (nt == T && bf3w) {                           // both directions of a product in one launch (gemm_bf3.hip)
+                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 1, P, w, w.dgi1, true, ss));
+                // dW_ih_d [3H, 2H] += dgi1_d^T x1: the transposed gate gradients are the ones just made
+                const long TBl = (long)T * B;
+                const long gp = (long)bf3_piece_bytes(6 * H, TBl), xp = (long)bf3_piece_bytes(2 * H, TBl);
+                const int KB = (int)(TBl / 32);
+                INET_TRY(bf3_split(x1, 2L * H, 1, 2 * H, (int)TBl, nullptr, 0, w.x1T, xp, KB, 0, 0, ss));
+                Bf3Gemm g{};
+                g.A = w.gT[1]; g.A2 = w.gT[1] + (long)(3 * H / 16) * KB * 1024; g.a_piece = gp; g.a_kb = KB;
+                g.B = w.x1T; g.B2 = w.x1T; g.b_piece = xp; g.b_kb = KB;
+                g.C = P[2].dw_ih; g.C2 = P[3].dw_ih; g.ldc = 2L * H;
+                g.M = 3 * H; g.N = 2 * H; g.K = (int)TBl; g.epi = EPI_NONE; g.acc = ACC_ADD; g.nbatch = 2;
+                INET_TRY(launch_gemm_bf3(g, ss));
+            } else if (nt == T) {                            // both directions of a product in one launch
                 INET_TRY(linear_wgrad2(w.dgh[2], w.dgh[3], 3L * H, w.sv[2] + 4 * TBH, w.sv[3] + 4 * TBH, H, P[2].dw_hh,
                                        P[3].dw_hh, H, T * B, 3 * H, H, ss));
                 INET_TRY(linear_wgrad2(w.dgi1, w.dgi1 + 3L * H, 6L * H, x1, x1, 2L * H, P[2].dw_ih, P[3].dw_ih, 2L * H,
@@ -415,6 +484,19 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
             }
         }
     }
+    if (stage != 2 && bf3d) {
+        // dx1 [TB, 2H] = (dgi1 [TB, 6H] . [W_ih_fwd; W_ih_bwd] [6H, 2H]) * mask: both directions as one K = 6H product
+        const long dp = (long)bf3_piece_bytes((long)T * B, 6 * H), wp = (long)bf3_piece_bytes(2 * H, 6 * H);
+        const int KB = 6 * H / 32;
+        INET_TRY(bf3_split(w.dgi1, 6L * H, 0, T * B, 6 * H, nullptr, 0, w.dgi1pk, dp, KB, 0, 0, s));
+        for (int dir = 0; dir < 2; ++dir)
+            INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 1, 2 * H, 3 * H, nullptr, 0, w.wih1Tpk, wp, KB, 0, dir * 3 * H / 32, s));
+        Bf3Gemm g{};
+        g.A = w.dgi1pk; g.a_piece = dp; g.a_kb = KB; g.B = w.wih1Tpk; g.b_piece = wp; g.b_kb = KB;
+        g.C = w.dx1; g.ldc = 2L * H; g.M = T * B; g.N = 2 * H; g.K = 6 * H;
+        g.epi = mask ? EPI_MUL_AUX : EPI_NONE; g.aux = mask; g.ldaux = 2L * H; g.acc = ACC_STORE; g.ksplit = 1;
+        INET_TRY(launch_gemm_bf3(g, s));
+    } else
     for (int dir = 0; dir < 2 && stage != 2; ++dir) {
         const float* dgi = w.dgi1 + dir * 3L * H;
         // dx1 [TB,2H] (+)= dgi1_dir [TB,3H] . W_ih_l1_dir [3H,2H]
@@ -446,7 +528,9 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
             hipStream_t ss = side_fork(s);
-            if (hi - lo + 1 == T)
+            if (hi - lo + 1 == T && bf3w)
+                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 0, P, w, w.dgi0, false, ss));
+            else if (hi - lo + 1 == T)
                 INET_TRY(linear_wgrad2(w.dgh[0], w.dgh[1], 3L * H, w.sv[0] + 4 * TBH, w.sv[1] + 4 * TBH, H, P[0].dw_hh,
                                        P[1].dw_hh, H, T * B, 3 * H, H, ss));
             else

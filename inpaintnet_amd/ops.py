@@ -297,6 +297,18 @@ def gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, epi=0, aux=No
     return out
 
 
+def gemm_bf3(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, out=None, accumulate=False, ksplit=0):
+    """The same product through exact three-piece bf16 splits on the bf16 matrix cores (csrc/gemm_bf3.hip); test / bench
+    entry: the pieces are made in a scratch allocated for the call."""
+    assert A.stride(1) == 1 and B.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(_lib.lib().inet_gemm_bf3(ptr(A), A.stride(0), int(a_kmajor), ptr(B), B.stride(0), int(b_kmajor), ptr(out),
+                                   out.stride(0), M, N, K, ptr(bias), int(accumulate), int(ksplit), stream_ptr()),
+          "inet_gemm_bf3")
+    return out
+
+
 def gemm_batched(A, B, out, M, N, K, nbatch, batchA, batchB, batchC, a_kmajor=True, b_kmajor=True):
     """out_i[M,N] += A_i . B_i^T for nbatch problems of one shape (element strides between problems), one launch where
     a batched kernel applies.  A, B, out: the 2-D views of problem 0."""

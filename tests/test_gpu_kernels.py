@@ -63,6 +63,49 @@ def test_gemm_layouts(akm, bkm, M, N, K):
     assert relmax(C1, ref + C0.double()) < 2e-5
 
 
+@pytest.mark.parametrize("akm,bkm,M,N,K,ksplit", [(0, 0, 384, 384, 256, 0), (0, 0, 192, 128, 64, 1), (0, 1, 768, 256, 1536, 0),
+                                                  (1, 1, 1536, 512, 6144, 0), (1, 1, 192, 128, 2048, 4), (1, 0, 192, 640, 96, 1),
+                                                  (0, 0, 1536, 3072, 1024, 0)])
+def test_gemm_bf3_layouts(akm, bkm, M, N, K, ksplit):
+    """Products through exact three-piece bf16 splits on the bf16 matrix cores (csrc/gemm_bf3.hip) against float64: every
+    source layout (the split kernels' row and column forms), both tile widths, the k range split over the grid, bias,
+    accumulation into a live destination, a strided destination; the error bound is the f32-input kernels'."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + akm * 2 + bkm)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad = (A.t().contiguous() if akm else A).to(DEV)
+    Bd = (B.t().contiguous() if bkm else B).to(DEV)
+    for mode in (9, 6):
+        ops.set_option(8, mode)
+        try:
+            C = ops.gemm_bf3(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, ksplit=ksplit)
+            assert relmax(C, ref) < (2e-6 if mode == 9 else 4e-6), mode
+            Cb = ops.gemm_bf3(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, bias=bias.to(DEV), ksplit=ksplit)
+            assert relmax(Cb, ref + bias.double()) < 4e-6
+            C0 = torch.randn(M, N, generator=g)
+            C1 = C0.to(DEV).clone()
+            ops.gemm_bf3(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, out=C1, accumulate=True, ksplit=ksplit)
+            assert relmax(C1, ref + C0.double()) < 4e-6
+            big = torch.zeros(M, 2, N, device=DEV)
+            ops.gemm_bf3(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, out=big[:, 1, :], ksplit=ksplit)
+            assert relmax(big[:, 1, :], ref) < 4e-6
+            assert float(big[:, 0, :].abs().max()) == 0.0
+        finally:
+            ops.set_option(8, 9)
+    # the f32-input kernel on the same data, for the record of what "fp32 accuracy" means here
+    Cf = ops.gemm(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm)
+    assert relmax(Cf, ref) < 2e-5
+
+
+def test_gemm_bf3_rejects_shapes_it_does_not_tile():
+    A = torch.randn(100, 64, device=DEV)
+    B = torch.randn(128, 64, device=DEV)
+    with pytest.raises(ValueError):
+        ops.gemm_bf3(A, B, 100, 128, 64)
+
+
 @pytest.mark.parametrize("M,N,K", [(1536, 512, 6144), (1536, 1024, 1000), (384, 256, 131), (128, 128, 64),
                                    (576, 576, 777), (1024, 2048, 256)])
 def test_gemm_direct_kmajor_products(M, N, K):
