@@ -14,6 +14,22 @@ constexpr int kChainSyncWords = kChainZeroWord + 4;
 // launches its own (`prezeroed`), instead of one 5 us fill kernel in front of every launch (11 per training step).
 constexpr int kSyncAreas = 8;
 
+// Piece outputs of a second-generation chain kernel (gemm_bf3.h layouts) for the bf16-matrix-core products that consume the
+// layer's results: the wave that produces a value also splits it into its three bf16 pieces, so no separate pass reads the
+// f32 array again.  Row index of (t, b) in every layout: m = t * B_full + r0 + b  (B_full % 32 == 0, r0 % 32 == 0).
+//   forward:  rows = masked output [T*B, .] (this direction's H columns at k blocks rows_kb0 ..), colsA = masked output^T
+//             (row blocks colsA_rb0 ..), colsB = previous hidden state^T (row blocks colsB_rb0 ..)
+//   backward: rows = dgi [T*B, .] (gates r, z, n at k blocks rows_kb0 + g * H / 32 ..), colsA = (r, z[, n])^T (row blocks
+//             colsA_rb0 + g * H / 16 ..; colsA_n: with the n block), colsB = (n * r)^T
+// Null pointers: nothing is written.  First-generation kernels ignore the descriptor (callers check which kernel ran).
+struct ChainEmit {
+    unsigned char* rows; long rows_piece; int rows_kb, rows_kb0;
+    unsigned char* colsA; long colsA_piece; int colsA_rb0, colsA_n;
+    unsigned char* colsB; long colsB_piece; int colsB_rb0;
+    int B_full, r0;
+    int skip_dgi, skip_dgh;                       // backward: the f32 dgi / dgh arrays have no reader left, do not write them
+};
+
 struct GruChainFwdProb {
     const float* W_hh; const float* b_hh;         // [3H,H] row-major, [3H]
     const float* h0; long ld_h0;                  // [B,H] initial hidden (row-major); slot 1 of hx holds it fragment-major
@@ -31,6 +47,7 @@ struct GruChainFwdProb {
     float* hx;                                    // exchange: [2][ceil16(B)][H] fragment-major
     int reverse;
     int hx_slot_bytes;                            // distance between the two slots of hx (0: adjacent)
+    ChainEmit em;
 };
 struct GruChainFwd {
     int H, B, T, nprob, tiles_per_prob, members, prio;
@@ -60,6 +77,7 @@ struct GruChainBwdProb {
     float* gx;                                    // exchange: [2][ceil16(B)][3H] fragment-major
     int reverse;
     float* dgi_sum;                               // optional [B,3H]: sum over the T steps of the input-side gate gradients
+    ChainEmit em;
 };                                                // (the decoder's beat-constant input half: one value per beat)
 struct GruChainBwd {
     int H, B, T, nprob, tiles_per_prob, members, prio;
@@ -73,11 +91,15 @@ bool gru_chain_ok(int H, int B, int T, int nprob);
 bool gru_chain_bwd_ok(int H, int B, int T, int nprob);      // as above, with two row tiles per workgroup when needed
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s);     // (dispatches to the second generation where it applies)
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s);
+// which generation the two launchers above pick for a shape (second: the ChainEmit outputs are written)
+bool gru_chain_fwd_is_v2(int H, int B, int T, int nprob, int h0_packed);
+bool gru_chain_bwd_is_v2(int H, int B, int T, int nprob);
 // Second generation (gru_chain2.hip): one row block per wave, W in LDS, contraction on the bf16 matrix cores at fp32
 // accuracy (three-way exact split, 9 or 6 piece products).  Its exchange holds three bf16 pieces per state: rings must be
 // sized 3 * pk_floats(B, K) floats (seq.h chain_ring_floats) instead of 2 * pk_floats.
 int chain2_mode();                                          // 0 = off (INET_CHAIN2=0), 6 or 9 piece products (default 9)
 void chain2_set_mode(int np);
 bool gru_chain2_ok(int H, int B, int T, int nprob);
+bool gru_chain2_emits(int H, int B, int T, int nprob);      // ... and its build writes the ChainEmit outputs (four waves)
 int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s);
 int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s);

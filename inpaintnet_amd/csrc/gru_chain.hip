@@ -378,9 +378,17 @@ bool gru_chain_bwd_ok(int H, int B, int T, int nprob) {
     return nprob * tiles * (H / 16) <= chain_capacity() && nprob * tiles <= kChainMaxGroups;
 }
 
-int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
+bool gru_chain_fwd_is_v2(int H, int B, int T, int nprob, int h0_packed) {
     static const bool v2f = [] { const char* v = std::getenv("INET_CHAIN2_FWD"); return !(v && v[0] == '0'); }();   // (debug switch)
-    if (v2f && !a.h0_packed && gru_chain2_ok(a.H, a.B, a.T, a.nprob)) return launch_gru_chain2_fwd(a, s);
+    return v2f && !h0_packed && gru_chain2_ok(H, B, T, nprob);
+}
+bool gru_chain_bwd_is_v2(int H, int B, int T, int nprob) {
+    static const bool v2b = [] { const char* v = std::getenv("INET_CHAIN2_BWD"); return !(v && v[0] == '0'); }();   // (debug switch)
+    return v2b && gru_chain2_ok(H, B, T, nprob);
+}
+
+int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
+    if (gru_chain_fwd_is_v2(a.H, a.B, a.T, a.nprob, a.h0_packed)) return launch_gru_chain2_fwd(a, s);
     if (!gru_chain_ok(a.H, a.B, a.T, a.nprob)) return -1;
     const int ms = rows_ms(a.B, a.H, a.nprob);
     a.tiles_per_prob = (a.B + 16 * ms - 1) / (16 * ms);
@@ -406,8 +414,7 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
 }
 
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
-    static const bool v2b = [] { const char* v = std::getenv("INET_CHAIN2_BWD"); return !(v && v[0] == '0'); }();   // (debug switch)
-    if (v2b && gru_chain2_ok(a.H, a.B, a.T, a.nprob)) return launch_gru_chain2_bwd(a, s);
+    if (gru_chain_bwd_is_v2(a.H, a.B, a.T, a.nprob)) return launch_gru_chain2_bwd(a, s);
     if (!gru_chain_bwd_ok(a.H, a.B, a.T, a.nprob)) return -1;
     const int ms = rows_ms_bwd(a.H, a.B, a.nprob);
     a.tiles_per_prob = (a.B + 16 * ms - 1) / (16 * ms);

@@ -49,6 +49,39 @@ __device__ __forceinline__ void publish8(__amdgpu_buffer_rsrc_t rs, int off, int
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p2), rs, off + 2 * pb, 0, 16);
 }
 
+__device__ __forceinline__ void pieces8(const float* src, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, c;
+        split3(src[j], a, b, c);
+        p0[j] = a; p1[j] = b; p2[j] = c;
+    }
+}
+__device__ __forceinline__ void publish_pieces(__amdgpu_buffer_rsrc_t rs, int off, int pb, bf16x8 p0, bf16x8 p1, bf16x8 p2) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p0), rs, off, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p1), rs, off + pb, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p2), rs, off + 2 * pb, 0, 16);
+}
+// plain (cached) stores of the three pieces: outputs for kernels launched later (ChainEmit), not part of the hand-off
+__device__ __forceinline__ void store_pieces(unsigned char* dst, long piece, bf16x8 p0, bf16x8 p1, bf16x8 p2) {
+    *reinterpret_cast<bf16x8*>(dst) = p0;
+    *reinterpret_cast<bf16x8*>(dst + piece) = p1;
+    *reinterpret_cast<bf16x8*>(dst + 2 * piece) = p2;
+}
+// One 16 x 16 tile of a wave in the accumulator layout (lane (c, q): rows 4q .. 4q+3 of unit c) -> its half of the transposed
+// fragment (unit block, 32-row m block): fragment lane (kg, unit c) holds rows 8 kg .. 8 kg + 7 of the m block; this wave's
+// 16 rows are the m block's half `par`.  Lanes of even q take the four rows of lane + 16 (q + 1) next to their own.
+__device__ __forceinline__ void emit_cols(unsigned char* frag, long piece, const float (&v)[4], int q, int c, int par) {
+    float x[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x[r] = v[r]; x[4 + r] = __shfl_down(v[r], 16, 64); }
+    if (!(q & 1)) {
+        bf16x8 p0, p1, p2;
+        pieces8(x, p0, p1, p2);
+        store_pieces(frag + ((2 * par + (q >> 1)) * 16 + c) * 16, piece, p0, p1, p2);
+    }
+}
+
 // acc[g] += A[row block, all K] x W_g^T for NG B-operands held as pieces in LDS: wl + ((p * NG + g) * S32 + s) * 1024
 template <int NG, int S32, int NP>
 __device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char* wl, __amdgpu_buffer_rsrc_t rs, int abase,
@@ -126,7 +159,8 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
     constexpr int H = 32 * S32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;                             // [3 pieces][3 gates][S32][64][16 B]
-    float* const xt = reinterpret_cast<float*>(smem + 3 * 3 * S32 * 1024);   // [WV][256]
+    constexpr int NTILE = WV == 4 ? 4 : 1;                      // transpose tiles per wave (4: 144 + 16 KB = all of the LDS at H = 512)
+    float* const xt = reinterpret_cast<float*>(smem + 3 * 3 * S32 * 1024);   // [WV][NTILE][256]
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
     if (group >= A.nprob * A.tiles_per_prob) return;
@@ -164,7 +198,7 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.hx);
     unsigned* counter = A.counters + (prob * nrb + rb) * kChainCounterStride;
     const chain::Status status = A.status;
-    float* myxt = xt + w * 256;
+    float* myxt = xt + w * 256 * NTILE;
     const int abase = (rb * S32 * 64 + lane) * 16;
     // this wave's 16 columns inside a fragment: k block member / 2, k groups 2 (member % 2) + {0, 1}
     const int pub_off = ((rb * S32 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
@@ -209,6 +243,15 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
     float* const svp = P.sv; const int sv_as = (int)P.sv_astride, sv_ts = P.sv_ts ? (int)P.sv_ts : B * H;
     float* const hlastp = P.hlast; const int hlast_ld = (int)P.ld_hlast;
     const int rev = P.reverse, members = A.members;
+    // piece outputs (ChainEmit): the descriptor in SGPRs before the loop (kernarg reads sink to their first use otherwise)
+    unsigned char* const em_rows = NTILE > 1 ? P.em.rows : nullptr;      // (one-tile builds write no piece outputs)
+    unsigned char* const em_colsA = NTILE > 1 ? P.em.colsA : nullptr; unsigned char* const em_colsB = NTILE > 1 ? P.em.colsB : nullptr;
+    const long em_rows_piece = P.em.rows_piece, em_colsA_piece = P.em.colsA_piece, em_colsB_piece = P.em.colsB_piece;
+    const int em_rows_kb = P.em.rows_kb, em_rows_kb0 = P.em.rows_kb0, em_colsA_rb0 = P.em.colsA_rb0, em_colsB_rb0 = P.em.colsB_rb0;
+    const int em_b16 = P.em.B_full >> 4, em_rb0 = P.em.r0 >> 4, em_kbm = T * (P.em.B_full >> 5);
+    kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
+                  em_colsA_rb0, em_colsB_rb0, em_b16, em_rb0, em_kbm);
+    const bool em_any = em_rows || em_colsA || em_colsB;
     long tok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) tok[r] = idxp[brow[r] * idx_bs + (rev ? T - 1 : 0) * idx_ts];
@@ -246,11 +289,38 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
             myxt[(4 * q + r) * 16 + c] = hn;
             er[r] = rr; ez[r] = z; en[r] = n; eg[r] = ghn; eh[r] = hn; ehp[r] = hprev;
         }
-        if (step != T - 1) {                                   // nobody reads the last state from the exchange
-            __builtin_amdgcn_wave_barrier();                   // (the tile is exchanged between lanes: see the backward kernel)
-            if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
+        // One pass through the wave's transpose tiles: tile 0 = the new state (the exchange's next operand), tile 1 = the
+        // masked state (the row pieces of the layer's output, ChainEmit).  The exchange stores go first and the arrival right
+        // behind them (its vmcnt(0) then only waits for those); the piece outputs follow.
+        float em_v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) em_v[r] = has_mask ? eh[r] * pm[r] : eh[r];
+        const bool rows_masked = em_rows && has_mask;
+        if (rows_masked) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) myxt[256 + (4 * q + r) * 16 + c] = em_v[r];
+        }
+        const int rbg = em_rb0 + rb;                           // row block within the full batch
+        if (step != T - 1 || em_rows) {                        // (nobody reads the last state from the exchange)
+            __builtin_amdgcn_wave_barrier();                   // (the tiles are exchanged between lanes: see the backward kernel)
+            bf16x8 p0, p1, p2;
+            const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
+            if (lane < 32) {
+                pieces8(src, p0, p1, p2);
+                if (step != T - 1) publish_pieces(rs, (step & 1) * slot_bytes + pub_off, pb, p0, p1, p2);
+            }
+            if (step != T - 1) arrive_rows(counter, lane);
+            if (em_rows && lane < 32) {
+                if (rows_masked) pieces8(src + 256, p0, p1, p2);
+                store_pieces(em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
+                                        (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16, em_rows_piece, p0, p1, p2);
+            }
             __builtin_amdgcn_wave_barrier();
-            arrive_rows(counter, lane);
+        }
+        if (em_colsA || em_colsB) {
+            const long mb = (long)tt * (em_b16 >> 1) + (rbg >> 1);
+            if (em_colsA) emit_cols(em_colsA + ((long)(em_colsA_rb0 + member) * em_kbm + mb) * 1024, em_colsA_piece, em_v, q, c, rbg & 1);
+            if (em_colsB) emit_cols(em_colsB + ((long)(em_colsB_rb0 + member) * em_kbm + mb) * 1024, em_colsB_piece, ehp, q, c, rbg & 1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -276,7 +346,8 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
     constexpr int H = 32 * S32 / 3, SH = H / 32;     // SH: k blocks per gate
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;                             // [3 pieces][S32][64][16 B]: W_hh^T columns j0..j0+15
-    float* const xt = reinterpret_cast<float*>(smem + 3 * S32 * 1024);   // [WV][256]: one transpose tile per wave
+    constexpr int NTILE = WV == 4 ? 4 : 1;
+    float* const xt = reinterpret_cast<float*>(smem + 3 * S32 * 1024);   // [WV][NTILE][256]: the wave's transpose tiles
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
     if (group >= A.nprob * A.tiles_per_prob) return;
@@ -311,7 +382,7 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
     const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.gx);
     unsigned* counter = A.counters + (prob * nrb + rb) * kChainCounterStride;
     const chain::Status status = A.status;
-    float* myxt = xt + w * 256;
+    float* myxt = xt + w * 256 * NTILE;
     const int abase = (rb * S32 * 64 + lane) * 16;
     // gate g's 16 columns of this member: k block g * SH + member / 2
     const int pub_off = ((rb * S32 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
@@ -334,6 +405,16 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
     float* const dghp = P.dgh; const int dgh_ts = P.dgh_ts ? (int)P.dgh_ts : B * 3 * H;
     float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
     const int rev = P.reverse, members = A.members;
+    unsigned char* const em_rows = NTILE > 1 ? P.em.rows : nullptr;      // (one-tile builds write no piece outputs)
+    unsigned char* const em_colsA = NTILE > 1 ? P.em.colsA : nullptr; unsigned char* const em_colsB = NTILE > 1 ? P.em.colsB : nullptr;
+    const long em_rows_piece = P.em.rows_piece, em_colsA_piece = P.em.colsA_piece, em_colsB_piece = P.em.colsB_piece;
+    const int em_rows_kb = P.em.rows_kb, em_rows_kb0 = P.em.rows_kb0, em_colsA_rb0 = P.em.colsA_rb0, em_colsB_rb0 = P.em.colsB_rb0;
+    const int em_colsA_n = P.em.colsA_n;
+    const bool em_skip_dgi = NTILE > 1 && P.em.skip_dgi, em_skip_dgh = NTILE > 1 && P.em.skip_dgh;
+    const int em_b16 = P.em.B_full >> 4, em_rb0 = P.em.r0 >> 4, em_kbm = T * (P.em.B_full >> 5);
+    kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
+                  em_colsA_rb0, em_colsB_rb0, em_colsA_n, em_b16, em_rb0, em_kbm);
+    const bool em_any = em_rows || em_colsA || em_colsB;
     for (int step = T - 1; step >= -1; --step) {
         const bool tail = step < 0;                            // dh0 = dgh(first step) W_hh + dhz
         if (tail && !dh0p) break;
@@ -380,30 +461,83 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
             dhz[r] = dh * z;
             e_r[r] = dr_pre; e_z[r] = dz_pre; e_n[r] = dn_pre; e_nr[r] = dnr;
         }
-        if (step != 0 || dh0p) {                               // (nothing reads the last gate gradients unless dh0 is wanted)
+        // One pass through the wave's transpose tiles (NTILE = 4; a one-tile build takes them one after the other): the three
+        // gate gradients of the exchange (r, z, n*r) and, for the row pieces of dgi (ChainEmit), n.  The exchange stores go first
+        // and the arrival right behind them (its vmcnt(0) then only waits for those); the piece outputs follow.
+        const bool pub = step != 0 || dh0p;                    // (nothing reads the last gate gradients unless dh0 is wanted)
+        const int rbg = em_rb0 + rb;
+        if (NTILE > 1) {
+            if (pub || em_rows) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {                      // gate by gate through the wave's transpose tile
+                for (int r = 0; r < 4; ++r) {
+                    float* tp = myxt + (4 * q + r) * 16 + c;
+                    tp[0] = e_r[r]; tp[256] = e_z[r]; tp[512] = e_nr[r];
+                    if (em_rows) tp[768] = e_n[r];
+                }
+                // The tiles are exchanged BETWEEN lanes: lanes 32..63 must not run ahead into the next step's writes while
+                // lanes 0..31 still have this step's reads in front of them.  The compiler reasons per thread and did exactly
+                // that (it hoisted the next tile's writes of the upper half-wave over the branch); the convergent wave barrier
+                // pins the order for the whole wave (the LDS itself executes one wave's operations in issue order).
+                __builtin_amdgcn_wave_barrier();
+                bf16x8 pr[3], pz[3], pn[3];
+                const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
+                if (lane < 32) {
+                    pieces8(src, pr[0], pr[1], pr[2]);
+                    pieces8(src + 256, pz[0], pz[1], pz[2]);
+                    if (pub) {
+                        pieces8(src + 512, pn[0], pn[1], pn[2]);
+                        const int off = (step & 1) * slot_bytes + pub_off;
+                        publish_pieces(rs, off, pb, pr[0], pr[1], pr[2]);
+                        publish_pieces(rs, off + SH * 1024, pb, pz[0], pz[1], pz[2]);
+                        publish_pieces(rs, off + 2 * SH * 1024, pb, pn[0], pn[1], pn[2]);
+                    }
+                }
+                if (pub) arrive_rows(counter, lane);
+                if (em_rows && lane < 32) {
+                    unsigned char* dst = em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
+                                                    (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16;
+                    store_pieces(dst, em_rows_piece, pr[0], pr[1], pr[2]);
+                    store_pieces(dst + SH * 1024, em_rows_piece, pz[0], pz[1], pz[2]);
+                    pieces8(src + 768, pn[0], pn[1], pn[2]);
+                    store_pieces(dst + 2 * SH * 1024, em_rows_piece, pn[0], pn[1], pn[2]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (pub) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {                      // gate by gate through the wave's one transpose tile
 #pragma unroll
                 for (int r = 0; r < 4; ++r) myxt[(4 * q + r) * 16 + c] = g == 0 ? e_r[r] : (g == 1 ? e_z[r] : e_nr[r]);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 32)
                     publish8(rs, (step & 1) * slot_bytes + pub_off + g * SH * 1024, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
-                // The tile is exchanged BETWEEN lanes: lanes 32..63 must not run ahead into the next gate's writes while
-                // lanes 0..31 still have this gate's reads in front of them.  The compiler reasons per thread and did exactly
-                // that (it hoisted the next tile's writes of the upper half-wave over the branch); the convergent wave barrier
-                // pins the order for the whole wave (the LDS itself executes one wave's operations in issue order).
                 __builtin_amdgcn_wave_barrier();
             }
             arrive_rows(counter, lane);
+        }
+        if (em_colsA || em_colsB) {
+            const long mb = (long)tt * (em_b16 >> 1) + (rbg >> 1);
+            if (em_colsA) {
+                unsigned char* fa = em_colsA + ((long)(em_colsA_rb0 + member) * em_kbm + mb) * 1024;
+                const long gstep = (long)(H / 16) * em_kbm * 1024;
+                emit_cols(fa, em_colsA_piece, e_r, q, c, rbg & 1);
+                emit_cols(fa + gstep, em_colsA_piece, e_z, q, c, rbg & 1);
+                if (em_colsA_n) emit_cols(fa + 2 * gstep, em_colsA_piece, e_n, q, c, rbg & 1);
+            }
+            if (em_colsB) emit_cols(em_colsB + ((long)(em_colsB_rb0 + member) * em_kbm + mb) * 1024, em_colsB_piece, e_nr, q, c, rbg & 1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = rb * 16 + 4 * q + r;
             if (b < B) {
-                float* gi = dgip + tt * dgi_ts + b * dgi_ld;
-                gi[jc] = e_r[r]; gi[H + jc] = e_z[r]; gi[2 * H + jc] = e_n[r];
-                float* gh = dghp + tt * dgh_ts + b * 3 * H;
-                gh[jc] = e_r[r]; gh[H + jc] = e_z[r]; gh[2 * H + jc] = e_nr[r];
+                if (!em_skip_dgi) {
+                    float* gi = dgip + tt * dgi_ts + b * dgi_ld;
+                    gi[jc] = e_r[r]; gi[H + jc] = e_z[r]; gi[2 * H + jc] = e_n[r];
+                }
+                if (!em_skip_dgh) {
+                    float* gh = dghp + tt * dgh_ts + b * 3 * H;
+                    gh[jc] = e_r[r]; gh[H + jc] = e_z[r]; gh[2 * H + jc] = e_nr[r];
+                }
                 bs[0] += e_r[r]; bs[1] += e_z[r]; bs[2] += e_n[r]; bs[3] += e_nr[r];
                 gs[r][0] += e_r[r]; gs[r][1] += e_z[r]; gs[r][2] += e_n[r];
             }
@@ -466,6 +600,7 @@ static int chain2_waves(int H, int B, int T, int nprob) {
     return 0;
 }
 bool gru_chain2_ok(int H, int B, int T, int nprob) { return chain2_waves(H, B, T, nprob) > 0; }
+bool gru_chain2_emits(int H, int B, int T, int nprob) { return chain2_waves(H, B, T, nprob) == 4; }
 
 int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
     const int wv = chain2_waves(a.H, a.B, a.T, a.nprob);
@@ -485,7 +620,7 @@ int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
     ProfScope prof(PROF_GRU_FWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))));
     const dim3 grid(chain::blocks_for(groups, a.members));
-    const size_t lds = (size_t)3 * 3 * (a.H / 32) * 1024 + (size_t)wv * 256 * 4;
+    const size_t lds = (size_t)3 * 3 * (a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (wv == 4 ? 4 : 1);
 #define INET_C2F(W, S, N)                                                                                               \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
@@ -524,7 +659,7 @@ int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s) {
     ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)));
     const dim3 grid(chain::blocks_for(groups, a.members));
-    const size_t lds = (size_t)3 * (3 * a.H / 32) * 1024 + (size_t)wv * 256 * 4;
+    const size_t lds = (size_t)3 * (3 * a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (wv == 4 ? 4 : 1);
 #define INET_C2B(W, S, N)                                                                                               \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \

@@ -42,6 +42,10 @@ struct DirFwd {
     // chain kernel (gru_chain.h): kChainSyncWords words for the launch's group counters, given for direction 0 (or null)
     unsigned* sync;
     int sync_prezeroed;                                       // those words are zero already (one memset per library call)
+    // piece outputs for the bf16-matrix-core products (gru_chain.h ChainEmit; B_full / r0 are filled in by gru_layer_fwd);
+    // `emitted` is set to 1 by gru_layer_fwd when the kernels it launched wrote them, else to 0 (the caller then splits the
+    // f32 arrays with bf3_split)
+    ChainEmit em; mutable int emitted;
 };
 
 struct DirBwd {
@@ -62,6 +66,7 @@ struct DirBwd {
     int sync_prezeroed;
     float* dgi_sum;                                           // optional [B,3H] sum_t dgi(t); `*dgi_sum_done` is set to 1 when the
     int* dgi_sum_done;                                        // layer's launch produced it (chain kernel), else left alone
+    ChainEmit em; mutable int emitted;                        // as in DirFwd
 };
 
 // floats of a fragment-major [rows,K] operand (rows padded to 16)
@@ -74,6 +79,10 @@ inline size_t chain_ring_floats(int rows, int K) { return 3 * pk_floats(rows, K)
 // rows per chain launch for a batch of B rows (B itself when one launch holds it; 0: no chain kernel applies)
 int chain_chunk_rows(int H, int B, int T, int nd, int save = 1);
 int chain_chunk_rows_bwd(int H, int B, int T, int nd);
+// whether gru_layer_fwd / gru_layer_bwd write ChainEmit outputs for this shape (the kernels that run are the second generation's,
+// rows in multiples of 32): the same decision the layer functions make, for callers that must know it in another library call
+bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save);
+bool gru_layer_bwd_emits(int H, int B, int T, int nd);
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
 int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_hi, int step_lo, hipStream_t s);

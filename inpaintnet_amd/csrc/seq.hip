@@ -30,7 +30,27 @@ int chain_chunk_rows_bwd(int H, int B, int T, int nd) {
     return 0;
 }
 
+// which piece outputs the chains write themselves (bit 0: forward rows, 1: forward transposed, 2: backward rows, 3: backward
+// transposed); what they do not write is split from the f32 arrays by bf3_split launches (the transposed ones on the side stream)
+static int emit_mask() {
+    static const int m = [] { const char* v = std::getenv("INET_EMIT"); return v ? std::atoi(v) : 15; }();
+    return m;
+}
+
+bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save) {
+    if (!pk_ok(H) || B % 32) return false;
+    if (gru_chain_ok(H, B, T, nd)) return gru_chain_fwd_is_v2(H, B, T, nd, 0) && gru_chain2_emits(H, B, T, nd);
+    const int CH = chain_chunk_rows(H, B, T, nd, save);
+    return CH > 0 && CH < B && CH % 32 == 0 && gru_chain_fwd_is_v2(H, CH, T, nd, 0) && gru_chain2_emits(H, CH, T, nd);
+}
+bool gru_layer_bwd_emits(int H, int B, int T, int nd) {
+    if (!pk_ok(H) || B % 32) return false;
+    const int CHB = chain_chunk_rows_bwd(H, B, T, nd);
+    return CHB > 0 && CHB % 32 == 0 && gru_chain_bwd_is_v2(H, CHB, T, nd) && gru_chain2_emits(H, CHB, T, nd);
+}
+
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
+    for (int i = 0; i < nd; ++i) d[i].emitted = 0;
     const long BH = (long)B * H;
     const long pkh = (long)pk_floats(B, H);
     bool pk = pk_ok(H);
@@ -67,6 +87,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
             P.hlast = D.hlast; P.ld_hlast = D.hlast_ld;
             P.sv = D.sv; P.sv_astride = D.sv_astride;
             P.hx = D.hpk; P.reverse = D.reverse;
+            if (B % 32 == 0 && gru_chain_fwd_is_v2(H, B, T, nd, a.h0_packed) && gru_chain2_emits(H, B, T, nd)) { P.em = D.em; P.em.B_full = B; P.em.r0 = 0; D.emitted = 1; }
         }
         a.counters = d[0].sync; a.prezeroed = d[0].sync_prezeroed;
         return launch_gru_chain_fwd(a, s);
@@ -112,6 +133,9 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
                 if (v2) P.hx = D.hpk + (long)c * 3 * pkc;
                 else { P.hx = D.hpk + (long)c * pkc; P.hx_slot_bytes = (int)(pkh * sizeof(float)); }
                 P.reverse = D.reverse;
+                if (v2 && B % 32 == 0 && CH % 32 == 0 && gru_chain_fwd_is_v2(H, CH, T, nd, 0) && gru_chain2_emits(H, CH, T, nd)) {
+                    P.em = D.em; P.em.B_full = B; P.em.r0 = (int)r0; D.emitted = 1;
+                }
             }
             a.counters = d[0].sync + (c & 1) * kChainSyncWords;
             INET_TRY(launch_gru_chain_fwd(a, (c & 1) ? s2 : s));
@@ -167,6 +191,7 @@ int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s) {
 
 // Steps step_hi .. step_lo (descending) of the BPTT chain; the gradient wrt the initial hidden follows step 0.
 int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_hi, int step_lo, hipStream_t s) {
+    for (int i = 0; i < nd; ++i) d[i].emitted = 0;
     const long BH = (long)B * H, B3H = 3 * BH;
     const long pkg = (long)pk_floats(B, 3 * H);
     bool pk = pk_ok(H);
@@ -199,6 +224,9 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
                     else { P.gx = D.dghpk + (long)c * pkc; P.gx_slot_bytes = (int)(pkg * sizeof(float)); }
                     P.reverse = D.reverse;
                     P.dgi_sum = D.dgi_sum ? D.dgi_sum + r0 * 3 * H : nullptr;
+                    if (B % 32 == 0 && CHB % 32 == 0 && gru_chain_bwd_is_v2(H, CHB, T, nd) && gru_chain2_emits(H, CHB, T, nd)) {
+                        P.em = D.em; P.em.B_full = B; P.em.r0 = (int)r0; D.emitted = 1;
+                    }
                 }
                 a.counters = d[0].sync; a.prezeroed = (c == 0 && CHB == B) ? d[0].sync_prezeroed : 0;
                 INET_TRY(launch_gru_chain_bwd(a, s));
@@ -319,12 +347,27 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
     const float* const hzero = chained ? nullptr : w.zeros;
     if (!h0 && !chained && pw_zero(w.zeros, BH, s) != 0) return -2;
     const bool one_launch = chained && gru_chain_ok(H, B, T, 2);      // (not the chunked form: it reuses one area per launch)
+    const long TBl = (long)T * B;
+    const bool bf3f = w.x1pk && w.wih1pk && bf3_mode() != 0 && gemm_bf3_ok(T * B, 6 * H, 2 * H);
     if (one_launch && !sync_prezeroed &&
         hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     if (w.wpk[0] && !chained)
     {
         const float* ins[4] = {P[0].w_hh, P[1].w_hh, P[2].w_hh, P[3].w_hh};
         INET_TRY(pw_pack_frag_multi(ins, w.wpk, 4, H, 3 * H, H, 0, s));
+    }
+    // The layer-1 input weights as bf16 pieces (both directions stacked: the forward products' B operand; with saves also
+    // k-major, the data gradient's B operand of the backward call -- the weights do not change in between): on the side
+    // stream, under the layer-0 chain.
+    hipStream_t wss = s;
+    if (bf3f) {
+        wss = side_fork(s);
+        const long wp = (long)bf3_piece_bytes(6 * H, 2 * H), wpT = (long)bf3_piece_bytes(2 * H, 6 * H);
+        for (int dir = 0; dir < 2; ++dir)
+            INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 0, 3 * H, 2 * H, nullptr, 0, w.wih1pk, wp, 2 * H / 32, dir * 3 * H / 16, 0, wss));
+        if (save && w.wih1Tpk)
+            for (int dir = 0; dir < 2; ++dir)
+                INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 1, 2 * H, 3 * H, nullptr, 0, w.wih1Tpk, wpT, 6 * H / 32, 0, dir * 3 * H / 32, wss));
     }
     DirFwd d[2];
     for (int dir = 0; dir < 2; ++dir) {
@@ -345,17 +388,25 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         D.reverse = dir;
         D.Wpk_hh = w.wpk[dir]; D.hpk = w.hpk[dir];
         D.sync = w.sync; D.sync_prezeroed = one_launch;
+        if (bf3f && (emit_mask() & 1)) {                       // the layer-1 input products' A operand, written by the chain
+            D.em.rows = w.x1pk; D.em.rows_piece = (long)bf3_piece_bytes(TBl, 2 * H); D.em.rows_kb = 2 * H / 32; D.em.rows_kb0 = dir * H / 32;
+        }
+        if (bf3f && save && w.x1T && w.hpT[dir] && (emit_mask() & 2)) {   // the weight gradients' B operands (read by the backward call)
+            D.em.colsA = w.x1T; D.em.colsA_piece = (long)bf3_piece_bytes(2 * H, TBl); D.em.colsA_rb0 = dir * H / 16;
+            D.em.colsB = w.hpT[dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0;
+        }
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
+    const bool x1_emitted = bf3f && d[0].emitted && d[1].emitted && (emit_mask() & 1);
+    if (bf3f && (emit_mask() & 1) && x1_emitted != gru_layer_fwd_emits(H, B, T, 2, save != 0)) return -3;   // (the backward call relies on the predicate)
     const float* x1 = mask ? w.x1m : w.x1raw;
-    if (w.x1pk && w.wih1pk && bf3_mode() != 0 && gemm_bf3_ok(T * B, 6 * H, 2 * H)) {
+    if (bf3f) {
         // both directions' input products as ONE product on the bf16 matrix cores (gemm_bf3.hip): gi1 [TB, 6H] =
         // x1 [TB, 2H] . [W_ih_fwd; W_ih_bwd]^T + [b_fwd | b_bwd]
         const long xp = (long)bf3_piece_bytes((long)T * B, 2 * H), wp = (long)bf3_piece_bytes(6 * H, 2 * H);
         const int KB = 2 * H / 32;
-        INET_TRY(bf3_split(x1, 2L * H, 0, T * B, 2 * H, nullptr, 0, w.x1pk, xp, KB, 0, 0, s));
-        for (int dir = 0; dir < 2; ++dir)
-            INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 0, 3 * H, 2 * H, nullptr, 0, w.wih1pk, wp, KB, dir * 3 * H / 16, 0, s));
+        if (!x1_emitted) INET_TRY(bf3_split(x1, 2L * H, 0, T * B, 2 * H, nullptr, 0, w.x1pk, xp, KB, 0, 0, s));
+        if (wss != s) INET_TRY(stream_wait(s, wss));           // the weight pieces
         Bf3Gemm g{};
         g.A = w.x1pk; g.a_piece = xp; g.a_kb = KB; g.B = w.wih1pk; g.b_piece = wp; g.b_kb = KB;
         g.C = w.gi1; g.ldc = 6L * H; g.M = T * B; g.N = 6 * H; g.K = 2 * H;
@@ -378,6 +429,9 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         D.reverse = dir;
         D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir];
         D.sync = one_launch ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = one_launch;
+        if (bf3f && save && w.hpT[2 + dir] && (emit_mask() & 2)) {
+            D.em.colsB = w.hpT[2 + dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0;
+        }
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     return 0;
@@ -387,16 +441,18 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
 // dW_hh_d [3H, H] += dgh_d^T hprev_d.  The transposed gate gradients gT (r, z of both directions; with `n_too` the n block as
 // well: the layer's dgi^T) and n*r (nrT) are split here from the chain's dgi / dgh arrays.
 static int bigru2_wgrad_hh_bf3(int B, int T, int H, int layer, const GruDirPtr* P, BiGru2Ws& w, const float* dgi, bool n_too,
-                               hipStream_t ss) {
+                               bool gates_emitted, bool hprev_emitted, hipStream_t ss) {
     const long TB = (long)T * B, TBH = TB * H;
     const long gp = (long)bf3_piece_bytes(6 * H, TB), hp = (long)bf3_piece_bytes(H, TB);
     const int KB = (int)(TB / 32);
     for (int dir = 0; dir < 2; ++dir) {
         const int i = 2 * layer + dir;
         // r, z (, n) of dgi_d [TB, 3H] at column dir * 3H of the [TB, 6H] array -> row blocks dir * 3H / 16 ..
-        INET_TRY(bf3_split(dgi + dir * 3L * H, 6L * H, 1, (n_too ? 3 : 2) * H, (int)TB, nullptr, 0, w.gT[layer], gp, KB, dir * 3 * H / 16, 0, ss));
-        INET_TRY(bf3_split(w.dgh[i] + 2L * H, 3L * H, 1, H, (int)TB, nullptr, 0, w.nrT[i], hp, KB, 0, 0, ss));
-        INET_TRY(bf3_split(w.sv[i] + 4 * TBH, H, 1, H, (int)TB, nullptr, 0, w.hpT[i], hp, KB, 0, 0, ss));
+        if (!gates_emitted) {
+            INET_TRY(bf3_split(dgi + dir * 3L * H, 6L * H, 1, (n_too ? 3 : 2) * H, (int)TB, nullptr, 0, w.gT[layer], gp, KB, dir * 3 * H / 16, 0, ss));
+            INET_TRY(bf3_split(w.dgh[i] + 2L * H, 3L * H, 1, H, (int)TB, nullptr, 0, w.nrT[i], hp, KB, 0, 0, ss));
+        }
+        if (!hprev_emitted) INET_TRY(bf3_split(w.sv[i] + 4 * TBH, H, 1, H, (int)TB, nullptr, 0, w.hpT[i], hp, KB, 0, 0, ss));
     }
     const int i0 = 2 * layer;
     Bf3Gemm g{};
@@ -415,6 +471,10 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     // both layers run as backward chains (they read W_hh as stored) iff the conditions of gru_layer_bwd_range hold:
     // the transposed fragment-major twins are then never read
     const bool chained = w.wpkT[0] && w.dghpk[0] && w.sync && pk_ok(H) && chain_chunk_rows_bwd(H, B, T, 2) > 0;
+    const bool bf3d_pre = bf3_mode() != 0 && w.dgi1pk && w.wih1Tpk && gemm_bf3_ok(T * B, 2 * H, 6 * H);
+    const bool bf3w_pre = bf3_mode() != 0 && w.gT[0] && w.hpT[0] && P[0].dw_hh != nullptr;
+    // what the forward call's chains wrote (the same predicate it checked itself against)
+    const bool fwd_emitted = bf3w_pre && w.x1pk && gemm_bf3_ok(T * B, 6 * H, 2 * H) && gru_layer_fwd_emits(H, B, T, 2, true) && (emit_mask() & 2);
     // (stage 2 continues on what stage 1 left in the workspace: zeroed sync areas, packed / transposed weights, dx1)
     if (stage != 2 && chained &&
         hipMemsetAsync(w.sync, 0, (size_t)kSyncAreas * kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
@@ -442,6 +502,16 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[2 + dir]; D.dghpk = w.dghpk[2 + dir];
         D.W_hh = P[2 + dir].w_hh; D.sync = w.sync; D.sync_prezeroed = chained;
+        if (bf3d_pre && (emit_mask() & 4)) {
+            D.em.rows = w.dgi1pk; D.em.rows_piece = (long)bf3_piece_bytes((long)T * B, 6 * H); D.em.rows_kb = 6 * H / 32;
+            D.em.rows_kb0 = dir * 3 * H / 32;
+        }
+        if (bf3w_pre && (emit_mask() & 8)) {
+            D.em.colsA = w.gT[1]; D.em.colsA_piece = (long)bf3_piece_bytes(6 * H, (long)T * B); D.em.colsA_rb0 = dir * 3 * H / 16; D.em.colsA_n = 1;
+            D.em.colsB = w.nrT[2 + dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, (long)T * B); D.em.colsB_rb0 = 0;
+            D.em.skip_dgh = 1;                                 // (its only reader was the weight-gradient product)
+            D.em.skip_dgi = D.em.rows != nullptr;              // (data gradient and weight gradient both read pieces)
+        }
     }
     // The chains can hand their weight-gradient products to the side stream a chunk of steps at a time (CH < T) instead
     // of a layer's whole K = T*B product at the end of its chain.  Measured at B=256 with 2, 3, 4 chunks per layer:
@@ -457,12 +527,13 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
             if (nt == T && bf3w) {                           // both directions of a product in one launch (gemm_bf3.hip)
-                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 1, P, w, w.dgi1, true, ss));
+                const bool gem = d[0].emitted && d[1].emitted && (emit_mask() & 8);
+                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 1, P, w, w.dgi1, true, gem, fwd_emitted, ss));
                 // dW_ih_d [3H, 2H] += dgi1_d^T x1: the transposed gate gradients are the ones just made
                 const long TBl = (long)T * B;
                 const long gp = (long)bf3_piece_bytes(6 * H, TBl), xp = (long)bf3_piece_bytes(2 * H, TBl);
                 const int KB = (int)(TBl / 32);
-                INET_TRY(bf3_split(x1, 2L * H, 1, 2 * H, (int)TBl, nullptr, 0, w.x1T, xp, KB, 0, 0, ss));
+                if (!fwd_emitted) INET_TRY(bf3_split(x1, 2L * H, 1, 2 * H, (int)TBl, nullptr, 0, w.x1T, xp, KB, 0, 0, ss));
                 Bf3Gemm g{};
                 g.A = w.gT[1]; g.A2 = w.gT[1] + (long)(3 * H / 16) * KB * 1024; g.a_piece = gp; g.a_kb = KB;
                 g.B = w.x1T; g.B2 = w.x1T; g.b_piece = xp; g.b_kb = KB;
@@ -484,13 +555,13 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
             }
         }
     }
+    const bool l1_rows_emitted = stage != 2 && bf3d_pre && d[0].emitted && d[1].emitted && (emit_mask() & 4);
     if (stage != 2 && bf3d) {
         // dx1 [TB, 2H] = (dgi1 [TB, 6H] . [W_ih_fwd; W_ih_bwd] [6H, 2H]) * mask: both directions as one K = 6H product
         const long dp = (long)bf3_piece_bytes((long)T * B, 6 * H), wp = (long)bf3_piece_bytes(2 * H, 6 * H);
         const int KB = 6 * H / 32;
-        INET_TRY(bf3_split(w.dgi1, 6L * H, 0, T * B, 6 * H, nullptr, 0, w.dgi1pk, dp, KB, 0, 0, s));
-        for (int dir = 0; dir < 2; ++dir)
-            INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 1, 2 * H, 3 * H, nullptr, 0, w.wih1Tpk, wp, KB, 0, dir * 3 * H / 32, s));
+        if (!l1_rows_emitted) INET_TRY(bf3_split(w.dgi1, 6L * H, 0, T * B, 6 * H, nullptr, 0, w.dgi1pk, dp, KB, 0, 0, s));
+        // (B operand: the k-major weight pieces the forward call left in the workspace)
         Bf3Gemm g{};
         g.A = w.dgi1pk; g.a_piece = dp; g.a_kb = KB; g.B = w.wih1Tpk; g.b_piece = wp; g.b_kb = KB;
         g.C = w.dx1; g.ldc = 2L * H; g.M = T * B; g.N = 2 * H; g.K = 6 * H;
@@ -522,6 +593,11 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[dir]; D.dghpk = w.dghpk[dir];
         D.W_hh = P[dir].w_hh; D.sync = chained ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = chained;
+        if (bf3w_pre && (emit_mask() & 8)) {
+            D.em.colsA = w.gT[0]; D.em.colsA_piece = (long)bf3_piece_bytes(6 * H, (long)T * B); D.em.colsA_rb0 = dir * 3 * H / 16; D.em.colsA_n = 0;
+            D.em.colsB = w.nrT[dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, (long)T * B); D.em.colsB_rb0 = 0;
+            D.em.skip_dgh = 1;                                 // (dgi0 still feeds the embedding / table gradients)
+        }
     }
     for (int hi = T - 1; hi >= 0; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0;
@@ -529,7 +605,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (wg) {
             hipStream_t ss = side_fork(s);
             if (hi - lo + 1 == T && bf3w)
-                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 0, P, w, w.dgi0, false, ss));
+                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 0, P, w, w.dgi0, false, d[0].emitted && d[1].emitted && (emit_mask() & 8), fwd_emitted, ss));
             else if (hi - lo + 1 == T)
                 INET_TRY(linear_wgrad2(w.dgh[0], w.dgh[1], 3L * H, w.sv[0] + 4 * TBH, w.sv[1] + 4 * TBH, H, P[0].dw_hh,
                                        P[1].dw_hh, H, T * B, 3 * H, H, ss));
