@@ -18,8 +18,9 @@ the visible devices: a mismatch is an error, never a silent 1-GPU number.
 
 Prints ONE JSON line on rank 0 (contract in the task brief) carrying
   roofline       the kernel with the largest summed time in the step (per-launch HIP-event timing on the launch
-                 stream during separate un-timed steps), its algorithmic FLOPs and bytes per launch against the
-                 157.3 TFLOP/s fp32-MFMA and 8 TB/s HBM peaks of gfx950, `traffic` = HBM bytes per launch from the
+                 stream during separate un-timed steps), its algorithmic FLOPs and bytes per launch against the MFMA roof of
+                 the pipe it runs on (157.3 TFLOP/s f32-input; kernels on the bf16 pipe through exact three-piece splits:
+                 2500 / 9 = 277.8 TFLOP/s of f32 products) and the 8 TB/s HBM peak of gfx950, `traffic` = HBM bytes per launch from the
                  committed rocprofv3 PMC pass (profiles/), and the same table for the top kernels;
   cpu_baseline   the oracle's CPU port of the same step on the host cores (bounded sample, best thread count);
   parity_checked one un-timed step at the bench's own batch compared with the oracle (loss, logits, every gradient).
@@ -44,6 +45,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (16x the f32-input rate)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E (6.3 TB/s achievable)
 NUM_NOTES = 48
 VAE_BATCH_PER_GPU = 256
@@ -344,12 +346,33 @@ def kernel_table(step, nprof=4):
         us, n = g["us"], g["n"]
         tflops = g["gflop"] * 1e9 / (us * 1e-6) / 1e12 if us > 0 else 0.0
         gbps = g["mb"] * 1e6 / (us * 1e-6) / 1e9 if us > 0 else 0.0
-        table.append({"kernel": label, "launches_per_step": round(n / nprof, 2), "avg_us": round(us / n, 3),
-                      "ms_per_step": round(us / nprof / 1e3, 4), "gflop_per_launch": round(g["gflop"] / n, 4),
-                      "mbytes_per_launch": round(g["mb"] / n, 4), "tflops": round(tflops, 2), "gbps": round(gbps, 1),
-                      "frac_mfma": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4)})
+        row = {"kernel": label, "launches_per_step": round(n / nprof, 2), "avg_us": round(us / n, 3),
+               "ms_per_step": round(us / nprof / 1e3, 4), "gflop_per_launch": round(g["gflop"] / n, 4),
+               "mbytes_per_launch": round(g["mb"] / n, 4), "tflops": round(tflops, 2), "gbps": round(gbps, 1),
+               "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4)}
+        npieces = piece_products(label)
+        if npieces:
+            # the kernel runs its products on the bf16 matrix cores, `npieces` bf16 MFMA products per f32 product: its MFMA
+            # roof in ALGORITHMIC (f32-product) FLOP/s is the bf16 dense peak / npieces
+            row["mfma_pipe"] = f"bf16 x{npieces}"
+            row["peak_tflops"] = round(PEAK_BF16_MFMA_TFLOPS / npieces, 1)
+            row["executed_bf16_tflops"] = round(tflops * npieces, 1)
+            row["frac_of_f32_input_peak"] = round(tflops / PEAK_F32_MFMA_TFLOPS, 4)
+        else:
+            row["mfma_pipe"] = "f32"
+            row["peak_tflops"] = PEAK_F32_MFMA_TFLOPS
+        row["frac_mfma"] = round(tflops / row["peak_tflops"], 4)
+        table.append(row)
     table.sort(key=lambda r: -r["ms_per_step"])
     return table
+
+
+def piece_products(label):
+    """bf16 piece products per f32 product of a kernel label (csrc/gemm_bf3.hip 'bf3p9', csrc/gru_chain2.hip 'v2w4 p9'), 0 for
+    the f32-input MFMA kernels."""
+    import re
+    m = re.search(r"\bbf3p(\d)\b", label) or re.search(r" v2w\d+ p(\d) ", label)
+    return int(m.group(1)) if m else 0
 
 
 def dump_kernel_sequences(step, path, nsteps=6):
@@ -417,6 +440,12 @@ def pmc_key(label):
         return f"decode_chain_kernel<{ms}, {H // 64}, {tf(train)}, 0, 0>|g{grid}"
     if label == "adam":
         return "adam_kernel|"
+    mb = re.match(r"M(\d+) N(\d+) K(\d+) bf3p(\d) t(\d+)x(\d+) s(\d+)(?: e\d+)?(?: x(\d+))?", label)
+    if mb:                                               # csrc/gemm_bf3.hip: 512 threads; 192x192 = waves 2x4 of 6x3 tiles, 192x128 = 4x2 of 3x4
+        M, N, K, npp, bm, bn, sp, nb = mb.groups()
+        grid = 512 * (int(M) // int(bm)) * (int(N) // int(bn)) * int(sp) * int(nb or 1)
+        cfg = "2, 4, 6, 3" if int(bn) == 192 else "4, 2, 3, 4"
+        return f"gemm_bf3_kernel<{cfg}, {npp}>|g{grid}"
     m = re.match(r"M(\d+) N(\d+) K(\d+) ([TN])([TN]) ([tdk])(\d+)x(\d+) s(\d+)(?: e\d+)?(?: x(\d+))?", label)
     if m:
         M, N, K, a, b, kind, bm, bn, sp, nb = m.groups()
@@ -457,7 +486,8 @@ def roofline(step):
     mfma_bound = top["frac_mfma"] >= top["frac_hbm"]
     out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": top["kernel"],
            "achieved": top["tflops"] if mfma_bound else top["gbps"],
-           "peak": PEAK_F32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBPS,
+           "peak": top["peak_tflops"] if mfma_bound else PEAK_HBM_GBPS,
+           "mfma_pipe": top["mfma_pipe"],
            "unit": "TFLOP/s" if mfma_bound else "GB/s",
            "frac": top["frac_mfma"] if mfma_bound else top["frac_hbm"],
            "traffic": top.get("traffic_mbytes_per_launch"),
@@ -607,13 +637,15 @@ def vocab_extra(num_notes=61, steps=40, warmup=8):
 
 
 def chain_generations_extra(wl, steps=60, warmup=10):
-    """The headline step under the other forms of the recurrent contraction (inet_set_option key 7): 0 = first-generation
-    chain kernels (f32-input MFMA), 6 = second generation with the three piece products below 2^-24 |ab| dropped."""
+    """The headline step under the other forms of its products (inet_set_option keys 7: chain kernels, 8: large products):
+    everything on the f32-input MFMA (round 2's arithmetic), the chain kernels alone on the bf16 pipe, and both with the three
+    piece products below 2^-24 |ab| dropped (six instead of nine)."""
     from inpaintnet_amd import ops
     out = {}
     try:
-        for mode, key in ((0, "f32_input_mfma"), (6, "bf16_split_6_products")):
-            ops.set_option(7, mode)
+        for chain, gemm, key in ((0, 0, "f32_input_mfma"), (9, 0, "bf16_split_chains_only"), (6, 6, "bf16_split_6_products")):
+            ops.set_option(7, chain)
+            ops.set_option(8, gemm)
             for _ in range(warmup):
                 wl.step()
             torch.cuda.synchronize()
@@ -625,6 +657,7 @@ def chain_generations_extra(wl, steps=60, warmup=10):
             out[key] = {"measures_per_s": round(wl.units_per_step * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4)}
     finally:
         ops.set_option(7, 9)
+        ops.set_option(8, 9)
     return {"chain_generations": out}
 
 
@@ -806,11 +839,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "arithmetic": "f32 throughout; products on the f32-input MFMA (v_mfma_f32_*_f32) except the recurrent contractions of "
-                          "the GRU chain kernels, which split every f32 operand EXACTLY into three bf16 pieces and accumulate all "
-                          "nine piece products in f32 on the bf16 MFMA: the products of fp32 arithmetic (csrc/gru_chain2.hip; "
-                          "error against float64 equal to the f32-input form, tests/test_gpu_kernels.py::"
-                          "test_chain_generations_against_float64; INET_CHAIN2=0 selects the f32-input form)",
+            "arithmetic": "f32 throughout.  The recurrent contractions of the GRU chain kernels (csrc/gru_chain2.hip) and the "
+                          "encoder's large products (csrc/gemm_bf3.hip: layer-1 input products, their data gradient, the weight "
+                          "gradients) split every f32 operand EXACTLY into three bf16 pieces and accumulate all nine piece products "
+                          "in f32 on the bf16 MFMA: the products of fp32 arithmetic, only the f32 summation order differs (error "
+                          "against float64 equal to the f32-input form: tests/test_gpu_kernels.py::test_chain_generations_against_"
+                          "float64, ::test_gemm_bf3_layouts); every other product runs on the f32-input MFMA (v_mfma_f32_*_f32).  "
+                          "INET_CHAIN2=0 / INET_GEMM_BF3=0 select the f32-input forms (extras.chain_generations times them).",
             "data": "synthetic",
             "config": dict(wl.describe(world), final_loss=round(final_loss, 5)),
             "roofline": roof,

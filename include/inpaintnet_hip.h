@@ -140,6 +140,12 @@ int inet_sample_multinomial(const float* weights, int64_t ld_w, int rows, int V,
 /* p,g,m,v: arenas of n floats; step is 1-based; grads are multiplied by gscale first (1/world_size for DP) */
 int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int step, float gscale, void* stream);
+/* Epoch statistics of the training loop (utils/trainer.py:124-163 accumulates mean_loss / mean_accuracy per batch):
+ * sums[0] += *loss, sums[1] += *accuracy (nullable), sums[2] += 1 -- on the device, and only while no chain launch of this
+ * process has timed out since the last inet_chain_status(reset): a step the optimizer kernel skipped (inet_adam_step reads the
+ * same flag) does not enter the means either. */
+int inet_epoch_stats_add(float* sums, const float* loss, const float* accuracy, void* stream);
+
 
 /* ---- dropout masks (nn.GRU inter-layer dropout, encoder.py:32, decoder.py:346,365) --- */
 int inet_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "inet_bigru2_fwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "inet_bigru2_bwd": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "inet_gemm": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _P]),
+    "inet_epoch_stats_add": (C.c_int, [_P, _P, _P, _P]),
     "inet_gemm_bf3": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _I, _P]),
     "inet_gemm_batched": (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _L, _L, _L, _P]),
     "inet_gru_step": (C.c_int, [_I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -177,6 +177,10 @@ int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
     if (!p || !g || !m || !v || n <= 0 || step < 1) return -1;
     return pw_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, (hipStream_t)stream);
 }
+int inet_epoch_stats_add(float* sums, const float* loss, const float* accuracy, void* stream) {
+    if (!sums || !loss) return -1;
+    return pw_epoch_stats_add(sums, loss, accuracy, (hipStream_t)stream);
+}
 int inet_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
     if (!out || n <= 0 || p < 0.f || p >= 1.f) return -1;
     return pw_dropout_mask(out, n, p, seed, offset, (hipStream_t)stream);

@@ -22,6 +22,7 @@ int pw_sample_multinomial(const float* W, long ld_w, int rows, int V, long long*
                           uint64_t offset, hipStream_t s);
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
             float gscale, hipStream_t s);
+int pw_epoch_stats_add(float* sums, const float* loss, const float* acc, hipStream_t s);
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);
 // up to 8 column sums (bias gradients of one module) in one launch: out_i[n] += sum_m X_i[m*ld_i + n]
 struct PwColsumJob { const float* X; long ld; int M, N; float* out; };

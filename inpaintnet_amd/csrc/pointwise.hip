@@ -687,6 +687,20 @@ int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
                        (const unsigned*)chain_dev_status());
     return ok();
 }
+
+// sums[0..2] += (loss, accuracy, 1) unless a chain launch of this process has timed out since the last reset: the statistics of
+// steps whose results are not valid (and that the optimizer kernel skipped) stay out of the epoch means
+__global__ void epoch_stats_add_kernel(float* sums, const float* loss, const float* acc, const unsigned* abort_word) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    sums[0] += loss[0];
+    if (acc) sums[1] += acc[0];
+    sums[2] += 1.f;
+}
+int pw_epoch_stats_add(float* sums, const float* loss, const float* acc, hipStream_t s) {
+    hipLaunchKernelGGL(epoch_stats_add_kernel, dim3(1), dim3(64), 0, s, sums, loss, acc, (const unsigned*)chain_dev_status());
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s) {
     int gy = (M + 255) / 256;
     if (gy > 64) gy = 64;

@@ -297,6 +297,11 @@ def gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, epi=0, aux=No
     return out
 
 
+def epoch_stats_add(sums, loss, accuracy=None):
+    """sums[:3] += (loss, accuracy, 1) on the device unless a chain launch has timed out (inet_epoch_stats_add)."""
+    check(_lib.lib().inet_epoch_stats_add(ptr(sums), ptr(loss), ptr(accuracy), stream_ptr()), "inet_epoch_stats_add")
+
+
 def gemm_bf3(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, out=None, accumulate=False, ksplit=0):
     """The same product through exact three-piece bf16 splits on the bf16 matrix cores (csrc/gemm_bf3.hip); test / bench
     entry: the pieces are made in a scratch allocated for the call."""

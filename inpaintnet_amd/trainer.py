@@ -154,7 +154,6 @@ class Trainer(ABC):
         dev = self.model.flat.device
         sums = torch.zeros(3, dtype=torch.float32, device=dev)        # loss sum, accuracy sum, batches
         t0 = time.time()
-        batches = 0
         prev_overlap, self.overlap_backward = self.overlap_backward, bool(train)
         try:
             if not isinstance(data_loader, DeviceFeed):
@@ -182,11 +181,9 @@ class Trainer(ABC):
                             raise
                         self._fall_back_from_chains()
                 self._accumulate_stats(sums, loss, accuracy)
-                batches += 1
         finally:
             self.overlap_backward = prev_overlap
             ops.side_defer(False)
-        sums[2] += float(batches)                    # counted on the host, added once
         dp.allreduce_sum_(sums)                      # every rank reports (and early-stops on) the global means
         out = sums.tolist()                          # the one device->host sync of the epoch
         timeouts = ops.chain_status(reset=True)      # persistent kernels: bounded spins report here instead of hanging
@@ -199,15 +196,20 @@ class Trainer(ABC):
 
     @staticmethod
     def _accumulate_stats(sums, loss, accuracy):
-        """sums[:2] += (loss, accuracy) on the device: two launches (stack + add) per batch."""
+        """sums[:3] += (loss, accuracy, 1) on the device in one launch (inet_epoch_stats_add); a batch whose chain kernels
+        timed out -- its results are not valid and the optimizer kernel skipped it -- stays out of the means."""
         loss = loss.detach()
         if loss.dim() > 0:
             loss = loss.mean()
-        loss = loss.reshape(()).to(sums.dtype)
-        if accuracy is None:
-            sums[0] += loss
-        else:
-            sums[:2] += torch.stack((loss, accuracy.detach().reshape(()).to(sums.dtype)))
+        loss = loss.reshape(1).to(sums.dtype).contiguous()
+        acc = None if accuracy is None else accuracy.detach().reshape(1).to(sums.dtype).contiguous()
+        if not sums.is_cuda:                         # (the world_size-2 gloo tests drive this loop with host tensors)
+            sums[0] += loss[0]
+            if acc is not None:
+                sums[1] += acc[0]
+            sums[2] += 1.0
+            return
+        ops.epoch_stats_add(sums, loss, acc)
 
     def zero_grad(self):
         """utils/trainer.py:165-170.  With `overlap_backward` set (the epoch loop and bench.py set it) the step that

@@ -22,6 +22,10 @@ def bench():
     ("M1536 N512 K6144 TN d192x128 s4 e0 x2", "gemm_tn_direct_kernel<3, 2>|g65536"),          # two products, half the split
     ("M1536 N1024 K6144 TN d192x128 s2 e0 x2", "gemm_tn_direct_kernel<3, 2>|g65536"),
     ("M6144 N1536 K1024 NT d192x192 s1 e0", "gemm_kc_direct_kernel<6, 6, false>|g65536"),
+    ("M6144 N3072 K1024 bf3p9 t192x192 s1 e0", "gemm_bf3_kernel<2, 4, 6, 3, 9>|g262144"),     # bf16-piece products: 512 threads per workgroup
+    ("M6144 N1024 K3072 bf3p9 t192x128 s1 e4", "gemm_bf3_kernel<4, 2, 3, 4, 9>|g131072"),
+    ("M1536 N512 K6144 bf3p9 t192x128 s4 e0 x2", "gemm_bf3_kernel<4, 2, 3, 4, 9>|g131072"),
+    ("M1536 N1024 K6144 bf3p6 t192x128 s2 e0 x2", "gemm_bf3_kernel<4, 2, 3, 4, 6>|g131072"),
     ("M6144 N1024 K1536 NN d192x128 s1 e4", "gemm_kc_direct_kernel<6, 4, true>|g65536"),
     ("M256 N1024 K2048 NT k32x32 s1 e1", "gemm_ks_kernel<2, 2, false, false>|g65536"),
     ("M48 N1536 K10 NT t64x64 s1 e0", "gemm_kernel<1, 1, false, false>|g6144"),
@@ -46,3 +50,12 @@ def test_committed_pmc_file_has_the_dominant_kernel(bench):
     hit = pmc[bench.pmc_key(label) + "#" + label]
     assert 100.0 < hit["hbm_mbytes_per_launch"] < 200.0      # 107 MB algorithmic (two 53.5 MB products)
     assert pmc["adam_kernel|g1048576"]["hbm_mbytes_per_launch"] == pytest.approx(494.7, rel=0.01)   # the calibration point
+
+
+def test_piece_products_of_labels(bench):
+    """Kernels on the bf16 pipe are priced against that pipe's roof divided by their piece products per f32 product."""
+    assert bench.piece_products("M6144 N3072 K1024 bf3p9 t192x192 s1 e0") == 9
+    assert bench.piece_products("M1536 N1024 K6144 bf3p6 t192x128 s2 e0 x2") == 6
+    assert bench.piece_products("gru_chain_bwd v2w4 p9 np2 T24 B256 H512") == 9
+    assert bench.piece_products("gru_chain_fwd ms4 np2 T24 B256 H512") == 0
+    assert bench.piece_products("M1536 N512 K6144 TN d192x128 s4 e0 x2") == 0

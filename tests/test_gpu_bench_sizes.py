@@ -101,10 +101,16 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     # the big products run on the LDS-free direct kernels (forward NT 192x192, data-gradient NN 192x128, weight-gradient
     # TN 192x128 split over the XCDs); the 192-row LDS-tiled instantiations are covered by the forced-tile test below
     big = sorted(set(l for l in labels if l.startswith("M")))
-    for wl in () if B != 256 else ("M6144 N1536 K1024 NT d192x192 s1 e0", "M6144 N1024 K1536 NN d192x128 s1 e4",   # e4: dropout mask epilogue
-               "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N512 K6144 TN d192x128 s4 e0 x2", "M1536 N1024 K6144 TN d192x128 s2 e0 x2",
+    # the encoder's big products run on the bf16 matrix cores through exact three-piece splits (csrc/gemm_bf3.hip): both
+    # directions' layer-1 input products as one N = 6H product, their data gradient as one K = 6H product (e4: dropout mask
+    # epilogue), the weight gradients two directions per launch; the decoder's on the LDS-free f32-input direct kernels
+    for wl in () if B != 256 else ("M6144 N3072 K1024 bf3p9 t192x192 s1 e0", "M6144 N1024 K3072 bf3p9 t192x128 s1 e4",
+               "M1536 N512 K6144 bf3p9 t192x128 s4 e0 x2", "M1536 N1024 K6144 bf3p9 t192x128 s2 e0 x2",
+               "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N512 K6144 TN d192x128 s4 e0 x2",
                "group2 M256 N1024 K2048 NT k64x32 e1"):                                        # both SELU heads in one grouped split-K launch
         assert wl in labels, (wl, big)
+    if B == 256:     # the chains wrote the pieces themselves: the only split launches left are the layer-1 input weights'
+        assert sorted(set(l for l in labels if l.startswith("bf3_split"))) == ["bf3_split cols R1024 K1536", "bf3_split rows R1536 K1024"], big
     if not tf and B == 256:      # the 24 free-running ticks with dropout and backward saves: one launch of the fused decode kernel
         assert "decode_chain_train ms2 T24 B256 H512 V48" in labels, sorted(set(l for l in labels if l.startswith("dec")))
     print(sorted(set(l for l in labels if l.startswith("gru"))))
