@@ -154,12 +154,14 @@ __device__ __forceinline__ void arrive_rows(unsigned* counter, int lane) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward:  h_t = GRUCell(gi_t, h_{t-1})
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int WV, int S32, int NP>                   // WV waves (= row blocks) per workgroup; S32 = H / 32
+// EM: the build that writes the ChainEmit piece outputs (four transpose tiles per wave: 144 + 16 KB = all of the LDS at H = 512);
+// launches without piece outputs run the lean build (one tile, no descriptor in registers)
+template <int WV, int S32, int NP, bool EM>          // WV waves (= row blocks) per workgroup; S32 = H / 32
 __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) {
     constexpr int H = 32 * S32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;                             // [3 pieces][3 gates][S32][64][16 B]
-    constexpr int NTILE = WV == 4 ? 4 : 1;                      // transpose tiles per wave (4: 144 + 16 KB = all of the LDS at H = 512)
+    constexpr int NTILE = EM ? 4 : 1;                           // transpose tiles per wave
     float* const xt = reinterpret_cast<float*>(smem + 3 * 3 * S32 * 1024);   // [WV][NTILE][256]
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
@@ -244,13 +246,13 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
     float* const hlastp = P.hlast; const int hlast_ld = (int)P.ld_hlast;
     const int rev = P.reverse, members = A.members;
     // piece outputs (ChainEmit): the descriptor in SGPRs before the loop (kernarg reads sink to their first use otherwise)
-    unsigned char* const em_rows = NTILE > 1 ? P.em.rows : nullptr;      // (one-tile builds write no piece outputs)
-    unsigned char* const em_colsA = NTILE > 1 ? P.em.colsA : nullptr; unsigned char* const em_colsB = NTILE > 1 ? P.em.colsB : nullptr;
+    unsigned char* const em_rows = EM ? P.em.rows : nullptr;             // (the lean build writes no piece outputs)
+    unsigned char* const em_colsA = EM ? P.em.colsA : nullptr; unsigned char* const em_colsB = EM ? P.em.colsB : nullptr;
     const long em_rows_piece = P.em.rows_piece, em_colsA_piece = P.em.colsA_piece, em_colsB_piece = P.em.colsB_piece;
     const int em_rows_kb = P.em.rows_kb, em_rows_kb0 = P.em.rows_kb0, em_colsA_rb0 = P.em.colsA_rb0, em_colsB_rb0 = P.em.colsB_rb0;
     const int em_b16 = P.em.B_full >> 4, em_rb0 = P.em.r0 >> 4, em_kbm = T * (P.em.B_full >> 5);
-    kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
-                  em_colsA_rb0, em_colsB_rb0, em_b16, em_rb0, em_kbm);
+    if (EM) kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
+                          em_colsA_rb0, em_colsB_rb0, em_b16, em_rb0, em_kbm);
     const bool em_any = em_rows || em_colsA || em_colsB;
     long tok[4];
 #pragma unroll
@@ -289,33 +291,41 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
             myxt[(4 * q + r) * 16 + c] = hn;
             er[r] = rr; ez[r] = z; en[r] = n; eg[r] = ghn; eh[r] = hn; ehp[r] = hprev;
         }
-        // One pass through the wave's transpose tiles: tile 0 = the new state (the exchange's next operand), tile 1 = the
-        // masked state (the row pieces of the layer's output, ChainEmit).  The exchange stores go first and the arrival right
-        // behind them (its vmcnt(0) then only waits for those); the piece outputs follow.
         float em_v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) em_v[r] = has_mask ? eh[r] * pm[r] : eh[r];
-        const bool rows_masked = em_rows && has_mask;
-        if (rows_masked) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) myxt[256 + (4 * q + r) * 16 + c] = em_v[r];
-        }
         const int rbg = em_rb0 + rb;                           // row block within the full batch
-        if (step != T - 1 || em_rows) {                        // (nobody reads the last state from the exchange)
-            __builtin_amdgcn_wave_barrier();                   // (the tiles are exchanged between lanes: see the backward kernel)
-            bf16x8 p0, p1, p2;
-            const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
-            if (lane < 32) {
-                pieces8(src, p0, p1, p2);
-                if (step != T - 1) publish_pieces(rs, (step & 1) * slot_bytes + pub_off, pb, p0, p1, p2);
+        if (!EM) {
+            if (step != T - 1) {                               // nobody reads the last state from the exchange
+                __builtin_amdgcn_wave_barrier();               // (the tile is exchanged between lanes: see the backward kernel)
+                if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
+                __builtin_amdgcn_wave_barrier();
+                arrive_rows(counter, lane);
             }
-            if (step != T - 1) arrive_rows(counter, lane);
-            if (em_rows && lane < 32) {
-                if (rows_masked) pieces8(src + 256, p0, p1, p2);
-                store_pieces(em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
-                                        (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16, em_rows_piece, p0, p1, p2);
+        } else {
+            // One pass through the wave's transpose tiles: tile 0 = the new state (the exchange's next operand), tile 1 = the
+            // masked state (the row pieces of the layer's output).  The exchange stores go first and the arrival right behind
+            // them (its vmcnt(0) then only waits for those); the piece outputs follow, re-read from the tiles.
+            const bool rows_masked = em_rows && has_mask;
+            if (rows_masked) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) myxt[256 + (4 * q + r) * 16 + c] = em_v[r];
             }
-            __builtin_amdgcn_wave_barrier();
+            if (step != T - 1 || em_rows) {
+                __builtin_amdgcn_wave_barrier();
+                const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
+                if (step != T - 1) {
+                    if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, src);
+                    arrive_rows(counter, lane);
+                }
+                if (em_rows && lane < 32) {
+                    bf16x8 p0, p1, p2;
+                    pieces8(rows_masked ? src + 256 : src, p0, p1, p2);
+                    store_pieces(em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
+                                            (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16, em_rows_piece, p0, p1, p2);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         if (em_colsA || em_colsB) {
             const long mb = (long)tt * (em_b16 >> 1) + (rbg >> 1);
@@ -341,12 +351,12 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward:  dh_t = dgh_{t+1} W_hh + dh_{t+1} z_{t+1} + dout_t ; gate derivatives; the exchange carries dgh (K = 3H)
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int WV, int S32, int NP>                   // S32 = 3H / 32 k blocks of the exchange
+template <int WV, int S32, int NP, bool EM>          // S32 = 3H / 32 k blocks of the exchange
 __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) {
     constexpr int H = 32 * S32 / 3, SH = H / 32;     // SH: k blocks per gate
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const wl = smem;                             // [3 pieces][S32][64][16 B]: W_hh^T columns j0..j0+15
-    constexpr int NTILE = WV == 4 ? 4 : 1;
+    constexpr int NTILE = EM ? 4 : 1;
     float* const xt = reinterpret_cast<float*>(smem + 3 * S32 * 1024);   // [WV][NTILE][256]: the wave's transpose tiles
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
@@ -405,15 +415,15 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
     float* const dghp = P.dgh; const int dgh_ts = P.dgh_ts ? (int)P.dgh_ts : B * 3 * H;
     float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
     const int rev = P.reverse, members = A.members;
-    unsigned char* const em_rows = NTILE > 1 ? P.em.rows : nullptr;      // (one-tile builds write no piece outputs)
-    unsigned char* const em_colsA = NTILE > 1 ? P.em.colsA : nullptr; unsigned char* const em_colsB = NTILE > 1 ? P.em.colsB : nullptr;
+    unsigned char* const em_rows = EM ? P.em.rows : nullptr;             // (the lean build writes no piece outputs)
+    unsigned char* const em_colsA = EM ? P.em.colsA : nullptr; unsigned char* const em_colsB = EM ? P.em.colsB : nullptr;
     const long em_rows_piece = P.em.rows_piece, em_colsA_piece = P.em.colsA_piece, em_colsB_piece = P.em.colsB_piece;
     const int em_rows_kb = P.em.rows_kb, em_rows_kb0 = P.em.rows_kb0, em_colsA_rb0 = P.em.colsA_rb0, em_colsB_rb0 = P.em.colsB_rb0;
     const int em_colsA_n = P.em.colsA_n;
-    const bool em_skip_dgi = NTILE > 1 && P.em.skip_dgi, em_skip_dgh = NTILE > 1 && P.em.skip_dgh;
+    const bool em_skip_dgi = EM && P.em.skip_dgi, em_skip_dgh = EM && P.em.skip_dgh;
     const int em_b16 = P.em.B_full >> 4, em_rb0 = P.em.r0 >> 4, em_kbm = T * (P.em.B_full >> 5);
-    kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
-                  em_colsA_rb0, em_colsB_rb0, em_colsA_n, em_b16, em_rb0, em_kbm);
+    if (EM) kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
+                          em_colsA_rb0, em_colsB_rb0, em_colsA_n, em_b16, em_rb0, em_kbm);
     const bool em_any = em_rows || em_colsA || em_colsB;
     for (int step = T - 1; step >= -1; --step) {
         const bool tail = step < 0;                            // dh0 = dgh(first step) W_hh + dhz
@@ -461,12 +471,12 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
             dhz[r] = dh * z;
             e_r[r] = dr_pre; e_z[r] = dz_pre; e_n[r] = dn_pre; e_nr[r] = dnr;
         }
-        // One pass through the wave's transpose tiles (NTILE = 4; a one-tile build takes them one after the other): the three
-        // gate gradients of the exchange (r, z, n*r) and, for the row pieces of dgi (ChainEmit), n.  The exchange stores go first
-        // and the arrival right behind them (its vmcnt(0) then only waits for those); the piece outputs follow.
         const bool pub = step != 0 || dh0p;                    // (nothing reads the last gate gradients unless dh0 is wanted)
         const int rbg = em_rb0 + rb;
-        if (NTILE > 1) {
+        if (EM) {
+            // One pass through the wave's four transpose tiles: the three gate gradients of the exchange (r, z, n*r) and, for
+            // the row pieces of dgi, n.  The exchange stores go first and the arrival right behind them (its vmcnt(0) then only
+            // waits for those); the piece outputs follow, re-read from the tiles (nothing is kept in registers across the arrival).
             if (pub || em_rows) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -474,43 +484,40 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
                     tp[0] = e_r[r]; tp[256] = e_z[r]; tp[512] = e_nr[r];
                     if (em_rows) tp[768] = e_n[r];
                 }
-                // The tiles are exchanged BETWEEN lanes: lanes 32..63 must not run ahead into the next step's writes while
-                // lanes 0..31 still have this step's reads in front of them.  The compiler reasons per thread and did exactly
-                // that (it hoisted the next tile's writes of the upper half-wave over the branch); the convergent wave barrier
-                // pins the order for the whole wave (the LDS itself executes one wave's operations in issue order).
-                __builtin_amdgcn_wave_barrier();
-                bf16x8 pr[3], pz[3], pn[3];
+                __builtin_amdgcn_wave_barrier();               // (the tiles are exchanged between lanes: see below)
                 const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
-                if (lane < 32) {
-                    pieces8(src, pr[0], pr[1], pr[2]);
-                    pieces8(src + 256, pz[0], pz[1], pz[2]);
-                    if (pub) {
-                        pieces8(src + 512, pn[0], pn[1], pn[2]);
+                if (pub) {
+                    if (lane < 32) {
                         const int off = (step & 1) * slot_bytes + pub_off;
-                        publish_pieces(rs, off, pb, pr[0], pr[1], pr[2]);
-                        publish_pieces(rs, off + SH * 1024, pb, pz[0], pz[1], pz[2]);
-                        publish_pieces(rs, off + 2 * SH * 1024, pb, pn[0], pn[1], pn[2]);
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) publish8(rs, off + g * SH * 1024, pb, src + g * 256);
                     }
+                    arrive_rows(counter, lane);
                 }
-                if (pub) arrive_rows(counter, lane);
                 if (em_rows && lane < 32) {
                     unsigned char* dst = em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
                                                     (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16;
-                    store_pieces(dst, em_rows_piece, pr[0], pr[1], pr[2]);
-                    store_pieces(dst + SH * 1024, em_rows_piece, pz[0], pz[1], pz[2]);
-                    pieces8(src + 768, pn[0], pn[1], pn[2]);
-                    store_pieces(dst + 2 * SH * 1024, em_rows_piece, pn[0], pn[1], pn[2]);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {              // dgi: r, z, n (tile 3)
+                        bf16x8 p0, p1, p2;
+                        pieces8(src + (g == 2 ? 768 : g * 256), p0, p1, p2);
+                        store_pieces(dst + g * SH * 1024, em_rows_piece, p0, p1, p2);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         } else if (pub) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {                      // gate by gate through the wave's one transpose tile
+            for (int g = 0; g < 3; ++g) {                      // gate by gate through the wave's transpose tile
 #pragma unroll
                 for (int r = 0; r < 4; ++r) myxt[(4 * q + r) * 16 + c] = g == 0 ? e_r[r] : (g == 1 ? e_z[r] : e_nr[r]);
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 32)
                     publish8(rs, (step & 1) * slot_bytes + pub_off + g * SH * 1024, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
+                // The tile is exchanged BETWEEN lanes: lanes 32..63 must not run ahead into the next gate's writes while
+                // lanes 0..31 still have this gate's reads in front of them.  The compiler reasons per thread and did exactly
+                // that (it hoisted the next tile's writes of the upper half-wave over the branch); the convergent wave barrier
+                // pins the order for the whole wave (the LDS itself executes one wave's operations in issue order).
                 __builtin_amdgcn_wave_barrier();
             }
             arrive_rows(counter, lane);
@@ -620,16 +627,24 @@ int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
     ProfScope prof(PROF_GRU_FWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))));
     const dim3 grid(chain::blocks_for(groups, a.members));
-    const size_t lds = (size_t)3 * 3 * (a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (wv == 4 ? 4 : 1);
-#define INET_C2F(W, S, N)                                                                                               \
+    bool em = false;                                           // piece outputs wanted (four-wave build only): the EM build
+    for (int i = 0; i < a.nprob; ++i) em = em || a.p[i].em.rows || a.p[i].em.colsA || a.p[i].em.colsB;
+    if (wv != 4) { em = false; for (int i = 0; i < a.nprob; ++i) a.p[i].em = ChainEmit{}; }
+    const size_t lds = (size_t)3 * 3 * (a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (em ? 4 : 1);
+#define INET_C2F_(W, S, N, E)                                                                                           \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_chain2_fwd_kernel<W, S, N>),                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_chain2_fwd_kernel<W, S, N, E>),                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((gru_chain2_fwd_kernel<W, S, N>), grid, dim3(64 * W), lds, s, a);                            \
+        hipLaunchKernelGGL((gru_chain2_fwd_kernel<W, S, N, E>), grid, dim3(64 * W), lds, s, a);                         \
+    } while (0)
+#define INET_C2F(W, S, N)                                                                                               \
+    do {                                                                                                                \
+        if (em && W == 4) INET_C2F_(4, S, N, true);                                                                     \
+        else INET_C2F_(W, S, N, false);                                                                                 \
     } while (0)
     if (a.H == 512) {
         if (wv == 4) { if (np == 9) INET_C2F(4, 16, 9); else INET_C2F(4, 16, 6); }
@@ -639,6 +654,7 @@ int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
         else { if (np == 9) INET_C2F(8, 8, 9); else INET_C2F(8, 8, 6); }
     }
 #undef INET_C2F
+#undef INET_C2F_
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -659,16 +675,24 @@ int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s) {
     ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)));
     const dim3 grid(chain::blocks_for(groups, a.members));
-    const size_t lds = (size_t)3 * (3 * a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (wv == 4 ? 4 : 1);
-#define INET_C2B(W, S, N)                                                                                               \
+    bool em = false;
+    for (int i = 0; i < a.nprob; ++i) em = em || a.p[i].em.rows || a.p[i].em.colsA || a.p[i].em.colsB;
+    if (wv != 4) { em = false; for (int i = 0; i < a.nprob; ++i) a.p[i].em = ChainEmit{}; }
+    const size_t lds = (size_t)3 * (3 * a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (em ? 4 : 1);
+#define INET_C2B_(W, S, N, E)                                                                                           \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_chain2_bwd_kernel<W, S, N>),                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_chain2_bwd_kernel<W, S, N, E>),                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((gru_chain2_bwd_kernel<W, S, N>), grid, dim3(64 * W), lds, s, a);                            \
+        hipLaunchKernelGGL((gru_chain2_bwd_kernel<W, S, N, E>), grid, dim3(64 * W), lds, s, a);                         \
+    } while (0)
+#define INET_C2B(W, S, N)                                                                                               \
+    do {                                                                                                                \
+        if (em && W == 4) INET_C2B_(4, S, N, true);                                                                     \
+        else INET_C2B_(W, S, N, false);                                                                                 \
     } while (0)
     if (a.H == 512) {
         if (wv == 4) { if (np == 9) INET_C2B(4, 48, 9); else INET_C2B(4, 48, 6); }
@@ -678,5 +702,6 @@ int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s) {
         else { if (np == 9) INET_C2B(8, 24, 9); else INET_C2B(8, 24, 6); }
     }
 #undef INET_C2B
+#undef INET_C2B_
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
