@@ -37,6 +37,15 @@ static int emit_mask() {
     return m;
 }
 
+// which layers' weight gradients run on the bf16 pipe (bit 0: layer 1, bit 1: layer 0): the others stay on the LDS-free
+// f32-input kernels.  Measured in one call (profiles/r03_t_wgrad_pipe.txt): 3.75 / 3.72 / 3.85 / 3.82 ms per step for both /
+// layer 1 only / layer 0 only / neither -- layer 0's product is the last kernel of the backward pass, and what its bf16 form
+// saves (172 -> 118 us) the layer-0 chains pay for writing its operands (the transposed gate gradients and previous states).
+static int wgrad_mask() {
+    static const int m = [] { const char* v = std::getenv("INET_BF3_WGRAD"); return v ? std::atoi(v) : 1; }();
+    return m;
+}
+
 bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save) {
     if (!pk_ok(H) || B % 32) return false;
     if (gru_chain_ok(H, B, T, nd)) return gru_chain_fwd_is_v2(H, B, T, nd, 0) && gru_chain2_emits(H, B, T, nd);
@@ -392,8 +401,8 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
             D.em.rows = w.x1pk; D.em.rows_piece = (long)bf3_piece_bytes(TBl, 2 * H); D.em.rows_kb = 2 * H / 32; D.em.rows_kb0 = dir * H / 32;
         }
         if (bf3f && save && w.x1T && w.hpT[dir] && (emit_mask() & 2)) {   // the weight gradients' B operands (read by the backward call)
-            D.em.colsA = w.x1T; D.em.colsA_piece = (long)bf3_piece_bytes(2 * H, TBl); D.em.colsA_rb0 = dir * H / 16;
-            D.em.colsB = w.hpT[dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0;
+            if (wgrad_mask() & 1) { D.em.colsA = w.x1T; D.em.colsA_piece = (long)bf3_piece_bytes(2 * H, TBl); D.em.colsA_rb0 = dir * H / 16; }
+            if (wgrad_mask() & 2) { D.em.colsB = w.hpT[dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0; }
         }
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
@@ -429,7 +438,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         D.reverse = dir;
         D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir];
         D.sync = one_launch ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = one_launch;
-        if (bf3f && save && w.hpT[2 + dir] && (emit_mask() & 2)) {
+        if (bf3f && save && w.hpT[2 + dir] && (emit_mask() & 2) && (wgrad_mask() & 1)) {
             D.em.colsB = w.hpT[2 + dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0;
         }
     }
@@ -506,7 +515,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
             D.em.rows = w.dgi1pk; D.em.rows_piece = (long)bf3_piece_bytes((long)T * B, 6 * H); D.em.rows_kb = 6 * H / 32;
             D.em.rows_kb0 = dir * 3 * H / 32;
         }
-        if (bf3w_pre && (emit_mask() & 8)) {
+        if (bf3w_pre && (emit_mask() & 8) && (wgrad_mask() & 1)) {
             D.em.colsA = w.gT[1]; D.em.colsA_piece = (long)bf3_piece_bytes(6 * H, (long)T * B); D.em.colsA_rb0 = dir * 3 * H / 16; D.em.colsA_n = 1;
             D.em.colsB = w.nrT[2 + dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, (long)T * B); D.em.colsB_rb0 = 0;
             D.em.skip_dgh = 1;                                 // (its only reader was the weight-gradient product)
@@ -526,7 +535,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
-            if (nt == T && bf3w) {                           // both directions of a product in one launch (gemm_bf3.hip)
+            if (nt == T && bf3w && (wgrad_mask() & 1)) {      // both directions of a product in one launch (gemm_bf3.hip)
                 const bool gem = d[0].emitted && d[1].emitted && (emit_mask() & 8);
                 INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 1, P, w, w.dgi1, true, gem, fwd_emitted, ss));
                 // dW_ih_d [3H, 2H] += dgi1_d^T x1: the transposed gate gradients are the ones just made
@@ -593,7 +602,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[dir]; D.dghpk = w.dghpk[dir];
         D.W_hh = P[dir].w_hh; D.sync = chained ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = chained;
-        if (bf3w_pre && (emit_mask() & 8)) {
+        if (bf3w_pre && (emit_mask() & 8) && (wgrad_mask() & 2)) {
             D.em.colsA = w.gT[0]; D.em.colsA_piece = (long)bf3_piece_bytes(6 * H, (long)T * B); D.em.colsA_rb0 = dir * 3 * H / 16; D.em.colsA_n = 0;
             D.em.colsB = w.nrT[dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, (long)T * B); D.em.colsB_rb0 = 0;
             D.em.skip_dgh = 1;                                 // (dgi0 still feeds the embedding / table gradients)
@@ -604,7 +613,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
             hipStream_t ss = side_fork(s);
-            if (hi - lo + 1 == T && bf3w)
+            if (hi - lo + 1 == T && bf3w && (wgrad_mask() & 2))
                 INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 0, P, w, w.dgi0, false, d[0].emitted && d[1].emitted && (emit_mask() & 8), fwd_emitted, ss));
             else if (hi - lo + 1 == T)
                 INET_TRY(linear_wgrad2(w.dgh[0], w.dgh[1], 3L * H, w.sv[0] + 4 * TBH, w.sv[1] + 4 * TBH, H, P[0].dw_hh,

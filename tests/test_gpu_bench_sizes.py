@@ -105,8 +105,8 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     # directions' layer-1 input products as one N = 6H product, their data gradient as one K = 6H product (e4: dropout mask
     # epilogue), the weight gradients two directions per launch; the decoder's on the LDS-free f32-input direct kernels
     for wl in () if B != 256 else ("M6144 N3072 K1024 bf3p9 t192x192 s1 e0", "M6144 N1024 K3072 bf3p9 t192x128 s1 e4",
-               "M1536 N512 K6144 bf3p9 t192x128 s4 e0 x2", "M1536 N1024 K6144 bf3p9 t192x128 s2 e0 x2",
-               "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N512 K6144 TN d192x128 s4 e0 x2",
+               "M1536 N512 K6144 bf3p9 t192x128 s4 e0 x2", "M1536 N1024 K6144 bf3p9 t192x128 s2 e0 x2",      # layer 1's
+               "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N512 K6144 TN d192x128 s4 e0 x2",                 # layer 0's, the decoder's
                "group2 M256 N1024 K2048 NT k64x32 e1"):                                        # both SELU heads in one grouped split-K launch
         assert wl in labels, (wl, big)
     if B == 256:     # the chains wrote the pieces themselves: the only split launches left are the layer-1 input weights'
