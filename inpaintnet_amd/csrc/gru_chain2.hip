@@ -307,25 +307,25 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
             // masked state (the row pieces of the layer's output).  The exchange stores go first and the arrival right behind
             // them (its vmcnt(0) then only waits for those); the piece outputs follow, re-read from the tiles.
             const bool rows_masked = em_rows && has_mask;
-            if (rows_masked) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) myxt[256 + (4 * q + r) * 16 + c] = em_v[r];
-            }
-            if (step != T - 1 || em_rows) {
+            if (step != T - 1) {
                 __builtin_amdgcn_wave_barrier();
-                const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
-                if (step != T - 1) {
-                    if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, src);
-                    arrive_rows(counter, lane);
+                if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
+                arrive_rows(counter, lane);
+            }
+            if (em_rows) {                                     // (everything below is behind the hand-off)
+                if (rows_masked) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) myxt[256 + (4 * q + r) * 16 + c] = em_v[r];
                 }
-                if (em_rows && lane < 32) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) {
                     bf16x8 p0, p1, p2;
-                    pieces8(rows_masked ? src + 256 : src, p0, p1, p2);
+                    pieces8(myxt + (rows_masked ? 256 : 0) + (lane & 15) * 16 + 8 * (lane >> 4), p0, p1, p2);
                     store_pieces(em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
                                             (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16, em_rows_piece, p0, p1, p2);
                 }
-                __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_wave_barrier();
         }
         if (em_colsA || em_colsB) {
             const long mb = (long)tt * (em_b16 >> 1) + (rbg >> 1);
@@ -482,7 +482,6 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
                 for (int r = 0; r < 4; ++r) {
                     float* tp = myxt + (4 * q + r) * 16 + c;
                     tp[0] = e_r[r]; tp[256] = e_z[r]; tp[512] = e_nr[r];
-                    if (em_rows) tp[768] = e_n[r];
                 }
                 __builtin_amdgcn_wave_barrier();               // (the tiles are exchanged between lanes: see below)
                 const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
@@ -494,14 +493,19 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
                     }
                     arrive_rows(counter, lane);
                 }
-                if (em_rows && lane < 32) {
-                    unsigned char* dst = em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
-                                                    (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16;
+                if (em_rows) {                                 // (behind the hand-off: the fourth tile, n, and the row pieces of dgi)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) {              // dgi: r, z, n (tile 3)
-                        bf16x8 p0, p1, p2;
-                        pieces8(src + (g == 2 ? 768 : g * 256), p0, p1, p2);
-                        store_pieces(dst + g * SH * 1024, em_rows_piece, p0, p1, p2);
+                    for (int r = 0; r < 4; ++r) myxt[768 + (4 * q + r) * 16 + c] = e_n[r];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 32) {
+                        unsigned char* dst = em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
+                                                        (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16;
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {          // dgi: r, z, n (tile 3)
+                            bf16x8 p0, p1, p2;
+                            pieces8(src + (g == 2 ? 768 : g * 256), p0, p1, p2);
+                            store_pieces(dst + g * SH * 1024, em_rows_piece, p0, p1, p2);
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
