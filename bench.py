@@ -371,7 +371,7 @@ def piece_products(label):
     """bf16 piece products per f32 product of a kernel label (csrc/gemm_bf3.hip 'bf3p9', csrc/gru_chain2.hip 'v2w4 p9'), 0 for
     the f32-input MFMA kernels."""
     import re
-    m = re.search(r"\bbf3p(\d)\b", label) or re.search(r" v2w\d+ p(\d) ", label)
+    m = re.search(r"\bbf3p(\d)\b", label) or re.search(r" v2w\d+e? p(\d) ", label)
     return int(m.group(1)) if m else 0
 
 
@@ -412,13 +412,14 @@ def pmc_key(label):
     import re
     f = {k: int(v) for k, v in re.findall(r"\b(ms|np|nc|pk|x|T|B|H|M|N|K|s)(\d+)", label)}
     tf = lambda v: "true" if v else "false"
-    m2 = re.match(r"gru_chain_(fwd|bwd) v2w(\d+) p(\d+) np(\d+) T(\d+) B(\d+) H(\d+)", label)
+    m2 = re.match(r"gru_chain_(fwd|bwd) v2w(\d+)(e?) p(\d+) np(\d+) T(\d+) B(\d+) H(\d+)", label)
     if m2:                                               # second generation (csrc/gru_chain2.hip): waves per workgroup, piece products
-        kind, wv, npp, nprob, _, B_, H = m2.group(1), *[int(x) for x in m2.groups()[1:]]
+        em = m2.group(3) == "e"                          # ("e": the build that writes the ChainEmit piece outputs)
+        kind, (wv, npp, nprob, _, B_, H) = m2.group(1), [int(x) for x in (m2.group(2),) + m2.groups()[3:]]
         groups = nprob * math.ceil(math.ceil(B_ / 16) / wv)
         grid = 64 * wv * 8 * (H // 16) * math.ceil(groups / 8)
         s32 = H // 32 if kind == "fwd" else 3 * H // 32
-        return f"gru_chain2_{kind}_kernel<{wv}, {s32}, {npp}>|g{grid}"
+        return f"gru_chain2_{kind}_kernel<{wv}, {s32}, {npp}, {tf(em)}>|g{grid}"
     if label.startswith("gru_chain_fwd") or label.startswith("gru_chain_bwd"):
         fwd = label.startswith("gru_chain_fwd")
         H, ms = f["H"], f["ms"]

@@ -625,15 +625,18 @@ int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status = chain_status_for(a.counters + kChainStatusWord);
     const int np = chain2_mode();
-    char label[72];
-    std::snprintf(label, sizeof label, "gru_chain_fwd v2w%d p%d np%d T%d B%d H%d", wv, np, a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;
-    ProfScope prof(PROF_GRU_FWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
-                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))));
-    const dim3 grid(chain::blocks_for(groups, a.members));
     bool em = false;                                           // piece outputs wanted (four-wave build only): the EM build
     for (int i = 0; i < a.nprob; ++i) em = em || a.p[i].em.rows || a.p[i].em.colsA || a.p[i].em.colsB;
     if (wv != 4) { em = false; for (int i = 0; i < a.nprob; ++i) a.p[i].em = ChainEmit{}; }
+    char label[72];                                            // "v2w4e": the build that writes piece outputs
+    std::snprintf(label, sizeof label, "gru_chain_fwd v2w%d%s p%d np%d T%d B%d H%d", wv, em ? "e" : "", np, a.nprob, a.T, a.B, a.H);
+    double em_bytes = 0.0;                                     // piece outputs: 6 bytes per element and layout
+    for (int i = 0; i < a.nprob; ++i)
+        em_bytes += 6.0 * a.T * a.B * a.H * ((a.p[i].em.rows ? 1 : 0) + (a.p[i].em.colsA ? 1 : 0) + (a.p[i].em.colsB ? 1 : 0));
+    ProfScope prof(PROF_GRU_FWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
+                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))) + em_bytes);
+    const dim3 grid(chain::blocks_for(groups, a.members));
     const size_t lds = (size_t)3 * 3 * (a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (em ? 4 : 1);
 #define INET_C2F_(W, S, N, E)                                                                                           \
     do {                                                                                                                \
@@ -673,15 +676,21 @@ int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s) {
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status = chain_status_for(a.counters + kChainStatusWord);
     const int np = chain2_mode();
-    char label[72];
-    std::snprintf(label, sizeof label, "gru_chain_bwd v2w%d p%d np%d T%d B%d H%d", wv, np, a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;
-    ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
-                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)));
-    const dim3 grid(chain::blocks_for(groups, a.members));
     bool em = false;
     for (int i = 0; i < a.nprob; ++i) em = em || a.p[i].em.rows || a.p[i].em.colsA || a.p[i].em.colsB;
     if (wv != 4) { em = false; for (int i = 0; i < a.nprob; ++i) a.p[i].em = ChainEmit{}; }
+    char label[72];
+    std::snprintf(label, sizeof label, "gru_chain_bwd v2w%d%s p%d np%d T%d B%d H%d", wv, em ? "e" : "", np, a.nprob, a.T, a.B, a.H);
+    double em_bytes = 0.0;                                     // piece outputs (6 bytes per element and layout) minus the f32 arrays not written
+    for (int i = 0; i < a.nprob; ++i) {
+        const ChainEmit& e = a.p[i].em;
+        em_bytes += (double)a.T * a.B * a.H * (6.0 * ((e.rows ? 3 : 0) + (e.colsA ? (e.colsA_n ? 3 : 2) : 0) + (e.colsB ? 1 : 0)) -
+                                               4.0 * ((e.skip_dgi ? 3 : 0) + (e.skip_dgh ? 3 : 0)));
+    }
+    ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
+                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)) + em_bytes);
+    const dim3 grid(chain::blocks_for(groups, a.members));
     const size_t lds = (size_t)3 * (3 * a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (em ? 4 : 1);
 #define INET_C2B_(W, S, N, E)                                                                                           \
     do {                                                                                                                \

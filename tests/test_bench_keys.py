@@ -32,9 +32,11 @@ def bench():
     ("gru_chain_fwd ms4 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 1>|g65536"),
     ("gru_chain_fwd ms4x2 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 2>|g65536"),         # two launches per CU
     ("gru_chain_bwd ms8 np4 T6 B256 H512", "gru_chain_bwd_kernel<8, 24>|g65536"),
-    ("gru_chain_fwd v2w4 p9 np2 T24 B256 H512", "gru_chain2_fwd_kernel<4, 16, 9>|g65536"),      # second generation
-    ("gru_chain_bwd v2w4 p6 np2 T24 B256 H512", "gru_chain2_bwd_kernel<4, 48, 6>|g65536"),
-    ("gru_chain_fwd v2w4 p9 np2 T6 B128 H256", "gru_chain2_fwd_kernel<4, 8, 9>|g32768"),
+    ("gru_chain_fwd v2w4 p9 np2 T24 B256 H512", "gru_chain2_fwd_kernel<4, 16, 9, false>|g65536"),      # second generation
+    ("gru_chain_fwd v2w4e p9 np2 T24 B256 H512", "gru_chain2_fwd_kernel<4, 16, 9, true>|g65536"),     # ... the build that writes piece outputs
+    ("gru_chain_bwd v2w4e p9 np2 T24 B256 H512", "gru_chain2_bwd_kernel<4, 48, 9, true>|g65536"),
+    ("gru_chain_bwd v2w4 p6 np2 T24 B256 H512", "gru_chain2_bwd_kernel<4, 48, 6, false>|g65536"),
+    ("gru_chain_fwd v2w4 p9 np2 T6 B128 H256", "gru_chain2_fwd_kernel<4, 8, 9, false>|g32768"),
     ("gru_chain_bwd ms2 np2 T6 B128 H512", "gru_chain_bwd_kernel<2, 24>|g65536"),
     ("adam", "adam_kernel|"),
 ])
@@ -57,5 +59,6 @@ def test_piece_products_of_labels(bench):
     assert bench.piece_products("M6144 N3072 K1024 bf3p9 t192x192 s1 e0") == 9
     assert bench.piece_products("M1536 N1024 K6144 bf3p6 t192x128 s2 e0 x2") == 6
     assert bench.piece_products("gru_chain_bwd v2w4 p9 np2 T24 B256 H512") == 9
+    assert bench.piece_products("gru_chain_bwd v2w4e p9 np2 T24 B256 H512") == 9
     assert bench.piece_products("gru_chain_fwd ms4 np2 T24 B256 H512") == 0
     assert bench.piece_products("M1536 N512 K6144 TN d192x128 s4 e0 x2") == 0

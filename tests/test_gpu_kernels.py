@@ -658,8 +658,8 @@ def test_chain_generations_against_float64():
                 ops.prof_dump(td + "/l.csv")
                 labels = [r["label"] for r in csv.DictReader(open(td + "/l.csv"))]
             ops.prof_enable(False)
-            tag = "gru_chain_fwd ms" if mode == 0 else f"gru_chain_fwd v2w4 p{mode}"
-            assert any(l.startswith(tag) for l in labels), (mode, sorted(set(l for l in labels if l.startswith("gru"))))
+            tags = ("gru_chain_fwd ms",) if mode == 0 else (f"gru_chain_fwd v2w4 p{mode}", f"gru_chain_fwd v2w4e p{mode}")   # (e: writes piece outputs)
+            assert any(l.startswith(tags) for l in labels), (mode, sorted(set(l for l in labels if l.startswith("gru"))))
             got = {"out": o.cpu(), "hn": h.cpu(), "dx": dx.cpu()}
             for k, (off, sh) in offs.items():
                 got["d" + k] = grads[off:off + P[k].numel()].reshape(sh).cpu()
