@@ -46,6 +46,16 @@ static int wgrad_mask() {
     return m;
 }
 
+// Where layer 1's bf16-pipe weight gradients run: 0 = on a side stream (beside the data gradient and the layer-0 BPTT chain;
+// default), 1 = on the caller's stream between the data gradient and the layer-0 chain.  gemm_bf3 workgroups (120-144 KB of LDS)
+// and second-generation chain workgroups (148-160 KB) cannot share a CU, and in the kernel TRACE the two collide badly (the 203 us
+// product 808 us, the 265 us chain 616 us: profiles/r03_s_timeline_full_step.txt) -- untraced, the side stream is the faster
+// place all the same: 3.61 / 3.62 ms per step against 3.70 / 3.69 on the caller's stream (profiles/r03_t_wgrad_pipe.txt).
+static int wgrad_at() {
+    static const int m = [] { const char* v = std::getenv("INET_BF3_WGRAD_AT"); return v ? std::atoi(v) : 0; }();
+    return m;
+}
+
 bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save) {
     if (!pk_ok(H) || B % 32) return false;
     if (gru_chain_ok(H, B, T, nd)) return gru_chain_fwd_is_v2(H, B, T, nd, 0) && gru_chain2_emits(H, B, T, nd);
@@ -528,6 +538,22 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     // chip busy, and smaller-K products are less efficient -- so one chunk.
     const int CH = T;
     const float* x1 = mask ? w.x1m : w.x1raw;
+    bool l1_gem = false, l1_wgrads_pending = false;
+    // layer 1's weight gradients on the bf16 pipe: dW_hh (both directions), then dW_ih_d [3H, 2H] += dgi1_d^T x1 on the transposed
+    // gate gradients just made
+    auto l1_wgrads_bf3 = [&](hipStream_t ss) -> int {
+        INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 1, P, w, w.dgi1, true, l1_gem, fwd_emitted, ss));
+        const long TBl = (long)T * B;
+        const long gp = (long)bf3_piece_bytes(6 * H, TBl), xp = (long)bf3_piece_bytes(2 * H, TBl);
+        const int KB = (int)(TBl / 32);
+        if (!fwd_emitted) INET_TRY(bf3_split(x1, 2L * H, 1, 2 * H, (int)TBl, nullptr, 0, w.x1T, xp, KB, 0, 0, ss));
+        Bf3Gemm g{};
+        g.A = w.gT[1]; g.A2 = w.gT[1] + (long)(3 * H / 16) * KB * 1024; g.a_piece = gp; g.a_kb = KB;
+        g.B = w.x1T; g.B2 = w.x1T; g.b_piece = xp; g.b_kb = KB;
+        g.C = P[2].dw_ih; g.C2 = P[3].dw_ih; g.ldc = 2L * H;
+        g.M = 3 * H; g.N = 2 * H; g.K = (int)TBl; g.epi = EPI_NONE; g.acc = ACC_ADD; g.nbatch = 2;
+        return launch_gemm_bf3(g, ss);
+    };
     const bool bf3d = bf3_mode() != 0 && w.dgi1pk && w.wih1Tpk && gemm_bf3_ok(T * B, 2 * H, 6 * H);
     const bool bf3w = bf3_mode() != 0 && w.gT[0] && w.hpT[0] && wg;
     for (int hi = T - 1; hi >= 0 && stage != 2; hi -= CH) {
@@ -536,19 +562,9 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
             if (nt == T && bf3w && (wgrad_mask() & 1)) {      // both directions of a product in one launch (gemm_bf3.hip)
-                const bool gem = d[0].emitted && d[1].emitted && (emit_mask() & 8);
-                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 1, P, w, w.dgi1, true, gem, fwd_emitted, ss));
-                // dW_ih_d [3H, 2H] += dgi1_d^T x1: the transposed gate gradients are the ones just made
-                const long TBl = (long)T * B;
-                const long gp = (long)bf3_piece_bytes(6 * H, TBl), xp = (long)bf3_piece_bytes(2 * H, TBl);
-                const int KB = (int)(TBl / 32);
-                if (!fwd_emitted) INET_TRY(bf3_split(x1, 2L * H, 1, 2 * H, (int)TBl, nullptr, 0, w.x1T, xp, KB, 0, 0, ss));
-                Bf3Gemm g{};
-                g.A = w.gT[1]; g.A2 = w.gT[1] + (long)(3 * H / 16) * KB * 1024; g.a_piece = gp; g.a_kb = KB;
-                g.B = w.x1T; g.B2 = w.x1T; g.b_piece = xp; g.b_kb = KB;
-                g.C = P[2].dw_ih; g.C2 = P[3].dw_ih; g.ldc = 2L * H;
-                g.M = 3 * H; g.N = 2 * H; g.K = (int)TBl; g.epi = EPI_NONE; g.acc = ACC_ADD; g.nbatch = 2;
-                INET_TRY(launch_gemm_bf3(g, ss));
+                l1_gem = d[0].emitted && d[1].emitted && (emit_mask() & 8);
+                if (wgrad_at() == 0) INET_TRY(l1_wgrads_bf3(ss));
+                else l1_wgrads_pending = true;               // (on the main stream, behind the data gradient: see wgrad_at)
             } else if (nt == T) {                            // both directions of a product in one launch
                 INET_TRY(linear_wgrad2(w.dgh[2], w.dgh[3], 3L * H, w.sv[2] + 4 * TBH, w.sv[3] + 4 * TBH, H, P[2].dw_hh,
                                        P[3].dw_hh, H, T * B, 3 * H, H, ss));
@@ -585,6 +601,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(linear_dgrad(dgi, 6L * H, P[2 + dir].w_ih, 2L * H, w.dx1, 2L * H, T * B, 3 * H, 2 * H,
                               mask ? EPI_MUL_AUX : EPI_NONE, mask, 2L * H, dir == 0 ? ACC_STORE : ACC_ADD, s));
     }
+    if (l1_wgrads_pending) INET_TRY(l1_wgrads_bf3(s));
     if (stage == 1) return 0;
     // ---- layer 0 ----
     for (int dir = 0; dir < 2; ++dir) {
