@@ -186,14 +186,17 @@ def parity_check(model, tokens_dev):
         lr.backward()
         worst[f"loss_{tag}"] = abs(loss - lr.item()) / abs(lr.item())
         worst[f"logits_{tag}"] = float((w.cpu() - wr.detach()).abs().max() / wr.detach().abs().max())
-        gerr, gname = 0.0, ""
+        gerr, gname, gnext = 0.0, "", 0.0                       # (worst tensor, and the worst of all the others)
         for name, off, shape in model._table:
             gr = Pr[name].grad
             e = float((grads[off:off + gr.numel()].view(shape).cpu() - gr).abs().max() / (gr.abs().max() + 1e-12))
             if e > gerr:
-                gerr, gname = e, name
+                gerr, gname, gnext = e, name, gerr
+            elif e > gnext:
+                gnext = e
         worst[f"grads_{tag}"] = gerr
         worst[f"grads_{tag}_worst_tensor"] = gname
+        worst[f"grads_{tag}_all_other_tensors"] = gnext
         top2 = torch.topk(wr.detach(), 2, dim=-1).values
         ok = (top2[..., 0] - top2[..., 1]) > 1e-4
         worst[f"token_mismatch_{tag}"] = int((s.cpu()[:, 0][ok] != sr[:, 0][ok]).sum())

@@ -378,15 +378,19 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
     // The layer-1 input weights as bf16 pieces (both directions stacked: the forward products' B operand; with saves also
     // k-major, the data gradient's B operand of the backward call -- the weights do not change in between): on the side
     // stream, under the layer-0 chain.
-    hipStream_t wss = s;
+    // (Two forks: the k-major split stages through LDS and cannot start beside a chain workgroup that holds all of it; only the
+    //  row split gates the forward product, the other is joined at the end of this call.)
+    hipStream_t wss = s, wss2 = s;
     if (bf3f) {
         wss = side_fork(s);
         const long wp = (long)bf3_piece_bytes(6 * H, 2 * H), wpT = (long)bf3_piece_bytes(2 * H, 6 * H);
         for (int dir = 0; dir < 2; ++dir)
             INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 0, 3 * H, 2 * H, nullptr, 0, w.wih1pk, wp, 2 * H / 32, dir * 3 * H / 16, 0, wss));
-        if (save && w.wih1Tpk)
+        if (save && w.wih1Tpk) {
+            wss2 = side_fork(s);
             for (int dir = 0; dir < 2; ++dir)
-                INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 1, 2 * H, 3 * H, nullptr, 0, w.wih1Tpk, wpT, 6 * H / 32, 0, dir * 3 * H / 32, wss));
+                INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 1, 2 * H, 3 * H, nullptr, 0, w.wih1Tpk, wpT, 6 * H / 32, 0, dir * 3 * H / 32, wss2));
+        }
     }
     DirFwd d[2];
     for (int dir = 0; dir < 2; ++dir) {
@@ -453,6 +457,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         }
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
+    if (wss2 != s) INET_TRY(stream_wait(s, wss2));             // the k-major weight pieces: read by the backward call on this stream
     return 0;
 }
 
