@@ -341,7 +341,9 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
         w.dghpk[i] = pk && save ? c.take<float>(chain_ring_floats(B, 3 * H)) : nullptr;
     }
     w.sync = c.take<unsigned>(kSyncAreas * kChainSyncWords);
-    const bool bf3 = gemm_bf3_ok(T * B, 6 * H, 2 * H);
+    // The bf16-pipe products (gemm_bf3.hip) tile 192 rows x 192 / 128 columns: below ~3072 rows (T*B) a launch leaves most CUs idle
+    // (LatentRNN's context GRUs, T*B = 768: 27-52 TFLOP/s against 65-105 on the f32-input kernels) -- those stay on gemm.hip.
+    const bool bf3 = gemm_bf3_ok(T * B, 6 * H, 2 * H) && (long)T * B >= 3072;
     w.x1pk = bf3 ? c.take<unsigned char>(bf3_bytes((long)T * B, 2 * H)) : nullptr;
     w.wih1pk = bf3 ? c.take<unsigned char>(bf3_bytes(6 * H, 2 * H)) : nullptr;
     const bool bf3b = bf3 && save && gemm_bf3_ok(T * B, 2 * H, 6 * H);
