@@ -492,6 +492,8 @@ def roofline(step):
            "achieved": top["tflops"] if mfma_bound else top["gbps"],
            "peak": top["peak_tflops"] if mfma_bound else PEAK_HBM_GBPS,
            "mfma_pipe": top["mfma_pipe"],
+           # continuity with rounds 1-2, which priced every kernel against the f32-input MFMA peak
+           "frac_of_f32_input_peak": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
            "unit": "TFLOP/s" if mfma_bound else "GB/s",
            "frac": top["frac_mfma"] if mfma_bound else top["frac_hbm"],
            "traffic": top.get("traffic_mbytes_per_launch"),
