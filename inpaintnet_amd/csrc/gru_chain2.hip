@@ -25,6 +25,9 @@
 
 namespace {
 
+#ifndef INET_EM_TOUCH
+#define INET_EM_TOUCH 0           // 1: the ChainEmit descriptor is pinned in SGPRs before the step loop (27 spilled SGPRs in the forward build)
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 using chain::u32x4;
 
@@ -70,15 +73,16 @@ __device__ __forceinline__ void store_pieces(unsigned char* dst, long piece, bf1
 }
 // One 16 x 16 tile of a wave in the accumulator layout (lane (c, q): rows 4q .. 4q+3 of unit c) -> its half of the transposed
 // fragment (unit block, 32-row m block): fragment lane (kg, unit c) holds rows 8 kg .. 8 kg + 7 of the m block; this wave's
-// 16 rows are the m block's half `par`.  Lanes of even q take the four rows of lane + 16 (q + 1) next to their own.
-__device__ __forceinline__ void emit_cols(unsigned char* frag, long piece, const float (&v)[4], int q, int c, int par) {
+// 16 rows are the m block's half `par`: dst_lane = the fragment + ((2 par + q / 2) * 16 + c) * 16 (meaningful for even q).
+// Lanes of even q take the four rows of lane + 16 (q + 1) next to their own.
+__device__ __forceinline__ void emit_cols(unsigned char* dst_lane, long piece, const float (&v)[4], int q) {
     float x[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { x[r] = v[r]; x[4 + r] = __shfl_down(v[r], 16, 64); }
     if (!(q & 1)) {
         bf16x8 p0, p1, p2;
         pieces8(x, p0, p1, p2);
-        store_pieces(frag + ((2 * par + (q >> 1)) * 16 + c) * 16, piece, p0, p1, p2);
+        store_pieces(dst_lane, piece, p0, p1, p2);
     }
 }
 
@@ -246,14 +250,18 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
     float* const hlastp = P.hlast; const int hlast_ld = (int)P.ld_hlast;
     const int rev = P.reverse, members = A.members;
     // piece outputs (ChainEmit): the descriptor in SGPRs before the loop (kernarg reads sink to their first use otherwise)
-    unsigned char* const em_rows = EM ? P.em.rows : nullptr;             // (the lean build writes no piece outputs)
-    unsigned char* const em_colsA = EM ? P.em.colsA : nullptr; unsigned char* const em_colsB = EM ? P.em.colsB : nullptr;
+    // The descriptor is folded into one destination pointer per lane and layout (time step 0) plus two byte strides per time
+    // step: kept as 13 scalars it spilled 27 SGPRs in this kernel.
+    const bool em_rows = EM && P.em.rows, em_colsA = EM && P.em.colsA, em_colsB = EM && P.em.colsB;   // (the lean build writes no piece outputs)
     const long em_rows_piece = P.em.rows_piece, em_colsA_piece = P.em.colsA_piece, em_colsB_piece = P.em.colsB_piece;
-    const int em_rows_kb = P.em.rows_kb, em_rows_kb0 = P.em.rows_kb0, em_colsA_rb0 = P.em.colsA_rb0, em_colsB_rb0 = P.em.colsB_rb0;
-    const int em_b16 = P.em.B_full >> 4, em_rb0 = P.em.r0 >> 4, em_kbm = T * (P.em.B_full >> 5);
-    if (EM) kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
-                          em_colsA_rb0, em_colsB_rb0, em_b16, em_rb0, em_kbm);
-    const bool em_any = em_rows || em_colsA || em_colsB;
+    const int em_b16 = P.em.B_full >> 4, em_kbm = T * (P.em.B_full >> 5);
+    const int rbg = (P.em.r0 >> 4) + rb;                       // row block within the full batch
+    const int em_rows_tstride = em_b16 * P.em.rows_kb * 1024, em_cols_tstride = (em_b16 >> 1) * 1024;
+    unsigned char* const em_rows_lane = !em_rows ? nullptr :   // (lanes 0..31: row lane % 16, k half lane / 16 of this member's 16 columns)
+        P.em.rows + (((long)rbg * P.em.rows_kb + P.em.rows_kb0 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
+    const int em_cl = ((2 * (rbg & 1) + (q >> 1)) * 16 + c) * 16;   // this lane inside a transposed fragment
+    unsigned char* const em_colsA_lane = !em_colsA ? nullptr : P.em.colsA + ((long)(P.em.colsA_rb0 + member) * em_kbm + (rbg >> 1)) * 1024 + em_cl;
+    unsigned char* const em_colsB_lane = !em_colsB ? nullptr : P.em.colsB + ((long)(P.em.colsB_rb0 + member) * em_kbm + (rbg >> 1)) * 1024 + em_cl;
     long tok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) tok[r] = idxp[brow[r] * idx_bs + (rev ? T - 1 : 0) * idx_ts];
@@ -294,7 +302,6 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
         float em_v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) em_v[r] = has_mask ? eh[r] * pm[r] : eh[r];
-        const int rbg = em_rb0 + rb;                           // row block within the full batch
         if (!EM) {
             if (step != T - 1) {                               // nobody reads the last state from the exchange
                 __builtin_amdgcn_wave_barrier();               // (the tile is exchanged between lanes: see the backward kernel)
@@ -321,17 +328,13 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
                 if (lane < 32) {
                     bf16x8 p0, p1, p2;
                     pieces8(myxt + (rows_masked ? 256 : 0) + (lane & 15) * 16 + 8 * (lane >> 4), p0, p1, p2);
-                    store_pieces(em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
-                                            (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16, em_rows_piece, p0, p1, p2);
+                    store_pieces(em_rows_lane + (long)tt * em_rows_tstride, em_rows_piece, p0, p1, p2);
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (em_colsA || em_colsB) {
-            const long mb = (long)tt * (em_b16 >> 1) + (rbg >> 1);
-            if (em_colsA) emit_cols(em_colsA + ((long)(em_colsA_rb0 + member) * em_kbm + mb) * 1024, em_colsA_piece, em_v, q, c, rbg & 1);
-            if (em_colsB) emit_cols(em_colsB + ((long)(em_colsB_rb0 + member) * em_kbm + mb) * 1024, em_colsB_piece, ehp, q, c, rbg & 1);
-        }
+        if (em_colsA) emit_cols(em_colsA_lane + (long)tt * em_cols_tstride, em_colsA_piece, em_v, q);
+        if (em_colsB) emit_cols(em_colsB_lane + (long)tt * em_cols_tstride, em_colsB_piece, ehp, q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = rb * 16 + 4 * q + r;
@@ -415,16 +418,20 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
     float* const dghp = P.dgh; const int dgh_ts = P.dgh_ts ? (int)P.dgh_ts : B * 3 * H;
     float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
     const int rev = P.reverse, members = A.members;
-    unsigned char* const em_rows = EM ? P.em.rows : nullptr;             // (the lean build writes no piece outputs)
-    unsigned char* const em_colsA = EM ? P.em.colsA : nullptr; unsigned char* const em_colsB = EM ? P.em.colsB : nullptr;
+    // (the descriptor folded into per-lane destination pointers, as in the forward kernel)
+    const bool em_rows = EM && P.em.rows, em_colsA = EM && P.em.colsA, em_colsB = EM && P.em.colsB;
     const long em_rows_piece = P.em.rows_piece, em_colsA_piece = P.em.colsA_piece, em_colsB_piece = P.em.colsB_piece;
-    const int em_rows_kb = P.em.rows_kb, em_rows_kb0 = P.em.rows_kb0, em_colsA_rb0 = P.em.colsA_rb0, em_colsB_rb0 = P.em.colsB_rb0;
     const int em_colsA_n = P.em.colsA_n;
     const bool em_skip_dgi = EM && P.em.skip_dgi, em_skip_dgh = EM && P.em.skip_dgh;
-    const int em_b16 = P.em.B_full >> 4, em_rb0 = P.em.r0 >> 4, em_kbm = T * (P.em.B_full >> 5);
-    if (EM) kernarg_touch(em_rows, em_colsA, em_colsB, em_rows_piece, em_colsA_piece, em_colsB_piece, em_rows_kb, em_rows_kb0,
-                          em_colsA_rb0, em_colsB_rb0, em_colsA_n, em_b16, em_rb0, em_kbm);
-    const bool em_any = em_rows || em_colsA || em_colsB;
+    const int em_b16 = P.em.B_full >> 4, em_kbm = T * (P.em.B_full >> 5);
+    const int rbg = (P.em.r0 >> 4) + rb;
+    const int em_rows_tstride = em_b16 * P.em.rows_kb * 1024, em_cols_tstride = (em_b16 >> 1) * 1024;
+    const long em_gstep = (long)(H / 16) * em_kbm * 1024;      // from one gate's row blocks to the next in the transposed layout
+    unsigned char* const em_rows_lane = !em_rows ? nullptr :
+        P.em.rows + (((long)rbg * P.em.rows_kb + P.em.rows_kb0 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
+    const int em_cl = ((2 * (rbg & 1) + (q >> 1)) * 16 + c) * 16;
+    unsigned char* const em_colsA_lane = !em_colsA ? nullptr : P.em.colsA + ((long)(P.em.colsA_rb0 + member) * em_kbm + (rbg >> 1)) * 1024 + em_cl;
+    unsigned char* const em_colsB_lane = !em_colsB ? nullptr : P.em.colsB + ((long)(P.em.colsB_rb0 + member) * em_kbm + (rbg >> 1)) * 1024 + em_cl;
     for (int step = T - 1; step >= -1; --step) {
         const bool tail = step < 0;                            // dh0 = dgh(first step) W_hh + dhz
         if (tail && !dh0p) break;
@@ -472,7 +479,6 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
             e_r[r] = dr_pre; e_z[r] = dz_pre; e_n[r] = dn_pre; e_nr[r] = dnr;
         }
         const bool pub = step != 0 || dh0p;                    // (nothing reads the last gate gradients unless dh0 is wanted)
-        const int rbg = em_rb0 + rb;
         if (EM) {
             // One pass through the wave's four transpose tiles: the three gate gradients of the exchange (r, z, n*r) and, for
             // the row pieces of dgi, n.  The exchange stores go first and the arrival right behind them (its vmcnt(0) then only
@@ -498,8 +504,7 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
                     for (int r = 0; r < 4; ++r) myxt[768 + (4 * q + r) * 16 + c] = e_n[r];
                     __builtin_amdgcn_wave_barrier();
                     if (lane < 32) {
-                        unsigned char* dst = em_rows + (((long)(tt * em_b16 + rbg) * em_rows_kb + em_rows_kb0 + (member >> 1)) * 64 +
-                                                        (2 * (member & 1) + (lane >> 4)) * 16 + (lane & 15)) * 16;
+                        unsigned char* dst = em_rows_lane + (long)tt * em_rows_tstride;
 #pragma unroll
                         for (int g = 0; g < 3; ++g) {          // dgi: r, z, n (tile 3)
                             bf16x8 p0, p1, p2;
@@ -526,17 +531,13 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) 
             }
             arrive_rows(counter, lane);
         }
-        if (em_colsA || em_colsB) {
-            const long mb = (long)tt * (em_b16 >> 1) + (rbg >> 1);
-            if (em_colsA) {
-                unsigned char* fa = em_colsA + ((long)(em_colsA_rb0 + member) * em_kbm + mb) * 1024;
-                const long gstep = (long)(H / 16) * em_kbm * 1024;
-                emit_cols(fa, em_colsA_piece, e_r, q, c, rbg & 1);
-                emit_cols(fa + gstep, em_colsA_piece, e_z, q, c, rbg & 1);
-                if (em_colsA_n) emit_cols(fa + 2 * gstep, em_colsA_piece, e_n, q, c, rbg & 1);
-            }
-            if (em_colsB) emit_cols(em_colsB + ((long)(em_colsB_rb0 + member) * em_kbm + mb) * 1024, em_colsB_piece, e_nr, q, c, rbg & 1);
+        if (em_colsA) {
+            unsigned char* fa = em_colsA_lane + (long)tt * em_cols_tstride;
+            emit_cols(fa, em_colsA_piece, e_r, q);
+            emit_cols(fa + em_gstep, em_colsA_piece, e_z, q);
+            if (em_colsA_n) emit_cols(fa + 2 * em_gstep, em_colsA_piece, e_n, q);
         }
+        if (em_colsB) emit_cols(em_colsB_lane + (long)tt * em_cols_tstride, em_colsB_piece, e_nr, q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = rb * 16 + 4 * q + r;
