@@ -276,6 +276,12 @@ int inet_set_option(int key, int value);
  * per wave, W in LDS, the contraction on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces
  * and all nine piece products accumulated in f32 -- the products of fp32 arithmetic), 6 = the same with the three terms below
  * 2^-24 |ab| dropped, 0 = first generation (f32-input MFMA, W in registers). */
+/* key 8 = the encoder's large products (csrc/gemm_bf3.hip; INET_GEMM_BF3): 9 (default) = on the bf16 matrix cores through the same
+ * exact three-piece split, nine piece products; 6 = six; 0 = on the f32-input kernels of csrc/gemm.hip.
+ * key 9 = which bf16 pieces the chain kernels write themselves (INET_EMIT; bit 0 forward rows, 1 forward transposed, 2 backward
+ * rows, 3 backward transposed; default 15) -- what they do not write, bf3_split launches make from the f32 arrays: same results.
+ * key 10 = which layers' weight gradients run on the bf16 pipe (INET_BF3_WGRAD; bit 0 layer 1, bit 1 layer 0; default 1).
+ * Keys 8-10 must not change between a forward call and its backward call. */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.
  * Unlike inet_side_join nothing is consumed: the issuing stream still joins the same work at its own next join (a

@@ -82,6 +82,8 @@ int chain_chunk_rows_bwd(int H, int B, int T, int nd);
 // whether gru_layer_fwd / gru_layer_bwd write ChainEmit outputs for this shape (the kernels that run are the second generation's,
 // rows in multiples of 32): the same decision the layer functions make, for callers that must know it in another library call
 bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save);
+void bf3_set_emit_mask(int m);      // which piece outputs the chain kernels write themselves (INET_EMIT)
+void bf3_set_wgrad_mask(int m);     // which layers' weight gradients run on the bf16 pipe (INET_BF3_WGRAD)
 bool gru_layer_bwd_emits(int H, int B, int T, int nd);
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);

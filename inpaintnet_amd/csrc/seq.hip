@@ -32,19 +32,22 @@ int chain_chunk_rows_bwd(int H, int B, int T, int nd) {
 
 // which piece outputs the chains write themselves (bit 0: forward rows, 1: forward transposed, 2: backward rows, 3: backward
 // transposed); what they do not write is split from the f32 arrays by bf3_split launches (the transposed ones on the side stream)
+static int g_emit_mask = -1, g_wgrad_mask = -1;
 static int emit_mask() {
-    static const int m = [] { const char* v = std::getenv("INET_EMIT"); return v ? std::atoi(v) : 15; }();
-    return m;
+    if (g_emit_mask < 0) { const char* v = std::getenv("INET_EMIT"); g_emit_mask = v ? std::atoi(v) & 15 : 15; }
+    return g_emit_mask;
 }
+void bf3_set_emit_mask(int m) { g_emit_mask = m & 15; }     // inet_set_option key 9 (tests: the same step with and without emission)
 
 // which layers' weight gradients run on the bf16 pipe (bit 0: layer 1, bit 1: layer 0): the others stay on the LDS-free
 // f32-input kernels.  Measured in one call (profiles/r03_t_wgrad_pipe.txt): 3.75 / 3.72 / 3.85 / 3.82 ms per step for both /
 // layer 1 only / layer 0 only / neither -- layer 0's product is the last kernel of the backward pass, and what its bf16 form
 // saves (172 -> 118 us) the layer-0 chains pay for writing its operands (the transposed gate gradients and previous states).
 static int wgrad_mask() {
-    static const int m = [] { const char* v = std::getenv("INET_BF3_WGRAD"); return v ? std::atoi(v) : 1; }();
-    return m;
+    if (g_wgrad_mask < 0) { const char* v = std::getenv("INET_BF3_WGRAD"); g_wgrad_mask = v ? std::atoi(v) & 3 : 1; }
+    return g_wgrad_mask;
 }
+void bf3_set_wgrad_mask(int m) { g_wgrad_mask = m & 3; }    // inet_set_option key 10
 
 // Where layer 1's bf16-pipe weight gradients run: 0 = on a side stream (beside the data gradient and the layer-0 BPTT chain;
 // default), 1 = on the caller's stream between the data gradient and the layer-0 chain.  gemm_bf3 workgroups (120-144 KB of LDS)

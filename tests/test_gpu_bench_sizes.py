@@ -376,3 +376,53 @@ def test_gemm_repeatability_bound():
     scale = float(outs[0].abs().max())
     for o in outs[1:]:
         assert float((o - outs[0]).abs().max()) <= 4e-6 * scale
+
+
+@pytest.mark.parametrize("B", [256, 512])
+def test_piece_outputs_written_by_chains_or_by_split_launches_give_the_same_step(B):
+    """The bf16 pieces of the encoder's products are the same whoever writes them -- the chain kernels (ChainEmit) or bf3_split
+    launches over the f32 arrays --, and so is the step: loss, logits and every gradient of the teacher-forced step (B = 256:
+    one chain launch per layer; 512: row chunks) under inet_set_option key 9 = 0 / 5 / 10 and key 10 = 3 / 2 / 0 agree with the
+    default's to the order of the f32 atomics (split-K weight gradients); with the products on the f32-input kernels (key 8 = 0)
+    to the usual f32 bound."""
+    T = 24
+    c = G.CFGS["full"]
+    H = c["H"]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params("full"))
+    g = torch.Generator().manual_seed(4048 + B)
+    tok = torch.randint(0, c["V"], (B, T), generator=g).to(DEV)
+    eps = torch.randn(B, c["Z"], generator=g).to(DEV)
+    masks = {"enc": ops.dropout_mask((T, B, 2 * H), 0.5, 78, 0, DEV), "beat": ops.dropout_mask((4, B, H), 0.5, 78, 10 ** 8, DEV),
+             "tick": ops.dropout_mask((T, B, H), 0.5, 78, 2 * 10 ** 8, DEV)}
+
+    def step():
+        grads = torch.zeros_like(params)
+        hl, hce, hkl, hacc, hw, hs, hz, _ = _vae_step_with_kinks(cfg, params, grads, tok, eps, True, masks)
+        torch.cuda.synchronize()
+        return hl, hw.clone(), grads
+
+    default = {8: 9, 9: 15, 10: 1}
+    try:
+        l0, w0, g0 = step()
+        for key, val in ((9, 0), (9, 5), (9, 10), (10, 3), (10, 2), (10, 0), (8, 0), (8, 6)):
+            ops.set_option(key, val)
+            try:
+                l, w, gr = step()
+            finally:
+                ops.set_option(key, default[key])
+            tol = 2e-5 if key == 8 else 2e-6
+            assert abs(l - l0) <= 1e-6 * abs(l0), (key, val, l, l0)
+            assert relmax(w, w0) < tol, (key, val)
+            bad = []
+            for pname, off, shape in table:
+                a, b = unpack(table, gr, pname), unpack(table, g0, pname)
+                err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+                if not err < (5e-4 if pname.endswith("b_0") else tol * 5):      # (decoder.b_0: an atomics-ordered scalar sum)
+                    bad.append((pname, err))
+            assert not bad, (key, val, bad)
+    finally:
+        for k, v in default.items():
+            ops.set_option(k, v)
+    assert ops.chain_status() == 0
