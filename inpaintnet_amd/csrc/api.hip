@@ -272,8 +272,8 @@ int inet_gemm_bf3(const float* A, int64_t lda, int a_kmajor, const float* B, int
     unsigned char* scratch = nullptr;
     const size_t ab = bf3_bytes(M, K), bb = bf3_bytes(N, K);
     if (hipMalloc(&scratch, ab + bb) != hipSuccess) return -2;
-    int rc = bf3_split(A, lda, a_kmajor, M, K, nullptr, 0, scratch, (long)bf3_piece_bytes(M, K), K / 32, 0, 0, s);
-    if (rc == 0) rc = bf3_split(B, ldb, b_kmajor, N, K, nullptr, 0, scratch + ab, (long)bf3_piece_bytes(N, K), K / 32, 0, 0, s);
+    int rc = bf3_split(A, lda, a_kmajor, M, K, scratch, (long)bf3_piece_bytes(M, K), K / 32, 0, 0, s);
+    if (rc == 0) rc = bf3_split(B, ldb, b_kmajor, N, K, scratch + ab, (long)bf3_piece_bytes(N, K), K / 32, 0, 0, s);
     if (rc == 0) {
         Bf3Gemm g{};
         g.A = scratch; g.a_piece = (long)bf3_piece_bytes(M, K); g.a_kb = K / 32;

@@ -12,9 +12,9 @@ inline size_t bf3_piece_bytes(long R, long K) { return (size_t)R * (size_t)K * 2
 inline size_t bf3_bytes(long R, long K) { return 3 * bf3_piece_bytes(R, K); }
 
 // X(r, k) = kmajor ? X[k * ld + r] : X[r * ld + k]  ->  row blocks rb0.., k blocks kb0.. of the piece buffer P.
-// R % 16 == 0 (k-major sources: R % 64 == 0), K % 32 == 0.  `mul` (optional, indexed like X): the pieces of X * mul.
-int bf3_split(const float* X, long ld, int kmajor, int R, int K, const float* mul, long ld_mul, unsigned char* P,
-              long piece_bytes, int kb_total, int rb0, int kb0, hipStream_t s);
+// R % 16 == 0 (k-major sources: R % 64 == 0), K % 32 == 0.
+int bf3_split(const float* X, long ld, int kmajor, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0,
+              int kb0, hipStream_t s);
 
 struct Bf3Gemm {
     // C[M, N] (op)= epi(sum_k A(m, k) B(n, k) + bias):  A, B piece buffers (k blocks 0 .. K/32 of each row block)

@@ -45,7 +45,7 @@ __device__ __forceinline__ void split8_store(const float* v, unsigned char* dst,
 }
 
 struct SplitArgs {
-    const float* X; long ld; const float* mul; long ld_mul;
+    const float* X; long ld;
     unsigned char* P; long piece_bytes; int kb_total, rb0, kb0, R, K;
 };
 
@@ -59,13 +59,7 @@ __global__ __launch_bounds__(256) void bf3_split_rows_kernel(SplitArgs a) {
     if (rb >= a.R / 16) return;
     const long off = (rb * 16 + (lane & 15)) * a.ld + kb * 32 + (lane >> 4) * 8;
     const f32x4 v0 = ld4u(a.X + off), v1 = ld4u(a.X + off + 4);
-    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    if (a.mul) {
-        const long mo = (rb * 16 + (lane & 15)) * a.ld_mul + kb * 32 + (lane >> 4) * 8;
-        const f32x4 m0 = ld4u(a.mul + mo), m1 = ld4u(a.mul + mo + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] *= m0[j]; v[4 + j] *= m1[j]; }
-    }
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     split8_store(v, a.P + (((a.rb0 + rb) * a.kb_total + a.kb0 + kb) * 64 + lane) * 16, a.piece_bytes);
 }
 
@@ -78,12 +72,7 @@ __global__ __launch_bounds__(256) void bf3_split_cols_kernel(SplitArgs a) {
     for (int i = 0; i < 2; ++i) {
         const int kk = (t >> 4) + 16 * i, rr = (t & 15) * 4;
         const long off = (long)(kb * 32 + kk) * a.ld + r0 + rr;
-        f32x4 v = ld4u(a.X + off);
-        if (a.mul) {
-            const f32x4 m = ld4u(a.mul + (long)(kb * 32 + kk) * a.ld_mul + r0 + rr);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= m[j];
-        }
+        const f32x4 v = ld4u(a.X + off);
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[kk][rr + j] = v[j];
     }
@@ -235,10 +224,10 @@ bool gemm_bf3_ok(int M, int N, int K) {
     return M > 0 && M % 192 == 0 && N > 0 && N % 128 == 0 && K >= 64 && K % 32 == 0;
 }
 
-int bf3_split(const float* X, long ld, int kmajor, int R, int K, const float* mul, long ld_mul, unsigned char* P,
-              long piece_bytes, int kb_total, int rb0, int kb0, hipStream_t s) {
+int bf3_split(const float* X, long ld, int kmajor, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0,
+              int kb0, hipStream_t s) {
     if (!X || !P || R <= 0 || K <= 0 || R % 16 || K % 32 || (kmajor && R % 64)) return -1;
-    SplitArgs a{X, ld, mul, ld_mul, P, piece_bytes, kb_total, rb0, kb0, R, K};
+    SplitArgs a{X, ld, P, piece_bytes, kb_total, rb0, kb0, R, K};
     char label[64];
     std::snprintf(label, sizeof label, "bf3_split %s R%d K%d", kmajor ? "cols" : "rows", R, K);
     ProfScope prof(PROF_HBM, 0.0, s, label, 10.0 * R * K);

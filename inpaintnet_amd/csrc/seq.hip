@@ -390,11 +390,11 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         wss = side_fork(s);
         const long wp = (long)bf3_piece_bytes(6 * H, 2 * H), wpT = (long)bf3_piece_bytes(2 * H, 6 * H);
         for (int dir = 0; dir < 2; ++dir)
-            INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 0, 3 * H, 2 * H, nullptr, 0, w.wih1pk, wp, 2 * H / 32, dir * 3 * H / 16, 0, wss));
+            INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 0, 3 * H, 2 * H, w.wih1pk, wp, 2 * H / 32, dir * 3 * H / 16, 0, wss));
         if (save && w.wih1Tpk) {
             wss2 = side_fork(s);
             for (int dir = 0; dir < 2; ++dir)
-                INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 1, 2 * H, 3 * H, nullptr, 0, w.wih1Tpk, wpT, 6 * H / 32, 0, dir * 3 * H / 32, wss2));
+                INET_TRY(bf3_split(P[2 + dir].w_ih, 2L * H, 1, 2 * H, 3 * H, w.wih1Tpk, wpT, 6 * H / 32, 0, dir * 3 * H / 32, wss2));
         }
     }
     DirFwd d[2];
@@ -433,7 +433,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         // x1 [TB, 2H] . [W_ih_fwd; W_ih_bwd]^T + [b_fwd | b_bwd]
         const long xp = (long)bf3_piece_bytes((long)T * B, 2 * H), wp = (long)bf3_piece_bytes(6 * H, 2 * H);
         const int KB = 2 * H / 32;
-        if (!x1_emitted) INET_TRY(bf3_split(x1, 2L * H, 0, T * B, 2 * H, nullptr, 0, w.x1pk, xp, KB, 0, 0, s));
+        if (!x1_emitted) INET_TRY(bf3_split(x1, 2L * H, 0, T * B, 2 * H, w.x1pk, xp, KB, 0, 0, s));
         if (wss != s) INET_TRY(stream_wait(s, wss));           // the weight pieces
         Bf3Gemm g{};
         g.A = w.x1pk; g.a_piece = xp; g.a_kb = KB; g.B = w.wih1pk; g.b_piece = wp; g.b_kb = KB;
@@ -478,10 +478,10 @@ static int bigru2_wgrad_hh_bf3(int B, int T, int H, int layer, const GruDirPtr* 
         const int i = 2 * layer + dir;
         // r, z (, n) of dgi_d [TB, 3H] at column dir * 3H of the [TB, 6H] array -> row blocks dir * 3H / 16 ..
         if (!gates_emitted) {
-            INET_TRY(bf3_split(dgi + dir * 3L * H, 6L * H, 1, (n_too ? 3 : 2) * H, (int)TB, nullptr, 0, w.gT[layer], gp, KB, dir * 3 * H / 16, 0, ss));
-            INET_TRY(bf3_split(w.dgh[i] + 2L * H, 3L * H, 1, H, (int)TB, nullptr, 0, w.nrT[i], hp, KB, 0, 0, ss));
+            INET_TRY(bf3_split(dgi + dir * 3L * H, 6L * H, 1, (n_too ? 3 : 2) * H, (int)TB, w.gT[layer], gp, KB, dir * 3 * H / 16, 0, ss));
+            INET_TRY(bf3_split(w.dgh[i] + 2L * H, 3L * H, 1, H, (int)TB, w.nrT[i], hp, KB, 0, 0, ss));
         }
-        if (!hprev_emitted) INET_TRY(bf3_split(w.sv[i] + 4 * TBH, H, 1, H, (int)TB, nullptr, 0, w.hpT[i], hp, KB, 0, 0, ss));
+        if (!hprev_emitted) INET_TRY(bf3_split(w.sv[i] + 4 * TBH, H, 1, H, (int)TB, w.hpT[i], hp, KB, 0, 0, ss));
     }
     const int i0 = 2 * layer;
     Bf3Gemm g{};
@@ -556,7 +556,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         const long TBl = (long)T * B;
         const long gp = (long)bf3_piece_bytes(6 * H, TBl), xp = (long)bf3_piece_bytes(2 * H, TBl);
         const int KB = (int)(TBl / 32);
-        if (!fwd_emitted) INET_TRY(bf3_split(x1, 2L * H, 1, 2 * H, (int)TBl, nullptr, 0, w.x1T, xp, KB, 0, 0, ss));
+        if (!fwd_emitted) INET_TRY(bf3_split(x1, 2L * H, 1, 2 * H, (int)TBl, w.x1T, xp, KB, 0, 0, ss));
         Bf3Gemm g{};
         g.A = w.gT[1]; g.A2 = w.gT[1] + (long)(3 * H / 16) * KB * 1024; g.a_piece = gp; g.a_kb = KB;
         g.B = w.x1T; g.B2 = w.x1T; g.b_piece = xp; g.b_kb = KB;
@@ -595,7 +595,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         // dx1 [TB, 2H] = (dgi1 [TB, 6H] . [W_ih_fwd; W_ih_bwd] [6H, 2H]) * mask: both directions as one K = 6H product
         const long dp = (long)bf3_piece_bytes((long)T * B, 6 * H), wp = (long)bf3_piece_bytes(2 * H, 6 * H);
         const int KB = 6 * H / 32;
-        if (!l1_rows_emitted) INET_TRY(bf3_split(w.dgi1, 6L * H, 0, T * B, 6 * H, nullptr, 0, w.dgi1pk, dp, KB, 0, 0, s));
+        if (!l1_rows_emitted) INET_TRY(bf3_split(w.dgi1, 6L * H, 0, T * B, 6 * H, w.dgi1pk, dp, KB, 0, 0, s));
         // (B operand: the k-major weight pieces the forward call left in the workspace)
         Bf3Gemm g{};
         g.A = w.dgi1pk; g.a_piece = dp; g.a_kb = KB; g.B = w.wih1Tpk; g.b_piece = wp; g.b_kb = KB;
