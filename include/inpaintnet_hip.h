@@ -281,7 +281,9 @@ int inet_set_option(int key, int value);
  * key 9 = which bf16 pieces the chain kernels write themselves (INET_EMIT; bit 0 forward rows, 1 forward transposed, 2 backward
  * rows, 3 backward transposed; default 15) -- what they do not write, bf3_split launches make from the f32 arrays: same results.
  * key 10 = which layers' weight gradients run on the bf16 pipe (INET_BF3_WGRAD; bit 0 layer 1, bit 1 layer 0; default 1).
- * Keys 8-10 must not change between a forward call and its backward call. */
+ * key 11 = second-generation kernel for the BPTT chains too (default 0; INET_CHAIN2_BWD=1): the faster kernel alone, the slower
+ * step -- it holds the CU's LDS, which keeps the backward pass's leaf work out for the length of the chain (csrc/gru_chain.hip).
+ * Keys 8-11 must not change between a forward call and its backward call. */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.
  * Unlike inet_side_join nothing is consumed: the issuing stream still joins the same work at its own next join (a

@@ -415,6 +415,7 @@ int inet_set_option(int key, int value) {
     if (key == 8) { if (value != 0 && value != 6 && value != 9) return -1; bf3_set_mode(value); return 0; }
     if (key == 9) { if (value < 0 || value > 15) return -1; bf3_set_emit_mask(value); return 0; }
     if (key == 10) { if (value < 0 || value > 3) return -1; bf3_set_wgrad_mask(value); return 0; }
+    if (key == 11) { chain2_set_bwd(value); return 0; }
     return -1;
 }
 

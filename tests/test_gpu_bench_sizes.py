@@ -33,7 +33,7 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     from inpaintnet_amd import ops
-    from tests.test_gpu_kernels import pack, relmax, unpack
+    from tests.test_gpu_kernels import _assert_kinks, _vae_step_with_kinks, pack, relmax, unpack
 
 DEV = "cuda:0"
 
@@ -109,8 +109,13 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
                "M1536 N512 K6144 TN d192x128 s8 e0", "M1536 N512 K6144 TN d192x128 s4 e0 x2",                 # layer 0's, the decoder's
                "group2 M256 N1024 K2048 NT k64x32 e1"):                                        # both SELU heads in one grouped split-K launch
         assert wl in labels, (wl, big)
-    if B == 256:     # the chains wrote the pieces themselves: the only split launches left are the layer-1 input weights'
-        assert sorted(set(l for l in labels if l.startswith("bf3_split"))) == ["bf3_split cols R1024 K1536", "bf3_split rows R1536 K1024"], big
+    if B == 256:     # the forward chains wrote their pieces themselves (layer-1 input rows, x1^T, the previous states^T); the BPTT chains
+        # run on the first generation (no LDS: the leaf work shares the CUs with them), so the gate gradients' pieces come from split
+        # launches -- dgi1 rows for the data gradient, (r, z, n)^T and (n*r)^T of layer 1 for its weight gradients -- next to the
+        # layer-1 input weights' (rows for the forward product, k-major for the data gradient)
+        assert sorted(set(l for l in labels if l.startswith("bf3_split"))) == [
+            "bf3_split cols R1024 K1536", "bf3_split cols R1536 K6144", "bf3_split cols R512 K6144", "bf3_split rows R1536 K1024",
+            "bf3_split rows R6144 K3072"], big
     if not tf and B == 256:      # the 24 free-running ticks with dropout and backward saves: one launch of the fused decode kernel
         assert "decode_chain_train ms2 T24 B256 H512 V48" in labels, sorted(set(l for l in labels if l.startswith("dec")))
     print(sorted(set(l for l in labels if l.startswith("gru"))))
@@ -148,43 +153,6 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     bound["decoder.b_0"] = 5e-4
     bad = {k: v for k, v in errs.items() if v >= bound[k]}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
-
-
-def _assert_kinks(what):
-    """The oracle followed the GPU's SELU / ReLU branch only inside |x| < O.KINK_TOL (oracle/torch_ref.py): nothing may
-    disagree outside that band, and inside it only the handful of elements fp32 noise explains."""
-    st = dict(O.KINK_STATS)
-    print(f"kinks ({what}): {st}")
-    assert st["elements"] > 0
-    assert st["violations"] == 0, st                     # a branch taken wrongly on a clearly non-zero pre-activation
-    assert st["flips"] <= 8 + 1e-5 * st["elements"], st
-    assert st["max_abs_flip"] <= O.KINK_TOL, st
-
-
-def _vae_step_with_kinks(cfg, params, grads, tok, eps, teacher_forced, masks):
-    """tests.test_gpu_kernels._vae_step_hip plus the branch every SELU / ReLU element took (read from the workspaces
-    through the inet_vae_ws_field test hook and from the logits)."""
-    B, T = tok.shape
-    V, nb = cfg.num_notes, cfg.beats
-    He, Hd = cfg.enc_hidden, cfg.dec_hidden
-    mu, ls, ews = ops.encoder_fwd(cfg, tok, params, mask=masks.get("enc"), save=True)
-    acc3 = torch.zeros(3, device=DEV)
-    z, _ = ops.reparam_kl(mu, ls, eps, kl_sum=acc3[2:3])
-    w, s, dws = ops.decoder_fwd(cfg, z, tok, teacher_forced, params, masks.get("beat"), masks.get("tick"), save=True)
-    kinks = {"a_mu": ops.ws_field(cfg, ews, B, 0, "a_mu").view(B, 2 * He).cpu() > 0,
-             "a_ls": ops.ws_field(cfg, ews, B, 0, "a_ls").view(B, 2 * He).cpu() > 0,
-             "hb0": ops.ws_field(cfg, dws, B, 1, "hb0").view(B, 2 * Hd).cpu() > 0,
-             "ht0": ops.ws_field(cfg, dws, B, 1, "ht0").view(nb, B, 2 * Hd).cpu() > 0,
-             "c_all": ops.ws_field(cfg, dws, B, 1, "c_all").view(nb, B, Hd).cpu() > 0,
-             "relu": w.cpu() > 0}
-    dW = torch.empty_like(w)
-    ops.cross_entropy(w.view(B * T, V), tok.reshape(-1), acc3, dW=dW.view(B * T, V), scale=1.0 / (B * T))
-    dz = ops.decoder_bwd(cfg, dW, w, s, params, grads, masks.get("beat"), masks.get("tick"), dws)
-    dmu, dls = ops.latent_bwd(dz, mu, ls, eps, 1e-3 / B)
-    ops.encoder_bwd(cfg, tok, params, grads, masks.get("enc"), dmu, dls, ews)
-    a = acc3.cpu().double()
-    ce, kl = a[0] / (B * T), 1e-3 * a[2] / B
-    return float(ce + kl), float(ce), float(kl), float(a[1] / (B * T)), w, s, z, kinks
 
 
 @pytest.mark.parametrize("variant", ["nar", "ar_tf", "ar_fr"])
@@ -383,8 +351,8 @@ def test_piece_outputs_written_by_chains_or_by_split_launches_give_the_same_step
     """The bf16 pieces of the encoder's products are the same whoever writes them -- the chain kernels (ChainEmit) or bf3_split
     launches over the f32 arrays --, and so is the step: loss, logits and every gradient of the teacher-forced step (B = 256:
     one chain launch per layer; 512: row chunks) under inet_set_option key 9 = 0 / 5 / 10 and key 10 = 3 / 2 / 0 agree with the
-    default's to the order of the f32 atomics (split-K weight gradients); with the products on the f32-input kernels (key 8 = 0)
-    to the usual f32 bound."""
+    default's to the order of the f32 atomics (split-K weight gradients) -- also with the second-generation BPTT kernel (key 11),
+    which is off by default --; with the products on the f32-input kernels (key 8 = 0) to the usual f32 bound."""
     T = 24
     c = G.CFGS["full"]
     H = c["H"]
@@ -403,16 +371,20 @@ def test_piece_outputs_written_by_chains_or_by_split_launches_give_the_same_step
         torch.cuda.synchronize()
         return hl, hw.clone(), grads
 
-    default = {8: 9, 9: 15, 10: 1}
+    default = {8: 9, 9: 15, 10: 1, 11: 0}
     try:
         l0, w0, g0 = step()
-        for key, val in ((9, 0), (9, 5), (9, 10), (10, 3), (10, 2), (10, 0), (8, 0), (8, 6)):
+        # (key 11 = 1: the second-generation BPTT kernel, which writes the gate gradients' pieces itself; alone and with the masks)
+        for key, val, bwd2 in ((9, 0, 0), (9, 1, 0), (10, 3, 0), (10, 0, 0), (11, 1, 1), (9, 0, 1), (9, 5, 1), (9, 10, 1), (10, 3, 1),
+                               (10, 2, 1), (8, 0, 0), (8, 6, 1)):
+            ops.set_option(11, bwd2)
             ops.set_option(key, val)
             try:
                 l, w, gr = step()
             finally:
                 ops.set_option(key, default[key])
-            tol = 2e-5 if key == 8 else 2e-6
+                ops.set_option(11, 0)
+            tol = 2e-5 if key == 8 or bwd2 else 2e-6           # (another kernel's f32 summation order: the usual f32 bound)
             assert abs(l - l0) <= 1e-6 * abs(l0), (key, val, l, l0)
             assert relmax(w, w0) < tol, (key, val)
             bad = []
