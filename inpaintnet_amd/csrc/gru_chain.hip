@@ -383,7 +383,7 @@ bool gru_chain_fwd_is_v2(int H, int B, int T, int nprob, int h0_packed) {
     return v2f && !h0_packed && gru_chain2_ok(H, B, T, nprob);
 }
 // The BPTT chains stay on the FIRST generation by default (INET_CHAIN2_BWD=1 / inet_set_option key 11 select the second): its
-// kernel uses no LDS, so the leaf work of the backward pass (weight-gradient products, column sums, the bf16-pipe products' split
+// kernel takes 28 KB of LDS and ~300 registers per lane, so the leaf work of the backward pass (weight-gradient products, column sums, the bf16-pipe products' split
 // launches) shares the CUs with it, while a second-generation workgroup holds 148-160 KB of the CU's LDS and keeps everything
 // that needs LDS out for the length of the chain.  One box, one call: 3.62 / 3.64 ms per step against 3.73 / 3.76 with the
 // second-generation BPTT kernel, which is the faster kernel alone (220 vs 232 us per 24-step launch) -- profiles/r03_t_wgrad_pipe.txt.

@@ -110,7 +110,7 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
                "group2 M256 N1024 K2048 NT k64x32 e1"):                                        # both SELU heads in one grouped split-K launch
         assert wl in labels, (wl, big)
     if B == 256:     # the forward chains wrote their pieces themselves (layer-1 input rows, x1^T, the previous states^T); the BPTT chains
-        # run on the first generation (no LDS: the leaf work shares the CUs with them), so the gate gradients' pieces come from split
+        # run on the first generation (28 KB of LDS: the leaf work shares the CUs with them), so the gate gradients' pieces come from split
         # launches -- dgi1 rows for the data gradient, (r, z, n)^T and (n*r)^T of layer 1 for its weight gradients -- next to the
         # layer-1 input weights' (rows for the forward product, k-major for the data gradient)
         assert sorted(set(l for l in labels if l.startswith("bf3_split"))) == [
