@@ -387,11 +387,14 @@ bool gru_chain_fwd_is_v2(int H, int B, int T, int nprob, int h0_packed) {
 // launches) shares the CUs with it, while a second-generation workgroup holds 148-160 KB of the CU's LDS and keeps everything
 // that needs LDS out for the length of the chain.  One box, one call: 3.62 / 3.64 ms per step against 3.73 / 3.76 with the
 // second-generation BPTT kernel, which is the faster kernel alone (220 vs 232 us per 24-step launch) -- profiles/r03_t_wgrad_pipe.txt.
-static int g_chain2_bwd = -1;
-void chain2_set_bwd(int on) { g_chain2_bwd = on ? 1 : 0; }
+static int g_chain2_bwd = -1, g_chain2_bwd_layer = 0;
+void chain2_set_bwd(int on) { g_chain2_bwd = on < 0 ? 0 : (on > 3 ? 1 : on); }
+// (experiment: values 2 / 3 select the second generation for the encoder's layer 1 / layer 0 only; bigru2_core_bwd names the layer)
+void chain2_bwd_layer(int layer) { g_chain2_bwd_layer = layer; }
 bool gru_chain_bwd_is_v2(int H, int B, int T, int nprob) {
-    if (g_chain2_bwd < 0) { const char* v = std::getenv("INET_CHAIN2_BWD"); g_chain2_bwd = (v && v[0] == '1') ? 1 : 0; }
-    return g_chain2_bwd && gru_chain2_ok(H, B, T, nprob);
+    if (g_chain2_bwd < 0) { const char* v = std::getenv("INET_CHAIN2_BWD"); g_chain2_bwd = v ? std::atoi(v) : 0; if (g_chain2_bwd < 0 || g_chain2_bwd > 3) g_chain2_bwd = 0; }
+    const bool on = g_chain2_bwd == 1 || (g_chain2_bwd == 2 && g_chain2_bwd_layer == 1) || (g_chain2_bwd == 3 && g_chain2_bwd_layer == 0);
+    return on && gru_chain2_ok(H, B, T, nprob);
 }
 
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {

@@ -568,7 +568,9 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     const bool bf3w = bf3_mode() != 0 && w.gT[0] && w.hpT[0] && wg;
     for (int hi = T - 1; hi >= 0 && stage != 2; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0, nt = hi - lo + 1;
+        chain2_bwd_layer(1);
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
+        chain2_bwd_layer(0);
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
             if (nt == T && bf3w && (wgrad_mask() & 1)) {      // both directions of a product in one launch (gemm_bf3.hip)
