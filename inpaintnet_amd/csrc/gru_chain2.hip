@@ -16,7 +16,9 @@
 // produces it; the exchange carries the three pieces in the MFMA's A-fragment order (6 bytes per element instead of 4):
 //   piece p of a [rows, K] state: [row/16][K/32][lane = (k%32)/8 * 16 + row%16][8 bf16 = k%8]   (1 KB per fragment)
 // Semantics (operand sources, masks, saves, h0 / hlast / dh0, reverse, row chunks) are those of the first-generation kernels;
-// tests run both against the oracle (INET_CHAIN2=0 selects the first generation).
+// tests run both against the oracle (INET_CHAIN2=0 selects the first generation).  The forward kernel is the default for chains of
+// >= 6 steps; the BPTT kernel is behind INET_CHAIN2_BWD=1: it is the faster kernel alone and the slower step, because a workgroup
+// of it holds the CU's LDS and keeps the backward pass's leaf work out (gru_chain.hip gru_chain_bwd_is_v2).
 #include <cstdio>
 #include <cstdlib>
 #include "chain.h"
