@@ -133,6 +133,14 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension is not built. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and the tensors this library is handed live in
+        # that runtime's context.  Loaded first, libinpaintnet_hip.so would pull in /opt/rocm's copy as a SECOND runtime, and
+        # its first launch then fails with hipErrorNoDevice (build() followed by smoke() in one process did exactly that).
+        # With torch imported first, the library's NEEDED libamdhip64 resolves to the runtime already in the process.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
