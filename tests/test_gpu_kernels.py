@@ -616,7 +616,7 @@ def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
     offs, total = layout.arena_offsets(dict(shapes))
     # (long sequences of wide layers: weights scaled so that the recurrence is not chaotic -- at std 0.3 and H = 512 six
     #  steps amplify one ulp to 1e-3 and two correct fp32 evaluations, this kernel and the CPU oracle alike, differ from a
-    #  float64 one and from each other by that much: tools/dbg2.py)
+    #  float64 one and from each other by that much: tools/bigru2_vs_float64.py)
     wstd = 0.3 if T < 6 else 1.0 / np.sqrt(H)
     P = {k: (torch.randn(*s, generator=g) * (wstd if "weight" in k else 0.1)) for k, s in shapes}
     flat = torch.zeros(total)

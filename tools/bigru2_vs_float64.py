@@ -1,3 +1,5 @@
+"""bigru2 forward + backward of a given shape under the chain generations (inet_set_option key 7) against a float64 CPU run:
+    python tools/bigru2_vs_float64.py B T K H   -- how far f32-input and bf16-piece arithmetic sit from float64 and from each other"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
