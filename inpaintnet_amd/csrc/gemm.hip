@@ -126,6 +126,49 @@ __device__ __forceinline__ float apply_epi(float v, int epi, float aux) {
     }
 }
 
+// Products with a handful of rows (M <= 8: the beat-level projections and the z -> hidden linear of a b = 1 / b = 2 decode call,
+// decoder.py:412-453): a tile kernel spends 9-15 us on them (one 64-row tile per workgroup, a k loop for rows that are not there).
+// Here a WAVE owns one output column n: its lanes stride over k (16-byte loads of the weight row, coalesced), every lane keeps M
+// partial sums, a butterfly sums the wave.  Both operands k-contiguous; all epilogues; store or accumulate.
+template <int M>
+__device__ __forceinline__ void gemv_rows_body(const GemmArgs& g, int n) {
+    const int lane = threadIdx.x & 63;
+    if (n >= g.N) return;
+    const float* wrow = g.B + (long)n * g.ldb;
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = 0.f;
+    const int K4 = g.K & ~3;
+    for (int k = lane * 4; k < K4; k += 256) {
+        const f32x4 w = ld4u(wrow + k);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const f32x4 a = ld4u(g.A + (long)m * g.lda + k);
+            acc[m] += a[0] * w[0] + a[1] * w[1] + a[2] * w[2] + a[3] * w[3];
+        }
+    }
+    for (int k = K4 + lane; k < g.K; k += 64) {
+        const float w = wrow[k];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] += g.A[(long)m * g.lda + k] * w;
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[m] += __shfl_xor(acc[m], off, 64);
+    if (lane < M) {
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) v = lane == m ? acc[m] : v;
+        if (g.bias) v += g.bias[n];
+        if (g.epi != EPI_NONE) v = apply_epi(v, g.epi, g.aux ? g.aux[(long)lane * g.ldaux + n] : 0.f);
+        float* dst = g.C + (long)lane * g.ldc + n;
+        *dst = g.acc == ACC_ADD ? *dst + v : v;
+    }
+}
+template <int M>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(GemmArgs g) { gemv_rows_body<M>(g, blockIdx.x * 4 + (threadIdx.x >> 6)); }
+
 template <int TM, int TN, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -625,6 +668,12 @@ __global__ __launch_bounds__(256) void gemm_ks_kernel(GemmArgs g, int tiles_n, i
 // [first[i], first[i+1]) holds it; every product keeps its own shape, bias, epilogue and accumulation mode.
 struct GemmGroupArgs { int n; int first[kGemmGroupMax + 1]; int tiles_n[kGemmGroupMax]; GemmArgs g[kGemmGroupMax]; };
 
+// several few-row products (one M for all) in one launch: blockIdx.y = product
+template <int M>
+__global__ __launch_bounds__(256) void gemv_rows_group_kernel(GemmGroupArgs a) {
+    gemv_rows_body<M>(a.g[blockIdx.y], blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
 template <int TA, int TB, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_ks_group_kernel(GemmGroupArgs a) {
     const int v = blockIdx.x;
@@ -662,6 +711,8 @@ __global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int
     }
 }
 
+// INET_GEMV=0: products of <= 8 rows on the tile kernels (A/B switch)
+bool gemv_enabled() { static const bool on = [] { const char* v = std::getenv("INET_GEMV"); return !(v && v[0] == '0'); }(); return on; }
 int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (INET_GEMM_FORCE="cfg,split"), -1: cost model
 int g_direct = -1;   // INET_GEMM_DIRECT: 0 never, 1 (default) by shape, 2 direct whenever applicable, 3 big shapes only, 4 split-K first
 
@@ -869,6 +920,40 @@ void launch_ks_group(const GemmGroupArgs& a, bool akm, bool bkm, dim3 grid, hipS
 int launch_gemm_group(const GemmArgs* list, int n, hipStream_t s) {
     static const bool grouped = [] { const char* v = std::getenv("INET_GEMM_GROUP"); return !(v && v[0] == '0'); }();
     if (g_direct < 0) { const char* v = std::getenv("INET_GEMM_DIRECT"); g_direct = v ? std::atoi(v) : 1; }
+    {   // a group of few-row products of one M (the beat -> tick projections of a b = 1 decode call): one launch of the wave-per-column kernel
+        bool gv = grouped && n >= 2 && n <= kGemmGroupMax && g_force_cfg < 0 && gemv_enabled() && list[0].M >= 1 && list[0].M <= 8;
+        int maxN = 0;
+        double flops = 0, bytes = 0;
+        for (int i = 0; i < n && gv; ++i) {
+            const GemmArgs& g = list[i];
+            gv = g.M == list[0].M && g.N > 0 && g.K > 0 && !g.a_kmajor && !g.b_kmajor && g.nbatch <= 1 && g.acc != ACC_ATOMIC;
+            maxN = g.N > maxN ? g.N : maxN;
+            flops += 2.0 * g.M * g.N * g.K; bytes += 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+        }
+        if (gv) {
+            GemmGroupArgs a{};
+            a.n = n;
+            for (int i = 0; i < n; ++i) {
+                if (list[i].acc == ACC_ADD && side_is(s) && side_order_dest(list[i].C, s) != 0) return -2;
+                a.g[i] = list[i];
+            }
+            char label[64];
+            std::snprintf(label, sizeof label, "group%d M%d N%d K%d NT gemv e%d", n, list[0].M, list[0].N, list[0].K, list[0].epi);
+            ProfScope prof(PROF_GEMM, flops, s, label, bytes);
+            const dim3 grid((maxN + 3) / 4, n);
+            switch (list[0].M) {
+                case 1: hipLaunchKernelGGL(gemv_rows_group_kernel<1>, grid, dim3(256), 0, s, a); break;
+                case 2: hipLaunchKernelGGL(gemv_rows_group_kernel<2>, grid, dim3(256), 0, s, a); break;
+                case 3: hipLaunchKernelGGL(gemv_rows_group_kernel<3>, grid, dim3(256), 0, s, a); break;
+                case 4: hipLaunchKernelGGL(gemv_rows_group_kernel<4>, grid, dim3(256), 0, s, a); break;
+                case 5: hipLaunchKernelGGL(gemv_rows_group_kernel<5>, grid, dim3(256), 0, s, a); break;
+                case 6: hipLaunchKernelGGL(gemv_rows_group_kernel<6>, grid, dim3(256), 0, s, a); break;
+                case 7: hipLaunchKernelGGL(gemv_rows_group_kernel<7>, grid, dim3(256), 0, s, a); break;
+                default: hipLaunchKernelGGL(gemv_rows_group_kernel<8>, grid, dim3(256), 0, s, a); break;
+            }
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+    }
     bool ok = grouped && n >= 2 && n <= kGemmGroupMax && g_direct > 0 && g_direct != 3 && g_force_cfg < 0;
     for (int i = 0; i < n && ok; ++i) {
         const GemmArgs& g = list[i];
@@ -969,6 +1054,23 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
             if ((rc = launch_gemm(one, s)) != 0) return rc;
         }
         return 0;
+    }
+    if (g.M <= 8 && !g.a_kmajor && !g.b_kmajor && g.nbatch <= 1 && g_force_cfg < 0 && g.acc != ACC_ATOMIC && gemv_enabled()) {
+        char label[64];
+        std::snprintf(label, sizeof label, "M%d N%d K%d NT gemv e%d", g.M, g.N, g.K, g.epi);
+        ProfScope prof(PROF_GEMM, 2.0 * g.M * g.N * g.K, s, label, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+        const dim3 grid((g.N + 3) / 4);
+        switch (g.M) {
+            case 1: hipLaunchKernelGGL(gemv_rows_kernel<1>, grid, dim3(256), 0, s, g); break;
+            case 2: hipLaunchKernelGGL(gemv_rows_kernel<2>, grid, dim3(256), 0, s, g); break;
+            case 3: hipLaunchKernelGGL(gemv_rows_kernel<3>, grid, dim3(256), 0, s, g); break;
+            case 4: hipLaunchKernelGGL(gemv_rows_kernel<4>, grid, dim3(256), 0, s, g); break;
+            case 5: hipLaunchKernelGGL(gemv_rows_kernel<5>, grid, dim3(256), 0, s, g); break;
+            case 6: hipLaunchKernelGGL(gemv_rows_kernel<6>, grid, dim3(256), 0, s, g); break;
+            case 7: hipLaunchKernelGGL(gemv_rows_kernel<7>, grid, dim3(256), 0, s, g); break;
+            default: hipLaunchKernelGGL(gemv_rows_kernel<8>, grid, dim3(256), 0, s, g); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     const int force_cfg = g_force_cfg, force_split = g_force_split;
     const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};

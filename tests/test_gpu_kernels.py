@@ -63,6 +63,36 @@ def test_gemm_layouts(akm, bkm, M, N, K):
     assert relmax(C1, ref + C0.double()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 1024, 256), (4, 1536, 512), (4, 512, 512), (8, 130, 1030), (3, 48, 10), (2, 7, 5)])
+def test_gemv_rows(M, N, K):
+    """Products of up to 8 rows (the small projections of a b = 1 decode call) on the wave-per-column kernel (csrc/gemm.hip
+    gemv_rows_kernel): plain, bias + every epilogue, accumulation into a live strided destination; odd N and K."""
+    g = torch.Generator().manual_seed(M * 100 + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    ops.prof_enable(True)
+    try:
+        C = ops.gemm(Ad, Bd, M, N, K)
+        torch.cuda.synchronize()
+        ops.prof_dump("/tmp/_inet_gemv.csv")
+    finally:
+        ops.prof_enable(False)
+    assert "gemv" in open("/tmp/_inet_gemv.csv").read().strip().splitlines()[-1].split(",")[1]
+    assert relmax(C, ref) < 2e-5
+    assert relmax(ops.gemm(Ad, Bd, M, N, K, bias=bias.to(DEV), epi=1), O.selu(ref + bias.double())) < 2e-5
+    assert relmax(ops.gemm(Ad, Bd, M, N, K, bias=bias.to(DEV), epi=2), torch.relu(ref + bias.double())) < 2e-5
+    assert relmax(ops.gemm(Ad, Bd, M, N, K, epi=4, aux=aux.to(DEV)), ref * aux.double()) < 2e-5
+    big = torch.randn(M, 2, N, generator=g)
+    bd = big.to(DEV).clone()
+    ops.gemm(Ad, Bd, M, N, K, out=bd[:, 1, :], accumulate=True)
+    assert relmax(bd[:, 1, :], ref + big[:, 1, :].double()) < 2e-5
+    assert torch.equal(bd[:, 0, :].cpu(), big[:, 0, :])
+
+
 @pytest.mark.parametrize("akm,bkm,M,N,K,ksplit", [(0, 0, 384, 384, 256, 0), (0, 0, 192, 128, 64, 1), (0, 1, 768, 256, 1536, 0),
                                                   (1, 1, 1536, 512, 6144, 0), (1, 1, 192, 128, 2048, 4), (1, 0, 192, 640, 96, 1),
                                                   (0, 0, 1536, 3072, 1024, 0)])
