@@ -20,6 +20,7 @@
 #include "common.h"
 #include "prof.h"
 #include "gemm_bf3.h"
+#include "side.h"
 
 namespace {
 
@@ -242,6 +243,10 @@ int launch_gemm_bf3(const Bf3Gemm& gin, hipStream_t s) {
     if (g.nbatch > 1 && (!g.A2 || !g.B2 || !g.C2)) return -1;
     if (g.a_alt_from && (!g.A_alt || (g.nbatch > 1 && !g.A2_alt))) return -1;
     const int nbt = g.nbatch > 1 ? 2 : 1;
+    // accumulations queued on different side streams into one tensor (a module applied twice in a step) are ordered, as in launch_gemm
+    if (g.acc == ACC_ADD && side_is(s)) {
+        if (side_order_dest(g.C, s) != 0 || (nbt > 1 && side_order_dest(g.C2, s) != 0)) return -2;
+    }
     const bool wide = g.N % 192 == 0;                          // 192 x 192 tiles, else 192 x 128
     const int tiles = (g.M / 192) * (g.N / (wide ? 192 : 128)) * nbt;
     const int KB = g.K / 32;
