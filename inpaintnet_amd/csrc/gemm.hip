@@ -835,7 +835,7 @@ int launch_gemm_kc_direct(const GemmArgs& g, hipStream_t s) {
 }
 
 struct KsCfg { int ta, tb; };
-const KsCfg kKs[] = {{4, 4}, {4, 2}, {2, 2}, {6, 4}};
+const KsCfg kKs[] = {{4, 4}, {4, 2}, {2, 2}, {6, 4}, {4, 6}};
 
 template <int TA, int TB>
 void launch_ks(const GemmArgs& g, dim3 grid, hipStream_t s, int tiles_n, int tiles) {
@@ -856,13 +856,17 @@ int launch_gemm_ks(const GemmArgs& gin, hipStream_t s, int force_split) {
     if ((double)(g.a_kmajor ? g.K : g.M) * g.lda * 4 >= 2.0e9 || (double)(g.b_kmajor ? g.K : g.N) * g.ldb * 4 >= 2.0e9) return 1;
     const bool nonlinear = g.epi != EPI_NONE;
     // rounds of 256 workgroups x MFMAs per workgroup, the smaller tiles charged for their higher L2 traffic per MFMA
-    const double kL2[] = {1.0, 1.15, 1.5, 0.95};
+    const double kL2[] = {1.0, 1.15, 1.5, 0.95, 0.95};
     int bi = -1, bs = 1;
     double best = 1e300;
-    for (int ci = 0; ci < 4; ++ci) {
+    static const bool wide46 = [] { const char* v = std::getenv("INET_KS_64x96"); return !(v && v[0] == '0'); }();
+    for (int ci = 0; ci < 5; ++ci) {
         const KsCfg& c = kKs[ci];
         if (g.M % (16 * c.ta) || g.N % (16 * c.tb)) continue;
         if (ci == 3 && !(g.a_kmajor && g.K >= 2048)) continue;
+        // 64 x 96 tiles (k-contiguous A): products whose 64 x 64 tiling needs two rounds of workgroups and whose 64 x 32 tiling pays
+        // for it in L2 traffic (M1024 N1536 K512: 256 tiles instead of 384 / 768)
+        if (ci == 4 && (g.a_kmajor || !wide46)) continue;
         const long tiles = (long)(g.M / (16 * c.ta)) * (g.N / (16 * c.tb));
         for (int sp = 1; sp <= 8; sp *= 2) {
             if (sp > 1 && (!g.a_kmajor || g.K / sp < 1024 || nonlinear)) break;
@@ -897,6 +901,7 @@ int launch_gemm_ks(const GemmArgs& gin, hipStream_t s, int force_split) {
         case 0: launch_ks<4, 4>(g, grid, s, tiles_n, tiles); break;
         case 1: launch_ks<4, 2>(g, grid, s, tiles_n, tiles); break;
         case 2: launch_ks<2, 2>(g, grid, s, tiles_n, tiles); break;
+        case 4: launch_ks<4, 6>(g, grid, s, tiles_n, tiles); break;
         default:
             if (!g.a_kmajor) return 1;
             hipLaunchKernelGGL((gemm_ks_kernel<6, 4, true, true>), grid, dim3(256), 0, s, g, tiles_n, tiles);
