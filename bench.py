@@ -430,7 +430,8 @@ def pmc_key(label):
         grid = 256 * 8 * (H // 16) * math.ceil(groups / 8)
         if fwd:                                          # third parameter: the build for two launches per CU ("ms4x2")
             return f"gru_chain_fwd_kernel<{ms}, {H // 64}, {2 if re.search(r'ms[0-9]+x2', label) else 1}>|g{grid}"
-        return f"gru_chain_bwd_kernel<{ms}, {3 * H // 64}>|g{grid}"
+        emr = re.search(r" ms\d+e ", label) is not None    # ("ms4e": the build that writes the row pieces of dgi)
+        return f"gru_chain_bwd_kernel<{ms}, {3 * H // 64}, {tf(emr)}>|g{grid}"
     if label.startswith("gru_fwd"):
         grid = 256 * f["np"] * math.ceil(f["B"] / (16 * f["ms"])) * (f["H"] // 16)
         return f"gru_step_fwd_kernel<{tf(f['x'])}, {f['ms']}, {tf(f['pk'])}>|g{grid}"

@@ -174,10 +174,30 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
     }
 }
 
-template <int MS, int SQ>                          // SQ = 3H/64 k-steps per wave over K = 3H
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// x = x0 + x1 + x2 exactly (gru_chain2.hip / gemm_bf3.hip): 8 consecutive floats -> the three pieces, stored 16 bytes each
+__device__ __forceinline__ void store_pieces8(const float* src, unsigned char* dst, long piece) {
+    bf16x8_t p0, p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = src[j];
+        const __bf16 a = (__bf16)x;
+        const float r1 = x - (float)a;
+        const __bf16 b = (__bf16)r1;
+        p0[j] = a; p1[j] = b; p2[j] = (__bf16)(r1 - (float)b);
+    }
+    *reinterpret_cast<bf16x8_t*>(dst) = p0;
+    *reinterpret_cast<bf16x8_t*>(dst + piece) = p1;
+    *reinterpret_cast<bf16x8_t*>(dst + 2 * piece) = p2;
+}
+
+// EMR: the build that also writes the ROW pieces of dgi (ChainEmit.rows: the A operand of the layer's data gradient on the bf16
+// pipe, gemm_bf3.hip) -- from the transpose tiles it publishes from anyway, behind the hand-off.  (The transposed pieces of the
+// weight gradients are left to split launches: they run beside this kernel, which keeps most of the CU's LDS free for them.)
+template <int MS, int SQ, bool EMR = false>         // SQ = 3H/64 k-steps per wave over K = 3H
 __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     __shared__ __attribute__((aligned(16))) float red[4 * MS * 256];
-    __shared__ __attribute__((aligned(16))) float xt[3][MS * 256];
+    __shared__ __attribute__((aligned(16))) float xt[EMR ? 4 : 3][MS * 256];
     __shared__ unsigned flag[2];
     int group, member;
     chain::decode_block(blockIdx.x, A.members, group, member);
@@ -223,6 +243,12 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
     float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
     const int rev = P.reverse, members = A.members;
     const chain::Status status = A.status;
+    // row pieces of dgi (EMR): row block (t * B_full / 16 + rbg), k block rows_kb0 + gate * H / 32 + member / 2, this member's half
+    unsigned char* const em_rows = EMR ? P.em.rows : nullptr;
+    const long em_rows_piece = P.em.rows_piece;
+    const int em_rows_kb = P.em.rows_kb, em_rbg = (P.em.r0 >> 4) + rb0;
+    const long em_tstride = (long)(P.em.B_full >> 4) * em_rows_kb * 1024;
+    const int em_lane = ((P.em.rows_kb0 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
     for (int step = T - 1; step >= -1; --step) {
         const bool tail = step < 0;                // dh0 = dgh(first step) W_hh + dhz
         if (tail && !dh0p) break;
@@ -282,6 +308,7 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
             dhz[p] = dh * z;
             const int xo = rl * 16 + (t & 15);
             xt[0][xo] = dr_pre; xt[1][xo] = dz_pre; xt[2][xo] = dnr;
+            if (EMR) xt[3][xo] = dn_pre;
             e_r[p] = dr_pre; e_z[p] = dz_pre; e_n[p] = dn_pre; e_nr[p] = dnr;
         }
         if (step != 0 || dh0p) {                   // (nothing reads the last gate gradients unless dh0 is wanted)
@@ -292,6 +319,17 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
                     chain::publish_block(rs, (step & 1) * slot_bytes, xt[g], p, lane, rb0 + p, S3, g * (H >> 4) + member);
             }
             chain::arrive(counter);
+        }
+        if (EMR && em_rows) {                       // (behind the hand-off; the tiles stay valid until the next step's barrier)
+            if (!(step != 0 || dh0p)) __syncthreads();             // (the publish above did not run: its barrier neither)
+            for (int blk = t >> 6; blk < 3 * MS; blk += 4) {
+                const int g = blk / MS, p = blk % MS;               // gate 0 r, 1 z, 2 n (tile 3); row block p of this workgroup's tile
+                if (lane < 32 && rb0 + p <= rb_last) {
+                    const float* src = xt[g == 2 ? 3 : g] + (p * 16 + (lane & 15)) * 16 + 8 * (lane >> 4);
+                    store_pieces8(src, em_rows + ((long)tt * em_tstride + (long)(em_rbg + p) * em_rows_kb * 1024 + (long)g * (H >> 5) * 1024 +
+                                                  em_lane), em_rows_piece);
+                }
+            }
         }
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
@@ -423,6 +461,10 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// the first-generation BPTT launch for this shape writes ChainEmit.rows itself (H = 512, 64 rows per workgroup)
+bool gru_chain_bwd_emits_rows(int H, int B, int T, int nprob) {
+    return !gru_chain_bwd_is_v2(H, B, T, nprob) && H == 512 && gru_chain_bwd_ok(H, B, T, nprob) && rows_ms_bwd(H, B, nprob) == 4;
+}
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
     if (gru_chain_bwd_is_v2(a.H, a.B, a.T, a.nprob)) return launch_gru_chain2_bwd(a, s);
     if (!gru_chain_bwd_ok(a.H, a.B, a.T, a.nprob)) return -1;
@@ -434,13 +476,23 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
     a.prio = chain_prio();
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status = chain_status_for(a.counters + kChainStatusWord);
+    // row pieces of dgi (ChainEmit.rows): written by the H = 512, 64-rows-per-workgroup build; everything else of the descriptor is
+    // the second generation's (the callers split what was not written)
+    bool emr = a.H == 512 && ms == 4;
+    for (int i = 0; i < a.nprob; ++i) {
+        emr = emr && a.p[i].em.rows;
+        a.p[i].em.colsA = a.p[i].em.colsB = nullptr; a.p[i].em.skip_dgi = a.p[i].em.skip_dgh = 0;
+    }
+    if (!emr) for (int i = 0; i < a.nprob; ++i) a.p[i].em.rows = nullptr;
     char label[72];
-    std::snprintf(label, sizeof label, "gru_chain_bwd ms%d np%d T%d B%d H%d", ms, a.nprob, a.T, a.B, a.H);
+    std::snprintf(label, sizeof label, "gru_chain_bwd ms%d%s np%d T%d B%d H%d", ms, emr ? "e" : "", a.nprob, a.T, a.B, a.H);
     const double rows = (double)a.nprob * a.T * a.B;
     ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
-                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)));
+                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)) + (emr ? 18.0 * rows * a.H : 0.0));
     const dim3 grid(chain::blocks_for(groups, a.members));
 #define INET_CB(M, Q) hipLaunchKernelGGL((gru_chain_bwd_kernel<M, Q>), grid, dim3(256), 0, s, a)
+    if (emr) hipLaunchKernelGGL((gru_chain_bwd_kernel<4, 24, true>), grid, dim3(256), 0, s, a);
+    else
     if (a.H == 512) { if (ms == 1) INET_CB(1, 24); else if (ms == 2) INET_CB(2, 24); else if (ms == 4) INET_CB(4, 24); else INET_CB(8, 24); }
     else { if (ms == 1) INET_CB(1, 12); else if (ms == 2) INET_CB(2, 12); else if (ms == 4) INET_CB(4, 12); else INET_CB(8, 12); }
 #undef INET_CB

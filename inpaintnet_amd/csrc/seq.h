@@ -43,8 +43,8 @@ struct DirFwd {
     unsigned* sync;
     int sync_prezeroed;                                       // those words are zero already (one memset per library call)
     // piece outputs for the bf16-matrix-core products (gru_chain.h ChainEmit; B_full / r0 are filled in by gru_layer_fwd);
-    // `emitted` is set to 1 by gru_layer_fwd when the kernels it launched wrote them, else to 0 (the caller then splits the
-    // f32 arrays with bf3_split)
+    // `emitted` is set by gru_layer_fwd / gru_layer_bwd to what the kernels they launched wrote (bit 0: rows, bit 1: the transposed
+    // pieces; 0: nothing) -- the caller splits the rest from the f32 arrays with bf3_split
     ChainEmit em; mutable int emitted;
 };
 

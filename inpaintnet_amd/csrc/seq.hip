@@ -109,7 +109,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
             P.hlast = D.hlast; P.ld_hlast = D.hlast_ld;
             P.sv = D.sv; P.sv_astride = D.sv_astride;
             P.hx = D.hpk; P.reverse = D.reverse;
-            if (B % 32 == 0 && gru_chain_fwd_is_v2(H, B, T, nd, a.h0_packed) && gru_chain2_emits(H, B, T, nd)) { P.em = D.em; P.em.B_full = B; P.em.r0 = 0; D.emitted = 1; }
+            if (B % 32 == 0 && gru_chain_fwd_is_v2(H, B, T, nd, a.h0_packed) && gru_chain2_emits(H, B, T, nd)) { P.em = D.em; P.em.B_full = B; P.em.r0 = 0; D.emitted = 3; }
         }
         a.counters = d[0].sync; a.prezeroed = d[0].sync_prezeroed;
         return launch_gru_chain_fwd(a, s);
@@ -156,7 +156,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
                 else { P.hx = D.hpk + (long)c * pkc; P.hx_slot_bytes = (int)(pkh * sizeof(float)); }
                 P.reverse = D.reverse;
                 if (v2 && B % 32 == 0 && CH % 32 == 0 && gru_chain_fwd_is_v2(H, CH, T, nd, 0) && gru_chain2_emits(H, CH, T, nd)) {
-                    P.em = D.em; P.em.B_full = B; P.em.r0 = (int)r0; D.emitted = 1;
+                    P.em = D.em; P.em.B_full = B; P.em.r0 = (int)r0; D.emitted = 3;
                 }
             }
             a.counters = d[0].sync + (c & 1) * kChainSyncWords;
@@ -247,7 +247,9 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
                     P.reverse = D.reverse;
                     P.dgi_sum = D.dgi_sum ? D.dgi_sum + r0 * 3 * H : nullptr;
                     if (B % 32 == 0 && CHB % 32 == 0 && gru_chain_bwd_is_v2(H, CHB, T, nd) && gru_chain2_emits(H, CHB, T, nd)) {
-                        P.em = D.em; P.em.B_full = B; P.em.r0 = (int)r0; D.emitted = 1;
+                        P.em = D.em; P.em.B_full = B; P.em.r0 = (int)r0; D.emitted = 3;
+                    } else if (B % 32 == 0 && CHB % 32 == 0 && D.em.rows && gru_chain_bwd_emits_rows(H, CHB, T, nd)) {
+                        P.em = D.em; P.em.B_full = B; P.em.r0 = (int)r0; D.emitted = 1;   // (the first generation: row pieces only)
                     }
                 }
                 a.counters = d[0].sync; a.prezeroed = (c == 0 && CHB == B) ? d[0].sync_prezeroed : 0;
@@ -574,7 +576,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
             if (nt == T && bf3w && (wgrad_mask() & 1)) {      // both directions of a product in one launch (gemm_bf3.hip)
-                l1_gem = d[0].emitted && d[1].emitted && (emit_mask() & 8);
+                l1_gem = (d[0].emitted & 2) && (d[1].emitted & 2) && (emit_mask() & 8);
                 if (wgrad_at() == 0) INET_TRY(l1_wgrads_bf3(ss));
                 else l1_wgrads_pending = true;               // (on the main stream, behind the data gradient: see wgrad_at)
             } else if (nt == T) {                            // both directions of a product in one launch
@@ -592,7 +594,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
             }
         }
     }
-    const bool l1_rows_emitted = stage != 2 && bf3d_pre && d[0].emitted && d[1].emitted && (emit_mask() & 4);
+    const bool l1_rows_emitted = stage != 2 && bf3d_pre && (d[0].emitted & 1) && (d[1].emitted & 1) && (emit_mask() & 4);
     if (stage != 2 && bf3d) {
         // dx1 [TB, 2H] = (dgi1 [TB, 6H] . [W_ih_fwd; W_ih_bwd] [6H, 2H]) * mask: both directions as one K = 6H product
         const long dp = (long)bf3_piece_bytes((long)T * B, 6 * H), wp = (long)bf3_piece_bytes(2 * H, 6 * H);
@@ -643,7 +645,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (wg) {
             hipStream_t ss = side_fork(s);
             if (hi - lo + 1 == T && bf3w && (wgrad_mask() & 2))
-                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 0, P, w, w.dgi0, false, d[0].emitted && d[1].emitted && (emit_mask() & 8), fwd_emitted, ss));
+                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 0, P, w, w.dgi0, false, (d[0].emitted & 2) && (d[1].emitted & 2) && (emit_mask() & 8), fwd_emitted, ss));
             else if (hi - lo + 1 == T)
                 INET_TRY(linear_wgrad2(w.dgh[0], w.dgh[1], 3L * H, w.sv[0] + 4 * TBH, w.sv[1] + 4 * TBH, H, P[0].dw_hh,
                                        P[1].dw_hh, H, T * B, 3 * H, H, ss));

@@ -31,13 +31,15 @@ def bench():
     ("M48 N1536 K10 NT t64x64 s1 e0", "gemm_kernel<1, 1, false, false>|g6144"),
     ("gru_chain_fwd ms4 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 1>|g65536"),
     ("gru_chain_fwd ms4x2 np2 T24 B256 H512", "gru_chain_fwd_kernel<4, 8, 2>|g65536"),         # two launches per CU
-    ("gru_chain_bwd ms8 np4 T6 B256 H512", "gru_chain_bwd_kernel<8, 24>|g65536"),
+    ("gru_chain_bwd ms8 np4 T6 B256 H512", "gru_chain_bwd_kernel<8, 24, false>|g65536"),
+    ("gru_chain_bwd ms4e np2 T24 B256 H512", "gru_chain_bwd_kernel<4, 24, true>|g65536"),      # ... the build that writes dgi row pieces
+    ("gru_chain_bwd ms4 np2 T24 B256 H512", "gru_chain_bwd_kernel<4, 24, false>|g65536"),
     ("gru_chain_fwd v2w4 p9 np2 T24 B256 H512", "gru_chain2_fwd_kernel<4, 16, 9, false>|g65536"),      # second generation
     ("gru_chain_fwd v2w4e p9 np2 T24 B256 H512", "gru_chain2_fwd_kernel<4, 16, 9, true>|g65536"),     # ... the build that writes piece outputs
     ("gru_chain_bwd v2w4e p9 np2 T24 B256 H512", "gru_chain2_bwd_kernel<4, 48, 9, true>|g65536"),
     ("gru_chain_bwd v2w4 p6 np2 T24 B256 H512", "gru_chain2_bwd_kernel<4, 48, 6, false>|g65536"),
     ("gru_chain_fwd v2w4 p9 np2 T6 B128 H256", "gru_chain2_fwd_kernel<4, 8, 9, false>|g32768"),
-    ("gru_chain_bwd ms2 np2 T6 B128 H512", "gru_chain_bwd_kernel<2, 24>|g65536"),
+    ("gru_chain_bwd ms2 np2 T6 B128 H512", "gru_chain_bwd_kernel<2, 24, false>|g65536"),
     ("adam", "adam_kernel|"),
 ])
 def test_profile_label_to_pmc_key(bench, label, key):

@@ -111,11 +111,13 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
         assert wl in labels, (wl, big)
     if B == 256:     # the forward chains wrote their pieces themselves (layer-1 input rows, x1^T, the previous states^T); the BPTT chains
         # run on the first generation (28 KB of LDS: the leaf work shares the CUs with them), so the gate gradients' pieces come from split
-        # launches -- dgi1 rows for the data gradient, (r, z, n)^T and (n*r)^T of layer 1 for its weight gradients -- next to the
-        # layer-1 input weights' (rows for the forward product, k-major for the data gradient)
+        # launches that run beside them -- (r, z, n)^T and (n*r)^T of layer 1 for its weight gradients -- next to the layer-1 input
+        # weights' (rows for the forward product, k-major for the data gradient); the ROW pieces of dgi1 (the data gradient's A
+        # operand, on the caller's stream) the layer-1 BPTT chain writes itself ("ms4e")
         assert sorted(set(l for l in labels if l.startswith("bf3_split"))) == [
-            "bf3_split cols R1024 K1536", "bf3_split cols R1536 K6144", "bf3_split cols R512 K6144", "bf3_split rows R1536 K1024",
-            "bf3_split rows R6144 K3072"], big
+            "bf3_split cols R1024 K1536", "bf3_split cols R1536 K6144", "bf3_split cols R512 K6144", "bf3_split rows R1536 K1024"], big
+        assert sum(l == "gru_chain_bwd ms4e np2 T24 B256 H512" for l in labels) == 1 and \
+            sum(l == "gru_chain_bwd ms4 np2 T24 B256 H512" for l in labels) == 1, big
     if not tf and B == 256:      # the 24 free-running ticks with dropout and backward saves: one launch of the fused decode kernel
         assert "decode_chain_train ms2 T24 B256 H512 V48" in labels, sorted(set(l for l in labels if l.startswith("dec")))
     print(sorted(set(l for l in labels if l.startswith("gru"))))
