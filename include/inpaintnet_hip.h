@@ -140,11 +140,32 @@ int inet_sample_multinomial(const float* weights, int64_t ld_w, int rows, int V,
 /* p,g,m,v: arenas of n floats; step is 1-based; grads are multiplied by gscale first (1/world_size for DP) */
 int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int step, float gscale, void* stream);
+/* The same step for a caller that must know, without stalling the queue, what the kernel decided (round 4):
+ *  - step_flag (nullable device float): when given it ALONE decides whether the step is applied -- non-zero = skip.  A
+ *    data-parallel caller writes its rank's chain status there with inet_step_flag_export() and sums the word over ranks
+ *    together with the gradients (one slot in front of the gradient arena: no extra collective), so that every rank skips a
+ *    step ANY rank's chain kernels failed in and the replicas stay bit-identical.  Null: this process's own status word decides,
+ *    as in inet_adam_step.
+ *  - tag: the kernel leaves a record {executed, skipped, nonfinite, 0} in a ring of 16 host-mapped slots (slot tag % 16), and an
+ *    event is recorded behind it; inet_step_report(tag, wait, out4) reads it (wait != 0: after the event -- a step issued two or
+ *    more steps ago has normally finished, so the read costs nothing and BOUNDS how far the host runs ahead).  nonfinite = a
+ *    parameter became NaN / inf in this update: the observable behaviour of MeasureVAE/encoder.py:111-116 and decoder.py:424-429
+ *    (ValueError "... has become nan") without a host scan of the weights per forward.  -1: no such tag in the ring. */
+int inet_adam_step_ex(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, int step, float gscale, const float* step_flag, uint32_t tag, void* stream);
+int inet_step_flag_export(float* dst, void* stream);
+int inet_step_report(uint32_t tag, int wait, uint32_t* out4);
+/* Number of prologue launches that met a token index outside [0, num_notes) since the last reset (encoder input tokens,
+ * teacher-forcing targets): decoder.py:36-45 check_index raises ValueError; here the host-mapped counter is read by the Python
+ * layer at its status reads (Trainer.step, the inference wrappers).  reset != 0 clears it.  -2: could not be allocated. */
+int inet_token_status(int reset);
 /* Epoch statistics of the training loop (utils/trainer.py:124-163 accumulates mean_loss / mean_accuracy per batch):
  * sums[0] += *loss, sums[1] += *accuracy (nullable), sums[2] += 1 -- on the device, and only while no chain launch of this
  * process has timed out since the last inet_chain_status(reset): a step the optimizer kernel skipped (inet_adam_step reads the
  * same flag) does not enter the means either. */
 int inet_epoch_stats_add(float* sums, const float* loss, const float* accuracy, void* stream);
+/* step_flag as in inet_adam_step_ex: the batch enters the means iff its optimizer step was applied */
+int inet_epoch_stats_add_ex(float* sums, const float* loss, const float* accuracy, const float* step_flag, void* stream);
 
 
 /* ---- dropout masks (nn.GRU inter-layer dropout, encoder.py:32, decoder.py:346,365) --- */

@@ -177,9 +177,37 @@ int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
     if (!p || !g || !m || !v || n <= 0 || step < 1) return -1;
     return pw_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, (hipStream_t)stream);
 }
+int inet_adam_step_ex(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, int step, float gscale, const float* step_flag, uint32_t tag, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return -1;
+    return pw_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, (hipStream_t)stream, step_flag, 1, tag);
+}
+int inet_step_flag_export(float* dst, void* stream) {
+    if (!dst) return -1;
+    return pw_step_flag_export(dst, (hipStream_t)stream);
+}
+int inet_step_report(uint32_t tag, int wait, uint32_t* out4) {
+    if (!out4) return -1;
+    unsigned tmp[4];
+    const int rc = step_report_read(tag, wait, tmp);
+    if (rc != 0) return rc;
+    for (int i = 0; i < 4; ++i) out4[i] = tmp[i];
+    return 0;
+}
+int inet_token_status(int reset) {
+    unsigned* p = token_host_status();
+    if (!p) return -2;
+    const int v = (int)__atomic_load_n(p, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(p, 0u, __ATOMIC_RELAXED);
+    return v;
+}
 int inet_epoch_stats_add(float* sums, const float* loss, const float* accuracy, void* stream) {
     if (!sums || !loss) return -1;
     return pw_epoch_stats_add(sums, loss, accuracy, (hipStream_t)stream);
+}
+int inet_epoch_stats_add_ex(float* sums, const float* loss, const float* accuracy, const float* step_flag, void* stream) {
+    if (!sums || !loss) return -1;
+    return pw_epoch_stats_add(sums, loss, accuracy, (hipStream_t)stream, step_flag);
 }
 int inet_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
     if (!out || n <= 0 || p < 0.f || p >= 1.f) return -1;

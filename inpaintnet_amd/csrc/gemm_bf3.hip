@@ -86,8 +86,17 @@ __global__ __launch_bounds__(256) void bf3_split_cols_kernel(SplitArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Tile order of a launch whose workgroups are ONE tile each (no k split, one product).  Workgroup ids go round-robin over
+// the 8 XCDs and every XCD has its own L2, so what an XCD's 32 CUs run AT THE SAME TIME decides what that L2 serves twice:
+// XCD x = (xi, xj) of an xm x xn arrangement owns the rm x rn tiles of its region, and walks it in blocks of bm x bn = 32
+// tiles (one per CU): a block reads bm A strips and bn B strips through that L2 once.  Round 3 gave an XCD a contiguous range
+// of the tm-major list -- 2 x 16 tiles at a time for the 32 x 16 tiles of the layer-1 input product: 18 strips per block, every
+// B strip fetched by every XCD twice (441 MB of memory-side traffic for 132 MB of operands + result); 4 x 8 blocks of an
+// 8 x 8 region need 12.  bm == 0: the contiguous-range order.
+struct Bf3Map { int xn, rm, rn, bm, bn; };
+
 template <int WM, int WN, int RM, int RN, int NP>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf3_kernel(Bf3Gemm g, int tiles_m, int tiles_n, int kb_per) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf3_kernel(Bf3Gemm g, int tiles_m, int tiles_n, int kb_per, Bf3Map mp) {
     constexpr int NW = WM * WN, TMB = WM * RM, TNB = WN * RN;
     constexpr int STAGE = (TMB + TNB) * 3 * 1024;
     constexpr int CH = (TMB + TNB) * 3;                        // 1 KB fragments per stage
@@ -102,7 +111,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf3_kernel(Bf3Gemm g, int t
     const int per_prob = tiles_m * tiles_n * g.ksplit;
     const int prob = tid / per_prob, v = tid - prob * per_prob;
     const int ks = v / (tiles_m * tiles_n), tt = v - ks * (tiles_m * tiles_n);
-    const int tm = tt / tiles_n, tn = tt - tm * tiles_n;
+    int tm = tt / tiles_n, tn = tt - tm * tiles_n;
+    if (mp.bm > 0) {
+        const int x = id & 7, slot = id >> 3, per = mp.bm * mp.bn;
+        const int blk = slot / per, in = slot - blk * per, bpr = mp.rn / mp.bn;
+        tm = (x / mp.xn) * mp.rm + (blk / bpr) * mp.bm + in / mp.bn;
+        tn = (x % mp.xn) * mp.rn + (blk % bpr) * mp.bn + in % mp.bn;
+    }
     const unsigned char* const Ap = prob ? g.A2 : g.A;
     const unsigned char* const Bp = prob ? g.B2 : g.B;
     float* const Cp = prob ? g.C2 : g.C;
@@ -196,15 +211,33 @@ int launch_cfg(const Bf3Gemm& g, int kb_per, hipStream_t s) {
     const int tiles_m = g.M / (TMB * 16), tiles_n = g.N / (TNB * 16);
     const dim3 grid(tiles_m * tiles_n * g.ksplit * (g.nbatch > 1 ? 2 : 1));
     const size_t lds = (size_t)2 * (TMB + TNB) * 3 * 1024;
+    // XCD-aware tile order (Bf3Map): the arrangement with the fewest strip bytes per XCD, counting every block of 32 tiles as
+    // fetching its strips afresh (an L2 holds ~4 MB; a strip is K * 6 bytes * 192 or 128 rows)
+    static const int map_on = [] { const char* v = std::getenv("INET_BF3_MAP"); return v ? std::atoi(v) : 1; }();
+    Bf3Map mp{1, 0, 0, 0, 0};
+    if (map_on && g.ksplit == 1 && g.nbatch <= 1 && (tiles_m * tiles_n) % 256 == 0) {
+        double best = 0.0;
+        for (int xm = 1; xm <= 8; xm *= 2) {
+            const int xn = 8 / xm;
+            if (tiles_m % xm || tiles_n % xn) continue;
+            const int rm = tiles_m / xm, rn = tiles_n / xn;
+            for (int bm = 1; bm <= 32; bm *= 2) {
+                const int bn = 32 / bm;
+                if (rm % bm || rn % bn) continue;
+                const double cost = (double)(rm / bm) * (rn / bn) * (bm * (double)TMB + bn * (double)TNB);
+                if (mp.bm == 0 || cost < best) { best = cost; mp = Bf3Map{xn, rm, rn, bm, bn}; }
+            }
+        }
+    }
     static bool attr_set[2] = {false, false};
     if (bf3_mode() == 6) {
         auto kern = &gemm_bf3_kernel<WM, WN, RM, RN, 6>;
         if (!attr_set[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[0] = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g, tiles_m, tiles_n, kb_per);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g, tiles_m, tiles_n, kb_per, mp);
     } else {
         auto kern = &gemm_bf3_kernel<WM, WN, RM, RN, 9>;
         if (!attr_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[1] = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g, tiles_m, tiles_n, kb_per);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g, tiles_m, tiles_n, kb_per, mp);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

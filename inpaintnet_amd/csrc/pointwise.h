@@ -20,9 +20,11 @@ int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float
                   float* dmu, float* dls, long n, hipStream_t s);
 int pw_sample_multinomial(const float* W, long ld_w, int rows, int V, long long* out, long stride, uint64_t seed,
                           uint64_t offset, hipStream_t s);
+// step_flag (optional device float): non-zero = skip (the ranks' summed chain status); tagged: leave a step report under `tag`
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
-            float gscale, hipStream_t s);
-int pw_epoch_stats_add(float* sums, const float* loss, const float* acc, hipStream_t s);
+            float gscale, hipStream_t s, const float* step_flag = nullptr, int tagged = 0, unsigned tag = 0);
+int pw_step_flag_export(float* dst, hipStream_t s);
+int pw_epoch_stats_add(float* sums, const float* loss, const float* acc, hipStream_t s, const float* step_flag = nullptr);
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);
 // up to 8 column sums (bias gradients of one module) in one launch: out_i[n] += sum_m X_i[m*ld_i + n]
 struct PwColsumJob { const float* X; long ld; int M, N; float* out; };
@@ -76,5 +78,8 @@ struct PwPrologue {
     const float* axpb_a; const float* axpb_x; long axpb_incx; const float* axpb_b; float* axpb_y; int axpb_n;
     long long* fill_ptr; long nfill; long long fill_val;
     const long long* tok_src; long long* tok_copy; long long* tok_shift; int tok_B, tok_T; long long tok_first;
+    int tok_V;                // > 0: indices of tok_src outside [0, tok_V) are counted into the host-mapped token status word
+                              // (decoder.py:36-45 check_index; chain.h token_host_status) -- set by pw_prologue
+    unsigned* tok_bad;
 };
 int pw_prologue(const PwPrologue& p, hipStream_t s);

@@ -193,10 +193,21 @@ __global__ void latent_bwd_kernel(const float* __restrict__ dz, const float* __r
 // torch.optim.Adam (2.x single-tensor form): denom = sqrt(v)/sqrt(bc2) + eps; p -= lr/bc1 * m/denom
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2,
-                            float eps, float gscale, const unsigned* __restrict__ abort_word) {
-    // a chain kernel of this process gave up waiting for its group (chain.h): the gradients of the step are not valid,
-    // so the step leaves parameters and moments as they are; the host sees inet_chain_status() != 0 and decides
-    if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+                            float eps, float gscale, const unsigned* __restrict__ abort_word,
+                            const float* __restrict__ step_flag, unsigned* __restrict__ report) {
+    // A chain kernel gave up waiting for its group (chain.h): the gradients of the step are not valid, so the step leaves
+    // parameters and moments as they are.  Which word decides: `step_flag` when the caller passes one -- the flags of ALL
+    // ranks summed with the gradients (inet_step_flag_export + the all-reduce), so that every rank of a data-parallel job
+    // takes the same decision --, else this process's own device word.  `report` (host-mapped, chain.h step reports) tells
+    // the host what was decided and whether a parameter left the finite range (encoder.py:111-116, decoder.py:424-429).
+    const bool skip = step_flag ? (*step_flag != 0.f)
+                                : (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+    if (report && blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(report + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (skip) __hip_atomic_store(report + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (skip) return;
+    bool bad = false;
     const long n4 = n >> 2;
     f32x4* p4 = reinterpret_cast<f32x4*>(p);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
@@ -211,6 +222,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
             vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
             const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
             pp[e] -= lr_over_bc1 * (mm[e] / denom);
+            bad |= !(fabsf(pp[e]) <= 3.402823466e38f);          // NaN or +-inf
         }
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
@@ -220,8 +232,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         const float mm = b1 * m[i] + (1.f - b1) * gr;
         const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
         m[i] = mm; v[i] = vv;
-        p[i] -= lr_over_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        const float pn = p[i] - lr_over_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        p[i] = pn;
+        bad |= !(fabsf(pn) <= 3.402823466e38f);
     }
+    if (bad && report) __hip_atomic_store(report + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// dst[0] = 1 if a chain launch of this process has timed out since the last reset, else 0: the word a data-parallel caller sums
+// over ranks together with the gradients (inet_step_flag_export)
+__global__ void step_flag_export_kernel(const unsigned* abort_word, float* dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        dst[0] = (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.f : 0.f;
 }
 
 // out[n] (+)= sum_m X[m*ld + n].  Block = 64 columns x 4 row-lanes; grid.y splits rows; atomics combine.
@@ -400,11 +422,14 @@ __global__ void prologue_kernel(PwPrologue a) {
     } else {
         if (!a.tok_src) return;
         const long n = (long)a.tok_B * a.tok_T;
+        bool bad = false;
         for (long i = i0; i < n; i += step) {
             const long long v = a.tok_src[i];
+            bad |= a.tok_V > 0 && (v < 0 || v >= a.tok_V);
             if (a.tok_copy) a.tok_copy[i] = v;
             if (a.tok_shift) a.tok_shift[i] = (i % a.tok_T) == 0 ? a.tok_first : a.tok_src[i - 1];
         }
+        if (bad && a.tok_bad) __hip_atomic_fetch_add(a.tok_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -679,26 +704,39 @@ int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float
     return ok();
 }
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
-            float gscale, hipStream_t s) {
+            float gscale, hipStream_t s, const float* step_flag, int tagged, unsigned tag) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    ProfScope prof(PROF_HBM, 0.0, s, "adam", 28.0 * (double)n);      // read p,g,m,v; write p,m,v
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
-                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale,
-                       (const unsigned*)chain_dev_status());
+    unsigned* report = nullptr;
+    if (tagged && !(report = step_report_begin(tag))) return -2;
+    {
+        ProfScope prof(PROF_HBM, 0.0, s, "adam", 28.0 * (double)n);      // read p,g,m,v; write p,m,v
+        hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
+                           (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale,
+                           (const unsigned*)chain_dev_status(), step_flag, report);
+    }
+    if (ok() != 0) return -2;
+    return tagged ? step_report_end(tag, s) : 0;
+}
+int pw_step_flag_export(float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(step_flag_export_kernel, dim3(1), dim3(64), 0, s, (const unsigned*)chain_dev_status(), dst);
     return ok();
 }
 
 // sums[0..2] += (loss, accuracy, 1) unless a chain launch of this process has timed out since the last reset: the statistics of
 // steps whose results are not valid (and that the optimizer kernel skipped) stay out of the epoch means
-__global__ void epoch_stats_add_kernel(float* sums, const float* loss, const float* acc, const unsigned* abort_word) {
+__global__ void epoch_stats_add_kernel(float* sums, const float* loss, const float* acc, const unsigned* abort_word,
+                                       const float* step_flag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    // the same decision as the optimizer kernel of the step (adam_kernel): the ranks' summed flag if the caller has one
+    if (step_flag ? (*step_flag != 0.f)
+                  : (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) return;
     sums[0] += loss[0];
     if (acc) sums[1] += acc[0];
     sums[2] += 1.f;
 }
-int pw_epoch_stats_add(float* sums, const float* loss, const float* acc, hipStream_t s) {
-    hipLaunchKernelGGL(epoch_stats_add_kernel, dim3(1), dim3(64), 0, s, sums, loss, acc, (const unsigned*)chain_dev_status());
+int pw_epoch_stats_add(float* sums, const float* loss, const float* acc, hipStream_t s, const float* step_flag) {
+    hipLaunchKernelGGL(epoch_stats_add_kernel, dim3(1), dim3(64), 0, s, sums, loss, acc, (const unsigned*)chain_dev_status(),
+                       step_flag);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s) {
@@ -865,6 +903,8 @@ int pw_split_measures(const int* score, int B, int M, int L, int n_past, int n_t
     return ok();
 }
 int pw_prologue(const PwPrologue& p, hipStream_t s) {
-    hipLaunchKernelGGL(prologue_kernel, dim3(48, 7), dim3(256), 0, s, p);
+    PwPrologue q = p;
+    q.tok_bad = q.tok_V > 0 ? token_host_status() : nullptr;
+    hipLaunchKernelGGL(prologue_kernel, dim3(48, 7), dim3(256), 0, s, q);
     return ok();
 }

@@ -82,6 +82,7 @@ int vae_encoder_fwd(const inet_vae_config& c, int B, const long long* tokens, co
             pr.tab[dir] = PwTableJob{p + L.enc_emb, E, V, P[dir].w_ih, E, P[dir].b_ih, dir ? w.tabR : w.tabF, 3L * H, 3 * H, E};
         pr.ntab = 2;
         pr.zero_words = w.g.sync; pr.nzero = (long)kSyncAreas * kChainSyncWords;
+        pr.tok_src = tokens; pr.tok_B = B; pr.tok_T = T; pr.tok_V = V;     // range check only (encoder.py:118 embeds them)
         INET_TRY(pw_prologue(pr, s));
     }
     BiGru2In in{};
@@ -330,7 +331,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         pr.axpb_y = w.gvec0; pr.axpb_n = 3 * H;
         pr.fill_ptr = w.idxV; pr.nfill = B; pr.fill_val = V;
         if (teacher_forced) {
-            pr.tok_src = target; pr.tok_copy = samples; pr.tok_B = B; pr.tok_T = T; pr.tok_first = V;
+            pr.tok_src = target; pr.tok_copy = samples; pr.tok_B = B; pr.tok_T = T; pr.tok_first = V; pr.tok_V = V;
             if (ticks_chained) pr.tok_shift = w.tokin;
         }
         INET_TRY(pw_prologue(pr, s));

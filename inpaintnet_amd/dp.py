@@ -122,16 +122,24 @@ def start_bucket(grad, start, stop, join_side=False):
         mine.append((start, stop, work))
 
 
-def allreduce_grads(grad):
+def allreduce_grads(grad, store=None, head=0):
     """Sum the (rest of the) flat gradient arena over ranks and wait for the buckets started earlier; returns the
-    scale (1/world) the optimizer kernel applies to it."""
+    scale (1/world) the optimizer kernel applies to it.  `store` / `head`: the allocation the arena is a view of and the
+    floats in front of the arena inside it (Model._grad_store, Model._HEAD: the step flag).  The head is never part of a
+    bucket, so it always travels with the first range that is left for this call -- by default no extra collective (MeasureVAE:
+    the layer-0 range at the start of the arena) -- and every rank's optimizer kernel sees the sum of all ranks' flags."""
     w = world_size()
     mine = _pending.pop(grad.data_ptr(), [])
     if w > 1:
-        pos = 0
-        for a, b in sorted((a, b) for a, b, _ in mine) + [(grad.numel(), grad.numel())]:
+        if store is None or head <= 0:
+            store, head = grad, 0
+        else:
+            assert store.data_ptr() + 4 * head == grad.data_ptr(), "dp.allreduce_grads: grad is not store[head:]"
+        pos = 0                                       # positions in `store`; buckets are in arena coordinates
+        end = head + grad.numel()
+        for a, b in sorted((a + head, b + head) for a, b, _ in mine) + [(end, end)]:
             if a > pos:
-                torch.distributed.all_reduce(grad[pos:a], op=torch.distributed.ReduceOp.SUM)
+                torch.distributed.all_reduce(store[pos:a], op=torch.distributed.ReduceOp.SUM)
             pos = max(pos, b)
         for _, _, work in mine:
             work.wait()

@@ -37,9 +37,13 @@ class Model(torch.nn.Module):
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         # the gradient arena carries a tail of _STATS floats: per-step accumulators of the loss kernels (KL sum, loss,
         # accuracy) live there, so that zero_grad()'s ONE fill also zeroes them (each used to cost a torch.zeros launch)
-        self._grad_store = torch.zeros(total + self._STATS, dtype=torch.float32, device=device)
-        self.grad = self._grad_store[:total]
-        self._stats = self._grad_store[total:]
+        # ... and a head of _HEAD floats in front of it (16 bytes: the arena keeps its alignment): word 0 is the STEP FLAG, this
+        # rank's chain status of the step (ops.step_flag_export), summed over ranks by the same all-reduce that carries the first
+        # gradient range (dp.allreduce_grads) and read by the optimizer kernel -- every rank skips a step any rank failed in
+        self._grad_store = torch.zeros(self._HEAD + total + self._STATS, dtype=torch.float32, device=device)
+        self.grad = self._grad_store[self._HEAD:self._HEAD + total]
+        self.step_flag = self._grad_store[0:1]
+        self._stats = self._grad_store[self._HEAD + total:]
         self._stats_used = 0
         self._views = OrderedDict()
         self._gviews = OrderedDict()
@@ -114,6 +118,12 @@ class Model(torch.nn.Module):
                     t = torch.as_tensor(sd[k])
                     if tuple(t.shape) != tuple(v.shape):
                         raise RuntimeError(f"size mismatch for {k}: {tuple(t.shape)} vs {tuple(v.shape)}")
+                    # MeasureVAE/encoder.py:111-116, decoder.py:424-429 scan the weights for NaN in EVERY forward pass and raise
+                    # ValueError; here the scan happens where weights can become NaN: at load time (once, host tensors) and in
+                    # the optimizer kernel (inet_adam_step_ex's step report, Trainer.check_steps)
+                    if t.is_floating_point() and bool(torch.isnan(t).any()):
+                        print(f'{type(self).__name__} has become nan')
+                        raise ValueError(f"{type(self).__name__} has become nan: {k} holds NaN")
                     v.copy_(t.to(dtype=torch.float32))
         return missing, unexpected
 
@@ -133,6 +143,7 @@ class Model(torch.nn.Module):
         self._stats_used = 0
 
     _STATS = 64
+    _HEAD = 4
 
     def take_stats(self, n):
         """n zeroed floats for a kernel to accumulate into: a fresh slice of the arena's tail (zeroed by the last zero_grad();

@@ -240,11 +240,47 @@ def latent_bwd(dz, mu, ls, eps, kscale, kscale_dev=None):
     return dmu, dls
 
 
-def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0):
+def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0, step_flag=None, tag=None):
+    """tag (int): the kernel leaves a step report (step_report(tag)); step_flag: 1-element device tensor that decides whether the
+    step is applied (the ranks' summed chain status, include/inpaintnet_hip.h inet_adam_step_ex)."""
     for t in (p, g, m, v):
         _f32c(t)
-    check(_lib.lib().inet_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(b1), float(b2),
-                                    float(eps), int(step), float(gscale), stream_ptr()), "inet_adam_step")
+    if tag is None:
+        assert step_flag is None
+        check(_lib.lib().inet_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(b1), float(b2),
+                                        float(eps), int(step), float(gscale), stream_ptr()), "inet_adam_step")
+    else:
+        check(_lib.lib().inet_adam_step_ex(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(b1), float(b2),
+                                           float(eps), int(step), float(gscale), ptr(step_flag), int(tag) & 0xffffffff,
+                                           stream_ptr()), "inet_adam_step_ex")
+
+
+def step_flag_export(dst):
+    """dst[0] = 1.0 if a chain launch of this process has timed out since the last reset else 0.0 (on the current stream)."""
+    check(_lib.lib().inet_step_flag_export(ptr(_f32c(dst)), stream_ptr()), "inet_step_flag_export")
+
+
+def step_report(tag, wait=True):
+    """(executed, skipped, nonfinite) of the optimizer step issued under `tag`; wait: after the event behind that launch."""
+    out = (C.c_uint32 * 4)()
+    check(_lib.lib().inet_step_report(int(tag) & 0xffffffff, int(bool(wait)), out), "inet_step_report")
+    return bool(out[0]), bool(out[1]), bool(out[2])
+
+
+def token_status(reset=False):
+    """Prologue launches that saw a token index outside [0, num_notes) since the last reset (host-mapped counter)."""
+    return int(_lib.lib().inet_token_status(int(bool(reset))))
+
+
+class TokenRangeError(ValueError):
+    """decoder.py:36-45 check_index: a token index outside the vocabulary reached the model."""
+
+
+def check_tokens(what=""):
+    if token_status() > 0:
+        n = token_status(reset=True)
+        raise TokenRangeError(f"Invalid Value of index: {n} launch(es) met a token outside [0, num_notes) "
+                              f"({what or 'inet_token_status'}); the results computed from it are not valid")
 
 
 def dropout_mask(shape, p, seed, offset, device):
@@ -297,9 +333,11 @@ def gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, epi=0, aux=No
     return out
 
 
-def epoch_stats_add(sums, loss, accuracy=None):
-    """sums[:3] += (loss, accuracy, 1) on the device unless a chain launch has timed out (inet_epoch_stats_add)."""
-    check(_lib.lib().inet_epoch_stats_add(ptr(sums), ptr(loss), ptr(accuracy), stream_ptr()), "inet_epoch_stats_add")
+def epoch_stats_add(sums, loss, accuracy=None, step_flag=None):
+    """sums[:3] += (loss, accuracy, 1) on the device unless the step was skipped (step_flag: the ranks' summed chain status as
+    given to adam_step; None: this process's own status word) -- inet_epoch_stats_add_ex."""
+    check(_lib.lib().inet_epoch_stats_add_ex(ptr(sums), ptr(loss), ptr(accuracy), ptr(step_flag), stream_ptr()),
+          "inet_epoch_stats_add_ex")
 
 
 def gemm_bf3(A, B, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, out=None, accumulate=False, ksplit=0):
@@ -531,10 +569,12 @@ class ChainTimeoutError(RuntimeError):
 
 def check_chains(what=""):
     """Raise if any chain-kernel workgroup has timed out (reads the host-mapped counter: no synchronisation, ~1 us).
-    The inference wrappers call it after their device->host reads, Trainer.step() after queueing the optimizer."""
+    The inference wrappers call it after their device->host reads (Trainer.step() reads step reports instead: check_steps).
+    Also raises TokenRangeError (a ValueError) if a prologue met a token outside the vocabulary (decoder.py:36-45)."""
     n = chain_status()
     if n > 0:
         raise ChainTimeoutError(f"{n} chain-kernel workgroups gave up waiting for their group ({what or 'inet_chain_status'}): "
                                 "the results are not valid.  All workgroups of such a launch must be resident at once -- "
                                 "is the GPU shared, partitioned or CU-masked?  INET_CHAIN=0 (or ops.set_option(4, 0)) "
                                 "selects the per-step kernels.")
+    check_tokens(what)

@@ -17,6 +17,7 @@ Plotting / tensorboard plumbing of the reference is out of scope.
 import os
 import time
 from abc import ABC, abstractmethod
+from collections import deque
 
 import torch
 
@@ -117,8 +118,18 @@ class Trainer(ABC):
         self.start_epoch = 0                         # load_training_state() moves it
         self.chain_fallback = True                   # on a chain-kernel timeout: per-step kernels + retry (else raise)
         self.chain_fallbacks = 0
+        self.lost_steps = 0                          # optimizer steps the device skipped (their batches were run again)
         # deferred side-stream joins for zero_grad() -> forward -> backward -> step() sequences (see zero_grad)
         self.overlap_backward = False
+        # Step reports (inet_adam_step_ex): every optimizer launch leaves a record of what it decided; the host reads the
+        # record of step k when it has queued step k + report_lag -- by then that kernel has normally run, so the read costs
+        # nothing, and it happens at the SAME step on every rank of a data-parallel job (the decision itself is the ranks'
+        # summed flag), so all ranks fall back and repeat the same batches together.
+        self.report_lag = 2
+        self._tag = 0
+        self._inflight = deque()                     # tags whose report has not been read yet, oldest first
+        self._recent = deque(maxlen=8)               # (tag, batch) of the epoch loop's last steps: what a fallback runs again
+        self._lost = []                              # tags found skipped since the last fallback
 
     # ---- utils/trainer.py:41-124 (plot/log plumbing omitted) -----------------------
     def train_model(self, batch_size, num_epochs, plot=False, log=False, seed=0):
@@ -152,7 +163,7 @@ class Trainer(ABC):
     # ---- utils/trainer.py:126-163 ---------------------------------------------------
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
         dev = self.model.flat.device
-        sums = torch.zeros(3, dtype=torch.float32, device=dev)        # loss sum, accuracy sum, batches
+        sums = torch.zeros(4, dtype=torch.float32, device=dev)        # loss sum, accuracy sum, batches, chain timeouts
         t0 = time.time()
         prev_overlap, self.overlap_backward = self.overlap_backward, bool(train)
         try:
@@ -161,43 +172,81 @@ class Trainer(ABC):
                 data_loader = DeviceFeed(data_loader, fields=self.feed_fields, device=dev)
             for sample_id, batch in enumerate(data_loader):
                 batch_data = self.process_batch_data(batch)
-                for attempt in (0, 1):
-                    try:
-                        self.zero_grad()
-                        if train:
-                            loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=True)
-                            loss.backward()
-                            self.step()
-                        else:
-                            with torch.no_grad():
-                                loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=False)
-                        break
-                    except ops.ChainTimeoutError:
-                        # A persistent kernel of an earlier step (the check does not synchronise) gave up waiting for its
-                        # group.  The optimizer kernel has left the weights alone since then (inet_adam_step reads the same
-                        # flag on the device), so nothing is corrupted: switch to the per-step kernels for the rest of the
-                        # process, and run this batch again.  Batches between the failure and its detection were not applied.
-                        if attempt or not self.chain_fallback:
-                            raise
-                        self._fall_back_from_chains()
-                self._accumulate_stats(sums, loss, accuracy)
+                self._run_batch(batch_data, epoch_num, train, sums)
+            if train:                                # the reports of the last report_lag steps (replays what they lost)
+                self._settle(epoch_num, sums)
         finally:
             self.overlap_backward = prev_overlap
             ops.side_defer(False)
+            self._recent.clear()
+        # Chain launches outside optimizer steps (validation passes) have no step report: their status travels with the sums, so
+        # that every rank sees every rank's failures and all of them raise together instead of one leaving the others in a
+        # collective.  (One synchronisation per epoch; the sums' read-back was one already.)
+        if sums.is_cuda:
+            torch.cuda.synchronize(dev)
+            sums[3] = float(max(ops.chain_status(), 0))
         dp.allreduce_sum_(sums)                      # every rank reports (and early-stops on) the global means
         out = sums.tolist()                          # the one device->host sync of the epoch
-        timeouts = ops.chain_status(reset=True)      # persistent kernels: bounded spins report here instead of hanging
-        if timeouts > 0:                             # < 0: no chain kernel has run in this process
-            raise RuntimeError(f"{timeouts} chain-kernel workgroups gave up waiting for their group during this epoch "
-                               "(inet_chain_status); its results are not valid")
+        if sums.is_cuda:
+            ops.chain_status(reset=True)             # persistent kernels: bounded spins report here instead of hanging
+            ops.check_tokens("Trainer.loss_and_acc_on_epoch")
+        if out[3] > 0:
+            raise RuntimeError(f"{int(out[3])} chain-kernel workgroups (all ranks) gave up waiting for their group during "
+                               "this epoch outside an optimizer step (inet_chain_status); its results are not valid")
         n = max(out[2], 1.0)
         self.last_epoch_seconds = time.time() - t0
         return out[0] / n, out[1] / n
 
+    def _run_batch(self, batch_data, epoch_num, train, sums, replay=False):
+        """One batch of the epoch loop.  A ChainTimeoutError out of step() means: an optimizer step issued report_lag steps ago
+        (or later) skipped itself because a persistent kernel of some rank gave up waiting for its group.  Nothing is corrupted
+        -- on EVERY rank the optimizer kernel has left the weights alone since (it reads the ranks' summed flag) and the masked
+        epoch statistics left those batches out -- so all ranks switch to the per-step kernels and run the lost batches again,
+        in order."""
+        try:
+            self.zero_grad()
+            if train:
+                loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=True)
+                loss.backward()
+                self._recent.append((self._tag, batch_data))       # step() issues its optimizer launch under this tag
+                self.step()
+            else:
+                with torch.no_grad():
+                    loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, train=False)
+        except ops.ChainTimeoutError:
+            if replay or not self.chain_fallback:
+                raise
+            self._replay(self._fall_back_from_chains(), epoch_num, sums)
+            return
+        self._accumulate_stats(sums, loss, accuracy, self._flag())
+
+    def _replay(self, lost, epoch_num, sums):
+        batches = dict(self._recent)
+        for tag in lost:
+            if tag not in batches:
+                raise RuntimeError(f"optimizer step {tag} was skipped after a chain-kernel timeout and its batch is no longer "
+                                   "held (report_lag too large for the replay window)")
+            self._run_batch(batches[tag], epoch_num, True, sums, replay=True)
+        self._settle(epoch_num, sums, replay=True)
+
+    def _settle(self, epoch_num, sums, replay=False):
+        """Read every outstanding step report (waits for those optimizer launches); lost steps are run again."""
+        try:
+            self.check_steps(wait_all=True)
+        except ops.ChainTimeoutError:
+            if replay or not self.chain_fallback:
+                raise
+            self._replay(self._fall_back_from_chains(), epoch_num, sums)
+
+    def _flag(self):
+        """The device word that decides whether this step counts: the ranks' summed chain status under data parallelism
+        (None = the process's own status word)."""
+        return self.model.step_flag if dp.world_size() > 1 and self.model.grad.is_cuda else None
+
     @staticmethod
-    def _accumulate_stats(sums, loss, accuracy):
-        """sums[:3] += (loss, accuracy, 1) on the device in one launch (inet_epoch_stats_add); a batch whose chain kernels
-        timed out -- its results are not valid and the optimizer kernel skipped it -- stays out of the means."""
+    def _accumulate_stats(sums, loss, accuracy, step_flag=None):
+        """sums[:3] += (loss, accuracy, 1) on the device in one launch (inet_epoch_stats_add_ex); a batch whose chain kernels
+        timed out on any rank -- its results are not valid and the optimizer kernel skipped it -- stays out of the means."""
         loss = loss.detach()
         if loss.dim() > 0:
             loss = loss.mean()
@@ -209,7 +258,7 @@ class Trainer(ABC):
                 sums[1] += acc[0]
             sums[2] += 1.0
             return
-        ops.epoch_stats_add(sums, loss, acc)
+        ops.epoch_stats_add(sums, loss, acc, step_flag)
 
     def zero_grad(self):
         """utils/trainer.py:165-170.  With `overlap_backward` set (the epoch loop and bench.py set it) the step that
@@ -221,25 +270,72 @@ class Trainer(ABC):
         self.model.zero_grad()
 
     def step(self):
-        """utils/trainer.py:172-177 (+ the data-parallel gradient exchange)."""
+        """utils/trainer.py:172-177 (+ the data-parallel gradient exchange).  May raise ops.ChainTimeoutError / ValueError
+        for an EARLIER step (see check_steps)."""
         ops.side_defer(False, release=False)         # joins; deferred mode only lives between zero_grad() and step()
-        gscale = dp.allreduce_grads(self.model.grad)
+        m = self.model
+        flag = self._flag()
+        if flag is not None:
+            ops.step_flag_export(flag)               # this rank's chain status -> the word in front of the arena ...
+        gscale = dp.allreduce_grads(m.grad, store=m._grad_store, head=m._HEAD)     # ... summed with the gradients
         ops.release_held()                           # (after the exchange: the buckets' streams were ordered behind side work)
         self.adam_t += 1
-        ops.adam_step(self.model.flat, self.model.grad, self.adam_m, self.adam_v, self.lr, self.adam_t,
-                      self.betas[0], self.betas[1], self.eps, gscale)
-        # persistent kernels: a bounded spin that ran out raises here, at the latest a few steps after it happened (the
-        # host-mapped counter is read without synchronising); the Adam kernel itself skips its update while the flag is up
-        ops.check_chains("Trainer.step")
+        tag = self._tag
+        self._tag += 1
+        if m.grad.is_cuda:
+            ops.adam_step(m.flat, m.grad, self.adam_m, self.adam_v, self.lr, self.adam_t, self.betas[0], self.betas[1],
+                          self.eps, gscale, step_flag=flag, tag=tag)
+            self._inflight.append(tag)
+            self.check_steps()
+        else:
+            ops.adam_step(m.flat, m.grad, self.adam_m, self.adam_v, self.lr, self.adam_t, self.betas[0], self.betas[1],
+                          self.eps, gscale)
+
+    def check_steps(self, wait_all=False):
+        """Read the reports of the optimizer steps issued at least `report_lag` steps ago (all outstanding ones with
+        wait_all).  Raises ops.ChainTimeoutError if one of them skipped itself -- a persistent kernel of SOME rank had timed out,
+        see _run_batch --, ValueError if a parameter became NaN / inf in one of them (the reference's "... has become nan",
+        MeasureVAE/encoder.py:111-116, decoder.py:424-429), ops.TokenRangeError for a token outside the vocabulary
+        (decoder.py:36-45).  Identical on every rank of a data-parallel job: same reports, read at the same step."""
+        newest = self._tag - 1
+        skipped = nonfinite = False
+        while self._inflight and (wait_all or self._inflight[0] <= newest - self.report_lag):
+            tag = self._inflight.popleft()
+            _, skip, bad = ops.step_report(tag, wait=True)
+            if skip:
+                self._lost.append(tag)
+            skipped |= skip
+            nonfinite |= bad
+        if skipped:
+            raise ops.ChainTimeoutError(
+                f"optimizer step(s) {self._lost} skipped: a chain kernel gave up waiting for its group (on this or another "
+                "rank), the gradients of those steps are not valid and the weights were left alone.  All workgroups of such a "
+                "launch must be resident at once -- is the GPU shared, partitioned or CU-masked?  INET_CHAIN=0 (or "
+                "ops.set_option(4, 0)) selects the per-step kernels.")
+        if nonfinite:
+            raise ValueError(f"{type(self.model).__name__} has become nan (a parameter left the finite range in an optimizer step)")
+        if self.model.flat.is_cuda:
+            ops.check_tokens("Trainer.step")
 
     def _fall_back_from_chains(self):
+        """After a ChainTimeoutError out of step() / check_steps(): wait for the device, find every skipped step, take their
+        count back out of the bias-correction step number, clear the status words, switch this process to the per-step
+        kernels.  Returns the tags of the lost steps, oldest first (every rank computes the same list)."""
         torch.cuda.synchronize()
+        while self._inflight:
+            tag = self._inflight.popleft()
+            if ops.step_report(tag, wait=True)[1]:
+                self._lost.append(tag)
+        lost, self._lost = sorted(set(self._lost)), []
         n = ops.chain_status(reset=True)
         ops.set_option(4, 0)                          # per-step kernels from here on (INET_CHAIN=0 semantics, in-process)
         self.chain_fallbacks += 1
-        self.adam_t = max(self.adam_t - 1, 0)         # the step that raised did not update anything
-        print(f"[inpaintnet_amd] {n} chain-kernel workgroups timed out; chain kernels are now OFF for this process and the "
-              "batch is run again (is the GPU shared, partitioned or CU-masked?)")
+        self.lost_steps += len(lost)
+        self.adam_t = max(self.adam_t - len(lost), 0)  # those launches did not update anything
+        print(f"[inpaintnet_amd] rank {dp.rank()}: {max(n, 0)} chain-kernel workgroups of this rank timed out; optimizer steps "
+              f"{lost} were skipped on every rank; chain kernels are now OFF for this process and those batches are run again "
+              "(is the GPU shared, partitioned or CU-masked?)")
+        return lost
 
     # ---- optimizer / epoch resume (SURVEY 8f1 add-on: the reference saves weights only, utils/model.py:16-53) ----
     def training_state(self, next_epoch=0):

@@ -165,45 +165,91 @@ def test_lstm_tagged_handoff_repeated():
 def test_injected_chain_timeout_skips_adam_and_trainer_falls_back():
     """Failure path of the persistent kernels on a healthy GPU (inet_set_option key 6 drops one workgroup of the next forward
     chain launch): the bounded spin runs out, inet_chain_status() reports it, the optimizer kernel leaves the weights
-    alone while the flag is up, Trainer.step() raises, and the epoch loop switches to the per-step kernels and runs the
-    batch again (Trainer._fall_back_from_chains)."""
+    alone while the flag is up and says so in its step report, Trainer.check_steps() raises when it reads that report
+    (report_lag steps later, or at once with wait_all), and the epoch loop switches to the per-step kernels and runs every
+    lost batch again (Trainer._fall_back_from_chains / _replay) -- with the bias-correction step number put right."""
     from inpaintnet_amd import synthetic
     from inpaintnet_amd.measure_vae import MeasureVAE
     from inpaintnet_amd.vae_trainer import VAETrainer
-    class SyncTrainer(VAETrainer):                   # detection lags the failure by design (no synchronisation in step());
-        def process_batch_data(self, batch):         # a sync per batch makes WHERE it is detected deterministic for the test
-            torch.cuda.synchronize()
-            return super().process_batch_data(batch)
     ds = synthetic.SyntheticFolkDataset(num_notes=48)
     model = MeasureVAE(ds)
-    trainer = SyncTrainer(ds, model, lr=1e-4)
+    trainer = VAETrainer(ds, model, lr=1e-4)
     model.train()
     tok = torch.from_numpy(synthetic.det_tokens("fault", (64, 24), 48)).cuda()
     assert ops.chain_status(reset=True) >= 0
     try:
-        # (a) direct: a failed step never reaches the weights
+        # (a) direct: a failed step never reaches the weights, and the report says it was skipped
         before = model.flat.clone()
         trainer.zero_grad()
         ops.set_option(6, 1)
         loss, acc = trainer.loss_and_acc_for_batch(tok, 0, train=True)
         loss.backward()
+        trainer.step()                               # (queues the optimizer launch; its report is read later)
         with pytest.raises(ops.ChainTimeoutError):
-            torch.cuda.synchronize()                 # (make the check deterministic: the spin takes ~0.4 s)
-            trainer.step()
+            trainer.check_steps(wait_all=True)       # waits for that launch (the spin takes ~0.4 s)
         torch.cuda.synchronize()
         assert ops.chain_status() > 0
         assert torch.equal(model.flat, before)       # Adam was queued and skipped itself
         assert ops.chain_status(reset=True) > 0 and ops.chain_status() == 0
-        # (b) the epoch loop: falls back to per-step kernels, repeats the batch, finishes the epoch
+        # (b) the epoch loop: the fault hits batch 0 of 5; its report is read two steps later, by which time steps 1 and 2 were
+        # skipped on the device as well (the flag is sticky): all three are run again on the per-step kernels
+        trainer = VAETrainer(ds, model, lr=1e-4)
         score, md = synthetic.SyntheticFolkDataset(num_notes=48, n_seq=8, seed=1).tensors()
-        loader = [(torch.from_numpy(score[:4]), torch.from_numpy(md[:4]))] * 3
+        loader = [(torch.from_numpy(score[:4]), torch.from_numpy(md[:4]))] * 5
         trainer.dataset.n_bars = 16
         ops.set_option(6, 1)
         l, a = trainer.loss_and_acc_on_epoch(loader, 0, train=True)
         assert np.isfinite(l) and trainer.chain_fallbacks == 1
+        assert trainer.lost_steps == trainer.report_lag + 1
+        assert trainer.adam_t == 5                   # five batches, five applied updates: the skipped launches do not count
         assert not torch.equal(model.flat, before)
         assert ops.chain_status() == 0
     finally:
         ops.set_option(6, 0)
         ops.set_option(4, 1)
         ops.chain_status(reset=True)
+
+
+def test_nonfinite_parameters_and_bad_tokens_raise_valueerror():
+    """Reference error semantics without host scans: MeasureVAE/encoder.py:111-116 and decoder.py:424-429 raise ValueError
+    ("... has become nan") when a weight is NaN, decoder.py:36-45 (check_index) for an index outside the vocabulary.  Here the
+    optimizer kernel flags a parameter that leaves the finite range in its step report and the prologue kernels count bad
+    tokens into a host-mapped word; Trainer.check_steps() raises at its next read."""
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    from inpaintnet_amd.vae_trainer import VAETrainer
+    ds = synthetic.SyntheticFolkDataset(num_notes=48)
+    model = MeasureVAE(ds)
+    trainer = VAETrainer(ds, model, lr=1e-4)
+    model.train()
+    tok = torch.from_numpy(synthetic.det_tokens("nan", (32, 24), 48)).cuda()
+    ops.token_status(reset=True)
+
+    def one_step(tokens):
+        trainer.zero_grad()
+        loss, acc = trainer.loss_and_acc_for_batch(tokens, 0, train=True)
+        loss.backward()
+        trainer.step()
+    one_step(tok)
+    trainer.check_steps(wait_all=True)               # healthy: nothing raised
+    # a token == V (one past the vocabulary)
+    bad = tok.clone()
+    bad[3, 7] = 48
+    with pytest.raises(ValueError, match="Invalid Value of index"):
+        one_step(bad)                                # (step() itself raises if the prologue has already run)
+        trainer.check_steps(wait_all=True)
+    torch.cuda.synchronize()
+    assert ops.token_status() == 0                   # raising consumed the count
+    model.load_state_dict({k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in model.state_dict().items()})
+    trainer = VAETrainer(ds, model, lr=1e-4)
+    one_step(tok)
+    trainer.check_steps(wait_all=True)
+    # a NaN weight: the next optimizer step sees a non-finite parameter
+    model.param("encoder.linear_mean.0.bias")[5] = float("nan")
+    with pytest.raises(ValueError, match="has become nan"):
+        one_step(tok)
+        trainer.check_steps(wait_all=True)
+    # ... and a state_dict with a NaN is refused at load time (inference-only users never run the optimizer)
+    sd = model.state_dict()
+    with pytest.raises(ValueError, match="has become nan"):
+        model.load_state_dict(sd)

@@ -183,3 +183,67 @@ def test_latent_trainer_two_ranks_match_single_process_global_batch(tmp_path):
     err = np.abs(ref - r0["grad0"]).max() / np.abs(ref).max()
     assert err < 2e-5, err
     assert abs(loss - 0.5 * (float(r0["loss0"]) + float(r1["loss0"]))) < 1e-5 * abs(loss)
+
+
+# ---- a chain-kernel timeout on ONE of two ranks ------------------------------------------------
+NB = 6                                      # global batches of 4 sequences x 16 bars: 32 measures per rank and step
+
+
+def _fault_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from inpaintnet_amd import dp, ops, synthetic
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    from inpaintnet_amd.vae_trainer import VAETrainer
+    assert dp.init_from_env(backend="gloo") == world
+    torch.cuda.set_device(0)
+
+    class FaultyTrainer(VAETrainer):
+        seen = 0
+
+        def process_batch_data(self, batch):
+            if self.seen == 1 and dp.rank() == 1 and self.chain_fallbacks == 0:
+                ops.set_option(6, 1)        # rank 1 only: the next forward chain launch loses a workgroup (~0.4 s spin)
+            self.seen += 1
+            return super().process_batch_data(batch)
+
+    ds = synthetic.SyntheticFolkDataset(num_notes=48)
+    ds.n_bars = 16
+    model = MeasureVAE(ds)                  # reference defaults (H = 512): the chain kernels run
+    trainer = FaultyTrainer(ds, model, lr=1e-3)
+    dp.seed_shared(3)
+    dp.seed_rank(3)
+    dp.broadcast_params(model.flat)
+    model.train()
+    start = model.flat.clone()
+    score, md = synthetic.SyntheticFolkDataset(num_notes=48, n_seq=4 * NB, seed=2).tensors()
+    loader = [(torch.from_numpy(score[4 * i:4 * i + 4]), torch.from_numpy(md[4 * i:4 * i + 4])) for i in range(NB)]
+    assert ops.chain_status(reset=True) >= 0
+    try:
+        loss, acc = trainer.loss_and_acc_on_epoch(loader, 0, train=True)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"f{rank}.npz"), flat=model.flat.cpu().numpy(), loss=loss, acc=acc,
+                 adam_t=trainer.adam_t, fallbacks=trainer.chain_fallbacks, lost=trainer.lost_steps, seen=trainer.seen,
+                 own_timeouts=ops.chain_status(), moved=float((model.flat - start).abs().max()),
+                 m=trainer.adam_m.cpu().numpy())
+    finally:
+        ops.set_option(6, 0)
+        ops.set_option(4, 1)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_chain_timeout_on_one_rank_is_handled_by_all_ranks_together(tmp_path):
+    """inet_set_option(6, 1) on rank 1 only, in the middle of an epoch.  The failing rank's flag travels with the gradients, so
+    BOTH ranks' optimizer kernels skip that step and the next ones, both read the same step reports at the same step, both
+    fall back to the per-step kernels and run the same lost batches again: the replicas end bit-identical, with the same
+    number of applied updates (= batches), and nobody is left waiting in a collective."""
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_fault_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "f0.npz"), np.load(tmp_path / "f1.npz")
+    assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["m"], r1["m"])
+    assert np.isfinite(r0["flat"]).all() and float(r0["moved"]) > 0
+    assert int(r0["adam_t"]) == int(r1["adam_t"]) == NB                       # every batch applied exactly once
+    assert int(r0["fallbacks"]) == int(r1["fallbacks"]) == 1
+    assert int(r0["lost"]) == int(r1["lost"]) == 3                            # report_lag + 1 steps were skipped and repeated
+    assert int(r0["seen"]) == int(r1["seen"]) == NB
+    assert float(r0["loss"]) == float(r1["loss"]) and np.isfinite(float(r0["loss"]))   # summed over ranks: identical means

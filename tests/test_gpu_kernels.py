@@ -95,7 +95,10 @@ def test_gemv_rows(M, N, K):
 
 @pytest.mark.parametrize("akm,bkm,M,N,K,ksplit", [(0, 0, 384, 384, 256, 0), (0, 0, 192, 128, 64, 1), (0, 1, 768, 256, 1536, 0),
                                                   (1, 1, 1536, 512, 6144, 0), (1, 1, 192, 128, 2048, 4), (1, 0, 192, 640, 96, 1),
-                                                  (0, 0, 1536, 3072, 1024, 0)])
+                                                  (0, 0, 1536, 3072, 1024, 0),
+                                                  # one tile per workgroup, tiles % 256 == 0: the XCD-block tile order (Bf3Map)
+                                                  (0, 0, 6144, 3072, 64, 1), (0, 1, 6144, 1024, 96, 1), (0, 0, 3072, 3072, 64, 1),
+                                                  (0, 0, 1536, 6144, 64, 1)])
 def test_gemm_bf3_layouts(akm, bkm, M, N, K, ksplit):
     """Products through exact three-piece bf16 splits on the bf16 matrix cores (csrc/gemm_bf3.hip) against float64: every
     source layout (the split kernels' row and column forms), both tile widths, the k range split over the grid, bias,
