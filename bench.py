@@ -63,7 +63,7 @@ def _free_port():
 def launch_ranks(args, argv):
     """Parent of a multi-GPU run: never initialises the GPU (device_count() does not, on this image)."""
     have = torch.cuda.device_count()
-    if args.gpus > have:
+    if args.gpus > have and os.environ.get("INET_BENCH_SHARE_GPU") != "1":
         print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to report a "
               f"{have}-GPU number as a {args.gpus}-GPU result", file=sys.stderr)
         return 2
@@ -197,19 +197,24 @@ def parity_check(model, tokens_dev):
         worst[f"grads_{tag}"] = gerr
         worst[f"grads_{tag}_worst_tensor"] = gname
         worst[f"grads_{tag}_all_other_tensors"] = gnext
+        # token indices: exact on every row whose top-2 margin exceeds 1e-4 of the row's own maximum (rows whose two best
+        # post-ReLU logits are both 0 cannot be compared); the fraction actually compared is reported
         top2 = torch.topk(wr.detach(), 2, dim=-1).values
-        ok = (top2[..., 0] - top2[..., 1]) > 1e-4
+        ok = (top2[..., 0] - top2[..., 1]) > 1e-4 * top2[..., 0].clamp_min(1e-30)
         worst[f"token_mismatch_{tag}"] = int((s.cpu()[:, 0][ok] != sr[:, 0][ok]).sum())
+        worst[f"token_rows_compared_{tag}"] = int(ok.sum())
+        worst[f"token_rows_compared_frac_{tag}"] = float(ok.float().mean())
     passed = all(worst[f"loss_{t}"] <= 1e-4 and worst[f"logits_{t}"] <= 1e-4 and worst[f"grads_{t}"] <= 5e-4 and
                  worst[f"token_mismatch_{t}"] == 0 and worst[f"kink_violations_{t}"] == 0 and
                  worst[f"kink_flips_{t}"] <= 8 + 1e-5 * worst[f"kink_elements_{t}"] for t in ("tf", "fr"))
     return {"parity_checked": bool(passed),
-            "max_rel_err": round(max(v for k, v in worst.items() if isinstance(v, float) and not k.startswith("kink_")), 8),
+            "max_rel_err": round(max(v for k, v in worst.items() if isinstance(v, float) and not k.startswith(("kink_", "token_"))), 8),
             "kink_flips": worst["kink_flips_tf"] + worst["kink_flips_fr"],
             "kink_violations": worst["kink_violations_tf"] + worst["kink_violations_fr"],
             "parity_detail": {k: (round(v, 8) if isinstance(v, float) else v) for k, v in worst.items()},
             "parity_tolerance": "loss 1e-4 rel, logits 1e-4 of max, every gradient tensor 5e-4 of its max, sampled "
-                                "tokens exact on rows with top-2 margin > 1e-4 (north_star); SELU/ReLU branches "
+                                "tokens exact on rows with top-2 margin > 1e-4 of the row's maximum (north_star; "
+                                "token_rows_compared_frac_* = the share of rows that was compared); SELU/ReLU branches "
                                 "aligned with the GPU's only where the oracle's pre-activation is within 1e-5 of 0 "
                                 "(kink_flips = how many; kink_violations = branch differences outside that band, must be 0)"}
 
@@ -302,6 +307,25 @@ def timed(step, steps, warmup, fence):
         loss = step()
     fence()
     return time.perf_counter() - t0, loss
+
+
+def exchange_report(wl, dp, step_s, fence, dev, steps=40):
+    """What the data-parallel exchange of one step looks like and what it costs: the ranges reduced under the backward pass
+    ("bucket") and in step() ("final": includes the step-flag word in front of the arena), in MB, and the exposed time = the
+    step with the exchange minus the same step with every gradient collective switched off (dp.set_exchange), MAX over ranks."""
+    wl.step()
+    torch.cuda.synchronize()
+    ranges = [{"kind": k, "mbytes": round(4 * (b - a) / 1e6, 3)} for k, a, b in dp.last_ranges]
+    dp.set_exchange(False)
+    try:
+        dt_off, _ = timed(wl.step, steps, 5, fence)
+    finally:
+        dp.set_exchange(True)
+    dp.broadcast_params(wl.model.flat)                         # (the ranks drifted apart while nothing was exchanged)
+    t = torch.tensor([dt_off / steps], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return {"ranges": ranges, "ms_per_step_without_exchange": round(1e3 * float(t.item()), 4),
+            "exposed_exchange_ms_per_step": round(1e3 * (step_s - float(t.item())), 4)}
 
 
 def allreduce_ms(grad, iters=10):
@@ -559,9 +583,10 @@ def epoch_loop_extra(wl, batches=100):
 
 def vae4096_extra(wl, batch=4096, steps=6, warmup=2):
     """The reference's default MeasureVAE step (train_measure_vae.py:33: batch_size 256 sequences x 16 bars = 4096 measures,
-    vae_trainer.py:49-52) on the same model: more rows than one resident chain launch holds, so every recurrent layer runs
-    as chain launches over row chunks (csrc/seq.hip chain_chunk_rows), forward and backward.  Secondary number; the
-    headline stays BASELINE.json's configs[1] (256 measures per GPU)."""
+    vae_trainer.py:49-52) on the same model: more rows than one resident chain launch holds.  Up to INET_CHAIN_CHUNK_MAX
+    (1024) rows the recurrent layers would run as chain launches over row chunks (csrc/seq.hip chain_chunk_rows); at 4096 the
+    H = 512 layers run one launch per time step over all rows, the faster form there (`per_step_gru_launches` counts them).
+    Secondary number; the headline stays BASELINE.json's configs[1] (256 measures per GPU)."""
     from inpaintnet_amd import ops, synthetic
     dev = wl.tokens.device
     tok = torch.from_numpy(synthetic.det_tokens("bench/4096", (batch, 24), NUM_NOTES)).to(dev)
@@ -595,7 +620,9 @@ def vae4096_extra(wl, batch=4096, steps=6, warmup=2):
                                "batch": batch, "launches_per_step": len(labels), "per_step_gru_launches": per_step,
                                "final_loss": round(float(loss.detach()), 5),
                                "workload": "MeasureVAE training at the reference's default batch: 256 sequences x 16 bars = "
-                                           "4096 measures per step (train_measure_vae.py:33), chain kernels over 256-row chunks"}}
+                                           "4096 measures per step (train_measure_vae.py:33); above INET_CHAIN_CHUNK_MAX = 1024 rows the H = 512 "
+                                           "layers run one launch per time step (per_step_gru_launches), which is the "
+                                           "faster form there (profiles/r03_e_batch_crossover.txt)"}}
 
 
 def vocab_extra(num_notes=61, steps=40, warmup=8):
@@ -734,13 +761,22 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # INET_BENCH_SHARE_GPU=1: a FUNCTIONAL check of the N > 1 code path on a box with one GPU -- all ranks use cuda:0 and gloo
+    # carries the exchange (RCCL wants one device per rank); the line it prints says so and is not a scaling number
+    share_gpu = os.environ.get("INET_BENCH_SHARE_GPU") == "1" and world_env > 1
+    if share_gpu:
+        local_rank = 0
+        # Every persistent launch must be resident in full, and two processes on one GPU cannot promise each other that (a first
+        # version gave each rank half the CUs, INET_CHAIN_CUS=128: a chain still ran into its bounded spin -- and both ranks
+        # reported it and left together, which is the failure path working on a real timeout): the per-step kernels here.
+        os.environ.setdefault("INET_CHAIN", "0")
     if local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)",
               file=sys.stderr)
         sys.exit(2)
 
     from inpaintnet_amd import dp, ops
-    world = dp.init_from_env(backend="nccl") if world_env > 1 else 1
+    world = dp.init_from_env(backend="gloo" if share_gpu else "nccl") if world_env > 1 else 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -766,7 +802,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    dt, loss = timed(wl.step, args.steps, args.warmup, fence)
+    try:
+        dt, loss = timed(wl.step, args.steps, args.warmup, fence)
+    except ops.ChainTimeoutError as e:
+        # raised by Trainer.step() on EVERY rank at the same step (the decision travels with the gradients): all ranks leave
+        print(f"[bench] rank {rank}: {e}\n[bench] result invalid", file=sys.stderr)
+        sys.exit(3)
     dt_local = dt
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -774,19 +815,40 @@ def main():
         dt = float(tmax.item())
     final_loss = float(loss.detach())
     from inpaintnet_amd import ops as _ops
-    chain_timeouts = _ops.chain_status(reset=True)
-    if chain_timeouts > 0:
-        print(f"[bench] {chain_timeouts} chain-kernel workgroups timed out in the timed region: result invalid", file=sys.stderr)
+    # Persistent-kernel health of the timed region, per rank: workgroups that gave up waiting (inet_chain_status) and optimizer
+    # steps that skipped themselves (the step reports; under data parallelism every rank skips a step ANY rank failed in).  The
+    # verdict is collective: all ranks exit together, nobody is left waiting in the next all-reduce.
+    skipped_steps = 0
+    try:
+        wl.trainer.check_steps(wait_all=True)
+    except _ops.ChainTimeoutError:
+        skipped_steps = len(wl.trainer._lost)
+    chain_timeouts = max(_ops.chain_status(reset=True), 0)
+    health = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+    health[2 * rank], health[2 * rank + 1] = float(chain_timeouts), float(skipped_steps)
+    if world > 1:
+        torch.distributed.all_reduce(health)
+    health = [int(v) for v in health.tolist()]
+    timeouts_per_rank, skipped_per_rank = health[0::2], health[1::2]
+    if sum(health) > 0:
+        print(f"[bench] rank {rank}: chain-kernel workgroups timed out in the timed region (per rank {timeouts_per_rank}, "
+              f"skipped optimizer steps per rank {skipped_per_rank}): result invalid", file=sys.stderr)
+        if world > 1:
+            torch.distributed.destroy_process_group()
         sys.exit(3)
 
     per_rank = None
     ar_ms = None
+    dp_report = None
     if world > 1:
         mine = torch.zeros(world, dtype=torch.float64, device=dev)
         mine[rank] = wl.units_per_step * args.steps / dt_local
         torch.distributed.all_reduce(mine)
         per_rank = [round(v, 1) for v in mine.tolist()]
         ar_ms = allreduce_ms(wl.model.grad)
+        dp_report = exchange_report(wl, dp, dt / args.steps, fence, dev)
+        dp_report["chain_timeouts_per_rank"] = timeouts_per_rank
+        dp_report["skipped_steps_per_rank"] = skipped_per_rank
 
     extras = {}
     roof = None
@@ -862,6 +924,9 @@ def main():
             out["per_rank_units_per_s"] = per_rank
             out["allreduce_ms_per_step"] = ar_ms
             out["allreduce_mbytes"] = round(wl.arena_mb, 1)
+            out["dp"] = dp_report
+            if share_gpu:
+                out["data"] = "synthetic; FUNCTIONAL CHECK ONLY: all ranks share one GPU and gloo carries the exchange"
         cpu = None
         if world == 1 and args.workload == "vae":
             if not args.no_parity:

@@ -304,7 +304,10 @@ int inet_set_option(int key, int value);
  * key 10 = which layers' weight gradients run on the bf16 pipe (INET_BF3_WGRAD; bit 0 layer 1, bit 1 layer 0; default 1).
  * key 11 = second-generation kernel for the BPTT chains too (default 0; INET_CHAIN2_BWD=1): the faster kernel alone, the slower
  * step -- it holds the CU's LDS, which keeps the backward pass's leaf work out for the length of the chain (csrc/gru_chain.hip).
- * Keys 8-11 must not change between a forward call and its backward call. */
+ * key 12 = big-batch GRU forward steps on the bf16 pipe (csrc/gru_step_bf3.hip; INET_STEP_BF3_MIN_TILES): a layer whose single time
+ * step has at least this many tiles of 128 rows x 64 units (default 256 = one per CU: B = 2048 at H = 512, two directions) runs one
+ * product per step with the GRU cell as its epilogue instead of chunked chain launches; 0 = never.
+ * Keys 4, 7-12 must not change between a forward call and its backward call, nor between sizing a workspace and using it. */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.
  * Unlike inet_side_join nothing is consumed: the issuing stream still joins the same work at its own next join (a

@@ -6,6 +6,7 @@
 #include "lstm.h"
 #include "chain.h"
 #include "gemm_bf3.h"
+#include "gru_step_bf3.h"
 
 namespace {
 
@@ -53,7 +54,7 @@ size_t bi_carve(int B, int T, int K, int H, int save, void* base, BiWs& w) {
     if (save) {
         w.dout_tm = cv.take<float>(TB * 2 * H);
         w.dx_tm = cv.take<float>(TB * K);
-        w.tmp3h = cv.take<float>(3 * H);
+        w.tmp3h = cv.take<float>(3 * H + 64);                   // + 64 partial sums of the scalar input's gradient (pw_beat_input_grad)
     } else {
         w.dout_tm = w.dx_tm = w.tmp3h = nullptr;
     }
@@ -277,7 +278,8 @@ int inet_bigru2_bwd(int B, int T, int K, int H, const float* x, const float* x_s
             INET_TRY(pw_zero(w.tmp3h, 3L * H, s));
             INET_TRY(pw_colsum(dgi, 6L * H, T * B, 3 * H, w.tmp3h, s));
             if (!dx_scalar) return -1;
-            INET_TRY(pw_beat_input_grad(w.tmp3h, P[dir].w_ih, 1, x_scalar, P[dir].dw_ih, dx_scalar, 3 * H, s));
+            INET_TRY(pw_beat_input_grad(w.tmp3h, P[dir].w_ih, 1, x_scalar, P[dir].dw_ih, dx_scalar, 3 * H, dgi, 6L * H, T * B,
+                                        w.tmp3h + 3 * H, s));
         }
     }
     if (x && dx) INET_TRY(pw_swap01(w.dx_tm, T, B, K, dx, s));
@@ -444,6 +446,7 @@ int inet_set_option(int key, int value) {
     if (key == 9) { if (value < 0 || value > 15) return -1; bf3_set_emit_mask(value); return 0; }
     if (key == 10) { if (value < 0 || value > 3) return -1; bf3_set_wgrad_mask(value); return 0; }
     if (key == 11) { chain2_set_bwd(value); return 0; }
+    if (key == 12) { gru_step_bf3_set_min_tiles(value); return 0; }
     return -1;
 }
 

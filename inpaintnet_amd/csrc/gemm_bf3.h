@@ -16,6 +16,11 @@ inline size_t bf3_bytes(long R, long K) { return 3 * bf3_piece_bytes(R, K); }
 int bf3_split(const float* X, long ld, int kmajor, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0,
               int kb0, hipStream_t s);
 
+// the k-contiguous form with a destination row-block stride: source row block rb -> row block rb0 + rb * rb_mul (interleaves the
+// gates of a GRU weight matrix: gru_step_bf3.hip)
+int bf3_split_strided(const float* X, long ld, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0, int rb_mul,
+                      hipStream_t s);
+
 struct Bf3Gemm {
     // C[M, N] (op)= epi(sum_k A(m, k) B(n, k) + bias):  A, B piece buffers (k blocks 0 .. K/32 of each row block)
     const unsigned char* A; long a_piece; int a_kb;

@@ -26,8 +26,16 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Edge cases (tests/test_gpu_kernels.py::test_gemm_bf3_edge_operands): denormals split like any other value (bf16 has f32's
+// exponent range); a finite |x| above the largest bf16 (3.3895e38) would ROUND to +-inf and leave inf - inf = NaN in the
+// residual where the f32-input kernels return a finite product, so there the first piece is truncated instead (still exact:
+// the residual just carries one more bit); +-inf and NaN stay non-finite in the first piece and poison the row / column of
+// the result, as they do -- as inf or NaN, by IEEE rules -- in the f32-input kernels: finite in, finite out; non-finite in,
+// non-finite out at the same positions.
 __device__ __forceinline__ void split3(float x, __bf16& a0, __bf16& a1, __bf16& a2) {
     a0 = (__bf16)x;                                  // round to nearest: |x - a0| <= 2^-9 |x|
+    if (__builtin_isinf((float)a0) && !__builtin_isinf(x))
+        a0 = (__bf16)__builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
     const float r1 = x - (float)a0;                  // exact
     a1 = (__bf16)r1;
     a2 = (__bf16)(r1 - (float)a1);                   // exact, and fits 8 bits
@@ -48,6 +56,7 @@ __device__ __forceinline__ void split8_store(const float* v, unsigned char* dst,
 struct SplitArgs {
     const float* X; long ld;
     unsigned char* P; long piece_bytes; int kb_total, rb0, kb0, R, K;
+    int rb_mul;                                      // source row block rb lands in row block rb0 + rb * rb_mul (rows form only)
 };
 
 // k-contiguous source: one thread = one lane of one fragment (32 contiguous bytes of a source row)
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256) void bf3_split_rows_kernel(SplitArgs a) {
     const long off = (rb * 16 + (lane & 15)) * a.ld + kb * 32 + (lane >> 4) * 8;
     const f32x4 v0 = ld4u(a.X + off), v1 = ld4u(a.X + off + 4);
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    split8_store(v, a.P + (((a.rb0 + rb) * a.kb_total + a.kb0 + kb) * 64 + lane) * 16, a.piece_bytes);
+    split8_store(v, a.P + (((a.rb0 + rb * a.rb_mul) * a.kb_total + a.kb0 + kb) * 64 + lane) * 16, a.piece_bytes);
 }
 
 // k-major source X[k * ld + r]: a workgroup transposes one k block (32 source rows) x 64 r through LDS
@@ -261,12 +270,20 @@ bool gemm_bf3_ok(int M, int N, int K) {
 int bf3_split(const float* X, long ld, int kmajor, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0,
               int kb0, hipStream_t s) {
     if (!X || !P || R <= 0 || K <= 0 || R % 16 || K % 32 || (kmajor && R % 64)) return -1;
-    SplitArgs a{X, ld, P, piece_bytes, kb_total, rb0, kb0, R, K};
+    SplitArgs a{X, ld, P, piece_bytes, kb_total, rb0, kb0, R, K, 1};
     char label[64];
     std::snprintf(label, sizeof label, "bf3_split %s R%d K%d", kmajor ? "cols" : "rows", R, K);
     ProfScope prof(PROF_HBM, 0.0, s, label, 10.0 * R * K);
     if (kmajor) hipLaunchKernelGGL(bf3_split_cols_kernel, dim3(K / 32, R / 64), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(bf3_split_rows_kernel, dim3((unsigned)(((long)R / 16 * (K / 32) * 64 + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int bf3_split_strided(const float* X, long ld, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0, int rb_mul,
+                      hipStream_t s) {
+    if (!X || !P || R <= 0 || K <= 0 || R % 16 || K % 32 || rb_mul < 1) return -1;
+    SplitArgs a{X, ld, P, piece_bytes, kb_total, rb0, 0, R, K, rb_mul};
+    hipLaunchKernelGGL(bf3_split_rows_kernel, dim3((unsigned)(((long)R / 16 * (K / 32) * 64 + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -1,0 +1,21 @@
+// GRU forward steps for large batches on the bf16 matrix cores (gru_step_bf3.hip): one launch per time step, gemm_bf3's main loop
+// with the GRU cell as its epilogue.  Descriptor = the chain kernels' (gru_chain.h GruChainFwdProb: `hx` is the two-slot ring of
+// three-piece states, chain_ring_floats(B, H) floats; W_hh is not read) plus the interleaved pieces of W_hh per direction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "gru_chain.h"
+
+struct GruStepsBf3 {
+    int H, B, T, nprob;
+    GruChainFwdProb p[2];
+    const unsigned char* Wp[2];          // gru_step_bf3_split_w() of W_hh: gru_step_bf3_w_bytes(H) bytes each
+};
+// shape rule: bf3 products on, H % 64 == 0, B % 128 == 0, one launch fills the chip (>= 256 tiles of 128 rows x 64 units;
+// INET_STEP_BF3_MIN_TILES overrides, 0 = never)
+bool gru_step_bf3_ok(int H, int B, int T, int nd);
+void gru_step_bf3_set_min_tiles(int n);                    // inet_set_option key 12 (0: never take this path)
+size_t gru_step_bf3_w_bytes(int H);
+int gru_step_bf3_split_w(int H, const float* W_hh, unsigned char* Wp, hipStream_t s);
+// all T steps (T launches on `s`); writes ChainEmit.rows if given (nothing else of the descriptor's `em`)
+int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s);

@@ -54,8 +54,10 @@ int pw_copy2d(float* dst, long ld_d, const float* src, long ld_s, const float* p
 int pw_dlogits_relayout(const float* dW, const float* Wt, int B, int T, int V, float* out, hipStream_t s);
 int pw_group_sum(const float* in, int groups, int G, long inner, float* out, hipStream_t s);
 int pw_axpb(const float* a, const float* x, long incx, const float* b, float* y, int n, hipStream_t s);
+// dw[i*incw] += b0 * sv[i] (sv = column sums of X [M, n]);  db0 += sum_{r,i} X[r][i] w[i*incw] in a FIXED order
+// (`partial`: 64 floats of scratch): deterministic from run to run
 int pw_beat_input_grad(const float* sv, const float* w, long incw, const float* b0, float* dw, float* db0, int n,
-                       hipStream_t s);
+                       const float* X, long ld, int M, float* partial, hipStream_t s);
 int pw_dropout_mask(float* out, long n, float p, uint64_t seed, uint64_t offset, hipStream_t s);
 int pw_scale(float* x, long n, float a, hipStream_t s);
 int pw_embedding_fwd(const float* table, const long long* idx, long rows, int E, float* out, const float* row_scale,

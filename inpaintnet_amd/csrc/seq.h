@@ -46,6 +46,9 @@ struct DirFwd {
     // `emitted` is set by gru_layer_fwd / gru_layer_bwd to what the kernels they launched wrote (bit 0: rows, bit 1: the transposed
     // pieces; 0: nothing) -- the caller splits the rest from the f32 arrays with bf3_split
     ChainEmit em; mutable int emitted;
+    // big batches (gru_step_bf3.h): scratch for the interleaved bf16 pieces of W_hh, gru_step_bf3_w_bytes(H) bytes; with it (and
+    // hpk) a layer whose single time step fills the chip runs one bf16-pipe product per step instead of chunked chain launches
+    unsigned char* wp3;
 };
 
 struct DirBwd {
@@ -143,6 +146,7 @@ struct BiGru2Ws {
     float *zeros, *x1raw, *x1m, *gi1, *h1, *sv[4];
     float *whhT[4], *dgi1, *dgh[4], *dhz, *dx1, *dgi0;
     float *wpk[4], *hpk[4], *wpkT[4], *dghpk[4];               // fragment-major twins (null unless pk_ok(H))
+    unsigned char* wp3[4];                                       // interleaved W_hh pieces for the big-batch step kernels (gru_step_bf3.h), or null
     unsigned* sync;                                            // chain-kernel counters: kSyncAreas areas (gru_chain.h)
     // piece buffers of the layer-1 input products (gemm_bf3.h; null unless the shapes tile): x1 [TB, 2H], W_ih of both
     // layer-1 directions stacked [6H, 2H]; backward: dgi1 [TB, 6H], the same weights k-major [2H, 6H]

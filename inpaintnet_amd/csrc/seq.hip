@@ -1,6 +1,7 @@
 #include <cstdlib>
 #include "seq.h"
 #include "gemm_bf3.h"
+#include "gru_step_bf3.h"
 
 // Rows per launch when a batch is too large for one resident chain launch: the largest of 1024 / 512 / 256 / 128 / 64 that
 // divides B and fits the chip (B itself when it fits; 0: no chain launch applies).
@@ -61,6 +62,7 @@ static int wgrad_at() {
 
 bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save) {
     if (!pk_ok(H) || B % 32) return false;
+    if (!gru_chain_ok(H, B, T, nd) && gru_step_bf3_ok(H, B, T, nd)) return false;   // (the step kernels write row pieces only)
     if (gru_chain_ok(H, B, T, nd)) return gru_chain_fwd_is_v2(H, B, T, nd, 0) && gru_chain2_emits(H, B, T, nd);
     const int CH = chain_chunk_rows(H, B, T, nd, save);
     return CH > 0 && CH < B && CH % 32 == 0 && gru_chain_fwd_is_v2(H, CH, T, nd, 0) && gru_chain2_emits(H, CH, T, nd);
@@ -113,6 +115,35 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
         }
         a.counters = d[0].sync; a.prezeroed = d[0].sync_prezeroed;
         return launch_gru_chain_fwd(a, s);
+    }
+    // One time step of the layer fills the chip by itself (LatentRNN's frozen encoder: 2048 measures; the reference's default
+    // MeasureVAE batch: 4096): a bf16-pipe product per step with the GRU cell as its epilogue (gru_step_bf3.hip) instead of
+    // chunked chain launches at 0.37 of that pipe.
+    bool stepbf3 = pk && nd <= 2 && gru_step_bf3_ok(H, B, T, nd);
+    for (int i = 0; i < nd; ++i) stepbf3 = stepbf3 && d[i].wp3;
+    if (stepbf3) {
+        GruStepsBf3 L{};
+        L.H = H; L.B = B; L.T = T; L.nprob = nd;
+        for (int i = 0; i < nd; ++i) {
+            const DirFwd& D = d[i];
+            GruChainFwdProb& P = L.p[i];
+            P.b_hh = D.b_hh;
+            P.h0 = D.h0; P.ld_h0 = D.h0_ld;
+            P.gi_dense = D.gi; P.ld_gi = D.gi_ld; P.ts_gi = D.gi_ts;
+            P.gi_table = D.table; P.ld_table = D.table_ld; P.idx = D.idx; P.idx_bs = D.idx_bs; P.idx_ts = D.idx_ts;
+            P.gi_vec = D.gvec;
+            P.out = D.out; P.ld_out = D.out_ld; P.ts_out = D.out_ts;
+            P.outm = D.outm; P.ld_outm = D.outm_ld; P.ts_outm = D.outm_ts;
+            P.mask = D.mask; P.ld_mask = D.mask_ld; P.ts_mask = D.mask_ts;
+            P.hlast = D.hlast; P.ld_hlast = D.hlast_ld;
+            P.sv = D.sv; P.sv_astride = D.sv_astride;
+            P.hx = D.hpk; P.reverse = D.reverse;
+            if (D.em.rows) { P.em.rows = D.em.rows; P.em.rows_piece = D.em.rows_piece; P.em.rows_kb = D.em.rows_kb; P.em.rows_kb0 = D.em.rows_kb0;
+                             P.em.B_full = B; P.em.r0 = 0; D.emitted = 1; }
+            INET_TRY(gru_step_bf3_split_w(H, D.W_hh, D.wp3, s));
+            L.Wp[i] = D.wp3;
+        }
+        return launch_gru_steps_bf3(L, s);
     }
     // More rows than one resident launch can take (the frozen encoder of LatentRNN runs 2048 measures at once, the
     // reference's default VAE batch is 4096 measures): the rows are independent, so the chain kernel runs over chunks of
@@ -344,6 +375,7 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
         w.hpk[i] = pk ? c.take<float>(chain_ring_floats(B, H)) : nullptr;
         w.wpkT[i] = pk && save ? c.take<float>((size_t)3 * H * H) : nullptr;
         w.dghpk[i] = pk && save ? c.take<float>(chain_ring_floats(B, 3 * H)) : nullptr;
+        w.wp3[i] = pk && !gru_chain_ok(H, B, T, 2) && gru_step_bf3_ok(H, B, T, 2) ? c.take<unsigned char>(gru_step_bf3_w_bytes(H)) : nullptr;
     }
     w.sync = c.take<unsigned>(kSyncAreas * kChainSyncWords);
     // The bf16-pipe products (gemm_bf3.hip) tile 192 rows x 192 / 128 columns: below ~3072 rows (T*B) a launch leaves most CUs idle
@@ -368,7 +400,9 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
                     float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s, int sync_prezeroed) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     // fragment-major W_hh twins: only the per-step kernels read them (the chain kernels take W_hh as stored)
-    const bool chained = w.wpk[0] && w.hpk[0] && w.sync && pk_ok(H) && chain_chunk_rows(H, B, T, 2, save) > 0;   // (one launch or row chunks)
+    // (one launch, row chunks, or -- big batches -- the bf16-pipe step kernels, which take the same null h0)
+    const bool stepf = w.wp3[0] && w.hpk[0] && pk_ok(H) && !gru_chain_ok(H, B, T, 2) && gru_step_bf3_ok(H, B, T, 2);
+    const bool chained = stepf || (w.wpk[0] && w.hpk[0] && w.sync && pk_ok(H) && chain_chunk_rows(H, B, T, 2, save) > 0);
     // zero initial state: the chain kernels take a null pointer (and skip step 0's contraction), the per-step kernels a buffer
     const float* const hzero = chained ? nullptr : w.zeros;
     if (!h0 && !chained && pw_zero(w.zeros, BH, s) != 0) return -2;
@@ -416,7 +450,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (hn && hn[dir]) { D.hlast = hn[dir]; D.hlast_ld = hn_ld; }
         if (save) { D.sv = w.sv[dir]; D.sv_astride = TBH; }
         D.reverse = dir;
-        D.Wpk_hh = w.wpk[dir]; D.hpk = w.hpk[dir];
+        D.Wpk_hh = w.wpk[dir]; D.hpk = w.hpk[dir]; D.wp3 = w.wp3[dir];
         D.sync = w.sync; D.sync_prezeroed = one_launch;
         if (bf3f && (emit_mask() & 1)) {                       // the layer-1 input products' A operand, written by the chain
             D.em.rows = w.x1pk; D.em.rows_piece = (long)bf3_piece_bytes(TBl, 2 * H); D.em.rows_kb = 2 * H / 32; D.em.rows_kb0 = dir * H / 32;
@@ -427,8 +461,9 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         }
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
-    const bool x1_emitted = bf3f && d[0].emitted && d[1].emitted && (emit_mask() & 1);
-    if (bf3f && (emit_mask() & 1) && x1_emitted != gru_layer_fwd_emits(H, B, T, 2, save != 0)) return -3;   // (the backward call relies on the predicate)
+    const bool x1_emitted = bf3f && (d[0].emitted & 1) && (d[1].emitted & 1) && (emit_mask() & 1);
+    // (the backward call relies on the predicate for the TRANSPOSED pieces the forward chains wrote)
+    if (bf3f && (emit_mask() & 1) && ((d[0].emitted & 2) && (d[1].emitted & 2)) != gru_layer_fwd_emits(H, B, T, 2, save != 0)) return -3;
     const float* x1 = mask ? w.x1m : w.x1raw;
     if (bf3f) {
         // both directions' input products as ONE product on the bf16 matrix cores (gemm_bf3.hip): gi1 [TB, 6H] =
@@ -457,7 +492,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         if (hn && hn[2 + dir]) { D.hlast = hn[2 + dir]; D.hlast_ld = hn_ld; }
         if (save) { D.sv = w.sv[2 + dir]; D.sv_astride = TBH; }
         D.reverse = dir;
-        D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir];
+        D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir]; D.wp3 = w.wp3[2 + dir];
         D.sync = one_launch ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = one_launch;
         if (bf3f && save && w.hpT[2 + dir] && (emit_mask() & 2) && (wgrad_mask() & 1)) {
             D.em.colsB = w.hpT[2 + dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0;

@@ -176,7 +176,7 @@ struct DecWs {
     long long* tokin;                                // teacher-forced input tokens [B,T] (start symbol, then target shifted)
     // backward
     float *whhT[4], *dlg, *dh1top, *dgi1t, *dgh1t, *dhz, *dht0, *dx1t, *dgi0t, *dgh0t, *dcgi, *dc_all, *onehot, *dtable;
-    float *dbeat_out, *dgi1b, *dgh1b, *dxb, *dgi0b, *dgh0b, *dhb0, *tmp3h;
+    float *dbeat_out, *dgi1b, *dgh1b, *dxb, *dgi0b, *dgh0b, *dhb0, *tmp3h, *b0part;
     // fragment-major twins (ksplit.h), null unless pk_ok(H): packed recurrent / layer-1 input weights, packed initial
     // tick hiddens [layer][beat], ping-pong packed hiddens [beat][2], packed masked layer-0 output [beat]
     float *wpk_b[2], *wpk_t0, *wpk_t1hh, *wpk_t1ih, *wpk_out, *hpk_b, *ht0pk, *hpk_t0, *hpk_t1, *hm0pk;
@@ -252,6 +252,7 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     static_assert(kDecodeSyncWords <= kChainSyncWords, "one sync area serves either kind of chain launch");
     w.sync = cv.take<unsigned>(kSyncAreas * kChainSyncWords);
     w.tmp3h = save ? cv.take<float>(3 * H) : nullptr;          // right behind the sync areas: one memset zeroes both
+    w.b0part = save ? cv.take<float>(64) : nullptr;            // fixed-order partial sums of the b_0 gradient (pw_beat_input_grad)
     return cv.bytes();
 }
 
@@ -720,7 +721,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
         const PwColsumJob cs[4] = {{w.dht0, 2L * H, nb * B, 2 * H, g + L.bh_b}, {w.dc_all, H, nb * B, H, g + L.bi_b},
                                    {w.dhb0, 2L * H, B, 2 * H, g + L.zb_b}, {w.dgi0b, 3L * H, nb * B, 3 * H, w.tmp3h}};
         INET_TRY(pw_colsum_multi(cs, 4, ss));
-        INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H, ss));
+        INET_TRY(pw_beat_input_grad(w.tmp3h, p + L.beat[0].w_ih, 1, p + L.b_0, g + L.beat[0].w_ih, g + L.b_0, 3 * H,
+                                    w.dgi0b, 3L * H, nb * B, w.b0part, ss));
     }
     return side_join(s);
 }

@@ -81,12 +81,26 @@ def reset_buckets(grad=None):
     """Forget started buckets (Trainer.zero_grad calls this: a step that died between backward and step() must not
     leave handles behind).  Outstanding work is waited for first so that no all-reduce is left writing the arena."""
     keys = list(_pending) if grad is None else [grad.data_ptr()]
+    del last_ranges[:]
     for k in keys:
         for _, _, work in _pending.pop(k, []):
             work.wait()
 
 
 _prep_streams = {}   # device index -> the stream the bucket all-reduces are issued from
+
+# Measurement aids (bench.py --gpus N): the ranges of the last step's exchange, in floats of the allocation that was reduced
+# ("bucket": started under the backward pass; "final": issued by allreduce_grads, what a step can expose), and a switch that
+# turns every gradient collective into a no-op so that the same step can be timed without its exchange.
+last_ranges = []
+_exchange = True
+
+
+def set_exchange(on):
+    """False: start_bucket / allreduce_grads skip their collectives (timing aid; the gradients stay rank-local)."""
+    global _exchange
+    _exchange = bool(on)
+
 
 
 def _prep_stream(device):
@@ -104,6 +118,9 @@ def start_bucket(grad, start, stop, join_side=False):
     GEMMs that fill the bucket): the backward pass itself is not held up.  No-op for a single process.  A range may be
     started only once per step (a second backward() before step() would otherwise be summed twice)."""
     if world_size() > 1 and stop > start:
+        last_ranges.append(("bucket", int(start), int(stop)))
+        if not _exchange:
+            return
         mine = _pending.setdefault(grad.data_ptr(), [])
         for a, b, _ in mine:
             if start < b and a < stop:
@@ -137,9 +154,13 @@ def allreduce_grads(grad, store=None, head=0):
             assert store.data_ptr() + 4 * head == grad.data_ptr(), "dp.allreduce_grads: grad is not store[head:]"
         pos = 0                                       # positions in `store`; buckets are in arena coordinates
         end = head + grad.numel()
-        for a, b in sorted((a + head, b + head) for a, b, _ in mine) + [(end, end)]:
+        started = sorted((a + head, b + head) for kind, a, b in last_ranges if kind == "bucket") if not _exchange else \
+            sorted((a + head, b + head) for a, b, _ in mine)
+        for a, b in started + [(end, end)]:
             if a > pos:
-                torch.distributed.all_reduce(store[pos:a], op=torch.distributed.ReduceOp.SUM)
+                last_ranges.append(("final", int(pos), int(a)))
+                if _exchange:
+                    torch.distributed.all_reduce(store[pos:a], op=torch.distributed.ReduceOp.SUM)
             pos = max(pos, b)
         for _, _, work in mine:
             work.wait()

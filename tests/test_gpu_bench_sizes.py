@@ -43,6 +43,18 @@ def _margin(w):
     return (top2[..., 0] - top2[..., 1]).numpy()
 
 
+def _comparable_rows(w, what):
+    """Rows whose sampled token must agree bit for bit: top-2 margin above 1e-4 OF THE ROW'S OWN MAXIMUM (the logits agree
+    within 2e-5 of the tensor's maximum, so a row is only excluded when its two best logits are closer than the arithmetic can
+    tell apart -- in particular the rows whose two best post-ReLU logits are both exactly 0).  Prints the fraction compared
+    (it lands in the committed GPU test log) and asserts it is most of the tensor."""
+    top2 = torch.topk(w, 2, dim=-1).values
+    ok = ((top2[..., 0] - top2[..., 1]) > 1e-4 * top2[..., 0].clamp_min(1e-30)).numpy()
+    print(f"token rows compared ({what}): {int(ok.sum())} of {ok.size} = {ok.mean():.4f}; "
+          f"excluded with a zero row maximum: {int((top2[..., 0] <= 0).sum())}")
+    return ok
+
+
 def _labels(path):
     with open(path) as f:
         return [row["label"] for row in csv.DictReader(f)]
@@ -77,6 +89,8 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     ops.prof_dump(tmp_path / "launches.csv")
     ops.prof_enable(False)
     labels = _labels(tmp_path / "launches.csv")
+    if B == 2048:                     # the encoder's forward layers: bf16-pipe step kernels with backward saves
+        assert sum(l == "gru_step_bf3 p9 np2 B2048 H512 sv" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
     if B == 512:
         gl = sorted(set(l for l in labels if l.startswith("gru") or l.startswith("dec")))
         assert not any(l.startswith("gru_fwd") or l.startswith("gru_bwd") for l in labels), gl      # no per-step launches
@@ -133,8 +147,8 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     loss.backward()
     assert relmax(hz, z) < 2e-5
     assert relmax(hw, w) < 2e-5
-    ok = _margin(w.detach()) > 1e-4
-    assert ok.mean() > 0.4                      # (post-ReLU logits: rows whose top-2 are both 0 have margin 0)
+    ok = _comparable_rows(w.detach(), f"vae B={B} tf={tf}")
+    assert ok.mean() > 0.99                     # (measured 0.9990-0.9998: near-ties only; no row of trained logits is all zeros)
     assert np.array_equal(hs.cpu().numpy()[:, 0][ok], s.numpy()[:, 0][ok])
     assert abs(hl - loss.item()) <= 1e-4 * abs(loss.item()), (hl, loss.item())
     assert abs(hce - ce.item()) <= 1e-4 * abs(ce.item())
@@ -151,8 +165,9 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     # themselves atomically accumulated column sums -- its "max" is the cancelled result, so run-to-run summation order
     # alone moves it by up to 2e-4 of itself; it keeps the north_star's 5e-4 bound, every tensor
     # with more than one element is held to 1e-4
+    # (round 4: that scalar is now a fixed-order two-stage sum, rowdot_partials_kernel -> beat_input_grad_kernel; it is held to
+    # the same bound as everything else)
     bound = {k: 1e-4 for k in errs}
-    bound["decoder.b_0"] = 5e-4
     bad = {k: v for k, v in errs.items() if v >= bound[k]}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
 
@@ -234,8 +249,9 @@ def test_latent_step_at_bench_batch_vs_oracle(variant, tmp_path, monkeypatch):
     ops.prof_enable(False)
     assert ops.chain_status() == 0
     labels = _labels(tmp_path / "launches.csv")
-    # frozen encoder over all 128 x 16 measures at once: the chain kernel over eight 256-row chunks per layer
-    assert sum(G.is_chain(l, "fwd", 2, 24, 256) for l in labels) == 16, sorted(set(l for l in labels if l.startswith("gru")))
+    # frozen encoder over all 128 x 16 measures at once: one time step of 2048 rows fills the chip, so each layer runs 24 bf16-pipe
+    # products with the GRU cell as their epilogue (csrc/gru_step_bf3.hip; round 3: the chain kernel over eight 256-row chunks)
+    assert sum(l == "gru_step_bf3 p9 np2 B2048 H512" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
     assert any(G.is_chain(l, "fwd", 2, 6, 128) for l in labels) and any(G.is_chain(l, "bwd", 2, 6, 128) for l in labels)   # contexts: 8 groups of 32 rows
     if variant == "nar":
         assert any(l.startswith("gru_fwd x0") and l.endswith("B128 H1024") for l in labels)      # generator
@@ -289,8 +305,8 @@ def test_latent_step_at_bench_batch_vs_oracle(variant, tmp_path, monkeypatch):
     lo.backward()
     assert G.rel_err(gz.detach().cpu(), gzo.detach()) < 5e-5
     assert G.rel_err(w.detach().cpu(), wo.detach()) < 5e-5
-    ok = _margin(wo.detach()).reshape(B, -1) > 1e-4
-    assert ok.mean() > 0.4
+    ok = _comparable_rows(wo.detach(), f"latent {variant}").reshape(B, -1)
+    assert ok.mean() > 0.99
     assert np.array_equal(s.cpu().numpy()[:, 0][ok], so.numpy()[:, 0][ok])
     assert abs(float(loss.detach()) - lo.item()) <= 1e-4 * abs(lo.item())
     assert abs(float(acc) - ao.item()) <= 2.0 / (B * n_target * 24)

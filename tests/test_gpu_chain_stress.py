@@ -72,8 +72,10 @@ def test_encoder_and_decoder_backward_chains_repeatedly():
 
 
 def test_chunked_chain_forward_for_large_batches():
-    """More rows than one resident chain launch takes (the frozen encoder of LatentRNN: 2048 measures): the forward runs
-    the chain kernel over 256-row chunks; compared with the per-step launches."""
+    """More rows than one resident chain launch takes (the frozen encoder of LatentRNN: 2048 measures).  Three forms of the
+    forward pass must agree: the default (B = 2048: one bf16-pipe product per time step with the GRU cell as its epilogue,
+    csrc/gru_step_bf3.hip; smaller batches: the chain kernel over 256-row chunks), the chunked chain launches everywhere
+    (inet_set_option key 12 = 0), and the f32-input per-step launches (key 4 = 0 as well)."""
     c = G.CFGS["full"]
     cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
     table, total = ops.vae_param_table(cfg)
@@ -83,20 +85,25 @@ def test_chunked_chain_forward_for_large_batches():
         for B in (2048, 512, 768):
             tok = torch.randint(0, c["V"], (B, 24), generator=g).cuda()
             res = []
-            for chain in (1, 0):
+            for chain, step_tiles in ((1, 256), (1, 0), (0, 0)):
                 ops.set_option(4, chain)
+                ops.set_option(12, step_tiles)
                 ops.prof_enable(True)
                 mu, ls, _ = ops.encoder_fwd(cfg, tok, params, mask=None, save=False)
                 torch.cuda.synchronize()
                 ops.prof_dump("/tmp/_inet_chunk.csv")
                 ops.prof_enable(False)
                 labels = [l.split(",")[1] for l in open("/tmp/_inet_chunk.csv").read().strip().splitlines()[1:]]
-                if chain:
-                    assert sum(G.is_chain(l, "fwd", 2, 24, 256) for l in labels) == 2 * (B // 256), labels[:6]   # x2: two chunks share the chip
+                nstep = sum(l.startswith("gru_step_bf3") for l in labels)
+                assert nstep == (48 if (B == 2048 and step_tiles) else 0), (B, chain, step_tiles, labels[:6])
+                if chain and not nstep:
+                    assert sum(G.is_chain(l, "fwd", 2, 24, 256) for l in labels) == 2 * (B // 256), labels[:6]   # x2: two layers
                 res.append((mu, ls))
-            assert _rel(res[0][0], res[1][0]) < 2e-5 and _rel(res[0][1], res[1][1]) < 2e-5, B
+            for k in (0, 1):
+                assert _rel(res[k][0], res[2][0]) < 2e-5 and _rel(res[k][1], res[2][1]) < 2e-5, (B, k)
     finally:
         ops.set_option(4, 1)
+        ops.set_option(12, 256)
         ops.prof_enable(False)
     assert ops.chain_status() == 0
 

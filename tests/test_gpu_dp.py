@@ -247,3 +247,34 @@ def test_chain_timeout_on_one_rank_is_handled_by_all_ranks_together(tmp_path):
     assert int(r0["lost"]) == int(r1["lost"]) == 3                            # report_lag + 1 steps were skipped and repeated
     assert int(r0["seen"]) == int(r1["seen"]) == NB
     assert float(r0["loss"]) == float(r1["loss"]) and np.isfinite(float(r0["loss"]))   # summed over ranks: identical means
+
+
+def test_bench_two_ranks_functional(tmp_path):
+    """`bench.py --gpus 2` end to end on ONE GPU (INET_BENCH_SHARE_GPU=1: both ranks on cuda:0, gloo carries the exchange): the
+    N > 1 code path the driver's scaling run takes -- rank spawn, world check, seeded shared draws, bucketed exchange with the
+    step flag, collective health verdict, exchange report, the LatentRNN step under the same exchange (BASELINE.json
+    configs[3]) -- prints one JSON line with the data-parallel fields.  A functional check, not a scaling number."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, INET_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3",
+                        "--no-cpu-baseline", "--no-roofline", "--no-parity"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 512
+    assert d["chain_timeouts"] == 0 and d["dp"]["chain_timeouts_per_rank"] == [0, 0] and d["dp"]["skipped_steps_per_rank"] == [0, 0]
+    kinds = [x["kind"] for x in d["dp"]["ranges"]]
+    assert "bucket" in kinds and kinds.count("final") >= 1
+    # the whole arena (+ the 4-float head that carries the step flag) is exchanged exactly once per step
+    assert abs(sum(x["mbytes"] for x in d["dp"]["ranges"]) - (d["allreduce_mbytes"] + 16e-6)) < 0.05
+    assert d["dp"]["ms_per_step_without_exchange"] > 0 and len(d["per_rank_units_per_s"]) == 2
+    lat = d["extras"]["latent_rnn_train_dp"]
+    assert lat["global_batch"] == 256 and lat["sequences_per_s"] > 0
+    assert "FUNCTIONAL CHECK ONLY" in d["data"]

@@ -132,6 +132,73 @@ def test_gemm_bf3_layouts(akm, bkm, M, N, K, ksplit):
     assert relmax(Cf, ref) < 2e-5
 
 
+def test_gemm_bf3_edge_operands():
+    """Operands at the edges of f32 through the three-piece split (csrc/gemm_bf3.hip split3): denormals, values above the
+    largest bf16 (which must not round to inf), and non-finite values.  Finite in -> finite out, equal to float64 within the
+    f32-input kernel's bound; inf / NaN in -> non-finite out at exactly the positions the f32-input kernel (inet_gemm) makes
+    non-finite."""
+    M, N, K = 192, 128, 64
+    g = torch.Generator().manual_seed(99)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    A[0, :] = 1e-40                                           # a denormal row
+    A[1, 3] = 3.4e38                                          # > bf16 max (3.3895e38), < FLT_MAX
+    A[2, 5] = -3.4028234e38                                   # -FLT_MAX
+    B[:, 3] *= 1e-3                                           # keep those products inside f32
+    B[:, 5] *= 1e-3
+    B[7, :] = 1e-41
+    ref = A.double() @ B.double().t()
+    C = ops.gemm_bf3(A.to(DEV), B.to(DEV), M, N, K)
+    Cf = ops.gemm(A.to(DEV), B.to(DEV), M, N, K)
+    assert bool(torch.isfinite(C).all()) and bool(torch.isfinite(Cf).all())
+    for r in range(M):                                        # row-wise: rows 1, 2 are ~1e35, the others O(10)
+        scale = float(ref[r].abs().max())
+        assert float((C[r].cpu().double() - ref[r]).abs().max()) <= 4e-6 * scale + 1e-37, r
+    # non-finite operands: the same positions go non-finite as in the f32-input kernel
+    A2, B2 = A.clone(), B.clone()
+    A2[10, 1] = float("inf")
+    A2[20, 2] = float("nan")
+    B2[30, 4] = float("-inf")
+    C2 = ops.gemm_bf3(A2.to(DEV), B2.to(DEV), M, N, K)
+    Cf2 = ops.gemm(A2.to(DEV), B2.to(DEV), M, N, K)
+    assert torch.equal(torch.isfinite(C2), torch.isfinite(Cf2))
+    fin = torch.isfinite(Cf2).cpu()[3:]                       # (rows 0..2 hold the huge / denormal values: checked above)
+    assert float(((C2.cpu().double() - ref)[3:][fin]).abs().max()) < 4e-6 * float(ref[3:].abs().max())
+
+
+@pytest.mark.parametrize("save", [False, True])
+def test_gru_step_bf3_matches_chain_path(save):
+    """Big batches: a 2-layer bi-GRU whose single time step fills the chip (B = 2048, H = 512) runs one bf16-pipe product per
+    step with the GRU cell as its epilogue (csrc/gru_step_bf3.hip; inet_set_option key 12) instead of chunked chain launches.
+    Same arithmetic (nine exact piece products, f32 accumulation), different summation order: outputs and final states agree
+    to fp32 rounding; the inter-layer dropout mask and (save) the layer-1 row pieces written by the step kernels are exercised."""
+    B, T, K, H = 2048, 5, 32, 512
+    g = torch.Generator().manual_seed(5 + save)
+    x = torch.randn(B, T, K, generator=g).to(DEV)
+    n_gru = 2 * (3 * H * K + 3 * H * H + 6 * H) + 2 * (3 * H * 2 * H + 3 * H * H + 6 * H)
+    weights = (torch.randn(n_gru + 64, generator=g) * 0.04).to(DEV)
+    mask = ops.dropout_mask((T, B, 2 * H), 0.5, 77, 0, DEV)
+    outs = {}
+    for key12 in (256, 0):
+        ops.set_option(12, key12)
+        try:
+            ops.prof_enable(True)
+            out, hn, ws = ops.bigru2_fwd(x, None, weights, H, B, T, K, mask=mask, save=save)
+            torch.cuda.synchronize()
+            ops.prof_dump("/tmp/_inet_stepbf3.csv")
+            ops.prof_enable(False)
+            labels = open("/tmp/_inet_stepbf3.csv").read()
+            assert ("gru_step_bf3" in labels) == (key12 == 256), labels[-600:]
+            assert ops.chain_status() <= 0
+            outs[key12] = (out.clone(), hn.clone())
+        finally:
+            ops.set_option(12, 256)
+            ops.prof_enable(False)
+    for a, b in zip(outs[256], outs[0]):
+        assert bool(torch.isfinite(a).all())
+        assert float((a - b).abs().max()) < 5e-6 * float(b.abs().max()), float((a - b).abs().max())
+
+
 def test_gemm_bf3_rejects_shapes_it_does_not_tile():
     A = torch.randn(100, 64, device=DEV)
     B = torch.randn(128, 64, device=DEV)
