@@ -429,8 +429,46 @@ def dump_kernel_sequences(step, path, nsteps=6):
     for key in seqs[0]:
         if all(s_.get(key) == seqs[0][key] for s_ in seqs) and len(set(seqs[0][key])) > 1:
             out[key] = seqs[0][key]
+    # every label of the profiled steps that maps to a PMC key: tools/pmc_summary.py copies the list (and its hash) into the
+    # traffic file, and roofline() refuses the file's figures when the library launches a label the file has never seen
+    out["__labels__"] = sorted({l for s_ in seqs for ls in s_.values() for l in ls})
     json.dump(out, open(path, "w"), indent=1)
     return out
+
+
+def label_hash(labels):
+    import hashlib
+    return hashlib.sha1("\n".join(sorted(set(labels))).encode()).hexdigest()[:16]
+
+
+def attach_traffic(table, pmc):
+    """Per-launch memory-side traffic (committed rocprofv3 PMC summary) for the rows of a kernel table.  Freshness: the file
+    lists the labels its passes saw (`labels`, hashed in `label_hash`); if the library now launches a label with a PMC key
+    that the file does not list -- a kernel was renamed, re-tiled or replaced since the passes -- NO figure is attached and the
+    missing labels are returned: a stale file is refused, not quoted.  Files without the list (rounds 2-3) are used as before."""
+    kern = pmc.get("kernels", {})
+    listed = set(pmc.get("labels", []))
+    current = {row["kernel"] for row in table if pmc_key(row["kernel"])}
+    missing = sorted(current - listed) if listed else []
+    if missing:
+        return missing
+    shared = collections.Counter(pmc_key(row["kernel"]) for row in table)
+    for row in table:
+        key = pmc_key(row["kernel"])
+        hit = None
+        if key:
+            hit = kern.get(key + "#" + row["kernel"])
+            # a kernel|grid key behind several shapes whose launch order differs between steps (teacher-forced steps add
+            # T = 6 launches of the forward chain kernel) has no per-shape PMC figure: null rather than the mixture
+            if hit is None and shared[key] == 1:
+                hit = kern.get(key) or next((v for k, v in kern.items() if k.startswith(key)), None)
+        if hit:
+            row["traffic_mbytes_per_launch"] = hit.get("hbm_mbytes_per_launch")
+            row["pmc_key"] = key
+            for extra in ("mfma_busy_frac", "gpu_busy_frac"):          # MFMA-busy counter pass (tools/profile_r04.sh), when merged in
+                if extra in hit:
+                    row[extra] = hit[extra]
+    return []
 
 
 def pmc_key(label):
@@ -498,20 +536,7 @@ def roofline(step):
             pmc = json.load(open(PMC_FILE))
         except Exception:
             pmc = {}
-    kern = pmc.get("kernels", {})
-    shared = collections.Counter(pmc_key(row["kernel"]) for row in table)
-    for row in table:
-        key = pmc_key(row["kernel"])
-        hit = None
-        if key:
-            hit = kern.get(key + "#" + row["kernel"])
-            # a kernel|grid key behind several shapes whose launch order differs between steps (teacher-forced steps add
-            # T = 6 launches of the forward chain kernel) has no per-shape PMC figure: null rather than the mixture
-            if hit is None and shared[key] == 1:
-                hit = kern.get(key) or next((v for k, v in kern.items() if k.startswith(key)), None)
-        if hit:
-            row["traffic_mbytes_per_launch"] = hit.get("hbm_mbytes_per_launch")
-            row["pmc_key"] = key
+    stale = attach_traffic(table, pmc)
     mfma_bound = top["frac_mfma"] >= top["frac_hbm"]
     out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": top["kernel"],
            "achieved": top["tflops"] if mfma_bound else top["gbps"],
@@ -530,6 +555,10 @@ def roofline(step):
            "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
            "step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
            "kernels": table[:int(os.environ.get("INET_BENCH_TOPK", "8"))]}
+    out["traffic_label_hash"] = pmc.get("label_hash")
+    if stale:
+        out["traffic_stale"] = {"reason": "the library launches labels the committed PMC file has never seen: its figures are "
+                                          "not quoted (regenerate with tools/profile_r04.sh)", "missing_labels": stale[:8]}
     return out
 
 

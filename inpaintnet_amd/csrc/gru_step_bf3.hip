@@ -208,17 +208,22 @@ __global__ __launch_bounds__(64 * NW) void gru_step_bf3_kernel(StepArgs a) {
     }
 
     // ---- GRU cell: lane (c, q) holds rows 4q + r, unit c of every 16 x 16 tile; tiles g = 0, 1, 2 are the gates r, z, n ----
-    float* const xt = reinterpret_cast<float*>(smem) + w * 512;       // two 16 x 16 transpose tiles per wave (the stages are free)
+    // Every result leaves through wave-private 16 x 16 transpose tiles in LDS (the stages are free now): the f32 arrays as ONE
+    // 16-byte store per lane and tile (lane = row L / 4, units 4 (L % 4) ..: a whole 1 KB tile per instruction -- scalar stores of
+    // the accumulator layout were store-issue-bound: 16 per lane and array), the pieces as 8 consecutive units per lane.
+    constexpr int NT = SAVE ? 7 : 2;                                   // tiles per wave: h, h * mask [, r, z, n, ghn, hprev]
+    float* const xt = reinterpret_cast<float*>(smem) + w * (NT * 256);
     const int kbj = tn * 2 + (wn >> 1);                               // k block of the piece layouts this wave's 16 units fall into
     const int prow = lane & 15, pgrp = (lane >> 4) & 1;
     const int plane = ((2 * (wn & 1) + pgrp) * 16 + prow) * 16;       // byte offset of (row, 8-unit group) inside the fragment
+    const int vrow = lane >> 2, vcol = (lane & 3) * 4;                // the lane's 4 consecutive units of one row (vector stores)
+    const int j0 = tn * 64 + wn * 16;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
         const int rb = tm * TMB + wm * RM + i;
-        float hv[4], hm[4];
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long row = (long)rb * 16 + 4 * q + r;
             const float ghn = acc[i][2][r] + bh[2];
             float xr = gr[i][r], xz = gz[i][r], xn = gn[i][r];
             if (TAB) { xr += tg[i][r][0]; xz += tg[i][r][1]; xn += tg[i][r][2]; }
@@ -227,20 +232,22 @@ __global__ __launch_bounds__(64 * NW) void gru_step_bf3_kernel(StepArgs a) {
             const float ng = tanh_f(xn + bv[2] + rg * ghn);
             const float hprev = hp[i][r];
             const float hn = (1.f - zg) * ng + zg * hprev;
-            hv[r] = hn; hm[r] = hn * mk[i][r];
-            P.out[row * P.out_ld + j] = hn;
-            if (P.outm) P.outm[row * P.outm_ld + j] = hm[r];
-            if (P.hlast) P.hlast[row * P.hlast_ld + j] = hn;
-            if (SAVE) {
-                float* sp = P.sv + row * H + j;
-                sp[0] = rg; sp[P.sv_astride] = zg; sp[2 * P.sv_astride] = ng; sp[3 * P.sv_astride] = ghn; sp[4 * P.sv_astride] = hprev;
-            }
+            const int o = (4 * q + r) * 16 + c;
+            xt[o] = hn; xt[256 + o] = hn * mk[i][r];
+            if (SAVE) { xt[512 + o] = rg; xt[768 + o] = zg; xt[1024 + o] = ng; xt[1280 + o] = ghn; xt[1536 + o] = hprev; }
         }
-        // pieces: through a wave-private transpose tile (row-major 16 x 16), 32 lanes x 8 consecutive units each
         __builtin_amdgcn_wave_barrier();
+        const long vr = (long)rb * 16 + vrow;
+        const f32x4 hv4 = *reinterpret_cast<const f32x4*>(xt + vrow * 16 + vcol);
+        *reinterpret_cast<f32x4*>(P.out + vr * P.out_ld + j0 + vcol) = hv4;
+        if (P.outm) *reinterpret_cast<f32x4*>(P.outm + vr * P.outm_ld + j0 + vcol) = *reinterpret_cast<const f32x4*>(xt + 256 + vrow * 16 + vcol);
+        if (P.hlast) *reinterpret_cast<f32x4*>(P.hlast + vr * P.hlast_ld + j0 + vcol) = hv4;
+        if (SAVE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { xt[(4 * q + r) * 16 + c] = hv[r]; xt[256 + (4 * q + r) * 16 + c] = hm[r]; }
-        __builtin_amdgcn_wave_barrier();
+            for (int a5 = 0; a5 < 5; ++a5)
+                *reinterpret_cast<f32x4*>(P.sv + a5 * P.sv_astride + vr * H + j0 + vcol) =
+                    *reinterpret_cast<const f32x4*>(xt + (2 + a5) * 256 + vrow * 16 + vcol);
+        }
         if (lane < 32) {
             if (P.An) pieces8_store(xt + prow * 16 + 8 * pgrp, P.An + ((long)rb * KB + kbj) * 1024 + plane, P.a_piece);
             if (P.em) pieces8_store(xt + 256 + prow * 16 + 8 * pgrp,

@@ -64,3 +64,22 @@ def test_piece_products_of_labels(bench):
     assert bench.piece_products("gru_chain_bwd v2w4e p9 np2 T24 B256 H512") == 9
     assert bench.piece_products("gru_chain_fwd ms4 np2 T24 B256 H512") == 0
     assert bench.piece_products("M1536 N512 K6144 TN d192x128 s4 e0 x2") == 0
+
+
+def test_stale_traffic_file_is_refused(bench):
+    """roofline.traffic comes from a committed PMC summary: when the library launches a label (with a PMC key) that the file's
+    passes never saw, no figure of the file is attached and the missing labels are reported; with every label listed the
+    per-shape figure is attached; files without a label list (rounds 2-3) keep working."""
+    lab_a, lab_b = "M6144 N3072 K1024 bf3p9 t192x192 s1 e0", "gru_chain_bwd ms4 np2 T24 B256 H512"
+    doc = {"labels": [lab_a], "label_hash": bench.label_hash([lab_a]),
+           "kernels": {bench.pmc_key(lab_a): {"hbm_mbytes_per_launch": 325.6}, bench.pmc_key(lab_b): {"hbm_mbytes_per_launch": 474.0}}}
+    table = [{"kernel": lab_a}, {"kernel": lab_b}, {"kernel": "dropout mask"}]
+    assert bench.attach_traffic(table, doc) == [lab_b]
+    assert all("traffic_mbytes_per_launch" not in r for r in table)
+    doc["labels"].append(lab_b)
+    assert bench.attach_traffic(table, doc) == []
+    assert table[0]["traffic_mbytes_per_launch"] == 325.6 and table[1]["traffic_mbytes_per_launch"] == 474.0
+    table2 = [{"kernel": lab_b}]
+    assert bench.attach_traffic(table2, {"kernels": doc["kernels"]}) == [] and table2[0]["traffic_mbytes_per_launch"] == 474.0
+    assert bench.pmc_key("gru_step_bf3 p9 np2 B2048 H512") == "gru_step_bf3_kernel<true, false, false>|g131072" or \
+        bench.pmc_key("gru_step_bf3 p9 np2 B2048 H512") is None
