@@ -260,7 +260,7 @@ class LatentWorkload:
     units_per_step = 16 * LATENT_SEQ_PER_GPU
     unit = "measures/s"
 
-    def __init__(self, dev, rank, vae=None, ds=None):
+    def __init__(self, dev, rank, vae=None, ds=None, auto_reg=False):
         from inpaintnet_amd import synthetic
         from inpaintnet_amd.latent_rnn import LatentRNN
         from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
@@ -271,7 +271,8 @@ class LatentWorkload:
             vae.load_state_dict({k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape)))
                                  for k, v in vae.state_dict().items()})
         self.model = LatentRNN(self.ds, vae, num_rnn_layers=2, rnn_hidden_size=512, dropout=0.5, rnn_class=torch.nn.GRU,
-                               auto_reg=False, teacher_forcing=True)
+                               auto_reg=auto_reg, teacher_forcing=True)
+        self.auto_reg = auto_reg
         own = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in self.model.named_parameters()}
         for k, v in own.items():
             self.model.param(k).copy_(v)
@@ -291,6 +292,11 @@ class LatentWorkload:
         return loss
 
     def describe(self, world):
+        if self.auto_reg:
+            return {"workload": "LatentRNN with auto_reg=True (the script default, train_inpaintnet.py:53; teacher-forcing coin per "
+                                "step: the generator runs measure by measure and, when free-running, decodes and re-encodes "
+                                "each generated measure), frozen MeasureVAE, 128 sequences x 16 measures per GPU, 6/4/6",
+                    "batch_per_gpu": LATENT_SEQ_PER_GPU, "global_batch": world * LATENT_SEQ_PER_GPU, "parallelism": f"dp{world}"}
         return {"workload": "LatentRNN (non-AR) training with the frozen MeasureVAE, 128 sequences x 16 measures per "
                             "GPU, past/target/future 6/4/6, dropout 0.5 (BASELINE.json configs[2]; configs[3] when "
                             "data-parallel: 1024 sequences global at 8 GPUs)",
@@ -394,11 +400,22 @@ def kernel_table(step, nprof=4):
     return table
 
 
+def secondary_table(step, top=8):
+    """The per-kernel roofline table of a secondary workload (LatentRNN, AnticipationRNN): the same rows as roofline.kernels,
+    without PMC traffic (the committed PMC passes profile the headline step)."""
+    keep = ("kernel", "launches_per_step", "avg_us", "ms_per_step", "tflops", "mfma_pipe", "peak_tflops", "frac_mfma", "gbps", "frac_hbm")
+    table = kernel_table(step, nprof=3)
+    return {"step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
+            "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
+            "launches_per_step": round(sum(r["launches_per_step"] for r in table), 1),
+            "top": [{k: r[k] for k in keep if k in r} for r in table[:top]]}
+
+
 def piece_products(label):
     """bf16 piece products per f32 product of a kernel label (csrc/gemm_bf3.hip 'bf3p9', csrc/gru_chain2.hip 'v2w4 p9'), 0 for
     the f32-input MFMA kernels."""
     import re
-    m = re.search(r"\bbf3p(\d)\b", label) or re.search(r" v2w\d+e? p(\d) ", label)
+    m = re.search(r"\bbf3p(\d)\b", label) or re.search(r" v2w\d+e? p(\d) ", label) or re.search(r"^gru_step_bf3 p(\d) ", label)
     return int(m.group(1)) if m else 0
 
 
@@ -724,7 +741,7 @@ def chain_generations_extra(wl, steps=60, warmup=10):
     return {"chain_generations": out}
 
 
-def arnn_extra(batch=32, steps=8, warmup=2):
+def arnn_extra(batch=32, steps=30, warmup=4, tables=True):
     """Secondary number (BASELINE.json configs[4]): AnticipationRNN gauss-reg model, teacher-forced training step,
     batch 32 sequences of 384 ticks, script defaults of train_arnn_reg.py.  Not the headline metric."""
     import types
@@ -762,6 +779,7 @@ def arnn_extra(batch=32, steps=8, warmup=2):
     return {"anticipation_rnn_train": {"sequences_per_s": round(batch * steps / dt, 1),
                                        "measures_per_s": round(16 * batch * steps / dt, 1),
                                        "ms_per_step": round(1e3 * dt / steps, 3),
+                                       "kernels": secondary_table(step) if tables else None,
                                        "workload": "AnticipationRNN gauss-reg (LSTM 2x2 layers, H=256), teacher-forced "
                                                    "train step, 32 sequences x 384 ticks"}}
 
@@ -905,10 +923,19 @@ def main():
         elif rank == 0 and world == 1:
             if args.workload == "vae":
                 lw = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds)
-                ldt, _ = timed(lw.step, 10, 3, fence)
-                extras["latent_rnn_train"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * 10 / ldt, 1),
-                                              "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 10 / ldt, 1),
-                                              "ms_per_step": round(1e3 * ldt / 10, 3), **lw.describe(1)}
+                ldt, _ = timed(lw.step, 20, 4, fence)
+                extras["latent_rnn_train"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * 20 / ldt, 1),
+                                              "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 20 / ldt, 1),
+                                              "ms_per_step": round(1e3 * ldt / 20, 3), **lw.describe(1),
+                                              "kernels": secondary_table(lw.step)}
+                del lw
+                random.seed(99)
+                la = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds, auto_reg=True)
+                adt, _ = timed(la.step, 20, 4, fence)
+                extras["latent_rnn_train_auto_reg"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * 20 / adt, 1),
+                                                       "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 20 / adt, 1),
+                                                       "ms_per_step": round(1e3 * adt / 20, 3), **la.describe(1)}
+                del la
                 wl.model.trainable = True                      # (LatentRNN froze the shared VAE)
                 wl.model.train()
             if args.workload == "vae":

@@ -95,12 +95,20 @@ __device__ __forceinline__ bool wait_group(unsigned* counter, unsigned target, S
     return *flag != 0;                                          // callers alternate between two flag words
 }
 
-// block -> (group, member): group = (b % 8) + 8 * (b / (8 * members)), member = (b / 8) % members.  Launch
-// 8 * members * ceil(groups / 8) blocks; blocks whose group >= groups leave at once.
-__host__ __device__ inline int blocks_for(int groups, int members) { return 8 * members * ((groups + 7) / 8); }
+// block -> (group, member).  Workgroup ids go round-robin over the 8 XCDs (32 CUs each) and a chain workgroup has its CU to
+// itself, so the members of a group must sit on as many XCDs as they need CUs: xpg = ceil(members / 32) XCDs per group
+// (1 up to H = 512; 2 for the 64 members of an H = 1024 layer -- with all 64 on ONE XCD half of them never become resident
+// and the group runs into its bounded spin).  x = b % 8, k = b / 8:  group = x / xpg + (8 / xpg) * (k / mpx),
+// member = (x % xpg) * mpx + k % mpx, mpx = members / xpg.  Launch blocks_for() blocks; those whose group >= groups leave at once.
+__host__ __device__ inline int xcds_per_group(int members) { return members > 32 ? (members + 31) / 32 : 1; }
+__host__ __device__ inline int blocks_for(int groups, int members) {
+    const int xpg = xcds_per_group(members), gpr = 8 / xpg;
+    return 8 * (members / xpg) * ((groups + gpr - 1) / gpr);
+}
 __device__ __forceinline__ void decode_block(int b, int members, int& group, int& member) {
-    group = (b & 7) + 8 * (b / (8 * members));
-    member = (b >> 3) % members;
+    const int xpg = xcds_per_group(members), mpx = members / xpg, x = b & 7, k = b >> 3;
+    group = x / xpg + (8 / xpg) * (k / mpx);
+    member = (x % xpg) * mpx + k % mpx;
 }
 
 // acc[ms][slot g] += A[16*MS rows of the group's state, this wave's K quarter] x Wr[g]^T, where the A fragments are

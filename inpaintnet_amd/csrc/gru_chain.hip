@@ -394,9 +394,13 @@ int chain_prio() {
 
 }  // namespace
 
+// H = 1024 (LatentRNN's generator; round 4): first-generation kernels with 192 registers of W_hh per lane, a group's 64 members
+// on two XCDs (chain.h decode_block); INET_CHAIN_H1024=0: that layer on the per-step kernels, as in rounds 1-3
+static bool h1024_on() { static const bool v = [] { const char* e = std::getenv("INET_CHAIN_H1024"); return !(e && e[0] == '0'); }(); return v; }
 bool gru_chain_ok(int H, int B, int T, int nprob) {
+    if (H == 1024 && !h1024_on()) return false;
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;   // the kernels index with 32-bit element offsets
-    if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
+    if (!chain_enabled() || (H != 256 && H != 512 && H != 1024) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
     const int ms = rows_ms(B, H, nprob), tiles = (B + 16 * ms - 1) / (16 * ms);
     return nprob * tiles * (H / 16) <= chain_capacity() && nprob * tiles <= kChainMaxGroups;   // every workgroup resident at once
 }
@@ -406,12 +410,13 @@ bool gru_chain_ok(int H, int B, int T, int nprob) {
 int rows_ms_bwd(int H, int B, int nprob) {
     const int ms = rows_ms(B, H, nprob);
     static const bool wide = [] { const char* e = std::getenv("INET_CHAIN_WIDE"); return !(e && e[0] == '0'); }();
-    if (wide && ms == 4 && B >= 128 && nprob * ((B + 63) / 64) * (H / 16) > chain_capacity()) return 8;
+    if (wide && H <= 512 && ms == 4 && B >= 128 && nprob * ((B + 63) / 64) * (H / 16) > chain_capacity()) return 8;
     return ms;
 }
 bool gru_chain_bwd_ok(int H, int B, int T, int nprob) {
+    if (H == 1024 && !h1024_on()) return false;
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;
-    if (!chain_enabled() || (H != 256 && H != 512) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
+    if (!chain_enabled() || (H != 256 && H != 512 && H != 1024) || T < 2 || nprob < 1 || nprob > 4 || B < 1) return false;
     const int ms = rows_ms_bwd(H, B, nprob), tiles = (B + 16 * ms - 1) / (16 * ms);
     return nprob * tiles * (H / 16) <= chain_capacity() && nprob * tiles <= kChainMaxGroups;
 }
@@ -455,6 +460,7 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     const dim3 grid(chain::blocks_for(groups, a.members));
 #define INET_CF(M, Q, O) hipLaunchKernelGGL((gru_chain_fwd_kernel<M, Q, O>), grid, dim3(256), 0, s, a)
     if (a.shared_chip && ms == 4) { if (a.H == 512) INET_CF(4, 8, 2); else INET_CF(4, 4, 2); }
+    else if (a.H == 1024) { if (ms == 1) INET_CF(1, 16, 1); else if (ms == 2) INET_CF(2, 16, 1); else INET_CF(4, 16, 1); }   // (LatentRNN's generator: 192 registers of W_hh per lane)
     else if (a.H == 512) { if (ms == 1) INET_CF(1, 8, 1); else if (ms == 2) INET_CF(2, 8, 1); else INET_CF(4, 8, 1); }
     else { if (ms == 1) INET_CF(1, 4, 1); else if (ms == 2) INET_CF(2, 4, 1); else INET_CF(4, 4, 1); }
 #undef INET_CF
@@ -493,7 +499,8 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
 #define INET_CB(M, Q) hipLaunchKernelGGL((gru_chain_bwd_kernel<M, Q>), grid, dim3(256), 0, s, a)
     if (emr) hipLaunchKernelGGL((gru_chain_bwd_kernel<4, 24, true>), grid, dim3(256), 0, s, a);
     else
-    if (a.H == 512) { if (ms == 1) INET_CB(1, 24); else if (ms == 2) INET_CB(2, 24); else if (ms == 4) INET_CB(4, 24); else INET_CB(8, 24); }
+    if (a.H == 1024) { if (ms == 1) INET_CB(1, 48); else if (ms == 2) INET_CB(2, 48); else if (ms == 4) INET_CB(4, 48); else return -1; }
+    else if (a.H == 512) { if (ms == 1) INET_CB(1, 24); else if (ms == 2) INET_CB(2, 24); else if (ms == 4) INET_CB(4, 24); else INET_CB(8, 24); }
     else { if (ms == 1) INET_CB(1, 12); else if (ms == 2) INET_CB(2, 12); else if (ms == 4) INET_CB(4, 12); else INET_CB(8, 12); }
 #undef INET_CB
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -28,12 +28,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int WM = 2, WN = 4, RM = 4, RN = 3;          // 8 waves: 2 x 4; wave tile 64 rows x (16 units x 3 gates)
-constexpr int TMB = WM * RM, TNB = WN * RN;            // 8 row blocks of h, 12 (interleaved) row blocks of W
-constexpr int NW = WM * WN;
-constexpr int STAGE = (TMB + TNB) * 3 * 1024;
-constexpr int CH = (TMB + TNB) * 3;
-constexpr int CPW = (CH + NW - 1) / NW;
+constexpr int RN = 3;                                   // a wave's three accumulator tiles per row block: the gates r, z, n of 16 units
+// tiling: WM x WN waves, RM row blocks per wave: 2 x 4 x 4 = 128 rows x 64 units, 8 waves, 120 KB of LDS, one workgroup per CU
 
 struct StepProb {
     const unsigned char* A; unsigned char* An; long a_piece;   // pieces of h_{t-1} / h_t: [B/16][H/32] fragments per piece
@@ -49,7 +45,7 @@ struct StepProb {
     float* sv; long sv_astride;                                  // at time t (row stride H), or null
     unsigned char* em; long em_piece; int em_kb, em_kb0; long em_rb0;   // row pieces of the (masked) output, or null
 };
-struct StepArgs { int H, B, nprob, zero_state, xm, xn; StepProb p[2]; };   // xm x xn: the XCDs of one problem over its (tm, tn) tiles; 0: contiguous ranges
+struct StepArgs { int H, B, nprob, zero_state; StepProb p[2]; };
 
 __device__ __forceinline__ void pieces8_store(const float* src, unsigned char* dst, long piece) {
     bf16x8 p0, p1, p2;
@@ -66,83 +62,65 @@ __device__ __forceinline__ void pieces8_store(const float* src, unsigned char* d
     *reinterpret_cast<bf16x8*>(dst + 2 * piece) = p2;
 }
 
-template <bool TAB, bool DEN, bool SAVE>
-__global__ __launch_bounds__(64 * NW) void gru_step_bf3_kernel(StepArgs a) {
+// Measured and not kept (one-box A/Bs, B = 2048, H = 512, 50 us per step either way): the epilogue's operand loads dealt over the
+// unrolled k blocks instead of requested up front; 64 x 32 tiles with two workgroups per CU so that one's prologue / epilogue
+// runs under the other's MFMAs (52.6 vs 50.6 us); an XCD owning 8 x 4 or 16 x 2 tiles.  The k loop sits on the MFMA issue
+// ceiling (~17 clocks per v_mfma_f32_16x16x32_bf16 and SIMD at the 1.7 GHz the chip sustains under this load: 34.5 us for the
+// nine piece products of a 128 x 192 x 512 tile); a launch without a k loop (step 0 of a zero initial state) takes 15 us.
+template <bool TAB, bool DEN, bool SAVE, int WM, int WN, int RM>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gru_step_bf3_kernel(StepArgs a) {
+    constexpr int TMB = WM * RM, TNB = WN * RN, NW = WM * WN;
+    constexpr int STAGE = (TMB + TNB) * 3 * 1024, CH = (TMB + TNB) * 3, CPW = (CH + NW - 1) / NW;
+    constexpr int UT = 16 * WN;                                    // hidden units per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w / WN, wn = w % WN;
     const int H = a.H, KB = H >> 5;
-    const int tiles_m = a.B / (TMB * 16), tiles_n = H / 64;
+    const int tiles_m = a.B / (TMB * 16), tiles_n = H / UT;
     // consecutive workgroup ids go round-robin over the 8 XCDs: each XCD takes a contiguous range of the (problem, tm, tn)
     // list -- 4 row tiles x all 8 unit tiles of one direction at B = 2048: 1.5 MB of h pieces + that direction's 4.7 MB of W
+    // (an XCD owning 8 x 4 or 16 x 2 tiles instead measured the same, 50.2-50.4 us per step)
     const int nb = gridDim.x, id = blockIdx.x;
     const int tid = (nb % 8 == 0) ? (id % 8) * (nb / 8) + id / 8 : id;
     const int per_prob = tiles_m * tiles_n;
-    int prob = tid / per_prob;
-    const int v = tid - prob * per_prob;
-    int tm = v / tiles_n, tn = v - tm * tiles_n;
-    if (a.xm > 0) {
-        const int xpp = 8 / a.nprob, x = id & 7, slot = id >> 3, xl = x % xpp;
-        const int rm = tiles_m / a.xm, rn = tiles_n / a.xn;
-        prob = x / xpp;
-        tm = (xl / a.xn) * rm + slot / rn;
-        tn = (xl % a.xn) * rn + slot % rn;
-    }
+    const int prob = tid / per_prob, v = tid - prob * per_prob;
+    const int tm = v / tiles_n, tn = v - tm * tiles_n;
     const StepProb& P = a.p[prob];
     const int c = lane & 15, q = lane >> 4;
-    const int j = tn * 64 + wn * 16 + c;                       // this lane's hidden unit
+    const int j0 = tn * UT + wn * 16, j = j0 + c;              // this wave's 16 hidden units; this lane's
 
-    // ---- epilogue operands, requested before the contraction (their latency hides behind it) ----
-    // (every batch of loads in a loop of its own: inside one loop hipcc waits for each token before it issues that row's table
-    //  loads -- 16 dependent round trips in front of the contraction, 20 us of a 52 us step in the first build)
-    float gr[RM][4], gz[RM][4], gn[RM][4], hp[RM][4], mk[RM][4];
-    long rowv[RM][4];
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rowv[i][r] = (long)(tm * TMB + wm * RM + i) * 16 + 4 * q + r;
+    // ---- epilogue operands: branch-free sources (an absent one aims at a valid word with zero strides and is replaced by a
+    // select -- a conditional load costs a branch and a full vmcnt(0) each) ----
+    const bool has_hp = P.hprev != nullptr, has_mk = P.mask != nullptr;
+    const float* const hpp = has_hp ? P.hprev + j : P.b_hh;
+    const long hp_ld = has_hp ? P.hprev_ld : 0;
+    const float* const mkp = has_mk ? P.mask + j : P.b_hh;
+    const long mk_ld = has_mk ? P.mask_ld : 0;
+    const long row00 = (long)(tm * TMB + wm * RM) * 16 + 4 * q;            // row of (i = 0, r = 0); (i, r) adds 16 i + r
     long tok[RM][4];
     if (TAB) {
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tok[i][r] = P.idx[rowv[i][r] * P.idx_bs];
+            for (int r = 0; r < 4; ++r) tok[i][r] = P.idx[(row00 + 16 * i + r) * P.idx_bs];
     }
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { gr[i][r] = 0.f; gz[i][r] = 0.f; gn[i][r] = 0.f; hp[i][r] = 0.f; mk[i][r] = 1.f; }
-    if (DEN) {
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* dp = P.gi + rowv[i][r] * P.gi_ld + j;
-                gr[i][r] = dp[0]; gz[i][r] = dp[H]; gn[i][r] = dp[2 * H];
-            }
-    }
-    if (P.hprev) {
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hp[i][r] = P.hprev[rowv[i][r] * P.hprev_ld + j];
-    }
-    if (P.mask) {
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mk[i][r] = P.mask[rowv[i][r] * P.mask_ld + j];
-    }
-    float tg[TAB ? RM : 1][4][3];
-    if (TAB) {
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* tp = P.table + tok[i][r] * P.table_ld + j;
-                tg[i][r][0] = tp[0]; tg[i][r][1] = tp[H]; tg[i][r][2] = tp[2 * H];
-            }
-    }
+    float gr[RM][4], gz[RM][4], gn[RM][4], hp[RM][4], mk[RM][4];
+    auto load_elem = [&](int i, int r) {
+        const long row = row00 + 16 * i + r;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+        if (DEN) {
+            const float* dp = P.gi + row * P.gi_ld + j;
+            x0 = dp[0]; x1 = dp[H]; x2 = dp[2 * H];
+        }
+        if (TAB) {
+            const float* tp = P.table + tok[i][r] * P.table_ld + j;
+            x0 += tp[0]; x1 += tp[H]; x2 += tp[2 * H];
+        }
+        gr[i][r] = x0; gz[i][r] = x1; gn[i][r] = x2;
+        const float hv = hpp[row * hp_ld], mv = mkp[row * mk_ld];
+        hp[i][r] = has_hp ? hv : 0.f;
+        mk[i][r] = has_mk ? mv : 1.f;
+    };
     float bh[3], bv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 3; ++g) bh[g] = P.b_hh[g * H + j];
@@ -157,6 +135,10 @@ __global__ __launch_bounds__(64 * NW) void gru_step_bf3_kernel(StepArgs a) {
 #pragma unroll
         for (int g = 0; g < RN; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_elem(i, r);
     if (!a.zero_state) {
         // fragment c of a stage: c < 3 TMB: A piece c / TMB, row block c % TMB; then W alike (gemm_bf3_kernel's operand stream)
         const unsigned char* gsrc[CPW]; int loff[CPW];
@@ -179,12 +161,9 @@ __global__ __launch_bounds__(64 * NW) void gru_step_bf3_kernel(StepArgs a) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[i] + (long)kb * 1024),
                                                  (__attribute__((address_space(3))) void*)(stage + loff[i]), 16, 0, 0);
         };
-        fill(0, smem);
-        __syncthreads();
-        for (int kb = 0; kb < KB; ++kb) {
+        auto block = [&](int kb) {
             const unsigned char* sa = smem + (kb & 1) * STAGE + lane * 16;
             const unsigned char* sb = sa + TMB * 3 * 1024;
-            if (kb + 1 < KB) fill(kb + 1, smem + ((kb + 1) & 1) * STAGE);
             bf16x8 Af[RM][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
@@ -203,65 +182,83 @@ __global__ __launch_bounds__(64 * NW) void gru_step_bf3_kernel(StepArgs a) {
                         for (int g = 0; g < RN; ++g)
                             acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[i][pi], Bf[g], acc[i][g], 0, 0, 0);
             }
-            __syncthreads();
+        };
+        fill(0, smem);
+        __syncthreads();
+        for (int kb = 0; kb < KB; ++kb) {
+            if (kb + 1 < KB) fill(kb + 1, smem + ((kb + 1) & 1) * STAGE);
+            block(kb);
+            __syncthreads();                                       // (carries the vmcnt(0) of this wave's fills)
         }
     }
 
     // ---- GRU cell: lane (c, q) holds rows 4q + r, unit c of every 16 x 16 tile; tiles g = 0, 1, 2 are the gates r, z, n ----
-    // Every result leaves through wave-private 16 x 16 transpose tiles in LDS (the stages are free now): the f32 arrays as ONE
-    // 16-byte store per lane and tile (lane = row L / 4, units 4 (L % 4) ..: a whole 1 KB tile per instruction -- scalar stores of
-    // the accumulator layout were store-issue-bound: 16 per lane and array), the pieces as 8 consecutive units per lane.
-    constexpr int NT = SAVE ? 7 : 2;                                   // tiles per wave: h, h * mask [, r, z, n, ghn, hprev]
-    float* const xt = reinterpret_cast<float*>(smem) + w * (NT * 256);
-    const int kbj = tn * 2 + (wn >> 1);                               // k block of the piece layouts this wave's 16 units fall into
-    const int prow = lane & 15, pgrp = (lane >> 4) & 1;
-    const int plane = ((2 * (wn & 1) + pgrp) * 16 + prow) * 16;       // byte offset of (row, 8-unit group) inside the fragment
+    // Every result leaves through wave-private 16 x 16 transpose tiles in LDS (the stages are free now), two row blocks at a
+    // time: the f32 arrays as ONE 16-byte store per lane and tile (a whole 1 KB tile per instruction -- scalar stores of the
+    // accumulator layout are store-issue-bound: 16 per lane and array), the pieces as 8 consecutive units per lane with the two
+    // halves of the wave on the two row blocks.
+    constexpr int NT = SAVE ? 7 : 2;                                   // tiles per row block: h, h * mask [, r, z, n, ghn, hprev]
+    float* const xt = reinterpret_cast<float*>(smem) + w * (2 * NT * 256);
+    const int kbj = j0 >> 5;                                          // k block of the piece layouts this wave's 16 units fall into
+    const int prow = lane & 15, pgrp = (lane >> 4) & 1, phalf = lane >> 5;
+    const int plane = ((2 * ((j0 >> 4) & 1) + pgrp) * 16 + prow) * 16; // byte offset of (row, 8-unit group) inside the fragment
     const int vrow = lane >> 2, vcol = (lane & 3) * 4;                // the lane's 4 consecutive units of one row (vector stores)
-    const int j0 = tn * 64 + wn * 16;
 #pragma unroll
-    for (int i = 0; i < RM; ++i) {
-        const int rb = tm * TMB + wm * RM + i;
+    for (int ip = 0; ip < RM; ip += 2) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ghn = acc[i][2][r] + bh[2];
-            float xr = gr[i][r], xz = gz[i][r], xn = gn[i][r];
-            if (TAB) { xr += tg[i][r][0]; xz += tg[i][r][1]; xn += tg[i][r][2]; }
-            const float rg = sigmoid_f(acc[i][0][r] + xr + bv[0] + bh[0]);
-            const float zg = sigmoid_f(acc[i][1][r] + xz + bv[1] + bh[1]);
-            const float ng = tanh_f(xn + bv[2] + rg * ghn);
-            const float hprev = hp[i][r];
-            const float hn = (1.f - zg) * ng + zg * hprev;
-            const int o = (4 * q + r) * 16 + c;
-            xt[o] = hn; xt[256 + o] = hn * mk[i][r];
-            if (SAVE) { xt[512 + o] = rg; xt[768 + o] = zg; xt[1024 + o] = ng; xt[1280 + o] = ghn; xt[1536 + o] = hprev; }
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = ip + ii;
+            float* const x = xt + ii * (NT * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ghn = acc[i][2][r] + bh[2];
+                const float rg = sigmoid_f(acc[i][0][r] + gr[i][r] + bv[0] + bh[0]);
+                const float zg = sigmoid_f(acc[i][1][r] + gz[i][r] + bv[1] + bh[1]);
+                const float ng = tanh_f(gn[i][r] + bv[2] + rg * ghn);
+                const float hprev = hp[i][r];
+                const float hn = (1.f - zg) * ng + zg * hprev;
+                const int o = (4 * q + r) * 16 + c;
+                x[o] = hn; x[256 + o] = hn * mk[i][r];
+                if (SAVE) { x[512 + o] = rg; x[768 + o] = zg; x[1024 + o] = ng; x[1280 + o] = ghn; x[1536 + o] = hprev; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        const long vr = (long)rb * 16 + vrow;
-        const f32x4 hv4 = *reinterpret_cast<const f32x4*>(xt + vrow * 16 + vcol);
-        *reinterpret_cast<f32x4*>(P.out + vr * P.out_ld + j0 + vcol) = hv4;
-        if (P.outm) *reinterpret_cast<f32x4*>(P.outm + vr * P.outm_ld + j0 + vcol) = *reinterpret_cast<const f32x4*>(xt + 256 + vrow * 16 + vcol);
-        if (P.hlast) *reinterpret_cast<f32x4*>(P.hlast + vr * P.hlast_ld + j0 + vcol) = hv4;
-        if (SAVE) {
 #pragma unroll
-            for (int a5 = 0; a5 < 5; ++a5)
-                *reinterpret_cast<f32x4*>(P.sv + a5 * P.sv_astride + vr * H + j0 + vcol) =
-                    *reinterpret_cast<const f32x4*>(xt + (2 + a5) * 256 + vrow * 16 + vcol);
+        for (int ii = 0; ii < 2; ++ii) {
+            const float* const x = xt + ii * (NT * 256);
+            const long vr = (long)(tm * TMB + wm * RM + ip + ii) * 16 + vrow;
+            const f32x4 hv4 = *reinterpret_cast<const f32x4*>(x + vrow * 16 + vcol);
+            *reinterpret_cast<f32x4*>(P.out + vr * P.out_ld + j0 + vcol) = hv4;
+            if (P.outm) *reinterpret_cast<f32x4*>(P.outm + vr * P.outm_ld + j0 + vcol) = *reinterpret_cast<const f32x4*>(x + 256 + vrow * 16 + vcol);
+            if (P.hlast) *reinterpret_cast<f32x4*>(P.hlast + vr * P.hlast_ld + j0 + vcol) = hv4;
+            if (SAVE) {
+#pragma unroll
+                for (int a5 = 0; a5 < 5; ++a5)
+                    *reinterpret_cast<f32x4*>(P.sv + a5 * P.sv_astride + vr * H + j0 + vcol) =
+                        *reinterpret_cast<const f32x4*>(x + (2 + a5) * 256 + vrow * 16 + vcol);
+            }
         }
-        if (lane < 32) {
-            if (P.An) pieces8_store(xt + prow * 16 + 8 * pgrp, P.An + ((long)rb * KB + kbj) * 1024 + plane, P.a_piece);
-            if (P.em) pieces8_store(xt + 256 + prow * 16 + 8 * pgrp,
+        {
+            const float* const x = xt + phalf * (NT * 256);
+            const long rb = tm * TMB + wm * RM + ip + phalf;
+            if (P.An) pieces8_store(x + prow * 16 + 8 * pgrp, P.An + (rb * KB + kbj) * 1024 + plane, P.a_piece);
+            if (P.em) pieces8_store(x + 256 + prow * 16 + 8 * pgrp,
                                     P.em + ((P.em_rb0 + rb) * P.em_kb + P.em_kb0 + kbj) * 1024 + plane, P.em_piece);
         }
     }
 }
 
 template <bool TAB, bool DEN, bool SAVE>
-int launch_one(const StepArgs& a, int grid, hipStream_t s) {
-    auto kern = &gru_step_bf3_kernel<TAB, DEN, SAVE>;
+int launch_one(const StepArgs& a, hipStream_t s) {
+    constexpr int WM = 2, WN = 4, RM = 4;                          // 8 waves; wave tile 64 rows x (16 units x 3 gates)
+    constexpr int TMB = WM * RM, TNB = WN * RN;
+    auto kern = &gru_step_bf3_kernel<TAB, DEN, SAVE, WM, WN, RM>;
+    const size_t lds = (size_t)2 * (TMB + TNB) * 3 * 1024;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), (size_t)2 * STAGE, s, a);
+    const int grid = a.nprob * (a.B / (TMB * 16)) * (a.H / (16 * WN));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -303,8 +300,7 @@ int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s) {
     const bool tab = L.p[0].gi_table != nullptr, den = L.p[0].gi_dense != nullptr, save = L.p[0].sv != nullptr;
     for (int i = 1; i < nd; ++i)
         if ((L.p[i].gi_table != nullptr) != tab || (L.p[i].gi_dense != nullptr) != den || (L.p[i].sv != nullptr) != save) return -1;
-    if (!tab && !den) return -1;
-    const int grid = nd * (B / 128) * (H / 64);
+    if (tab == den) return -1;                               // one input-side source per layer (gather table: layer 0; dense: layer 1)
     char label[96];
     std::snprintf(label, sizeof label, "gru_step_bf3 p9 np%d B%d H%d%s", nd, B, H, save ? " sv" : "");
     for (int step = 0; step < T; ++step) {
@@ -327,10 +323,8 @@ int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s) {
             if (step == 0) { Q.hprev = P.h0; Q.hprev_ld = P.ld_h0; if (P.h0) zero = false; }
             else { Q.hprev = P.out + (long)tp * P.ts_out; Q.hprev_ld = P.ld_out; zero = false; }
             Q.out = P.out + (long)tt * P.ts_out; Q.out_ld = P.ld_out;
-            if (P.outm) {
-                Q.outm = P.outm + (long)tt * P.ts_outm; Q.outm_ld = P.ld_outm;
-                Q.mask = P.mask ? P.mask + (long)tt * P.ts_mask : nullptr; Q.mask_ld = P.ld_mask;
-            }
+            if (P.outm) { Q.outm = P.outm + (long)tt * P.ts_outm; Q.outm_ld = P.ld_outm; }
+            if (P.mask) { Q.mask = P.mask + (long)tt * P.ts_mask; Q.mask_ld = P.ld_mask; }
             if (P.hlast && step == T - 1) { Q.hlast = P.hlast; Q.hlast_ld = P.ld_hlast; }
             if (P.sv) { Q.sv = P.sv + (long)tt * (P.sv_ts ? P.sv_ts : (long)B * H); Q.sv_astride = P.sv_astride; }
             if (P.em.rows) {
@@ -339,19 +333,12 @@ int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s) {
             }
         }
         a.zero_state = zero ? 1 : 0;
-        {   // XCD arrangement (A/B switch INET_STEP_BF3_MAP="xm,xn"; default: contiguous ranges)
-            static const int mx = [] { const char* v = std::getenv("INET_STEP_BF3_MAP"); return v ? std::atoi(v) : 0; }();
-            static const int mn = [] { const char* v = std::getenv("INET_STEP_BF3_MAP"); const char* c = v ? std::strchr(v, ',') : nullptr; return c ? std::atoi(c + 1) : 0; }();
-            const int tiles_m = B / 128, tiles_n = H / 64, xpp = 8 / nd;
-            if (mx > 0 && mn > 0 && 8 % nd == 0 && mx * mn == xpp && tiles_m % mx == 0 && tiles_n % mn == 0 && grid % 8 == 0) { a.xm = mx; a.xn = mn; }
-        }
         // algorithmic bytes of a step: W pieces once, state pieces in and out, gi, out (+ saves)
         ProfScope prof(PROF_GRU_FWD, zero ? 0.0 : 2.0 * nd * B * 3.0 * H * H, s, label,
                        nd * (6.0 * 3 * H * H + 12.0 * B * H + 4.0 * B * 3 * H + 4.0 * B * H * (save ? 7 : 2)));
         int rc;
-        if (tab && den) rc = save ? launch_one<true, true, true>(a, grid, s) : launch_one<true, true, false>(a, grid, s);
-        else if (tab) rc = save ? launch_one<true, false, true>(a, grid, s) : launch_one<true, false, false>(a, grid, s);
-        else rc = save ? launch_one<false, true, true>(a, grid, s) : launch_one<false, true, false>(a, grid, s);
+        if (tab) rc = save ? launch_one<true, false, true>(a, s) : launch_one<true, false, false>(a, s);
+        else rc = save ? launch_one<false, true, true>(a, s) : launch_one<false, true, false>(a, s);
         if (rc != 0) return rc;
     }
     return 0;

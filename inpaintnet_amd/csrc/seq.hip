@@ -139,7 +139,9 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
             P.sv = D.sv; P.sv_astride = D.sv_astride;
             P.hx = D.hpk; P.reverse = D.reverse;
             if (D.em.rows) { P.em.rows = D.em.rows; P.em.rows_piece = D.em.rows_piece; P.em.rows_kb = D.em.rows_kb; P.em.rows_kb0 = D.em.rows_kb0;
-                             P.em.B_full = B; P.em.r0 = 0; D.emitted = 1; }
+                             P.em.B_full = B; P.em.r0 = 0; D.emitted = 1;
+                             // forward-only: the masked output's only reader is the layer-1 product, which takes these pieces
+                             if (!D.sv) P.outm = nullptr; }
             INET_TRY(gru_step_bf3_split_w(H, D.W_hh, D.wp3, s));
             L.Wp[i] = D.wp3;
         }

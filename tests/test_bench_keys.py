@@ -81,5 +81,4 @@ def test_stale_traffic_file_is_refused(bench):
     assert table[0]["traffic_mbytes_per_launch"] == 325.6 and table[1]["traffic_mbytes_per_launch"] == 474.0
     table2 = [{"kernel": lab_b}]
     assert bench.attach_traffic(table2, {"kernels": doc["kernels"]}) == [] and table2[0]["traffic_mbytes_per_launch"] == 474.0
-    assert bench.pmc_key("gru_step_bf3 p9 np2 B2048 H512") == "gru_step_bf3_kernel<true, false, false>|g131072" or \
-        bench.pmc_key("gru_step_bf3 p9 np2 B2048 H512") is None
+    assert bench.piece_products("gru_step_bf3 p9 np2 B2048 H512 sv") == 9

@@ -254,10 +254,11 @@ def test_latent_step_at_bench_batch_vs_oracle(variant, tmp_path, monkeypatch):
     assert sum(l == "gru_step_bf3 p9 np2 B2048 H512" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
     assert any(G.is_chain(l, "fwd", 2, 6, 128) for l in labels) and any(G.is_chain(l, "bwd", 2, 6, 128) for l in labels)   # contexts: 8 groups of 32 rows
     if variant == "nar":
-        assert any(l.startswith("gru_fwd x0") and l.endswith("B128 H1024") for l in labels)      # generator
+        # generator (H = 1024, 4 target measures): first-generation chain launches, a group's 64 members on two XCDs
+        assert sum(l == "gru_chain_fwd ms4 np2 T4 B128 H1024" for l in labels) == 2, sorted(set(l for l in labels if "H1024" in l))
         # the frozen decoder's 512 free-running rows: the fused decode kernel over two chunks of 256 rows (with backward saves)
         assert sum(l == "decode_chain_train ms2 T24 B256 H512 V48" for l in labels) == 2, sorted(set(l for l in labels if l.startswith("dec")))
-        assert any(l.startswith("gru_bwd") and l.endswith("B128 H1024") for l in labels)
+        assert sum(l == "gru_chain_bwd ms4 np2 T4 B128 H1024" for l in labels) == 2, sorted(set(l for l in labels if "H1024" in l))
     if free_ar:                                                     # one fused decode launch of 128 rows per generated measure
         assert sum(l.startswith("decode_chain_train") for l in labels) == n_target, sorted(set(l for l in labels if l.startswith("dec")))
 
