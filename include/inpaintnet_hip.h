@@ -146,15 +146,16 @@ int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
  *    together with the gradients (one slot in front of the gradient arena: no extra collective), so that every rank skips a
  *    step ANY rank's chain kernels failed in and the replicas stay bit-identical.  Null: this process's own status word decides,
  *    as in inet_adam_step.
- *  - tag: the kernel leaves a record {executed, skipped, nonfinite, 0} in a ring of 16 host-mapped slots (slot tag % 16), and an
- *    event is recorded behind it; inet_step_report(tag, wait, out4) reads it (wait != 0: after the event -- a step issued two or
- *    more steps ago has normally finished, so the read costs nothing and BOUNDS how far the host runs ahead).  nonfinite = a
- *    parameter became NaN / inf in this update: the observable behaviour of MeasureVAE/encoder.py:111-116 and decoder.py:424-429
- *    (ValueError "... has become nan") without a host scan of the weights per forward.  -1: no such tag in the ring. */
+ *  - report (nullable): FOUR 32-bit words of caller-owned, device-visible HOST memory (pinned / host-mapped), zeroed by the
+ *    caller before the call; the kernel sets [0] = 1 when it has run, [1] = 1 if it skipped the step, [2] = 1 if a parameter
+ *    became NaN / inf in this update -- the observable behaviour of MeasureVAE/encoder.py:111-116 and decoder.py:424-429
+ *    (ValueError "... has become nan") without a host scan of the weights per forward.  The caller reads the record behind an
+ *    event of its own a few steps later (inpaintnet_amd/trainer.py keeps a ring of 16 records per Trainer and reads the one of
+ *    step k when it has queued step k + 2: by then that launch has normally finished, the read costs nothing and BOUNDS how far
+ *    the host runs ahead). */
 int inet_adam_step_ex(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                      float eps, int step, float gscale, const float* step_flag, uint32_t tag, void* stream);
+                      float eps, int step, float gscale, const float* step_flag, uint32_t* report, void* stream);
 int inet_step_flag_export(float* dst, void* stream);
-int inet_step_report(uint32_t tag, int wait, uint32_t* out4);
 /* Number of prologue launches that met a token index outside [0, num_notes) since the last reset (encoder input tokens,
  * teacher-forcing targets): decoder.py:36-45 check_index raises ValueError; here the host-mapped counter is read by the Python
  * layer at its status reads (Trainer.step, the inference wrappers).  reset != 0 clears it.  -2: could not be allocated. */

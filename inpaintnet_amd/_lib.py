@@ -90,9 +90,8 @@ _SIGNATURES = {
     "inet_sample_multinomial": (C.c_int, [_P, _L, _I, _I, _P, _L, C.c_uint64, C.c_uint64, _P]),
     "inet_latent_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _P, _P, _L, _P]),
     "inet_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
-    "inet_adam_step_ex": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, C.c_uint32, _P]),
+    "inet_adam_step_ex": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _P, _P]),
     "inet_step_flag_export": (C.c_int, [_P, _P]),
-    "inet_step_report": (C.c_int, [C.c_uint32, _I, C.POINTER(C.c_uint32)]),
     "inet_token_status": (C.c_int, [_I]),
     "inet_epoch_stats_add_ex": (C.c_int, [_P, _P, _P, _P, _P]),
     "inet_dropout_mask": (C.c_int, [_P, _L, _F, _U, _U, _P]),

@@ -179,21 +179,13 @@ int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
     return pw_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, (hipStream_t)stream);
 }
 int inet_adam_step_ex(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                      float eps, int step, float gscale, const float* step_flag, uint32_t tag, void* stream) {
+                      float eps, int step, float gscale, const float* step_flag, uint32_t* report, void* stream) {
     if (!p || !g || !m || !v || n <= 0 || step < 1) return -1;
-    return pw_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, (hipStream_t)stream, step_flag, 1, tag);
+    return pw_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale, (hipStream_t)stream, step_flag, report);
 }
 int inet_step_flag_export(float* dst, void* stream) {
     if (!dst) return -1;
     return pw_step_flag_export(dst, (hipStream_t)stream);
-}
-int inet_step_report(uint32_t tag, int wait, uint32_t* out4) {
-    if (!out4) return -1;
-    unsigned tmp[4];
-    const int rc = step_report_read(tag, wait, tmp);
-    if (rc != 0) return rc;
-    for (int i = 0; i < 4; ++i) out4[i] = tmp[i];
-    return 0;
 }
 int inet_token_status(int reset) {
     unsigned* p = token_host_status();

@@ -207,14 +207,6 @@ unsigned* chain_host_status();
 // the Adam kernel (pw_adam) so that a failed step leaves the parameters untouched; inet_chain_status(reset) clears both
 unsigned* chain_dev_status();
 int chain_status_reset();
-// ---- step reports (round 4): what the optimizer kernel of step `tag` decided, readable by the host a fixed number of
-// steps later without stalling the queue.  A ring of kStepReports host-mapped records {executed, skipped, nonfinite, -};
-// step_report_begin() clears the record of `tag` on the host and returns its device-visible address for pw_adam(),
-// step_report_end() records an event behind the launch, step_report_read() optionally waits for that event.
-constexpr int kStepReports = 16;
-unsigned* step_report_begin(unsigned tag);
-int step_report_end(unsigned tag, hipStream_t s);
-int step_report_read(unsigned tag, int wait, unsigned out[4]);
 // host-mapped count of token indices outside [0, V) seen by a module's prologue (decoder.py:36-45 check_index raises
 // ValueError; here the host raises at its next status read); null if it could not be allocated
 unsigned* token_host_status();

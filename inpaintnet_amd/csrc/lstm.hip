@@ -20,6 +20,33 @@ constexpr int kCounterStride = 64;
 constexpr int kBwdCounters = 32 * kCounterStride;
 constexpr int kStatusWord = 64 * kCounterStride;
 constexpr int kSyncWords = kStatusWord + 4;
+// chunked pipelines (lstm2_seq_*): one backward counter area per chunk behind the base area, zeroed by ONE memset per call
+// instead of a 5 us fill in front of every chunk launch
+constexpr int kMaxChunks = 16;
+constexpr int kSyncWordsAll = kSyncWords + 60 + kMaxChunks * kBwdCounters;
+
+// One launch in front of a forward chunk instead of three (memset of the counters, memset 0xFF of the armed ring slots,
+// pack of the previous state into its slot: 16 us per chunk of a 150 us chain launch): blockIdx.y = job.
+__global__ void lstm_chunk_prologue_kernel(unsigned* zero_words, int nzero, unsigned* fill_words, long nfill,
+                                           const float* __restrict__ hprev, int B, int H, float* __restrict__ slot) {
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    if (blockIdx.y == 0) {
+        for (long i = i0; i < nzero; i += stride) zero_words[i] = 0u;
+        for (long i = i0; i < nfill; i += stride) fill_words[i] = 0xffffffffu;
+    } else {
+        const int S = H >> 4;                                        // pack_frag_kernel's layout (pointwise.hip)
+        const long slots = (long)((B + 15) >> 4) * S * 64;
+        for (long i = i0; i < slots; i += stride) {
+            const int lane = (int)(i & 63);
+            const long blk = i >> 6;
+            const int sb = (int)(blk % S), rb = (int)(blk / S);
+            const int row = 16 * rb + (lane & 15), k = 16 * sb + 4 * (lane >> 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < B) { const float* q = hprev + (long)row * H + k; v = make_float4(q[0], q[1], q[2], q[3]); }
+            *reinterpret_cast<float4*>(slot + 4 * i) = v;
+        }
+    }
+}
 
 struct LstmFwdArgs {
     int B, H;
@@ -575,7 +602,7 @@ size_t lstm_carve(int B, int T, int H, int save, void* base, LstmWs& w) {
     w.hx = cv.take<float>(4 * pk_floats(B, H));           // 2 slots (counter hand-off) or a ring of 4 (tagged hand-off)
     w.gx = save ? cv.take<float>(2 * pk_floats(B, 4 * H)) : nullptr;
     w.carry = save ? cv.take<float>(4 * BH) : nullptr;        // (dh, dc) handed from one chunk of a chunked backward to the next, x2
-    w.sync = cv.take<unsigned>(kSyncWords);
+    w.sync = cv.take<unsigned>(kSyncWordsAll);
     return cv.bytes();
 }
 
@@ -650,12 +677,11 @@ int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, cons
     // than its counter: 9.34 vs 9.23 ms per AnticipationRNN step with both, 8.87 with the forward chains only.)
     static const bool tag_on = [] { const char* e = std::getenv("INET_LSTM_TAG"); return !(e && e[0] == '0'); }();
     const bool tagged = tag_on && H == 256 && chain_ms(B, H) <= 2;
-    if (hipMemsetAsync(w.sync, 0, kSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    if (tagged) {                                  // slots 0, 1 armed; slot 3 = the previous step's h
-        if (hipMemsetAsync(w.hx, 0xff, 2 * pk_floats(B, H) * sizeof(float), s) != hipSuccess) return -2;
-        INET_TRY(pw_pack_frag(hprev, H, B, H, w.hx + 3 * pk_floats(B, H), 0, 1, 0, 0, s));
-    } else
-    INET_TRY(pw_pack_frag(hprev, H, B, H, w.hx + pk_floats(B, H), 0, 1, 0, 0, s));   // slot 1 = the previous step's h
+    // counters zeroed; tagged: slots 0, 1 armed and slot 3 = the previous step's h; counter protocol: slot 1 = that h
+    hipLaunchKernelGGL(lstm_chunk_prologue_kernel, dim3(16, 2), dim3(256), 0, s, w.sync, kSyncWords,
+                       reinterpret_cast<unsigned*>(w.hx), tagged ? 2L * (long)pk_floats(B, H) : 0L, hprev, B, H,
+                       w.hx + (tagged ? 3 : 1) * pk_floats(B, H));
+    if (hipGetLastError() != hipSuccess) return -2;
     LstmChainFwdArgs a{};
     a.B = B; a.H = H; a.T = nt; a.reverse = reverse; a.members = H / 16;
     a.gi = gi + t_lo * B * 4 * H; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = cprev;
@@ -679,19 +705,22 @@ int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, cons
 // Backward through forward steps [s_lo, s_lo + nt) as one chain launch: (dhT, dcT) = the gradient into the state after
 // the chunk's last step (from the chunk that ran before this one, or null), (dh0, dc0) = the gradient into the state in
 // front of its first step (for the next chunk, or null).  w.whhT must hold W_hh^T.
+// `area` >= 0: the chunk's own pre-zeroed counter area (lstm2_seq_bwd zeroes all of them with one memset); < 0: the base area,
+// zeroed here.
 int lstm_chunk_bwd(int B, int T, int H, const float* dout, const float* dhT, const float* dcT, int reverse, float* dgi,
-                   float* db_ih, float* db_hh, float* dh0, float* dc0, LstmWs& w, int s_lo, int nt, hipStream_t s) {
+                   float* db_ih, float* db_hh, float* dh0, float* dc0, LstmWs& w, int s_lo, int nt, hipStream_t s, int area = -1) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
     const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
-    if (hipMemsetAsync(w.sync + kBwdCounters, 0, kBwdCounters * sizeof(unsigned), s) != hipSuccess) return -2;
+    unsigned* const counters = area >= 0 ? w.sync + kSyncWords + 60 + (long)area * kBwdCounters : w.sync + kBwdCounters;
+    if (area < 0 && hipMemsetAsync(counters, 0, kBwdCounters * sizeof(unsigned), s) != hipSuccess) return -2;
     LstmChainBwdArgs a{};
     a.B = B; a.H = H; a.T = nt; a.reverse = reverse; a.members = H / 16;
     a.W_hhT = w.whhT; a.dout = dout ? dout + t_lo * BH : nullptr; a.dhT = dhT; a.dcT = dcT;
     a.sv = w.sv + t_lo * BH; a.sv_stride = TBH;
     a.dg = dgi + t_lo * B * 4 * H; a.dh0 = dh0; a.dc0 = dc0;
     a.db_ih = db_ih; a.db_hh = db_hh;
-    a.gx = w.gx; a.counters = w.sync + kBwdCounters; a.status = chain_status_for(w.sync + kStatusWord);
+    a.gx = w.gx; a.counters = counters; a.status = chain_status_for(w.sync + kStatusWord);
     char label[64];
     std::snprintf(label, sizeof label, "lstm_chain_bwd ms%d T%d B%d H%d", ms, nt, B, H);
     ProfScope prof(PROF_GRU_BWD, 2.0 * nt * B * 4.0 * H * H, s, label,
@@ -733,13 +762,18 @@ int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, con
     const long BH = (long)B * H;
     if (pw_zero(w0.zeros, BH, s) != 0 || pw_zero(w1.zeros, BH, s) != 0) return -2;
     hipStream_t s2 = twin_fork(s);
+    static const bool third = [] { const char* e = std::getenv("INET_LSTM_THIRD"); return !(e && e[0] == '0'); }();
     for (int s_lo = 0; s_lo < T; s_lo += CH) {
         const int nt = T - s_lo < CH ? T - s_lo : CH;
         const long t_lo = reverse ? T - (s_lo + nt) : s_lo, tp = reverse ? t_lo + nt : t_lo - 1;
         INET_TRY(lstm_chunk_fwd(B, T, H, gi0, W_hh0, b_hh0, s_lo ? out0 + tp * BH : w0.zeros, s_lo ? w0.cseq + tp * BH : w0.zeros,
                                 reverse, out0, w0, save, s_lo, nt, s));
-        INET_TRY(stream_wait(s2, s));
-        INET_TRY(linear_fwd(out0 + t_lo * BH, H, W_ih1, H, b_ih1, gi1 + t_lo * B * 4 * H, 4L * H, nt * B, 4 * H, H, EPI_NONE, s2));
+        // the chunk's projection gi1 = out0 W_ih1^T + b_ih1 on a THIRD stream (a side stream forked behind layer 0's chunk), so
+        // that layer 1's queue holds nothing but its chain launches: the product (30 us) runs under layer 1's previous chunk
+        hipStream_t s3 = third ? side_fork(s) : s2;
+        if (s3 == s2 || s3 == s) { s3 = s2; INET_TRY(stream_wait(s2, s)); }
+        INET_TRY(linear_fwd(out0 + t_lo * BH, H, W_ih1, H, b_ih1, gi1 + t_lo * B * 4 * H, 4L * H, nt * B, 4 * H, H, EPI_NONE, s3));
+        if (s3 != s2) INET_TRY(stream_wait(s2, s3));
         INET_TRY(lstm_chunk_fwd(B, T, H, gi1, W_hh1, b_hh1, s_lo ? out1 + tp * BH : w1.zeros, s_lo ? w1.cseq + tp * BH : w1.zeros,
                                 reverse, out1, w1, save, s_lo, nt, s2));
     }
@@ -762,6 +796,12 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
     INET_TRY(pw_transpose(W_hh0, H, w0.whhT, 4L * H, 4 * H, H, s));
     INET_TRY(pw_transpose(W_hh1, H, w1.whhT, 4L * H, 4 * H, H, s));
     hipStream_t s2 = twin_fork(s);
+    static const bool third = [] { const char* e = std::getenv("INET_LSTM_THIRD"); return !(e && e[0] == '0'); }();
+    const int nchunks = (T + CH - 1) / CH;
+    const bool areas = nchunks <= kMaxChunks;            // one pre-zeroed counter area per chunk and layer
+    if (areas && (hipMemsetAsync(w0.sync + kSyncWords, 0, (kSyncWordsAll - kSyncWords) * sizeof(unsigned), s) != hipSuccess ||
+                  hipMemsetAsync(w1.sync + kSyncWords, 0, (kSyncWordsAll - kSyncWords) * sizeof(unsigned), s) != hipSuccess)) return -2;
+    if (s2 != s) INET_TRY(stream_wait(s2, s));           // (the second stream's first launch must see those zeros)
     int c = 0;
     for (int s_end = T; s_end > 0; s_end -= CH, ++c) {
         const int nt = s_end < CH ? s_end : CH, s_lo = s_end - nt;
@@ -771,12 +811,14 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
         float* in0 = w0.carry + (long)((c + 1) & 1) * 2 * BH;
         float* ou0 = w0.carry + (long)(c & 1) * 2 * BH;
         INET_TRY(lstm_chunk_bwd(B, T, H, dout1, c ? in1 : nullptr, c ? in1 + BH : nullptr, reverse, dgi1, db_ih1, db_hh1,
-                                s_lo ? ou1 : nullptr, s_lo ? ou1 + BH : nullptr, w1, s_lo, nt, s));
-        INET_TRY(stream_wait(s2, s));
+                                s_lo ? ou1 : nullptr, s_lo ? ou1 + BH : nullptr, w1, s_lo, nt, s, areas ? c : -1));
+        hipStream_t s3 = third ? side_fork(s) : s2;          // (as in the forward pipeline: the chunk's product on a third stream)
+        if (s3 == s2 || s3 == s) { s3 = s2; INET_TRY(stream_wait(s2, s)); }
         INET_TRY(linear_dgrad(dgi1 + t_lo * B4H, 4L * H, W_ih1, H, dout0 + t_lo * BH, H, nt * B, 4 * H, H, EPI_NONE, nullptr, 0,
-                              ACC_STORE, s2));
+                              ACC_STORE, s3));
+        if (s3 != s2) INET_TRY(stream_wait(s2, s3));
         INET_TRY(lstm_chunk_bwd(B, T, H, dout0, c ? in0 : nullptr, c ? in0 + BH : nullptr, reverse, dgi0, db_ih0, db_hh0,
-                                s_lo ? ou0 : nullptr, s_lo ? ou0 + BH : nullptr, w0, s_lo, nt, s2));
+                                s_lo ? ou0 : nullptr, s_lo ? ou0 + BH : nullptr, w0, s_lo, nt, s2, areas ? c : -1));
     }
     if (s2 != s) INET_TRY(twin_join(s));
     if (dW_hh0) {

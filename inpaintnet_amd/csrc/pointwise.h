@@ -20,9 +20,10 @@ int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float
                   float* dmu, float* dls, long n, hipStream_t s);
 int pw_sample_multinomial(const float* W, long ld_w, int rows, int V, long long* out, long stride, uint64_t seed,
                           uint64_t offset, hipStream_t s);
-// step_flag (optional device float): non-zero = skip (the ranks' summed chain status); tagged: leave a step report under `tag`
+// step_flag (optional device float): non-zero = skip (the ranks' summed chain status); report (optional, 4 host-mapped words
+// zeroed by the caller): [0] = 1 executed, [1] = 1 skipped, [2] = 1 a parameter became non-finite
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
-            float gscale, hipStream_t s, const float* step_flag = nullptr, int tagged = 0, unsigned tag = 0);
+            float gscale, hipStream_t s, const float* step_flag = nullptr, unsigned* report = nullptr);
 int pw_step_flag_export(float* dst, hipStream_t s);
 int pw_epoch_stats_add(float* sums, const float* loss, const float* acc, hipStream_t s, const float* step_flag = nullptr);
 int pw_colsum(const float* X, long ld, int M, int N, float* out, hipStream_t s);

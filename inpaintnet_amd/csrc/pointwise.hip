@@ -198,7 +198,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     // A chain kernel gave up waiting for its group (chain.h): the gradients of the step are not valid, so the step leaves
     // parameters and moments as they are.  Which word decides: `step_flag` when the caller passes one -- the flags of ALL
     // ranks summed with the gradients (inet_step_flag_export + the all-reduce), so that every rank of a data-parallel job
-    // takes the same decision --, else this process's own device word.  `report` (host-mapped, chain.h step reports) tells
+    // takes the same decision --, else this process's own device word.  `report` (four host-mapped words owned by the caller) tells
     // the host what was decided and whether a parameter left the finite range (encoder.py:111-116, decoder.py:424-429).
     const bool skip = step_flag ? (*step_flag != 0.f)
                                 : (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
@@ -728,18 +728,13 @@ int pw_latent_bwd(const float* dz, const float* mu, const float* ls, const float
     return ok();
 }
 int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
-            float gscale, hipStream_t s, const float* step_flag, int tagged, unsigned tag) {
+            float gscale, hipStream_t s, const float* step_flag, unsigned* report) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    unsigned* report = nullptr;
-    if (tagged && !(report = step_report_begin(tag))) return -2;
-    {
-        ProfScope prof(PROF_HBM, 0.0, s, "adam", 28.0 * (double)n);      // read p,g,m,v; write p,m,v
-        hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
-                           (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale,
-                           (const unsigned*)chain_dev_status(), step_flag, report);
-    }
-    if (ok() != 0) return -2;
-    return tagged ? step_report_end(tag, s) : 0;
+    ProfScope prof(PROF_HBM, 0.0, s, "adam", 28.0 * (double)n);      // read p,g,m,v; write p,m,v
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, gscale,
+                       (const unsigned*)chain_dev_status(), step_flag, report);
+    return ok();
 }
 int pw_step_flag_export(float* dst, hipStream_t s) {
     hipLaunchKernelGGL(step_flag_export_kernel, dim3(1), dim3(64), 0, s, (const unsigned*)chain_dev_status(), dst);

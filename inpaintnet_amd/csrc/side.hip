@@ -173,49 +173,7 @@ int chain_status_reset() {
     if (d && (hipDeviceSynchronize() != hipSuccess || hipMemset(d, 0, 4) != hipSuccess)) return -2;
     return 0;
 }
-// ---- step reports (chain.h) ----
-namespace {
-struct StepSlot { unsigned tag; bool used; hipEvent_t ev; };
-StepSlot g_steps[kStepReports] = {};
-unsigned* g_step_words = nullptr;          // host-mapped, 4 words per slot
-bool g_step_tried = false;
-unsigned* step_words() {
-    if (!g_step_tried) {
-        g_step_tried = true;
-        void* q = nullptr;
-        if (hipHostMalloc(&q, kStepReports * 16, hipHostMallocMapped) == hipSuccess) {
-            g_step_words = static_cast<unsigned*>(q);
-            for (int i = 0; i < kStepReports * 4; ++i) g_step_words[i] = 0u;
-        }
-    }
-    return g_step_words;
-}
-}  // namespace
-unsigned* step_report_begin(unsigned tag) {
-    unsigned* w = step_words();
-    if (!w) return nullptr;
-    StepSlot& sl = g_steps[tag % kStepReports];
-    // the slot's previous owner (tag - kStepReports) must have run before its words are cleared under it
-    if (sl.used && sl.ev && hipEventSynchronize(sl.ev) != hipSuccess) return nullptr;
-    unsigned* r = w + 4 * (tag % kStepReports);
-    for (int i = 0; i < 4; ++i) __atomic_store_n(r + i, 0u, __ATOMIC_RELAXED);
-    sl.tag = tag; sl.used = true;
-    return r;
-}
-int step_report_end(unsigned tag, hipStream_t s) {
-    StepSlot& sl = g_steps[tag % kStepReports];
-    if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) { sl.ev = nullptr; return -2; }
-    return hipEventRecord(sl.ev, s) == hipSuccess ? 0 : -2;
-}
-int step_report_read(unsigned tag, int wait, unsigned out[4]) {
-    unsigned* w = step_words();
-    StepSlot& sl = g_steps[tag % kStepReports];
-    if (!w || !sl.used || sl.tag != tag || !sl.ev) return -1;
-    if (wait && hipEventSynchronize(sl.ev) != hipSuccess) return -2;
-    const unsigned* r = w + 4 * (tag % kStepReports);
-    for (int i = 0; i < 4; ++i) out[i] = __atomic_load_n(r + i, __ATOMIC_RELAXED);
-    return 0;
-}
+// ---- token range status (chain.h) ----
 unsigned* token_host_status() {
     static unsigned* p = nullptr;
     static bool tried = false;

@@ -240,31 +240,26 @@ def latent_bwd(dz, mu, ls, eps, kscale, kscale_dev=None):
     return dmu, dls
 
 
-def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0, step_flag=None, tag=None):
-    """tag (int): the kernel leaves a step report (step_report(tag)); step_flag: 1-element device tensor that decides whether the
-    step is applied (the ranks' summed chain status, include/inpaintnet_hip.h inet_adam_step_ex)."""
+def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0, step_flag=None, report=None):
+    """report: 4 int32 words of PINNED host memory, zeroed by the caller; the kernel sets [0] executed, [1] skipped, [2] a
+    parameter became non-finite.  step_flag: 1-element device tensor that alone decides whether the step is applied (the ranks'
+    summed chain status, include/inpaintnet_hip.h inet_adam_step_ex)."""
     for t in (p, g, m, v):
         _f32c(t)
-    if tag is None:
-        assert step_flag is None
+    if report is None and step_flag is None:
         check(_lib.lib().inet_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(b1), float(b2),
                                         float(eps), int(step), float(gscale), stream_ptr()), "inet_adam_step")
     else:
+        if report is not None:
+            assert report.dtype == torch.int32 and report.numel() >= 4 and report.is_pinned() and report.is_contiguous()
         check(_lib.lib().inet_adam_step_ex(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(b1), float(b2),
-                                           float(eps), int(step), float(gscale), ptr(step_flag), int(tag) & 0xffffffff,
-                                           stream_ptr()), "inet_adam_step_ex")
+                                           float(eps), int(step), float(gscale), ptr(step_flag), ptr(report), stream_ptr()),
+              "inet_adam_step_ex")
 
 
 def step_flag_export(dst):
     """dst[0] = 1.0 if a chain launch of this process has timed out since the last reset else 0.0 (on the current stream)."""
     check(_lib.lib().inet_step_flag_export(ptr(_f32c(dst)), stream_ptr()), "inet_step_flag_export")
-
-
-def step_report(tag, wait=True):
-    """(executed, skipped, nonfinite) of the optimizer step issued under `tag`; wait: after the event behind that launch."""
-    out = (C.c_uint32 * 4)()
-    check(_lib.lib().inet_step_report(int(tag) & 0xffffffff, int(bool(wait)), out), "inet_step_report")
-    return bool(out[0]), bool(out[1]), bool(out[2])
 
 
 def token_status(reset=False):

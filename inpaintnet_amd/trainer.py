@@ -125,10 +125,16 @@ class Trainer(ABC):
         # record of step k when it has queued step k + report_lag -- by then that kernel has normally run, so the read costs
         # nothing, and it happens at the SAME step on every rank of a data-parallel job (the decision itself is the ranks'
         # summed flag), so all ranks fall back and repeat the same batches together.
-        self.report_lag = 2
+        # The lag is also how far the host may run ahead, and that must be FAR: with a lag of 2 the B = 256 step measured 3.87 ms
+        # against 3.63 without any report (4: 3.78, 8: 3.66-3.73, 14: 3.62-3.64; one box, profiles/r04_b_report_lag.txt) whatever the
+        # wait was made of (event synchronize, event query, a plain host spin on the pinned word): the host's launch loop has
+        # pauses of several milliseconds now and then, and only a deep queue hides them from the GPU.
+        self.report_lag = int(os.environ.get("INET_REPORT_LAG", "12"))
         self._tag = 0
         self._inflight = deque()                     # tags whose report has not been read yet, oldest first
-        self._recent = deque(maxlen=8)               # (tag, batch) of the epoch loop's last steps: what a fallback runs again
+        self._reports = None                         # ring of _NREP records in pinned host memory, written by the kernel
+        self._report_events = None                   # one event per record, recorded behind its optimizer launch
+        self._recent = deque(maxlen=self._NREP)      # (tag, batch) of the epoch loop's last steps: what a fallback runs again
         self._lost = []                              # tags found skipped since the last fallback
 
     # ---- utils/trainer.py:41-124 (plot/log plumbing omitted) -----------------------
@@ -283,13 +289,34 @@ class Trainer(ABC):
         tag = self._tag
         self._tag += 1
         if m.grad.is_cuda:
+            if len(self._inflight) >= self._NREP - 1:     # (only if check_steps() was overridden away: never reuse an unread record)
+                self.check_steps(wait_all=True)
+            rec = self._report_slot(tag)
+            rec.zero_()                              # host write: the launch that last wrote this record was waited for when it was read
             ops.adam_step(m.flat, m.grad, self.adam_m, self.adam_v, self.lr, self.adam_t, self.betas[0], self.betas[1],
-                          self.eps, gscale, step_flag=flag, tag=tag)
+                          self.eps, gscale, step_flag=flag, report=rec)
+            self._report_events[tag % self._NREP].record()
             self._inflight.append(tag)
             self.check_steps()
         else:
             ops.adam_step(m.flat, m.grad, self.adam_m, self.adam_v, self.lr, self.adam_t, self.betas[0], self.betas[1],
                           self.eps, gscale)
+
+    _NREP = 16
+
+    def _report_slot(self, tag):
+        if self._reports is None:
+            self._reports = torch.zeros(self._NREP, 4, dtype=torch.int32).pin_memory()
+            self._report_events = [torch.cuda.Event() for _ in range(self._NREP)]
+        return self._reports[tag % self._NREP]
+
+    def _read_report(self, tag):
+        """(executed, skipped, nonfinite) of the optimizer launch issued under `tag`, after the event behind it."""
+        self._report_events[tag % self._NREP].synchronize()
+        r = self._reports[tag % self._NREP].tolist()
+        if not r[0]:
+            raise RuntimeError(f"optimizer launch {tag} left no report (the kernel did not run?)")
+        return bool(r[0]), bool(r[1]), bool(r[2])
 
     def check_steps(self, wait_all=False):
         """Read the reports of the optimizer steps issued at least `report_lag` steps ago (all outstanding ones with
@@ -301,7 +328,7 @@ class Trainer(ABC):
         skipped = nonfinite = False
         while self._inflight and (wait_all or self._inflight[0] <= newest - self.report_lag):
             tag = self._inflight.popleft()
-            _, skip, bad = ops.step_report(tag, wait=True)
+            _, skip, bad = self._read_report(tag)
             if skip:
                 self._lost.append(tag)
             skipped |= skip
@@ -324,7 +351,7 @@ class Trainer(ABC):
         torch.cuda.synchronize()
         while self._inflight:
             tag = self._inflight.popleft()
-            if ops.step_report(tag, wait=True)[1]:
+            if self._read_report(tag)[1]:
                 self._lost.append(tag)
         lost, self._lost = sorted(set(self._lost)), []
         n = ops.chain_status(reset=True)

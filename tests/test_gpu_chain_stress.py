@@ -201,6 +201,7 @@ def test_injected_chain_timeout_skips_adam_and_trainer_falls_back():
         # (b) the epoch loop: the fault hits batch 0 of 5; its report is read two steps later, by which time steps 1 and 2 were
         # skipped on the device as well (the flag is sticky): all three are run again on the per-step kernels
         trainer = VAETrainer(ds, model, lr=1e-4)
+        trainer.report_lag = 2                       # (the default keeps the host 12 steps ahead; a short lag shows the mid-epoch path)
         score, md = synthetic.SyntheticFolkDataset(num_notes=48, n_seq=8, seed=1).tensors()
         loader = [(torch.from_numpy(score[:4]), torch.from_numpy(md[:4]))] * 5
         trainer.dataset.n_bars = 16

@@ -210,6 +210,7 @@ def _fault_worker(rank, world, port, out_dir):
     ds.n_bars = 16
     model = MeasureVAE(ds)                  # reference defaults (H = 512): the chain kernels run
     trainer = FaultyTrainer(ds, model, lr=1e-3)
+    trainer.report_lag = 2                  # (default 12: the host stays far ahead; 2 puts the detection in the middle of this short epoch)
     dp.seed_shared(3)
     dp.seed_rank(3)
     dp.broadcast_params(model.flat)

@@ -7,4 +7,4 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-print(json.dumps(bench.arnn_extra(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20, warmup=3)))
+print(json.dumps(bench.arnn_extra(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20, warmup=3, tables=False)))

@@ -128,8 +128,47 @@ def merge(out_json, *parts):
     print(f"wrote {out_json}: {len(doc['kernels'])} kernel/grid keys")
 
 
+def busy(csv_path, traffic_json=None, seq_json=None, simds=1024, xccs=8):
+    """MFMA-busy pass (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE): per kernel|grid key (split by
+    launch order like the traffic passes) the share of SIMD-cycles in which the MFMA pipe was busy,
+        mfma_busy = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * SIMDs),
+    the clock the kernel ran at (GRBM_GUI_ACTIVE / wall time: the chip clocks to its power budget, MI355X_MICROARCH.md DVFS), and
+    SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE.  The CSV holds every counter SUMMED over its hardware instances: GRBM_GUI_ACTIVE over the 8
+    XCCs (rocprofv3's own MfmaUtil takes the max over instances), so it is divided by `xccs` here -- the first table of round 4
+    showed 17-20 "GHz" and MFMA-busy fractions 8x too small without that.  Kernels of a few tens of microseconds read too high a
+    clock (the counter window is wider than the kernel).  Printed as a table; with `traffic_json` the two fractions are merged
+    into that file's entries (bench.py quotes them next to the traffic figures)."""
+    seqs = json.load(open(seq_json)) if seq_json else None
+    cols = {}
+    for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+        cols[name] = read_counter(csv_path, name, seqs)
+    gui = cols["GRBM_GUI_ACTIVE"]
+    rows = []
+    for key, (n, gsum, us) in gui.items():
+        if n == 0 or gsum <= 0:
+            continue
+        gsum = gsum / xccs
+        mf = cols["SQ_VALU_MFMA_BUSY_CYCLES"].get(key, [0, 0.0, 0.0])[1]
+        sq = cols["SQ_BUSY_CYCLES"].get(key, [0, 0.0, 0.0])[1]
+        rows.append((us, key, n, us / n, mf / (gsum * simds), gsum / n / (us / n * 1e3), sq / gsum))
+    rows.sort(reverse=True)
+    print(f"{'kernel|grid[#label]':<78} {'calls':>6} {'avg_us':>9} {'mfma_busy':>10} {'clock_GHz':>10} {'sq_busy/gui':>12}")
+    for us, key, n, avg, mfb, ghz, sqb in rows[:40]:
+        print(f"{key:<78} {n:>6d} {avg:>9.2f} {mfb:>10.3f} {ghz:>10.2f} {sqb:>12.2f}")
+    if traffic_json:
+        doc = json.load(open(traffic_json))
+        for us, key, n, avg, mfb, ghz, sqb in rows:
+            if key in doc["kernels"]:
+                doc["kernels"][key]["mfma_busy_frac"] = round(mfb, 4)
+                doc["kernels"][key]["clock_ghz_profiled"] = round(ghz, 3)
+        doc["source"] += " ; mfma_busy_frac / clock_ghz_profiled from a pass with --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+        json.dump(doc, open(traffic_json, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "merge":
+    if sys.argv[1] == "busy":
+        busy(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None, sys.argv[4] if len(sys.argv) > 4 else None)
+    elif sys.argv[1] == "merge":
         merge(sys.argv[2], *sys.argv[3:])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], seq_json=sys.argv[3] if len(sys.argv) > 3 else None)
