@@ -718,12 +718,11 @@ def vocab_extra(num_notes=61, steps=40, warmup=8):
 
 def chain_generations_extra(wl, steps=60, warmup=10):
     """The headline step under the other forms of its products (inet_set_option keys 7: chain kernels, 8: large products):
-    everything on the f32-input MFMA (round 2's arithmetic), the chain kernels alone on the bf16 pipe, and both with the three
-    piece products below 2^-24 |ab| dropped (six instead of nine)."""
+    everything on the f32-input MFMA (round 2's arithmetic), and the chain kernels alone on the bf16 pipe."""
     from inpaintnet_amd import ops
     out = {}
     try:
-        for chain, gemm, key in ((0, 0, "f32_input_mfma"), (9, 0, "bf16_split_chains_only"), (6, 6, "bf16_split_6_products")):
+        for chain, gemm, key in ((0, 0, "f32_input_mfma"), (9, 0, "bf16_split_chains_only")):
             ops.set_option(7, chain)
             ops.set_option(8, gemm)
             for _ in range(warmup):

@@ -294,17 +294,16 @@ int inet_set_option(int key, int value);
 /* key 6 = test hook: value 1 arms ONE injected fault -- the next forward GRU chain launch loses a workgroup, its group runs
  * into the bounded spin (~0.4 s) and inet_chain_status() turns non-zero: lets the failure path (optimizer skip, fallback to
  * per-step kernels) be tested on a healthy GPU. */
-/* key 7 = generation of the GRU chain kernels: 9 (default; INET_CHAIN2) = second generation (csrc/gru_chain2.hip: one row block
- * per wave, W in LDS, the contraction on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces
- * and all nine piece products accumulated in f32 -- the products of fp32 arithmetic), 6 = the same with the three terms below
- * 2^-24 |ab| dropped, 0 = first generation (f32-input MFMA, W in registers). */
+/* key 7 = generation of the GRU FORWARD chain kernels: 9 (default; INET_CHAIN2) = second generation (csrc/gru_chain2.hip: one row
+ * block per wave, W in LDS, the contraction on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces
+ * and all nine piece products accumulated in f32 = the products of fp32 arithmetic), 0 = first generation (f32-input MFMA, W in
+ * registers).  The BPTT chains always run on the first generation. */
 /* key 8 = the encoder's large products (csrc/gemm_bf3.hip; INET_GEMM_BF3): 9 (default) = on the bf16 matrix cores through the same
- * exact three-piece split, nine piece products; 6 = six; 0 = on the f32-input kernels of csrc/gemm.hip.
- * key 9 = which bf16 pieces the chain kernels write themselves (INET_EMIT; bit 0 forward rows, 1 forward transposed, 2 backward
- * rows, 3 backward transposed; default 15) -- what they do not write, bf3_split launches make from the f32 arrays: same results.
- * key 10 = which layers' weight gradients run on the bf16 pipe (INET_BF3_WGRAD; bit 0 layer 1, bit 1 layer 0; default 1).
- * key 11 = second-generation kernel for the BPTT chains too (default 0; INET_CHAIN2_BWD=1): the faster kernel alone, the slower
- * step -- it holds the CU's LDS, which keeps the backward pass's leaf work out for the length of the chain (csrc/gru_chain.hip).
+ * exact three-piece split, nine piece products; 0 = on the f32-input kernels of csrc/gemm.hip.
+ * key 9 = which bf16 pieces the chain kernels write themselves (INET_EMIT; bit 0 the forward chains' rows, 1 their transposed pieces,
+ * 2 the BPTT kernel's dgi rows; default 7) -- what they do not write, bf3_split launches make from the f32 arrays: same results.
+ * (Round 3's keys 10 and 11 and the value 6 of keys 7 / 8 -- weight-gradient pipe per layer, second-generation BPTT kernel, six
+ * piece products -- selected builds that lost their A/Bs or were not fp32 arithmetic; they were removed in round 4: -1.)
  * key 12 = big-batch GRU forward steps on the bf16 pipe (csrc/gru_step_bf3.hip; INET_STEP_BF3_MIN_TILES): a layer whose single time
  * step has at least this many tiles of 128 rows x 64 units (default 256 = one per CU: B = 2048 at H = 512, two directions) runs one
  * product per step with the GRU cell as its epilogue instead of chunked chain launches; 0 = never.

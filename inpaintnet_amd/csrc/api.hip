@@ -433,11 +433,10 @@ int inet_set_option(int key, int value) {
     if (key == 3) { if (value < 0) return -1; gemm_set_force(-2, value); return 0; }
     if (key == 5) { if (value < 0 || value > 4) return -1; gemm_set_direct(value); return 0; }
     if (key == 6) { chain_arm_fault(value); return 0; }
-    if (key == 7) { if (value != 0 && value != 6 && value != 9) return -1; chain2_set_mode(value); return 0; }
-    if (key == 8) { if (value != 0 && value != 6 && value != 9) return -1; bf3_set_mode(value); return 0; }
-    if (key == 9) { if (value < 0 || value > 15) return -1; bf3_set_emit_mask(value); return 0; }
-    if (key == 10) { if (value < 0 || value > 3) return -1; bf3_set_wgrad_mask(value); return 0; }
-    if (key == 11) { chain2_set_bwd(value); return 0; }
+    if (key == 7) { if (value != 0 && value != 9) return -1; chain2_set_mode(value); return 0; }
+    if (key == 8) { if (value != 0 && value != 9) return -1; bf3_set_mode(value); return 0; }
+    if (key == 9) { if (value < 0 || value > 7) return -1; bf3_set_emit_mask(value); return 0; }
+    // (keys 10, 11 -- which layers' weight gradients run on the bf16 pipe; the second-generation BPTT kernel -- were removed in round 4)
     if (key == 12) { gru_step_bf3_set_min_tiles(value); return 0; }
     return -1;
 }

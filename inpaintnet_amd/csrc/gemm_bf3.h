@@ -43,6 +43,7 @@ struct Bf3Gemm {
 // shape alone, callers use the path when bf3_mode() != 0 as well
 bool gemm_bf3_ok(int M, int N, int K);
 int launch_gemm_bf3(const Bf3Gemm& g, hipStream_t s);
-// piece products per element product: 9 (all: the products of fp32 arithmetic) or 6; 0 switches the bf3 products off
+// piece products per element product: 9 (all of them: the products of fp32 arithmetic); 0 switches the bf3 products off
+// (a six-product form that dropped the three terms below 2^-24 |ab| existed in round 3: faster, not fp32 arithmetic, removed)
 int bf3_mode();
 void bf3_set_mode(int m);

@@ -238,16 +238,10 @@ int launch_cfg(const Bf3Gemm& g, int kb_per, hipStream_t s) {
             }
         }
     }
-    static bool attr_set[2] = {false, false};
-    if (bf3_mode() == 6) {
-        auto kern = &gemm_bf3_kernel<WM, WN, RM, RN, 6>;
-        if (!attr_set[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[0] = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g, tiles_m, tiles_n, kb_per, mp);
-    } else {
-        auto kern = &gemm_bf3_kernel<WM, WN, RM, RN, 9>;
-        if (!attr_set[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[1] = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g, tiles_m, tiles_n, kb_per, mp);
-    }
+    static bool attr_set = false;
+    auto kern = &gemm_bf3_kernel<WM, WN, RM, RN, 9>;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g, tiles_m, tiles_n, kb_per, mp);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -257,11 +251,11 @@ int bf3_mode() {
     if (g_mode < 0) {
         const char* v = std::getenv("INET_GEMM_BF3");
         const int m = v ? std::atoi(v) : 9;
-        g_mode = (m == 0 || m == 6) ? m : 9;
+        g_mode = m == 0 ? 0 : 9;
     }
     return g_mode;
 }
-void bf3_set_mode(int m) { g_mode = (m == 0 || m == 6) ? m : 9; }
+void bf3_set_mode(int m) { g_mode = m == 0 ? 0 : 9; }
 
 bool gemm_bf3_ok(int M, int N, int K) {
     return M > 0 && M % 192 == 0 && N > 0 && N % 128 == 0 && K >= 64 && K % 32 == 0;

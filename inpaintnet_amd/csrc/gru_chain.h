@@ -94,15 +94,12 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s);
 // which generation the two launchers above pick for a shape (second: the ChainEmit outputs are written)
 bool gru_chain_fwd_is_v2(int H, int B, int T, int nprob, int h0_packed);
 bool gru_chain_bwd_is_v2(int H, int B, int T, int nprob);
-void chain2_set_bwd(int on);                                // second-generation BPTT kernel on / off (default off)
-void chain2_bwd_layer(int layer);
 bool gru_chain_bwd_emits_rows(int H, int B, int T, int nprob);   // first-generation BPTT launch that writes ChainEmit.rows
 // Second generation (gru_chain2.hip): one row block per wave, W in LDS, contraction on the bf16 matrix cores at fp32
 // accuracy (three-way exact split, 9 or 6 piece products).  Its exchange holds three bf16 pieces per state: rings must be
 // sized 3 * pk_floats(B, K) floats (seq.h chain_ring_floats) instead of 2 * pk_floats.
-int chain2_mode();                                          // 0 = off (INET_CHAIN2=0), 6 or 9 piece products (default 9)
+int chain2_mode();                                          // 0 = off (INET_CHAIN2=0), 9 piece products (default)
 void chain2_set_mode(int np);
 bool gru_chain2_ok(int H, int B, int T, int nprob);
 bool gru_chain2_emits(int H, int B, int T, int nprob);      // ... and its build writes the ChainEmit outputs (four waves)
 int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s);
-int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s);

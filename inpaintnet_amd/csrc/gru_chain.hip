@@ -425,20 +425,11 @@ bool gru_chain_fwd_is_v2(int H, int B, int T, int nprob, int h0_packed) {
     static const bool v2f = [] { const char* v = std::getenv("INET_CHAIN2_FWD"); return !(v && v[0] == '0'); }();   // (debug switch)
     return v2f && !h0_packed && gru_chain2_ok(H, B, T, nprob);
 }
-// The BPTT chains stay on the FIRST generation by default (INET_CHAIN2_BWD=1 / inet_set_option key 11 select the second): its
-// kernel takes 28 KB of LDS and ~300 registers per lane, so the leaf work of the backward pass (weight-gradient products, column sums, the bf16-pipe products' split
-// launches) shares the CUs with it, while a second-generation workgroup holds 148-160 KB of the CU's LDS and keeps everything
-// that needs LDS out for the length of the chain.  One box, one call: 3.62 / 3.64 ms per step against 3.73 / 3.76 with the
-// second-generation BPTT kernel, which is the faster kernel alone (220 vs 232 us per 24-step launch) -- profiles/r03_t_wgrad_pipe.txt.
-static int g_chain2_bwd = -1, g_chain2_bwd_layer = 0;
-void chain2_set_bwd(int on) { g_chain2_bwd = on < 0 ? 0 : (on > 3 ? 1 : on); }
-// (experiment: values 2 / 3 select the second generation for the encoder's layer 1 / layer 0 only; bigru2_core_bwd names the layer)
-void chain2_bwd_layer(int layer) { g_chain2_bwd_layer = layer; }
-bool gru_chain_bwd_is_v2(int H, int B, int T, int nprob) {
-    if (g_chain2_bwd < 0) { const char* v = std::getenv("INET_CHAIN2_BWD"); g_chain2_bwd = v ? std::atoi(v) : 0; if (g_chain2_bwd < 0 || g_chain2_bwd > 3) g_chain2_bwd = 0; }
-    const bool on = g_chain2_bwd == 1 || (g_chain2_bwd == 2 && g_chain2_bwd_layer == 1) || (g_chain2_bwd == 3 && g_chain2_bwd_layer == 0);
-    return on && gru_chain2_ok(H, B, T, nprob);
-}
+// The BPTT chains run on the FIRST generation: its kernel takes 28 KB of LDS and ~300 registers per lane, so the leaf work of the
+// backward pass (weight-gradient products, column sums, the bf16-pipe products' split launches) shares the CUs with it.  A
+// second-generation BPTT kernel existed in round 3 (the faster kernel alone, 220 vs 232 us per 24-step launch; the slower step, 3.73
+// vs 3.62 ms: a workgroup held 148-160 KB of its CU's LDS for the length of the chain) and was removed in round 4 (HISTORY.md).
+bool gru_chain_bwd_is_v2(int, int, int, int) { return false; }
 
 int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     if (gru_chain_fwd_is_v2(a.H, a.B, a.T, a.nprob, a.h0_packed)) return launch_gru_chain2_fwd(a, s);
@@ -472,7 +463,6 @@ bool gru_chain_bwd_emits_rows(int H, int B, int T, int nprob) {
     return !gru_chain_bwd_is_v2(H, B, T, nprob) && H == 512 && gru_chain_bwd_ok(H, B, T, nprob) && rows_ms_bwd(H, B, nprob) == 4;
 }
 int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
-    if (gru_chain_bwd_is_v2(a.H, a.B, a.T, a.nprob)) return launch_gru_chain2_bwd(a, s);
     if (!gru_chain_bwd_ok(a.H, a.B, a.T, a.nprob)) return -1;
     const int ms = rows_ms_bwd(a.H, a.B, a.nprob);
     a.tiles_per_prob = (a.B + 16 * ms - 1) / (16 * ms);

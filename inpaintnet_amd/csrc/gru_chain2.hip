@@ -353,236 +353,7 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// backward:  dh_t = dgh_{t+1} W_hh + dh_{t+1} z_{t+1} + dout_t ; gate derivatives; the exchange carries dgh (K = 3H)
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int WV, int S32, int NP, bool EM>          // S32 = 3H / 32 k blocks of the exchange
-__global__ __launch_bounds__(64 * WV) void gru_chain2_bwd_kernel(GruChainBwd A) {
-    constexpr int H = 32 * S32 / 3, SH = H / 32;     // SH: k blocks per gate
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const wl = smem;                             // [3 pieces][S32][64][16 B]: W_hh^T columns j0..j0+15
-    constexpr int NTILE = EM ? 4 : 1;
-    float* const xt = reinterpret_cast<float*>(smem + 3 * S32 * 1024);   // [WV][NTILE][256]: the wave's transpose tiles
-    int group, member;
-    chain::decode_block(blockIdx.x, A.members, group, member);
-    if (group >= A.nprob * A.tiles_per_prob) return;
-    if (A.prio) __builtin_amdgcn_s_setprio(3);
-    const int prob = group / A.tiles_per_prob, tile = group % A.tiles_per_prob;
-    const GruChainBwdProb& P = A.p[prob];
-    const int B = A.B, T = A.T;
-    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int c = lane & 15, q = lane >> 4;
-    const int j0 = member * 16, jc = j0 + c;
-    const int nrb = (B + 15) >> 4;
-    const int rb = tile * WV + w;
-    // B operand = W_hh^T: fragment s: lane (unit = lane % 16, k group = lane / 16) holds W_hh[32 s + 8 (lane / 16) + i][j0 + unit]
-    for (int i = t; i < S32 * 64; i += 64 * WV) {
-        const int ln = i & 63, s = i >> 6;
-        const float* src = P.W_hh + (long)(32 * s + 8 * (ln >> 4)) * H + j0 + (ln & 15);
-        bf16x8 p0, p1, p2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            __bf16 a, b, cc;
-            split3(src[(long)j * H], a, b, cc);
-            p0[j] = a; p1[j] = b; p2[j] = cc;
-        }
-        *reinterpret_cast<bf16x8*>(wl + (0 * S32 + s) * 1024 + ln * 16) = p0;
-        *reinterpret_cast<bf16x8*>(wl + (1 * S32 + s) * 1024 + ln * 16) = p1;
-        *reinterpret_cast<bf16x8*>(wl + (2 * S32 + s) * 1024 + ln * 16) = p2;
-    }
-    __syncthreads();
-    if (rb >= nrb) return;
-    const int pb = nrb * 16 * 3 * H * 2;                       // bytes of one piece of the [B,3H] exchange
-    const int slot_bytes = 3 * pb;
-    const __amdgpu_buffer_rsrc_t rs = chain::make_rsrc(P.gx);
-    unsigned* counter = A.counters + (prob * nrb + rb) * kChainCounterStride;
-    const chain::Status status = A.status;
-    float* myxt = xt + w * 256 * NTILE;
-    const int abase = (rb * S32 * 64 + lane) * 16;
-    // gate g's 16 columns of this member: k block g * SH + member / 2
-    const int pub_off = ((rb * S32 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
-    int brow[4];
-    float dhz[4], bs[4] = {0.f, 0.f, 0.f, 0.f}, gs[4][3];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        brow[r] = min(rb * 16 + 4 * q + r, B - 1);
-        dhz[r] = 0.f;
-        gs[r][0] = gs[r][1] = gs[r][2] = 0.f;
-    }
-    const float* const zf = reinterpret_cast<const float*>(A.counters + kChainZeroWord);
-    const bool has_dout = P.dout != nullptr, has_dhn = P.dhn != nullptr;
-    const float* const doutp = has_dout ? P.dout : zf;
-    const int dout_ld = has_dout ? (int)P.ld_dout : 0, dout_ts = has_dout ? (int)P.ts_dout : 0, dout_j = has_dout ? jc : 0;
-    const float* const dhnp = has_dhn ? P.dhn : zf;
-    const int dhn_ld = has_dhn ? (int)P.ld_dhn : 0, dhn_j = has_dhn ? jc : 0;
-    const float* const svp = P.sv; const int sv_as = (int)P.sv_astride, sv_ts = P.sv_ts ? (int)P.sv_ts : B * H;
-    float* const dgip = P.dgi; const int dgi_ld = (int)P.ld_dgi, dgi_ts = (int)P.ts_dgi;
-    float* const dghp = P.dgh; const int dgh_ts = P.dgh_ts ? (int)P.dgh_ts : B * 3 * H;
-    float* const dh0p = P.dh0; const int dh0_ld = (int)P.ld_dh0; const int dh0_acc = P.dh0_accumulate;
-    const int rev = P.reverse, members = A.members;
-    // (the descriptor folded into per-lane destination pointers, as in the forward kernel)
-    const bool em_rows = EM && P.em.rows, em_colsA = EM && P.em.colsA, em_colsB = EM && P.em.colsB;
-    const long em_rows_piece = P.em.rows_piece, em_colsA_piece = P.em.colsA_piece, em_colsB_piece = P.em.colsB_piece;
-    const int em_colsA_n = P.em.colsA_n;
-    const bool em_skip_dgi = EM && P.em.skip_dgi, em_skip_dgh = EM && P.em.skip_dgh;
-    const int em_b16 = P.em.B_full >> 4, em_kbm = T * (P.em.B_full >> 5);
-    const int rbg = (P.em.r0 >> 4) + rb;
-    const int em_rows_tstride = em_b16 * P.em.rows_kb * 1024, em_cols_tstride = (em_b16 >> 1) * 1024;
-    const long em_gstep = (long)(H / 16) * em_kbm * 1024;      // from one gate's row blocks to the next in the transposed layout
-    unsigned char* const em_rows_lane = !em_rows ? nullptr :
-        P.em.rows + (((long)rbg * P.em.rows_kb + P.em.rows_kb0 + (member >> 1)) * 64 + (2 * (member & 1) + ((lane >> 4) & 1)) * 16 + (lane & 15)) * 16;
-    const int em_cl = ((2 * (rbg & 1) + (q >> 1)) * 16 + c) * 16;
-    unsigned char* const em_colsA_lane = !em_colsA ? nullptr : P.em.colsA + ((long)(P.em.colsA_rb0 + member) * em_kbm + (rbg >> 1)) * 1024 + em_cl;
-    unsigned char* const em_colsB_lane = !em_colsB ? nullptr : P.em.colsB + ((long)(P.em.colsB_rb0 + member) * em_kbm + (rbg >> 1)) * 1024 + em_cl;
-    for (int step = T - 1; step >= -1; --step) {
-        const bool tail = step < 0;                            // dh0 = dgh(first step) W_hh + dhz
-        if (tail && !dh0p) break;
-        const int tt = tail ? 0 : (rev ? T - 1 - step : step);
-        float pd[4], psv[4][5];
-        if (!tail) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = brow[r];
-                const float d1 = doutp[tt * dout_ts + b * dout_ld + dout_j];
-                const float d2 = dhnp[b * dhn_ld + dhn_j];
-                const float* sp = svp + tt * sv_ts + b * H + jc;
-#pragma unroll
-                for (int a = 0; a < 5; ++a) psv[r][a] = sp[a * sv_as];
-                pd[r] = step == T - 1 ? d1 + d2 : d1;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pd[r] = dh0_acc ? dh0p[brow[r] * dh0_ld + jc] : 0.f;
-        }
-        f32x4 acc[1];
-        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (step != T - 1) {
-            if (!wait_rows(counter, (unsigned)((T - 1 - step) * members), status, lane)) return;
-            contract2<1, S32, NP>(acc, wl, rs, abase, ((step + 1) & 1) * slot_bytes, pb, lane);
-        }
-        if (tail) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = rb * 16 + 4 * q + r;
-                if (b < B) dh0p[b * dh0_ld + jc] = acc[0][r] + dhz[r] + pd[r];
-            }
-            break;
-        }
-        float e_r[4], e_z[4], e_n[4], e_nr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float dh = acc[0][r] + dhz[r] + pd[r];
-            const float rr = psv[r][0], z = psv[r][1], n = psv[r][2], ghn = psv[r][3], hprev = psv[r][4];
-            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-            const float dz_pre = dh * (hprev - n) * z * (1.f - z);
-            const float dr_pre = dn_pre * ghn * rr * (1.f - rr);
-            const float dnr = dn_pre * rr;
-            dhz[r] = dh * z;
-            e_r[r] = dr_pre; e_z[r] = dz_pre; e_n[r] = dn_pre; e_nr[r] = dnr;
-        }
-        const bool pub = step != 0 || dh0p;                    // (nothing reads the last gate gradients unless dh0 is wanted)
-        if (EM) {
-            // One pass through the wave's four transpose tiles: the three gate gradients of the exchange (r, z, n*r) and, for
-            // the row pieces of dgi, n.  The exchange stores go first and the arrival right behind them (its vmcnt(0) then only
-            // waits for those); the piece outputs follow, re-read from the tiles (nothing is kept in registers across the arrival).
-            if (pub || em_rows) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* tp = myxt + (4 * q + r) * 16 + c;
-                    tp[0] = e_r[r]; tp[256] = e_z[r]; tp[512] = e_nr[r];
-                }
-                __builtin_amdgcn_wave_barrier();               // (the tiles are exchanged between lanes: see below)
-                const float* src = myxt + (lane & 15) * 16 + 8 * (lane >> 4);
-                if (pub) {
-                    if (lane < 32) {
-                        const int off = (step & 1) * slot_bytes + pub_off;
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) publish8(rs, off + g * SH * 1024, pb, src + g * 256);
-                    }
-                    arrive_rows(counter, lane);
-                }
-                if (em_rows) {                                 // (behind the hand-off: the fourth tile, n, and the row pieces of dgi)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) myxt[768 + (4 * q + r) * 16 + c] = e_n[r];
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 32) {
-                        unsigned char* dst = em_rows_lane + (long)tt * em_rows_tstride;
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {          // dgi: r, z, n (tile 3)
-                            bf16x8 p0, p1, p2;
-                            pieces8(src + (g == 2 ? 768 : g * 256), p0, p1, p2);
-                            store_pieces(dst + g * SH * 1024, em_rows_piece, p0, p1, p2);
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else if (pub) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {                      // gate by gate through the wave's transpose tile
-#pragma unroll
-                for (int r = 0; r < 4; ++r) myxt[(4 * q + r) * 16 + c] = g == 0 ? e_r[r] : (g == 1 ? e_z[r] : e_nr[r]);
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 32)
-                    publish8(rs, (step & 1) * slot_bytes + pub_off + g * SH * 1024, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
-                // The tile is exchanged BETWEEN lanes: lanes 32..63 must not run ahead into the next gate's writes while
-                // lanes 0..31 still have this gate's reads in front of them.  The compiler reasons per thread and did exactly
-                // that (it hoisted the next tile's writes of the upper half-wave over the branch); the convergent wave barrier
-                // pins the order for the whole wave (the LDS itself executes one wave's operations in issue order).
-                __builtin_amdgcn_wave_barrier();
-            }
-            arrive_rows(counter, lane);
-        }
-        if (em_colsA) {
-            unsigned char* fa = em_colsA_lane + (long)tt * em_cols_tstride;
-            emit_cols(fa, em_colsA_piece, e_r, q);
-            emit_cols(fa + em_gstep, em_colsA_piece, e_z, q);
-            if (em_colsA_n) emit_cols(fa + 2 * em_gstep, em_colsA_piece, e_n, q);
-        }
-        if (em_colsB) emit_cols(em_colsB_lane + (long)tt * em_cols_tstride, em_colsB_piece, e_nr, q);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = rb * 16 + 4 * q + r;
-            if (b < B) {
-                if (!em_skip_dgi) {
-                    float* gi = dgip + tt * dgi_ts + b * dgi_ld;
-                    gi[jc] = e_r[r]; gi[H + jc] = e_z[r]; gi[2 * H + jc] = e_n[r];
-                }
-                if (!em_skip_dgh) {
-                    float* gh = dghp + tt * dgh_ts + b * 3 * H;
-                    gh[jc] = e_r[r]; gh[H + jc] = e_z[r]; gh[2 * H + jc] = e_nr[r];
-                }
-                bs[0] += e_r[r]; bs[1] += e_z[r]; bs[2] += e_n[r]; bs[3] += e_nr[r];
-                gs[r][0] += e_r[r]; gs[r][1] += e_z[r]; gs[r][2] += e_n[r];
-            }
-        }
-    }
-    if (P.dgi_sum) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = rb * 16 + 4 * q + r;
-            if (b < B) {
-                float* o = P.dgi_sum + (long)b * 3 * H + jc;
-                o[0] = gs[r][0]; o[H] = gs[r][1]; o[2 * H] = gs[r][2];
-            }
-        }
-    }
-    if (P.db_ih) {                                             // column sums of this wave's 16 rows: over the four row groups
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            bs[a] += __shfl_xor(bs[a], 16, 64);
-            bs[a] += __shfl_xor(bs[a], 32, 64);
-        }
-        if (lane < 16) {
-            unsafeAtomicAdd(P.db_ih + jc, bs[0]); unsafeAtomicAdd(P.db_hh + jc, bs[0]);
-            unsafeAtomicAdd(P.db_ih + H + jc, bs[1]); unsafeAtomicAdd(P.db_hh + H + jc, bs[1]);
-            unsafeAtomicAdd(P.db_ih + 2 * H + jc, bs[2]);
-            unsafeAtomicAdd(P.db_hh + 2 * H + jc, bs[3]);
-        }
-    }
-}
-
-int g_chain2 = -1;   // piece products per fp32 product: 0 = first-generation kernels, 6 or 9
+int g_chain2 = -1;   // piece products per fp32 product: 0 = first-generation kernels, 9 = second generation
 
 }  // namespace
 
@@ -590,11 +361,11 @@ int chain2_mode() {
     if (g_chain2 < 0) {
         const char* e = std::getenv("INET_CHAIN2");
         const int v = e ? std::atoi(e) : 9;
-        g_chain2 = (v == 6 || v == 9) ? v : 0;
+        g_chain2 = v == 9 ? 9 : 0;                           // (round 4: the six-product builds are gone; anything else = first generation)
     }
     return g_chain2;
 }
-void chain2_set_mode(int np) { g_chain2 = (np == 6 || np == 9) ? np : 0; }
+void chain2_set_mode(int np) { g_chain2 = np == 9 ? 9 : 0; }
 
 // waves per workgroup (4 or 8) with which the launch fits the chip and the sync area, or 0
 static int chain2_waves(int H, int B, int T, int nprob) {
@@ -604,14 +375,10 @@ static int chain2_waves(int H, int B, int T, int nprob) {
     if ((double)T * B * 6.0 * H >= 2.0e9) return 0;
     const int nrb = (B + 15) / 16;
     if (nprob * nrb > kChainMaxGroups) return 0;               // one counter per (problem, row block)
-    // Four waves per workgroup (one per SIMD).  Eight -- two row blocks per SIMD -- fit the decoder's four-beat tick BPTT into
-    // one launch, but two waves of a SIMD do not overlap (tools/exp_chain3.hip WAVES_=8) and that launch measured 128 us against
-    // 127 for the first generation's two-tiles-per-workgroup form: INET_CHAIN2_W8=1 enables it, the default leaves those shapes
-    // to the first generation.
-    static const bool w8 = [] { const char* v = std::getenv("INET_CHAIN2_W8"); return v && v[0] == '1'; }();
-    for (int wv = 4; wv <= (w8 ? 8 : 4); wv *= 2)
-        if (nprob * ((nrb + wv - 1) / wv) * (H / 16) <= chain_capacity()) return wv;
-    return 0;
+    // Four waves per workgroup (one per SIMD).  (Eight -- two row blocks per SIMD -- fit the decoder's four-beat tick BPTT into one
+    // launch, but two waves of a SIMD do not overlap: 128 us against 127 for the first generation's two-tiles-per-workgroup form;
+    // that build was removed in round 4, those shapes stay on the first generation.)
+    return nprob * ((nrb + 3) / 4) * (H / 16) <= chain_capacity() ? 4 : 0;
 }
 bool gru_chain2_ok(int H, int B, int T, int nprob) { return chain2_waves(H, B, T, nprob) > 0; }
 bool gru_chain2_emits(int H, int B, int T, int nprob) { return chain2_waves(H, B, T, nprob) == 4; }
@@ -653,71 +420,13 @@ int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
     } while (0)
 #define INET_C2F(W, S, N)                                                                                               \
     do {                                                                                                                \
-        if (em && W == 4) INET_C2F_(4, S, N, true);                                                                     \
-        else INET_C2F_(W, S, N, false);                                                                                 \
+        if (em) INET_C2F_(4, S, N, true);                                                                               \
+        else INET_C2F_(4, S, N, false);                                                                                 \
     } while (0)
-    if (a.H == 512) {
-        if (wv == 4) { if (np == 9) INET_C2F(4, 16, 9); else INET_C2F(4, 16, 6); }
-        else { if (np == 9) INET_C2F(8, 16, 9); else INET_C2F(8, 16, 6); }
-    } else {
-        if (wv == 4) { if (np == 9) INET_C2F(4, 8, 9); else INET_C2F(4, 8, 6); }
-        else { if (np == 9) INET_C2F(8, 8, 9); else INET_C2F(8, 8, 6); }
-    }
+    if (np != 9 || wv != 4) return -1;
+    if (a.H == 512) INET_C2F(4, 16, 9);
+    else INET_C2F(4, 8, 9);
 #undef INET_C2F
 #undef INET_C2F_
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
-int launch_gru_chain2_bwd(GruChainBwd a, hipStream_t s) {
-    const int wv = chain2_waves(a.H, a.B, a.T, a.nprob);
-    if (!wv) return -1;
-    const int nrb = (a.B + 15) / 16;
-    a.tiles_per_prob = (nrb + wv - 1) / wv;
-    a.members = a.H / 16;
-    const int groups = a.nprob * a.tiles_per_prob;
-    a.prio = 1;
-    if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kChainSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
-    a.status = chain_status_for(a.counters + kChainStatusWord);
-    const int np = chain2_mode();
-    const double rows = (double)a.nprob * a.T * a.B;
-    bool em = false;
-    for (int i = 0; i < a.nprob; ++i) em = em || a.p[i].em.rows || a.p[i].em.colsA || a.p[i].em.colsB;
-    if (wv != 4) { em = false; for (int i = 0; i < a.nprob; ++i) a.p[i].em = ChainEmit{}; }
-    char label[72];
-    std::snprintf(label, sizeof label, "gru_chain_bwd v2w%d%s p%d np%d T%d B%d H%d", wv, em ? "e" : "", np, a.nprob, a.T, a.B, a.H);
-    double em_bytes = 0.0;                                     // piece outputs (6 bytes per element and layout) minus the f32 arrays not written
-    for (int i = 0; i < a.nprob; ++i) {
-        const ChainEmit& e = a.p[i].em;
-        em_bytes += (double)a.T * a.B * a.H * (6.0 * ((e.rows ? 3 : 0) + (e.colsA ? (e.colsA_n ? 3 : 2) : 0) + (e.colsB ? 1 : 0)) -
-                                               4.0 * ((e.skip_dgi ? 3 : 0) + (e.skip_dgh ? 3 : 0)));
-    }
-    ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
-                   4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)) + em_bytes);
-    const dim3 grid(chain::blocks_for(groups, a.members));
-    const size_t lds = (size_t)3 * (3 * a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (em ? 4 : 1);
-#define INET_C2B_(W, S, N, E)                                                                                           \
-    do {                                                                                                                \
-        static bool attr = false;                                                                                       \
-        if (!attr) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_chain2_bwd_kernel<W, S, N, E>),                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
-            attr = true;                                                                                                \
-        }                                                                                                               \
-        hipLaunchKernelGGL((gru_chain2_bwd_kernel<W, S, N, E>), grid, dim3(64 * W), lds, s, a);                         \
-    } while (0)
-#define INET_C2B(W, S, N)                                                                                               \
-    do {                                                                                                                \
-        if (em && W == 4) INET_C2B_(4, S, N, true);                                                                     \
-        else INET_C2B_(W, S, N, false);                                                                                 \
-    } while (0)
-    if (a.H == 512) {
-        if (wv == 4) { if (np == 9) INET_C2B(4, 48, 9); else INET_C2B(4, 48, 6); }
-        else { if (np == 9) INET_C2B(8, 48, 9); else INET_C2B(8, 48, 6); }
-    } else {
-        if (wv == 4) { if (np == 9) INET_C2B(4, 24, 9); else INET_C2B(4, 24, 6); }
-        else { if (np == 9) INET_C2B(8, 24, 9); else INET_C2B(8, 24, 6); }
-    }
-#undef INET_C2B
-#undef INET_C2B_
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

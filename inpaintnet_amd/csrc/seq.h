@@ -86,8 +86,6 @@ int chain_chunk_rows_bwd(int H, int B, int T, int nd);
 // rows in multiples of 32): the same decision the layer functions make, for callers that must know it in another library call
 bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save);
 void bf3_set_emit_mask(int m);      // which piece outputs the chain kernels write themselves (INET_EMIT)
-void bf3_set_wgrad_mask(int m);     // which layers' weight gradients run on the bf16 pipe (INET_BF3_WGRAD)
-bool gru_layer_bwd_emits(int H, int B, int T, int nd);
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
 int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_hi, int step_lo, hipStream_t s);

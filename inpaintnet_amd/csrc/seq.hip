@@ -31,34 +31,18 @@ int chain_chunk_rows_bwd(int H, int B, int T, int nd) {
     return 0;
 }
 
-// which piece outputs the chains write themselves (bit 0: forward rows, 1: forward transposed, 2: backward rows, 3: backward
-// transposed); what they do not write is split from the f32 arrays by bf3_split launches (the transposed ones on the side stream)
-static int g_emit_mask = -1, g_wgrad_mask = -1;
+// which piece outputs the chains write themselves (bit 0: the forward chains' rows, 1: their transposed pieces, 2: the first-generation
+// BPTT kernel's dgi rows); what they do not write is split from the f32 arrays by bf3_split launches (the transposed ones on the
+// side stream).  inet_set_option key 9 / INET_EMIT: the tests run the same step both ways.
+static int g_emit_mask = -1;
 static int emit_mask() {
-    if (g_emit_mask < 0) { const char* v = std::getenv("INET_EMIT"); g_emit_mask = v ? std::atoi(v) & 15 : 15; }
+    if (g_emit_mask < 0) { const char* v = std::getenv("INET_EMIT"); g_emit_mask = v ? std::atoi(v) & 7 : 7; }
     return g_emit_mask;
 }
-void bf3_set_emit_mask(int m) { g_emit_mask = m & 15; }     // inet_set_option key 9 (tests: the same step with and without emission)
-
-// which layers' weight gradients run on the bf16 pipe (bit 0: layer 1, bit 1: layer 0): the others stay on the LDS-free
-// f32-input kernels.  Measured in one call (profiles/r03_t_wgrad_pipe.txt): 3.75 / 3.72 / 3.85 / 3.82 ms per step for both /
-// layer 1 only / layer 0 only / neither -- layer 0's product is the last kernel of the backward pass, and what its bf16 form
-// saves (172 -> 118 us) the layer-0 chains pay for writing its operands (the transposed gate gradients and previous states).
-static int wgrad_mask() {
-    if (g_wgrad_mask < 0) { const char* v = std::getenv("INET_BF3_WGRAD"); g_wgrad_mask = v ? std::atoi(v) & 3 : 1; }
-    return g_wgrad_mask;
-}
-void bf3_set_wgrad_mask(int m) { g_wgrad_mask = m & 3; }    // inet_set_option key 10
-
-// Where layer 1's bf16-pipe weight gradients run: 0 = on a side stream (beside the data gradient and the layer-0 BPTT chain;
-// default), 1 = on the caller's stream between the data gradient and the layer-0 chain.  gemm_bf3 workgroups (120-144 KB of LDS)
-// and second-generation chain workgroups (148-160 KB) cannot share a CU, and in the kernel TRACE the two collide badly (the 203 us
-// product 808 us, the 265 us chain 616 us: profiles/r03_s_timeline_full_step.txt) -- untraced, the side stream is the faster
-// place all the same: 3.61 / 3.62 ms per step against 3.70 / 3.69 on the caller's stream (profiles/r03_t_wgrad_pipe.txt).
-static int wgrad_at() {
-    static const int m = [] { const char* v = std::getenv("INET_BF3_WGRAD_AT"); return v ? std::atoi(v) : 0; }();
-    return m;
-}
+void bf3_set_emit_mask(int m) { g_emit_mask = m & 7; }
+// Layer 1's weight gradients run on the bf16 pipe, on a side stream; layer 0's stay on the LDS-free f32-input kernel: its product is
+// the last kernel of the backward pass, and what the bf16 form saves (172 -> 118 us) is spent on making its operands (one-box A/Bs
+// of round 3: 3.75 / 3.72 / 3.85 / 3.82 ms per step for both / layer 1 only / layer 0 only / neither; HISTORY.md).
 
 bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save) {
     if (!pk_ok(H) || B % 32) return false;
@@ -67,12 +51,6 @@ bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save) {
     const int CH = chain_chunk_rows(H, B, T, nd, save);
     return CH > 0 && CH < B && CH % 32 == 0 && gru_chain_fwd_is_v2(H, CH, T, nd, 0) && gru_chain2_emits(H, CH, T, nd);
 }
-bool gru_layer_bwd_emits(int H, int B, int T, int nd) {
-    if (!pk_ok(H) || B % 32) return false;
-    const int CHB = chain_chunk_rows_bwd(H, B, T, nd);
-    return CHB > 0 && CHB % 32 == 0 && gru_chain_bwd_is_v2(H, CHB, T, nd) && gru_chain2_emits(H, CHB, T, nd);
-}
-
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     for (int i = 0; i < nd; ++i) d[i].emitted = 0;
     const long BH = (long)B * H;
@@ -458,8 +436,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
             D.em.rows = w.x1pk; D.em.rows_piece = (long)bf3_piece_bytes(TBl, 2 * H); D.em.rows_kb = 2 * H / 32; D.em.rows_kb0 = dir * H / 32;
         }
         if (bf3f && save && w.x1T && w.hpT[dir] && (emit_mask() & 2)) {   // the weight gradients' B operands (read by the backward call)
-            if (wgrad_mask() & 1) { D.em.colsA = w.x1T; D.em.colsA_piece = (long)bf3_piece_bytes(2 * H, TBl); D.em.colsA_rb0 = dir * H / 16; }
-            if (wgrad_mask() & 2) { D.em.colsB = w.hpT[dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0; }
+            D.em.colsA = w.x1T; D.em.colsA_piece = (long)bf3_piece_bytes(2 * H, TBl); D.em.colsA_rb0 = dir * H / 16;   // (layer 1's dW_ih)
         }
     }
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
@@ -496,7 +473,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
         D.reverse = dir;
         D.Wpk_hh = w.wpk[2 + dir]; D.hpk = w.hpk[2 + dir]; D.wp3 = w.wp3[2 + dir];
         D.sync = one_launch ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = one_launch;
-        if (bf3f && save && w.hpT[2 + dir] && (emit_mask() & 2) && (wgrad_mask() & 1)) {
+        if (bf3f && save && w.hpT[2 + dir] && (emit_mask() & 2)) {
             D.em.colsB = w.hpT[2 + dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, TBl); D.em.colsB_rb0 = 0;
         }
     }
@@ -574,12 +551,6 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
             D.em.rows = w.dgi1pk; D.em.rows_piece = (long)bf3_piece_bytes((long)T * B, 6 * H); D.em.rows_kb = 6 * H / 32;
             D.em.rows_kb0 = dir * 3 * H / 32;
         }
-        if (bf3w_pre && (emit_mask() & 8) && (wgrad_mask() & 1)) {
-            D.em.colsA = w.gT[1]; D.em.colsA_piece = (long)bf3_piece_bytes(6 * H, (long)T * B); D.em.colsA_rb0 = dir * 3 * H / 16; D.em.colsA_n = 1;
-            D.em.colsB = w.nrT[2 + dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, (long)T * B); D.em.colsB_rb0 = 0;
-            D.em.skip_dgh = 1;                                 // (its only reader was the weight-gradient product)
-            D.em.skip_dgi = D.em.rows != nullptr;              // (data gradient and weight gradient both read pieces)
-        }
     }
     // The chains can hand their weight-gradient products to the side stream a chunk of steps at a time (CH < T) instead
     // of a layer's whole K = T*B product at the end of its chain.  Measured at B=256 with 2, 3, 4 chunks per layer:
@@ -587,7 +558,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     // chip busy, and smaller-K products are less efficient -- so one chunk.
     const int CH = T;
     const float* x1 = mask ? w.x1m : w.x1raw;
-    bool l1_gem = false, l1_wgrads_pending = false;
+    const bool l1_gem = false;                                 // (the gate gradients' transposed pieces always come from split launches)
     // layer 1's weight gradients on the bf16 pipe: dW_hh (both directions), then dW_ih_d [3H, 2H] += dgi1_d^T x1 on the transposed
     // gate gradients just made
     auto l1_wgrads_bf3 = [&](hipStream_t ss) -> int {
@@ -607,15 +578,11 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
     const bool bf3w = bf3_mode() != 0 && w.gT[0] && w.hpT[0] && wg;
     for (int hi = T - 1; hi >= 0 && stage != 2; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0, nt = hi - lo + 1;
-        chain2_bwd_layer(1);
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
-        chain2_bwd_layer(0);
         if (wg) {
             hipStream_t ss = side_fork(s);                   // leaf work: overlaps the rest of the BPTT chains
-            if (nt == T && bf3w && (wgrad_mask() & 1)) {      // both directions of a product in one launch (gemm_bf3.hip)
-                l1_gem = (d[0].emitted & 2) && (d[1].emitted & 2) && (emit_mask() & 8);
-                if (wgrad_at() == 0) INET_TRY(l1_wgrads_bf3(ss));
-                else l1_wgrads_pending = true;               // (on the main stream, behind the data gradient: see wgrad_at)
+            if (nt == T && bf3w) {                            // both directions of a product in one launch (gemm_bf3.hip)
+                INET_TRY(l1_wgrads_bf3(ss));
             } else if (nt == T) {                            // both directions of a product in one launch
                 INET_TRY(linear_wgrad2(w.dgh[2], w.dgh[3], 3L * H, w.sv[2] + 4 * TBH, w.sv[3] + 4 * TBH, H, P[2].dw_hh,
                                        P[3].dw_hh, H, T * B, 3 * H, H, ss));
@@ -652,7 +619,6 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         INET_TRY(linear_dgrad(dgi, 6L * H, P[2 + dir].w_ih, 2L * H, w.dx1, 2L * H, T * B, 3 * H, 2 * H,
                               mask ? EPI_MUL_AUX : EPI_NONE, mask, 2L * H, dir == 0 ? ACC_STORE : ACC_ADD, s));
     }
-    if (l1_wgrads_pending) INET_TRY(l1_wgrads_bf3(s));
     if (stage == 1) return 0;
     // ---- layer 0 ----
     for (int dir = 0; dir < 2; ++dir) {
@@ -670,20 +636,13 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[dir]; D.dghpk = w.dghpk[dir];
         D.W_hh = P[dir].w_hh; D.sync = chained ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = chained;
-        if (bf3w_pre && (emit_mask() & 8) && (wgrad_mask() & 2)) {
-            D.em.colsA = w.gT[0]; D.em.colsA_piece = (long)bf3_piece_bytes(6 * H, (long)T * B); D.em.colsA_rb0 = dir * 3 * H / 16; D.em.colsA_n = 0;
-            D.em.colsB = w.nrT[dir]; D.em.colsB_piece = (long)bf3_piece_bytes(H, (long)T * B); D.em.colsB_rb0 = 0;
-            D.em.skip_dgh = 1;                                 // (dgi0 still feeds the embedding / table gradients)
-        }
     }
     for (int hi = T - 1; hi >= 0; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0;
         INET_TRY(gru_layer_bwd_range(H, B, T, 2, d, hi, lo, s));
         if (wg) {
             hipStream_t ss = side_fork(s);
-            if (hi - lo + 1 == T && bf3w && (wgrad_mask() & 2))
-                INET_TRY(bigru2_wgrad_hh_bf3(B, T, H, 0, P, w, w.dgi0, false, (d[0].emitted & 2) && (d[1].emitted & 2) && (emit_mask() & 8), fwd_emitted, ss));
-            else if (hi - lo + 1 == T)
+            if (hi - lo + 1 == T)
                 INET_TRY(linear_wgrad2(w.dgh[0], w.dgh[1], 3L * H, w.sv[0] + 4 * TBH, w.sv[1] + 4 * TBH, H, P[0].dw_hh,
                                        P[1].dw_hh, H, T * B, 3 * H, H, ss));
             else

@@ -110,11 +110,11 @@ def test_gemm_bf3_layouts(akm, bkm, M, N, K, ksplit):
     ref = A.double() @ B.double().t()
     Ad = (A.t().contiguous() if akm else A).to(DEV)
     Bd = (B.t().contiguous() if bkm else B).to(DEV)
-    for mode in (9, 6):
+    for mode in (9,):                                          # (round 3 also had a six-product form: removed)
         ops.set_option(8, mode)
         try:
             C = ops.gemm_bf3(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, ksplit=ksplit)
-            assert relmax(C, ref) < (2e-6 if mode == 9 else 4e-6), mode
+            assert relmax(C, ref) < 2e-6, mode
             Cb = ops.gemm_bf3(Ad, Bd, M, N, K, a_kmajor=akm, b_kmajor=bkm, bias=bias.to(DEV), ksplit=ksplit)
             assert relmax(Cb, ref + bias.double()) < 4e-6
             C0 = torch.randn(M, N, generator=g)
@@ -770,11 +770,11 @@ def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
 
 
 def test_chain_generations_against_float64():
-    """The three forms of the recurrent contraction against a float64 evaluation of the same two-layer bi-GRU (forward and
-    backward, 12 steps, H = 512): first generation (f32-input MFMA), second generation with all nine bf16 piece products (the
-    products of fp32 arithmetic; only the f32 summation order differs) and with six (terms below 2^-24 |ab| dropped).  The
-    second generation must be as close to float64 as the first: its error may not exceed twice the first's (nine products) /
-    four times (six), on every output."""
+    """The two forms of the recurrent contraction against a float64 evaluation of the same two-layer bi-GRU (forward and
+    backward, 12 steps, H = 512): first generation (f32-input MFMA) and second generation with all nine bf16 piece products (the
+    products of fp32 arithmetic; only the f32 summation order differs).  The second generation must be as close to float64 as
+    the first: its error may not exceed twice the first's, on every output.  (Round 3 also shipped a six-product form that
+    dropped the terms below 2^-24 |ab|; it measured the same error here and was removed with the other non-default builds.)"""
     import csv
     import tempfile
     from inpaintnet_amd import layout
@@ -799,9 +799,8 @@ def test_chain_generations_against_float64():
         ref["d" + k] = P64[k].grad
     errs = {}
     try:
-        for mode in (0, 9, 6):
+        for mode in (0, 9):
             ops.set_option(7, mode)
-            ops.set_option(11, 1 if mode else 0)                  # (the BPTT chains of the second generation too: off by default)
             ops.prof_enable(True)
             o, h, ws = ops.bigru2_fwd(x.to(DEV), None, flat, H, B, T, K, save=True)
             grads = torch.zeros_like(flat)
@@ -812,9 +811,10 @@ def test_chain_generations_against_float64():
                 ops.prof_dump(td + "/l.csv")
                 labels = [r["label"] for r in csv.DictReader(open(td + "/l.csv"))]
             ops.prof_enable(False)
-            for kind in ("fwd", "bwd"):
-                tags = (f"gru_chain_{kind} ms",) if mode == 0 else (f"gru_chain_{kind} v2w4 p{mode}", f"gru_chain_{kind} v2w4e p{mode}")   # (e: writes piece outputs)
-                assert any(l.startswith(tags) for l in labels), (mode, kind, sorted(set(l for l in labels if l.startswith("gru"))))
+            # (the BPTT chains always run on the first generation; "e": the build that writes piece outputs)
+            ftags = ("gru_chain_fwd ms",) if mode == 0 else (f"gru_chain_fwd v2w4 p{mode}", f"gru_chain_fwd v2w4e p{mode}")
+            assert any(l.startswith(ftags) for l in labels) and any(l.startswith("gru_chain_bwd ms") for l in labels), \
+                (mode, sorted(set(l for l in labels if l.startswith("gru"))))
             got = {"out": o.cpu(), "hn": h.cpu(), "dx": dx.cpu()}
             for k, (off, sh) in offs.items():
                 got["d" + k] = grads[off:off + P[k].numel()].reshape(sh).cpu()
@@ -822,15 +822,13 @@ def test_chain_generations_against_float64():
     finally:
         ops.prof_enable(False)
         ops.set_option(7, 9)
-        ops.set_option(11, 0)
     assert ops.chain_status() == 0
     worst = {m: max(e.values()) for m, e in errs.items()}
     print("max error vs float64 (relative to each tensor's max):", {m: f"{v:.2e}" for m, v in worst.items()})
     for k in ref:
         floor = 3e-7                                               # (a few f32 ulp: both generations sit at this level)
         assert errs[9][k] <= 2.0 * errs[0][k] + floor, (k, errs[0][k], errs[9][k])
-        assert errs[6][k] <= 4.0 * errs[0][k] + floor, (k, errs[0][k], errs[6][k])
-        assert errs[0][k] < 2e-5 and errs[9][k] < 2e-5 and errs[6][k] < 2e-5, k
+        assert errs[0][k] < 2e-5 and errs[9][k] < 2e-5, k
 
 
 # ------------------------------------------------------------------------------- multinomial sampling (decoder.py:506-509)
