@@ -50,7 +50,7 @@ PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E (6.3 TB/s 
 NUM_NOTES = 48
 VAE_BATCH_PER_GPU = 256
 LATENT_SEQ_PER_GPU = 128
-PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -204,6 +204,11 @@ def parity_check(model, tokens_dev):
         worst[f"token_mismatch_{tag}"] = int((s.cpu()[:, 0][ok] != sr[:, 0][ok]).sum())
         worst[f"token_rows_compared_{tag}"] = int(ok.sum())
         worst[f"token_rows_compared_frac_{tag}"] = float(ok.float().mean())
+        # (on these weights -- synthetic initial values plus a few hundred optimizer steps -- most rows have NO positive logit: every
+        #  post-ReLU logit is 0 and the token is the tie-break index 0 in both implementations; such rows cannot be told apart from
+        #  a row whose best pre-activation sits within rounding of 0, so they are not counted as compared.  With trained-looking
+        #  logits the tests compare 99.9 % of the rows: tests/test_gpu_bench_sizes.py)
+        worst[f"token_rows_all_zero_{tag}"] = int((top2[..., 0] <= 0).sum())
     passed = all(worst[f"loss_{t}"] <= 1e-4 and worst[f"logits_{t}"] <= 1e-4 and worst[f"grads_{t}"] <= 5e-4 and
                  worst[f"token_mismatch_{t}"] == 0 and worst[f"kink_violations_{t}"] == 0 and
                  worst[f"kink_flips_{t}"] <= 8 + 1e-5 * worst[f"kink_elements_{t}"] for t in ("tf", "fr"))

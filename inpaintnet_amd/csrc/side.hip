@@ -94,10 +94,26 @@ int side_join_now(hipStream_t main_stream) {
     return 0;
 }
 
+// (`other` may be a stream whose kernels talk to OTHER devices -- the data-parallel exchange's all-reduce stream --, so these
+//  events keep the default system-scope fence; the pool's no-fence events only ever order streams of one device's own work)
+namespace {
+std::vector<hipEvent_t> g_fenced;
+size_t g_fenced_next = 0;
+hipEvent_t next_fenced_event() {
+    if (g_fenced.empty()) {
+        g_fenced.resize(16);
+        for (auto& e : g_fenced)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    }
+    hipEvent_t e = g_fenced[g_fenced_next];
+    g_fenced_next = (g_fenced_next + 1) % g_fenced.size();
+    return e;
+}
+}  // namespace
 int side_wait_on(hipStream_t other) {
     for (int i = 0; i < g_nside; ++i) {
         if (!g_dirty[i]) continue;
-        hipEvent_t e = next_event();
+        hipEvent_t e = next_fenced_event();
         if (!e || hipEventRecord(e, g_sides[i]) != hipSuccess || hipStreamWaitEvent(other, e, 0) != hipSuccess) return -2;
     }
     return 0;

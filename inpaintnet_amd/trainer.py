@@ -64,7 +64,10 @@ class _ElboFn(torch.autograd.Function):
                              add_term=kl_sum.reshape(1), add_scale=kscale)
         ctx.save_for_backward(weights2d, targets1d)
         ctx.kscale = kscale
-        loss, acc = out2[0], out2[1]
+        # (out2 is a slice of the gradient arena's tail, zeroed by the next zero_grad(): the caller gets its own two floats -- the
+        #  reference returns independent tensors, and a training script may keep them across steps)
+        res = out2.clone()
+        loss, acc = res[0], res[1]
         ctx.mark_non_differentiable(acc)
         return loss, acc
 
