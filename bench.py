@@ -772,14 +772,7 @@ def arnn_extra(batch=32, steps=30, warmup=4, tables=True):
         loss, acc = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, data[0][:, :, free].transpose(0, 1))
         loss.backward()
         trainer.step()
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, _ = timed(step, steps, warmup, torch.cuda.synchronize)
     return {"anticipation_rnn_train": {"sequences_per_s": round(batch * steps / dt, 1),
                                        "measures_per_s": round(16 * batch * steps / dt, 1),
                                        "ms_per_step": round(1e3 * dt / steps, 3),
@@ -942,7 +935,13 @@ def main():
                 del la
                 wl.model.trainable = True                      # (LatentRNN froze the shared VAE)
                 wl.model.train()
+            # (the latency-bound workloads first: the AnticipationRNN step -- 1,536 dependent hand-offs -- measures 7.6 ms here and
+            #  9.6 ms at the end of the extras, after minutes of sustained load on the chip: tools/gc_ab.py, profiles/r04_a_arnn_ab.txt)
+            extras.update(arnn_extra())
+            vae = wl.model if args.workload == "vae" else wl.model.vae_model
+            extras.update(decode_latency_extra(vae))
             if args.workload == "vae":
+                wl.model.train()
                 extras.update(epoch_loop_extra(wl))
                 for fn, key in ((lambda: chain_generations_extra(wl), "chain_generations"),
                                 (lambda: vae4096_extra(wl), "vae_train_4096"), (vocab_extra, "vae_train_v61")):
@@ -950,9 +949,6 @@ def main():
                         extras.update(fn())
                     except Exception as e:                   # a secondary number must never take the headline down
                         extras[key] = {"error": repr(e)}
-            extras.update(arnn_extra())
-            vae = wl.model if args.workload == "vae" else wl.model.vae_model
-            extras.update(decode_latency_extra(vae))
 
     if rank == 0:
         out = {
