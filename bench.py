@@ -420,7 +420,7 @@ def piece_products(label):
     """bf16 piece products per f32 product of a kernel label (csrc/gemm_bf3.hip 'bf3p9', csrc/gru_chain2.hip 'v2w4 p9'), 0 for
     the f32-input MFMA kernels."""
     import re
-    m = re.search(r"\bbf3p(\d)\b", label) or re.search(r" v2w\d+e? p(\d) ", label) or re.search(r"^gru_step_bf3 p(\d) ", label)
+    m = re.search(r"\bbf3p(\d)\b", label) or re.search(r" v2w\d+e? p(\d) ", label) or re.search(r"^gru_step_bf3(?:_bwd)? p(\d) ", label)
     return int(m.group(1)) if m else 0
 
 

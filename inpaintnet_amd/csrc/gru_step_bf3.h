@@ -19,3 +19,16 @@ size_t gru_step_bf3_w_bytes(int H);
 int gru_step_bf3_split_w(int H, const float* W_hh, unsigned char* Wp, hipStream_t s);
 // all T steps (T launches on `s`); writes ChainEmit.rows if given (nothing else of the descriptor's `em`)
 int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s);
+
+// Backward steps of the same layers (gru_step_bf3_bwd_kernel): descriptor = the chain kernels' BPTT descriptor (`gx` = the two-slot
+// ring of three-piece gate gradients, chain_ring_floats(B, 3H) floats) + the pieces of W_hh^T + the [2][B][H] dh z buffer per
+// direction.  Writes dgi, dgh, the bias gradients (column sums after the last step), dh0 if asked, ChainEmit.rows if given.
+struct GruStepsBf3Bwd {
+    int H, B, T, nprob;
+    GruChainBwdProb p[2];
+    const unsigned char* WpT[2];         // gru_step_bf3_split_wT() of W_hh: gru_step_bf3_w_bytes(H) bytes each
+    float* dhz[2];
+};
+bool gru_step_bf3_bwd_ok(int H, int B, int T, int nd);
+int gru_step_bf3_split_wT(int H, const float* W_hh, unsigned char* WpT, hipStream_t s);
+int launch_gru_steps_bf3_bwd(const GruStepsBf3Bwd& L, hipStream_t s);

@@ -249,6 +249,193 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gru_step
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward steps of the same layers (round 4): dh_t = dgh_{t+1} W_hh + dh_{t+1} z_{t+1} + dout_t, then the gate derivatives.
+// One launch per processed step: A = the pieces of dgh of the step processed before (K = 3H), B = the pieces of W_hh^T
+// (k-major split of W_hh: no interleaving -- one accumulator tile per 16 units), tile 128 rows x 128 units.  The epilogue
+// transposes the accumulators through LDS so that a lane owns four consecutive units of one row: the five saves, dout and
+// dh z arrive as 16-byte loads, dgi / dgh / dh z leave as 16-byte stores, and the three gate tiles go back through LDS to
+// become the next step's A pieces (32 units of one gate = exactly one k block: one 1 KB fragment per wave instruction).
+// Bias gradients are column sums of dgi / dgh taken once after the last step (pw_colsum_multi), not per-step atomics.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct BStepProb {
+    const unsigned char* A; unsigned char* An; long a_piece;   // pieces of dgh (next / this step): [B/16][3H/32] fragments per piece
+    const unsigned char* W; long w_piece;                        // pieces of W_hh^T: [H/16][3H/32]
+    const float* sv; long sv_astride;                            // saves at this time step (row stride H)
+    const float* dout; long dout_ld;                             // external gradient into h_t, or null
+    const float* dhn; long dhn_ld;                               // gradient into the final state (first processed step), or null
+    const float* dhz_in; float* dhz_out;                         // dh z of the step processed before / of this one, [B,H]
+    float* dgi; long dgi_ld;                                     // input-side gate gradients at this time step
+    float* dgh;                                                  // recurrent-side gate gradients at this time step, [B,3H]
+    unsigned char* em; long em_piece; int em_kb, em_kb0; long em_rb0;   // row pieces of dgi (ChainEmit.rows), or null
+    float* dh0; long dh0_ld; int dh0_acc;                        // tail launch: gradient into the initial state
+};
+struct BStepArgs { int H, B, nprob, first, tail; BStepProb p[2]; };
+
+constexpr int BWM = 2, BWN = 4, BRM = 4, BRN = 2;               // 8 waves; wave tile 64 rows x 32 units; tile 128 x 128
+
+__global__ __launch_bounds__(64 * BWM * BWN) void gru_step_bf3_bwd_kernel(BStepArgs a) {
+    constexpr int TMB = BWM * BRM, TNB = BWN * BRN, NW = BWM * BWN;
+    constexpr int STAGE = (TMB + TNB) * 3 * 1024, CH = (TMB + TNB) * 3, CPW = (CH + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w / BWN, wn = w % BWN;
+    const int H = a.H, KB = (3 * H) >> 5;
+    const int tiles_m = a.B / (TMB * 16), tiles_n = H / (TNB * 16);
+    const int nb = gridDim.x, id = blockIdx.x;
+    const int tid = (nb % 8 == 0) ? (id % 8) * (nb / 8) + id / 8 : id;
+    const int per_prob = tiles_m * tiles_n;
+    const int prob = tid / per_prob, v = tid - prob * per_prob;
+    const int tm = v / tiles_n, tn = v - tm * tiles_n;
+    const BStepProb& P = a.p[prob];
+    const int c = lane & 15, q = lane >> 4;
+    const int j0 = tn * (TNB * 16) + wn * 32;                   // this wave's 32 hidden units
+
+    f32x4 acc[BRM][BRN];
+#pragma unroll
+    for (int i = 0; i < BRM; ++i)
+#pragma unroll
+        for (int u = 0; u < BRN; ++u) acc[i][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Epilogue operands of one row block (16 rows x 32 units): eight 16-byte loads per 16-unit half -- the five saves, dh z, dout,
+    // dhn --, all issued back to back from branch-free sources (an absent one aims at the saves with a zero factor: a conditional
+    // load costs a branch and a drained vmcnt each, 8 x 7 dependent round trips = 80 us of a 164 us launch in the first build).
+    // Row block 0's are requested before the contraction, row block i + 1's while row block i is being computed.
+    const int vrow = lane >> 2, vcol = (lane & 3) * 4;                 // vector phase: row vrow, units vcol .. +3 of each 16-unit half
+    const float* const svp = a.tail ? P.dhz_in : P.sv;                 // (always valid memory of finite values)
+    const long sv_as = a.tail ? 0 : P.sv_astride;
+    const float f_dhz = P.dhz_in ? 1.f : 0.f, f_dout = (!a.tail && P.dout) ? 1.f : 0.f, f_dhn = (!a.tail && P.dhn) ? 1.f : 0.f;
+    const float* const dhzp = P.dhz_in ? P.dhz_in : svp;
+    const float* const doutp = f_dout != 0.f ? P.dout : svp;  const long dout_ld = f_dout != 0.f ? P.dout_ld : H;
+    const float* const dhnp = f_dhn != 0.f ? P.dhn : svp;     const long dhn_ld = f_dhn != 0.f ? P.dhn_ld : H;
+    auto issue = [&](int i, f32x4 (&L)[BRN][8]) {
+        const long row = (long)(tm * TMB + wm * BRM + i) * 16 + vrow;
+#pragma unroll
+        for (int u = 0; u < BRN; ++u) {
+            const int jj = j0 + 16 * u + vcol;
+            const float* sp = svp + row * H + jj;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) L[u][k] = *reinterpret_cast<const f32x4*>(sp + k * sv_as);
+            L[u][5] = *reinterpret_cast<const f32x4*>(dhzp + row * H + jj);
+            L[u][6] = *reinterpret_cast<const f32x4*>(doutp + row * dout_ld + jj);
+            L[u][7] = *reinterpret_cast<const f32x4*>(dhnp + row * dhn_ld + jj);
+        }
+    };
+    f32x4 ops[2][BRN][8];
+    issue(0, ops[0]);
+
+    if (!a.first) {
+        const unsigned char* gsrc[CPW]; int loff[CPW];
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int cc0 = w + i * NW;
+            const int cc = cc0 < CH ? cc0 : CH - 1;
+            if (cc < TMB * 3) {
+                const int p = cc / TMB, rbl = cc % TMB;
+                gsrc[i] = P.A + p * P.a_piece + ((long)(tm * TMB + rbl) * KB) * 1024 + lane * 16;
+            } else {
+                const int c2 = cc - TMB * 3, p = c2 / TNB, rbl = c2 % TNB;
+                gsrc[i] = P.W + p * P.w_piece + ((long)(tn * TNB + rbl) * KB) * 1024 + lane * 16;
+            }
+            loff[i] = cc * 1024;
+        }
+        auto fill = [&](int kb, unsigned char* stage) {
+#pragma unroll
+            for (int i = 0; i < CPW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[i] + (long)kb * 1024),
+                                                 (__attribute__((address_space(3))) void*)(stage + loff[i]), 16, 0, 0);
+        };
+        // (two LDS stages.  A third -- fill kb + 2 in flight across the barrier, manual vmcnt -- measured the same 152 us: the launch
+        //  is bound by its epilogue's memory traffic, ~390 MB per step at B = 4096, not by the fill latency)
+        fill(0, smem);
+        __syncthreads();
+        for (int kb = 0; kb < KB; ++kb) {
+            const unsigned char* sa = smem + (kb & 1) * STAGE + lane * 16;
+            const unsigned char* sb = sa + TMB * 3 * 1024;
+            if (kb + 1 < KB) fill(kb + 1, smem + ((kb + 1) & 1) * STAGE);
+            bf16x8 Af[BRM][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < BRM; ++i) Af[i][p] = *reinterpret_cast<const bf16x8*>(sa + (p * TMB + wm * BRM + i) * 1024);
+#pragma unroll
+            for (int pj = 0; pj < 3; ++pj) {
+                bf16x8 Bf[BRN];
+#pragma unroll
+                for (int u = 0; u < BRN; ++u) Bf[u] = *reinterpret_cast<const bf16x8*>(sb + (pj * TNB + wn * BRN + u) * 1024);
+#pragma unroll
+                for (int pi = 0; pi < 3; ++pi)
+#pragma unroll
+                    for (int i = 0; i < BRM; ++i)
+#pragma unroll
+                        for (int u = 0; u < BRN; ++u)
+                            acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[i][pi], Bf[u], acc[i][u], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: per row block, 16 rows x 32 units through wave-private LDS tiles ----
+    float* const xt = reinterpret_cast<float*>(smem) + w * (5 * 512);  // dh, then the gate tiles dr, dz, dnr, dn: 16 x 32 floats each
+    const int prow = lane & 15, pk8 = (lane >> 4) * 8;                 // piece phase: row prow, units pk8 .. +7 of the 32
+#pragma unroll
+    for (int i = 0; i < BRM; ++i) {
+        const int rb = tm * TMB + wm * BRM + i;
+        if (i + 1 < BRM) issue(i + 1, ops[(i + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < BRN; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xt[(4 * q + r) * 32 + 16 * u + c] = acc[i][u][r];
+        __builtin_amdgcn_wave_barrier();
+        const long row = (long)rb * 16 + vrow;
+        f32x4 (&L)[BRN][8] = ops[i & 1];
+#pragma unroll
+        for (int u = 0; u < BRN; ++u) {
+            const int jj = j0 + 16 * u + vcol;                          // four consecutive units
+            f32x4 dh = *reinterpret_cast<const f32x4*>(xt + vrow * 32 + 16 * u + vcol);
+            dh += f_dhz * L[u][5];
+            if (a.tail) {
+                float* o = P.dh0 + row * P.dh0_ld + jj;
+                if (P.dh0_acc) dh += *reinterpret_cast<const f32x4*>(o);
+                *reinterpret_cast<f32x4*>(o) = dh;
+                continue;
+            }
+            dh += f_dout * L[u][6] + f_dhn * L[u][7];
+            const f32x4 rg = L[u][0], zg = L[u][1], ng = L[u][2], ghn = L[u][3], hpv = L[u][4];
+            f32x4 dr, dz, dn, dnr, dhz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dn_pre = dh[e] * (1.f - zg[e]) * (1.f - ng[e] * ng[e]);
+                dz[e] = dh[e] * (hpv[e] - ng[e]) * zg[e] * (1.f - zg[e]);
+                dr[e] = dn_pre * ghn[e] * rg[e] * (1.f - rg[e]);
+                dn[e] = dn_pre; dnr[e] = dn_pre * rg[e];
+                dhz[e] = dh[e] * zg[e];
+            }
+            float* gi = P.dgi + row * P.dgi_ld + jj;
+            *reinterpret_cast<f32x4*>(gi) = dr; *reinterpret_cast<f32x4*>(gi + H) = dz; *reinterpret_cast<f32x4*>(gi + 2 * H) = dn;
+            float* gh = P.dgh + row * 3 * H + jj;
+            *reinterpret_cast<f32x4*>(gh) = dr; *reinterpret_cast<f32x4*>(gh + H) = dz; *reinterpret_cast<f32x4*>(gh + 2 * H) = dnr;
+            *reinterpret_cast<f32x4*>(P.dhz_out + row * H + jj) = dhz;
+            const int o = vrow * 32 + 16 * u + vcol;
+            *reinterpret_cast<f32x4*>(xt + 512 + o) = dr; *reinterpret_cast<f32x4*>(xt + 1024 + o) = dz;
+            *reinterpret_cast<f32x4*>(xt + 1536 + o) = dnr; *reinterpret_cast<f32x4*>(xt + 2048 + o) = dn;
+        }
+        if (a.tail) continue;
+        __builtin_amdgcn_wave_barrier();
+        // pieces: gate g's 32 units of these 16 rows = k block (g H + j0) / 32 of row block rb: one fragment per gate and layout
+        const int lfrag = ((lane >> 4) * 16 + prow) * 16;               // byte offset of (row, 8-unit group) inside the fragment
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int kbg = (g * H + j0) >> 5;
+            if (P.An) pieces8_store(xt + 512 * (g + 1) + prow * 32 + pk8, P.An + ((long)rb * KB + kbg) * 1024 + lfrag, P.a_piece);
+            if (P.em) pieces8_store(xt + 512 * (g == 2 ? 4 : g + 1) + prow * 32 + pk8,
+                                    P.em + ((P.em_rb0 + rb) * P.em_kb + P.em_kb0 + kbg) * 1024 + lfrag, P.em_piece);
+        }
+    }
+}
+
 template <bool TAB, bool DEN, bool SAVE>
 int launch_one(const StepArgs& a, hipStream_t s) {
     constexpr int WM = 2, WN = 4, RM = 4;                          // 8 waves; wave tile 64 rows x (16 units x 3 gates)
@@ -264,11 +451,16 @@ int launch_one(const StepArgs& a, hipStream_t s) {
 
 }  // namespace
 
-namespace { int g_min_tiles = -1; }
+namespace {
+int g_min_tiles = -1;
+int min_tiles_now() {
+    if (g_min_tiles < 0) { const char* v = std::getenv("INET_STEP_BF3_MIN_TILES"); g_min_tiles = v ? std::atoi(v) : 256; if (g_min_tiles < 0) g_min_tiles = 0; }
+    return g_min_tiles;
+}
+}  // namespace
 void gru_step_bf3_set_min_tiles(int n) { g_min_tiles = n < 0 ? 0 : n; }
 bool gru_step_bf3_ok(int H, int B, int T, int nd) {
-    if (g_min_tiles < 0) { const char* v = std::getenv("INET_STEP_BF3_MIN_TILES"); g_min_tiles = v ? std::atoi(v) : 256; if (g_min_tiles < 0) g_min_tiles = 0; }
-    const int min_tiles = g_min_tiles;
+    const int min_tiles = min_tiles_now();
     if (bf3_mode() == 0 || min_tiles <= 0) return false;
     if (H < 64 || H % 64 || B < 128 || B % 128 || T < 1 || nd < 1 || nd > 2) return false;
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;
@@ -341,5 +533,78 @@ int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s) {
         else rc = save ? launch_one<false, true, true>(a, s) : launch_one<false, true, false>(a, s);
         if (rc != 0) return rc;
     }
+    return 0;
+}
+
+// ---- backward steps ----
+bool gru_step_bf3_bwd_ok(int H, int B, int T, int nd) {
+    const int min_tiles = min_tiles_now();
+    if (bf3_mode() == 0 || min_tiles <= 0) return false;
+    if (H < 128 || H % 128 || B < 128 || B % 128 || T < 1 || nd < 1 || nd > 2) return false;
+    if ((double)T * B * 6.0 * H >= 2.0e9) return false;
+    return nd * (B / 128) * (H / 128) >= (min_tiles + 1) / 2;       // (128 x 128 tiles: half as many as the forward kernel's for a shape)
+}
+
+int gru_step_bf3_split_wT(int H, const float* W_hh, unsigned char* WpT, hipStream_t s) {
+    // B operand of dh = dgh W_hh: row n = hidden unit j, contraction over the 3H gate rows: B(j, k) = W_hh[k * H + j]
+    return bf3_split(W_hh, H, 1, H, 3 * H, WpT, (long)bf3_piece_bytes(H, 3L * H), 3 * H / 32, 0, 0, s);
+}
+
+int launch_gru_steps_bf3_bwd(const GruStepsBf3Bwd& L, hipStream_t s) {
+    const int H = L.H, B = L.B, T = L.T, nd = L.nprob;
+    if (!gru_step_bf3_bwd_ok(H, B, T, nd)) return -1;
+    const long apiece = (long)bf3_piece_bytes(B, 3L * H), slot = 3 * apiece, BH = (long)B * H;
+    for (int i = 0; i < nd; ++i) {
+        const GruChainBwdProb& P = L.p[i];
+        if (!L.WpT[i] || !L.dhz[i] || !P.gx || !P.sv || !P.dgi || !P.dgh) return -1;
+        if (P.ts_dgi != (long)B * P.ld_dgi || (P.dgh_ts && P.dgh_ts != 3 * BH)) return -1;    // (the column sums below walk [T*B] rows)
+        if ((L.p[i].dh0 != nullptr) != (L.p[0].dh0 != nullptr) || P.dgi_sum) return -1;
+    }
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_step_bf3_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const int grid = nd * (B / 128) * (H / 128);
+    const size_t lds = (size_t)2 * (BWM * BRM + BWN * BRN) * 3 * 1024;
+    char label[96];
+    std::snprintf(label, sizeof label, "gru_step_bf3_bwd p9 np%d B%d H%d", nd, B, H);
+    const bool want_dh0 = L.p[0].dh0 != nullptr;
+    for (int step = T - 1; step >= (want_dh0 ? -1 : 0); --step) {
+        BStepArgs a{};
+        a.H = H; a.B = B; a.nprob = nd; a.first = step == T - 1; a.tail = step < 0;
+        for (int i = 0; i < nd; ++i) {
+            const GruChainBwdProb& P = L.p[i];
+            BStepProb& Q = a.p[i];
+            unsigned char* ring = reinterpret_cast<unsigned char*>(P.gx);
+            Q.A = ring + (long)((step + 1) & 1) * slot; Q.a_piece = apiece;
+            Q.W = L.WpT[i]; Q.w_piece = (long)bf3_piece_bytes(H, 3L * H);
+            Q.dhz_in = a.first ? nullptr : L.dhz[i] + (long)((step + 1) & 1) * BH;
+            if (a.tail) { Q.dh0 = P.dh0; Q.dh0_ld = P.ld_dh0; Q.dh0_acc = P.dh0_accumulate; continue; }
+            const int tt = P.reverse ? T - 1 - step : step;
+            Q.An = (step > 0 || want_dh0) ? ring + (long)(step & 1) * slot : nullptr;
+            Q.sv = P.sv + (long)tt * (P.sv_ts ? P.sv_ts : BH); Q.sv_astride = P.sv_astride;
+            if (P.dout) { Q.dout = P.dout + (long)tt * P.ts_dout; Q.dout_ld = P.ld_dout; }
+            if (P.dhn && a.first) { Q.dhn = P.dhn; Q.dhn_ld = P.ld_dhn; }
+            Q.dhz_out = L.dhz[i] + (long)(step & 1) * BH;
+            Q.dgi = P.dgi + (long)tt * P.ts_dgi; Q.dgi_ld = P.ld_dgi;
+            Q.dgh = P.dgh + (long)tt * 3 * BH;
+            if (P.em.rows) {
+                Q.em = P.em.rows; Q.em_piece = P.em.rows_piece; Q.em_kb = P.em.rows_kb; Q.em_kb0 = P.em.rows_kb0;
+                Q.em_rb0 = ((long)tt * P.em.B_full + P.em.r0) / 16;
+            }
+        }
+        ProfScope prof(PROF_GRU_BWD, a.first ? 0.0 : 2.0 * nd * B * 3.0 * H * H, s, label,
+                       nd * (6.0 * 3 * H * H + 2 * 18.0 * B * H + 4.0 * B * H * (5 + 2 + 7)));
+        hipLaunchKernelGGL(gru_step_bf3_bwd_kernel, dim3(grid), dim3(64 * BWM * BWN), lds, s, a);
+        if (hipGetLastError() != hipSuccess) return -2;
+    }
+    // bias gradients: db_ih += column sums of dgi, db_hh += column sums of dgh over all T*B rows
+    PwColsumJob jobs[4];
+    int nj = 0;
+    for (int i = 0; i < nd; ++i) {
+        const GruChainBwdProb& P = L.p[i];
+        if (!P.db_ih || !P.db_hh) continue;
+        jobs[nj++] = PwColsumJob{P.dgi, P.ld_dgi, T * B, 3 * H, P.db_ih};
+        jobs[nj++] = PwColsumJob{P.dgh, 3L * H, T * B, 3 * H, P.db_hh};
+    }
+    if (nj) INET_TRY(pw_colsum_multi(jobs, nj, s));
     return 0;
 }

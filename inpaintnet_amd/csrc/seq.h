@@ -67,6 +67,7 @@ struct DirBwd {
     const float* W_hh;                                        // [3H,H] row-major (chain kernel reads it transposed once)
     unsigned* sync;                                           // as in DirFwd
     int sync_prezeroed;
+    unsigned char* wp3T;                                      // big batches (gru_step_bf3.h): scratch for the pieces of W_hh^T, or null
     float* dgi_sum;                                           // optional [B,3H] sum_t dgi(t); `*dgi_sum_done` is set to 1 when the
     int* dgi_sum_done;                                        // layer's launch produced it (chain kernel), else left alone
     ChainEmit em; mutable int emitted;                        // as in DirFwd
@@ -145,6 +146,7 @@ struct BiGru2Ws {
     float *whhT[4], *dgi1, *dgh[4], *dhz, *dx1, *dgi0;
     float *wpk[4], *hpk[4], *wpkT[4], *dghpk[4];               // fragment-major twins (null unless pk_ok(H))
     unsigned char* wp3[4];                                       // interleaved W_hh pieces for the big-batch step kernels (gru_step_bf3.h), or null
+    unsigned char* wp3T[4];                                      // ... and the pieces of W_hh^T for their backward steps (save only)
     unsigned* sync;                                            // chain-kernel counters: kSyncAreas areas (gru_chain.h)
     // piece buffers of the layer-1 input products (gemm_bf3.h; null unless the shapes tile): x1 [TB, 2H], W_ih of both
     // layer-1 directions stacked [6H, 2H]; backward: dgi1 [TB, 6H], the same weights k-major [2H, 6H]

@@ -271,6 +271,36 @@ int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_h
             return 0;
         }
     }
+    {
+        // More rows than the chain launches take (chunks stop at INET_CHAIN_CHUNK_MAX rows): one bf16-pipe product per time step with
+        // the gate derivatives as its epilogue (gru_step_bf3.hip) instead of the f32-input per-step kernels
+        bool any0 = false, all0 = true, stepb = pk && nd <= 2 && step_hi == T - 1 && step_lo == 0 && gru_step_bf3_bwd_ok(H, B, T, nd);
+        for (int i = 0; i < nd; ++i) {
+            if (d[i].dh0) any0 = true; else all0 = false;
+            stepb = stepb && d[i].wp3T && d[i].W_hh && d[i].dhz && !d[i].dgi_sum;
+        }
+        if (stepb && (!any0 || all0)) {
+            GruStepsBf3Bwd L{};
+            L.H = H; L.B = B; L.T = T; L.nprob = nd;
+            for (int i = 0; i < nd; ++i) {
+                const DirBwd& D = d[i];
+                GruChainBwdProb& P = L.p[i];
+                P.dout = D.dout; P.ld_dout = D.dout_ld; P.ts_dout = D.dout_ts;
+                P.dhn = D.dhn; P.ld_dhn = D.dhn_ld;
+                P.sv = D.sv; P.sv_astride = D.sv_astride;
+                P.dgi = D.dgi; P.ld_dgi = D.dgi_ld; P.ts_dgi = D.dgi_ts;
+                P.dgh = D.dgh;
+                P.db_ih = D.db_ih; P.db_hh = D.db_hh;
+                P.dh0 = D.dh0; P.ld_dh0 = D.dh0_ld; P.dh0_accumulate = D.dh0_acc;
+                P.gx = D.dghpk; P.reverse = D.reverse;
+                if (D.em.rows && B % 32 == 0) { P.em.rows = D.em.rows; P.em.rows_piece = D.em.rows_piece; P.em.rows_kb = D.em.rows_kb;
+                                                P.em.rows_kb0 = D.em.rows_kb0; P.em.B_full = B; P.em.r0 = 0; D.emitted = 1; }
+                INET_TRY(gru_step_bf3_split_wT(H, D.W_hh, D.wp3T, s));
+                L.WpT[i] = D.wp3T; L.dhz[i] = D.dhz;
+            }
+            return launch_gru_steps_bf3_bwd(L, s);
+        }
+    }
     for (int step = step_hi; step >= step_lo; --step) {
         GruBwdBatch bt{};
         bt.H = H; bt.nprob = nd;
@@ -356,6 +386,7 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
         w.wpkT[i] = pk && save ? c.take<float>((size_t)3 * H * H) : nullptr;
         w.dghpk[i] = pk && save ? c.take<float>(chain_ring_floats(B, 3 * H)) : nullptr;
         w.wp3[i] = pk && !gru_chain_ok(H, B, T, 2) && gru_step_bf3_ok(H, B, T, 2) ? c.take<unsigned char>(gru_step_bf3_w_bytes(H)) : nullptr;
+        w.wp3T[i] = pk && save && chain_chunk_rows_bwd(H, B, T, 2) == 0 && gru_step_bf3_bwd_ok(H, B, T, 2) ? c.take<unsigned char>(gru_step_bf3_w_bytes(H)) : nullptr;
     }
     w.sync = c.take<unsigned>(kSyncAreas * kChainSyncWords);
     // The bf16-pipe products (gemm_bf3.hip) tile 192 rows x 192 / 128 columns: below ~3072 rows (T*B) a launch leaves most CUs idle
@@ -546,7 +577,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (dh0) { D.dh0 = dh0 + (2 + dir) * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[2 + dir]; D.dghpk = w.dghpk[2 + dir];
-        D.W_hh = P[2 + dir].w_hh; D.sync = w.sync; D.sync_prezeroed = chained;
+        D.W_hh = P[2 + dir].w_hh; D.sync = w.sync; D.sync_prezeroed = chained; D.wp3T = w.wp3T[2 + dir];
         if (bf3d_pre && (emit_mask() & 4)) {
             D.em.rows = w.dgi1pk; D.em.rows_piece = (long)bf3_piece_bytes((long)T * B, 6 * H); D.em.rows_kb = 6 * H / 32;
             D.em.rows_kb0 = dir * 3 * H / 32;
@@ -635,7 +666,7 @@ int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, 
         if (dh0) { D.dh0 = dh0 + dir * BH; D.dh0_ld = H; D.dh0_acc = 0; }
         D.reverse = dir;
         D.Wpk_hhT = w.wpkT[dir]; D.dghpk = w.dghpk[dir];
-        D.W_hh = P[dir].w_hh; D.sync = chained ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = chained;
+        D.W_hh = P[dir].w_hh; D.sync = chained ? w.sync + kChainSyncWords : w.sync; D.sync_prezeroed = chained; D.wp3T = w.wp3T[dir];
     }
     for (int hi = T - 1; hi >= 0; hi -= CH) {
         const int lo = hi - CH + 1 > 0 ? hi - CH + 1 : 0;

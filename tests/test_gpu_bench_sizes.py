@@ -89,8 +89,9 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     ops.prof_dump(tmp_path / "launches.csv")
     ops.prof_enable(False)
     labels = _labels(tmp_path / "launches.csv")
-    if B == 2048:                     # the encoder's forward layers: bf16-pipe step kernels with backward saves
+    if B == 2048:                     # the encoder's layers: bf16-pipe step kernels, forward (with backward saves) and backward
         assert sum(l == "gru_step_bf3 p9 np2 B2048 H512 sv" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
+        assert sum(l == "gru_step_bf3_bwd p9 np2 B2048 H512" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
     if B == 512:
         gl = sorted(set(l for l in labels if l.startswith("gru") or l.startswith("dec")))
         assert not any(l.startswith("gru_fwd") or l.startswith("gru_bwd") for l in labels), gl      # no per-step launches
