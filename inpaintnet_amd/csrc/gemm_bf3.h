@@ -21,6 +21,10 @@ int bf3_split(const float* X, long ld, int kmajor, int R, int K, unsigned char* 
 int bf3_split_strided(const float* X, long ld, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0, int rb_mul,
                       hipStream_t s);
 
+// ... and up to 8 such splits of one shape in one launch
+struct Bf3SplitJob { const float* X; unsigned char* P; int rb0, rb_mul; };
+int bf3_split_strided_batch(const Bf3SplitJob* jobs, int n, int R, int K, long ld, long piece_bytes, int kb_total, hipStream_t s);
+
 struct Bf3Gemm {
     // C[M, N] (op)= epi(sum_k A(m, k) B(n, k) + bias):  A, B piece buffers (k blocks 0 .. K/32 of each row block)
     const unsigned char* A; long a_piece; int a_kb;

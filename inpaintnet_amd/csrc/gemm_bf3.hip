@@ -273,6 +273,35 @@ int bf3_split(const float* X, long ld, int kmajor, int R, int K, unsigned char* 
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// Up to 8 strided row splits of one shape in ONE launch (blockIdx.y = job): the three gates of up to two directions' W_hh for the
+// big-batch step kernels (six 4 us launches in front of every layer otherwise).
+struct SplitBatch { SplitArgs j[8]; int n; };
+__global__ __launch_bounds__(256) void bf3_split_rows_batch_kernel(SplitBatch b) {
+    if ((int)blockIdx.y >= b.n) return;
+    const SplitArgs& a = b.j[blockIdx.y];
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = id & 63;
+    const long frag = id >> 6;
+    const int KB = a.K / 32;
+    const long rb = frag / KB; const int kb = (int)(frag - rb * KB);
+    if (rb >= a.R / 16) return;
+    const long off = (rb * 16 + (lane & 15)) * a.ld + kb * 32 + (lane >> 4) * 8;
+    const f32x4 v0 = ld4u(a.X + off), v1 = ld4u(a.X + off + 4);
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    split8_store(v, a.P + (((a.rb0 + rb * a.rb_mul) * a.kb_total + a.kb0 + kb) * 64 + lane) * 16, a.piece_bytes);
+}
+int bf3_split_strided_batch(const Bf3SplitJob* jobs, int n, int R, int K, long ld, long piece_bytes, int kb_total, hipStream_t s) {
+    if (n < 1 || n > 8 || R <= 0 || K <= 0 || R % 16 || K % 32) return -1;
+    SplitBatch b{};
+    b.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (!jobs[i].X || !jobs[i].P || jobs[i].rb_mul < 1) return -1;
+        b.j[i] = SplitArgs{jobs[i].X, ld, jobs[i].P, piece_bytes, kb_total, jobs[i].rb0, 0, R, K, jobs[i].rb_mul};
+    }
+    hipLaunchKernelGGL(bf3_split_rows_batch_kernel, dim3((unsigned)(((long)R / 16 * (K / 32) * 64 + 255) / 256), n), dim3(256), 0, s, b);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int bf3_split_strided(const float* X, long ld, int R, int K, unsigned char* P, long piece_bytes, int kb_total, int rb0, int rb_mul,
                       hipStream_t s) {
     if (!X || !P || R <= 0 || K <= 0 || R % 16 || K % 32 || rb_mul < 1) return -1;

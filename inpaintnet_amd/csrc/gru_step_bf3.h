@@ -16,7 +16,7 @@ struct GruStepsBf3 {
 bool gru_step_bf3_ok(int H, int B, int T, int nd);
 void gru_step_bf3_set_min_tiles(int n);                    // inet_set_option key 12 (0: never take this path)
 size_t gru_step_bf3_w_bytes(int H);
-int gru_step_bf3_split_w(int H, const float* W_hh, unsigned char* Wp, hipStream_t s);
+int gru_step_bf3_split_w(int H, const float* const* W_hh, unsigned char* const* Wp, int nd, hipStream_t s);   // nd directions, one launch
 // all T steps (T launches on `s`); writes ChainEmit.rows if given (nothing else of the descriptor's `em`)
 int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s);
 

@@ -469,11 +469,13 @@ bool gru_step_bf3_ok(int H, int B, int T, int nd) {
 
 size_t gru_step_bf3_w_bytes(int H) { return bf3_bytes(3L * H, H); }
 
-int gru_step_bf3_split_w(int H, const float* W_hh, unsigned char* Wp, hipStream_t s) {
-    // gate g's H rows (H / 16 row blocks) -> row blocks 3u + g
-    for (int g = 0; g < 3; ++g)
-        if (bf3_split_strided(W_hh + (long)g * H * H, H, H, H, Wp, (long)bf3_piece_bytes(3L * H, H), H / 32, g, 3, s) != 0) return -2;
-    return 0;
+int gru_step_bf3_split_w(int H, const float* const* W_hh, unsigned char* const* Wp, int nd, hipStream_t s) {
+    // gate g's H rows (H / 16 row blocks) of direction d -> row blocks 3u + g of Wp[d]: all of them in one launch
+    if (nd < 1 || nd > 2) return -1;
+    Bf3SplitJob jobs[6];
+    for (int d = 0; d < nd; ++d)
+        for (int g = 0; g < 3; ++g) jobs[3 * d + g] = Bf3SplitJob{W_hh[d] + (long)g * H * H, Wp[d], g, 3};
+    return bf3_split_strided_batch(jobs, 3 * nd, H, H, H, (long)bf3_piece_bytes(3L * H, H), H / 32, s);
 }
 
 int launch_gru_steps_bf3(const GruStepsBf3& L, hipStream_t s) {

@@ -120,8 +120,12 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
                              P.em.B_full = B; P.em.r0 = 0; D.emitted = 1;
                              // forward-only: the masked output's only reader is the layer-1 product, which takes these pieces
                              if (!D.sv) P.outm = nullptr; }
-            INET_TRY(gru_step_bf3_split_w(H, D.W_hh, D.wp3, s));
             L.Wp[i] = D.wp3;
+        }
+        {
+            const float* ws[2] = {d[0].W_hh, nd > 1 ? d[1].W_hh : nullptr};
+            unsigned char* wp[2] = {d[0].wp3, nd > 1 ? d[1].wp3 : nullptr};
+            INET_TRY(gru_step_bf3_split_w(H, ws, wp, nd, s));
         }
         return launch_gru_steps_bf3(L, s);
     }

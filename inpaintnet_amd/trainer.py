@@ -250,7 +250,7 @@ class Trainer(ABC):
     def _flag(self):
         """The device word that decides whether this step counts: the ranks' summed chain status under data parallelism
         (None = the process's own status word)."""
-        return self.model.step_flag if dp.world_size() > 1 and self.model.grad.is_cuda else None
+        return self.model.step_flag if dp.world_size() > 1 and self._reports_on() else None
 
     @staticmethod
     def _accumulate_stats(sums, loss, accuracy, step_flag=None):
@@ -262,6 +262,8 @@ class Trainer(ABC):
         loss = loss.reshape(1).to(sums.dtype).contiguous()
         acc = None if accuracy is None else accuracy.detach().reshape(1).to(sums.dtype).contiguous()
         if not sums.is_cuda:                         # (the world_size-2 gloo tests drive this loop with host tensors)
+            if step_flag is not None and float(step_flag[0]) != 0.0:
+                return
             sums[0] += loss[0]
             if acc is not None:
                 sums[1] += acc[0]
@@ -281,29 +283,53 @@ class Trainer(ABC):
     def step(self):
         """utils/trainer.py:172-177 (+ the data-parallel gradient exchange).  May raise ops.ChainTimeoutError / ValueError
         for an EARLIER step (see check_steps)."""
-        ops.side_defer(False, release=False)         # joins; deferred mode only lives between zero_grad() and step()
+        self._join_side_work()
         m = self.model
         flag = self._flag()
         if flag is not None:
-            ops.step_flag_export(flag)               # this rank's chain status -> the word in front of the arena ...
+            self._export_flag(flag)                  # this rank's chain status -> the word in front of the arena ...
         gscale = dp.allreduce_grads(m.grad, store=m._grad_store, head=m._HEAD)     # ... summed with the gradients
         ops.release_held()                           # (after the exchange: the buckets' streams were ordered behind side work)
         self.adam_t += 1
         tag = self._tag
         self._tag += 1
-        if m.grad.is_cuda:
+        if self._reports_on():
             if len(self._inflight) >= self._NREP - 1:     # (only if check_steps() was overridden away: never reuse an unread record)
                 self.check_steps(wait_all=True)
-            rec = self._report_slot(tag)
-            rec.zero_()                              # host write: the launch that last wrote this record was waited for when it was read
-            ops.adam_step(m.flat, m.grad, self.adam_m, self.adam_v, self.lr, self.adam_t, self.betas[0], self.betas[1],
-                          self.eps, gscale, step_flag=flag, report=rec)
-            self._report_events[tag % self._NREP].record()
+            self._launch_optimizer(tag, gscale, flag)
             self._inflight.append(tag)
             self.check_steps()
         else:
             ops.adam_step(m.flat, m.grad, self.adam_m, self.adam_v, self.lr, self.adam_t, self.betas[0], self.betas[1],
                           self.eps, gscale)
+
+    # ---- the device-touching pieces of the protocol, one method each: tests/test_dp_gloo.py drives step(), check_steps() and the
+    # ---- fallback / replay logic with host stand-ins for them (world 2, gloo)
+    def _reports_on(self):
+        return self.model.grad.is_cuda
+
+    def _join_side_work(self):
+        ops.side_defer(False, release=False)         # joins; deferred mode only lives between zero_grad() and step()
+
+    def _export_flag(self, flag):
+        ops.step_flag_export(flag)
+
+    def _launch_optimizer(self, tag, gscale, flag):
+        m = self.model
+        rec = self._report_slot(tag)
+        rec.zero_()                                  # host write: the launch that last wrote this record was waited for when it was read
+        ops.adam_step(m.flat, m.grad, self.adam_m, self.adam_v, self.lr, self.adam_t, self.betas[0], self.betas[1],
+                      self.eps, gscale, step_flag=flag, report=rec)
+        self._report_events[tag % self._NREP].record()
+
+    def _device_sync(self):
+        torch.cuda.synchronize()
+
+    def _chains_off(self):
+        """Clear the status words and switch this process to the per-step kernels; returns this rank's timed-out workgroups."""
+        n = ops.chain_status(reset=True)
+        ops.set_option(4, 0)                          # per-step kernels from here on (INET_CHAIN=0 semantics, in-process)
+        return n
 
     _NREP = 16
 
@@ -351,14 +377,13 @@ class Trainer(ABC):
         """After a ChainTimeoutError out of step() / check_steps(): wait for the device, find every skipped step, take their
         count back out of the bias-correction step number, clear the status words, switch this process to the per-step
         kernels.  Returns the tags of the lost steps, oldest first (every rank computes the same list)."""
-        torch.cuda.synchronize()
+        self._device_sync()
         while self._inflight:
             tag = self._inflight.popleft()
             if self._read_report(tag)[1]:
                 self._lost.append(tag)
         lost, self._lost = sorted(set(self._lost)), []
-        n = ops.chain_status(reset=True)
-        ops.set_option(4, 0)                          # per-step kernels from here on (INET_CHAIN=0 semantics, in-process)
+        n = self._chains_off()
         self.chain_fallbacks += 1
         self.lost_steps += len(lost)
         self.adam_t = max(self.adam_t - len(lost), 0)  # those launches did not update anything

@@ -177,3 +177,115 @@ def test_epoch_loop_ranks_agree_on_statistics_and_early_stop(tmp_path):
     full_score, _ = synthetic.SyntheticFolkDataset(num_notes=12, n_seq=40).tensors()
     first_tokens = set(full_score[:28, 0, 0].tolist())
     assert set(r0["seen"][0].tolist()) <= first_tokens
+
+
+# ---- the rank-coordinated failure protocol of Trainer.step / check_steps / _run_batch on host stand-ins (round 4) --------------
+NBATCH = 7
+
+
+def _protocol_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    assert dp.init_from_env(backend="gloo") == world
+    from inpaintnet_amd.trainer import Trainer
+
+    class Arena:                                     # the layout of model.Model: [4-float head | arena | tail], flag = head[0]
+        _HEAD = 4
+
+        def __init__(self):
+            self.flat = torch.zeros(8)
+            self._grad_store = torch.zeros(4 + 8 + 4)
+            self.grad = self._grad_store[4:12]
+            self.step_flag = self._grad_store[0:1]
+
+        def train(self, mode=True):
+            return self
+
+        def zero_grad(self):
+            self._grad_store.zero_()
+
+    class ProtoTrainer(Trainer):
+        """The real step() / check_steps() / _run_batch() / _replay() / _fall_back_from_chains(); the five device-touching hooks
+        replaced by host code: a 'chain timeout' is a sticky local flag, the 'optimizer kernel' an SGD update that honours the
+        SUMMED flag, the 'step report' a dict."""
+        feed_fields = (0,)
+
+        def __init__(self, dataset, model):
+            super().__init__(dataset, model)
+            self.report_lag = 2
+            self.local_fail = False
+            self.chains_off = False
+            self.records, self.applied, self.seen = {}, [], 0
+
+        def process_batch_data(self, batch):
+            if self.seen == 2 and dp.rank() == 1 and not self.chains_off:
+                self.local_fail = True               # rank 1 only: "a persistent kernel gave up" while batch 2 is computed
+            self.seen += 1
+            return batch[0]
+
+        def loss_and_acc_for_batch(self, batch, epoch_num=None, train=True):
+            self.model.grad.copy_(batch.float().mean().expand(8))      # (as if the backward kernels had filled the arena)
+            self.current = int(batch[0, 0, 0])
+            return (torch.zeros(1, requires_grad=True) + float(batch.float().mean())).sum(), torch.tensor(0.5)
+
+        def zero_grad(self):
+            self.model.zero_grad()
+
+        def update_scheduler(self, epoch_num):
+            return
+
+        def _reports_on(self):
+            return True
+
+        def _join_side_work(self):
+            pass
+
+        def _export_flag(self, flag):
+            flag[0] = 1.0 if self.local_fail else 0.0
+
+        def _launch_optimizer(self, tag, gscale, flag):
+            skipped = float(flag[0]) != 0.0          # the ranks' SUM: identical everywhere
+            self.records[tag] = skipped
+            if not skipped:
+                self.model.flat -= 0.1 * gscale * self.model.grad
+                self.applied.append(self.current)
+
+        def _read_report(self, tag):
+            return True, self.records[tag], False
+
+        def _device_sync(self):
+            pass
+
+        def _chains_off(self):
+            self.local_fail, self.chains_off = False, True
+            return 1
+
+    model = Arena()
+    tr = ProtoTrainer(None, model)
+    # global batches of 4 rows x [1, 4]; row value = batch id, so a rank's shard mean identifies the batch
+    loader = [(torch.full((4, 1, 4), i, dtype=torch.int32), torch.zeros(4, 1, 4, dtype=torch.int32)) for i in range(NBATCH)]
+    loss, acc = tr.loss_and_acc_on_epoch(loader, 0, train=True)
+    np.savez(os.path.join(out_dir, f"p{rank}.npz"), flat=model.flat.numpy(), applied=np.array(tr.applied), adam_t=tr.adam_t,
+             fallbacks=tr.chain_fallbacks, lost=tr.lost_steps, loss=loss, seen=tr.seen,
+             skipped=np.array(sorted(t for t, s in tr.records.items() if s)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_failure_protocol_keeps_ranks_in_step(tmp_path):
+    """Rank 1 'times out' while batch 2 is computed.  The flag travels in the head of the gradient store through the SAME
+    all-reduce as the gradients, so both ranks' optimizers skip step 2 -- and 3 and 4, the flag being sticky until the fallback --,
+    both read the report of step 2 when step 4 has been queued (report_lag = 2), both fall back and run batches 2, 3, 4 again, in
+    order; every batch is applied exactly once, weights are bit-identical, the epoch mean counts every batch once."""
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_protocol_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "p0.npz"), np.load(tmp_path / "p1.npz")
+    for r in (r0, r1):
+        assert r["applied"].tolist() == list(range(NBATCH))
+        assert r["skipped"].tolist() == [2, 3, 4]
+        assert int(r["adam_t"]) == NBATCH and int(r["fallbacks"]) == 1 and int(r["lost"]) == 3
+    assert np.array_equal(r0["flat"], r1["flat"]) and float(r0["loss"]) == float(r1["loss"])
+    # the update is the mean of the two ranks' gradients (= the batch id): sum_i 0.1 * i
+    assert np.allclose(r0["flat"], -0.1 * sum(range(NBATCH)), rtol=1e-6)
+    assert abs(float(r0["loss"]) - np.mean(range(NBATCH))) < 1e-6     # every batch in the epoch mean exactly once
