@@ -15,7 +15,9 @@
  *  - all floating point is fp32; token tensors are int64 (as produced by
  *    utils/helpers.py:17-26 to_cuda_variable_long).
  *  - calls are asynchronous on `stream` (a hipStream_t passed as void*).
- *  - return value: 0 = ok, -1 = invalid argument, -2 = launch/runtime failure.
+ *  - return value: 0 = ok, -1 = invalid argument, -2 = launch/runtime failure, -3 = a *_bwd call on a workspace whose forward
+ *    call ran under other library options (inet_set_option keys 4, 7, 8, 9, 12: they decide which kernels run and which piece
+ *    buffers exist).
  *  - parameters live in ONE flat fp32 arena per model, laid out in the
  *    reference's state_dict() order; gradients / Adam
  *    moments use arenas of identical layout.  inet_*_param_info() is the

@@ -163,6 +163,9 @@ class InetError(RuntimeError):
 def check(rc, what):
     if rc == -1:
         raise ValueError(f"{what}: invalid argument (rc=-1)")
+    if rc == -3:
+        raise InetError(f"{what}: library options (inet_set_option keys 4, 7, 8, 9, 12) changed between a forward call and its "
+                        "backward call on the same workspace (rc=-3)")
     if rc != 0:
         raise InetError(f"{what}: HIP launch/runtime failure (rc={rc})")
 

@@ -1,4 +1,5 @@
 #include <cstdlib>
+#include <unordered_map>
 #include "seq.h"
 #include "gemm_bf3.h"
 #include "gru_step_bf3.h"
@@ -411,9 +412,21 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
     return c.bytes();
 }
 
+// The backward call re-derives from the library's options which kernels the forward call ran and which piece buffers it filled
+// (keys 4, 7, 8, 9, 12).  Changing one of them in between used to be silent wrong weight gradients: the forward call
+// now notes the options it ran under per workspace, and the backward call refuses (-3) a workspace written under other options.
+namespace {
+std::unordered_map<const void*, unsigned> g_ws_opts;
+unsigned opts_snapshot() {
+    return (unsigned)chain_enabled() | ((unsigned)chain2_mode() << 1) | ((unsigned)bf3_mode() << 5) | ((unsigned)emit_mask() << 9) |
+           ((unsigned)(gru_step_bf3_ok(512, 2048, 24, 2) ? 1 : 0) << 12) | ((unsigned)(gru_step_bf3_ok(512, 1 << 20, 2, 2) ? 1 : 0) << 13);
+}
+}  // namespace
+
 int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in, const float* h0, const float* mask,
                     float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s, int sync_prezeroed) {
     const long BH = (long)B * H, TBH = (long)T * BH;
+    if (save) g_ws_opts[w.sync] = opts_snapshot();
     // fragment-major W_hh twins: only the per-step kernels read them (the chain kernels take W_hh as stored)
     // (one launch, row chunks, or -- big batches -- the bf16-pipe step kernels, which take the same null h0)
     const bool stepf = w.wp3[0] && w.hpk[0] && pk_ok(H) && !gru_chain_ok(H, B, T, 2) && gru_step_bf3_ok(H, B, T, 2);
@@ -547,6 +560,10 @@ static int bigru2_wgrad_hh_bf3(int B, int T, int H, int layer, const GruDirPtr* 
 int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, const float* dout1,
                     const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s, int stage) {
     const long BH = (long)B * H, TBH = (long)T * BH;
+    {
+        const auto it = g_ws_opts.find(w.sync);
+        if (it != g_ws_opts.end() && it->second != opts_snapshot()) return -3;   // options changed since the forward call
+    }
     const bool wg = P[0].dw_hh != nullptr;
     // both layers run as backward chains (they read W_hh as stored) iff the conditions of gru_layer_bwd_range hold:
     // the transposed fragment-major twins are then never read

@@ -769,6 +769,33 @@ def test_bigru2_fwd_bwd_vs_oracle(B, T, K, H, scalar):
         assert "gru_chain_fwd ms" in open("/tmp/_inet_h1024.csv").read() and ops.chain_status() <= 0
 
 
+def test_backward_refuses_a_workspace_written_under_other_options():
+    """The backward call re-derives from the library's options which kernels the forward call ran: changing
+    inet_set_option key 7 / 4 between the two used to be silent wrong gradients; now the call fails (rc -3 -> InetError)."""
+    from inpaintnet_amd import layout
+    from inpaintnet_amd._lib import InetError
+    B, T, K, H = 64, 8, 16, 256
+    g = torch.Generator().manual_seed(3)
+    shapes = layout._gru("g", K, H, 2, True)
+    offs, total = layout.arena_offsets(dict(shapes))
+    flat = (torch.randn(total, generator=g) * 0.05).to(DEV)
+    x = torch.randn(B, T, K, generator=g).to(DEV)
+    wo, wh = torch.randn(B, T, 2 * H, generator=g).to(DEV), torch.randn(4, B, H, generator=g).to(DEV)
+    for key, other in ((7, 0), (4, 0)):
+        o, h, ws = ops.bigru2_fwd(x, None, flat, H, B, T, K, save=True)
+        grads = torch.zeros_like(flat)
+        ops.set_option(key, other)
+        try:
+            with pytest.raises(InetError, match="rc=-3"):
+                ops.bigru2_bwd(x, None, flat, grads, H, B, T, K, None, wo, wh, ws, want_dx=True)
+        finally:
+            ops.set_option(key, 9 if key == 7 else 1)
+        ops.bigru2_bwd(x, None, flat, grads, H, B, T, K, None, wo, wh, ws, want_dx=True)   # with the options restored: fine
+        ops.side_join()
+    torch.cuda.synchronize()
+    assert ops.chain_status() <= 0
+
+
 def test_chain_generations_against_float64():
     """The two forms of the recurrent contraction against a float64 evaluation of the same two-layer bi-GRU (forward and
     backward, 12 steps, H = 512): first generation (f32-input MFMA) and second generation with all nine bf16 piece products (the
