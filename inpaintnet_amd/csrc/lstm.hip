@@ -390,10 +390,10 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
                         acc[ms][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[ms][si][e], Wr[g][si][e], acc[ms][g], 0, 0, 0);
         float v[MS][4];
         reduce_waves<MS, 4>(acc, red, t, v);
+        float ev[MS][8];
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const int rl = (t + 256 * p) >> 4;
-            const int b = row0 + rl;
             const float i = sigmoid_f(v[p][0] + pg[p][0] + bh[0]);
             const float f = sigmoid_f(v[p][1] + pg[p][1] + bh[1]);
             const float g = tanh_f(v[p][2] + pg[p][2] + bh[2]);
@@ -404,22 +404,29 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
             const float h = o * tc;
             c[p] = cn;
             xt[rl * 16 + (t & 15)] = h;
-            if (b < B) {
-                const long qo = ((long)tt * B + b) * H + jc;
-                P.out[qo] = h;
-                P.cseq[qo] = cn;
-                if (P.sv) {
-                    float* sp = P.sv + qo;
-                    const long st = P.sv_stride;
-                    sp[0] = i; sp[st] = f; sp[2 * st] = g; sp[3 * st] = o; sp[4 * st] = cp; sp[5 * st] = tc;
-                }
-            }
+            ev[p][0] = i; ev[p][1] = f; ev[p][2] = g; ev[p][3] = o; ev[p][4] = cp; ev[p][5] = tc; ev[p][6] = h; ev[p][7] = cn;
         }
         __syncthreads();
         if (t < 64 * MS && rb0 + (t >> 6) <= rb_last) {
             const int rb = rb0 + (t >> 6);
             chain::publish_block(rs, (step & 3) * slot_bytes, xt, t >> 6, lane, rb, S, member);
             chain::st16_sc1(rs, ((step + 2) & 3) * slot_bytes + ((rb * S + member) * 256 + lane * 4) * 4, armed);   // re-arm
+        }
+        // (round 4) what nobody in the launch reads -- output, cell state, the six saves -- is stored BEHIND the hand-off stores:
+        // the memory pipe is in order, and eight scalar stores per thread used to go first
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = row0 + ((t + 256 * p) >> 4);
+            if (b < B) {
+                const long qo = ((long)tt * B + b) * H + jc;
+                P.out[qo] = ev[p][6];
+                P.cseq[qo] = ev[p][7];
+                if (P.sv) {
+                    float* sp = P.sv + qo;
+                    const long st = P.sv_stride;
+                    sp[0] = ev[p][0]; sp[st] = ev[p][1]; sp[2 * st] = ev[p][2]; sp[3 * st] = ev[p][3]; sp[4 * st] = ev[p][4]; sp[5 * st] = ev[p][5];
+                }
+            }
         }
         __syncthreads();                           // xt is rewritten by the next step's gates
     }
@@ -500,10 +507,10 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
             }
             break;
         }
+        float eg[MS][4];
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const int rl = (t + 256 * p) >> 4;
-            const int b = row0 + rl;
             const float dh = v[p][0] + pe[p][0];
             const float i = psv[p][0], f = psv[p][1], g = psv[p][2], o = psv[p][3], cp = psv[p][4], tc = psv[p][5];
             const float dct = dh * o * (1.f - tc * tc) + dc[p] + pe[p][1];
@@ -514,11 +521,7 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
             dc[p] = dct * f;
             const int xo = rl * 16 + (t & 15);
             xt[0][xo] = di; xt[1][xo] = df; xt[2][xo] = dgg; xt[3][xo] = dob;
-            if (b < B) {
-                float* d = P.dg + ((long)tt * B + b) * 4 * H;
-                d[jc] = di; d[H + jc] = df; d[2 * H + jc] = dgg; d[3 * H + jc] = dob;
-                bs[0] += di; bs[1] += df; bs[2] += dgg; bs[3] += dob;
-            }
+            eg[p][0] = di; eg[p][1] = df; eg[p][2] = dgg; eg[p][3] = dob;
         }
         __syncthreads();
         // publish the 4 gate blocks of every row sub-tile: (4 * MS) KB, one wave per block round-robin
@@ -528,6 +531,17 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
                 chain::publish_block(rs, (step & 1) * slot_bytes, xt[g], p, lane, rb0 + p, S4, g * (H >> 4) + member);
         }
         chain::arrive(P.counters + group * kCounterStride);
+        // the gate gradients nobody in the launch reads leave AFTER the hand-off (round 4: arrive() drains every outstanding store
+        // of the wave, and these four per thread used to sit in front of it)
+#pragma unroll
+        for (int p = 0; p < MS; ++p) {
+            const int b = row0 + ((t + 256 * p) >> 4);
+            if (b < B) {
+                float* d = P.dg + ((long)tt * B + b) * 4 * H;
+                d[jc] = eg[p][0]; d[H + jc] = eg[p][1]; d[2 * H + jc] = eg[p][2]; d[3 * H + jc] = eg[p][3];
+                bs[0] += eg[p][0]; bs[1] += eg[p][1]; bs[2] += eg[p][2]; bs[3] += eg[p][3];
+            }
+        }
     }
     if (P.dc0) {
 #pragma unroll
