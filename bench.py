@@ -750,7 +750,7 @@ def arnn_extra(batch=32, steps=30, warmup=4, tables=True):
     batch 32 sequences of 384 ticks, script defaults of train_arnn_reg.py.  Not the headline metric."""
     import types
     from inpaintnet_amd import synthetic
-    from inpaintnet_amd.arnn import AnticipationRNNGaussianRegTrainer, ConstraintModelGaussianReg
+    from inpaintnet_amd.arnn import AnticipationRNNGaussianRegTrainer, ConstraintModelGaussianReg, free_positions
     ds = synthetic.SyntheticFolkDataset(num_notes=NUM_NOTES)
     ds.metadatas = [types.SimpleNamespace(num_values=6), types.SimpleNamespace(num_values=6)]
     model = ConstraintModelGaussianReg(ds, note_embedding_dim=10, metadata_embedding_dim=2,
@@ -768,7 +768,7 @@ def arnn_extra(batch=32, steps=30, warmup=4, tables=True):
     def step():
         trainer.zero_grad()
         weights, _ = model(data[0], data[1], data[2], data[3], data[4], train=True, teacher_forcing=True)
-        free = (data[2][0, 0, :] == 0).nonzero().squeeze(-1)
+        free = free_positions(data[2])
         loss, acc = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, data[0][:, :, free].transpose(0, 1))
         loss.backward()
         trainer.step()

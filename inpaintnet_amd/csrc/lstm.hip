@@ -224,6 +224,7 @@ struct LstmChainFwdArgs {
     float* sv; long sv_stride;                    // 6 x [T,B,H] (i,f,g,o,c_prev,tanh c) or null
     float* hx;                                    // exchange [2][rows16][H] fragment-major; slot 1 holds h0
     unsigned* counters; chain::Status status;
+    int xrot;                                     // the launch's groups start at XCD xrot (two chains side by side: different XCDs)
 };
 
 template <int MS, int SQ>                          // SQ = H/64: k-steps of 16 per wave
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
     __shared__ __attribute__((aligned(16))) float xt[MS * 256];
     __shared__ unsigned flag[2];
     int group, member;
-    chain::decode_block(blockIdx.x, P.members, group, member);
+    chain::decode_block((blockIdx.x & ~7) | ((blockIdx.x + 8 - P.xrot) & 7), P.members, group, member);
     const int row0 = group * 16 * MS;
     if (row0 >= P.B) return;
     const int H = P.H, B = P.B, S = H >> 4, t = threadIdx.x, lane = t & 63;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * MS * 256];
     __shared__ __attribute__((aligned(16))) float xt[MS * 256];
     int group, member;
-    chain::decode_block(blockIdx.x, P.members, group, member);
+    chain::decode_block((blockIdx.x & ~7) | ((blockIdx.x + 8 - P.xrot) & 7), P.members, group, member);
     const int row0 = group * 16 * MS;
     if (row0 >= P.B) return;
     const int H = P.H, B = P.B, S = H >> 4, t = threadIdx.x, lane = t & 63;
@@ -443,6 +444,7 @@ struct LstmChainBwdArgs {
     float* db_ih; float* db_hh;                   // [4H] accumulated (nullable)
     float* gx;                                    // exchange [2][rows16][4H] fragment-major
     unsigned* counters; chain::Status status;
+    int xrot;                                     // the launch's groups start at XCD xrot (two chains side by side: different XCDs)
 };
 
 template <int MS, int SQ>                          // SQ = H/16: k-steps of 16 per wave over K = 4H
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
     __shared__ __attribute__((aligned(16))) float xt[4][MS * 256];
     __shared__ unsigned flag[2];
     int group, member;
-    chain::decode_block(blockIdx.x, P.members, group, member);
+    chain::decode_block((blockIdx.x & ~7) | ((blockIdx.x + 8 - P.xrot) & 7), P.members, group, member);
     const int row0 = group * 16 * MS;
     if (row0 >= P.B) return;
     const int H = P.H, B = P.B, T = P.T, S4 = (4 * H) >> 4, t = threadIdx.x, lane = t & 63;
@@ -682,7 +684,7 @@ namespace {
 // (the state after step s_lo - 1: rows of `out` / `cseq`, or zeros).  The kernel sees a sequence of nt steps whose
 // buffers start at the chunk's lowest time index; the saves keep the full sequence's array stride.
 int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, const float* b_hh, const float* hprev,
-                   const float* cprev, int reverse, float* out, LstmWs& w, int save, int s_lo, int nt, hipStream_t s) {
+                   const float* cprev, int reverse, float* out, LstmWs& w, int save, int s_lo, int nt, hipStream_t s, int xrot = 0) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
     const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
@@ -701,7 +703,7 @@ int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, cons
     a.gi = gi + t_lo * B * 4 * H; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = cprev;
     a.out = out + t_lo * BH; a.cseq = w.cseq + t_lo * BH;
     if (save) { a.sv = w.sv + t_lo * BH; a.sv_stride = TBH; }
-    a.hx = w.hx; a.counters = w.sync; a.status = chain_status_for(w.sync + kStatusWord);
+    a.hx = w.hx; a.counters = w.sync; a.status = chain_status_for(w.sync + kStatusWord); a.xrot = xrot & 7;
     char label[64];
     std::snprintf(label, sizeof label, "lstm_chain_fwd ms%d T%d B%d H%d", ms, nt, B, H);
     ProfScope prof(PROF_GRU_FWD, 2.0 * nt * B * 4.0 * H * H, s, label,
@@ -722,7 +724,8 @@ int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, cons
 // `area` >= 0: the chunk's own pre-zeroed counter area (lstm2_seq_bwd zeroes all of them with one memset); < 0: the base area,
 // zeroed here.
 int lstm_chunk_bwd(int B, int T, int H, const float* dout, const float* dhT, const float* dcT, int reverse, float* dgi,
-                   float* db_ih, float* db_hh, float* dh0, float* dc0, LstmWs& w, int s_lo, int nt, hipStream_t s, int area = -1) {
+                   float* db_ih, float* db_hh, float* dh0, float* dc0, LstmWs& w, int s_lo, int nt, hipStream_t s, int area = -1,
+                   int xrot = 0) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
     const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
@@ -734,7 +737,7 @@ int lstm_chunk_bwd(int B, int T, int H, const float* dout, const float* dhT, con
     a.sv = w.sv + t_lo * BH; a.sv_stride = TBH;
     a.dg = dgi + t_lo * B * 4 * H; a.dh0 = dh0; a.dc0 = dc0;
     a.db_ih = db_ih; a.db_hh = db_hh;
-    a.gx = w.gx; a.counters = counters; a.status = chain_status_for(w.sync + kStatusWord);
+    a.gx = w.gx; a.counters = counters; a.status = chain_status_for(w.sync + kStatusWord); a.xrot = xrot & 7;
     char label[64];
     std::snprintf(label, sizeof label, "lstm_chain_bwd ms%d T%d B%d H%d", ms, nt, B, H);
     ProfScope prof(PROF_GRU_BWD, 2.0 * nt * B * 4.0 * H * H, s, label,
@@ -747,6 +750,11 @@ int lstm_chunk_bwd(int B, int T, int H, const float* dout, const float* dhT, con
                      : launch_chain(lstm_chain_bwd_kernel<4, 32>, a, groups, s);
 }
 
+// XCD the second chain of a two-layer pipeline starts its groups on (the first starts on XCD 0): INET_LSTM_XROT
+int lstm_pipe_xrot() {
+    static const int v = [] { const char* e = std::getenv("INET_LSTM_XROT"); return e ? std::atoi(e) & 7 : 4; }();
+    return v;
+}
 int lstm_chunk_steps() {
     static const int v = [] { const char* e = std::getenv("INET_LSTM_CHUNK"); return e ? std::atoi(e) : 48; }();
     return v;
@@ -789,7 +797,7 @@ int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, con
         INET_TRY(linear_fwd(out0 + t_lo * BH, H, W_ih1, H, b_ih1, gi1 + t_lo * B * 4 * H, 4L * H, nt * B, 4 * H, H, EPI_NONE, s3));
         if (s3 != s2) INET_TRY(stream_wait(s2, s3));
         INET_TRY(lstm_chunk_fwd(B, T, H, gi1, W_hh1, b_hh1, s_lo ? out1 + tp * BH : w1.zeros, s_lo ? w1.cseq + tp * BH : w1.zeros,
-                                reverse, out1, w1, save, s_lo, nt, s2));
+                                reverse, out1, w1, save, s_lo, nt, s2, lstm_pipe_xrot()));
     }
     return s2 != s ? twin_join(s) : 0;
 }
@@ -832,7 +840,7 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
                               ACC_STORE, s3));
         if (s3 != s2) INET_TRY(stream_wait(s2, s3));
         INET_TRY(lstm_chunk_bwd(B, T, H, dout0, c ? in0 : nullptr, c ? in0 + BH : nullptr, reverse, dgi0, db_ih0, db_hh0,
-                                s_lo ? ou0 : nullptr, s_lo ? ou0 + BH : nullptr, w0, s_lo, nt, s2, areas ? c : -1));
+                                s_lo ? ou0 : nullptr, s_lo ? ou0 + BH : nullptr, w0, s_lo, nt, s2, areas ? c : -1, lstm_pipe_xrot()));
     }
     if (s2 != s) INET_TRY(twin_join(s));
     if (dW_hh0) {
