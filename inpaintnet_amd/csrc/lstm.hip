@@ -224,6 +224,7 @@ struct LstmChainFwdArgs {
     float* sv; long sv_stride;                    // 6 x [T,B,H] (i,f,g,o,c_prev,tanh c) or null
     float* hx;                                    // exchange [2][rows16][H] fragment-major; slot 1 holds h0
     unsigned* counters; chain::Status status;
+    int phase;                                    // tagged hand-off: steps the ring has carried before this launch (chunked layers)
     int xrot;                                     // the launch's groups start at XCD xrot (two chains side by side: different XCDs)
 };
 
@@ -311,7 +312,10 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
 // after publishing step t (its previous contents, step t - 2, have been consumed by everybody: a member that publishes step t
 // has read all of step t - 1, so all members have finished step t - 2's consumers).  Per step this drops the producer's
 // store drain + barrier + atomic and the consumer's counter round trip + barrier: what is left is one store -> load
-// latency through L2.  The host arms slots 0 and 1 (memset 0xFF) and packs the initial state into slot 3.
+// latency through L2.  The host arms slots 0 and 1 (memset 0xFF) and packs the initial state into slot 3 -- for a layer's first
+// launch.  The chunks of a chunked layer go on with the same ring (P.phase = steps carried so far): the previous launch's last
+// step left its state in slot (phase - 1) & 3, fragment-major as the consumers want it, and its last two steps armed slots
+// phase & 3 and (phase + 1) & 3 -- nothing to prepare, no launch in front of the chunk (round 4).
 // A lane's 16-byte element comes from ONE 16-byte store of one producer lane; all four words are checked, so a torn view of
 // that store would only delay the consumer, never feed it a sentinel.
 template <int MS, int SQ>                          // SQ = H/64: k-steps of 16 per wave
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) fo[ms] = ((min(rb0 + ms, rb_last) * S + w * SQ) * 256 + lane * 4) * 4;
     const f32x4 armed = __builtin_bit_cast(f32x4, chain::u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
+    const int ph = P.phase & 3;                    // the ring goes on where the layer's previous chunk left it
     for (int step = 0; step < P.T; ++step) {
         const int tt = P.reverse ? P.T - 1 - step : step;
         float pg[MS][4];                           // does not depend on h: requested before the poll
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
         }
         // poll the fragments of the previous step's state (slot (step - 1) & 3) until none of them is armed
         f32x4 A[MS][SQ];
-        const int in_base = ((step + 3) & 3) * slot_bytes;
+        const int in_base = ((ph + step + 3) & 3) * slot_bytes;
         for (unsigned spins = 0;; ++spins) {
             bool ok = true;
 #pragma unroll
@@ -410,8 +415,8 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
         __syncthreads();
         if (t < 64 * MS && rb0 + (t >> 6) <= rb_last) {
             const int rb = rb0 + (t >> 6);
-            chain::publish_block(rs, (step & 3) * slot_bytes, xt, t >> 6, lane, rb, S, member);
-            chain::st16_sc1(rs, ((step + 2) & 3) * slot_bytes + ((rb * S + member) * 256 + lane * 4) * 4, armed);   // re-arm
+            chain::publish_block(rs, ((ph + step) & 3) * slot_bytes, xt, t >> 6, lane, rb, S, member);
+            chain::st16_sc1(rs, ((ph + step + 2) & 3) * slot_bytes + ((rb * S + member) * 256 + lane * 4) * 4, armed);   // re-arm
         }
         // (round 4) what nobody in the launch reads -- output, cell state, the six saves -- is stored BEHIND the hand-off stores:
         // the memory pipe is in order, and eight scalar stores per thread used to go first
@@ -684,7 +689,8 @@ namespace {
 // (the state after step s_lo - 1: rows of `out` / `cseq`, or zeros).  The kernel sees a sequence of nt steps whose
 // buffers start at the chunk's lowest time index; the saves keep the full sequence's array stride.
 int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, const float* b_hh, const float* hprev,
-                   const float* cprev, int reverse, float* out, LstmWs& w, int save, int s_lo, int nt, hipStream_t s, int xrot = 0) {
+                   const float* cprev, int reverse, float* out, LstmWs& w, int save, int s_lo, int nt, hipStream_t s, int xrot = 0,
+                   bool ring_goes_on = false) {
     const long BH = (long)B * H, TBH = (long)T * BH;
     const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
     const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
@@ -694,16 +700,21 @@ int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, cons
     static const bool tag_on = [] { const char* e = std::getenv("INET_LSTM_TAG"); return !(e && e[0] == '0'); }();
     const bool tagged = tag_on && H == 256 && chain_ms(B, H) <= 2;
     // counters zeroed; tagged: slots 0, 1 armed and slot 3 = the previous step's h; counter protocol: slot 1 = that h
-    hipLaunchKernelGGL(lstm_chunk_prologue_kernel, dim3(16, 2), dim3(256), 0, s, w.sync, kSyncWords,
-                       reinterpret_cast<unsigned*>(w.hx), tagged ? 2L * (long)pk_floats(B, H) : 0L, hprev, B, H,
-                       w.hx + (tagged ? 3 : 1) * pk_floats(B, H));
-    if (hipGetLastError() != hipSuccess) return -2;
+    // (a tagged chunk behind another chunk of the same layer and call finds all of that in the ring: ring_goes_on)
+    const bool cont = tagged && ring_goes_on && s_lo > 0;
+    if (!cont) {
+        hipLaunchKernelGGL(lstm_chunk_prologue_kernel, dim3(16, 2), dim3(256), 0, s, w.sync, kSyncWords,
+                           reinterpret_cast<unsigned*>(w.hx), tagged ? 2L * (long)pk_floats(B, H) : 0L, hprev, B, H,
+                           w.hx + (tagged ? 3 : 1) * pk_floats(B, H));
+        if (hipGetLastError() != hipSuccess) return -2;
+    }
     LstmChainFwdArgs a{};
     a.B = B; a.H = H; a.T = nt; a.reverse = reverse; a.members = H / 16;
     a.gi = gi + t_lo * B * 4 * H; a.W_hh = W_hh; a.b_hh = b_hh; a.c0 = cprev;
     a.out = out + t_lo * BH; a.cseq = w.cseq + t_lo * BH;
     if (save) { a.sv = w.sv + t_lo * BH; a.sv_stride = TBH; }
     a.hx = w.hx; a.counters = w.sync; a.status = chain_status_for(w.sync + kStatusWord); a.xrot = xrot & 7;
+    a.phase = cont ? s_lo : 0;
     char label[64];
     std::snprintf(label, sizeof label, "lstm_chain_fwd ms%d T%d B%d H%d", ms, nt, B, H);
     ProfScope prof(PROF_GRU_FWD, 2.0 * nt * B * 4.0 * H * H, s, label,
@@ -785,11 +796,12 @@ int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, con
     if (pw_zero(w0.zeros, BH, s) != 0 || pw_zero(w1.zeros, BH, s) != 0) return -2;
     hipStream_t s2 = twin_fork(s);
     static const bool third = [] { const char* e = std::getenv("INET_LSTM_THIRD"); return !(e && e[0] == '0'); }();
+    static const bool ring_on = [] { const char* e = std::getenv("INET_LSTM_RING"); return !(e && e[0] == '0'); }();
     for (int s_lo = 0; s_lo < T; s_lo += CH) {
         const int nt = T - s_lo < CH ? T - s_lo : CH;
         const long t_lo = reverse ? T - (s_lo + nt) : s_lo, tp = reverse ? t_lo + nt : t_lo - 1;
         INET_TRY(lstm_chunk_fwd(B, T, H, gi0, W_hh0, b_hh0, s_lo ? out0 + tp * BH : w0.zeros, s_lo ? w0.cseq + tp * BH : w0.zeros,
-                                reverse, out0, w0, save, s_lo, nt, s));
+                                reverse, out0, w0, save, s_lo, nt, s, 0, ring_on));
         // the chunk's projection gi1 = out0 W_ih1^T + b_ih1 on a THIRD stream (a side stream forked behind layer 0's chunk), so
         // that layer 1's queue holds nothing but its chain launches: the product (30 us) runs under layer 1's previous chunk
         hipStream_t s3 = third ? side_fork(s) : s2;
@@ -797,7 +809,7 @@ int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, con
         INET_TRY(linear_fwd(out0 + t_lo * BH, H, W_ih1, H, b_ih1, gi1 + t_lo * B * 4 * H, 4L * H, nt * B, 4 * H, H, EPI_NONE, s3));
         if (s3 != s2) INET_TRY(stream_wait(s2, s3));
         INET_TRY(lstm_chunk_fwd(B, T, H, gi1, W_hh1, b_hh1, s_lo ? out1 + tp * BH : w1.zeros, s_lo ? w1.cseq + tp * BH : w1.zeros,
-                                reverse, out1, w1, save, s_lo, nt, s2, lstm_pipe_xrot()));
+                                reverse, out1, w1, save, s_lo, nt, s2, lstm_pipe_xrot(), ring_on));
     }
     return s2 != s ? twin_join(s) : 0;
 }
