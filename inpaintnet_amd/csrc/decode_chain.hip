@@ -113,6 +113,33 @@ __device__ __forceinline__ void contract_valu(f32x4 (&acc)[1][4], const int (&sl
         }
 }
 
+// reduce_waves through a buffer sized for two row blocks: the 64-row build (MS = 4) reduces its halves one after the other
+// (its [4 waves][4 acc][4 x 256] floats would not fit beside the 96 KB of W_ih(l1)).
+template <int MS, int NACC>
+__device__ __forceinline__ void reduce_tile(const f32x4 (&acc)[MS][4], float* red, int t, float (&out)[MS][NACC]) {
+    if constexpr (MS <= 2) {
+        reduce_waves<MS, NACC>(acc, red, t, out);
+    } else {
+        static_assert(MS == 4, "row blocks per group: 1, 2 or 4");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a2[2][4];
+            float o2[2][NACC];
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) a2[ms][a] = acc[2 * h + ms][a];
+            if (h) __syncthreads();                            // the first half has been read
+            reduce_waves<2, NACC>(a2, red, t, o2);
+            // reduce_waves hands thread t the elements t, t + 256 of its 32-row half: rows (t >> 4) and 16 + (t >> 4)
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) out[2 * h + ms][a] = o2[ms][a];
+        }
+    }
+}
+
 template <int MS, int SQ, bool TRAIN, int NV = 0, int VR = 0>  // SQ = H/64; TRAIN: dropout mask + backward saves; VR: VALU rows
 __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     static_assert(NV == 0 || (MS == 1 && !TRAIN && NV <= 4), "redundant logits: small-batch inference only");
@@ -121,7 +148,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wih = smem;                                   // [3][S][64][4]  W_ih(l1) slice, fragment-major
     float* const red = wih + 3 * S * 256;                      // [4 waves][4 acc][MS*256]
-    float* const xt = red + 4 * 4 * MS * 256;                  // [MS*256]
+    float* const xt = red + 4 * 4 * (MS < 2 ? MS : 2) * 256;   // [MS*256]  (red holds two row blocks at a time: reduce_tile)
     float* const xm = xt + MS * 256;                           // [MS*256] masked h0 (TRAIN)
     unsigned* const flag = reinterpret_cast<unsigned*>(xm + MS * 256);   // [2]
     int group, member;
@@ -252,7 +279,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             }
         }
         float v[MS][4];
-        reduce_waves<MS, 4>(acc, red, t, v);
+        reduce_tile<MS, 4>(acc, red, t, v);
         float sv[MS][6];                                       // TRAIN: r, z, n, ghn, h_prev, h0 as layer 1 sees it
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
@@ -311,7 +338,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
             if constexpr (VR > 0) contract_valu<3, SQ, VR>(acc, sx, gb, r_hxm, (tick & 1) * pkh * 4, rb0, S, w * SQ, lane);
             else contract_b<MS, 3, SQ>(acc, sx, gb, r_hxm, (masked ? beat : (tick & 1)) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
         }
-        reduce_waves<MS, 4>(acc, red, t, v);
+        reduce_tile<MS, 4>(acc, red, t, v);
 #pragma unroll
         for (int p = 0; p < MS; ++p) {
             const float ghn = v[p][3] + bh1[2];
@@ -423,7 +450,9 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     }
 }
 
-int rows_ms(int B) { return (B + 15) / 16 <= kDecodeMaxGroups ? 1 : 2; }      // the smallest tile that fits (gru_chain.hip)
+int rows_ms(int B) {                                            // the smallest tile that fits (gru_chain.hip)
+    return (B + 15) / 16 <= kDecodeMaxGroups ? 1 : (B + 31) / 32 <= kDecodeMaxGroups ? 2 : 4;
+}
 inline int groups_of(int B) { const int ms = rows_ms(B); return (B + 16 * ms - 1) / (16 * ms); }
 
 }  // namespace
@@ -439,7 +468,7 @@ bool decode_chain_ok(int B, int H, int V, int T, int G) {
 
 size_t decode_chain_lds_bytes(int B, int H) {
     const int ms = rows_ms(B), S = H / 16;
-    return (size_t)(3 * S * 256 + 4 * 4 * ms * 256 + 2 * ms * 256 + 4) * sizeof(float);
+    return (size_t)(3 * S * 256 + 4 * 4 * (ms < 2 ? ms : 2) * 256 + 2 * ms * 256 + 4) * sizeof(float);
 }
 
 int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
@@ -472,8 +501,8 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
 #define INET_DC4(M, Q, TR, NVV) INET_DC5(M, Q, TR, NVV, 0)
 #define INET_DC(M, Q, TR) INET_DC4(M, Q, TR, 0)
     if (train) {
-        if (a.H == 512) { if (ms == 1) INET_DC(1, 8, true); else INET_DC(2, 8, true); }
-        else { if (ms == 1) INET_DC(1, 4, true); else INET_DC(2, 4, true); }
+        if (a.H == 512) { if (ms == 1) INET_DC(1, 8, true); else if (ms == 2) INET_DC(2, 8, true); else INET_DC(4, 8, true); }
+        else { if (ms == 1) INET_DC(1, 4, true); else if (ms == 2) INET_DC(2, 4, true); else INET_DC(4, 4, true); }
     } else {
         // small-batch inference (one row block per group, V <= 64): every member computes the whole logits row itself
         static const bool fullv = [] { const char* v = std::getenv("INET_DECODE_FULLV"); return !(v && v[0] == '0'); }();
@@ -486,8 +515,8 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
         else if (nv == 4 && vr == 1) { if (a.H == 512) INET_DC5(1, 8, false, 4, 1); else INET_DC5(1, 4, false, 4, 1); }
         else if (nv == 3) { if (a.H == 512) INET_DC4(1, 8, false, 3); else INET_DC4(1, 4, false, 3); }
         else if (nv == 4) { if (a.H == 512) INET_DC4(1, 8, false, 4); else INET_DC4(1, 4, false, 4); }
-        else if (a.H == 512) { if (ms == 1) INET_DC(1, 8, false); else INET_DC(2, 8, false); }
-        else { if (ms == 1) INET_DC(1, 4, false); else INET_DC(2, 4, false); }
+        else if (a.H == 512) { if (ms == 1) INET_DC(1, 8, false); else if (ms == 2) INET_DC(2, 8, false); else INET_DC(4, 8, false); }
+        else { if (ms == 1) INET_DC(1, 4, false); else if (ms == 2) INET_DC(2, 4, false); else INET_DC(4, 4, false); }
     }
 #undef INET_DC
 #undef INET_DC4

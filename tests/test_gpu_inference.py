@@ -171,7 +171,8 @@ def test_arnn_forward_inpaint_and_baseline():
 
 
 @pytest.mark.parametrize("name,B", [("full", 5), ("full", 1), ("full", 16), ("full", 29), ("pk", 7), ("pk", 32),
-                                    ("v61", 5), ("v93", 33), ("pk20", 9), ("full125", 3)])
+                                    ("v61", 5), ("v93", 33), ("pk20", 9), ("full125", 3),
+                                    ("full", 300), ("full", 512), ("pk", 450)])     # 64-row groups (MS = 4), ragged and full
 def test_fused_decode_kernel_matches_per_tick_path(name, B):
     """The fused free-running decode (csrc/decode_chain.hip: 24 ticks x [layer 0, layer 1, projection + argmax] in one
     launch) against the per-tick launches and the oracle: logits to fp32 round-off, tokens exact on rows with a margin."""
@@ -216,6 +217,58 @@ def test_fused_decode_kernel_matches_per_tick_path(name, B):
     same = np.array_equal(s1.cpu().numpy(), s0.cpu().numpy())
     if same:
         assert G.rel_err(w1.cpu(), w0.cpu()) < 2e-5
+
+
+def test_fused_training_decode_of_512_rows_in_one_launch():
+    """The free-running half of a training step over 512 rows (LatentRNN decodes 128 x 4 target measures per step): ONE launch
+    of the 64-row build (`decode_chain_train ms4`) -- forward outputs, tokens and every gradient against the per-tick launches
+    (inet_set_option key 4 = 0) with the same dropout masks."""
+    import csv, os, tempfile
+    from tests.test_gpu_kernels import pack
+    c = G.CFGS["full"]
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    params = pack(table, total, G.vae_params("full"))
+    B, H, T = 512, c["H"], 24
+    z = torch.from_numpy(synthetic.det_normal("fused_train/512", (B, c["Z"]))).cuda()
+    mb = ops.dropout_mask((4, B, H), 0.5, 11, 0, "cuda")
+    mt = ops.dropout_mask((T, B, H), 0.5, 11, 4 * B * H, "cuda")
+    res = []
+    try:
+        for chain in (1, 0):
+            ops.set_option(4, chain)
+            ops.prof_enable(True)
+            w, smp, ws = ops.decoder_fwd(cfg, z, None, False, params, mask_beat=mb, mask_tick=mt, save=True)
+            torch.cuda.synchronize()
+            with tempfile.TemporaryDirectory() as td:
+                ops.prof_dump(os.path.join(td, "l.csv"))
+                labels = [r["label"] for r in csv.DictReader(open(os.path.join(td, "l.csv")))]
+            ops.prof_enable(False)
+            fused = [l for l in labels if l.startswith("decode_chain_train")]
+            assert (fused == [f"decode_chain_train ms4 T{T} B{B} H{H} V{c['V']}"]) if chain else not fused, fused
+            g = torch.zeros_like(params)
+            dw = torch.from_numpy(synthetic.det_normal("fused_train/dw", (B, T, c["V"]))).cuda() * 1e-3
+            dz = ops.decoder_bwd(cfg, dw, w, smp, params, g, mb, mt, ws)
+            torch.cuda.synchronize()
+            # the branch every SELU / ReLU element took (tests/test_gpu_kernels.py::_vae_step_with_kinks), per row
+            br = torch.cat([(ops.ws_field(cfg, ws, B, 1, "hb0").view(B, 2 * H) > 0),
+                            (ops.ws_field(cfg, ws, B, 1, "ht0").view(4, B, 2 * H) > 0).permute(1, 0, 2).reshape(B, -1),
+                            (ops.ws_field(cfg, ws, B, 1, "c_all").view(4, B, H) > 0).permute(1, 0, 2).reshape(B, -1),
+                            (w > 0).flatten(1)], 1)
+            res.append((w, smp, g, dz, br))
+    finally:
+        ops.set_option(4, 1)
+        ops.prof_enable(False)
+    assert ops.chain_status() == 0
+    (w1, s1, g1, dz1, br1), (w0, s0, g0, dz0, br0) = res
+    # comparable rows: the same 24 tokens (an argmax tie may flip a row) and the same branch at every SELU / ReLU (a
+    # pre-activation within round-off of 0 -- the beat chains differ by that between the two runs -- sits on the other side of
+    # the kink: its gradient is another one; row 148 of this input)
+    same = (s1 == s0).all(dim=-1).squeeze(1) & (br1 == br0).all(dim=1)
+    assert same.float().mean().item() > 0.99
+    assert G.rel_err(w1[same].cpu(), w0[same].cpu()) < 2e-5
+    assert G.rel_err(dz1[same].cpu(), dz0[same].cpu()) < 5e-5
+    assert G.rel_err(g1.cpu(), g0.cpu()) < (5e-5 if bool(same.all()) else 5e-3)
 
 
 def test_decoder_multinomial_sampling():
