@@ -100,8 +100,8 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
         assert sum(G.is_chain(l, "fwd", 2, 24, 256) for l in labels) == 4, gl
         assert sum(l.startswith("gru_chain_bwd") and " T24 " in l for l in labels) in (2, 4), gl
         assert sum(l.startswith("gru_chain_bwd") and " T6 " in l for l in labels) in (2, 4), gl
-        if not tf:
-            assert sum(l == "decode_chain_train ms2 T24 B256 H512 V48" for l in labels) == 2, gl
+        if not tf:                                               # 512 free-running rows: ONE launch of the 64-row build
+            assert sum(l == "decode_chain_train ms4 T24 B512 H512 V48" for l in labels) == 1, gl
     if B == 2048:
         assert any(l.startswith("gru_fwd") for l in labels) and any(l.startswith("gru_bwd") for l in labels)
         assert not any(l.startswith("gru_chain") for l in labels), sorted(set(l for l in labels if l.startswith("gru")))
@@ -257,8 +257,9 @@ def test_latent_step_at_bench_batch_vs_oracle(variant, tmp_path, monkeypatch):
     if variant == "nar":
         # generator (H = 1024, 4 target measures): first-generation chain launches, a group's 64 members on two XCDs
         assert sum(l == "gru_chain_fwd ms4 np2 T4 B128 H1024" for l in labels) == 2, sorted(set(l for l in labels if "H1024" in l))
-        # the frozen decoder's 512 free-running rows: the fused decode kernel over two chunks of 256 rows (with backward saves)
-        assert sum(l == "decode_chain_train ms2 T24 B256 H512 V48" for l in labels) == 2, sorted(set(l for l in labels if l.startswith("dec")))
+        # the frozen decoder's 512 free-running rows: ONE launch of the fused decode kernel's 64-row build (with backward saves;
+        # round 3: two launches of 256 rows)
+        assert sum(l == "decode_chain_train ms4 T24 B512 H512 V48" for l in labels) == 1, sorted(set(l for l in labels if l.startswith("dec")))
         assert sum(l == "gru_chain_bwd ms4 np2 T4 B128 H1024" for l in labels) == 2, sorted(set(l for l in labels if "H1024" in l))
     if free_ar:                                                     # one fused decode launch of 128 rows per generated measure
         assert sum(l.startswith("decode_chain_train") for l in labels) == n_target, sorted(set(l for l in labels if l.startswith("dec")))
