@@ -51,10 +51,12 @@ bool side_is(hipStream_t s) {
     return false;
 }
 
+namespace { void twin_create(); }
 hipStream_t side_fork(hipStream_t main_stream) {
     if (!side_enabled()) return main_stream;
     if (!g_init) {
         g_init = true;
+        twin_create();                // (the twin stream first, whoever asks first: see twin_fork)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         const char* v = std::getenv("INET_SIDE_STREAMS");
@@ -119,12 +121,20 @@ int side_wait_on(hipStream_t other) {
     return 0;
 }
 
-namespace { hipStream_t g_twin = nullptr; bool g_twin_tried = false, g_twin_dirty = false; }
+// The twin stream is created BEFORE the side streams, whichever of the two is asked for first: the runtime deals its hardware
+// queues to streams in creation order, and AnticipationRNN's layer pipelines (caller's stream + twin, both running chains) measured
+// 6.8 ms per step in a process whose first library call was theirs and 7.8 ms behind a MeasureVAE step, which creates the side
+// streams first (tools/arnn_order.py).
+namespace {
+hipStream_t g_twin = nullptr; bool g_twin_tried = false, g_twin_dirty = false;
+void twin_create() {
+    if (g_twin_tried) return;
+    g_twin_tried = true;
+    if (hipStreamCreateWithFlags(&g_twin, hipStreamNonBlocking) != hipSuccess) g_twin = nullptr;
+}
+}  // namespace
 hipStream_t twin_fork(hipStream_t main_stream) {
-    if (!g_twin_tried) {
-        g_twin_tried = true;
-        if (hipStreamCreateWithFlags(&g_twin, hipStreamNonBlocking) != hipSuccess) g_twin = nullptr;
-    }
+    twin_create();
     hipEvent_t e = g_twin ? next_event() : nullptr;
     if (!e || hipEventRecord(e, main_stream) != hipSuccess || hipStreamWaitEvent(g_twin, e, 0) != hipSuccess) return main_stream;
     g_twin_dirty = true;
