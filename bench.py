@@ -935,8 +935,9 @@ def main():
                 del la
                 wl.model.trainable = True                      # (LatentRNN froze the shared VAE)
                 wl.model.train()
-            # (the latency-bound workloads first: the AnticipationRNN step -- 1,536 dependent hand-offs -- measures 7.6 ms here and
-            #  9.6 ms at the end of the extras, after minutes of sustained load on the chip: tools/gc_ab.py, profiles/r04_a_arnn_ab.txt)
+            # (AnticipationRNN: 1,536 dependent hand-offs per step.  It used to measure 1 ms more here than alone -- the hardware queue
+            #  its second chain's stream got depended on which workload had created its streams first; csrc/side.hip creates them
+            #  in one order now: DESIGN.md section 8, tools/arnn_order.py)
             extras.update(arnn_extra())
             vae = wl.model if args.workload == "vae" else wl.model.vae_model
             extras.update(decode_latency_extra(vae))

@@ -402,7 +402,8 @@ def test_piece_outputs_written_by_chains_or_by_split_launches_give_the_same_step
             finally:
                 ops.set_option(key, default[key])
             tol = 2e-5 if key == 8 or bwd2 else 2e-6           # (another kernel's f32 summation order: the usual f32 bound)
-            assert abs(l - l0) <= 1e-6 * abs(l0), (key, val, l, l0)
+            # (the loss is a sum of B * T row terms accumulated with f32 atomics: its last bits depend on their order)
+            assert abs(l - l0) <= 4e-6 * abs(l0), (key, val, l, l0)
             assert relmax(w, w0) < tol, (key, val)
             bad = []
             for pname, off, shape in table:
