@@ -503,7 +503,9 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chain::contract_stream<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S4, w * SQ, lane);
+            // (a ring of 8 k-steps: with one gate block per k-step -- 4 MFMAs, 60 ns -- the GRU chains' ring of 4 covers a third
+            //  of the L2 latency; 8: +2 % on the AnticipationRNN step, 16: +1 %)
+            chain::contract_stream<MS, 1, SQ, 8>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S4, w * SQ, lane);
             reduce_waves<MS, 1>(acc, red, t, v);
         }
         if (tail) {
