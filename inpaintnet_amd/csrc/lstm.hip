@@ -769,7 +769,7 @@ int lstm_pipe_xrot() {
     return v;
 }
 int lstm_chunk_steps() {
-    static const int v = [] { const char* e = std::getenv("INET_LSTM_CHUNK"); return e ? std::atoi(e) : 48; }();
+    static const int v = [] { const char* e = std::getenv("INET_LSTM_CHUNK"); return e ? std::atoi(e) : 32; }();
     return v;
 }
 
