@@ -240,7 +240,7 @@ def test_arnn_bench_shape_step_with_input_dropout_vs_oracle(tmp_path, monkeypatc
     """The shape bench.py times (BASELINE.json configs[4]): 32 sequences x 384 ticks, H = 256, 2 + 2 LSTM layers, teacher
     forced, Dropout2d(0.2) on the shifted note embeddings -- the mask the product drew is recorded and replayed in the
     oracle (`input_mask`), every gradient tensor is compared element-wise, and the profile labels prove that both LSTM
-    stacks ran as the two-layer chunk pipeline (inet_lstm2_*: chain launches of 48 steps)."""
+    stacks ran as the two-layer chunk pipeline (inet_lstm2_*: chain launches of 32 steps)."""
     import csv
     name = "full"
     c = G.ARNN_CFGS[name]
@@ -280,10 +280,10 @@ def test_arnn_bench_shape_step_with_input_dropout_vs_oracle(tmp_path, monkeypatc
     assert ops.chain_status() == 0
     with open(tmp_path / "l.csv") as f:
         labels = [r["label"] for r in csv.DictReader(f)]
-    # two stacks x two layers x 8 chunks of 48 steps, forward and backward
-    nf = sum(l.startswith("lstm_chain_fwd") and " T48 B32 H256" in l for l in labels)
-    nb_ = sum(l.startswith("lstm_chain_bwd") and " T48 B32 H256" in l for l in labels)
-    assert nf == 32 and nb_ == 32, sorted(set(l for l in labels if l.startswith("lstm")))
+    # two stacks x two layers x 12 chunks of 32 steps, forward and backward
+    nf = sum(l.startswith("lstm_chain_fwd") and " T32 B32 H256" in l for l in labels)
+    nb_ = sum(l.startswith("lstm_chain_bwd") and " T32 B32 H256" in l for l in labels)
+    assert nf == 48 and nb_ == 48, sorted(set(l for l in labels if l.startswith("lstm")))
     assert [(sh, p) for sh, p, _ in rec] == [((L, B), 0.2)], [(sh, p) for sh, p, _ in rec]
     m = rec[0][2].cpu()                                            # [L,B], pre-scaled {0, 1/0.8}
     assert set(np.unique(m.numpy()).round(4)) <= {0.0, 1.25}
