@@ -856,14 +856,22 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
         INET_TRY(lstm_chunk_bwd(B, T, H, dout0, c ? in0 : nullptr, c ? in0 + BH : nullptr, reverse, dgi0, db_ih0, db_hh0,
                                 s_lo ? ou0 : nullptr, s_lo ? ou0 + BH : nullptr, w0, s_lo, nt, s2, areas ? c : -1, lstm_pipe_xrot()));
     }
-    if (s2 != s) INET_TRY(twin_join(s));
-    if (dW_hh0) {
-        // (handing each chunk's products to an in-order stream as soon as its gate gradients exist was slower -- 9.2 -> 10.5
-        // ms per AnticipationRNN step: beside the chains they slow every hand-off -- so they run once, after the pipeline)
-        // dW_hh += sum_t dg(t)^T h_prev(t) with h_prev(t) = out(t -/+ 1) (zero initial state); dW_ih1 += dgi1^T out0
-        hipStream_t ss = side_fork(s);
+    // Weight gradients, once per layer (handing each chunk's products to an in-order stream as soon as its gate gradients exist
+    // was slower -- 9.2 -> 10.5 ms per AnticipationRNN step: beside the chains they slow every hand-off):
+    // dW_hh += sum_t dg(t)^T h_prev(t) with h_prev(t) = out(t -/+ 1) (zero initial state); dW_ih1 += dgi1^T out0.
+    // Layer 1's two products start when ITS last chunk is done -- the caller's stream, before it joins layer 0's -- and run under
+    // layer 0's last chunk; only dW_hh0 is left behind the pipeline (INET_LSTM_WGRAD_EARLY=0: all three behind it).
+    static const bool early = [] { const char* e = std::getenv("INET_LSTM_WGRAD_EARLY"); return !(e && e[0] == '0'); }();
+    auto wgrad1 = [&](hipStream_t ss) -> int {
         INET_TRY(linear_wgrad(reverse ? dgi1 : dgi1 + B4H, 4L * H, reverse ? out1 + BH : out1, H, dW_hh1, H, (T - 1) * B, 4 * H, H, ss));
         INET_TRY(linear_wgrad(dgi1, 4L * H, out0, H, dW_ih1, H, T * B, 4 * H, H, ss));
+        return 0;
+    };
+    if (dW_hh0 && early) INET_TRY(wgrad1(side_fork(s)));
+    if (s2 != s) INET_TRY(twin_join(s));
+    if (dW_hh0) {
+        hipStream_t ss = side_fork(s);
+        if (!early) INET_TRY(wgrad1(ss));
         INET_TRY(linear_wgrad(reverse ? dgi0 : dgi0 + B4H, 4L * H, reverse ? out0 + BH : out0, H, dW_hh0, H, (T - 1) * B, 4 * H, H, ss));
     }
     return side_join(s);
