@@ -309,12 +309,22 @@ int inet_set_option(int key, int value);
  * key 12 = big-batch GRU forward steps on the bf16 pipe (csrc/gru_step_bf3.hip; INET_STEP_BF3_MIN_TILES): a layer whose single time
  * step has at least this many tiles of 128 rows x 64 units (default 256 = one per CU: B = 2048 at H = 512, two directions) runs one
  * product per step with the GRU cell as its epilogue instead of chunked chain launches; 0 = never.
+ * key 13 = how many of the side streams take leaf work in rotation from now on (0 = all that exist, default; 1: what a process with
+ * a gradient exchange beside its steps wants -- inpaintnet_amd.dp sets it: the runtime deals FOUR hardware queues, and caller + two
+ * side streams + the exchange's two streams measured 4.94 ms per B = 256 step against 3.87 with one side stream).
  * Keys 4, 7-12 must not change between a forward call and its backward call, nor between sizing a workspace and using it. */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.
  * Unlike inet_side_join nothing is consumed: the issuing stream still joins the same work at its own next join (a
  * data-parallel bucket's all-reduce stream orders itself behind the leaf GEMMs this way without the backward pass waiting). */
 int inet_side_wait(void* stream);
+/* The library's second compute stream ("twin": hipStream_t through *stream; created on first use, before the side streams).  The
+ * HIP runtime deals its hardware queues to streams in creation order and a process that keeps more than four of them busy is
+ * time-sliced (a fifth stream that carried the optimizer launch made every LatentRNN step 1.7x slower: DESIGN.md section 8), so a
+ * caller that wants work beside the library's own -- the trainer's late optimizer launch, a data-parallel bucket's pre-processing --
+ * borrows this stream instead of creating one; it orders it against its own stream with events.  The two-layer LSTM pipelines use
+ * the same stream inside their calls (never across calls).  -2 if the stream could not be created. */
+int inet_twin_stream(void** stream);
 /* Number of chain-kernel workgroups that gave up waiting for their group since the last reset (0 = healthy; every
  * in-kernel spin is bounded, so a broken hand-off shows up here instead of hanging the GPU).  Complete after the
  * stream has been synchronised; a non-zero value read earlier is already a definite failure (the counter lives in

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "inet_set_option": (C.c_int, [_I, _I]),
     "inet_side_join": (C.c_int, [_P]),
     "inet_side_wait": (C.c_int, [_P]),
+    "inet_twin_stream": (C.c_int, [C.POINTER(C.c_void_p)]),
     "inet_chain_status": (C.c_int, [_I]),
     "inet_prof_enable": (C.c_int, [_I]),
     "inet_prof_dump": (C.c_int, [C.c_char_p]),

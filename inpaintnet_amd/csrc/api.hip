@@ -438,6 +438,7 @@ int inet_set_option(int key, int value) {
     if (key == 9) { if (value < 0 || value > 7) return -1; bf3_set_emit_mask(value); return 0; }
     // (keys 10, 11 -- which layers' weight gradients run on the bf16 pipe; the second-generation BPTT kernel -- were removed in round 4)
     if (key == 12) { gru_step_bf3_set_min_tiles(value); return 0; }
+    if (key == 13) { if (value < 0 || value > 3) return -1; side_set_active(value); return 0; }
     return -1;
 }
 
@@ -451,6 +452,11 @@ int inet_chain_status(int reset) {
 
 int inet_side_join(void* stream) { return side_join_now((hipStream_t)stream); }
 int inet_side_wait(void* stream) { return side_wait_on((hipStream_t)stream); }
+int inet_twin_stream(void** stream) {
+    if (!stream) return -1;
+    *stream = (void*)twin_stream();
+    return *stream ? 0 : -2;
+}
 
 int inet_gru_step(int B, int H, const float* gi, const float* h_prev, const float* W_hh, const float* b_hh,
                   float* h_new, float* sv5, void* stream) {

@@ -18,12 +18,14 @@ int side_join_now(hipStream_t main_stream);
 int side_wait_on(hipStream_t other);
 void side_set_defer(int on);
 void side_set_enabled(int on);
+void side_set_active(int n);                        // side streams used in rotation from now on (1 .. created; 0: all) -- option key 13
 int side_enabled();
 bool side_is(hipStream_t s);                         // s is the side stream
 // A second stream of the main stream's kind for work that is split over two queues on purpose (row chunks of the frozen
 // encoder's chain launches): twin_fork() makes it wait for the main stream's current point, twin_join() the reverse.
 hipStream_t twin_fork(hipStream_t main_stream);      // returns main_stream itself if no stream could be created
 int twin_join(hipStream_t main_stream);
+hipStream_t twin_stream();                           // the twin stream itself (created on first use; null if it could not be)
 // `waiter` waits for everything queued on `on` so far (one event)
 int stream_wait(hipStream_t waiter, hipStream_t on);
 // A non-atomic accumulation into `dest` is about to be queued on side stream `s`: if another side stream has queued one into

@@ -45,6 +45,8 @@ int side_enabled() {
     return g_enabled;
 }
 void side_set_enabled(int on) { g_enabled = on ? 1 : 0; }
+namespace { int g_active = 0; }
+void side_set_active(int n) { g_active = n > 0 ? n : 0; }
 bool side_is(hipStream_t s) {
     for (int i = 0; i < g_nside; ++i)
         if (s == g_sides[i]) return true;
@@ -62,13 +64,14 @@ hipStream_t side_fork(hipStream_t main_stream) {
         const char* v = std::getenv("INET_SIDE_STREAMS");
         int want = v ? std::atoi(v) : 2;
         want = want < 1 ? 1 : (want > kMaxSide ? kMaxSide : want);
+        if (g_active > 0 && g_active < want) want = g_active;      // (key 13 set before the first fork: no more streams than will be used)
         for (int i = 0; i < want; ++i) {
             if (hipStreamCreateWithPriority(&g_sides[g_nside], hipStreamNonBlocking, lo) != hipSuccess) break;
             ++g_nside;
         }
     }
     if (g_nside == 0) return main_stream;
-    const int i = g_turn++ % g_nside;
+    const int i = g_turn++ % (g_active > 0 && g_active < g_nside ? g_active : g_nside);
     hipEvent_t e = next_event();
     if (!e || hipEventRecord(e, main_stream) != hipSuccess || hipStreamWaitEvent(g_sides[i], e, 0) != hipSuccess)
         return main_stream;
@@ -133,6 +136,7 @@ void twin_create() {
     if (hipStreamCreateWithFlags(&g_twin, hipStreamNonBlocking) != hipSuccess) g_twin = nullptr;
 }
 }  // namespace
+hipStream_t twin_stream() { twin_create(); return g_twin; }
 hipStream_t twin_fork(hipStream_t main_stream) {
     twin_create();
     hipEvent_t e = g_twin ? next_event() : nullptr;

@@ -39,6 +39,7 @@ def init_from_env(backend=None):
         return world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}
@@ -47,6 +48,8 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local_rank)
         kw["device_id"] = torch.device("cuda", local_rank)
     torch.distributed.init_process_group(backend=backend, **kw)
+    if backend == "nccl":
+        one_side_stream()
     return world
 
 
@@ -66,9 +69,21 @@ def seed_rank(seed, r=None):
     set_dropout_seed(seed, r)
 
 
+def one_side_stream():
+    """One side stream instead of two when a gradient exchange runs beside the steps (inet_set_option key 13): the process then keeps
+    caller, side, bucket and process-group streams busy and the runtime has four hardware queues to deal.  On one GPU, with a stand-in
+    all-reduce that really runs on its own stream, the B = 256 step measured 4.94 ms with two side streams and 3.87 ms with one (3.65
+    without any exchange; tools/dp_streams_1gpu.py, profiles/r04_c_arnn_xcd.txt).  INET_DP_SIDE_STREAMS=n overrides (0: all)."""
+    if torch.cuda.is_available():
+        from . import ops
+        ops.set_option(13, int(os.environ.get("INET_DP_SIDE_STREAMS", "1")))
+
+
 def broadcast_params(flat, src=0):
-    """Identical initial weights on every rank."""
+    """Identical initial weights on every rank (and, on the way, the library's stream budget for a process with an exchange)."""
     if world_size() > 1:
+        if flat.is_cuda:
+            one_side_stream()
         torch.distributed.broadcast(flat, src=src)
 
 

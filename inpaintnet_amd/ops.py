@@ -132,6 +132,21 @@ def side_join_on(stream):
     check(_lib.lib().inet_side_wait(C.c_void_p(stream.cuda_stream)), "inet_side_wait")
 
 
+_twin = {}
+
+
+def twin_stream(device=None):
+    """The library's second compute stream as a torch stream (inet_twin_stream).  Work that should run beside the caller's stream
+    goes HERE, not on a new torch.cuda.Stream(): a fifth busy stream in the process gets every stream time-sliced."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _twin:
+        h = C.c_void_p()
+        check(_lib.lib().inet_twin_stream(C.byref(h)), "inet_twin_stream")
+        _twin[key] = torch.cuda.ExternalStream(h.value, device=dev)
+    return _twin[key]
+
+
 def _hold(*tensors):
     if _DEFER:
         _HELD.append(tensors)
