@@ -86,3 +86,12 @@ def test_invalid_args_rejected(L):
     assert L.inet_vae_encoder_ws_bytes(C.byref(ok), 0, 0) == -1
     assert L.inet_vae_encoder_ws_bytes(C.byref(ok), 256, 1) > 0
     assert L.inet_vae_decoder_ws_bytes(C.byref(ok), 256, 1) > 0
+
+
+def test_option_keys_validate_their_values(L):
+    """inet_set_option rejects what it does not know (no GPU needed: the options are host state)."""
+    assert L.inet_set_option(13, 1) == 0 and L.inet_set_option(13, 0) == 0      # side streams in rotation: 0 (all) .. 3
+    assert L.inet_set_option(13, 4) == -1 and L.inet_set_option(13, -1) == -1
+    assert L.inet_set_option(10, 1) == -1 and L.inet_set_option(11, 1) == -1     # removed in round 4
+    assert L.inet_set_option(7, 6) == -1 and L.inet_set_option(8, 6) == -1       # six piece products: removed
+    assert L.inet_set_option(99, 0) == -1
