@@ -58,7 +58,9 @@ hipStream_t side_fork(hipStream_t main_stream) {
     if (!side_enabled()) return main_stream;
     if (!g_init) {
         g_init = true;
-        twin_create();                // (the twin stream first, whoever asks first: see twin_fork)
+        // (the twin stream first, whoever asks first: see twin_fork.  INET_TWIN_EAGER=0: only when a two-layer LSTM pipeline asks)
+        static const bool eager = [] { const char* v = std::getenv("INET_TWIN_EAGER"); return !(v && v[0] == '0'); }();
+        if (eager) twin_create();
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         const char* v = std::getenv("INET_SIDE_STREAMS");
