@@ -892,6 +892,8 @@ def main():
         ar_ms = allreduce_ms(wl.model.grad)
         dp_report = exchange_report(wl, dp, dt / args.steps, fence, dev)
         dp_report["chain_timeouts_per_rank"] = timeouts_per_rank
+        # (dp.one_side_stream: a process with an exchange keeps ONE side stream in rotation -- DESIGN.md section 6)
+        dp_report["side_streams_in_rotation"] = int(os.environ.get("INET_DP_SIDE_STREAMS", "1"))
         dp_report["skipped_steps_per_rank"] = skipped_per_rank
 
     extras = {}
