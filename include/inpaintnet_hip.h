@@ -249,6 +249,18 @@ int inet_lstm2_bwd(int batch, int T, int H, const float* W_hh0, const float* W_i
                    const float* out0, const float* out1, const float* dout1, int reverse, float* dgi0, float* dgi1,
                    float* dout0, float* dW_hh0, float* db_ih0, float* db_hh0, float* dW_ih1, float* dW_hh1,
                    float* db_ih1, float* db_hh1, void* ws0, void* ws1, int64_t ws_bytes, void* stream);
+
+/* The sequential part of AnticipationRNN's free-running pass (AnticipationRNN/anticipation_rnn_gauss_reg_model.py:190-259): the
+ * generation LSTMs feed the argmax of BATCH ELEMENT 0 back to the whole batch (:253-256), so the token sequence depends on that one
+ * row.  L ticks of [embedding of the previous token (start: token 0) | oc0 + t * oc_stride (the tick's constraint output, Hc floats)]
+ * -> LSTM 0 -> LSTM 1 -> ReLU(linear_1) -> note head -> argmax (lowest index on ties), queued as small launches without a host
+ * round trip; tokens [L] int64 on the device.  emb [.,E]; W_ih0 [4H, E+Hc]; W_ih1, W_hh* [4H,H]; W1 [U,H]; W2 [V,U].  The caller
+ * then runs the whole batch over these tokens with the batched kernels (inpaintnet_amd.arnn._forward_no_tf). */
+int64_t inet_arnn_generate_ws_floats(int E, int Hc, int H, int U, int V);
+int inet_arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, int64_t oc_stride,
+                       const float* W_ih0, const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
+                       const float* b_ih1, const float* W_hh1, const float* b_hh1, const float* W1, const float* b1,
+                       const float* W2, const float* b2, int64_t* tokens, float* ws, int64_t ws_floats, void* stream);
 /* nn.Embedding forward / backward (rows of E floats gathered by int64 index; backward accumulates with atomics).
  * row_scale (nullable, [rows]) multiplies each gathered row: the Dropout2d on the shifted note embeddings
  * (drop_input, anticipation_rnn_gauss_reg_model.py:437-442) and the all-zero first time step (:373-376). */

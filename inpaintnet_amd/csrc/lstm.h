@@ -15,3 +15,9 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
                   const float* out1, const float* dout1, int reverse, float* dgi0, float* dgi1, float* dout0, float* dW_hh0,
                   float* db_ih0, float* db_hh0, float* dW_ih1, float* dW_hh1, float* db_ih1, float* db_hh1, void* ws0,
                   void* ws1, hipStream_t s);
+// the sequential part of AnticipationRNN's free-running pass: L ticks of batch element 0 -> its argmax tokens (lstm.hip)
+size_t arnn_generate_ws_floats(int E, int Hc, int H, int U, int V);
+int arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, long oc_stride, const float* W_ih0,
+                  const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1, const float* b_ih1,
+                  const float* W_hh1, const float* b_hh1, const float* W1, const float* b1, const float* W2, const float* b2,
+                  long long* tokens, float* ws, hipStream_t s);

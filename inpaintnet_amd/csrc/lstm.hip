@@ -949,3 +949,55 @@ int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const 
     }
     return side_join(s);
 }
+
+// ---- AnticipationRNN's free-running pass, the part that is sequential (anticipation_rnn_gauss_reg_model.py:190-259) ---------------
+// The generation LSTMs feed back the argmax of BATCH ELEMENT 0 to the whole batch (:253-256) and nothing else of a tick's output:
+// the token sequence depends on batch element 0 alone.  This runs those L ticks for that one row -- per tick: input = [embedding of
+// the previous token | constraint output of the tick], two LSTM cells, linear_1 + ReLU, the note head, argmax -- as 8 small launches
+// per tick queued from here (no host round trip: the token stays on the device), and hands back the L tokens.  With them the
+// caller runs the whole batch through the batched (teacher-forced-shaped) kernels: 195 -> ~20 ms per training step.
+namespace {
+__global__ void arnn_input_kernel(const float* __restrict__ emb, int E, const long long* __restrict__ prev_tok,
+                                  const float* __restrict__ oc_t, int Hc, float* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long tok = prev_tok ? *prev_tok : 0;            // the start symbol is token 0 (:215-221)
+    if (i < E) x[i] = emb[tok * E + i];
+    else if (i < E + Hc) x[i] = oc_t[i - E];
+}
+}  // namespace
+
+size_t arnn_generate_ws_floats(int E, int Hc, int H, int U, int V) {
+    return (size_t)(E + Hc) + 4 * (size_t)H + 8 * (size_t)H + U + V + 64;
+}
+
+int arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, long oc_stride, const float* W_ih0,
+                  const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1, const float* b_ih1,
+                  const float* W_hh1, const float* b_hh1, const float* W1, const float* b1, const float* W2, const float* b2,
+                  long long* tokens, float* ws, hipStream_t s) {
+    float* x = ws;
+    float* gi = x + E + Hc;
+    float* hc = gi + 4 * H;                                     // [layer][h|c][ping-pong][H]
+    float* u = hc + 8 * H;
+    float* logits = u + U;
+    if (pw_zero(hc, 8L * H, s) != 0) return -2;
+    auto H_ = [&](int l, int p) { return hc + ((l * 2 + 0) * 2 + p) * H; };
+    auto C_ = [&](int l, int p) { return hc + ((l * 2 + 1) * 2 + p) * H; };
+    const int K0 = E + Hc;
+    for (int t = 0, p = 0; t < L; ++t, p ^= 1) {
+        hipLaunchKernelGGL(arnn_input_kernel, dim3((K0 + 255) / 256), dim3(256), 0, s, emb, E, t ? tokens + t - 1 : nullptr,
+                           oc0 + (long)t * oc_stride, Hc, x);
+        INET_TRY(linear_fwd(x, K0, W_ih0, K0, b_ih0, gi, 4L * H, 1, 4 * H, K0, EPI_NONE, s));
+        LstmFwdArgs a{};
+        a.B = 1; a.H = H; a.h_prev = H_(0, p); a.c_prev = C_(0, p); a.W_hh = W_hh0; a.b_hh = b_hh0; a.gi = gi;
+        a.h_new = H_(0, p ^ 1); a.c_new = C_(0, p ^ 1);
+        INET_TRY(launch_fwd(a, s));
+        INET_TRY(linear_fwd(H_(0, p ^ 1), H, W_ih1, H, b_ih1, gi, 4L * H, 1, 4 * H, H, EPI_NONE, s));
+        a.h_prev = H_(1, p); a.c_prev = C_(1, p); a.W_hh = W_hh1; a.b_hh = b_hh1;
+        a.h_new = H_(1, p ^ 1); a.c_new = C_(1, p ^ 1);
+        INET_TRY(launch_fwd(a, s));
+        INET_TRY(linear_fwd(H_(1, p ^ 1), H, W1, H, b1, u, U, 1, U, H, EPI_RELU, s));
+        INET_TRY(linear_fwd(u, U, W2, U, b2, logits, V, 1, V, U, EPI_NONE, s));
+        if (pw_argmax(logits, V, 1, V, tokens + t, 1, s) != 0) return -2;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

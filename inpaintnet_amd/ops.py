@@ -132,6 +132,24 @@ def side_join_on(stream):
     check(_lib.lib().inet_side_wait(C.c_void_p(stream.cuda_stream)), "inet_side_wait")
 
 
+def arnn_generate(emb, oc0, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1, W2, b2):
+    """inet_arnn_generate: the L argmax tokens of batch element 0 of AnticipationRNN's free-running pass.  oc0 [L,Hc] (rows may be
+    strided); -> tokens [L] int64 on the device, no host round trip."""
+    L, Hc = oc0.shape
+    assert oc0.stride(1) == 1
+    E, H, U, V = emb.shape[1], W_hh0.shape[1], W1.shape[0], W2.shape[0]
+    for t in (emb, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1, W2, b2):
+        _f32c(t)
+    nws = int(_lib.lib().inet_arnn_generate_ws_floats(E, Hc, H, U, V))
+    ws = torch.empty(nws, dtype=torch.float32, device=emb.device)
+    tokens = torch.empty(L, dtype=torch.int64, device=emb.device)
+    check(_lib.lib().inet_arnn_generate(L, E, Hc, H, U, V, ptr(emb), ptr(oc0), oc0.stride(0), ptr(W_ih0), ptr(b_ih0), ptr(W_hh0),
+                                        ptr(b_hh0), ptr(W_ih1), ptr(b_ih1), ptr(W_hh1), ptr(b_hh1), ptr(W1), ptr(b1), ptr(W2),
+                                        ptr(b2), ptr(tokens), ptr(ws), nws, stream_ptr()), "inet_arnn_generate")
+    _hold(ws, oc0)
+    return tokens
+
+
 _twin = {}
 
 

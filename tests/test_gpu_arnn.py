@@ -236,6 +236,36 @@ def test_arnn_free_running_backward_vs_oracle():
         assert not bad, bad
 
 
+def test_arnn_free_running_batched_form_equals_the_per_tick_loop(monkeypatch):
+    """The free-running pass as [one sequential pass over batch element 0 for the tokens (inet_arnn_generate) + the batched kernels
+    over the whole batch] against the per-tick loop of the reference's shape (INET_ARNN_FREE_RUN=loop): the same tokens, logits and
+    gradients (the reference feeds back only batch element 0's argmax, anticipation_rnn_gauss_reg_model.py:253-256)."""
+    from inpaintnet_amd import arnn
+    fx = G.load("arnn_small")
+    score = torch.from_numpy(fx["score"]).cuda()
+    md = torch.from_numpy(fx["metadata"]).cuda()
+    loc = torch.from_numpy(fx["constraints_loc"]).cuda()
+    a, b = [int(x) for x in fx["ticks"]]
+    res = []
+    for batched in (True, False):
+        monkeypatch.setattr(arnn, "_FREE_RUN_BATCHED", batched)
+        ds, model = build("small")
+        model.train()
+        model.zero_grad()
+        trainer = AnticipationRNNGaussianRegTrainer(ds, model)
+        weights, gen = model(score, md, loc, a, b, train=True, teacher_forcing=False)
+        loss, _ = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, score[:, :, a:b].transpose(0, 1))
+        loss.backward()
+        ops.side_join()
+        torch.cuda.synchronize()
+        res.append((weights[0].detach().clone(), gen.clone(), model.grad.clone(), float(loss.detach())))
+    (w1, g1, gr1, l1), (w0, g0, gr0, l0) = res
+    assert torch.equal(g1, g0)
+    assert G.rel_err(w1.cpu(), w0.cpu()) < 2e-5
+    assert abs(l1 - l0) < 1e-5 * abs(l0)
+    assert G.rel_err(gr1.cpu(), gr0.cpu()) < 1e-4
+
+
 def test_arnn_bench_shape_step_with_input_dropout_vs_oracle(tmp_path, monkeypatch):
     """The shape bench.py times (BASELINE.json configs[4]): 32 sequences x 384 ticks, H = 256, 2 + 2 LSTM layers, teacher
     forced, Dropout2d(0.2) on the shifted note embeddings -- the mask the product drew is recorded and replayed in the
