@@ -773,9 +773,20 @@ def arnn_extra(batch=32, steps=30, warmup=4, tables=True):
         loss.backward()
         trainer.step()
     dt, _ = timed(step, steps, warmup, torch.cuda.synchronize)
+
+    def step_fr():                                   # the coin's other side (the reference draws it per batch, p = 0.5)
+        trainer.zero_grad()
+        weights, _ = model(data[0], data[1], data[2], data[3], data[4], train=True, teacher_forcing=False)
+        free = free_positions(data[2])
+        loss, acc = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, data[0][:, :, free].transpose(0, 1))
+        loss.backward()
+        trainer.step()
+    dt_fr, _ = timed(step_fr, 10, 2, torch.cuda.synchronize)
     return {"anticipation_rnn_train": {"sequences_per_s": round(batch * steps / dt, 1),
                                        "measures_per_s": round(16 * batch * steps / dt, 1),
                                        "ms_per_step": round(1e3 * dt / steps, 3),
+                                       "ms_per_step_free_running": round(1e3 * dt_fr / 10, 3),
+                                       "ms_per_step_mean_of_the_coin": round(0.5e3 * (dt / steps + dt_fr / 10), 3),
                                        "kernels": secondary_table(step) if tables else None,
                                        "workload": "AnticipationRNN gauss-reg (LSTM 2x2 layers, H=256), teacher-forced "
                                                    "train step, 32 sequences x 384 ticks"}}
