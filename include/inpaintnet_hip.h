@@ -254,13 +254,16 @@ int inet_lstm2_bwd(int batch, int T, int H, const float* W_hh0, const float* W_i
  * generation LSTMs feed the argmax of BATCH ELEMENT 0 back to the whole batch (:253-256), so the token sequence depends on that one
  * row.  L ticks of [embedding of the previous token (start: token 0) | oc0 + t * oc_stride (the tick's constraint output, Hc floats)]
  * -> LSTM 0 -> LSTM 1 -> ReLU(linear_1) -> note head -> argmax (lowest index on ties), queued as small launches without a host
- * round trip; tokens [L] int64 on the device.  emb [.,E]; W_ih0 [4H, E+Hc]; W_ih1, W_hh* [4H,H]; W1 [U,H]; W2 [V,U].  The caller
- * then runs the whole batch over these tokens with the batched kernels (inpaintnet_amd.arnn._forward_no_tf). */
+ * round trip; tokens [L] int64 on the device.  emb [.,E]; W_ih0 [4H, E+Hc]; W_ih1, W_hh* [4H,H]; W1 [U,H]; W2 [V,U].  hc_init
+ * (nullable: zeros) = the state the ticks go on from, [layer][h | c][H]; first_tok (nullable: token 0) = device pointer to the token in
+ * front of the first tick -- forward_inpaint (:261-346) generates a window behind a teacher-forced prefix.  The caller then runs the
+ * whole batch over these tokens with the batched kernels (inpaintnet_amd.arnn._forward_no_tf / forward_inpaint). */
 int64_t inet_arnn_generate_ws_floats(int E, int Hc, int H, int U, int V);
 int inet_arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, int64_t oc_stride,
                        const float* W_ih0, const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
                        const float* b_ih1, const float* W_hh1, const float* b_hh1, const float* W1, const float* b1,
-                       const float* W2, const float* b2, int64_t* tokens, float* ws, int64_t ws_floats, void* stream);
+                       const float* W2, const float* b2, const float* hc_init, const int64_t* first_tok, int64_t* tokens, float* ws,
+                       int64_t ws_floats, void* stream);
 /* nn.Embedding forward / backward (rows of E floats gathered by int64 index; backward accumulates with atomics).
  * row_scale (nullable, [rows]) multiplies each gathered row: the Dropout2d on the shifted note embeddings
  * (drop_input, anticipation_rnn_gauss_reg_model.py:437-442) and the all-zero first time step (:373-376). */

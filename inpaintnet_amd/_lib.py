@@ -120,7 +120,7 @@ _SIGNATURES = {
     "inet_set_option": (C.c_int, [_I, _I]),
     "inet_side_join": (C.c_int, [_P]),
     "inet_arnn_generate_ws_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
-    "inet_arnn_generate": (C.c_int, [_I] * 6 + [_P, _P, _L] + [_P] * 12 + [_P, _P, _L, _P]),
+    "inet_arnn_generate": (C.c_int, [_I] * 6 + [_P, _P, _L] + [_P] * 12 + [_P, _P, _P, _P, _L, _P]),
     "inet_side_wait": (C.c_int, [_P]),
     "inet_twin_stream": (C.c_int, [C.POINTER(C.c_void_p)]),
     "inet_chain_status": (C.c_int, [_I]),

@@ -324,6 +324,33 @@ class ConstraintModelGaussianReg(Model):
             for l in range(self.num_layers):
                 h, hT, cT = self._lstm(f"lstm_generation.{l}", h, False)
                 states[l] = (hT, cT)
+        if _FREE_RUN_BATCHED and self.num_layers == 2 and oc.is_cuda:
+            # as in _forward_no_tf: the window's tokens depend on batch element 0 alone (its state behind the prefix, its token in
+            # front of the window) -- one sequential pass over that row, then the window for the whole batch in one batched pass
+            W, H, dev = end_tick - start_tick, self.num_lstm_generation_units, gen.device
+            pr = self.param
+            with torch.no_grad():
+                hc = None
+                if start_tick > 0:
+                    hc = torch.stack([torch.stack((states[l][0].reshape(-1, H)[0], states[l][1].reshape(-1, H)[0])) for l in range(2)])
+                first = gen[0, 0, start_tick - 1].reshape(1).contiguous() if start_tick > 0 else None
+                toks = ops.arnn_generate(pr("note_embeddings.0.weight"), oc.detach()[start_tick:end_tick, 0, :],
+                                         pr("lstm_generation.0.weight_ih_l0"), pr("lstm_generation.0.bias_ih_l0"),
+                                         pr("lstm_generation.0.weight_hh_l0"), pr("lstm_generation.0.bias_hh_l0"),
+                                         pr("lstm_generation.1.weight_ih_l0"), pr("lstm_generation.1.bias_ih_l0"),
+                                         pr("lstm_generation.1.weight_hh_l0"), pr("lstm_generation.1.bias_hh_l0"),
+                                         pr("linear_1.weight"), pr("linear_1.bias"),
+                                         pr("linear_ouput_notes.0.weight"), pr("linear_ouput_notes.0.bias"),
+                                         hc_init=hc.contiguous() if hc is not None else None, first_tok=first)
+                gen[:, 0, start_tick:end_tick] = toks.view(1, W)
+                # the token in front of the window is each row's own ground truth (or the start symbol), behind it the generated ones
+                row0 = gen[:, 0, start_tick - 1].reshape(1, B) if start_tick > 0 else torch.zeros(1, B, dtype=torch.int64, device=dev)
+                prev_tm = torch.cat((row0, toks[:-1].view(W - 1, 1).expand(W - 1, B)), 0).contiguous()
+            inp = torch.cat((self._embed("note_embeddings.0.weight", prev_tm), oc[start_tick:end_tick]), 2)
+            for l in range(self.num_layers):
+                inp, _, _ = self._lstm(f"lstm_generation.{l}", inp, False, states[l])
+            w = self._head(inp.view(W * B, -1)).view(W, B, -1).permute(1, 0, 2)
+            return [w], gen
         ws = []
         for tick in range(start_tick - 1, end_tick - 1):
             # token at `tick` predicts tick + 1; before the first tick the start symbol 0 is embedded (:308-313)

@@ -383,13 +383,14 @@ int64_t inet_arnn_generate_ws_floats(int E, int Hc, int H, int U, int V) {
 int inet_arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, int64_t oc_stride,
                        const float* W_ih0, const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
                        const float* b_ih1, const float* W_hh1, const float* b_hh1, const float* W1, const float* b1,
-                       const float* W2, const float* b2, int64_t* tokens, float* ws, int64_t ws_floats, void* stream) {
+                       const float* W2, const float* b2, const float* hc_init, const int64_t* first_tok, int64_t* tokens, float* ws,
+                       int64_t ws_floats, void* stream) {
     if (L <= 0 || E <= 0 || Hc < 0 || H <= 0 || H % 16 || U <= 0 || V <= 0 || !emb || (Hc && !oc0) || !W_ih0 || !b_ih0 || !W_hh0 ||
         !b_hh0 || !W_ih1 || !b_ih1 || !W_hh1 || !b_hh1 || !W1 || !b1 || !W2 || !b2 || !tokens || !ws)
         return -1;
     if (ws_floats < (int64_t)arnn_generate_ws_floats(E, Hc, H, U, V)) return -1;
     return arnn_generate(L, E, Hc, H, U, V, emb, oc0, (long)oc_stride, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1,
-                         W2, b2, (long long*)tokens, ws, (hipStream_t)stream);
+                         W2, b2, hc_init, (const long long*)first_tok, (long long*)tokens, ws, (hipStream_t)stream);
 }
 int inet_lstm2_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, const float* W_hh1, const float* out0,
                    const float* out1, const float* dout1, int reverse, float* dgi0, float* dgi1, float* dout0,

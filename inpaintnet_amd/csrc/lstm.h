@@ -20,4 +20,4 @@ size_t arnn_generate_ws_floats(int E, int Hc, int H, int U, int V);
 int arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, long oc_stride, const float* W_ih0,
                   const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1, const float* b_ih1,
                   const float* W_hh1, const float* b_hh1, const float* W1, const float* b1, const float* W2, const float* b2,
-                  long long* tokens, float* ws, hipStream_t s);
+                  const float* hc_init, const long long* first_tok, long long* tokens, float* ws, hipStream_t s);

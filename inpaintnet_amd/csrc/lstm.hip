@@ -973,7 +973,7 @@ size_t arnn_generate_ws_floats(int E, int Hc, int H, int U, int V) {
 int arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, long oc_stride, const float* W_ih0,
                   const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1, const float* b_ih1,
                   const float* W_hh1, const float* b_hh1, const float* W1, const float* b1, const float* W2, const float* b2,
-                  long long* tokens, float* ws, hipStream_t s) {
+                  const float* hc_init, const long long* first_tok, long long* tokens, float* ws, hipStream_t s) {
     float* x = ws;
     float* gi = x + E + Hc;
     float* hc = gi + 4 * H;                                     // [layer][h|c][ping-pong][H]
@@ -982,9 +982,13 @@ int arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, c
     if (pw_zero(hc, 8L * H, s) != 0) return -2;
     auto H_ = [&](int l, int p) { return hc + ((l * 2 + 0) * 2 + p) * H; };
     auto C_ = [&](int l, int p) { return hc + ((l * 2 + 1) * 2 + p) * H; };
+    if (hc_init)                                               // [layer][h | c][H]: the state the ticks go on from (inpainting: after the prefix)
+        for (int l = 0; l < 2; ++l)
+            if (pw_copy_bytes(H_(l, 0), hc_init + (2 * l) * H, H * sizeof(float), s) != 0 ||
+                pw_copy_bytes(C_(l, 0), hc_init + (2 * l + 1) * H, H * sizeof(float), s) != 0) return -2;
     const int K0 = E + Hc;
     for (int t = 0, p = 0; t < L; ++t, p ^= 1) {
-        hipLaunchKernelGGL(arnn_input_kernel, dim3((K0 + 255) / 256), dim3(256), 0, s, emb, E, t ? tokens + t - 1 : nullptr,
+        hipLaunchKernelGGL(arnn_input_kernel, dim3((K0 + 255) / 256), dim3(256), 0, s, emb, E, t ? tokens + t - 1 : first_tok,
                            oc0 + (long)t * oc_stride, Hc, x);
         INET_TRY(linear_fwd(x, K0, W_ih0, K0, b_ih0, gi, 4L * H, 1, 4 * H, K0, EPI_NONE, s));
         LstmFwdArgs a{};

@@ -132,9 +132,10 @@ def side_join_on(stream):
     check(_lib.lib().inet_side_wait(C.c_void_p(stream.cuda_stream)), "inet_side_wait")
 
 
-def arnn_generate(emb, oc0, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1, W2, b2):
+def arnn_generate(emb, oc0, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1, W2, b2, hc_init=None, first_tok=None):
     """inet_arnn_generate: the L argmax tokens of batch element 0 of AnticipationRNN's free-running pass.  oc0 [L,Hc] (rows may be
-    strided); -> tokens [L] int64 on the device, no host round trip."""
+    strided); hc_init [2,2,H] (layer, h|c) or None (zeros); first_tok: 1-element int64 device tensor or None (token 0);
+    -> tokens [L] int64 on the device, no host round trip."""
     L, Hc = oc0.shape
     assert oc0.stride(1) == 1
     E, H, U, V = emb.shape[1], W_hh0.shape[1], W1.shape[0], W2.shape[0]
@@ -145,8 +146,10 @@ def arnn_generate(emb, oc0, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_h
     tokens = torch.empty(L, dtype=torch.int64, device=emb.device)
     check(_lib.lib().inet_arnn_generate(L, E, Hc, H, U, V, ptr(emb), ptr(oc0), oc0.stride(0), ptr(W_ih0), ptr(b_ih0), ptr(W_hh0),
                                         ptr(b_hh0), ptr(W_ih1), ptr(b_ih1), ptr(W_hh1), ptr(b_hh1), ptr(W1), ptr(b1), ptr(W2),
-                                        ptr(b2), ptr(tokens), ptr(ws), nws, stream_ptr()), "inet_arnn_generate")
-    _hold(ws, oc0)
+                                        ptr(b2), ptr(_f32c(hc_init) if hc_init is not None else None),
+                                        ptr(_i64c(first_tok) if first_tok is not None else None), ptr(tokens), ptr(ws), nws,
+                                        stream_ptr()), "inet_arnn_generate")
+    _hold(ws, oc0, hc_init, first_tok)
     return tokens
 
 

@@ -266,6 +266,31 @@ def test_arnn_free_running_batched_form_equals_the_per_tick_loop(monkeypatch):
     assert G.rel_err(gr1.cpu(), gr0.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("window", ["golden", "from_zero", "to_end"])
+def test_arnn_forward_inpaint_batched_form_equals_the_per_tick_loop(window, monkeypatch):
+    """forward_inpaint the same way: the window's tokens from one sequential pass over batch element 0 behind the teacher-forced
+    prefix (its state, its token in front of the window), the window for the whole batch in one batched pass -- against the loop."""
+    from inpaintnet_amd import arnn
+    fx = G.load("arnn_small")
+    score = torch.from_numpy(fx["score"]).cuda()
+    md = torch.from_numpy(fx["metadata"]).cuda()
+    loc = torch.from_numpy(fx["constraints_loc"]).cuda()
+    L = score.shape[2]
+    a, b = {"golden": [int(x) for x in fx["ticks"]], "from_zero": (0, 30), "to_end": (L - 40, L)}[window]
+    ds, model = build("small")
+    model.eval()
+    res = []
+    for batched in (True, False):
+        monkeypatch.setattr(arnn, "_FREE_RUN_BATCHED", batched)
+        with torch.no_grad():
+            w, gen = model.forward_inpaint(score, md, loc, a, b)
+        torch.cuda.synchronize()
+        res.append((w[0].clone(), gen.clone()))
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][0].shape == res[1][0].shape == (score.shape[0], b - a, res[0][0].shape[-1])
+    assert G.rel_err(res[0][0].cpu(), res[1][0].cpu()) < 2e-5
+
+
 def test_arnn_bench_shape_step_with_input_dropout_vs_oracle(tmp_path, monkeypatch):
     """The shape bench.py times (BASELINE.json configs[4]): 32 sequences x 384 ticks, H = 256, 2 + 2 LSTM layers, teacher
     forced, Dropout2d(0.2) on the shifted note embeddings -- the mask the product drew is recorded and replayed in the
