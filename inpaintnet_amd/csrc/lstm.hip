@@ -953,16 +953,103 @@ int lstm_seq_bwd(int B, int T, int H, const float* W_hh, const float* h0, const 
 // ---- AnticipationRNN's free-running pass, the part that is sequential (anticipation_rnn_gauss_reg_model.py:190-259) ---------------
 // The generation LSTMs feed back the argmax of BATCH ELEMENT 0 to the whole batch (:253-256) and nothing else of a tick's output:
 // the token sequence depends on batch element 0 alone.  This runs those L ticks for that one row -- per tick: input = [embedding of
-// the previous token | constraint output of the tick], two LSTM cells, linear_1 + ReLU, the note head, argmax -- as 8 small launches
+// the previous token | constraint output of the tick], two LSTM cells, linear_1 + ReLU, the note head, argmax -- as 4 small launches
 // per tick queued from here (no host round trip: the token stays on the device), and hands back the L tokens.  With them the
 // caller runs the whole batch through the batched (teacher-forced-shaped) kernels: 195 -> ~20 ms per training step.
 namespace {
-__global__ void arnn_input_kernel(const float* __restrict__ emb, int E, const long long* __restrict__ prev_tok,
-                                  const float* __restrict__ oc_t, int Hc, float* __restrict__ x) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const long long tok = prev_tok ? *prev_tok : 0;            // the start symbol is token 0 (:215-221)
-    if (i < E) x[i] = emb[tok * E + i];
-    else if (i < E + Hc) x[i] = oc_t[i - E];
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// dot products of ONE row against weight rows, lanes striding over k: every load of a wave is issued before the first multiply (NI =
+// ceil(K / 64) is a template bound: a runtime k loop waits for each 64-wide slice in turn -- 7 us per launch instead of 2)
+template <int NI>
+__device__ __forceinline__ void load_x(float (&xv)[NI], const float* pa, int Ka, const float* pb, int K, int lane) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int k = lane + 64 * i;
+        xv[i] = k < Ka ? pa[k] : (k < K ? pb[k - Ka] : 0.f);
+    }
+}
+template <int NI>
+__device__ __forceinline__ float dot_row(const float* __restrict__ Wrow, const float (&xv)[NI], int K, int lane) {
+    float wv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int k = lane + 64 * i; wv[i] = k < K ? Wrow[k] : 0.f; }
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a = fmaf(wv[i], xv[i], a);
+    return a;
+}
+
+// One LSTM cell for ONE row, both products in the launch: gates = W_ih [xa | xb] + b_ih + W_hh h_prev + b_hh.  One wave per hidden
+// unit (its four gate rows), four units per workgroup.  xa = the embedding row of *tok (tok null: token 0) when `emb` is given.
+template <int NI, int NH>
+__global__ __launch_bounds__(256) void lstm_cell_b1_kernel(const float* __restrict__ emb, const long long* __restrict__ tok,
+                                                           const float* __restrict__ xa, int Ka, const float* __restrict__ xb, int Kb,
+                                                           const float* __restrict__ W_ih, const float* __restrict__ b_ih,
+                                                           const float* __restrict__ h_prev, const float* __restrict__ c_prev,
+                                                           const float* __restrict__ W_hh, const float* __restrict__ b_hh,
+                                                           float* __restrict__ h_new, float* __restrict__ c_new, int H) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    const int K = Ka + Kb;
+    const float* pa = emb ? emb + (tok ? *tok : 0) * Ka : xa;
+    float xv[NI], hv[NH];
+    load_x<NI>(xv, pa, Ka, xb, K, lane);
+    load_x<NH>(hv, h_prev, H, nullptr, H, lane);
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        pre[g] = dot_row<NI>(W_ih + (long)(g * H + j) * K, xv, K, lane) + dot_row<NH>(W_hh + (long)(g * H + j) * H, hv, H, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = wave_sum(pre[g]);
+    if (lane == 0) {
+        const float i = sigmoid_f(pre[0] + b_ih[j] + b_hh[j]);
+        const float f = sigmoid_f(pre[1] + b_ih[H + j] + b_hh[H + j]);
+        const float g = tanh_f(pre[2] + b_ih[2 * H + j] + b_hh[2 * H + j]);
+        const float o = sigmoid_f(pre[3] + b_ih[3 * H + j] + b_hh[3 * H + j]);
+        const float c = f * c_prev[j] + i * g;
+        c_new[j] = c;
+        h_new[j] = o * tanh_f(c);
+    }
+}
+
+// y[j] = ReLU(W[j,:] . x + b[j]) for ONE row: a wave per output
+template <int NI>
+__global__ __launch_bounds__(256) void relu_linear_b1_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                             const float* __restrict__ b, float* __restrict__ y, int N, int K) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= N) return;
+    float xv[NI];
+    load_x<NI>(xv, x, K, nullptr, K, lane);
+    const float v = wave_sum(dot_row<NI>(W + (long)j * K, xv, K, lane));
+    if (lane == 0) y[j] = fmaxf(v + b[j], 0.f);
+}
+
+// token = argmax_v (W[v,:] . x + b[v]), lowest index on ties, V <= 256: ONE workgroup (a wave per row in turn), the logits through LDS
+template <int NI>
+__global__ __launch_bounds__(1024) void head_argmax_b1_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                              const float* __restrict__ b, long long* __restrict__ tok, int V, int K) {
+    __shared__ float lg[256];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float xv[NI];
+    load_x<NI>(xv, x, K, nullptr, K, lane);
+    for (int v = w; v < V; v += 16) {                          // 16 waves: V = 48 is three rows per wave
+        const float a = wave_sum(dot_row<NI>(W + (long)v * K, xv, K, lane));
+        if (lane == 0) lg[v] = a + b[v];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float best = lg[0];
+        int bi = 0;
+        for (int v = 1; v < V; ++v)
+            if (lg[v] > best) { best = lg[v]; bi = v; }
+        *tok = bi;
+    }
 }
 }  // namespace
 
@@ -974,11 +1061,8 @@ int arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, c
                   const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1, const float* b_ih1,
                   const float* W_hh1, const float* b_hh1, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* hc_init, const long long* first_tok, long long* tokens, float* ws, hipStream_t s) {
-    float* x = ws;
-    float* gi = x + E + Hc;
-    float* hc = gi + 4 * H;                                     // [layer][h|c][ping-pong][H]
+    float* hc = ws;                                            // [layer][h|c][ping-pong][H]
     float* u = hc + 8 * H;
-    float* logits = u + U;
     if (pw_zero(hc, 8L * H, s) != 0) return -2;
     auto H_ = [&](int l, int p) { return hc + ((l * 2 + 0) * 2 + p) * H; };
     auto C_ = [&](int l, int p) { return hc + ((l * 2 + 1) * 2 + p) * H; };
@@ -986,22 +1070,17 @@ int arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, c
         for (int l = 0; l < 2; ++l)
             if (pw_copy_bytes(H_(l, 0), hc_init + (2 * l) * H, H * sizeof(float), s) != 0 ||
                 pw_copy_bytes(C_(l, 0), hc_init + (2 * l + 1) * H, H * sizeof(float), s) != 0) return -2;
-    const int K0 = E + Hc;
+    // per tick four launches (round 4's first form had eight: input build, two GEMVs + two cell kernels, two head GEMVs, argmax)
+    if (V > 256 || E + Hc > 320 || H > 256 || U > 256) return -1;      // (the template bounds of the one-row kernels)
     for (int t = 0, p = 0; t < L; ++t, p ^= 1) {
-        hipLaunchKernelGGL(arnn_input_kernel, dim3((K0 + 255) / 256), dim3(256), 0, s, emb, E, t ? tokens + t - 1 : first_tok,
-                           oc0 + (long)t * oc_stride, Hc, x);
-        INET_TRY(linear_fwd(x, K0, W_ih0, K0, b_ih0, gi, 4L * H, 1, 4 * H, K0, EPI_NONE, s));
-        LstmFwdArgs a{};
-        a.B = 1; a.H = H; a.h_prev = H_(0, p); a.c_prev = C_(0, p); a.W_hh = W_hh0; a.b_hh = b_hh0; a.gi = gi;
-        a.h_new = H_(0, p ^ 1); a.c_new = C_(0, p ^ 1);
-        INET_TRY(launch_fwd(a, s));
-        INET_TRY(linear_fwd(H_(0, p ^ 1), H, W_ih1, H, b_ih1, gi, 4L * H, 1, 4 * H, H, EPI_NONE, s));
-        a.h_prev = H_(1, p); a.c_prev = C_(1, p); a.W_hh = W_hh1; a.b_hh = b_hh1;
-        a.h_new = H_(1, p ^ 1); a.c_new = C_(1, p ^ 1);
-        INET_TRY(launch_fwd(a, s));
-        INET_TRY(linear_fwd(H_(1, p ^ 1), H, W1, H, b1, u, U, 1, U, H, EPI_RELU, s));
-        INET_TRY(linear_fwd(u, U, W2, U, b2, logits, V, 1, V, U, EPI_NONE, s));
-        if (pw_argmax(logits, V, 1, V, tokens + t, 1, s) != 0) return -2;
+        hipLaunchKernelGGL((lstm_cell_b1_kernel<5, 4>), dim3(H / 4), dim3(256), 0, s, emb, t ? tokens + t - 1 : first_tok,
+                           (const float*)nullptr, E, oc0 + (long)t * oc_stride, Hc, W_ih0, b_ih0, (const float*)H_(0, p),
+                           (const float*)C_(0, p), W_hh0, b_hh0, H_(0, p ^ 1), C_(0, p ^ 1), H);
+        hipLaunchKernelGGL((lstm_cell_b1_kernel<4, 4>), dim3(H / 4), dim3(256), 0, s, (const float*)nullptr, (const long long*)nullptr,
+                           (const float*)H_(0, p ^ 1), H, (const float*)nullptr, 0, W_ih1, b_ih1, (const float*)H_(1, p),
+                           (const float*)C_(1, p), W_hh1, b_hh1, H_(1, p ^ 1), C_(1, p ^ 1), H);
+        hipLaunchKernelGGL((relu_linear_b1_kernel<4>), dim3((U + 3) / 4), dim3(256), 0, s, (const float*)H_(1, p ^ 1), W1, b1, u, U, H);
+        hipLaunchKernelGGL((head_argmax_b1_kernel<4>), dim3(1), dim3(1024), 0, s, (const float*)u, W2, b2, tokens + t, V, U);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
