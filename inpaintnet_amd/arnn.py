@@ -264,10 +264,10 @@ class ConstraintModelGaussianReg(Model):
         dev = score_tensor.device
         if _FREE_RUN_BATCHED and self.num_layers == 2 and oc.is_cuda:
             # Only the argmax of batch element 0 is fed back (:253-256): its L tokens come from one sequential pass over that one row
-            # (ops.arnn_generate: 8 small launches per tick, no host round trip, no autograd), and with the tokens known the whole
+            # (ops.arnn_generate: 4 small launches per tick, no host round trip, no autograd), and with the tokens known the whole
             # batch goes through the batched kernels -- the same graph as the teacher-forced pass over the sequence [0, tok_0, ..,
             # tok_{L-2}] (the start symbol is TOKEN 0 here, not the zero vector, and there is no input dropout: :215-231).
-            # 195 -> ~20 ms per training step; INET_ARNN_FREE_RUN=loop: the per-tick loop below.
+            # 195 -> 14 ms per training step; INET_ARNN_FREE_RUN=loop: the per-tick loop below.
             pr = self.param
             with torch.no_grad():
                 toks = ops.arnn_generate(pr("note_embeddings.0.weight"), oc.detach()[:, 0, :],
