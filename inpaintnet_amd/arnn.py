@@ -256,13 +256,21 @@ class ConstraintModelGaussianReg(Model):
         w = self._head(h.view(L * B, -1)).view(L, B, -1).permute(1, 0, 2)
         return [w], None
 
+    def _batched_free_run(self, oc):
+        """Whether the free-running passes take the [token pass over batch element 0 + batched kernels] form (else: the per-tick loop)."""
+        if not (_FREE_RUN_BATCHED and self.num_layers == 2 and oc.is_cuda):
+            return False
+        E = self.param("note_embeddings.0.weight").shape[1]
+        U, V = self.param("linear_1.weight").shape[0], self.param("linear_ouput_notes.0.weight").shape[0]
+        return ops.arnn_generate_ok(E, oc.shape[-1], self.num_lstm_generation_units, U, V)
+
     def _forward_no_tf(self, score_tensor, metadata_tensor, constraints_loc):
         """-> [weights (B,L,V)], gen_chorale (B,1,L): the argmax of BATCH ELEMENT 0 is fed to the whole batch
         (:190-259, quirk at :253-256)."""
         B, _, L = score_tensor.shape
         oc = self._constraints(score_tensor, metadata_tensor, constraints_loc)
         dev = score_tensor.device
-        if _FREE_RUN_BATCHED and self.num_layers == 2 and oc.is_cuda:
+        if self._batched_free_run(oc):
             # Only the argmax of batch element 0 is fed back (:253-256): its L tokens come from one sequential pass over that one row
             # (ops.arnn_generate: 4 small launches per tick, no host round trip, no autograd), and with the tokens known the whole
             # batch goes through the batched kernels -- the same graph as the teacher-forced pass over the sequence [0, tok_0, ..,
@@ -324,7 +332,7 @@ class ConstraintModelGaussianReg(Model):
             for l in range(self.num_layers):
                 h, hT, cT = self._lstm(f"lstm_generation.{l}", h, False)
                 states[l] = (hT, cT)
-        if _FREE_RUN_BATCHED and self.num_layers == 2 and oc.is_cuda:
+        if self._batched_free_run(oc):
             # as in _forward_no_tf: the window's tokens depend on batch element 0 alone (its state behind the prefix, its token in
             # front of the window) -- one sequential pass over that row, then the window for the whole batch in one batched pass
             W, H, dev = end_tick - start_tick, self.num_lstm_generation_units, gen.device

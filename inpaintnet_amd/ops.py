@@ -132,6 +132,12 @@ def side_join_on(stream):
     check(_lib.lib().inet_side_wait(C.c_void_p(stream.cuda_stream)), "inet_side_wait")
 
 
+def arnn_generate_ok(E, Hc, H, U, V):
+    """The shapes the one-row kernels of inet_arnn_generate are built for (csrc/lstm.hip: template bounds); callers keep their
+    per-tick loop for anything else."""
+    return E + Hc <= 320 and H <= 256 and H % 16 == 0 and U <= 256 and V <= 256
+
+
 def arnn_generate(emb, oc0, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1, W2, b2, hc_init=None, first_tok=None):
     """inet_arnn_generate: the L argmax tokens of batch element 0 of AnticipationRNN's free-running pass.  oc0 [L,Hc] (rows may be
     strided); hc_init [2,2,H] (layer, h|c) or None (zeros); first_tok: 1-element int64 device tensor or None (token 0);
