@@ -32,8 +32,9 @@ for i in range(nl // 2):
 la.trainer.check_steps(wait_all=True)
 torch.cuda.synchronize()
 print(f"latent auto_reg: {nl // 2} steps in {time.time() - t0:.1f} s, final loss {float(loss.detach()):.4f}, chain_status {ops.chain_status()}", flush=True)
-r = bench.arnn_extra(steps=na, warmup=3, tables=False)["anticipation_rnn_train"]
+r = bench.arnn_extra(steps=na, warmup=3, tables=False, free_steps=max(10, na // 4))["anticipation_rnn_train"]
 torch.cuda.synchronize()
-print(f"arnn: {na} steps at {r['ms_per_step']} ms, chain_status {ops.chain_status()}", flush=True)
+print(f"arnn: {na} teacher-forced steps at {r['ms_per_step']} ms, {max(10, na // 4)} free-running steps at {r['ms_per_step_free_running']} ms, "
+      f"chain_status {ops.chain_status()}", flush=True)
 assert ops.chain_status() == 0 and ops.token_status() == 0
 print("soak ok")
