@@ -1030,7 +1030,8 @@ __global__ __launch_bounds__(256) void relu_linear_b1_kernel(const float* __rest
     if (lane == 0) y[j] = fmaxf(v + b[j], 0.f);
 }
 
-// token = argmax_v (W[v,:] . x + b[v]), lowest index on ties, V <= 256: ONE workgroup (a wave per row in turn), the logits through LDS
+// token = argmax_v (W[v,:] . x + b[v]), lowest index on ties, V <= 256: ONE workgroup of 16 waves; a wave's rows (V = 48: three) are all
+// requested before the first sum, the logits meet in LDS and the first wave takes the argmax with shuffles
 template <int NI>
 __global__ __launch_bounds__(1024) void head_argmax_b1_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ b, long long* __restrict__ tok, int V, int K) {
@@ -1038,17 +1039,33 @@ __global__ __launch_bounds__(1024) void head_argmax_b1_kernel(const float* __res
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float xv[NI];
     load_x<NI>(xv, x, K, nullptr, K, lane);
-    for (int v = w; v < V; v += 16) {                          // 16 waves: V = 48 is three rows per wave
-        const float a = wave_sum(dot_row<NI>(W + (long)v * K, xv, K, lane));
-        if (lane == 0) lg[v] = a + b[v];
+    float part[16];                                            // rows w, w + 16, ...: V <= 256
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int v = w + 16 * r;
+        part[r] = v < V ? dot_row<NI>(W + (long)v * K, xv, K, lane) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int v = w + 16 * r;
+        if (v < V) {                                           // (wave-uniform)
+            const float a = wave_sum(part[r]);
+            if (lane == 0) lg[v] = a + b[v];
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float best = lg[0];
-        int bi = 0;
-        for (int v = 1; v < V; ++v)
-            if (lg[v] > best) { best = lg[v]; bi = v; }
-        *tok = bi;
+    if (w == 0) {
+        float best = -3.0e38f;
+        int bi = 0x7fffffff;
+        for (int v = lane; v < V; v += 64)
+            if (lg[v] > best) { best = lg[v]; bi = v; }       // (ascending v per lane: the lane's lowest index wins its ties)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float b2 = __shfl_xor(best, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (b2 > best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
+        }
+        if (lane == 0) *tok = bi;
     }
 }
 }  // namespace
