@@ -28,6 +28,7 @@ Prints ONE JSON line on rank 0 (contract in the task brief) carrying
 import argparse
 import collections
 import csv
+import gc
 import json
 import os
 import random
@@ -309,15 +310,44 @@ class LatentWorkload:
                 "parallelism": f"dp{world}"}
 
 
-def timed(step, steps, warmup, fence):
+def timed(step, steps, warmup, fence, trace=None):
+    """W un-timed steps, a fence, EXACTLY `steps` timed steps, a fence.  trace (a dict): also the first 32 timed steps one by one --
+    host time to queue each and the GPU's time between events recorded behind consecutive steps -- and Python's garbage
+    collections inside the region (a full collection over the import-time heap is a 40 ms host stall: profiles/r05_cold_start.txt)."""
     for _ in range(warmup):
         step()
+    ntr = min(steps, 32) if trace is not None else 0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(ntr + 1)]
+    host, gcs, g0 = [], [], [0.0]
+
+    def on_gc(phase, info):
+        if phase == "start":
+            g0[0] = time.perf_counter()
+        else:
+            gcs.append((info["generation"], round(1e3 * (time.perf_counter() - g0[0]), 3)))
+    if trace is not None:
+        gc.callbacks.append(on_gc)
     fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
+    if ntr:
+        ev[0].record()
+    for i in range(steps):
+        if i < ntr:
+            h0 = time.perf_counter()
+            loss = step()
+            ev[i + 1].record()
+            host.append(time.perf_counter() - h0)
+        else:
+            loss = step()
     fence()
-    return time.perf_counter() - t0, loss
+    dt = time.perf_counter() - t0
+    if trace is not None:
+        gc.callbacks.remove(on_gc)
+        trace["first_steps_ms"] = [round(ev[i].elapsed_time(ev[i + 1]), 3) for i in range(ntr)]
+        trace["first_steps_host_ms"] = [round(1e3 * h, 3) for h in host]
+        trace["gc_in_timed_region"] = {"collections": len(gcs), "generation2": sum(1 for g, _ in gcs if g == 2),
+                                       "longest_ms": max([m for _, m in gcs], default=0.0)}
+    return dt, loss
 
 
 def exchange_report(wl, dp, step_s, fence, dev, steps=40):
@@ -858,7 +888,8 @@ def main():
         torch.cuda.synchronize()
 
     try:
-        dt, loss = timed(wl.step, args.steps, args.warmup, fence)
+        trace = {}
+        dt, loss = timed(wl.step, args.steps, args.warmup, fence, trace)
     except ops.ChainTimeoutError as e:
         # raised by Trainer.step() on EVERY rank at the same step (the decision travels with the gradients): all ranks leave
         print(f"[bench] rank {rank}: {e}\n[bench] result invalid", file=sys.stderr)
@@ -974,6 +1005,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "chain_timeouts": chain_timeouts,                      # inet_chain_status after the timed region: 0 = healthy
+            # the timed steps one by one (the first 32): GPU time between events behind consecutive steps, host time to queue each,
+            # Python garbage collections inside the region -- a cold-start transient shows up HERE (profiles/r05_cold_start.txt)
+            **trace,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -988,7 +1023,6 @@ def main():
             "data": "synthetic",
             "config": dict(wl.describe(world), final_loss=round(final_loss, 5)),
             "roofline": roof,
-            "chain_timeouts": chain_timeouts,                      # inet_chain_status after the timed region: 0 = healthy
         }
         if world > 1:
             out["per_rank_units_per_s"] = per_rank

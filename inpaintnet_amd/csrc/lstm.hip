@@ -1030,6 +1030,13 @@ __global__ __launch_bounds__(256) void relu_linear_b1_kernel(const float* __rest
     if (lane == 0) y[j] = fmaxf(v + b[j], 0.f);
 }
 
+// does (b2, i2) come before (best, bi) in numpy's argmax order?  NaN > everything, ties to the lower index
+__device__ __forceinline__ bool argmax_better(float b2, int i2, float best, int bi) {
+    const bool n2 = b2 != b2, n1 = best != best;
+    if (n2 || n1) return n2 && (!n1 || i2 < bi);
+    return b2 > best || (b2 == best && i2 < bi);
+}
+
 // token = argmax_v (W[v,:] . x + b[v]), lowest index on ties, V <= 256: ONE workgroup of 16 waves; a wave's rows (V = 48: three) are all
 // requested before the first sum, the logits meet in LDS and the first wave takes the argmax with shuffles
 template <int NI>
@@ -1055,17 +1062,19 @@ __global__ __launch_bounds__(1024) void head_argmax_b1_kernel(const float* __res
     }
     __syncthreads();
     if (w == 0) {
-        float best = -3.0e38f;
-        int bi = 0x7fffffff;
-        for (int v = lane; v < V; v += 64)
-            if (lg[v] > best) { best = lg[v]; bi = v; }       // (ascending v per lane: the lane's lowest index wins its ties)
+        // np.argmax order (anticipation_rnn_gauss_reg_model.py:253): a NaN is the maximum, the lowest index wins among equals -- an
+        // all-NaN or all -inf row yields a token INSIDE the vocabulary (the next tick gathers the embedding row by it)
+        float best = lane < V ? lg[lane] : -INFINITY;
+        int bi = lane < V ? lane : 0x7fffffff;
+        for (int v = lane + 64; v < V; v += 64)
+            if (argmax_better(lg[v], v, best, bi)) { best = lg[v]; bi = v; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float b2 = __shfl_xor(best, o, 64);
             const int i2 = __shfl_xor(bi, o, 64);
-            if (b2 > best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
+            if (argmax_better(b2, i2, best, bi)) { best = b2; bi = i2; }
         }
-        if (lane == 0) *tok = bi;
+        if (lane == 0) *tok = bi < V ? bi : 0;
     }
 }
 }  // namespace

@@ -14,6 +14,7 @@ the static loss helpers.  Differences that are the point of the build:
     (the reference syncs every batch: utils/trainer.py:154).
 Plotting / tensorboard plumbing of the reference is out of scope.
 """
+import gc
 import os
 import time
 from abc import ABC, abstractmethod
@@ -27,6 +28,25 @@ from .feed import DeviceFeed
 
 def _dist_ready():
     return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def settle_python_heap():
+    """gc.collect() + gc.freeze(): everything alive now (torch's, numpy's and this package's modules: ~170 k tracked objects)
+    moves to the permanent generation, which later collections do not traverse.
+
+    Why a trainer cares (round 5, profiles/r05_cold_start.txt): a training step queues ~80 launches in ~1 ms of host time and
+    the GPU needs 3.6 ms for them, so the host runs ahead -- until CPython's cyclic collector decides on a FULL collection.
+    In a fresh process the third generation's threshold trips within the first dozen steps (the step objects, autograd nodes
+    and ctypes arguments are the young objects that count towards it), and one traversal of the import-time heap takes
+    36-40 ms on the GPU box: the launch queue drains, the GPU idles for ten steps' worth of time, and a 20-step epoch (a
+    validation pass, the driver's `bench.py --steps 20 --warmup 5`) measures 1.7x the steady state -- the whole of round 4's
+    "cold-start transient" (6.31 vs 3.65 ms per step).  With the old heap frozen a full collection only looks at what was
+    created since: < 1 ms.  INET_GC_FREEZE=0 leaves the collector alone."""
+    if os.environ.get("INET_GC_FREEZE", "1") == "0":
+        return False
+    gc.collect()
+    gc.freeze()
+    return True
 
 
 class _CrossEntropyFn(torch.autograd.Function):
@@ -139,6 +159,13 @@ class Trainer(ABC):
         self._report_events = None                   # one event per record, recorded behind its optimizer launch
         self._recent = deque(maxlen=self._NREP)      # (tag, batch) of the epoch loop's last steps: what a fallback runs again
         self._lost = []                              # tags found skipped since the last fallback
+        # the host must stay ahead of the GPU from the first step on: no full garbage collection over the import-time heap
+        # in the middle of the first steps (settle_python_heap)
+        settle_python_heap()
+        if model.grad.is_cuda:                       # the report ring and its events exist before the first step, not in it
+            self._report_slot(0)
+            for e in self._report_events:
+                e.record()
 
     # ---- utils/trainer.py:41-124 (plot/log plumbing omitted) -----------------------
     def train_model(self, batch_size, num_epochs, plot=False, log=False, seed=0):
