@@ -362,7 +362,9 @@ def exchange_report(wl, dp, step_s, fence, dev, steps=40):
         dt_off, _ = timed(wl.step, steps, 5, fence)
     finally:
         dp.set_exchange(True)
-    dp.broadcast_params(wl.model.flat)                         # (the ranks drifted apart while nothing was exchanged)
+    dp.broadcast_params(wl.model.flat)                         # (the ranks drifted apart while nothing was exchanged:
+    for t in (wl.trainer.adam_m, wl.trainer.adam_v):           #  weights AND Adam moments, for whatever the ranks run next)
+        dp.broadcast_params(t)
     t = torch.tensor([dt_off / steps], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     return {"ranges": ranges, "ms_per_step_without_exchange": round(1e3 * float(t.item()), 4),

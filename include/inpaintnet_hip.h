@@ -143,20 +143,23 @@ int inet_sample_multinomial(const float* weights, int64_t ld_w, int rows, int V,
 int inet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, int step, float gscale, void* stream);
 /* The same step for a caller that must know, without stalling the queue, what the kernel decided (round 4):
- *  - step_flag (nullable device float): when given it ALONE decides whether the step is applied -- non-zero = skip.  A
- *    data-parallel caller writes its rank's chain status there with inet_step_flag_export() and sums the word over ranks
- *    together with the gradients (one slot in front of the gradient arena: no extra collective), so that every rank skips a
- *    step ANY rank's chain kernels failed in and the replicas stay bit-identical.  Null: this process's own status word decides,
+ *  - step_flag (nullable; TWO device floats): when given, word 0 ALONE decides whether the step is applied -- non-zero = skip.  A
+ *    data-parallel caller writes its rank's status there with inet_step_flag_export() -- word 0 = a chain kernel of this rank
+ *    timed out, word 1 = a prologue kernel of this rank met a token outside the vocabulary -- and sums the words over ranks
+ *    together with the gradients (a 16-byte head in front of the gradient arena: no extra collective), so that every rank skips
+ *    a step ANY rank's chain kernels failed in and the replicas stay bit-identical.  Null: this process's own status word decides,
  *    as in inet_adam_step.
  *  - report (nullable): FOUR 32-bit words of caller-owned, device-visible HOST memory (pinned / host-mapped), zeroed by the
  *    caller before the call; the kernel sets [0] = 1 when it has run, [1] = 1 if it skipped the step, [2] = 1 if a parameter
  *    became NaN / inf in this update -- the observable behaviour of MeasureVAE/encoder.py:111-116 and decoder.py:424-429
- *    (ValueError "... has become nan") without a host scan of the weights per forward.  The caller reads the record behind an
- *    event of its own a few steps later (inpaintnet_amd/trainer.py keeps a ring of 16 records per Trainer and reads the one of
- *    step k when it has queued step k + 2: by then that launch has normally finished, the read costs nothing and BOUNDS how far
- *    the host runs ahead). */
+ *    (ValueError "... has become nan") without a host scan of the weights per forward --, [3] = 1 if step_flag[1] is non-zero
+ *    (decoder.py:36-45 check_index: every rank raises its ValueError at the same step).  The caller reads the record behind an
+ *    event of its own some steps later: inpaintnet_amd/trainer.py keeps a ring of 16 records per Trainer and reads the one of
+ *    step k when it has queued step k + 12 (INET_REPORT_LAG).  The lag is how far the host may run ahead of the GPU and must be
+ *    generous: a lag of 2 cost the B = 256 step 5 % (profiles/r04_b_report_lag.txt); Trainer.finish() reads what is outstanding. */
 int inet_adam_step_ex(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, int step, float gscale, const float* step_flag, uint32_t* report, void* stream);
+/* dst: the TWO floats described above (chain status, token status of this process) */
 int inet_step_flag_export(float* dst, void* stream);
 /* Number of prologue launches that met a token index outside [0, num_notes) since the last reset (encoder input tokens,
  * teacher-forcing targets): decoder.py:36-45 check_index raises ValueError; here the host-mapped counter is read by the Python

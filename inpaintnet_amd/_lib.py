@@ -169,6 +169,9 @@ def check(rc, what):
     if rc == -3:
         raise InetError(f"{what}: library options (inet_set_option keys 4, 7, 8, 9, 12) changed between a forward call and its "
                         "backward call on the same workspace (rc=-3)")
+    if rc == -4:
+        raise InetError(f"{what}: the workspace was sized under other library options than this call runs under (inet_set_option "
+                        "keys 4, 7, 8, 9, 12 changed between *_ws_bytes and the call: a piece buffer it needs is missing) (rc=-4)")
     if rc != 0:
         raise InetError(f"{what}: HIP launch/runtime failure (rc={rc})")
 

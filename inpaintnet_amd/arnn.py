@@ -276,6 +276,9 @@ class ConstraintModelGaussianReg(Model):
             # batch goes through the batched kernels -- the same graph as the teacher-forced pass over the sequence [0, tok_0, ..,
             # tok_{L-2}] (the start symbol is TOKEN 0 here, not the zero vector, and there is no input dropout: :215-231).
             # 195 -> 14 ms per training step; INET_ARNN_FREE_RUN=loop: the per-tick loop below.
+            # The tokens come from fp32 one-row kernels, the returned logits from the batched MFMA kernels (another summation
+            # order): gen_chorale equals argmax(weights[0]) except possibly on rows whose top-2 logits agree to rounding (~1e-6
+            # relative) -- the equivalence test compares them on rows with a clear margin.
             pr = self.param
             with torch.no_grad():
                 toks = ops.arnn_generate(pr("note_embeddings.0.weight"), oc.detach()[:, 0, :],
@@ -394,7 +397,11 @@ def free_positions(constraints_loc, host_copy=None):
     `(constraints_loc[0, i, :] == 0).nonzero()`).  On the device nonzero() is a device -> host round trip: the launch queue
     drains and the ~40 small launches of the loss behind it run at host pace (0.9 ms of a 7.3 ms training step in the
     kernel trace).  So the answer is computed once per tensor and kept on it (dropped if the tensor is written in place:
-    `_version`); the trainer, which builds the tensor on the host, fills it from the host copy without any round trip."""
+    `_version`); the trainer, which builds the tensor on the host, fills it from the host copy without any round trip.
+
+    The cache assumes that writes to `constraints_loc` go through torch in-place operations (they move `_version`).  Writes
+    that bypass it -- `.data` edits, a numpy view of a CPU tensor, a kernel writing through `data_ptr()` -- are not seen:
+    `del constraints_loc._inet_free` (or a fresh tensor) after such a write."""
     cached = getattr(constraints_loc, "_inet_free", None)
     if cached is not None and cached[0] == constraints_loc._version:
         return cached[1]

@@ -205,6 +205,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     if (report && blockIdx.x == 0 && threadIdx.x == 0) {
         __hip_atomic_store(report + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (skip) __hip_atomic_store(report + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // word 3: SOME rank's prologue kernels met a token outside the vocabulary (step_flag[1] = the ranks' exported token words,
+        // summed with the gradients): every rank raises the reference's check_index ValueError at the same step
+        if (step_flag && step_flag[1] != 0.f) __hip_atomic_store(report + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (skip) return;
     bool bad = false;
@@ -241,9 +244,13 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // dst[0] = 1 if a chain launch of this process has timed out since the last reset, else 0: the word a data-parallel caller sums
 // over ranks together with the gradients (inet_step_flag_export)
-__global__ void step_flag_export_kernel(const unsigned* abort_word, float* dst) {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
+// dst[1] = 1 if a prologue kernel of this process has met a token outside the vocabulary since the last reset (the host-mapped
+// word behind inet_token_status): decoder.py:36-45's ValueError, raised by all ranks together
+__global__ void step_flag_export_kernel(const unsigned* abort_word, const unsigned* tok_word, float* dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         dst[0] = (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.f : 0.f;
+        dst[1] = (tok_word && __hip_atomic_load(tok_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ? 1.f : 0.f;
+    }
 }
 
 // out[n] (+)= sum_m X[m*ld + n].  Block = 64 columns x 4 row-lanes; grid.y splits rows; atomics combine.
@@ -737,7 +744,8 @@ int pw_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
     return ok();
 }
 int pw_step_flag_export(float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(step_flag_export_kernel, dim3(1), dim3(64), 0, s, (const unsigned*)chain_dev_status(), dst);
+    hipLaunchKernelGGL(step_flag_export_kernel, dim3(1), dim3(64), 0, s, (const unsigned*)chain_dev_status(),
+                       (const unsigned*)token_host_status(), dst);
     return ok();
 }
 

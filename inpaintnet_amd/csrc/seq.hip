@@ -1,4 +1,5 @@
 #include <cstdlib>
+#include <mutex>
 #include <unordered_map>
 #include "seq.h"
 #include "gemm_bf3.h"
@@ -416,7 +417,22 @@ size_t bigru2_carve(Carver& c, int B, int T, int H, int save, BiGru2Ws& w) {
 // (keys 4, 7, 8, 9, 12).  Changing one of them in between used to be silent wrong weight gradients: the forward call
 // now notes the options it ran under per workspace, and the backward call refuses (-3) a workspace written under other options.
 namespace {
-std::unordered_map<const void*, unsigned> g_ws_opts;
+std::unordered_map<const void*, unsigned> g_ws_opts;      // workspace -> options of the forward call that wrote it
+std::mutex g_ws_opts_mu;
+void ws_opts_note(const void* key, unsigned opts) {
+    std::lock_guard<std::mutex> lk(g_ws_opts_mu);
+    if (g_ws_opts.size() > 4096) g_ws_opts.clear();       // (workspaces whose backward call never came: forget them all)
+    g_ws_opts[key] = opts;
+}
+// 0 = fine (or unknown workspace), -3 = written under other options; `consume`: the last backward stage forgets the entry
+int ws_opts_check(const void* key, unsigned opts, bool consume) {
+    std::lock_guard<std::mutex> lk(g_ws_opts_mu);
+    const auto it = g_ws_opts.find(key);
+    if (it == g_ws_opts.end()) return 0;
+    const bool same = it->second == opts;
+    if (consume || !same) g_ws_opts.erase(it);
+    return same ? 0 : -3;
+}
 unsigned opts_snapshot() {
     return (unsigned)chain_enabled() | ((unsigned)chain2_mode() << 1) | ((unsigned)bf3_mode() << 5) | ((unsigned)emit_mask() << 9) |
            ((unsigned)(gru_step_bf3_ok(512, 2048, 24, 2) ? 1 : 0) << 12) | ((unsigned)(gru_step_bf3_ok(512, 1 << 20, 2, 2) ? 1 : 0) << 13);
@@ -426,7 +442,7 @@ unsigned opts_snapshot() {
 int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in, const float* h0, const float* mask,
                     float* const* hn, long hn_ld, BiGru2Ws& w, int save, hipStream_t s, int sync_prezeroed) {
     const long BH = (long)B * H, TBH = (long)T * BH;
-    if (save) g_ws_opts[w.sync] = opts_snapshot();
+    if (save) ws_opts_note(w.sync, opts_snapshot());
     // fragment-major W_hh twins: only the per-step kernels read them (the chain kernels take W_hh as stored)
     // (one launch, row chunks, or -- big batches -- the bf16-pipe step kernels, which take the same null h0)
     const bool stepf = w.wp3[0] && w.hpk[0] && pk_ok(H) && !gru_chain_ok(H, B, T, 2) && gru_step_bf3_ok(H, B, T, 2);
@@ -490,7 +506,7 @@ int bigru2_core_fwd(int B, int T, int H, const GruDirPtr* P, const BiGru2In& in,
     INET_TRY(gru_layer_fwd(H, B, T, 2, d, s));
     const bool x1_emitted = bf3f && (d[0].emitted & 1) && (d[1].emitted & 1) && (emit_mask() & 1);
     // (the backward call relies on the predicate for the TRANSPOSED pieces the forward chains wrote)
-    if (bf3f && (emit_mask() & 1) && ((d[0].emitted & 2) && (d[1].emitted & 2)) != gru_layer_fwd_emits(H, B, T, 2, save != 0)) return -3;
+    if (bf3f && (emit_mask() & 1) && ((d[0].emitted & 2) && (d[1].emitted & 2)) != gru_layer_fwd_emits(H, B, T, 2, save != 0)) return -4;   // (options changed between sizing the workspace and this call)
     const float* x1 = mask ? w.x1m : w.x1raw;
     if (bf3f) {
         // both directions' input products as ONE product on the bf16 matrix cores (gemm_bf3.hip): gi1 [TB, 6H] =
@@ -560,10 +576,7 @@ static int bigru2_wgrad_hh_bf3(int B, int T, int H, int layer, const GruDirPtr* 
 int bigru2_core_bwd(int B, int T, int H, const GruDirPtr* P, const float* mask, const float* dout1,
                     const float* const* dhn, long dhn_ld, float* dh0, BiGru2Ws& w, hipStream_t s, int stage) {
     const long BH = (long)B * H, TBH = (long)T * BH;
-    {
-        const auto it = g_ws_opts.find(w.sync);
-        if (it != g_ws_opts.end() && it->second != opts_snapshot()) return -3;   // options changed since the forward call
-    }
+    if (ws_opts_check(w.sync, opts_snapshot(), stage != 1) != 0) return -3;      // options changed since the forward call
     const bool wg = P[0].dw_hh != nullptr;
     // both layers run as backward chains (they read W_hh as stored) iff the conditions of gru_layer_bwd_range hold:
     // the transposed fragment-major twins are then never read

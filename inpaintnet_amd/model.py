@@ -42,7 +42,7 @@ class Model(torch.nn.Module):
         # gradient range (dp.allreduce_grads) and read by the optimizer kernel -- every rank skips a step any rank failed in
         self._grad_store = torch.zeros(self._HEAD + total + self._STATS, dtype=torch.float32, device=device)
         self.grad = self._grad_store[self._HEAD:self._HEAD + total]
-        self.step_flag = self._grad_store[0:1]
+        self.step_flag = self._grad_store[0:2]
         self._stats = self._grad_store[self._HEAD + total:]
         self._stats_used = 0
         self._views = OrderedDict()

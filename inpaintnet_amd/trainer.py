@@ -180,26 +180,30 @@ class Trainer(ABC):
         train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
         print('Num Train Batches: ', len(train_loader))
         print('Num Valid Batches: ', len(val_loader))
-        for epoch in range(self.start_epoch, num_epochs):
-            self.update_scheduler(epoch)
-            stats = []
-            for loader, train in ((train_loader, True), (val_loader, False)):
-                self.model.train(train)
-                stats += self.loss_and_acc_on_epoch(data_loader=loader, epoch_num=epoch, train=train)
-            self.print_epoch_stats(epoch, num_epochs, *stats)
-            if dp.rank() == 0:
-                self.model.save()
-                if epoch > 0 and epoch % 10 == 0:
-                    self.model.save_checkpoint(epoch)
-                    self.save_training_state(self.model.filepath + f'_{epoch}.trainer', epoch + 1)
-            if self.early_stopping and self.early_stopper(stats[2], self.model):
-                print("Early Stopping")
-                return
+        try:
+            for epoch in range(self.start_epoch, num_epochs):
+                self.update_scheduler(epoch)
+                stats = []
+                for loader, train in ((train_loader, True), (val_loader, False)):
+                    self.model.train(train)
+                    stats += self.loss_and_acc_on_epoch(data_loader=loader, epoch_num=epoch, train=train)
+                self.print_epoch_stats(epoch, num_epochs, *stats)
+                if dp.rank() == 0:
+                    self.model.save()
+                    if epoch > 0 and epoch % 10 == 0:
+                        self.model.save_checkpoint(epoch)
+                        self.save_training_state(self.model.filepath + f'_{epoch}.trainer', epoch + 1)
+                if self.early_stopping and self.early_stopper(stats[2], self.model):
+                    print("Early Stopping")
+                    return
+        finally:
+            if self._inflight:                       # (every exit path: nothing a late report holds may go unread)
+                self.finish()
 
     # ---- utils/trainer.py:126-163 ---------------------------------------------------
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
         dev = self.model.flat.device
-        sums = torch.zeros(4, dtype=torch.float32, device=dev)        # loss sum, accuracy sum, batches, chain timeouts
+        sums = torch.zeros(5, dtype=torch.float32, device=dev)        # loss sum, accuracy sum, batches, chain timeouts, bad tokens
         t0 = time.time()
         prev_overlap, self.overlap_backward = self.overlap_backward, bool(train)
         try:
@@ -221,11 +225,15 @@ class Trainer(ABC):
         if sums.is_cuda:
             torch.cuda.synchronize(dev)
             sums[3] = float(max(ops.chain_status(), 0))
+            sums[4] = float(max(ops.token_status(), 0))     # (validation passes have no step report: the count travels here)
         dp.allreduce_sum_(sums)                      # every rank reports (and early-stops on) the global means
         out = sums.tolist()                          # the one device->host sync of the epoch
         if sums.is_cuda:
             ops.chain_status(reset=True)             # persistent kernels: bounded spins report here instead of hanging
-            ops.check_tokens("Trainer.loss_and_acc_on_epoch")
+            ops.token_status(reset=True)
+        if out[4] > 0:                               # on every rank together (decoder.py:36-45 check_index)
+            raise ops.TokenRangeError(f"Invalid Value of index: {int(out[4])} launch(es) (all ranks) met a token outside "
+                                      "[0, num_notes) (Trainer.loss_and_acc_on_epoch); the results computed from it are not valid")
         if out[3] > 0:
             raise RuntimeError(f"{int(out[3])} chain-kernel workgroups (all ranks) gave up waiting for their group during "
                                "this epoch outside an optimizer step (inet_chain_status); its results are not valid")
@@ -372,7 +380,7 @@ class Trainer(ABC):
         r = self._reports[tag % self._NREP].tolist()
         if not r[0]:
             raise RuntimeError(f"optimizer launch {tag} left no report (the kernel did not run?)")
-        return bool(r[0]), bool(r[1]), bool(r[2])
+        return bool(r[0]), bool(r[1]), bool(r[2]), bool(r[3])
 
     def check_steps(self, wait_all=False):
         """Read the reports of the optimizer steps issued at least `report_lag` steps ago (all outstanding ones with
@@ -381,14 +389,16 @@ class Trainer(ABC):
         MeasureVAE/encoder.py:111-116, decoder.py:424-429), ops.TokenRangeError for a token outside the vocabulary
         (decoder.py:36-45).  Identical on every rank of a data-parallel job: same reports, read at the same step."""
         newest = self._tag - 1
-        skipped = nonfinite = False
+        skipped = nonfinite = badtok = False
         while self._inflight and (wait_all or self._inflight[0] <= newest - self.report_lag):
             tag = self._inflight.popleft()
-            _, skip, bad = self._read_report(tag)
+            rep = self._read_report(tag)
+            skip, bad, tok = rep[1], rep[2], (rep[3] if len(rep) > 3 else False)
             if skip:
                 self._lost.append(tag)
             skipped |= skip
             nonfinite |= bad
+            badtok |= tok
         if skipped:
             raise ops.ChainTimeoutError(
                 f"optimizer step(s) {self._lost} skipped: a chain kernel gave up waiting for its group (on this or another "
@@ -397,8 +407,38 @@ class Trainer(ABC):
                 "ops.set_option(4, 0)) selects the per-step kernels.")
         if nonfinite:
             raise ValueError(f"{type(self.model).__name__} has become nan (a parameter left the finite range in an optimizer step)")
-        if self.model.flat.is_cuda:
-            ops.check_tokens("Trainer.step")
+        if badtok:
+            # data parallel: SOME rank's prologue kernels met a token outside the vocabulary (the token words travel with the
+            # step flag and come back in the report): every rank raises here, at the same step -- nobody is left in a collective
+            if self.model.flat.is_cuda:
+                ops.token_status(reset=True)
+            raise ops.TokenRangeError("Invalid Value of index: a token outside [0, num_notes) reached the model on this or another "
+                                      "rank (Trainer.step); the results computed from it are not valid")
+        if self.model.flat.is_cuda and self._flag() is None:
+            ops.check_tokens("Trainer.step")         # single process: the host-mapped counter of this process
+
+    def finish(self):
+        """Read every outstanding step report NOW (waits for the optimizer launches still in flight) and raise what they hold.
+        The errors of a step surface up to `report_lag` steps late by design (the host must run ahead of the GPU); a manual
+        training loop -- zero_grad / loss / backward / step without loss_and_acc_on_epoch -- calls this after its last step,
+        or runs inside `with trainer:`, so that a NaN weight, a bad token or a chain timeout in the LAST steps is not lost.
+        The epoch loop and train_model do it themselves."""
+        self.check_steps(wait_all=True)
+
+    close = finish
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.finish()
+        else:                                        # do not mask the exception that is already on its way out
+            try:
+                self.finish()
+            except Exception:
+                pass
+        return False
 
     def _fall_back_from_chains(self):
         """After a ChainTimeoutError out of step() / check_steps(): wait for the device, find every skipped step, take their

@@ -183,7 +183,7 @@ def test_epoch_loop_ranks_agree_on_statistics_and_early_stop(tmp_path):
 NBATCH = 7
 
 
-def _protocol_worker(rank, world, port, out_dir):
+def _protocol_worker(rank, world, port, out_dir, mode="timeout"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     torch.set_num_threads(1)
@@ -197,7 +197,7 @@ def _protocol_worker(rank, world, port, out_dir):
             self.flat = torch.zeros(8)
             self._grad_store = torch.zeros(4 + 8 + 4)
             self.grad = self._grad_store[4:12]
-            self.step_flag = self._grad_store[0:1]
+            self.step_flag = self._grad_store[0:2]
 
         def train(self, mode=True):
             return self
@@ -215,12 +215,15 @@ def _protocol_worker(rank, world, port, out_dir):
             super().__init__(dataset, model)
             self.report_lag = 2
             self.local_fail = False
+            self.local_badtok = False
             self.chains_off = False
-            self.records, self.applied, self.seen = {}, [], 0
+            self.records, self.applied, self.seen, self.tokrec = {}, [], 0, {}
 
         def process_batch_data(self, batch):
-            if self.seen == 2 and dp.rank() == 1 and not self.chains_off:
+            if self.seen == 2 and dp.rank() == 1 and not self.chains_off and mode == "timeout":
                 self.local_fail = True               # rank 1 only: "a persistent kernel gave up" while batch 2 is computed
+            if self.seen == 2 and dp.rank() == 1 and mode == "token":
+                self.local_badtok = True             # rank 1 only: "a prologue kernel met a token outside the vocabulary"
             self.seen += 1
             return batch[0]
 
@@ -243,16 +246,18 @@ def _protocol_worker(rank, world, port, out_dir):
 
         def _export_flag(self, flag):
             flag[0] = 1.0 if self.local_fail else 0.0
+            flag[1] = 1.0 if self.local_badtok else 0.0
 
         def _launch_optimizer(self, tag, gscale, flag):
             skipped = float(flag[0]) != 0.0          # the ranks' SUM: identical everywhere
             self.records[tag] = skipped
+            self.tokrec[tag] = float(flag[1]) != 0.0
             if not skipped:
                 self.model.flat -= 0.1 * gscale * self.model.grad
                 self.applied.append(self.current)
 
         def _read_report(self, tag):
-            return True, self.records[tag], False
+            return True, self.records[tag], False, self.tokrec[tag]
 
         def _device_sync(self):
             pass
@@ -265,6 +270,17 @@ def _protocol_worker(rank, world, port, out_dir):
     tr = ProtoTrainer(None, model)
     # global batches of 4 rows x [1, 4]; row value = batch id, so a rank's shard mean identifies the batch
     loader = [(torch.full((4, 1, 4), i, dtype=torch.int32), torch.zeros(4, 1, 4, dtype=torch.int32)) for i in range(NBATCH)]
+    if mode == "token":
+        from inpaintnet_amd import ops
+        raised_at = -1
+        try:
+            tr.loss_and_acc_on_epoch(loader, 0, train=True)
+        except ops.TokenRangeError:
+            raised_at = tr._tag                      # how many optimizer launches this rank had issued when it raised
+        np.savez(os.path.join(out_dir, f"p{rank}.npz"), raised_at=raised_at, applied=np.array(tr.applied))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
     loss, acc = tr.loss_and_acc_on_epoch(loader, 0, train=True)
     np.savez(os.path.join(out_dir, f"p{rank}.npz"), flat=model.flat.numpy(), applied=np.array(tr.applied), adam_t=tr.adam_t,
              fallbacks=tr.chain_fallbacks, lost=tr.lost_steps, loss=loss, seen=tr.seen,
@@ -289,3 +305,15 @@ def test_failure_protocol_keeps_ranks_in_step(tmp_path):
     # the update is the mean of the two ranks' gradients (= the batch id): sum_i 0.1 * i
     assert np.allclose(r0["flat"], -0.1 * sum(range(NBATCH)), rtol=1e-6)
     assert abs(float(r0["loss"]) - np.mean(range(NBATCH))) < 1e-6     # every batch in the epoch mean exactly once
+
+
+def test_bad_token_on_one_rank_raises_on_all_ranks_at_the_same_step(tmp_path):
+    """the token-range error (decoder.py:36-45 check_index) used to be read from a rank-local counter, so only the
+    rank that saw the token raised and the others waited in the next all-reduce.  The token word now travels in the head of the
+    gradient store next to the step flag (word 1) and comes back in the step report: rank 1 'sees' a bad token in batch 2, BOTH
+    ranks raise TokenRangeError when they read that report -- after the same number of optimizer launches."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_protocol_worker, args=(2, port, str(tmp_path), "token"), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "p0.npz"), np.load(tmp_path / "p1.npz")
+    assert int(r0["raised_at"]) == int(r1["raised_at"]) == 2 + 2 + 1      # report of step 2 read behind step 4 (report_lag 2)
+    assert r0["applied"].tolist() == r1["applied"].tolist()

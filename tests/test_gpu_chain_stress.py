@@ -261,3 +261,49 @@ def test_nonfinite_parameters_and_bad_tokens_raise_valueerror():
     sd = model.state_dict()
     with pytest.raises(ValueError, match="has become nan"):
         model.load_state_dict(sd)
+
+
+@pytest.mark.gpu
+def test_error_in_the_last_step_of_a_manual_loop_surfaces_at_finish():
+    """Step reports are read report_lag = 12 steps late (the host must run ahead of the GPU), so a manual loop's LAST steps have
+    nobody to read them: Trainer.finish() / `with trainer:` does.  The reference raises at the next forward
+    pass (MeasureVAE/encoder.py:111-116); a script whose loop has ended has no next forward pass."""
+    from inpaintnet_amd import synthetic
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    from inpaintnet_amd.vae_trainer import VAETrainer
+    ds = synthetic.SyntheticFolkDataset(num_notes=48)
+    model = MeasureVAE(ds)
+    tok = torch.from_numpy(synthetic.det_tokens("finish", (32, 24), 48)).cuda()
+
+    def one_step(trainer):
+        trainer.zero_grad()
+        loss, acc = trainer.loss_and_acc_for_batch(tok, 0, train=True)
+        loss.backward()
+        trainer.step()
+    trainer = VAETrainer(ds, model, lr=1e-4)
+    model.train()
+    for _ in range(3):
+        one_step(trainer)
+    model.param("decoder.x_0")[2] = float("nan")     # ... and the loop's LAST step runs on it
+    one_step(trainer)                                # nothing raised: its report is 12 steps away
+    assert len(trainer._inflight) == 4
+    with pytest.raises(ValueError, match="has become nan"):
+        trainer.finish()
+    assert not trainer._inflight
+    # the context-manager form, healthy and faulty
+    sd = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    with VAETrainer(ds, model, lr=1e-4) as t2:
+        one_step(t2)
+    assert not t2._inflight
+    with pytest.raises(ValueError, match="has become nan"):
+        with VAETrainer(ds, model, lr=1e-4) as t3:
+            one_step(t3)
+            model.param("encoder.linear_mean.0.bias")[1] = float("inf")
+            one_step(t3)
+    # an exception of the loop's own is not masked by what finish() finds
+    model.load_state_dict(sd)
+    with pytest.raises(KeyError):
+        with VAETrainer(ds, model, lr=1e-4) as t4:
+            one_step(t4)
+            raise KeyError("the loop's own")
