@@ -256,12 +256,14 @@ int inet_lstm2_bwd(int batch, int T, int H, const float* W_hh0, const float* W_i
 /* The sequential part of AnticipationRNN's free-running pass (AnticipationRNN/anticipation_rnn_gauss_reg_model.py:190-259): the
  * generation LSTMs feed the argmax of BATCH ELEMENT 0 back to the whole batch (:253-256), so the token sequence depends on that one
  * row.  L ticks of [embedding of the previous token (start: token 0) | oc0 + t * oc_stride (the tick's constraint output, Hc floats)]
- * -> LSTM 0 -> LSTM 1 -> ReLU(linear_1) -> note head -> argmax (lowest index on ties), queued as small launches without a host
- * round trip; tokens [L] int64 on the device.  emb [.,E]; W_ih0 [4H, E+Hc]; W_ih1, W_hh* [4H,H]; W1 [U,H]; W2 [V,U].  hc_init
+ * -> LSTM 0 -> LSTM 1 -> ReLU(linear_1) -> note head -> argmax (numpy order: NaN is the maximum, lowest index among equals), without a
+ * host round trip: ONE persistent launch of 13 workgroups with their weights in registers for the reference's configuration (H = U =
+ * 256, V <= 128; csrc/arnn_gen.hip, round 5: two hand-offs per tick), four small launches per tick otherwise (inet_set_option key 14 /
+ * INET_ARNN_GEN: 0 = always the launches, 1 = persistent kernel, 2 = default: its workgroups on one XCD); tokens [L] int64 on the device.  emb [.,E]; W_ih0 [4H, E+Hc]; W_ih1, W_hh* [4H,H]; W1 [U,H]; W2 [V,U].  hc_init
  * (nullable: zeros) = the state the ticks go on from, [layer][h | c][H]; first_tok (nullable: token 0) = device pointer to the token in
  * front of the first tick -- forward_inpaint (:261-346) generates a window behind a teacher-forced prefix.  The caller then runs the
  * whole batch over these tokens with the batched kernels (inpaintnet_amd.arnn._forward_no_tf / forward_inpaint). */
-int64_t inet_arnn_generate_ws_floats(int E, int Hc, int H, int U, int V);
+int64_t inet_arnn_generate_ws_floats(int L, int E, int Hc, int H, int U, int V);
 int inet_arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, int64_t oc_stride,
                        const float* W_ih0, const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
                        const float* b_ih1, const float* W_hh1, const float* b_hh1, const float* W1, const float* b1,
@@ -330,7 +332,9 @@ int inet_set_option(int key, int value);
  * key 13 = how many of the side streams take leaf work in rotation from now on (0 = all that exist, default; 1: what a process with
  * a gradient exchange beside its steps wants -- inpaintnet_amd.dp sets it: the runtime deals FOUR hardware queues, and caller + two
  * side streams + the exchange's two streams measured 4.94 ms per B = 256 step against 3.87 with one side stream).
- * Keys 4, 7-12 must not change between a forward call and its backward call, nor between sizing a workspace and using it. */
+ * key 14 = AnticipationRNN's token pass (inet_arnn_generate; INET_ARNN_GEN): 2 (default) = one persistent launch where the shape
+ * allows, its 13 workgroups on every 8th workgroup id (one XCD as dispatched today); 1 = on 13 consecutive ids; 0 = four launches per tick.
+ * Keys 4, 7-12, 14 must not change between a forward call and its backward call, nor between sizing a workspace and using it. */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.
  * Unlike inet_side_join nothing is consumed: the issuing stream still joins the same work at its own next join (a

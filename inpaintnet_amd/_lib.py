@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INET_LIB_PATH") or os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip", "gemm_bf3.hip", "gru_step_bf3.hip"]
+SOURCES = ["arnn_gen.hip", "gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip", "gemm_bf3.hip", "gru_step_bf3.hip"]
 
 _lib = None
 
@@ -119,7 +119,7 @@ _SIGNATURES = {
     "inet_split_score": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "inet_set_option": (C.c_int, [_I, _I]),
     "inet_side_join": (C.c_int, [_P]),
-    "inet_arnn_generate_ws_floats": (C.c_int64, [_I, _I, _I, _I, _I]),
+    "inet_arnn_generate_ws_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
     "inet_arnn_generate": (C.c_int, [_I] * 6 + [_P, _P, _L] + [_P] * 12 + [_P, _P, _P, _P, _L, _P]),
     "inet_side_wait": (C.c_int, [_P]),
     "inet_twin_stream": (C.c_int, [C.POINTER(C.c_void_p)]),

@@ -376,9 +376,9 @@ int inet_lstm2_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, co
     return lstm2_seq_fwd(B, T, H, gi0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, reverse, out0, gi1, out1, ws0, ws1, save,
                          (hipStream_t)stream);
 }
-int64_t inet_arnn_generate_ws_floats(int E, int Hc, int H, int U, int V) {
-    if (E <= 0 || Hc < 0 || H <= 0 || H % 16 || U <= 0 || V <= 0) return -1;
-    return (int64_t)arnn_generate_ws_floats(E, Hc, H, U, V);
+int64_t inet_arnn_generate_ws_floats(int L, int E, int Hc, int H, int U, int V) {
+    if (L <= 0 || E <= 0 || Hc < 0 || H <= 0 || H % 16 || U <= 0 || V <= 0) return -1;
+    return (int64_t)arnn_generate_ws_floats(L, E, Hc, H, U, V);
 }
 int inet_arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* emb, const float* oc0, int64_t oc_stride,
                        const float* W_ih0, const float* b_ih0, const float* W_hh0, const float* b_hh0, const float* W_ih1,
@@ -388,7 +388,7 @@ int inet_arnn_generate(int L, int E, int Hc, int H, int U, int V, const float* e
     if (L <= 0 || E <= 0 || Hc < 0 || H <= 0 || H % 16 || U <= 0 || V <= 0 || !emb || (Hc && !oc0) || !W_ih0 || !b_ih0 || !W_hh0 ||
         !b_hh0 || !W_ih1 || !b_ih1 || !W_hh1 || !b_hh1 || !W1 || !b1 || !W2 || !b2 || !tokens || !ws)
         return -1;
-    if (ws_floats < (int64_t)arnn_generate_ws_floats(E, Hc, H, U, V)) return -1;
+    if (ws_floats < (int64_t)arnn_generate_ws_floats(L, E, Hc, H, U, V)) return -1;
     return arnn_generate(L, E, Hc, H, U, V, emb, oc0, (long)oc_stride, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1,
                          W2, b2, hc_init, (const long long*)first_tok, (long long*)tokens, ws, (hipStream_t)stream);
 }
@@ -455,6 +455,7 @@ int inet_set_option(int key, int value) {
     // (keys 10, 11 -- which layers' weight gradients run on the bf16 pipe; the second-generation BPTT kernel -- were removed in round 4)
     if (key == 12) { gru_step_bf3_set_min_tiles(value); return 0; }
     if (key == 13) { if (value < 0 || value > 3) return -1; side_set_active(value); return 0; }
+    if (key == 14) { if (value < 0 || value > 2) return -1; arnn_gen_set_mode(value); return 0; }
     return -1;
 }
 

@@ -147,7 +147,7 @@ def arnn_generate(emb, oc0, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_h
     E, H, U, V = emb.shape[1], W_hh0.shape[1], W1.shape[0], W2.shape[0]
     for t in (emb, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_hh1, W1, b1, W2, b2):
         _f32c(t)
-    nws = int(_lib.lib().inet_arnn_generate_ws_floats(E, Hc, H, U, V))
+    nws = int(_lib.lib().inet_arnn_generate_ws_floats(L, E, Hc, H, U, V))
     ws = torch.empty(nws, dtype=torch.float32, device=emb.device)
     tokens = torch.empty(L, dtype=torch.int64, device=emb.device)
     check(_lib.lib().inet_arnn_generate(L, E, Hc, H, U, V, ptr(emb), ptr(oc0), oc0.stride(0), ptr(W_ih0), ptr(b_ih0), ptr(W_hh0),
@@ -156,7 +156,12 @@ def arnn_generate(emb, oc0, W_ih0, b_ih0, W_hh0, b_hh0, W_ih1, b_ih1, W_hh1, b_h
                                         ptr(_i64c(first_tok) if first_tok is not None else None), ptr(tokens), ptr(ws), nws,
                                         stream_ptr()), "inet_arnn_generate")
     _hold(ws, oc0, hc_init, first_tok)
+    if _ARNN_KEEP_WS:                                # diagnostics (tools/arnn_token_pass.py reads the kernel's phase stamps out of it)
+        _ARNN_KEEP_WS[:] = [ws]
     return tokens
+
+
+_ARNN_KEEP_WS = []
 
 
 _twin = {}

@@ -480,7 +480,7 @@ class CpuVaeTrainStep:
         loss, ce, kl, acc = vae_loss(w, tokens, mu, ls)
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())
 
 
 def decoder_forward_fast(P, z, tokens, teacher_forced, dropout=0.0, train=False, prefix="decoder"):

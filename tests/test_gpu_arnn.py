@@ -359,3 +359,85 @@ def test_arnn_bench_shape_step_with_input_dropout_vs_oracle(tmp_path, monkeypatc
     worst = max(errs, key=errs.get)
     print(f"worst ARNN gradient tensor {worst}: {errs[worst]:.2e} of its max")
     assert errs[worst] < 5e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+def _token_pass_inputs(L=384, V=48, E=10, Hc=256, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+
+    def rnd(*shape, s=0.08):
+        return ((torch.rand(*shape, generator=g) * 2 - 1) * s * scale).cuda()
+    H = U = 256
+    return dict(emb=rnd(V + 1, E, s=1.0), oc=rnd(L, Hc, s=1.0), W_ih0=rnd(4 * H, E + Hc), b_ih0=rnd(4 * H), W_hh0=rnd(4 * H, H),
+                b_hh0=rnd(4 * H), W_ih1=rnd(4 * H, H), b_ih1=rnd(4 * H), W_hh1=rnd(4 * H, H), b_hh1=rnd(4 * H), W1=rnd(U, H),
+                b1=rnd(U), W2=rnd(V, U, s=0.5), b2=rnd(V))
+
+
+def _token_pass(x, mode, hc_init=None, first_tok=None):
+    ops.set_option(14, mode)
+    try:
+        t = ops.arnn_generate(x["emb"], x["oc"], x["W_ih0"], x["b_ih0"], x["W_hh0"], x["b_hh0"], x["W_ih1"], x["b_ih1"], x["W_hh1"],
+                              x["b_hh1"], x["W1"], x["b1"], x["W2"], x["b2"], hc_init=hc_init, first_tok=first_tok)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option(14, 2)
+    return t
+
+
+@pytest.mark.parametrize("V,L", [(48, 384), (61, 100), (128, 37)])
+def test_arnn_token_pass_persistent_kernel_equals_the_per_tick_launches(V, L):
+    """inet_arnn_generate as ONE persistent launch (csrc/arnn_gen.hip: 13 resident workgroups, weights in registers, 8-byte {value, tick}
+    granules between them) against round 4's four launches per tick: the same L tokens (fp32 both, other summation orders: a
+    difference may only appear on a tick whose top two logits agree to rounding, and the test says so), for both placements of the
+    workgroups, from zero state and -- forward_inpaint's use -- from a given state behind a given token."""
+    x = _token_pass_inputs(L=L, V=V, seed=V)
+    ref = _token_pass(x, 0)
+    assert ops.chain_status() == 0
+    assert int(ref.min()) >= 0 and int(ref.max()) < V and len(torch.unique(ref)) > 3      # (a sequence worth comparing)
+    for mode in (1, 2):
+        got = _token_pass(x, mode)
+        assert ops.chain_status() == 0
+        same = (got == ref)
+        first = L if bool(same.all()) else int((~same).int().argmax())
+        assert first == L, f"mode {mode}: token {first} differs ({int(got[first])} vs {int(ref[first])}): a near-tie of the two sums?"
+    g = torch.Generator().manual_seed(5)
+    hc = ((torch.rand(2, 2, 256, generator=g) * 2 - 1) * 0.5).cuda()
+    ft = torch.tensor([V], dtype=torch.int64).cuda()             # a token the head cannot produce (row V of the embedding table)
+    ref = _token_pass(x, 0, hc_init=hc, first_tok=ft)
+    got = _token_pass(x, 1, hc_init=hc, first_tok=ft)
+    assert torch.equal(got, ref)
+    assert not torch.equal(got, _token_pass(x, 1))                # (the state and the token matter)
+
+
+def test_arnn_token_pass_with_nan_weights_stays_inside_the_vocabulary():
+    """an all-NaN logit row used to yield token INT_MAX and the next tick's embedding gather faulted.  Both forms follow
+    np.argmax now (a NaN is the maximum, lowest index among equals): tokens stay in [0, V), nothing faults, and the NaN shows up where
+    the reference reports it -- Trainer.finish() / check_steps() raise ValueError('... has become nan')."""
+    x = _token_pass_inputs(L=64, V=48)
+    x["W2"][:] = float("nan")
+    for mode in (0, 1):
+        t = _token_pass(x, mode)
+        assert int(t.min()) == 0 and int(t.max()) == 0
+    x = _token_pass_inputs(L=64, V=48)
+    x["W_hh1"][5, 7] = float("nan")                              # the state becomes NaN at tick 1, the logits with it
+    for mode in (0, 1):
+        t = _token_pass(x, mode)
+        assert 0 <= int(t.min()) and int(t.max()) < 48
+    assert ops.chain_status() == 0
+    # through the trainer: a free-running step on NaN weights raises the reference's ValueError, no memory fault
+    ds, model = build("full")
+    model.train()
+    trainer = AnticipationRNNGaussianRegTrainer(ds, model)
+    fx = G.load("arnn_full")
+    score = torch.from_numpy(fx["score"]).cuda()
+    md = torch.from_numpy(fx["metadata"]).cuda()
+    loc = torch.from_numpy(fx["constraints_loc"]).cuda()
+    a, b = [int(v) for v in fx["ticks"]]
+    model.param("linear_ouput_notes.0.weight")[:] = float("nan")
+    trainer.zero_grad()
+    weights, gen = model(score, md, loc, a, b, train=True, teacher_forcing=False)
+    assert int(gen.min()) >= 0 and int(gen.max()) < 48
+    loss, _ = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, score[:, :, a:b].transpose(0, 1))
+    loss.backward()
+    trainer.step()
+    with pytest.raises(ValueError, match="has become nan"):
+        trainer.finish()

@@ -136,8 +136,12 @@ def busy(csv_path, traffic_json=None, seq_json=None, simds=1024, xccs=8):
     SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE.  The CSV holds every counter SUMMED over its hardware instances: GRBM_GUI_ACTIVE over the 8
     XCCs (rocprofv3's own MfmaUtil takes the max over instances), so it is divided by `xccs` here -- the first table of round 4
     showed 17-20 "GHz" and MFMA-busy fractions 8x too small without that.  Kernels of a few tens of microseconds read too high a
-    clock (the counter window is wider than the kernel).  Printed as a table; with `traffic_json` the two fractions are merged
-    into that file's entries (bench.py quotes them next to the traffic figures)."""
+    clock: the counter window is wider than the kernel's timestamps, so GRBM_GUI_ACTIVE -- the denominator of mfma_busy too --
+    is inflated (3.2-15.8 "GHz" for everything under ~50 us).  A row whose derived clock exceeds the part's 2.4 GHz
+    (+2 %) is marked `unreliable`: its clock is not reported, and its MFMA-busy share is given as a LOWER BOUND -- the larger of
+    busy / (inflated window) and busy / (duration x 2.4 GHz x SIMDs); bench.py does not quote unreliable rows.  Printed as a
+    table; with `traffic_json` the fractions are merged into that file's entries."""
+    MAX_GHZ = 2.4
     seqs = json.load(open(seq_json)) if seq_json else None
     cols = {}
     for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
@@ -150,18 +154,35 @@ def busy(csv_path, traffic_json=None, seq_json=None, simds=1024, xccs=8):
         gsum = gsum / xccs
         mf = cols["SQ_VALU_MFMA_BUSY_CYCLES"].get(key, [0, 0.0, 0.0])[1]
         sq = cols["SQ_BUSY_CYCLES"].get(key, [0, 0.0, 0.0])[1]
-        rows.append((us, key, n, us / n, mf / (gsum * simds), gsum / n / (us / n * 1e3), sq / gsum))
+        ghz = gsum / n / (us / n * 1e3)
+        mfb = mf / (gsum * simds)
+        bad = ghz > 1.02 * MAX_GHZ
+        if bad:                                                   # the window, not the kernel: lower bound from both denominators
+            mfb = max(mfb, mf / (us * 1e3 * MAX_GHZ * simds))
+        rows.append((us, key, n, us / n, mfb, ghz, sq / gsum, bad))
     rows.sort(reverse=True)
     print(f"{'kernel|grid[#label]':<78} {'calls':>6} {'avg_us':>9} {'mfma_busy':>10} {'clock_GHz':>10} {'sq_busy/gui':>12}")
-    for us, key, n, avg, mfb, ghz, sqb in rows[:40]:
-        print(f"{key:<78} {n:>6d} {avg:>9.2f} {mfb:>10.3f} {ghz:>10.2f} {sqb:>12.2f}")
+    for us, key, n, avg, mfb, ghz, sqb, bad in rows[:40]:
+        if bad:
+            print(f"{key:<78} {n:>6d} {avg:>9.2f} {'>=' + format(mfb, '.3f'):>10} {'unreliable':>10} {'-':>12}")
+        else:
+            print(f"{key:<78} {n:>6d} {avg:>9.2f} {mfb:>10.3f} {ghz:>10.2f} {sqb:>12.2f}")
     if traffic_json:
         doc = json.load(open(traffic_json))
-        for us, key, n, avg, mfb, ghz, sqb in rows:
+        for us, key, n, avg, mfb, ghz, sqb, bad in rows:
             if key in doc["kernels"]:
-                doc["kernels"][key]["mfma_busy_frac"] = round(mfb, 4)
-                doc["kernels"][key]["clock_ghz_profiled"] = round(ghz, 3)
-        doc["source"] += " ; mfma_busy_frac / clock_ghz_profiled from a pass with --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+                ent = doc["kernels"][key]
+                for k in ("mfma_busy_frac", "clock_ghz_profiled", "mfma_busy_frac_lower_bound", "busy_counters_unreliable"):
+                    ent.pop(k, None)
+                if bad:
+                    ent["mfma_busy_frac_lower_bound"] = round(mfb, 4)
+                    ent["busy_counters_unreliable"] = True
+                else:
+                    ent["mfma_busy_frac"] = round(mfb, 4)
+                    ent["clock_ghz_profiled"] = round(ghz, 3)
+        doc["source"] += (" ; mfma_busy_frac / clock_ghz_profiled from a pass with --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
+                          "GRBM_GUI_ACTIVE (rows whose counter window exceeds the kernel -- derived clock > 2.4 GHz -- carry "
+                          "mfma_busy_frac_lower_bound instead)")
         json.dump(doc, open(traffic_json, "w"), indent=1)
 
 

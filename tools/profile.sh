@@ -4,7 +4,7 @@
 #   TCC slots; never combined with trace domains) once with every step teacher-forced and once free-running (INET_BENCH_COIN), so
 #   that every step of a pass launches the same kernel sequence and kernels that share an instantiation + grid can be told apart
 #   by launch order; kernel stats of the LatentRNN and AnticipationRNN steps.
-# usage: tools/profile_r04.sh <tag>
+# usage: tools/profile.sh <tag>
 set -u
 TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round refresh of the secondary workloads' traces (the headline kernels did not change after profiles/r04_y_*):
-#   kernel stats + one-step timeline of the AnticipationRNN and LatentRNN steps.   usage: tools/profile_r04z.sh <tag>
+#   kernel stats + one-step timeline of the AnticipationRNN and LatentRNN steps.   usage: tools/profile_secondary.sh <tag>
 set -u
 TAG=${1:-r04z}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
