@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INET_LIB_PATH") or os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["arnn_gen.hip", "gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip", "gemm_bf3.hip", "gru_step_bf3.hip"]
+SOURCES = ["arnn_gen.hip", "decode_b1.hip", "gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip", "gemm_bf3.hip", "gru_step_bf3.hip"]
 
 _lib = None
 

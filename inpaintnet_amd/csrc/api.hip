@@ -5,6 +5,7 @@
 #include "vae.h"
 #include "lstm.h"
 #include "chain.h"
+#include "decode_chain.h"
 #include "gemm_bf3.h"
 #include "gru_step_bf3.h"
 
@@ -456,6 +457,7 @@ int inet_set_option(int key, int value) {
     if (key == 12) { gru_step_bf3_set_min_tiles(value); return 0; }
     if (key == 13) { if (value < 0 || value > 3) return -1; side_set_active(value); return 0; }
     if (key == 14) { if (value < 0 || value > 2) return -1; arnn_gen_set_mode(value); return 0; }
+    if (key == 15) { if (value < 0 || value > 2) return -1; decode_b1_set_mode(value); return 0; }
     return -1;
 }
 

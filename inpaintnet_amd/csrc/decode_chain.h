@@ -18,6 +18,7 @@ struct DecodeChainArgs {
     const float* ht0pk;                           // [2 layers][beats][pk(B,H)] the same, fragment-major
     float* hx0; float* hx1;                       // exchange rings [2][pk(B,H)]
     float* amax;                                  // [2][V/16][ceil16(B)] x {idx, max} (8 bytes each)
+    unsigned long long* b1ex;                     // b = 1 (decode_b1.hip): 8 H zeroed 8-byte granules, or null
     float* weights; long long* samples;           // outputs [B,T,V], [B,1,T]
     unsigned* counters; chain::Status status;
     int prezeroed;                                // the sync words are already zero (gru_chain.h kSyncAreas)
@@ -33,3 +34,10 @@ struct DecodeChainArgs {
 
 bool decode_chain_ok(int B, int H, int V, int T, int G);
 int launch_decode_chain(DecodeChainArgs a, hipStream_t s);
+// one measure, inference: the register-resident persistent launch of decode_b1.hip (launch_decode_chain takes it when it applies;
+// INET_DECODE_B1 / inet_set_option key 15: 0 = never, 1 = consecutive workgroup ids, 2 = default: every 8th id, one XCD)
+constexpr int kDecodeB1Words = 2 * 8 * 512;       // 32-bit words of the granule exchange (8 H granules at H = 512)
+bool decode_b1_shape_ok(int B, int H, int V, int T, int G);
+bool decode_b1_ok(const DecodeChainArgs& a);
+int launch_decode_b1(const DecodeChainArgs& a, hipStream_t s);
+void decode_b1_set_mode(int m);

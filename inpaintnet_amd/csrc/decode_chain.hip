@@ -477,6 +477,7 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
     a.members = a.H / 16;
     if (!a.prezeroed && hipMemsetAsync(a.counters, 0, kDecodeSyncWords * sizeof(unsigned), s) != hipSuccess) return -2;
     a.status = chain_status_for(a.counters + kDecodeStatusWord);
+    if (decode_b1_ok(a)) return launch_decode_b1(a, s);        // one measure: weights in registers, two hand-offs per tick
     const size_t lds = decode_chain_lds_bytes(a.B, a.H);
     char label[72];
     const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;

@@ -182,6 +182,7 @@ struct DecWs {
     float *wpk_b[2], *wpk_t0, *wpk_t1hh, *wpk_t1ih, *wpk_out, *hpk_b, *ht0pk, *hpk_t0, *hpk_t1, *hm0pk;
     float *wpkT[4], *dghpk;
     float* amax; unsigned* sync;                     // fused decode kernel (decode_chain.h): partial argmax, counters
+    unsigned* b1ex;                                  // b = 1: the granule exchange of decode_b1.hip, right in front of `sync` (one zero range)
 };
 
 size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w) {
@@ -250,6 +251,7 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.dghpk = pk && save ? cv.take<float>(nb * chain_ring_floats(B, 3 * (int)H)) : nullptr;
     w.amax = cv.take<float>(2 * 2 * ((V + 15) / 16) * ((B + 15) / 16) * 16);
     static_assert(kDecodeSyncWords <= kChainSyncWords, "one sync area serves either kind of chain launch");
+    w.b1ex = (B == 1 && H == 512 && !save) ? cv.take<unsigned>(kDecodeB1Words) : nullptr;
     w.sync = cv.take<unsigned>(kSyncAreas * kChainSyncWords);
     w.tmp3h = save ? cv.take<float>(3 * H) : nullptr;          // right behind the sync areas: one memset zeroes both
     w.b0part = save ? cv.take<float>(64) : nullptr;            // fixed-order partial sums of the b_0 gradient (pw_beat_input_grad)
@@ -305,6 +307,9 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     const bool fused_chunked = fused_shape && !fused_whole && dec_chunks && B > kDecodeChunk && B % kDecodeChunk == 0 &&
                                decode_chain_ok(kDecodeChunk, H, V, T, G);
     const bool fused_decode = fused_whole || fused_chunked;
+    // one measure, inference: decode_b1.hip's register-resident launch (reads the row-major initial hiddens: no packed twins)
+    const bool b1_decode = fused_whole && !save && !mask_tick && w.b1ex && w.b1ex + kDecodeB1Words == w.sync &&
+                           decode_b1_shape_ok(B, H, V, T, G);
     // teacher-forced ticks: every input token is known and the 4 beats are independent, so each tick layer is a chain of
     // G steps over the beats as problems -- `npl` beats per launch, as many as fit the chip at once (2 at B = 256)
     static const bool tf_chain = [] { const char* v = std::getenv("INET_TF_CHAIN"); return !(v && v[0] == '0'); }();
@@ -328,6 +333,9 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         pr.tab[1] = PwTableJob{p + L.x_0, E, 1, wih0, ldw0, p + L.tick[0].b_ih, w.table + (long)V * 3 * H, 3L * H, 3 * H, E};
         pr.ntab = 2;
         if (beats_chained || fused_decode || ticks_chained) { pr.zero_words = w.sync; pr.nzero = (long)kSyncAreas * kChainSyncWords; }
+        if (b1_decode) {                                       // ... and the b = 1 kernel's granules in front of them
+            pr.zero_words = w.b1ex; pr.nzero = kDecodeB1Words + (long)kSyncAreas * kChainSyncWords;
+        }
         if (save) { pr.copy_src = reinterpret_cast<const unsigned*>(z); pr.copy_dst = reinterpret_cast<unsigned*>(w.zsave); pr.ncopy = (long)B * Z; }
         pr.axpb_a = p + L.b_0; pr.axpb_x = p + L.beat[0].w_ih; pr.axpb_incx = 1; pr.axpb_b = p + L.beat[0].b_ih;
         pr.axpb_y = w.gvec0; pr.axpb_n = 3 * H;
@@ -385,7 +393,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
                                 linear_fwd_args(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU)};
         INET_TRY(launch_gemm_group(bt, 2, s));
     }
-    if (pk && !ticks_chained && !fused_chunked)                // packed initial tick hiddens: [layer][beat]
+    if (pk && !ticks_chained && !fused_chunked && !b1_decode)  // packed initial tick hiddens: [layer][beat]
         for (int l = 0; l < 2; ++l)
             INET_TRY(pw_pack_frag(w.ht0 + (long)l * H, 2L * H, B, H, w.ht0pk + (long)l * nb * pkh, 0, nb, (long)B * 2 * H, pkh, s));
     INET_TRY(linear_fwd(w.c_all, H, wih0 + E, ldw0, nullptr, w.cgi, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
@@ -495,6 +503,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
             a.W_out = p + L.out_w; a.b_out = p + L.out_b;
             a.ht0 = w.ht0 + (long)r0 * 2 * H; a.ht0pk = w.ht0pk;
             a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
+            a.b1ex = b1_decode ? reinterpret_cast<unsigned long long*>(w.b1ex) : nullptr;
             a.weights = weights + (long)r0 * T * V; a.samples = samples + (long)r0 * T;
             a.counters = w.sync + 2 * kChainSyncWords; a.prezeroed = r0 == 0;   // (later chunks: the launcher zeroes the area)
             if (mask_tick) { a.mask = mask_tick + (long)r0 * H; a.hx0m = w.hm0pk; }

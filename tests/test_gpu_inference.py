@@ -200,7 +200,9 @@ def test_fused_decode_kernel_matches_per_tick_path(name, B):
         ops.prof_dump(os.path.join(td, "l.csv"))
         labels = [r["label"] for r in csv.DictReader(open(os.path.join(td, "l.csv")))]
     ops.prof_enable(False)
-    assert any(l.startswith("decode_chain") for l in labels), sorted(set(labels))
+    # (one measure at H = 512 runs the register-resident persistent launch of csrc/decode_b1.hip, everything else decode_chain.hip)
+    want = "decode_b1" if (B == 1 and c["H"] == 512) else "decode_chain"
+    assert any(l.startswith(want) for l in labels), sorted(set(labels))
     assert ops.chain_status() == 0
     ops.set_option(4, 0)
     try:
@@ -349,3 +351,48 @@ def test_fused_decode_matches_per_tick_path_repeatedly():
     finally:
         ops.set_option(4, 1)
     assert ops.chain_status() == 0
+
+
+@pytest.mark.parametrize("V", [48, 20, 61, 93, 128])
+def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V):
+    """One measure (the call the north_star prices: LatentRNNTester.generate, decode_mid_point) through csrc/decode_b1.hip -- 25
+    resident workgroups, the tick GRU's weights in registers, 8-byte {value, tick} granules, two hand-offs per tick -- against the
+    32-member exchange kernel of csrc/decode_chain.hip (inet_set_option key 15 = 0) and the oracle: logits to fp32 round-off, tokens
+    exact on ticks with a margin; both workgroup placements; repeated with a dirtied allocator pool (the granules are zeroed per
+    call by the prologue launch: stale tags of an earlier call must never match)."""
+    from oracle import torch_ref as O
+    from tests.test_gpu_kernels import pack
+    from inpaintnet_amd import layout
+    c = dict(G.CFGS["full"], V=V)
+    cfg = ops.vae_config(c["V"], c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    shapes = layout.vae_param_shapes(V, c["E"], c["H"], c["Z"], c["H"])
+    P = {k: torch.from_numpy(synthetic.det_param(k, s)) for k, s in shapes.items()}
+    params = pack(table, total, P)
+    rng = np.random.RandomState(V)
+    try:
+        for it in range(6):
+            z = torch.from_numpy(synthetic.det_normal(f"b1/{V}/{it}", (1, c["Z"]))).cuda()
+            junk = torch.empty(int(rng.randint(1, 32)) << 20, device="cuda").uniform_(-100, 100)
+            del junk
+            outs = {}
+            for mode in (2, 1, 0):
+                ops.set_option(15, mode)
+                w, s_, _ = ops.decoder_fwd(cfg, z, None, False, params)
+                torch.cuda.synchronize()
+                outs[mode] = (w.clone(), s_.clone())
+            assert ops.chain_status() == 0
+            with torch.no_grad():
+                wr, sr = O.decoder_forward(P, z.cpu(), None, False, feed_tokens=outs[2][1].cpu()[:, 0])
+            top2 = torch.topk(wr, 2, dim=-1).values
+            ok = ((top2[..., 0] - top2[..., 1]) > 1e-4).numpy()
+            for mode in (2, 1):
+                w, s_ = outs[mode]
+                assert G.rel_err(w.cpu(), wr) < 2e-5, (V, it, mode)
+                assert np.array_equal(s_.cpu().numpy()[:, 0][ok], sr.numpy()[:, 0][ok]), (V, it, mode)
+                assert int(s_.min()) >= 0 and int(s_.max()) < V
+            if torch.equal(outs[2][1], outs[0][1]):
+                assert G.rel_err(outs[2][0].cpu(), outs[0][0].cpu()) < 2e-5
+            assert torch.equal(outs[2][1], outs[1][1]) and torch.equal(outs[2][0], outs[1][0])     # placement changes nothing
+    finally:
+        ops.set_option(15, 2)
