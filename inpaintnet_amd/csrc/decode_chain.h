@@ -7,6 +7,19 @@ constexpr int kDecodeCounterStride = 64;          // one 256-byte block per grou
 constexpr int kDecodeStatusWord = kDecodeMaxGroups * kDecodeCounterStride;
 constexpr int kDecodeSyncWords = kDecodeStatusWord + 4;
 
+// b = 1 (decode_b1.hip), beat path folded into the launch: the operands of forward_beat_rnn and the per-beat projections
+// (decoder.py:455-471, 485-497).  z == null: the beat path ran as launches of its own and `cgi` / `ht0` below hold its results.
+struct DecodeB1Beat {
+    const float* z;                               // [Z]
+    const float* zb_w; const float* zb_b;         // z_to_beat_rnn_input: [2H, Z], [2H]
+    const float* gvec0;                           // [3H] beat layer 0's constant input gates b_0 W_ih[:, 0] + b_ih (prologue launch)
+    const float* W_hh0; const float* b_hh0;       // beat layer 0
+    const float* W_ih1; const float* b_ih1; const float* W_hh1; const float* b_hh1;   // beat layer 1
+    const float* bh_w; const float* bh_b;         // beat_emb_to_tick_rnn_hidden: [2H, H]
+    const float* bi_w; const float* bi_b;         // beat_emb_to_tick_rnn_input: [H, H]
+    const float* wih0_c; long wih0_ld;            // tick layer 0's W_ih[:, E:] (row stride E + H)
+};
+
 struct DecodeChainArgs {
     int B, H, T, G, V, members;                   // G = ticks per beat; T = beats * G
     const float* W_hh0; const float* b_hh0;       // tick layer 0: recurrent weights [3H,H], [3H]
@@ -18,7 +31,8 @@ struct DecodeChainArgs {
     const float* ht0pk;                           // [2 layers][beats][pk(B,H)] the same, fragment-major
     float* hx0; float* hx1;                       // exchange rings [2][pk(B,H)]
     float* amax;                                  // [2][V/16][ceil16(B)] x {idx, max} (8 bytes each)
-    unsigned long long* b1ex;                     // b = 1 (decode_b1.hip): 8 H zeroed 8-byte granules, or null
+    unsigned long long* b1ex;                     // b = 1 (decode_b1.hip): kDecodeB1Words / 2 zeroed 8-byte granules, or null
+    DecodeB1Beat beat;                            // ... with the beat path folded in (beat.z != null)
     float* weights; long long* samples;           // outputs [B,T,V], [B,1,T]
     unsigned* counters; chain::Status status;
     int prezeroed;                                // the sync words are already zero (gru_chain.h kSyncAreas)
@@ -35,9 +49,11 @@ struct DecodeChainArgs {
 bool decode_chain_ok(int B, int H, int V, int T, int G);
 int launch_decode_chain(DecodeChainArgs a, hipStream_t s);
 // one measure, inference: the register-resident persistent launch of decode_b1.hip (launch_decode_chain takes it when it applies;
-// INET_DECODE_B1 / inet_set_option key 15: 0 = never, 1 = consecutive workgroup ids, 2 = default: every 8th id, one XCD)
-constexpr int kDecodeB1Words = 2 * 8 * 512;       // 32-bit words of the granule exchange (8 H granules at H = 512)
+// INET_DECODE_B1 / inet_set_option key 15: 0 = never; 1 / 2 = the tick path only, behind the beat path's own launches, on consecutive
+// workgroup ids / on every 8th id (one XCD); 3 = default: the beat path folded into the same launch, 73 workgroups)
+constexpr int kDecodeB1Words = 2 * 27648;         // 32-bit words of the granule area (decode_b1.hip's map: tick exchange + one slot per beat step)
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G);
+bool decode_b1_fused(int Z);                      // ... and the beat path goes into the same launch
 bool decode_b1_ok(const DecodeChainArgs& a);
 int launch_decode_b1(const DecodeChainArgs& a, hipStream_t s);
 void decode_b1_set_mode(int m);

@@ -310,6 +310,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     // one measure, inference: decode_b1.hip's register-resident launch (reads the row-major initial hiddens: no packed twins)
     const bool b1_decode = fused_whole && !save && !mask_tick && w.b1ex && w.b1ex + kDecodeB1Words == w.sync &&
                            decode_b1_shape_ok(B, H, V, T, G);
+    const bool b1_fused = b1_decode && !mask_beat && decode_b1_fused((int)Z);   // ... with the beat path inside the same launch
     // teacher-forced ticks: every input token is known and the 4 beats are independent, so each tick layer is a chain of
     // G steps over the beats as problems -- `npl` beats per launch, as many as fit the chip at once (2 at B = 256)
     static const bool tf_chain = [] { const char* v = std::getenv("INET_TF_CHAIN"); return !(v && v[0] == '0'); }();
@@ -349,7 +350,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     if (pk) {
         const float* ins[5]; float* outs[5];
         int n = 0;
-        if (!beats_chained) {
+        if (!beats_chained && !b1_fused) {
             ins[n] = p + L.beat[0].w_hh; outs[n++] = w.wpk_b[0];
             ins[n] = p + L.beat[1].w_hh; outs[n++] = w.wpk_b[1];
         }
@@ -363,40 +364,42 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
             INET_TRY(pw_pack_frag(p + L.out_w, H, V, H, w.wpk_out, 0, 1, 0, 0, s));
     }
 
-    // ---- beat RNN (forward_beat_rnn, decoder.py:455-471) ----
-    INET_TRY(linear_fwd(z, Z, p + L.zb_w, Z, p + L.zb_b, w.hb0, 2L * H, B, 2 * H, Z, EPI_SELU, s));
-    DirFwd d{};
-    d.W_hh = p + L.beat[0].w_hh; d.b_hh = p + L.beat[0].b_hh;
-    d.gvec = w.gvec0;
-    d.h0 = w.hb0; d.h0_ld = 2L * H;
-    d.out = w.beat0; d.out_ld = H; d.out_ts = BH;
-    if (mask_beat) { d.outm = w.beat0m; d.outm_ld = H; d.outm_ts = BH; d.mask = mask_beat; d.mask_ld = H; d.mask_ts = BH; }
-    if (save) { d.sv = w.svb0; d.sv_astride = nb * BH; }
-    d.Wpk_hh = w.wpk_b[0]; d.hpk = w.hpk_b;
-    if (beats_chained) { d.sync = w.sync; d.sync_prezeroed = 1; }   // 4 steps in one launch (8 groups of 32 rows at B = 256)
-    INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
-    const float* xb = mask_beat ? w.beat0m : w.beat0;
-    INET_TRY(linear_fwd(xb, H, p + L.beat[1].w_ih, H, p + L.beat[1].b_ih, w.gi1b, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
-    d = DirFwd{};
-    d.W_hh = p + L.beat[1].w_hh; d.b_hh = p + L.beat[1].b_hh;
-    d.gi = w.gi1b; d.gi_ld = 3L * H; d.gi_ts = 3 * BH;
-    d.h0 = w.hb0 + H; d.h0_ld = 2L * H;
-    d.out = w.beat_out; d.out_ld = H; d.out_ts = BH;
-    if (save) { d.sv = w.svb1; d.sv_astride = nb * BH; }
-    d.Wpk_hh = w.wpk_b[1]; d.hpk = w.hpk_b;
-    if (beats_chained) { d.sync = w.sync + kChainSyncWords; d.sync_prezeroed = 1; }
-    INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
+    if (!b1_fused) {                                           // (one measure: these eight launches are roles of decode_b1.hip's launch)
+        // ---- beat RNN (forward_beat_rnn, decoder.py:455-471) ----
+        INET_TRY(linear_fwd(z, Z, p + L.zb_w, Z, p + L.zb_b, w.hb0, 2L * H, B, 2 * H, Z, EPI_SELU, s));
+        DirFwd d{};
+        d.W_hh = p + L.beat[0].w_hh; d.b_hh = p + L.beat[0].b_hh;
+        d.gvec = w.gvec0;
+        d.h0 = w.hb0; d.h0_ld = 2L * H;
+        d.out = w.beat0; d.out_ld = H; d.out_ts = BH;
+        if (mask_beat) { d.outm = w.beat0m; d.outm_ld = H; d.outm_ts = BH; d.mask = mask_beat; d.mask_ld = H; d.mask_ts = BH; }
+        if (save) { d.sv = w.svb0; d.sv_astride = nb * BH; }
+        d.Wpk_hh = w.wpk_b[0]; d.hpk = w.hpk_b;
+        if (beats_chained) { d.sync = w.sync; d.sync_prezeroed = 1; }   // 4 steps in one launch (8 groups of 32 rows at B = 256)
+        INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
+        const float* xb = mask_beat ? w.beat0m : w.beat0;
+        INET_TRY(linear_fwd(xb, H, p + L.beat[1].w_ih, H, p + L.beat[1].b_ih, w.gi1b, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
+        d = DirFwd{};
+        d.W_hh = p + L.beat[1].w_hh; d.b_hh = p + L.beat[1].b_hh;
+        d.gi = w.gi1b; d.gi_ld = 3L * H; d.gi_ts = 3 * BH;
+        d.h0 = w.hb0 + H; d.h0_ld = 2L * H;
+        d.out = w.beat_out; d.out_ld = H; d.out_ts = BH;
+        if (save) { d.sv = w.svb1; d.sv_astride = nb * BH; }
+        d.Wpk_hh = w.wpk_b[1]; d.hpk = w.hpk_b;
+        if (beats_chained) { d.sync = w.sync + kChainSyncWords; d.sync_prezeroed = 1; }
+        INET_TRY(gru_layer_fwd(H, B, nb, 1, &d, s));
 
-    // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
-    {
-        const GemmArgs bt[2] = {linear_fwd_args(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU),
-                                linear_fwd_args(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU)};
-        INET_TRY(launch_gemm_group(bt, 2, s));
+        // ---- per-beat constants for the tick RNN (decoder.py:494-495), all 4 beats at once ----
+        {
+            const GemmArgs bt[2] = {linear_fwd_args(w.beat_out, H, p + L.bh_w, H, p + L.bh_b, w.ht0, 2L * H, nb * B, 2 * H, H, EPI_SELU),
+                                    linear_fwd_args(w.beat_out, H, p + L.bi_w, H, p + L.bi_b, w.c_all, H, nb * B, H, H, EPI_SELU)};
+            INET_TRY(launch_gemm_group(bt, 2, s));
+        }
+        if (pk && !ticks_chained && !fused_chunked && !b1_decode)  // packed initial tick hiddens: [layer][beat]
+            for (int l = 0; l < 2; ++l)
+                INET_TRY(pw_pack_frag(w.ht0 + (long)l * H, 2L * H, B, H, w.ht0pk + (long)l * nb * pkh, 0, nb, (long)B * 2 * H, pkh, s));
+        INET_TRY(linear_fwd(w.c_all, H, wih0 + E, ldw0, nullptr, w.cgi, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
     }
-    if (pk && !ticks_chained && !fused_chunked && !b1_decode)  // packed initial tick hiddens: [layer][beat]
-        for (int l = 0; l < 2; ++l)
-            INET_TRY(pw_pack_frag(w.ht0 + (long)l * H, 2L * H, B, H, w.ht0pk + (long)l * nb * pkh, 0, nb, (long)B * 2 * H, pkh, s));
-    INET_TRY(linear_fwd(w.c_all, H, wih0 + E, ldw0, nullptr, w.cgi, 3L * H, nb * B, 3 * H, H, EPI_NONE, s));
 
     // ---- tick RNN (forward_tick_rnn, decoder.py:473-529) ----
     if (ticks_chained) {
@@ -504,6 +507,14 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
             a.ht0 = w.ht0 + (long)r0 * 2 * H; a.ht0pk = w.ht0pk;
             a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
             a.b1ex = b1_decode ? reinterpret_cast<unsigned long long*>(w.b1ex) : nullptr;
+            if (b1_fused) {
+                DecodeB1Beat& bt = a.beat;
+                bt.z = z; bt.zb_w = p + L.zb_w; bt.zb_b = p + L.zb_b; bt.gvec0 = w.gvec0;
+                bt.W_hh0 = p + L.beat[0].w_hh; bt.b_hh0 = p + L.beat[0].b_hh;
+                bt.W_ih1 = p + L.beat[1].w_ih; bt.b_ih1 = p + L.beat[1].b_ih; bt.W_hh1 = p + L.beat[1].w_hh; bt.b_hh1 = p + L.beat[1].b_hh;
+                bt.bh_w = p + L.bh_w; bt.bh_b = p + L.bh_b; bt.bi_w = p + L.bi_w; bt.bi_b = p + L.bi_b;
+                bt.wih0_c = wih0 + E; bt.wih0_ld = ldw0;
+            }
             a.weights = weights + (long)r0 * T * V; a.samples = samples + (long)r0 * T;
             a.counters = w.sync + 2 * kChainSyncWords; a.prezeroed = r0 == 0;   // (later chunks: the launcher zeroes the area)
             if (mask_tick) { a.mask = mask_tick + (long)r0 * H; a.hx0m = w.hm0pk; }
