@@ -1016,7 +1016,9 @@ def main():
                 adt, _ = timed(la.step, 20, 4, fence)
                 extras["latent_rnn_train_auto_reg"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * 20 / adt, 1),
                                                        "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 20 / adt, 1),
-                                                       "ms_per_step": round(1e3 * adt / 20, 3), **la.describe(1)}
+                                                       "ms_per_step": round(1e3 * adt / 20, 3), **la.describe(1),
+                                                       # (the mean over the teacher-forcing coin of the four profiled steps)
+                                                       "kernels": secondary_table(la.step)}
                 del la
                 wl.model.trainable = True                      # (LatentRNN froze the shared VAE)
                 wl.model.train()

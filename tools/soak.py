@@ -38,3 +38,24 @@ print(f"arnn: {na} teacher-forced steps at {r['ms_per_step']} ms, {max(10, na //
       f"chain_status {ops.chain_status()}", flush=True)
 assert ops.chain_status() == 0 and ops.token_status() == 0
 print("soak ok")
+# round 5: the one-row persistent kernels back to back with training steps in between (their granule areas are re-zeroed per call, their
+# 13 / 73 workgroups must all become resident next to whatever the previous step left running on the side streams)
+vae = wl.model
+lat = bench.LatentWorkload(dev, 0, vae=vae, ds=wl.ds)
+z = torch.randn(1, vae.latent_space_dim, device=dev)
+dummy = torch.zeros(1, 24, device=dev)
+t0 = time.time()
+nd = max(200, nv // 4)
+for i in range(nd):
+    if i % 8 == 0:
+        lat.step()                                   # (a training step, then straight into eval-mode decodes)
+        vae.eval()
+    with torch.no_grad():
+        w, s_ = vae.decoder(z, dummy, train=False)
+    if i % 50 == 0:
+        z = torch.randn(1, vae.latent_space_dim, device=dev)
+lat.trainer.finish()
+torch.cuda.synchronize()
+print(f"b = 1 decodes: {nd} calls interleaved with {nd // 8} LatentRNN steps in {time.time() - t0:.1f} s, chain_status {ops.chain_status()}", flush=True)
+assert ops.chain_status() == 0 and ops.token_status() == 0
+print("soak of the one-row kernels ok")
