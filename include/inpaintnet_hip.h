@@ -334,9 +334,9 @@ int inet_set_option(int key, int value);
  * side streams + the exchange's two streams measured 4.94 ms per B = 256 step against 3.87 with one side stream).
  * key 14 = AnticipationRNN's token pass (inet_arnn_generate; INET_ARNN_GEN): 2 (default) = one persistent launch where the shape
  * allows, its 13 workgroups on every 8th workgroup id (one XCD as dispatched today); 1 = on 13 consecutive ids; 0 = four launches per tick.
- * key 15 = the free-running decode of ONE measure at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 3 (default) = ONE
- * register-resident persistent launch for the whole call behind the prologue launch (73 workgroups: 25 for the 24 ticks -- two
- * hand-offs per tick -- and 48 for the beat path); 2 / 1 = the tick path only, behind the beat path's eight launches, on every 8th
+ * key 15 = the free-running decode of ONE to FOUR measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 3 (default) =
+ * ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for the 24 ticks -- two
+ * hand-offs per tick -- and 80 for the beat path); 2 / 1 = the tick path only, behind the beat path's eight launches, on every 4th
  * workgroup id / on consecutive ids; 0 = decode_chain.hip's 32-member exchange kernel.
  * Keys 4, 7-12, 14 must not change between a forward call and its backward call, nor between sizing a workspace and using it. */
 int inet_side_join(void* stream);

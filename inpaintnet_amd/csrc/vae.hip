@@ -182,7 +182,8 @@ struct DecWs {
     float *wpk_b[2], *wpk_t0, *wpk_t1hh, *wpk_t1ih, *wpk_out, *hpk_b, *ht0pk, *hpk_t0, *hpk_t1, *hm0pk;
     float *wpkT[4], *dghpk;
     float* amax; unsigned* sync;                     // fused decode kernel (decode_chain.h): partial argmax, counters
-    unsigned* b1ex;                                  // b = 1: the granule exchange of decode_b1.hip, right in front of `sync` (one zero range)
+    unsigned* b1ex;                                  // b <= 4: the granule exchange of decode_b1.hip, right in front of `sync` (one zero range)
+    unsigned* b1stamps;                              // ... and its diagnostic stamps (vae_ws_field which = 2, "b1stamps")
 };
 
 size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w) {
@@ -251,7 +252,8 @@ size_t dec_carve(const inet_vae_config& c, int B, int save, void* base, DecWs& w
     w.dghpk = pk && save ? cv.take<float>(nb * chain_ring_floats(B, 3 * (int)H)) : nullptr;
     w.amax = cv.take<float>(2 * 2 * ((V + 15) / 16) * ((B + 15) / 16) * 16);
     static_assert(kDecodeSyncWords <= kChainSyncWords, "one sync area serves either kind of chain launch");
-    w.b1ex = (B == 1 && H == 512 && !save) ? cv.take<unsigned>(kDecodeB1Words) : nullptr;
+    w.b1stamps = (B <= kDecodeB1MaxRows && H == 512 && !save) ? cv.take<unsigned>(kDecodeB1StampWords) : nullptr;
+    w.b1ex = (B <= kDecodeB1MaxRows && H == 512 && !save) ? cv.take<unsigned>(decode_b1_words(B)) : nullptr;
     w.sync = cv.take<unsigned>(kSyncAreas * kChainSyncWords);
     w.tmp3h = save ? cv.take<float>(3 * H) : nullptr;          // right behind the sync areas: one memset zeroes both
     w.b0part = save ? cv.take<float>(64) : nullptr;            // fixed-order partial sums of the b_0 gradient (pw_beat_input_grad)
@@ -308,7 +310,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
                                decode_chain_ok(kDecodeChunk, H, V, T, G);
     const bool fused_decode = fused_whole || fused_chunked;
     // one measure, inference: decode_b1.hip's register-resident launch (reads the row-major initial hiddens: no packed twins)
-    const bool b1_decode = fused_whole && !save && !mask_tick && w.b1ex && w.b1ex + kDecodeB1Words == w.sync &&
+    const bool b1_decode = fused_whole && !save && !mask_tick && w.b1ex && w.b1ex + decode_b1_words(B) == w.sync &&
                            decode_b1_shape_ok(B, H, V, T, G);
     const bool b1_fused = b1_decode && !mask_beat && decode_b1_fused((int)Z);   // ... with the beat path inside the same launch
     // teacher-forced ticks: every input token is known and the 4 beats are independent, so each tick layer is a chain of
@@ -335,7 +337,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
         pr.ntab = 2;
         if (beats_chained || fused_decode || ticks_chained) { pr.zero_words = w.sync; pr.nzero = (long)kSyncAreas * kChainSyncWords; }
         if (b1_decode) {                                       // ... and the b = 1 kernel's granules in front of them
-            pr.zero_words = w.b1ex; pr.nzero = kDecodeB1Words + (long)kSyncAreas * kChainSyncWords;
+            pr.zero_words = w.b1ex; pr.nzero = decode_b1_words(B) + (long)kSyncAreas * kChainSyncWords;
         }
         if (save) { pr.copy_src = reinterpret_cast<const unsigned*>(z); pr.copy_dst = reinterpret_cast<unsigned*>(w.zsave); pr.ncopy = (long)B * Z; }
         pr.axpb_a = p + L.b_0; pr.axpb_x = p + L.beat[0].w_ih; pr.axpb_incx = 1; pr.axpb_b = p + L.beat[0].b_ih;
@@ -507,6 +509,8 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
             a.ht0 = w.ht0 + (long)r0 * 2 * H; a.ht0pk = w.ht0pk;
             a.hx0 = w.hpk_t0; a.hx1 = w.hpk_t1; a.amax = w.amax;
             a.b1ex = b1_decode ? reinterpret_cast<unsigned long long*>(w.b1ex) : nullptr;
+            static const bool b1st = [] { const char* v = std::getenv("INET_DECODE_B1_STAMPS"); return v && v[0] == '1'; }();
+            a.b1stamps = (b1_decode && b1st && T <= 32) ? reinterpret_cast<unsigned long long*>(w.b1stamps) : nullptr;
             if (b1_fused) {
                 DecodeB1Beat& bt = a.beat;
                 bt.z = z; bt.zb_w = p + L.zb_w; bt.zb_b = p + L.zb_b; bt.gvec0 = w.gvec0;
@@ -770,6 +774,11 @@ int vae_ws_field(const inet_vae_config& c, int B, int which, const char* name, l
         if (f == "hb0") { p = w.hb0; n = (long long)B * 2 * H; }                 // [B, 2H]
         else if (f == "ht0") { p = w.ht0; n = nb * B * 2 * H; }                  // [beats, B, 2H]
         else if (f == "c_all") { p = w.c_all; n = nb * B * H; }                  // [beats, B, H]
+    }
+    else if (which == 2) {                                   // the inference workspace (save = 0)
+        DecWs w{};
+        dec_carve(c, B, 0, base, w);
+        if (f == "b1stamps" && w.b1stamps) { p = reinterpret_cast<const float*>(w.b1stamps); n = kDecodeB1StampWords; }
     }
     if (!p) return -1;
     if (offset_floats) *offset_floats = (reinterpret_cast<const char*>(p) - base) / (long long)sizeof(float);

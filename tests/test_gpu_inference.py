@@ -200,8 +200,8 @@ def test_fused_decode_kernel_matches_per_tick_path(name, B):
         ops.prof_dump(os.path.join(td, "l.csv"))
         labels = [r["label"] for r in csv.DictReader(open(os.path.join(td, "l.csv")))]
     ops.prof_enable(False)
-    # (one measure at H = 512 runs the register-resident persistent launch of csrc/decode_b1.hip, everything else decode_chain.hip)
-    want = "decode_b1" if (B == 1 and c["H"] == 512) else "decode_chain"
+    # (one to four measures at H = 512 run the register-resident persistent launch of csrc/decode_b1.hip, everything else decode_chain.hip)
+    want = "decode_b1" if (B <= 4 and c["H"] == 512) else "decode_chain"
     assert any(l.startswith(want) for l in labels), sorted(set(labels))
     assert ops.chain_status() == 0
     ops.set_option(4, 0)
@@ -353,10 +353,11 @@ def test_fused_decode_matches_per_tick_path_repeatedly():
     assert ops.chain_status() == 0
 
 
-@pytest.mark.parametrize("V", [48, 20, 61, 93, 128])
-def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V):
-    """One measure (the call the north_star prices: LatentRNNTester.generate, decode_mid_point) through csrc/decode_b1.hip -- 73
-    resident workgroups (25 for the ticks, 48 for the beat path folded into the same launch), every weight matrix in registers, 8-byte {value, tick} granules, two hand-offs per tick -- against the
+@pytest.mark.parametrize("V,B", [(48, 1), (20, 1), (61, 1), (93, 1), (128, 1), (48, 2), (48, 3), (48, 4), (61, 4), (125, 3)])
+def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V, B):
+    """One measure (the call the north_star prices: LatentRNNTester.generate, decode_mid_point) -- and the two to four measures of the
+    reference's non-auto-regressive inpainting call -- through csrc/decode_b1.hip -- 129
+    resident workgroups (49 for the ticks, 80 for the beat path folded into the same launch), every weight matrix in registers, 8-byte {value, tick} granules, two hand-offs per tick, the rows looped inside every phase -- against the
     32-member exchange kernel of csrc/decode_chain.hip (inet_set_option key 15 = 0) and the oracle: logits to fp32 round-off, tokens
     exact on ticks with a margin; both workgroup placements; repeated with a dirtied allocator pool (the granules are zeroed per
     call by the prologue launch: stale tags of an earlier call must never match)."""
@@ -371,8 +372,8 @@ def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V):
     params = pack(table, total, P)
     rng = np.random.RandomState(V)
     try:
-        for it in range(6):
-            z = torch.from_numpy(synthetic.det_normal(f"b1/{V}/{it}", (1, c["Z"]))).cuda()
+        for it in range(6 if B == 1 else 3):
+            z = torch.from_numpy(synthetic.det_normal(f"b1/{V}/{B}/{it}", (B, c["Z"]))).cuda()
             junk = torch.empty(int(rng.randint(1, 32)) << 20, device="cuda").uniform_(-100, 100)
             del junk
             outs = {}
@@ -395,7 +396,13 @@ def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V):
                 assert int(s_.min()) >= 0 and int(s_.max()) < V
             if torch.equal(outs[3][1], outs[0][1]):
                 assert G.rel_err(outs[3][0].cpu(), outs[0][0].cpu()) < 2e-5
-            assert torch.equal(outs[2][1], outs[1][1]) and torch.equal(outs[2][0], outs[1][0])     # placement changes nothing
+            # placement changes nothing: bit-identical where the beat path's launches in front are deterministic (one row: wave-per-
+            # column products); with more rows their split-K products sum in launch order, so round-off there
+            assert torch.equal(outs[2][1], outs[1][1])
+            if B == 1:
+                assert torch.equal(outs[2][0], outs[1][0])
+            else:
+                assert G.rel_err(outs[2][0].cpu(), outs[1][0].cpu()) < 2e-6
             # tick 0 depends on no sampled token: the folded beat path must reproduce the launches' beat 0 to round-off
             assert float((outs[3][0][:, 0] - outs[2][0][:, 0]).abs().max()) < 2e-5 * float(outs[2][0].abs().max())
     finally:

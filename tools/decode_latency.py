@@ -27,3 +27,44 @@ for mode in (0, 1, 2, 3):
         torch.cuda.synchronize()
     print(f"b = 1, decode kernel mode {mode}: {1e3 * (time.perf_counter() - t0) / 300:.4f} ms per call, chain status {ops.chain_status()}")
 ops.set_option(15, 3)
+
+# two to four measures (the reference's non-auto-regressive inpainting call) on the register-resident kernel (mode 3) and on
+# decode_chain.hip's exchange kernel (mode 0)
+for b in (2, 3, 4, 5, 8):
+    z = torch.randn(b, vae.latent_space_dim, device="cuda")
+    dummy = torch.zeros(b, 24, device="cuda")
+    line = []
+    for mode in (0, 3):
+        ops.set_option(15, mode)
+        with torch.no_grad():
+            for _ in range(5):
+                vae.decoder(z, dummy, train=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                vae.decoder(z, dummy, train=False)
+            torch.cuda.synchronize()
+        line.append(f"mode {mode}: {1e3 * (time.perf_counter() - t0) / 200:.4f} ms")
+    print(f"b = {b}: " + ", ".join(line) + f", chain status {ops.chain_status()}")
+ops.set_option(15, 3)
+
+if os.environ.get("INET_DECODE_B1_STAMPS") == "1":
+    # anatomy of a tick from in-kernel wall-clock stamps (10 ns units), workgroup C and workgroup TBi_0
+    from inpaintnet_amd import ops as _o
+    for b in (1, 2, 4):
+        z = torch.randn(b, vae.latent_space_dim, device="cuda")
+        with torch.no_grad():
+            for _ in range(3):
+                w, s_, ws = _o.decoder_fwd(vae.cfg, z, None, False, vae.flat)
+        torch.cuda.synchronize()
+        st = _o.ws_field(vae.cfg, ws, b, 2, "b1stamps").cpu().view(torch.int64).view(2, 32, 8).double() * 0.01
+        c, t = st[0, 2:23], st[1, 2:23]
+        names = ["table rows + cells + publish h0", "wait for h1 (TBi: product, cell, two hand-offs)", "barrier", "head product(s) + barrier",
+                 "argmax + barrier", "look at the next tick's gh0"]
+        print(f"b = {b}: C, mean us per phase over ticks 2..22 (tick period {float((st[0, 3:24, 0] - st[0, 2:23, 0]).mean()):.2f} us)")
+        for i, n in enumerate(names):
+            print(f"  {float((c[:, i + 1] - c[:, i]).mean()):6.2f}  {n}")
+        names_t = ["wait for gh1 (requested early)", "wait for h0", "barrier", "W_ih1 product(s) + cells + publish h1"]
+        print("  TBi_0:")
+        for i, n in enumerate(names_t):
+            print(f"  {float((t[:, i + 1] - t[:, i]).mean()):6.2f}  {n}")
