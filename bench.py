@@ -274,7 +274,7 @@ class LatentWorkload:
     units_per_step = 16 * LATENT_SEQ_PER_GPU
     unit = "measures/s"
 
-    def __init__(self, dev, rank, vae=None, ds=None, auto_reg=False):
+    def __init__(self, dev, rank, vae=None, ds=None, auto_reg=False, encode_all=True):
         from inpaintnet_amd import synthetic
         from inpaintnet_amd.latent_rnn import LatentRNN
         from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
@@ -287,6 +287,12 @@ class LatentWorkload:
         self.model = LatentRNN(self.ds, vae, num_rnn_layers=2, rnn_hidden_size=512, dropout=0.5, rnn_class=torch.nn.GRU,
                                auto_reg=auto_reg, teacher_forcing=True)
         self.auto_reg = auto_reg
+        # encode_all: the reference's work measure for measure -- it encodes the target measures in every forward pass and reads
+        # the result only when the auto-regressive generator is teacher-forced (latent_rnn.py:133, 148-149).  The package drops
+        # that dead encode by default (LatentRNN.encode_unused_target = False); SURVEY.md section 8(d) prices 16 encodes per
+        # sequence, so the LatentRNN lines of this file time all 16 and `latent_rnn_train_default` the package's default.
+        self.model.encode_unused_target = bool(encode_all)
+        self.encode_all = bool(encode_all)
         own = {k: torch.from_numpy(synthetic.det_param(k, tuple(v.shape))) for k, v in self.model.named_parameters()}
         for k, v in own.items():
             self.model.param(k).copy_(v)
@@ -1011,6 +1017,17 @@ def main():
                                               "ms_per_step": round(1e3 * ldt / 20, 3), **lw.describe(1),
                                               "kernels": secondary_table(lw.step)}
                 del lw
+                ld = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds, encode_all=False)
+                ddt, _ = timed(ld.step, 20, 4, fence)
+                extras["latent_rnn_train_default"] = {
+                    "sequences_per_s": round(LATENT_SEQ_PER_GPU * 20 / ddt, 1), "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 20 / ddt, 1),
+                    "ms_per_step": round(1e3 * ddt / 20, 3),
+                    "workload": "the same step as latent_rnn_train with the package's default: the target measures are NOT encoded when "
+                                "nothing reads their latents (auto_reg=False: never; the reference encodes them in every forward pass and "
+                                "drops the result, latent_rnn.py:133,148-149): 12 instead of 16 frozen-encoder passes per sequence, "
+                                "identical outputs, gradients and weights",
+                    "kernels": secondary_table(ld.step)}
+                del ld
                 random.seed(99)
                 la = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds, auto_reg=True)
                 adt, _ = timed(la.step, 20, 4, fence)

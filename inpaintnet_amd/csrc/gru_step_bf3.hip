@@ -208,7 +208,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gru_step
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
-            const int i = ip + ii;
+            const int i = ip + ii < RM ? ip + ii : RM - 1;         // (odd RM -- the 96-row tile --: the last pair's second half is idle)
+            if (ip + ii >= RM) break;
             float* const x = xt + ii * (NT * 256);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gru_step
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
+            if (ip + ii >= RM) break;
             const float* const x = xt + ii * (NT * 256);
             const long vr = (long)(tm * TMB + wm * RM + ip + ii) * 16 + vrow;
             const f32x4 hv4 = *reinterpret_cast<const f32x4*>(x + vrow * 16 + vcol);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gru_step
                         *reinterpret_cast<const f32x4*>(x + (2 + a5) * 256 + vrow * 16 + vcol);
             }
         }
-        {
+        if (ip + phalf < RM) {
             const float* const x = xt + phalf * (NT * 256);
             const long rb = tm * TMB + wm * RM + ip + phalf;
             if (P.An) pieces8_store(x + prow * 16 + 8 * pgrp, P.An + (rb * KB + kbj) * 1024 + plane, P.a_piece);
@@ -436,9 +438,9 @@ __global__ __launch_bounds__(64 * BWM * BWN) void gru_step_bf3_bwd_kernel(BStepA
     }
 }
 
-template <bool TAB, bool DEN, bool SAVE>
-int launch_one(const StepArgs& a, hipStream_t s) {
-    constexpr int WM = 2, WN = 4, RM = 4;                          // 8 waves; wave tile 64 rows x (16 units x 3 gates)
+template <bool TAB, bool DEN, bool SAVE, int RM>
+int launch_one_rm(const StepArgs& a, hipStream_t s) {
+    constexpr int WM = 2, WN = 4;                                  // 8 waves; wave tile 16 RM rows x (16 units x 3 gates)
     constexpr int TMB = WM * RM, TNB = WN * RN;
     auto kern = &gru_step_bf3_kernel<TAB, DEN, SAVE, WM, WN, RM>;
     const size_t lds = (size_t)2 * (TMB + TNB) * 3 * 1024;
@@ -447,6 +449,17 @@ int launch_one(const StepArgs& a, hipStream_t s) {
     const int grid = a.nprob * (a.B / (TMB * 16)) * (a.H / (16 * WN));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// Tile height: 128 rows (RM = 4) or 96 (RM = 3, round 5): one workgroup per CU and launch, so what counts is rounds of 256 tiles x
+// rows per tile -- 1536 rows (LatentRNN's frozen encoder without the target measures nobody reads) are 192 tiles of 128 rows = one
+// round at 128 rows per CU, or 256 tiles of 96 rows = one round at 96.
+int step_tile_rows(int H, int B, int nd) {
+    auto cost = [&](int rows) { return B % rows ? 1 << 30 : ((nd * (B / rows) * (H / 64) + 255) / 256) * rows; };
+    return cost(96) < cost(128) ? 96 : 128;
+}
+template <bool TAB, bool DEN, bool SAVE>
+int launch_one(const StepArgs& a, hipStream_t s) {
+    return step_tile_rows(a.H, a.B, a.nprob) == 96 ? launch_one_rm<TAB, DEN, SAVE, 3>(a, s) : launch_one_rm<TAB, DEN, SAVE, 4>(a, s);
 }
 
 }  // namespace
@@ -462,9 +475,9 @@ void gru_step_bf3_set_min_tiles(int n) { g_min_tiles = n < 0 ? 0 : n; }
 bool gru_step_bf3_ok(int H, int B, int T, int nd) {
     const int min_tiles = min_tiles_now();
     if (bf3_mode() == 0 || min_tiles <= 0) return false;
-    if (H < 64 || H % 64 || B < 128 || B % 128 || T < 1 || nd < 1 || nd > 2) return false;
+    if (H < 64 || H % 64 || B < 96 || (B % 128 && B % 96) || T < 1 || nd < 1 || nd > 2) return false;
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;
-    return nd * (B / 128) * (H / 64) >= min_tiles;
+    return nd * (B / step_tile_rows(H, B, nd)) * (H / 64) >= min_tiles;
 }
 
 size_t gru_step_bf3_w_bytes(int H) { return bf3_bytes(3L * H, H); }

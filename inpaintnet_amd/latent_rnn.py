@@ -100,6 +100,12 @@ class LatentRNN(Model):
         self.trainable = True
         self.lcfg = LatentConfig(self.z_dim, rnn_hidden_size, int(bool(auto_reg)))
         # which contexts initialise the generator: both (LatentRNN) or one of them (LatentRNNAblations)
+        # The reference encodes the target measures in every forward pass (latent_rnn.py:133) but reads the result only when the
+        # auto-regressive generator is teacher-forced (:148-149): for auto_reg=False, for the free-running side of the coin and in
+        # eval mode a quarter of the frozen encoder's work (4 of 16 measures at 6/4/6) is computed and dropped.  Outputs, gradients
+        # and updated weights do not depend on it, so by default it is not computed (the coin is drawn first; the `random` stream
+        # sees the same draws).  True = do the reference's work measure for measure (what bench.py's LatentRNN lines time).
+        self.encode_unused_target = os.environ.get("INET_LATENT_ENCODE_ALL", "0") == "1"
         self.context_mode = getattr(self, "context_mode", "both")
         self.gen_hidden = 2 * rnn_hidden_size if self.context_mode == "both" else rnn_hidden_size
         if self.context_mode == "both":
@@ -204,34 +210,38 @@ class LatentRNN(Model):
         batch_size, _, measure_seq_len = past_context.size()
         n_past, n_future = past_context.size(1), future_context.size(1)
         n_target = target.size(1) if target is not None else 0        # inference: no target (latent_rnn_tester.py:231-236)
-        # one encoder call over all measures of the sequence
-        parts = (past_context, target, future_context) if target is not None else (past_context, future_context)
+        # the teacher-forcing coin first (the reference draws it behind the context GRUs, :142-145: nothing else reads `random` in
+        # between, so the stream is the same): whether the target measures' latents are needed depends on it
+        if teacher_forcing is None:
+            if self.use_teacher_forcing and train:
+                teacher_forcing = random.random() < self.teacher_forcing_prob
+            else:
+                teacher_forcing = False
+        if teacher_forcing and target is None:
+            raise ValueError("teacher forcing needs the target measures")
+        encode_target = target is not None and (teacher_forcing or self.encode_unused_target)
+        # one encoder call over all measures of the sequence that are read
+        parts = (past_context, target, future_context) if encode_target else (past_context, future_context)
         allm = torch.cat(parts, 1)
         e = None
         if eps is not None:
             es = [eps[0].view(batch_size, n_past, -1)]
-            if target is not None:
+            if encode_target:
                 es.append(eps[2].view(batch_size, n_target, -1))
             es.append(eps[1].view(batch_size, n_future, -1))
             e = torch.cat(es, 1)
         z_all = self.get_z_seq(allm, e)
+        n_enc_t = n_target if encode_target else 0
         zp = z_all[:, :n_past].contiguous()
-        zt = z_all[:, n_past:n_past + n_target].contiguous()
-        zf = z_all[:, n_past + n_target:].contiguous()
+        zt = z_all[:, n_past:n_past + n_enc_t].contiguous()
+        zf = z_all[:, n_past + n_enc_t:].contiguous()
         if self.context_mode == "both":
             comb_context = torch.cat((self.forward_context(zp, type="past"), self.forward_context(zf, type="future")), 2)
         elif self.context_mode == "past":                          # latent_rnn_ablations.py:143-146
             comb_context = self.forward_context(zp, type="past")
         else:
             comb_context = self.forward_context(zf, type="future")
-        if teacher_forcing is None:
-            if self.use_teacher_forcing and train:
-                teacher_forcing = random.random() < self.teacher_forcing_prob
-            else:
-                teacher_forcing = False
         if teacher_forcing:
-            if target is None:
-                raise ValueError("teacher forcing needs the target measures")
             seed = torch.cat((zp[:, -1, :].unsqueeze(1), zt[:, :-1, :]), 1)
         else:
             seed = zp[:, -1, :].unsqueeze(1)

@@ -195,6 +195,7 @@ def test_latent_step_at_bench_batch_vs_oracle(variant, tmp_path, monkeypatch):
                       auto_reg=auto_reg, teacher_forcing=True)
     P = G.latent_params("full", auto_reg)
     model.load_state_dict(P)
+    model.encode_unused_target = True              # the reference's work measure for measure: all 16 measures are encoded (what bench.py times)
     trainer = LatentRNNTrainer(ds, model, lr=1e-4)
     model.train()
     MV.set_dropout_seed(99)

@@ -9,7 +9,7 @@ from tests import golden_util as G
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from inpaintnet_amd import synthetic
+    from inpaintnet_amd import ops, synthetic
     from inpaintnet_amd.latent_rnn import LatentRNN
     from inpaintnet_amd.latent_rnn_trainer import LatentRNNTrainer
     from inpaintnet_amd.measure_vae import MeasureVAE
@@ -115,3 +115,41 @@ def test_state_dict_contains_frozen_vae_and_trainer_loop():
     model.eval()
     lv, av = trainer.loss_and_acc_on_epoch(loader[:1], 0, train=False)
     assert np.isfinite(lv)
+
+
+@pytest.mark.parametrize("auto_reg,tf", [(False, False), (True, False), (True, True)])
+def test_unused_target_encode_changes_nothing(auto_reg, tf):
+    """The reference encodes the target measures in every forward pass (latent_rnn.py:133) and reads the result only when the
+    auto-regressive generator is teacher-forced (:148-149).  The package skips that encode by default when nothing reads it
+    (LatentRNN.encode_unused_target = False): weights, samples, gen_z, the loss and every gradient are IDENTICAL to the pass that
+    encodes all measures (no dropout here, injected eps: the same arithmetic on the same rows)."""
+    name = "small"
+    c = G.CFGS[name]
+    ds = synthetic.SyntheticFolkDataset(num_notes=c["V"])
+    vae = MeasureVAE(ds, note_embedding_dim=c["E"], encoder_hidden_size=c["H"], latent_space_dim=c["Z"], decoder_hidden_size=c["H"],
+                     encoder_dropout_prob=0.0, decoder_dropout_prob=0.0)
+    model = LatentRNN(ds, vae, num_rnn_layers=2, rnn_hidden_size=c["H"], dropout=0.0, rnn_class=torch.nn.GRU, auto_reg=auto_reg,
+                      teacher_forcing=True)
+    model.load_state_dict(G.latent_params(name, auto_reg))
+    trainer = LatentRNNTrainer(ds, model, lr=1e-4)
+    model.train()
+    B, n_past, n_target, n_future = 5, 7, 3, 6
+    score = torch.from_numpy(synthetic.folk_score(B, c["V"], seed=4))
+    past, future, target = LatentRNNTrainer.split_score(score, n_past, n_future, n_target, 24)
+    g = torch.Generator().manual_seed(8)
+    eps = tuple(torch.randn(B, n, c["Z"], generator=g).cuda() for n in (n_past, n_future, n_target))
+    eps_ar = [torch.randn(B, c["Z"], generator=g).cuda() for _ in range(n_target)]
+    res = []
+    for enc_all in (True, False):
+        model.encode_unused_target = enc_all
+        trainer.zero_grad()
+        w, s, gz = model(past, future, target, n_target, train=True, eps=eps, teacher_forcing=tf, eps_ar=eps_ar)
+        loss, acc = trainer.mean_crossentropy_loss_and_accuracy(w, target)
+        loss.backward()
+        ops.side_join()
+        torch.cuda.synchronize()
+        res.append((w.detach().clone(), s.clone(), gz.detach().clone(), float(loss.detach()), model.grad.clone()))
+    (w1, s1, z1, l1, g1), (w0, s0, z0, l0, g0) = res
+    assert torch.equal(s1, s0)
+    assert G.rel_err(w1.cpu(), w0.cpu()) < 1e-6 and G.rel_err(z1.cpu(), z0.cpu()) < 1e-6 and abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert G.rel_err(g1.cpu(), g0.cpu()) < 1e-5
