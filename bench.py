@@ -859,11 +859,41 @@ def arnn_extra(batch=32, steps=30, warmup=4, tables=True, free_steps=10):
         loss.backward()
         trainer.step()
     dt_fr, _ = timed(step_fr, free_steps, 2, torch.cuda.synchronize)
+
+    # ... and as AnticipationRNNGaussianRegTrainer.loss_and_acc_for_batch calls the model (trim=True): the generation LSTMs stop behind the
+    # last unconstrained tick and the head runs on the unconstrained ticks only -- what the reference computes there is read by nobody
+    # (identical weights and gradients: tests/test_gpu_arnn.py); the lines above time ALL 384 ticks, as the reference computes them
+    torch.manual_seed(6)
+    many = [trainer.process_batch_data((score, md)) for _ in range(16)]      # sixteen windows drawn by the trainer's own sampler
+    turn = [0]
+
+    def step_trim(tf):
+        d = many[turn[0] % len(many)]
+        turn[0] += 1
+        trainer.zero_grad()
+        weights, _ = model(d[0], d[1], d[2], d[3], d[4], train=True, teacher_forcing=tf, trim=True)
+        free = free_positions(d[2])
+        loss, acc = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, d[0][:, :, free].transpose(0, 1))
+        loss.backward()
+        trainer.step()
+    nst = max(steps, 2 * len(many))
+    dt_t, _ = timed(lambda: step_trim(True), nst, len(many), torch.cuda.synchronize)
+    turn[0] = 0
+    dt_tf, _ = timed(lambda: step_trim(False), 2 * len(many), len(many), torch.cuda.synchronize)
+    trainer.finish()
     return {"anticipation_rnn_train": {"sequences_per_s": round(batch * steps / dt, 1),
                                        "measures_per_s": round(16 * batch * steps / dt, 1),
                                        "ms_per_step": round(1e3 * dt / steps, 3),
                                        "ms_per_step_free_running": round(1e3 * dt_fr / free_steps, 3),
                                        "ms_per_step_mean_of_the_coin": round(0.5e3 * (dt / steps + dt_fr / free_steps), 3),
+                                       "default_trimmed": {
+                                           "ms_per_step": round(1e3 * dt_t / nst, 3),
+                                           "ms_per_step_free_running": round(1e3 * dt_tf / (2 * len(many)), 3),
+                                           "ms_per_step_mean_of_the_coin": round(0.5e3 * (dt_t / nst + dt_tf / (2 * len(many))), 3),
+                                           "window_end_ticks": [int(d[4]) for d in many],
+                                           "what": "the trainer's own call (trim=True) over sixteen windows drawn by its sampler: the generation "
+                                                   "LSTMs and the head skip the ticks behind the window, which nobody reads (window_end_ticks .. "
+                                                   "383; the lines above use ONE batch whose window ends at tick %d and compute all 384 ticks)" % int(data[4])},
                                        "kernels": secondary_table(step) if tables else None,
                                        "workload": "AnticipationRNN gauss-reg (LSTM 2x2 layers, H=256), teacher-forced "
                                                    "train step, 32 sequences x 384 ticks"}}

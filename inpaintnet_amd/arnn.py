@@ -154,6 +154,13 @@ class ConstraintModelGaussianReg(Model):
         self.dropout_input_prob = dropout_input_prob
         self.dropout_prob = dropout_prob
         self.trainable = True
+        # The generation LSTMs run forward in time and only the unconstrained ticks' outputs are returned (:433-435): everything they
+        # compute BEHIND the last unconstrained tick -- a third of the 384 ticks on average for the trainer's windows -- is read by
+        # nobody, forward and backward (the gradient into those ticks is exactly zero), and the head's two products are read on the
+        # unconstrained ticks only.  A caller that does not read the second return value (the trainers) asks forward() to stop
+        # there (`trim=True`): identical weights and gradients.  False here: always all ticks, as the reference computes them
+        # (what bench.py's AnticipationRNN line times); INET_ARNN_ALL_TICKS=1 sets it.
+        self.skip_unread_ticks = os.environ.get("INET_ARNN_ALL_TICKS", "0") != "1"
         shapes = layout.arnn_param_shapes(self.num_notes_per_voice[0], note_embedding_dim, metadata_embedding_dim,
                                           num_lstm_constraints_units, linear_hidden_size, num_layers,
                                           tuple(self.num_elements_per_metadata))
@@ -239,8 +246,9 @@ class ConstraintModelGaussianReg(Model):
         oc = torch.cat(parts, 2)
         return self._lstm_stack("lstm_constraint", oc, True)
 
-    def _forward_tf(self, score_tensor, metadata_tensor, constraints_loc):
-        """-> [weights (B,L,V)], None   (:348-404)"""
+    def _forward_tf(self, score_tensor, metadata_tensor, constraints_loc, free=None, L_eff=None):
+        """-> [weights (B,L,V)], None   (:348-404).  With `free` (the unconstrained ticks) and L_eff = last of them + 1: the generation
+        LSTMs stop behind tick L_eff - 1 and the head runs on the free ticks only -> [weights (B, n_free, V)]."""
         B, _, L = score_tensor.shape
         oc = self._constraints(score_tensor, metadata_tensor, constraints_loc)
         tok_tm = score_tensor[:, 0].t()                                        # [L,B]
@@ -250,9 +258,14 @@ class ConstraintModelGaussianReg(Model):
             scale = ops.dropout_mask((L, B), self.dropout_input_prob, _DropState.seed, _next_mask_offset(L * B),
                                      tok_tm.device)
         scale[0] = 0.0                                                         # the sequence is offset by a zero vector
+        if free is not None:                                                   # (the same mask stream, its first L_eff steps)
+            shifted, scale, oc = shifted[:L_eff], scale[:L_eff].contiguous(), oc[:L_eff]
         off = self._embed("note_embeddings.0.weight", shifted, scale.view(-1))
         h = torch.cat((off, oc), 2)
         h = self._lstm_stack("lstm_generation", h, False)
+        if free is not None:
+            hf = h.index_select(0, free)                                       # [n_free, B, H]
+            return [self._head(hf.reshape(free.numel() * B, -1)).view(free.numel(), B, -1).permute(1, 0, 2)], None
         w = self._head(h.view(L * B, -1)).view(L, B, -1).permute(1, 0, 2)
         return [w], None
 
@@ -264,12 +277,15 @@ class ConstraintModelGaussianReg(Model):
         U, V = self.param("linear_1.weight").shape[0], self.param("linear_ouput_notes.0.weight").shape[0]
         return ops.arnn_generate_ok(E, oc.shape[-1], self.num_lstm_generation_units, U, V)
 
-    def _forward_no_tf(self, score_tensor, metadata_tensor, constraints_loc):
+    def _forward_no_tf(self, score_tensor, metadata_tensor, constraints_loc, free=None, L_eff=None):
         """-> [weights (B,L,V)], gen_chorale (B,1,L): the argmax of BATCH ELEMENT 0 is fed to the whole batch
-        (:190-259, quirk at :253-256)."""
+        (:190-259, quirk at :253-256).  With `free` / L_eff (see _forward_tf): the ticks behind the last unconstrained one are not
+        generated -> [weights (B, n_free, V)], gen_chorale (B,1,L_eff)."""
         B, _, L = score_tensor.shape
         oc = self._constraints(score_tensor, metadata_tensor, constraints_loc)
         dev = score_tensor.device
+        if free is not None:
+            oc, L = oc[:L_eff], L_eff
         if self._batched_free_run(oc):
             # Only the argmax of batch element 0 is fed back (:253-256): its L tokens come from one sequential pass over that one row
             # (ops.arnn_generate: 4 small launches per tick, no host round trip, no autograd), and with the tokens known the whole
@@ -291,8 +307,12 @@ class ConstraintModelGaussianReg(Model):
                 prev_tm = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), toks[:-1])).view(L, 1).expand(L, B).contiguous()
             h = torch.cat((self._embed("note_embeddings.0.weight", prev_tm), oc), 2)
             h = self._lstm_stack("lstm_generation", h, False)
+            gen = toks.view(1, 1, L).expand(B, 1, L).contiguous()
+            if free is not None:
+                hf = h.index_select(0, free)
+                return [self._head(hf.reshape(free.numel() * B, -1)).view(free.numel(), B, -1).permute(1, 0, 2)], gen
             w = self._head(h.view(L * B, -1)).view(L, B, -1).permute(1, 0, 2)
-            return [w], toks.view(1, 1, L).expand(B, 1, L).contiguous()
+            return [w], gen
         prev = torch.zeros(1, B, dtype=torch.int64, device=dev)               # start symbol 0
         states = [None] * self.num_layers
         ws, gen = [], []
@@ -306,7 +326,10 @@ class ConstraintModelGaussianReg(Model):
             tok = ops.argmax_rows(w.detach()[0:1])                             # batch element 0
             prev = tok.view(1, 1).expand(1, B).contiguous()
             gen.append(prev)
-        return [torch.stack(ws, 1)], torch.cat(gen, 0).t().unsqueeze(1).contiguous()
+        wall = torch.stack(ws, 1)
+        if free is not None:
+            wall = wall[:, free, :]
+        return [wall], torch.cat(gen, 0).t().unsqueeze(1).contiguous()
 
     def forward_inpaint(self, score_tensor, metadata_tensor, constraints_loc, start_tick, end_tick):
         """Inpainting as the testers use it (:261-346): the generation LSTMs read the ground truth up to start_tick
@@ -376,16 +399,21 @@ class ConstraintModelGaussianReg(Model):
         return [torch.stack(ws, 1)], gen
 
     def forward(self, score_tensor, metadata_tensor, constraints_loc, start_tick=None, end_tick=None, train=True,
-                teacher_forcing=None):
-        """-> list (one per voice) of (B, n_unconstrained, V) weights, extra   (:406-435)"""
+                teacher_forcing=None, trim=False):
+        """-> list (one per voice) of (B, n_unconstrained, V) weights, extra   (:406-435).  trim=True (a caller that does not read
+        `extra` behind the last unconstrained tick: the trainers): the generation LSTMs and the head skip what nobody reads
+        (`skip_unread_ticks`); the weights are the same."""
         if teacher_forcing is None:
             if self.use_teacher_forcing and train:
                 teacher_forcing = random.random() <= self.teacher_forcing_prob
             else:
                 teacher_forcing = False
         fwd = self._forward_tf if teacher_forcing else self._forward_no_tf
-        weights, add_args = fwd(score_tensor, metadata_tensor, constraints_loc)
         free = free_positions(constraints_loc)
+        if trim and self.skip_unread_ticks and free.numel() > 0:
+            weights, add_args = fwd(score_tensor, metadata_tensor, constraints_loc, free, last_free_position(constraints_loc) + 1)
+            return weights, add_args
+        weights, add_args = fwd(score_tensor, metadata_tensor, constraints_loc)
         return [w[:, free, :] for w in weights], add_args
 
 
@@ -406,9 +434,17 @@ def free_positions(constraints_loc, host_copy=None):
     if cached is not None and cached[0] == constraints_loc._version:
         return cached[1]
     src = constraints_loc if host_copy is None else host_copy
-    free = (src[0, 0, :] == 0).nonzero().squeeze(-1).to(constraints_loc.device)
-    constraints_loc._inet_free = (constraints_loc._version, free)
+    free_src = (src[0, 0, :] == 0).nonzero().squeeze(-1)
+    last = int(free_src[-1]) if free_src.numel() else -1          # (host copy: no round trip; device tensor: the nonzero() was one already)
+    free = free_src.to(constraints_loc.device)
+    constraints_loc._inet_free = (constraints_loc._version, free, last)
     return free
+
+
+def last_free_position(constraints_loc):
+    """The last unconstrained tick (-1: none), a host integer kept with the cached free positions."""
+    free_positions(constraints_loc)
+    return constraints_loc._inet_free[2]
 
 
 class AnticipationRNNBaseline(ConstraintModelGaussianReg):
@@ -431,7 +467,7 @@ class AnticipationRNNGaussianRegTrainer(Trainer):
     def loss_and_acc_for_batch(self, batch, epoch_num=None, train=True):
         score_tensor, metadata_tensor, constraints_loc, start_tick, end_tick = batch
         weights, _ = self.model(score_tensor=score_tensor, metadata_tensor=metadata_tensor,
-                                constraints_loc=constraints_loc, start_tick=start_tick, end_tick=end_tick, train=train)
+                                constraints_loc=constraints_loc, start_tick=start_tick, end_tick=end_tick, train=train, trim=True)
         free = free_positions(constraints_loc)
         targets = score_tensor[:, :, free].transpose(0, 1)                     # (voice, batch, n_free)
         return self.mean_crossentropy_loss_and_accuracy_voices(weights, targets)

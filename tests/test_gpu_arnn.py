@@ -441,3 +441,38 @@ def test_arnn_token_pass_with_nan_weights_stays_inside_the_vocabulary():
     trainer.step()
     with pytest.raises(ValueError, match="has become nan"):
         trainer.finish()
+
+
+@pytest.mark.parametrize("tf", [True, False])
+@pytest.mark.parametrize("window", [(48, 120), (0, 72), (300, 384)])
+def test_arnn_trimmed_forward_changes_nothing(tf, window):
+    """The trainers call the model with trim=True: the generation LSTMs stop behind the last unconstrained tick and the head runs on
+    the unconstrained ticks only.  What the reference computes behind the window is read by nobody -- forward, and backward (zero
+    gradient flows into those ticks) --, so weights, loss and EVERY gradient are those of the untrimmed pass
+    (anticipation_rnn_gauss_reg_model.py:348-435), teacher-forced and free-running, for windows at the start, inside and at the end."""
+    fx = G.load("arnn_small")
+    score = torch.from_numpy(fx["score"]).cuda()
+    md = torch.from_numpy(fx["metadata"]).cuda()
+    L = score.shape[2]
+    a, b = window
+    b = min(b, L)
+    loc = torch.ones_like(score)
+    loc[:, :, a:b] = 0
+    res = []
+    for trim in (False, True):
+        ds, model = build("small")
+        model.train()
+        trainer = AnticipationRNNGaussianRegTrainer(ds, model)
+        trainer.zero_grad()
+        weights, gen = model(score, md, loc, a, b, train=True, teacher_forcing=tf, trim=trim)
+        loss, _ = trainer.mean_crossentropy_loss_and_accuracy_voices(weights, score[:, :, a:b].transpose(0, 1))
+        loss.backward()
+        ops.side_join()
+        torch.cuda.synchronize()
+        res.append((weights[0].detach().clone(), float(loss.detach()), model.grad.clone(), None if gen is None else gen.clone()))
+    (w0, l0, g0, gen0), (w1, l1, g1, gen1) = res
+    assert w0.shape == w1.shape == (score.shape[0], b - a, w0.shape[-1])
+    assert G.rel_err(w1.cpu(), w0.cpu()) < 2e-6 and abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert G.rel_err(g1.cpu(), g0.cpu()) < 2e-5
+    if not tf:
+        assert torch.equal(gen1[:, :, :b], gen0[:, :, :b])        # (the trimmed pass does not generate the ticks behind the window)
