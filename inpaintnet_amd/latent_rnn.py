@@ -277,7 +277,9 @@ class LatentRNN(Model):
             w, s = self._decode(gen_z)
             samples.append(s)
             weights.append(w.unsqueeze(1))
-            gen_rnn_input = self.get_z_seq(s, eps_ar[i] if eps_ar is not None else None)
+            # (the reference re-encodes the LAST generated measure too, latent_rnn.py:259, and drops the result)
+            if i + 1 < measures_to_gen or self.encode_unused_target:
+                gen_rnn_input = self.get_z_seq(s, eps_ar[i] if eps_ar is not None else None)
         return torch.cat(weights, 1), torch.cat(samples, 2), torch.cat(z_out, 1)
 
     def save(self):
