@@ -712,7 +712,7 @@ __global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int
 }
 
 // INET_GEMV=0: products of <= 8 rows on the tile kernels (A/B switch)
-bool gemv_enabled() { static const bool on = [] { const char* v = std::getenv("INET_GEMV"); return !(v && v[0] == '0'); }(); return on; }
+bool gemv_enabled() { return true; }
 int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (INET_GEMM_FORCE="cfg,split"), -1: cost model
 int g_direct = -1;   // INET_GEMM_DIRECT: 0 never, 1 (default) by shape, 2 direct whenever applicable, 3 big shapes only, 4 split-K first
 
@@ -731,7 +731,7 @@ int launch_gemm_direct(const GemmArgs& gin, hipStream_t s, int force_split) {
     const int kSplits[] = {1, 2, 4, 8, 16, 32};
     double best = 1e300;
     int bi = -1, bs = 1;
-    static const int only_cfg = [] { const char* v = std::getenv("INET_TN_CFG"); return v ? std::atoi(v) : -1; }();
+    constexpr int only_cfg = -1;
     for (int ci = 0; ci < 3; ++ci) {
         const DirectCfg& c = kDirect[ci];
         if (g.M % (64 * c.ta) || g.N % (64 * c.tb)) continue;
@@ -1048,7 +1048,7 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     if (g.nbatch > 1) {
         // several products of one shape: one launch of the shared-strip direct kernel when it applies (half the split-K
         // factor of a single product for the same 256 workgroups), else one product after the other
-        static const bool batched = [] { const char* v = std::getenv("INET_GEMM_BATCH"); return !(v && v[0] == '0'); }();
+        constexpr bool batched = true;
         int rc = 1;
         if (batched && g_direct > 0 && g_direct != 4 && g_force_cfg < 0) rc = launch_gemm_direct(gin, s, g_force_split > 0 ? g_force_split : 0);
         if (rc != 1) return rc;

@@ -51,7 +51,7 @@ struct GruChainFwdProb {
 };
 struct GruChainFwd {
     int H, B, T, nprob, tiles_per_prob, members, prio;
-    int h0_packed;                                // slot 1 of every hx already holds h0 (packed by the host: INET_CHAIN_H0PACK=1, A/B switch)
+    int h0_packed;                                // slot 1 of every hx already holds h0 (packed by the host: a removed A/B switch of round 2)
     int fault;                                    // test hook (inet_set_option key 6): workgroup 0 leaves at once, so its
                                                   // group runs into the bounded spin and the failure path can be tested
     int shared_chip;                              // this launch runs beside another chain launch (two workgroups per CU):

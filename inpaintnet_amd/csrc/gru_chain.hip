@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
 // kChainMaxGroups groups).  A chain step is hand-off latency plus the MFMAs of ONE workgroup, so more, smaller groups
 // shorten every step: B = 128 with two directions runs 8 groups of 32 rows instead of 4 of 64.
 int rows_ms(int B, int H, int nprob) {
-    static const int force = [] { const char* e = std::getenv("INET_CHAIN_MS"); return e ? std::atoi(e) : 0; }();
+    constexpr int force = 0;
     if (force > 0) return B <= 16 ? 1 : (B <= 32 ? 2 : 4);                 // the fixed rule of the first chain kernels
     for (int ms = 1; ms <= 4; ms *= 2) {
         const int groups = nprob * ((B + 16 * ms - 1) / (16 * ms));
@@ -388,7 +388,7 @@ int rows_ms(int B, int H, int nprob) {
 }
 int chain_prio() {
     static int v = -1;
-    if (v < 0) { const char* e = std::getenv("INET_CHAIN_PRIO"); v = (e && e[0] == '0') ? 0 : 1; }
+    if (v < 0) v = 1;
     return v;
 }
 
@@ -409,7 +409,7 @@ bool gru_chain_ok(int H, int B, int T, int nprob) {
 // workgroups: the decoder's tick layers run their 4 beats as 4 problems x 256 rows.
 int rows_ms_bwd(int H, int B, int nprob) {
     const int ms = rows_ms(B, H, nprob);
-    static const bool wide = [] { const char* e = std::getenv("INET_CHAIN_WIDE"); return !(e && e[0] == '0'); }();
+    constexpr bool wide = true;
     if (wide && H <= 512 && ms == 4 && B >= 128 && nprob * ((B + 63) / 64) * (H / 16) > chain_capacity()) return 8;
     return ms;
 }
@@ -422,7 +422,7 @@ bool gru_chain_bwd_ok(int H, int B, int T, int nprob) {
 }
 
 bool gru_chain_fwd_is_v2(int H, int B, int T, int nprob, int h0_packed) {
-    static const bool v2f = [] { const char* v = std::getenv("INET_CHAIN2_FWD"); return !(v && v[0] == '0'); }();   // (debug switch)
+    constexpr bool v2f = true;
     return v2f && !h0_packed && gru_chain2_ok(H, B, T, nprob);
 }
 // The BPTT chains run on the FIRST generation: its kernel takes 28 KB of LDS and ~300 registers per lane, so the leaf work of the

@@ -586,7 +586,7 @@ int launch_chain(K kernel, const A& a, int groups, hipStream_t s) {
 // hand-off latency plus the MFMAs of ONE workgroup (B = 32, H = 256: 1.9 of 4.1 us with 32 rows per workgroup), so more,
 // smaller groups shorten every step (AnticipationRNN: two 16-row groups instead of one 32-row group)
 inline int chain_ms(int B, int H) {
-    static const int force = [] { const char* e = std::getenv("INET_LSTM_MS"); return e ? std::atoi(e) : 0; }();
+    constexpr int force = 0;
     if (force == 1 || force == 2 || force == 4) return force;
     for (int ms = 1; ms <= 4; ms *= 2) {
         const int groups = (B + 16 * ms - 1) / (16 * ms);

@@ -59,8 +59,8 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
     const long pkh = (long)pk_floats(B, H);
     bool pk = pk_ok(H);
     for (int i = 0; i < nd; ++i) if (!d[i].Wpk_hh || !d[i].hpk) pk = false;
-    // A/B switch: INET_CHAIN_H0PACK=1 packs the initial state into slot 1 with a launch in front of the chain (round 2)
-    static const bool h0pack = [] { const char* v = std::getenv("INET_CHAIN_H0PACK"); return v && v[0] == '1'; }();
+    // A/B switch: (round 2 had a switch that packed the initial state into slot 1 with a launch in front of the chain; removed in round 5)
+    constexpr bool h0pack = false;
     bool all_h0 = true;
     for (int i = 0; i < nd; ++i) all_h0 = all_h0 && d[i].h0;
     auto pack_h0 = [&]() -> int {
@@ -144,7 +144,7 @@ int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s) {
         // chunk's hand-off latency (a third of each step) is filled by the other chunk's MFMAs.  Chunk c works on its rows
         // of the two slots of the full-batch ring (row blocks are the outermost index of the fragment-major layout); even /
         // odd chunks count on different sync areas (the caller's and the one behind it).
-        static const bool twin = [] { const char* v = std::getenv("INET_CHUNK_TWIN"); return !(v && v[0] == '0'); }();
+        constexpr bool twin = true;
         const long pkc = (long)pk_floats(CH, H);
         // (the second-generation kernel keeps its W slice in 144 KB of LDS: one workgroup per CU, nothing to gain from two
         // streams; every chunk gets its own contiguous ring of three-piece slots)

@@ -24,8 +24,8 @@ hipEvent_t next_event() {
     if (g_pool.empty()) {
         // These events only order streams of ONE device against each other: the system-scope fence an event performs by
         // default when it completes (cache write-back + invalidate, ~7 us of bubble on the recording stream per fork,
-        // profiles/r02_v_timeline_full_step.txt) buys nothing here.  INET_EVENT_FENCE=1 restores the default.
-        static const bool fence = [] { const char* v = std::getenv("INET_EVENT_FENCE"); return v && v[0] == '1'; }();
+        // profiles/r02_v_timeline_full_step.txt) buys nothing here.  (The switch that restored the default was removed in round 5.)
+        constexpr bool fence = false;
         g_pool.resize(64);
         for (auto& e : g_pool)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (fence ? 0u : hipEventDisableSystemFence)) != hipSuccess &&

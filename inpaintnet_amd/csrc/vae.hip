@@ -140,7 +140,7 @@ int vae_encoder_bwd(const inet_vae_config& c, int B, const long long* tokens, co
     // step's backward pass and the side stream is still busy with the layer-0 dW_hh products (r02 timeline: queued behind
     // them they delayed the optimizer by ~0.14 ms).
     {
-        static const bool emb_main = [] { const char* v = std::getenv("INET_EMB_MAIN"); return !(v && v[0] == '0'); }();
+        constexpr bool emb_main = true;
         hipStream_t ss = emb_main ? s : side_fork(s);
         // dTable [V, 6H] (both directions side by side, as dgi0 holds them): the rows of dgi0 summed by token -- one pass over
         // dgi0 at HBM rate (it shares the chip with the layer-0 dW_hh products, which own the MFMA pipes); then
@@ -292,7 +292,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     DecWs w{};
     dec_carve(c, B, save, ws, w);
     const bool pk = w.wpk_t0 != nullptr;
-    static const bool tf_batch = [] { const char* v = std::getenv("INET_TF_BATCH"); return !(v && v[0] == '0'); }();
+    constexpr bool tf_batch = true;
     const long pkh = (long)pk_floats(B, H);
     static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
     static const bool train_chain = [] { const char* v = std::getenv("INET_DECODE_CHAIN_TRAIN"); return !(v && v[0] == '0'); }();
