@@ -316,6 +316,8 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             if (*bad) break;
             B1_STAMP(0, t, 3);
             // the next tick's recurrent summands left TA_k about when h1_t left TBi_k: request them now, look at them behind the head
+            // (measured and not kept: asking for them inside the polls for h1_t -- four requests per poll instead of one slow the
+            //  hand-off itself down, 0.122 -> 0.140 ms per call)
             if (more) {
 #pragma unroll
                 for (int r = 0; r < NB; ++r)
@@ -339,14 +341,16 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             }
             lds_barrier();
             B1_STAMP(0, t, 4);
-            // wave r takes the argmax of row r: the maximum by DPP, its lowest index by ballot
-            if (wave < NB) {
+            // wave r takes the argmax of row r (one row: every wave takes it for itself and the second barrier is not needed): the
+            // maximum by DPP, its lowest index by ballot
+            if (NB == 1 || wave < NB) {
+                const int arow = NB == 1 ? 0 : wave;
                 constexpr int NVL = (32 * NJ + 63) / 64;
                 float lg[NVL], m = -1.f;
 #pragma unroll
                 for (int j = 0; j < NVL; ++j) {
                     const int v = lane + 64 * j;
-                    lg[j] = v < a.V ? lgs[wave][v] : -1.f;      // (below every post-ReLU logit)
+                    lg[j] = v < a.V ? lgs[arow][v] : -1.f;      // (below every post-ReLU logit)
                     m = fmaxf(m, lg[j]);
                 }
                 m = wave_max_dpp(m);
@@ -357,15 +361,20 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                     if (eq) bi = 64 * j + __builtin_ctzll(eq);
                 }
                 bi = bi < a.V ? bi : 0;
-                if (lane == 0) {
-                    toks[wave] = bi;
-                    if (wave < a.B) a.samples[(long)wave * a.T + t] = bi;
+                if (NB == 1) {
+                    tok[0] = bi;
+                    if (tid == 0) a.samples[t] = bi;
+                } else if (lane == 0) {
+                    toks[arow] = bi;
+                    if (arow < a.B) a.samples[(long)arow * a.T + t] = bi;
                 }
             }
-            lds_barrier();                                     // (toks; lgs is rewritten next tick)
-            B1_STAMP(0, t, 5);
+            if (NB > 1) {
+                lds_barrier();                                 // (toks; lgs is rewritten behind the next tick's first barrier)
 #pragma unroll
-            for (int r = 0; r < NB; ++r) tok[r] = toks[r];
+                for (int r = 0; r < NB; ++r) tok[r] = toks[r];
+            }
+            B1_STAMP(0, t, 5);
             if (more && !get_2d<NB, 3>(ex + G_GH0 + u, G_END, DH, (unsigned)t + 2u, a.status, gh, hw, false)) *bad = 1;
             B1_STAMP(0, t, 6);
         }
