@@ -92,7 +92,14 @@ __device__ __forceinline__ void emit_cols(unsigned char* dst_lane, long piece, c
 template <int NG, int S32, int NP>
 __device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char* wl, __amdgpu_buffer_rsrc_t rs, int abase,
                                           int base, int pb, int lane) {
-    constexpr int R = 4;
+#ifndef INET_CHAIN2_RING
+#define INET_CHAIN2_RING 3
+#endif
+    // k-steps of A fragments requested ahead of the MFMAs.  Build-time A/B (tools/ab_chain2_variants.sh, round 5, T24 launch in the
+    // step): 2: 215-217 us, 3: 185-192, 4: 192-197 (rounds 3-4), 8: 203-206, 12: 210, 16: 220 -- the contraction is NOT short of loads
+    // in flight; a deeper ring only lengthens the burst in front of the first MFMA.  Dealing the three loads of a k-step over its 27
+    // MFMAs (INET_CHAIN2_DEAL=1) measures the same as the burst.
+    constexpr int R = INET_CHAIN2_RING;
     bf16x8 Ar[R][3];
     auto ldA = [&](int s, int slot) {
 #pragma unroll
@@ -114,9 +121,12 @@ __device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char*
 #pragma unroll
         for (int g = 0; g < NG; ++g) part[k][g] = k == 0 ? acc[g] : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int PI[9] = {0, 0, 1, 0, 1, 2, 1, 2, 2}, PJ[9] = {0, 1, 0, 2, 1, 0, 2, 1, 2};   // largest terms first; 6: the first six
+#ifndef INET_CHAIN2_DEAL
+#define INET_CHAIN2_DEAL 0
+#endif
 #pragma unroll
     for (int s = 0; s < S32; ++s) {
-        if (s + R - 1 < S32) ldA(s + R - 1, (s + R - 1) % R);
+        if (!INET_CHAIN2_DEAL && s + R - 1 < S32) ldA(s + R - 1, (s + R - 1) % R);
         bf16x8 Bf[NG][3];
 #pragma unroll
         for (int g = 0; g < NG; ++g)
@@ -124,10 +134,18 @@ __device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char*
             for (int p = 0; p < 3; ++p) Bf[g][p] = *reinterpret_cast<const bf16x8*>(wl + ((p * NG + g) * S32 + s) * 1024 + lane * 16);
         const bf16x8* a = Ar[s % R];
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
+        for (int k = 0; k < NP; ++k) {
+            // (build-time A/B: the three loads of the k-step R - 1 ahead dealt over this k-step's MFMAs, one in front of every third
+            //  of them and pinned there, instead of as one burst in front of the first)
+            if (INET_CHAIN2_DEAL && k % (NP / 3) == 0 && k / (NP / 3) < 3 && s + R - 1 < S32) {
+                const int p = k / (NP / 3), sn = s + R - 1;
+                Ar[sn % R][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, abase + sn * 1024 + p * pb, base, 16));
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < NG; ++g)
                 part[k % NPART][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PI[k]], Bf[g][PJ[k]], part[k % NPART][g], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
