@@ -124,19 +124,32 @@ __device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char*
 #ifndef INET_CHAIN2_DEAL
 #define INET_CHAIN2_DEAL 0
 #endif
-#pragma unroll
-    for (int s = 0; s < S32; ++s) {
-        if (!INET_CHAIN2_DEAL && s + R - 1 < S32) ldA(s + R - 1, (s + R - 1) % R);
-        bf16x8 Bf[NG][3];
+#ifndef INET_CHAIN2_BPF
+#define INET_CHAIN2_BPF 0
+#endif
+    // B fragments (the member's W pieces, LDS): nine 16-byte reads per lane and k-step.  The sched_barrier that pins the A loads also
+    // keeps hipcc from lifting the next k-step's LDS reads over this k-step's MFMAs, so every k-step started with an exposed LDS round
+    // trip (16 per contraction).  INET_CHAIN2_BPF=1 (round 5, build-time A/B): the reads of k-step s + 1 are issued in front of the MFMAs of
+    // k-step s (two register sets of nine fragments) -- measured NEUTRAL (188 vs 188 us per T24 launch, three alternations on one box):
+    // the LDS round trip is not what the contraction waits for either.
+    bf16x8 Bf[2][NG][3];
+    auto ldB = [&](int s, int slot) {
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Bf[g][p] = *reinterpret_cast<const bf16x8*>(wl + ((p * NG + g) * S32 + s) * 1024 + lane * 16);
+            for (int p = 0; p < 3; ++p) Bf[slot][g][p] = *reinterpret_cast<const bf16x8*>(wl + ((p * NG + g) * S32 + s) * 1024 + lane * 16);
+    };
+    if (INET_CHAIN2_BPF) ldB(0, 0);
+#pragma unroll
+    for (int s = 0; s < S32; ++s) {
+        if (!INET_CHAIN2_DEAL && s + R - 1 < S32) ldA(s + R - 1, (s + R - 1) % R);
+        if (INET_CHAIN2_BPF) { if (s + 1 < S32) ldB(s + 1, (s + 1) & 1); }
+        else ldB(s, s & 1);
         const bf16x8* a = Ar[s % R];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             // (build-time A/B: the three loads of the k-step R - 1 ahead dealt over this k-step's MFMAs, one in front of every third
-            //  of them and pinned there, instead of as one burst in front of the first)
+            //  of them and pinned there, instead of as one burst in front of the first: measures the same)
             if (INET_CHAIN2_DEAL && k % (NP / 3) == 0 && k / (NP / 3) < 3 && s + R - 1 < S32) {
                 const int p = k / (NP / 3), sn = s + R - 1;
                 Ar[sn % R][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, abase + sn * 1024 + p * pb, base, 16));
@@ -144,7 +157,7 @@ __device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char*
             }
 #pragma unroll
             for (int g = 0; g < NG; ++g)
-                part[k % NPART][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PI[k]], Bf[g][PJ[k]], part[k % NPART][g], 0, 0, 0);
+                part[k % NPART][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PI[k]], Bf[s & 1][g][PJ[k]], part[k % NPART][g], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
