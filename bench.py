@@ -677,13 +677,15 @@ def decode_latency_extra(vae, iters=20):
         out[f"b{b}"] = {"ms_per_call": round(ms, 4), "measures_per_s": round(b / ms * 1e3, 1),
                         "weights_once_GBps": round(gbps, 2), "frac_hbm_roofline": round(gbps / PEAK_HBM_GBPS, 5)}
     out["north_star_target_frac"] = 0.40
-    # What bounds the b = 1 call is a chain of dependent hand-offs, not bytes: 24 ticks x 2 hand-offs on the critical path (C -> TBi
-    # -> C, csrc/decode_b1.hip) + 5 for beat 0 (z2b -> beat layer 0 -> layer 1 -> projection -> cgi), each >= 0.8 us on this part
-    # (MI355X_MICROARCH.md "handoff-1to1"; 0.74 / 0.89 us measured in profiles/r05_arnn_token_pass.txt) -- the floor of THIS algorithm
-    # next to the 40 % HBM target (8.3 us per call), which it cannot reach.
-    handoffs = 24 * 2 + 5
+    # What bounds the b = 1 call is a chain of dependent hand-offs, not bytes: 24 ticks x 1 hand-off on the critical path (the
+    # all-gather of h1_t among the 16 layer-1 workgroups, csrc/decode_b1.hip's merged build; two per tick -- C -> TBi -> C -- where
+    # that build does not fit) + 5 for beat 0 (z2b -> beat layer 0 -> layer 1 -> projection -> cgi), each >= 0.8 us on this part
+    # (MI355X_MICROARCH.md "handoff-1to1"; 0.74 / 0.89 us measured one-to-one in profiles/r05_arnn_token_pass.txt, 1.5 us for the
+    # all-gather among 16 in profiles/r05_decode_b1_latency.txt) -- the floor of THIS algorithm next to the 40 % HBM target (8.3 us
+    # per call), which it cannot reach.
+    handoffs = 24 * 1 + 5
     out["b1"]["latency_floor_ms"] = round(handoffs * 0.8e-3, 4)
-    out["b1"]["latency_floor"] = f"{handoffs} dependent hand-offs x 0.8 us (two per tick + five for beat 0)"
+    out["b1"]["latency_floor"] = f"{handoffs} dependent hand-offs x 0.8 us (one per tick + five for beat 0)"
     vae.train()
     return {"decoder_eval": out}
 

@@ -259,7 +259,7 @@ int inet_lstm2_bwd(int batch, int T, int H, const float* W_hh0, const float* W_i
  * -> LSTM 0 -> LSTM 1 -> ReLU(linear_1) -> note head -> argmax (numpy order: NaN is the maximum, lowest index among equals), without a
  * host round trip: ONE persistent launch of 13 workgroups with their weights in registers for the reference's configuration (H = U =
  * 256, V <= 128; csrc/arnn_gen.hip, round 5: two hand-offs per tick), four small launches per tick otherwise (inet_set_option key 14 /
- * INET_ARNN_GEN: 0 = always the launches, 1 = persistent kernel, 2 = default: its workgroups on one XCD); tokens [L] int64 on the device.  emb [.,E]; W_ih0 [4H, E+Hc]; W_ih1, W_hh* [4H,H]; W1 [U,H]; W2 [V,U].  hc_init
+ * INET_ARNN_GEN: 0 = always the launches, 1 = persistent kernel, 2 = its workgroups on one XCD, 3 = default: 2 + XCD-local granule stores); tokens [L] int64 on the device.  emb [.,E]; W_ih0 [4H, E+Hc]; W_ih1, W_hh* [4H,H]; W1 [U,H]; W2 [V,U].  hc_init
  * (nullable: zeros) = the state the ticks go on from, [layer][h | c][H]; first_tok (nullable: token 0) = device pointer to the token in
  * front of the first tick -- forward_inpaint (:261-346) generates a window behind a teacher-forced prefix.  The caller then runs the
  * whole batch over these tokens with the batched kernels (inpaintnet_amd.arnn._forward_no_tf / forward_inpaint). */
@@ -332,12 +332,16 @@ int inet_set_option(int key, int value);
  * key 13 = how many of the side streams take leaf work in rotation from now on (0 = all that exist, default; 1: what a process with
  * a gradient exchange beside its steps wants -- inpaintnet_amd.dp sets it: the runtime deals FOUR hardware queues, and caller + two
  * side streams + the exchange's two streams measured 4.94 ms per B = 256 step against 3.87 with one side stream).
- * key 14 = AnticipationRNN's token pass (inet_arnn_generate; INET_ARNN_GEN): 2 (default) = one persistent launch where the shape
- * allows, its 13 workgroups on every 8th workgroup id (one XCD as dispatched today); 1 = on 13 consecutive ids; 0 = four launches per tick.
- * key 15 = the free-running decode of ONE to FOUR measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 3 (default) =
- * ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for the 24 ticks -- two
- * hand-offs per tick -- and 80 for the beat path); 2 / 1 = the tick path only, behind the beat path's eight launches, on every 4th
- * workgroup id / on consecutive ids; 0 = decode_chain.hip's 32-member exchange kernel.
+ * key 14 = AnticipationRNN's token pass (inet_arnn_generate; INET_ARNN_GEN): 3 (default) = one persistent launch where the shape
+ * allows, its 13 workgroups on every 8th workgroup id (one XCD as dispatched today) and -- once they have FOUND themselves on one XCD
+ * (they compare XCC ids at the start of the launch) -- granules as plain stores that stay in that XCD's L2; 2 = the same with
+ * agent-scope stores; 1 = on 13 consecutive ids; 0 = four launches per tick.
+ * key 15 = the free-running decode of ONE to SIXTEEN measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 3 (default) =
+ * up to four measures: ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for
+ * the 24 ticks -- two hand-offs per tick; one where a single workgroup kind can hold layer 1, the head and the argmax: one row with
+ * V <= 64 -- and 80 for the beat path); five to sixteen: two to four teams of the 49 tick workgroups, four rows each, behind the beat
+ * path's launches; 2 / 1 = the tick path only, behind the beat path's eight launches, on every 4th workgroup id / on consecutive ids;
+ * 0 = decode_chain.hip's 32-member exchange kernel.
  * Keys 4, 7-12, 14 must not change between a forward call and its backward call, nor between sizing a workspace and using it. */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.

@@ -38,9 +38,10 @@ namespace {
 using namespace granule;
 
 constexpr int GH = 256, G4 = 4 * GH;
+constexpr int kExXcc = 2 * GH + 2 * G4;          // granules behind the exchange: the workgroups' XCC ids (granule::same_xcd)
 
 struct GenArgs {
-    int L, V, E, K0, stride;                     // K0 = E + Hc: row stride of W_ih0; stride: block b works iff b % stride == 0, role b / stride
+    int L, V, E, K0, stride, near;                   // K0 = E + Hc: row stride of W_ih0; stride: block b works iff b % stride == 0, role b / stride
     const float* emb; const float* W_ih0;
     const float* W_hh0; const float* W_ih1; const float* b_ih1; const float* W_hh1; const float* b_hh1;
     const float* W1; const float* b1; const float* W2; const float* b2;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void dot4(const float (&w)[4][EK], const float* xe, f
 // a recurrent-side product off the critical path: y_t = W x_{t-1} (+ b) for the ticks 0 .. L-1, x_{-1} = the initial state
 __device__ __forceinline__ void recurrent_role(const GenArgs& a, int k, const float* __restrict__ W, const float* __restrict__ bias,
                                                const float* x_init, const unsigned long long* xin, unsigned long long* yout,
-                                               float (*xs)[XS], volatile int* bad) {
+                                               float (*xs)[XS], volatile int* bad, bool near) {
     const int tid = threadIdx.x, j = tid >> 3, e = tid & 7;
     const int row[4] = {64 * k + j, GH + 64 * k + j, 2 * GH + 64 * k + j, 3 * GH + 64 * k + j};      // the four gates of unit 64 k + j
     float w[4][EK];
@@ -120,7 +121,7 @@ __device__ __forceinline__ void recurrent_role(const GenArgs& a, int k, const fl
             if (*bad) break;
             dot4(w, xs[t & 1] + XP * e, y);
         }
-        if (e < 4) put(yout + myrow, (e == 0 ? y[0] : e == 1 ? y[1] : e == 2 ? y[2] : y[3]) + b, (unsigned)t + 1u);
+        if (e < 4) put(yout + myrow, (e == 0 ? y[0] : e == 1 ? y[1] : e == 2 ? y[2] : y[3]) + b, (unsigned)t + 1u, near);
     }
 }
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[2][XS];
     __shared__ __attribute__((aligned(16))) float us[GH];
     __shared__ float ps[8][64 * NV];
-    __shared__ int bad_s;
+    __shared__ int bad_s, near_s;
     if (blockIdx.x % a.stride) return;
     const int role = blockIdx.x / a.stride;
     const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
@@ -140,11 +141,13 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
     volatile int* const bad = &bad_s;
     if (tid == 0) bad_s = 0;
     __syncthreads();
+    // all 13 workgroups on one XCD (mode 3 asks; the answer is the hardware's): granules as plain stores (granule.h)
+    const bool near = a.near && same_xcd(a.ex + kExXcc, role, 13, a.status, &near_s);
 
     if (role >= 1 && role <= 4) {
-        recurrent_role(a, role - 1, a.W_hh0, nullptr, a.hc_init, e_h0, e_hh0, xs, bad);       // (b_hh0 sits in pre)
+        recurrent_role(a, role - 1, a.W_hh0, nullptr, a.hc_init, e_h0, e_hh0, xs, bad, near);  // (b_hh0 sits in pre)
     } else if (role >= 9) {
-        recurrent_role(a, role - 9, a.W_hh1, a.b_hh1, a.hc_init ? a.hc_init + 2 * GH : nullptr, e_h1, e_hh1, xs, bad);
+        recurrent_role(a, role - 9, a.W_hh1, a.b_hh1, a.hc_init ? a.hc_init + 2 * GH : nullptr, e_h1, e_hh1, xs, bad, near);
     } else if (role >= 5) {
         // ---- Bi_k: layer 1's input-side product and its cell: thread (unit j, eighth e) holds the four gate rows of its unit, the
         // sums land in every lane of the 8-lane group, lane e = 0 computes the cell -- no LDS, no barrier behind the product ----
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
                 const float ig = sigmoid_f(y[0] + bb[0] + hh[0]), fg = sigmoid_f(y[1] + bb[1] + hh[1]);
                 const float gv = tanh_f(y[2] + bb[2] + hh[2]), og = sigmoid_f(y[3] + bb[3] + hh[3]);
                 c1 = fg * c1 + ig * gv;
-                put(e_h1 + 64 * k + j, og * tanh_f(c1), (unsigned)t + 1u);
+                put(e_h1 + 64 * k + j, og * tanh_f(c1), (unsigned)t + 1u, near);
             }
             if (k == 0) GEN_STAMP(1, t, 5);
         }
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
                 }
                 const float ig = sigmoid_f(gate[0]), fg = sigmoid_f(gate[1]), gv = tanh_f(gate[2]), og = sigmoid_f(gate[3]);
                 c0 = fg * c0 + ig * gv;
-                put(e_h0 + tid, og * tanh_f(c0), (unsigned)t + 1u);
+                put(e_h0 + tid, og * tanh_f(c0), (unsigned)t + 1u, near);
                 GEN_STAMP(0, t, 1);
                 if (more) {
 #pragma unroll
@@ -364,21 +367,23 @@ __global__ __launch_bounds__(256) void arnn_gen_prep_kernel(PrepArgs a) {
 }
 
 int g_mode = -1;                                 // 0 = the per-tick launches, 1 = persistent kernel on 13 consecutive workgroups,
-                                                 // 2 (default) = on every 8th workgroup of 104: one XCD under the round-robin dispatch
-                                                 // observed today (speed only, 4.0 vs 4.2 us per tick; correct under any placement)
+                                                 // 2 = on every 8th workgroup of 104: one XCD under the round-robin dispatch observed
+                                                 // today (speed only, 4.0 vs 4.2 us per tick; correct under any placement),
+                                                 // 3 (default) = 2 + plain granule stores once the workgroups have FOUND themselves on
+                                                 // one XCD (granule.h: 3.6 -> 3.2 us per tick; agent-scope stores otherwise)
 int mode() {
     if (g_mode < 0) {
         const char* v = std::getenv("INET_ARNN_GEN");
-        g_mode = v ? std::atoi(v) : 2;
-        if (g_mode < 0 || g_mode > 2) g_mode = 2;
+        g_mode = v ? std::atoi(v) : 3;
+        if (g_mode < 0 || g_mode > 3) g_mode = 3;
     }
     return g_mode;
 }
-constexpr long kExGranules = 2 * GH + 2 * G4;    // 8-byte granules of the exchange
+constexpr long kExGranules = kExXcc + 16;         // 8-byte granules of the exchange
 constexpr long kExFloats = 2 * kExGranules + 64; // ... as floats, + the launch's status word (64 floats behind them)
 }  // namespace
 
-void arnn_gen_set_mode(int m) { g_mode = (m < 0 || m > 2) ? 2 : m; }
+void arnn_gen_set_mode(int m) { g_mode = (m < 0 || m > 3) ? 3 : m; }
 
 bool arnn_token_pass_ok(int H, int U, int V) { return mode() != 0 && chain_enabled() && H == GH && U == GH && V >= 1 && V <= 128; }
 
@@ -403,7 +408,7 @@ int arnn_token_pass(int L, int E, int Hc, int V, const float* emb, const float* 
     const int nb_t0 = (int)(((long)V * G4 + 255) / 256);
     hipLaunchKernelGGL(arnn_gen_prep_kernel, dim3(p.nb_pre + nb_t0), dim3(256), 0, s, p);
     GenArgs a{};
-    a.L = L; a.V = V; a.E = E; a.K0 = E + Hc; a.stride = mode() == 2 ? 8 : 1;
+    a.L = L; a.V = V; a.E = E; a.K0 = E + Hc; a.stride = mode() >= 2 ? 8 : 1; a.near = mode() == 3;
     a.emb = emb; a.W_ih0 = W_ih0; a.W_hh0 = W_hh0; a.W_ih1 = W_ih1; a.b_ih1 = b_ih1; a.W_hh1 = W_hh1; a.b_hh1 = b_hh1;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.pre = pre; a.T0 = T0;
     a.hc_init = hc_init; a.first_tok = first_tok; a.tokens = tokens; a.ex = ex;

@@ -41,7 +41,15 @@
 // hand-offs of a tick are paid once, not per row.  B is rounded up to NB = 1 / 2 / 4 (rows beyond B repeat row B - 1 and store
 // nothing); every row has its own granule area.  (Eight rows do not fit: workgroup C keeps seven floats and six granule words per row
 // and unit next to its slice of the head, 256 VGPRs are gone at NB = 8.)
-// Shapes: H = 512, Z = 256, V <= 128, <= 4 beats, B <= 4, inference (no dropout mask, no backward saves); else decode_chain.hip.
+// FIVE TO SIXTEEN MEASURES: two to four TEAMS of the tick path's 49 workgroups, four rows each, in one launch (196 of 256 CUs at
+// B = 16) behind the beat path's launches -- the beat roles do not fit beside four teams.  0.35 -> 0.30 ms per call at B = 16.
+//
+// THE MERGED BUILD (one row with V <= 64, two rows with V <= 32 -- what fits 256 registers without spills): workgroup C does not
+// exist.  Its work -- layer 0's cell, which needs no product, the V x 512 head and the argmax -- is REPLICATED in every TBi_k: h0_t
+// never leaves the workgroup, the token never travels, and a tick is ONE hand-off (the all-gather of h1_t among the 16 workgroups)
+// instead of two.  The 16 copies run the same instructions on the same values and agree bit for bit.  3.95 -> 3.78 us per tick:
+// less than the 0.8 us a hand-off costs, because an all-gather among 16 waits for the slowest of 16 (1.5 us, profiles/r05_decode_b1_*).
+// Shapes: H = 512, Z = 256, V <= 128, <= 4 beats, B <= 16, inference (no dropout mask, no backward saves); else decode_chain.hip.
 #include <cstdio>
 #include <cstdlib>
 #include "chain.h"
@@ -59,13 +67,14 @@ constexpr int R_C = 0, R_TA = 1, R_TBI = R_TA + NU, R_TBH = R_TBI + NU, kTickRol
 constexpr int R_Z2B = kTickRoles, R_BA = R_Z2B + 4, R_BBI = R_BA + NU, R_BBH = R_BBI + NU, R_PH = R_BBH + NU, R_PI = R_PH + 8,
               R_CG = R_PI + 4, kFusedRoles = R_CG + NU;
 // granule map of ONE row (8-byte units); row r lives at r * G_END
-constexpr int G_H0 = 0, G_H1 = DH, G_GH0 = 2 * DH, G_GH1 = 2 * DH + D3, G_TICK_END = 2 * DH + 2 * D3;
+constexpr int G_H0 = 0, G_H1 = DH, G_GH0 = 2 * DH, G_GH1 = 2 * DH + D3, G_H1X = 2 * DH + 2 * D3, G_GH0X = G_H1X + DH, G_TICK_END = G_GH0X + D3;
+// (G_H1X / G_GH0X: the second slots of h1 and gh0 in the merged build, which alternates between two slots by the tag's parity)
 constexpr int G_HB0 = G_TICK_END, G_H0B = G_HB0 + 2 * DH, G_H1B = G_H0B + 4 * DH, G_GH1B = G_H1B + 4 * DH, G_C = G_GH1B + 4 * D3,
               G_HT0 = G_C + 4 * DH, G_CGI = G_HT0 + 4 * 2 * DH, G_END = G_CGI + 4 * D3;
 static_assert(2 * G_END == kDecodeB1WordsPerRow, "the workspace's granule area holds the map");
 
 struct B1Args {
-    int B, T, G, V, Z, stride, fused;
+    int B, T, G, V, Z, stride, fused, teams;     // teams: groups of kTickRoles workgroups, NB rows each (tick path only beyond one)
     const float* W_hh0; const float* b_hh0; const float* cgi; const float* table;
     const float* W_ih1; const float* b_ih1; const float* W_hh1; const float* b_hh1;
     const float* W_out; const float* b_out; const float* ht0;
@@ -157,6 +166,7 @@ __device__ __forceinline__ bool get_2d(const unsigned long long* g, int rs, int 
 template <int NB>
 struct Ctx {                                     // what every role needs
     const B1Args& a; unsigned long long* ex; float (*xs)[2][XS]; volatile int* bad; int tid;
+    int rb, nrow;                                // the team's first row, and how many of its NB rows exist
     // every thread fetches granule `tid` (of the vector at `off`) of every row and files it as that row's x (buffer `buf`)
     __device__ __forceinline__ void gather(int off, unsigned tag, int buf) const {
         float v[NB];
@@ -171,7 +181,7 @@ struct Ctx {                                     // what every role needs
 // a beat's first tick, else the layer's output of tick t - 1 ----
 template <int NB>
 __device__ __forceinline__ void tick_recurrent_role(const Ctx<NB>& c, int k, const float* __restrict__ W, const float* __restrict__ bias,
-                                                    int layer, int g_in, int g_out) {
+                                                    int layer, int g_in, int g_out, int g_in_odd, int g_out_odd) {
     const B1Args& a = c.a;
     const int tid = c.tid, p = tid >> 4, s = tid & 15, u = UW * k + p;
     const int row[3] = {u, DH + u, 2 * DH + u};
@@ -186,14 +196,14 @@ __device__ __forceinline__ void tick_recurrent_role(const Ctx<NB>& c, int k, con
         // (the previous tick's output is waited for at a beat's first tick too, although the beat's initial state is what gets
         //  multiplied: the single-buffered granules are safe only while every producer stays behind its consumers -- a workgroup
         //  that ran ahead here would overwrite gh of tick t - 1 before the cell that needs it has looked)
-        if (t > 0) c.gather(g_in, (unsigned)t, t & 1);
+        if (t > 0) c.gather((t & 1) ? g_in_odd : g_in, (unsigned)t, t & 1);
         if (t % a.G == 0) {
             const int beat = t / a.G;
             if (a.fused) c.gather(G_HT0 + beat * 2 * DH + layer * DH, 1u, t & 1);
             else {
 #pragma unroll
                 for (int r = 0; r < NB; ++r)
-                    c.xs[r][t & 1][xs_index<32>(tid)] = a.ht0[((long)beat * a.B + min(r, a.B - 1)) * 2 * DH + layer * DH + tid];
+                    c.xs[r][t & 1][xs_index<32>(tid)] = a.ht0[((long)beat * a.B + c.rb + min(r, c.nrow - 1)) * 2 * DH + layer * DH + tid];
             }
         }
         lds_barrier();
@@ -204,7 +214,8 @@ __device__ __forceinline__ void tick_recurrent_role(const Ctx<NB>& c, int k, con
             dot_rows<3, 32>(w, c.xs[r][t & 1] + 36 * s, y);
             if (s == 0) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g) put(c.ex + (long)r * G_END + g_out + g * DH + u, y[g] + b[g], (unsigned)t + 1u);
+                for (int g = 0; g < 3; ++g)
+                    put(c.ex + (long)r * G_END + (((t + 1) & 1) ? g_out_odd : g_out) + g * DH + u, y[g] + b[g], (unsigned)t + 1u);
             }
         }
     }
@@ -249,17 +260,22 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     __shared__ int toks[NB];
     __shared__ int bad_s;
     if (blockIdx.x % a.stride) return;
-    const int role = blockIdx.x / a.stride;
+    // more than four rows: `teams` teams of the tick path's workgroups, NB rows and one granule area per row each, nothing shared
+    const int wg = blockIdx.x / a.stride, team = a.teams > 1 ? wg / kTickRoles : 0, role = a.teams > 1 ? wg % kTickRoles : wg;
+    const int rb = team * NB, nrow = min(NB, a.B - rb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long* const ex = a.ex;
+    unsigned long long* const ex = a.ex + (long)rb * G_END;
     volatile int* const bad = &bad_s;
     if (tid == 0) bad_s = 0;
     __syncthreads();
-    const Ctx<NB> c{a, ex, xs, bad, tid};
+    const Ctx<NB> c{a, ex, xs, bad, tid, rb, nrow};
     const int nb = a.T / a.G;
     const DecodeB1Beat& bp = a.bp;
+    // MG, the merged build: workgroup C does not exist, every TBi_k does C's work for itself next to its own (CB below)
+    constexpr bool MG = NB * NJ <= 2;
 
     if (role == R_C) {
+        if (MG) return;
         // ---- C: layer 0's cell (its three summands are made elsewhere and arrive), the output projection, argmax ----
         const int rv = tid >> 4, s = tid & 15;
         int row[NJ];
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 } else {
 #pragma unroll
                     for (int r = 0; r < NB; ++r) {
-                        const long br = beat * a.B + min(r, a.B - 1);
+                        const long br = beat * a.B + rb + min(r, nrow - 1);
                         h0[r] = a.ht0[br * 2 * DH + u];
 #pragma unroll
                         for (int g = 0; g < 3; ++g) cg[r][g] = a.cgi[br * D3 + g * DH + u];
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                         float lg = y[j] + bo[j];
                         lg = lg > 0.f ? lg : 0.f;              // ReLU (decoder.py:372, 503)
                         lgs[r][v] = lg;
-                        if (r < a.B) a.weights[((long)r * a.T + t) * a.V + v] = lg;
+                        if (r < nrow) a.weights[((long)(rb + r) * a.T + t) * a.V + v] = lg;
                     }
                 }
             }
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                     if (tid == 0) a.samples[t] = bi;
                 } else if (lane == 0) {
                     toks[arow] = bi;
-                    if (arow < a.B) a.samples[(long)arow * a.T + t] = bi;
+                    if (arow < nrow) a.samples[(long)(rb + arow) * a.T + t] = bi;
                 }
             }
             if (NB > 1) {
@@ -379,7 +395,167 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             B1_STAMP(0, t, 6);
         }
     } else if (role < R_TBI) {
-        tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0);
+        tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0, MG ? G_GH0X : G_GH0);
+    } else if (role < R_TBH && MG) {
+        // ---- CB_k (merged build): C's work REPLICATED in every TBi_k.  Layer 0's cell needs no product (its summands arrive), the
+        // head is V x 512: cheap enough to compute 16 times over, and then h0_t never leaves the workgroup and the token never
+        // travels -- of the two hand-offs of a tick (C -> TBi -> C) only the all-gather of h1_t among the 16 workgroups is left.
+        // All of them run the same instructions on the same values, so they agree on every token bit for bit.  CB_0 alone
+        // publishes h0_t (for TA) and writes the outputs.  h1 and gh0 alternate between two granule slots by tag parity: a CB
+        // workgroup does not wait for its 15 peers to have READ a value before it writes the next one (a peer's read of h1_t is
+        // ordered before its own h1_t+1, which the writer of h1_t+2 has to have seen: two slots are enough; likewise gh0).
+        const int k = role - R_TBI, p = tid >> 4, s = tid & 15, uc = UW * k + p;
+        const int row[3] = {uc, DH + uc, 2 * DH + uc};
+        float w[3][32];
+        load_rows<3, 32>(w, a.W_ih1, DH, row, s);
+        int orow[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) orow[j] = min(p + 32 * j, a.V - 1);
+        float wo[NJ][32];
+        load_rows<NJ, 32>(wo, a.W_out, DH, orow, s);
+        float bo[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bo[j] = a.b_out[orow[j]];
+        const bool cell = s == 0, out = k == 0;
+        float bi[3] = {0.f, 0.f, 0.f};
+        if (cell) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) bi[g] = a.b_ih1[g * DH + uc];
+        }
+        const int u = tid;                                     // layer 0: every thread owns one unit, for every row
+        float h0[NB], h1[NB], cg[NB][3], gh[NB][3];
+        unsigned long long hw[NB][3];
+        int tok[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) { h0[r] = 0.f; h1[r] = 0.f; tok[r] = a.V; }
+        if (!get_2d<NB, 3>(ex + G_GH0X + u, G_END, DH, 1u, a.status, gh, hw)) *bad = 1;
+        for (int t = 0; t < a.T; ++t) {
+            const bool more = t + 1 < a.T;
+            const unsigned tag = (unsigned)t + 1u;
+            const int g_h1 = (tag & 1) ? G_H1X : G_H1;
+            float gh1[NB][3];
+            unsigned long long hw1[NB][3];
+            if (t % a.G == 0) {
+                const long beat = t / a.G;
+                if (FUSED) {
+                    unsigned long long cw[NB][3], h1w[NB];
+                    if (!get_n<NB>(ex + G_HT0 + beat * 2 * DH + u, G_END, 1u, a.status, h0, h1w)) *bad = 1;
+                    if (!get_2d<NB, 3>(ex + G_CGI + beat * D3 + u, G_END, DH, 1u, a.status, cg, cw)) *bad = 1;
+                    if (cell && !get_n<NB>(ex + G_HT0 + beat * 2 * DH + DH + uc, G_END, 1u, a.status, h1, h1w)) *bad = 1;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) {
+                        const long br = beat * a.B + rb + min(r, nrow - 1);
+                        h0[r] = a.ht0[br * 2 * DH + u];
+                        if (cell) h1[r] = a.ht0[br * 2 * DH + DH + uc];
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) cg[r][g] = a.cgi[br * D3 + g * DH + u];
+                    }
+                }
+            }
+            if (out) B1_STAMP(0, t, 0);
+            {
+                float tb[NB][3];
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
+                // layer 1's recurrent summands were started a tick ago: requested here, next to the table rows
+                if (cell) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) hw1[r][g] = peek(ex + (long)r * G_END + G_GH1 + g * DH + uc);
+                }
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    h0[r] = gru_cell(cg[r][0] + tb[r][0], cg[r][1] + tb[r][1], cg[r][2] + tb[r][2], gh[r][0], gh[r][1], gh[r][2], h0[r]);
+                    xs[r][0][xs_index<32>(u)] = h0[r];
+                }
+                if (out) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + G_H0 + u, h0[r], tag);
+                }
+            }
+            if (out) B1_STAMP(0, t, 1);
+            lds_barrier();
+            {
+                float y[NB][3];
+#pragma unroll
+                for (int r = 0; r < NB; ++r) dot_rows<3, 32>(w, xs[r][0] + 36 * s, y[r]);
+                if (cell) {
+                    if (!get_2d<NB, 3>(ex + G_GH1 + uc, G_END, DH, tag, a.status, gh1, hw1, false)) *bad = 1;
+#pragma unroll
+                    for (int r = 0; r < NB; ++r)
+                        h1[r] = gru_cell(y[r][0] + bi[0], y[r][1] + bi[1], y[r][2] + bi[2], gh1[r][0], gh1[r][1], gh1[r][2], h1[r]);
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + g_h1 + uc, h1[r], tag);
+                }
+            }
+            if (out) B1_STAMP(0, t, 2);
+            c.gather(g_h1, tag, 1);
+            if (out) B1_STAMP(0, t, 3);
+            lds_barrier();
+            if (*bad) break;
+            if (more) {
+                const int g_gh0 = ((tag + 1u) & 1) ? G_GH0X : G_GH0;
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) hw[r][g] = peek(ex + (long)r * G_END + g_gh0 + g * DH + u);
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                float y[NJ];
+                dot_rows<NJ, 32>(wo, xs[r][1] + 36 * s, y);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int v = p + 32 * j;
+                    if (s == j && v < a.V) {
+                        float lg = y[j] + bo[j];
+                        lg = lg > 0.f ? lg : 0.f;
+                        lgs[r][v] = lg;
+                        if (out && r < nrow) a.weights[((long)(rb + r) * a.T + t) * a.V + v] = lg;
+                    }
+                }
+            }
+            lds_barrier();
+            if (out) B1_STAMP(0, t, 4);
+            if (NB == 1 || wave < NB) {
+                const int arow = NB == 1 ? 0 : wave;
+                constexpr int NVL = (32 * NJ + 63) / 64;
+                float lg[NVL], m = -1.f;
+#pragma unroll
+                for (int j = 0; j < NVL; ++j) {
+                    const int v = lane + 64 * j;
+                    lg[j] = v < a.V ? lgs[arow][v] : -1.f;
+                    m = fmaxf(m, lg[j]);
+                }
+                m = wave_max_dpp(m);
+                int best = 0;
+#pragma unroll
+                for (int j = NVL - 1; j >= 0; --j) {
+                    const unsigned long long eq = __ballot(lg[j] == m);
+                    if (eq) best = 64 * j + __builtin_ctzll(eq);
+                }
+                best = best < a.V ? best : 0;
+                if (NB == 1) {
+                    tok[0] = best;
+                    if (out && tid == 0) a.samples[t] = best;
+                } else if (lane == 0) {
+                    toks[arow] = best;
+                    if (out && arow < nrow) a.samples[(long)(rb + arow) * a.T + t] = best;
+                }
+            }
+            if (NB > 1) {
+                lds_barrier();
+#pragma unroll
+                for (int r = 0; r < NB; ++r) tok[r] = toks[r];
+            }
+            if (out) B1_STAMP(0, t, 5);
+            if (more && !get_2d<NB, 3>(ex + (((tag + 1u) & 1) ? G_GH0X : G_GH0) + u, G_END, DH, tag + 1u, a.status, gh, hw, false)) *bad = 1;
+            if (out) B1_STAMP(0, t, 6);
+        }
     } else if (role < R_TBH) {
         // ---- TBi_k: tick layer 1's input-side product and its cell ----
         const int k = role - R_TBI, p = tid >> 4, s = tid & 15, u = UW * k + p;
@@ -409,7 +585,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                         if (!get_n<NB>(ex + G_HT0 + beat * 2 * DH + DH + u, G_END, 1u, a.status, h1, h1w)) *bad = 1;
                     } else {
 #pragma unroll
-                        for (int r = 0; r < NB; ++r) h1[r] = a.ht0[(beat * a.B + min(r, a.B - 1)) * 2 * DH + DH + u];
+                        for (int r = 0; r < NB; ++r) h1[r] = a.ht0[(beat * a.B + rb + min(r, nrow - 1)) * 2 * DH + DH + u];
                     }
                 }
             }
@@ -433,7 +609,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             if (k == 0) B1_STAMP(1, t, 4);
         }
     } else if (role < kTickRoles) {
-        tick_recurrent_role<NB>(c, role - R_TBH, a.W_hh1, a.b_hh1, 1, G_H1, G_GH1);
+        tick_recurrent_role<NB>(c, role - R_TBH, a.W_hh1, a.b_hh1, 1, G_H1, G_GH1, MG ? G_H1X : G_H1, G_GH1);
     } else if (FUSED) {
         if (role < R_BA) {
             // ---- Z2B_k: hb0 = SELU(W_zb z + b_zb) (decoder.py:455-461), 256 rows per workgroup, K = 256: 8 rows x 16 values per thread ----
@@ -445,7 +621,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             load_rows<8, 16>(w, bp.zb_w, DZ, row, s);
             if (tid < DZ) {
 #pragma unroll
-                for (int r = 0; r < NB; ++r) xs[r][0][xs_index<16>(tid)] = bp.z[(long)min(r, a.B - 1) * DZ + tid];
+                for (int r = 0; r < NB; ++r) xs[r][0][xs_index<16>(tid)] = bp.z[(long)(rb + min(r, nrow - 1)) * DZ + tid];
             }
             lds_barrier();
 #pragma unroll
@@ -570,9 +746,9 @@ void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 3) ? 3 : m; }
 
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
     return mode() != 0 && chain_enabled() && B >= 1 && B <= kDecodeB1MaxRows && H == DH && V >= 1 && V <= 128 && T % G == 0 && T / G <= 4 &&
-           kFusedRoles <= chain_capacity();
+           kFusedRoles <= chain_capacity() && decode_b1_teams(B) * kTickRoles <= chain_capacity();
 }
-bool decode_b1_fused(int Z) { return mode() == 3 && Z == DZ; }
+bool decode_b1_fused(int Z, int B) { return mode() == 3 && Z == DZ && decode_b1_teams(B) == 1; }
 bool decode_b1_ok(const DecodeChainArgs& a) {
     const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;
     return decode_b1_shape_ok(a.B, a.H, a.V, a.T, a.G) && !train && a.b1ex;
@@ -581,7 +757,8 @@ bool decode_b1_ok(const DecodeChainArgs& a) {
 int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     B1Args a{};
     a.fused = d.beat.z != nullptr;
-    a.B = d.B; a.T = d.T; a.G = d.G; a.V = d.V; a.Z = DZ; a.stride = (!a.fused && mode() == 2) ? 4 : 1;
+    a.teams = decode_b1_teams(d.B);
+    a.B = d.B; a.T = d.T; a.G = d.G; a.V = d.V; a.Z = DZ; a.stride = (!a.fused && mode() == 2 && a.teams == 1) ? 4 : 1;
     a.W_hh0 = d.W_hh0; a.b_hh0 = d.b_hh0; a.cgi = d.cgi; a.table = d.table;
     a.W_ih1 = d.W_ih1; a.b_ih1 = d.b_ih1; a.W_hh1 = d.W_hh1; a.b_hh1 = d.b_hh1;
     a.W_out = d.W_out; a.b_out = d.b_out; a.ht0 = d.ht0;
@@ -597,8 +774,8 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const double beat_w = a.fused ? 2.0 * DH * DZ + 9.0 * DH * DH + 3.0 * DH * DH + 3.0 * DH * DH : 0.0;
     ProfScope prof(PROF_GRU_FWD, 2.0 * d.B * (d.T * (9.0 * DH * DH + (double)d.V * DH) + beat_mac), s, label,
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
-    const dim3 grid((a.fused ? kFusedRoles : kTickRoles) * a.stride);
-    const int nj = (d.V + 31) / 32, nbr = rows_nb(d.B);
+    const dim3 grid((a.fused ? kFusedRoles : a.teams * kTickRoles) * a.stride);
+    const int nj = (d.V + 31) / 32, nbr = a.teams > 1 ? 4 : rows_nb(d.B);
 #define INET_B1(NJ, NBR)                                                                                        \
     do {                                                                                                        \
         if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR>), grid, dim3(NT), 0, s, a);            \

@@ -31,7 +31,7 @@ struct DecodeChainArgs {
     const float* ht0pk;                           // [2 layers][beats][pk(B,H)] the same, fragment-major
     float* hx0; float* hx1;                       // exchange rings [2][pk(B,H)]
     float* amax;                                  // [2][V/16][ceil16(B)] x {idx, max} (8 bytes each)
-    unsigned long long* b1ex;                     // B <= 4 (decode_b1.hip): decode_b1_words(B) / 2 zeroed 8-byte granules, or null
+    unsigned long long* b1ex;                     // B <= 16 (decode_b1.hip): decode_b1_words(B) / 2 zeroed 8-byte granules, or null
     DecodeB1Beat beat;                            // ... with the beat path folded in (beat.z != null)
     unsigned long long* b1stamps;                 // diagnostics (INET_DECODE_B1_STAMPS=1): [C, TBi_0][T][8] wall-clock stamps, or null
     float* weights; long long* samples;           // outputs [B,T,V], [B,1,T]
@@ -49,16 +49,18 @@ struct DecodeChainArgs {
 
 bool decode_chain_ok(int B, int H, int V, int T, int G);
 int launch_decode_chain(DecodeChainArgs a, hipStream_t s);
-// one to four measures, inference: the register-resident persistent launch of decode_b1.hip (launch_decode_chain takes it when it applies;
+// one to sixteen measures, inference: the register-resident persistent launch of decode_b1.hip (launch_decode_chain takes it when it applies;
 // INET_DECODE_B1 / inet_set_option key 15: 0 = never; 1 / 2 = the tick path only, behind the beat path's own launches, on consecutive
-// workgroup ids / on every 8th id (one XCD); 3 = default: the beat path folded into the same launch, 73 workgroups)
-constexpr int kDecodeB1WordsPerRow = 2 * 27648;   // 32-bit words of ONE row's granule area (decode_b1.hip's map: tick exchange + one slot per beat step)
+// workgroup ids / on every 8th id (one XCD); 3 = default: up to four measures with the beat path folded into the same launch, 129 workgroups; five to sixteen: teams of the tick path's workgroups)
+constexpr int kDecodeB1WordsPerRow = 2 * 29696;   // 32-bit words of ONE row's granule area (decode_b1.hip's map: tick exchange + one slot per beat step)
 constexpr int kDecodeB1StampWords = 2 * 2 * 32 * 8;   // 32-bit words of the stamp area (2 roles x <= 32 ticks x 8 stamps of 8 bytes)
-constexpr int kDecodeB1MaxRows = 4;               // rows (measures) per call the register-resident launch takes; rounded up to 1 / 2 / 4 inside
-inline int decode_b1_rows(int B) { return B <= 1 ? 1 : B <= 2 ? 2 : 4; }
+constexpr int kDecodeB1MaxRows = 16;              // rows (measures) per call the register-resident launch takes: 1 / 2 / 4 per team of
+                                                  // workgroups, up to four teams (tick path only beyond four rows)
+inline int decode_b1_teams(int B) { return B <= 4 ? 1 : (B + 3) / 4; }
+inline int decode_b1_rows(int B) { return B <= 1 ? 1 : B <= 2 ? 2 : 4 * decode_b1_teams(B); }
 inline long decode_b1_words(int B) { return (long)decode_b1_rows(B) * kDecodeB1WordsPerRow; }
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G);
-bool decode_b1_fused(int Z);                      // ... and the beat path goes into the same launch
+bool decode_b1_fused(int Z, int B);                    // ... and the beat path goes into the same launch
 bool decode_b1_ok(const DecodeChainArgs& a);
 int launch_decode_b1(const DecodeChainArgs& a, hipStream_t s);
 void decode_b1_set_mode(int m);

@@ -312,7 +312,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     // one measure, inference: decode_b1.hip's register-resident launch (reads the row-major initial hiddens: no packed twins)
     const bool b1_decode = fused_whole && !save && !mask_tick && w.b1ex && w.b1ex + decode_b1_words(B) == w.sync &&
                            decode_b1_shape_ok(B, H, V, T, G);
-    const bool b1_fused = b1_decode && !mask_beat && decode_b1_fused((int)Z);   // ... with the beat path inside the same launch
+    const bool b1_fused = b1_decode && !mask_beat && decode_b1_fused((int)Z, B);   // ... with the beat path inside the same launch
     // teacher-forced ticks: every input token is known and the 4 beats are independent, so each tick layer is a chain of
     // G steps over the beats as problems -- `npl` beats per launch, as many as fit the chip at once (2 at B = 256)
     static const bool tf_chain = [] { const char* v = std::getenv("INET_TF_CHAIN"); return !(v && v[0] == '0'); }();

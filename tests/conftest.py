@@ -17,3 +17,42 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def poison_allocator_pool(total_mb=1536):
+    """Fill the caching allocator's free blocks with NaN: what a later `torch.empty` hands out is then poisoned, and a kernel that
+    reads a buffer (or a workspace region) before anything wrote it shows up as NaN instead of passing on the zeros a fresh
+    process happens to get.  Blocks of many sizes, so both of the allocator's pools and every split of a large block are covered."""
+    import torch
+    blocks = []
+    nan = float("nan")
+    for mb, count in ((64, max(1, total_mb // 128)), (16, max(1, total_mb // 64)), (1, 256)):
+        for _ in range(count):
+            blocks.append(torch.full((mb << 18,), nan, dtype=torch.float32, device="cuda"))
+    for kb, count in ((256, 256), (16, 1024), (1, 2048)):
+        for _ in range(count):
+            blocks.append(torch.full((kb << 8,), nan, dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    del blocks
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_pool(request):
+    """INET_TEST_POISON=1: every GPU test starts with a NaN-filled allocator pool (tools/README: the uninitialised-read sweep)."""
+    if os.environ.get("INET_TEST_POISON") == "1" and request.node.get_closest_marker("gpu"):
+        poison_allocator_pool()
+    yield
+
+
+@pytest.fixture(autouse=True)
+def _fresh_dropout_stream(request):
+    """Every GPU test starts from the package's initial dropout stream (seed, call counter): a test that seeds the stream
+    (set_dropout_seed) or draws masks must not change which masks a later test sees.  (Found the hard way: behind
+    test_decoder_multinomial_sampling the AnticipationRNN step drew a mask under which one pre-activation of linear_1 lands within
+    round-off of the ReLU kink -- product and oracle take different branches there and one row of one gradient tensor moves by
+    4 % -- so the suite passed in file order and failed when test_gpu_inference.py ran first.)"""
+    if request.node.get_closest_marker("gpu"):
+        from inpaintnet_amd import measure_vae as MV
+        MV._DropState.seed = 0x5eed
+        MV._mask_counter[0] = 0
+    yield

@@ -33,5 +33,8 @@ def test_fresh_process_first_steps_cost_what_later_steps_cost():
     print(f"steps 5..24: {early / 20:.3f} ms per step (GPU timeline), steps 100..119: {late / 20:.3f}; "
           f"host: {(wall[24] - wall[4]) / 20:.3f} / {(wall[119] - wall[99]) / 20:.3f} ms per step; gc events {d['gc'][:8]}")
     assert early <= 1.15 * late, (early, late)
-    assert max(d["host_ms"][5:25]) < 10.0, d["host_ms"][5:25]            # no host stall in the region either
+    # no collection-sized host stall in the region either (a full collection is 36-40 ms; the host runs ~2.5 ms per step ahead of
+    # the GPU, so a stall below ~20 ms is absorbed by the queue -- one 11 ms hiccup at step 5 was seen once in a dozen runs, with the
+    # GPU timeline unaffected: 3.634 vs 3.622 ms per step)
+    assert max(d["host_ms"][5:25]) < 20.0, d["host_ms"][5:25]
     assert all(ms < 5.0 for _, _, ms in d["gc"]), d["gc"]

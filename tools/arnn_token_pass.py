@@ -22,7 +22,7 @@ args = (pr("note_embeddings.0.weight"), oc0, pr("lstm_generation.0.weight_ih_l0"
         pr("lstm_generation.1.bias_ih_l0"), pr("lstm_generation.1.weight_hh_l0"), pr("lstm_generation.1.bias_hh_l0"),
         pr("linear_1.weight"), pr("linear_1.bias"), pr("linear_ouput_notes.0.weight"), pr("linear_ouput_notes.0.bias"))
 # option key 14: 0 = four launches per tick (round 4), 1 = one persistent launch (csrc/arnn_gen.hip), 2 = ... on one XCD
-for mode in (0, 1, 2):
+for mode in (0, 1, 2, 3):
     ops.set_option(14, mode)
     for _ in range(3): t = ops.arnn_generate(*args)
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -59,11 +59,19 @@ if os.environ.get("INET_DECODE_B1_STAMPS") == "1":
         torch.cuda.synchronize()
         st = _o.ws_field(vae.cfg, ws, b, 2, "b1stamps").cpu().view(torch.int64).view(2, 32, 8).double() * 0.01
         c, t = st[0, 2:23], st[1, 2:23]
-        names = ["table rows + cells + publish h0", "wait for h1 (TBi: product, cell, two hand-offs)", "barrier", "head product(s) + barrier",
-                 "argmax + barrier", "look at the next tick's gh0"]
-        print(f"b = {b}: C, mean us per phase over ticks 2..22 (tick period {float((st[0, 3:24, 0] - st[0, 2:23, 0]).mean()):.2f} us)")
+        merged = b == 1 and vae.num_notes <= 64 or b == 2 and vae.num_notes <= 32       # decode_b1.hip's MG build: stamps of CB_0 only
+        if merged:
+            names = ["table rows + layer-0 cells (+ publish h0 for TA)", "barrier + W_ih1 product + layer-1 cell + publish h1",
+                     "wait for h1 of all 16 workgroups (the tick's ONE hand-off)", "barrier + head product(s) + barrier",
+                     "argmax", "look at the next tick's gh0"]
+        else:
+            names = ["table rows + cells + publish h0", "wait for h1 (TBi: product, cell, two hand-offs)", "barrier", "head product(s) + barrier",
+                     "argmax + barrier", "look at the next tick's gh0"]
+        print(f"b = {b}: {'CB_0' if merged else 'C'}, mean us per phase over ticks 2..22 (tick period {float((st[0, 3:24, 0] - st[0, 2:23, 0]).mean()):.2f} us)")
         for i, n in enumerate(names):
             print(f"  {float((c[:, i + 1] - c[:, i]).mean()):6.2f}  {n}")
+        if merged:
+            continue
         names_t = ["wait for gh1 (requested early)", "wait for h0", "barrier", "W_ih1 product(s) + cells + publish h1"]
         print("  TBi_0:")
         for i, n in enumerate(names_t):
