@@ -324,6 +324,27 @@ class LatentWorkload:
                 "parallelism": f"dp{world}"}
 
 
+def prime_branches(wl):
+    """One full training step per branch of the teacher-forcing coin, at workload construction, before the warm-up steps.
+    `--warmup 5` leaves it to the coin whether the free-running branch has ever run when the timed region starts (with this
+    file's seed the first free-running step IS the first timed step), and the first pass through a branch does one-time host
+    work: +1.3 ms typically, 11 and 16 ms in two of ~25 fresh-process runs of round 5 (no collection, no hipMalloc: `tools/
+    cold_start.py` shows the allocator's 14 segments all made in step 0) -- on an empty queue that is GPU idle time, 58.8 k instead
+    of 70 k measures/s for a 20-step region.  The `random` stream is put back, so warm-up and timed steps see the coins they saw
+    before.  Reported as `priming_steps`; --no-prime skips it."""
+    dec = wl.model.decoder
+    st = random.getstate()
+    p0 = dec.teacher_forcing_prob
+    try:
+        for p in (1.0, 0.0):                                   # random.random() < 1.0: always teacher-forced; < 0.0: never
+            dec.teacher_forcing_prob = p
+            wl.step()
+    finally:
+        dec.teacher_forcing_prob = p0
+        random.setstate(st)
+    return 2
+
+
 def timed(step, steps, warmup, fence, trace=None):
     """W un-timed steps, a fence, EXACTLY `steps` timed steps, a fence.  trace (a dict): also the first 32 timed steps one by one --
     host time to queue each and the GPU's time between events recorded behind consecutive steps -- and Python's garbage
@@ -912,6 +933,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-prime", action="store_true", help="skip the two priming steps (one per coin branch) in front of the warm-up")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -959,6 +981,9 @@ def main():
     dp.seed_shared(4321)                                       # the teacher-forcing coin is shared by all ranks
     wl = (VaeWorkload if args.workload == "vae" else LatentWorkload)(dev, rank)
     dp.broadcast_params(wl.model.flat)
+    priming_steps = 0
+    if args.workload == "vae" and coin not in ("tf", "fr") and not args.no_prime:
+        priming_steps = prime_branches(wl)
 
     def fence():
         torch.cuda.synchronize()
@@ -1113,7 +1138,7 @@ def main():
                           "float64, ::test_gemm_bf3_layouts); every other product runs on the f32-input MFMA (v_mfma_f32_*_f32).  "
                           "INET_CHAIN2=0 / INET_GEMM_BF3=0 select the f32-input forms (extras.chain_generations times them).",
             "data": "synthetic",
-            "config": dict(wl.describe(world), final_loss=round(final_loss, 5)),
+            "config": dict(wl.describe(world), final_loss=round(final_loss, 5), priming_steps=priming_steps),
             "roofline": roof,
         }
         if world > 1:

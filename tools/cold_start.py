@@ -71,6 +71,7 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     host = []
     wall = []
+    mallocs = []                                     # hipMalloc calls of the caching allocator (segments) and reserved MB behind each step
     torch.cuda.synchronize()
     t_begin = time.perf_counter()
     ev[0].record()
@@ -80,15 +81,17 @@ def main():
         wl.step()
         ev[i + 1].record()
         host.append(time.perf_counter() - t0)
+        ms_ = torch.cuda.memory_stats()
+        mallocs.append((ms_.get("num_device_alloc", 0), ms_.get("reserved_bytes.all.current", 0) >> 20))
         if args.sync_each:
             torch.cuda.synchronize()
         wall.append(time.perf_counter() - t_begin)
     torch.cuda.synchronize()
     t_end = time.perf_counter() - t_begin
     gpu = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    print(f"{'step':>4} {'coin':>4} {'host_ms':>9} {'gpu_ms':>9} {'wall_at_queue_ms':>17}")
+    print(f"{'step':>4} {'coin':>4} {'host_ms':>9} {'gpu_ms':>9} {'wall_at_queue_ms':>17} {'hipMallocs':>10} {'reserved_MB':>11}")
     for i in range(args.steps):
-        print(f"{i:>4} {coins[i]:>4} {1e3 * host[i]:>9.3f} {gpu[i]:>9.3f} {1e3 * wall[i]:>17.3f}")
+        print(f"{i:>4} {coins[i]:>4} {1e3 * host[i]:>9.3f} {gpu[i]:>9.3f} {1e3 * wall[i]:>17.3f} {mallocs[i][0]:>10} {mallocs[i][1]:>11}")
     cur_step[0] = 10 ** 6
     for st_, gen, ms, n in gc_log:
         if gen >= 1 or ms > 0.5:
