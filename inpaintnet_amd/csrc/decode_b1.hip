@@ -85,7 +85,7 @@ struct B1Args {
     chain::Status status;
 };
 
-#define B1_STAMP(who, t, i) do { if (a.stamps && tid == 0) a.stamps[((who) * 32 + (t)) * 8 + (i)] = wall_clock64(); } while (0)
+#define B1_STAMP(who, t, i) do { if (stamps && tid == 0) stamps[((who) * 32 + (t)) * 8 + (i)] = wall_clock64(); } while (0)
 
 template <int SK> __device__ __forceinline__ int xs_index(int k) { return (k / SK) * (SK + 4) + (k % SK); }
 
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     const int rb = team * NB, nrow = min(NB, a.B - rb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* const ex = a.ex + (long)rb * G_END;
+    unsigned long long* const stamps = team == 0 ? a.stamps : nullptr;      // (diagnostics: the first team's workgroups only)
     volatile int* const bad = &bad_s;
     if (tid == 0) bad_s = 0;
     __syncthreads();

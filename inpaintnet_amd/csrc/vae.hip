@@ -613,8 +613,8 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
 
     // ---- output projection ----
     // Leaf work (weight / bias gradients: nothing downstream reads them before the optimizer) goes to the side streams in
-    // THREE fork sessions -- after the layer-1 tick chain, after the layer-0 tick chain, at the end -- instead of one per
-    // module: every fork is an event on the main stream, and the small products of one session share a grouped launch.
+    // TWO fork sessions -- after the layer-0 tick chain (both tick layers' products), at the end (the beat path's) -- instead of
+    // one per module: every fork is an event on the main stream, and the small products of one session share a grouped launch.
     INET_TRY(pw_dlogits_relayout(dweights, weights, B, T, V, w.dlg, s));
     INET_TRY(linear_dgrad(w.dlg, V, p + L.out_w, H, w.dh1top, H, T * B, V, H, EPI_NONE, nullptr, 0, ACC_STORE, s));
 
@@ -636,12 +636,22 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     }
     INET_TRY(gru_layer_bwd(H, B, G, nb, d, s));
     const float* x1 = mask_tick ? w.h0m : w.h0seq;
-    if (g) {
-        hipStream_t ss = side_fork(s);                       // overlaps the layer-0 BPTT chain below
+    // Layer 1's leaf work is issued BEHIND the layer-0 chain, not beside it (round 5, profiles/r05_s_leaf_schedule.txt): beside the
+    // chain its 6144-row products doubled the chain's time (231 us against 124 alone -- a persistent chain and a throughput product on
+    // the same CUs overlap almost not at all), behind it they run beside the beat path's small latency-bound products, which lose
+    // little: 3.60 -> 3.55 ms per step.  (INET_DEC_LEAF=0: beside the layer-0 chain, as rounds 2-4 had it; 2: with the beat path's
+    // session at the end -- beside the encoder's layer-1 BPTT chain, 3.76 ms.)
+    static const int leaf_when = [] { const char* v = std::getenv("INET_DEC_LEAF"); return v ? std::atoi(v) : 1; }();
+    auto layer1_leaf = [&](hipStream_t ss) -> int {
         INET_TRY(linear_wgrad2(w.dgh1t, w.dgi1t, 3L * H, w.svt1 + 4 * TBH, x1, H, g + L.tick[1].w_hh, g + L.tick[1].w_ih, H,
                                T * B, 3 * H, H, ss));      // recurrent and input weights of layer 1 in one launch
         INET_TRY(linear_wgrad(w.dlg, V, w.h1seq, H, g + L.out_w, H, T * B, V, H, ss));
         INET_TRY(pw_colsum(w.dlg, V, T * B, V, g + L.out_b, ss));
+        return 0;
+    };
+    if (g && leaf_when == 0) {
+        hipStream_t ss = side_fork(s);
+        INET_TRY(layer1_leaf(ss));
     }
     INET_TRY(linear_dgrad(w.dgi1t, 3L * H, p + L.tick[1].w_ih, H, w.dx1t, H, T * B, 3 * H, H,
                           mask_tick ? EPI_MUL_AUX : EPI_NONE, mask_tick, H, ACC_STORE, s));
@@ -672,6 +682,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
                           ACC_STORE, s));
     if (g) {
         hipStream_t ss = side_fork(s);
+        if (leaf_when == 1) INET_TRY(layer1_leaf(ss));
         INET_TRY(gru_dir_wgrad(H, B, T, w.dgh0t, w.svt0 + 4 * TBH, g + L.tick[0].w_hh, ss));
         INET_TRY(linear_wgrad(w.dcgi, 3L * H, w.c_all, H, g + L.tick[0].w_ih + E, ldw0, nb * B, 3 * H, H, ss));
         // token-embedding half through the gather table (rows 0..V-1 = the embeddings, row V = the start symbol x_0)
@@ -734,6 +745,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     if (g) {
         // the beat path's leaf work in one session: six weight gradients in two grouped launches, four column sums in one
         hipStream_t ss = side_fork(s);
+        if (leaf_when == 2) INET_TRY(layer1_leaf(ss));
         const GemmArgs ga[4] = {linear_wgrad_args(w.dht0, 2L * H, w.beat_out, H, g + L.bh_w, H, nb * B, 2 * H, H),
                                 linear_wgrad_args(w.dc_all, H, w.beat_out, H, g + L.bi_w, H, nb * B, H, H),
                                 linear_wgrad_args(w.dgh1b, 3L * H, w.svb1 + 4 * nb * BH, H, g + L.beat[1].w_hh, H, nb * B, 3 * H, H),
