@@ -337,11 +337,12 @@ int inet_set_option(int key, int value);
  * (they compare XCC ids at the start of the launch) -- granules as plain stores that stay in that XCD's L2; 2 = the same with
  * agent-scope stores; 1 = on 13 consecutive ids; 0 = four launches per tick.
  * key 15 = the free-running decode of ONE to SIXTEEN measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 3 (default) =
- * up to four measures: ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for
+ * one or two measures: ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for
  * the 24 ticks -- two hand-offs per tick; one where a single workgroup kind can hold layer 1, the head and the argmax: one row with
- * V <= 64 -- and 80 for the beat path); five to sixteen: two to four teams of the 49 tick workgroups, four rows each, behind the beat
- * path's launches; 2 / 1 = the tick path only, behind the beat path's eight launches, on every 4th workgroup id / on consecutive ids;
- * 0 = decode_chain.hip's 32-member exchange kernel.
+ * V <= 64 -- and 80 for the beat path); three to sixteen: teams of the 49 tick workgroups in one launch, two rows per team up to ten
+ * measures, four beyond -- up to six measures still with the beat path's workgroups in the same launch, beyond behind the beat path's
+ * own launches; 2 / 1 = the tick path only, behind the beat path's eight launches, on
+ * every 4th workgroup id / on consecutive ids; 0 = decode_chain.hip's 32-member exchange kernel.
  * Keys 4, 7-12, 14 must not change between a forward call and its backward call, nor between sizing a workspace and using it. */
 int inet_side_join(void* stream);
 /* `stream` -- a THIRD stream, not the one the library calls were issued on -- waits for all side-stream work queued so far.

@@ -41,8 +41,12 @@
 // hand-offs of a tick are paid once, not per row.  B is rounded up to NB = 1 / 2 / 4 (rows beyond B repeat row B - 1 and store
 // nothing); every row has its own granule area.  (Eight rows do not fit: workgroup C keeps seven floats and six granule words per row
 // and unit next to its slice of the head, 256 VGPRs are gone at NB = 8.)
-// FIVE TO SIXTEEN MEASURES: two to four TEAMS of the tick path's 49 workgroups, four rows each, in one launch (196 of 256 CUs at
-// B = 16) behind the beat path's launches -- the beat roles do not fit beside four teams.  0.35 -> 0.30 ms per call at B = 16.
+// THREE TO SIXTEEN MEASURES: TEAMS of the tick path's 49 workgroups in one launch, every team with its own rows and granule areas: teams
+// of TWO rows while they fit the chip (a two-row tick is 5.5 us, a four-row tick 8.4; five teams = 245 of 256 CUs: B <= 10), of four
+// rows beyond (196 CUs at B = 16).  With two or three teams (B <= 6) the beat path's 80 workgroups still fit beside them (227 CUs)
+// and serve all six rows of the call; beyond, the beat path runs as its own launches in front.  Per call
+// (profiles/r05_u_decode_team_rows.txt): B = 4 0.194 ms (one four-row team: 0.256), B = 6 0.201, B = 8 0.224 (four-row teams 0.288;
+// decode_chain.hip 0.348), B = 16 0.30 (0.355).
 //
 // THE MERGED BUILD (one row with V <= 64, two rows with V <= 32 -- what fits 256 registers without spills): workgroup C does not
 // exist.  Its work -- layer 0's cell, which needs no product, the V x 512 head and the argmax -- is REPLICATED in every TBi_k: h0_t
@@ -253,15 +257,140 @@ __device__ __forceinline__ void beat_product_role(const Ctx<NB>& c, int row0, co
     }
 }
 
-template <int NJ, bool FUSED, int NB>
+// ---- beat path (the launch's other 80 workgroups when it is folded in): NR rows, which may be MORE than a tick team's -- with two or
+// three two-row teams (B = 3 .. 6) the beat path's workgroups serve all rows of the call ----
+template <int NR>
+__device__ __forceinline__ void beat_path_role(const Ctx<NR>& c, int role, int nb) {
+    const B1Args& a = c.a;
+    const DecodeB1Beat& bp = a.bp;
+    const int tid = c.tid;
+    if (role < R_BA) {
+        // ---- Z2B_k: hb0 = SELU(W_zb z + b_zb) (decoder.py:455-461), 256 rows per workgroup, K = 256: 8 rows x 16 values per thread ----
+        const int k = role - R_Z2B, p = tid >> 4, s = tid & 15;
+        int row[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] = 256 * k + 8 * p + i;
+        float w[8][16];
+        load_rows<8, 16>(w, bp.zb_w, DZ, row, s);
+        if (tid < DZ) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) c.xs[r][0][xs_index<16>(tid)] = bp.z[(long)(c.rb + min(r, c.nrow - 1)) * DZ + tid];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float y[8];
+            dot_rows<8, 16>(w, c.xs[r][0] + 20 * s, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s == j) put(c.ex + (long)r * G_END + G_HB0 + row[j], selu_f(y[j] + bp.zb_b[row[j]]), 1u);
+        }
+    } else if (role < R_BBI) {
+        // ---- BA_k: beat layer 0, product and cell (the input gates are the constant gvec0 = b_0 W_ih[:, 0] + b_ih) ----
+        const int k = role - R_BA, p = tid >> 4, s = tid & 15, u = UW * k + p;
+        const int row[3] = {u, DH + u, 2 * DH + u};
+        float w[3][32];
+        load_rows<3, 32>(w, bp.W_hh0, DH, row, s);
+        const bool cell = s == 0;
+        float gv[3] = {0.f, 0.f, 0.f}, bh[3] = {0.f, 0.f, 0.f}, h[NR];
+        if (cell) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { gv[g] = bp.gvec0[g * DH + u]; bh[g] = bp.b_hh0[g * DH + u]; }
+        }
+        for (int i = 0; i < nb; ++i) {
+            c.gather(i == 0 ? G_HB0 : G_H0B + (i - 1) * DH, 1u, i & 1);
+            lds_barrier();
+            if (*c.bad) break;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float y[3];
+                dot_rows<3, 32>(w, c.xs[r][i & 1] + 36 * s, y);
+                if (cell) {
+                    if (i == 0) h[r] = c.xs[r][0][xs_index<32>(u)];
+                    h[r] = gru_cell(gv[0], gv[1], gv[2], y[0] + bh[0], y[1] + bh[1], y[2] + bh[2], h[r]);
+                    put(c.ex + (long)r * G_END + G_H0B + i * DH + u, h[r], 1u);
+                }
+            }
+        }
+    } else if (role < R_BBH) {
+        // ---- BBi_k: beat layer 1's input-side product and its cell -> the beat outputs ----
+        const int k = role - R_BBI, p = tid >> 4, s = tid & 15, u = UW * k + p;
+        const int row[3] = {u, DH + u, 2 * DH + u};
+        float w[3][32];
+        load_rows<3, 32>(w, bp.W_ih1, DH, row, s);
+        const bool cell = s == 0;
+        float bi[3] = {0.f, 0.f, 0.f}, h[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) h[r] = 0.f;
+        if (cell) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) bi[g] = bp.b_ih1[g * DH + u];
+            unsigned long long hw0[NR];
+            if (!get_n<NR>(c.ex + G_HB0 + DH + u, G_END, 1u, a.status, h, hw0)) *c.bad = 1;      // layer 1's initial state
+        }
+        for (int i = 0; i < nb; ++i) {
+            float gh[NR][3];
+            unsigned long long hw[NR][3];
+            if (cell && !get_2d<NR, 3>(c.ex + G_GH1B + i * D3 + u, G_END, DH, 1u, a.status, gh, hw)) *c.bad = 1;
+            c.gather(G_H0B + i * DH, 1u, i & 1);
+            lds_barrier();
+            if (*c.bad) break;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float y[3];
+                dot_rows<3, 32>(w, c.xs[r][i & 1] + 36 * s, y);
+                if (cell) {
+                    h[r] = gru_cell(y[0] + bi[0], y[1] + bi[1], y[2] + bi[2], gh[r][0], gh[r][1], gh[r][2], h[r]);
+                    put(c.ex + (long)r * G_END + G_H1B + i * DH + u, h[r], 1u);
+                }
+            }
+        }
+    } else if (role < R_PH) {
+        // ---- BBh_k: beat layer 1's recurrent-side product for step i from the output of step i - 1 (the initial state at i = 0) ----
+        const int k = role - R_BBH, p = tid >> 4, s = tid & 15, u = UW * k + p;
+        const int row[3] = {u, DH + u, 2 * DH + u};
+        float w[3][32];
+        load_rows<3, 32>(w, bp.W_hh1, DH, row, s);
+        float b[3] = {0.f, 0.f, 0.f};
+        if (s == 0) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) b[g] = bp.b_hh1[g * DH + u];
+        }
+        for (int i = 0; i < nb; ++i) {
+            c.gather(i == 0 ? G_HB0 + DH : G_H1B + (i - 1) * DH, 1u, i & 1);
+            lds_barrier();
+            if (*c.bad) break;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float y[3];
+                dot_rows<3, 32>(w, c.xs[r][i & 1] + 36 * s, y);
+                if (s == 0) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) put(c.ex + (long)r * G_END + G_GH1B + i * D3 + g * DH + u, y[g] + b[g], 1u);
+                }
+            }
+        }
+    } else if (role < R_PI) {
+        beat_product_role<NR, 4, true>(c, 128 * (role - R_PH), bp.bh_w, DH, bp.bh_b, G_H1B, DH, G_HT0, 2 * DH, nb);     // ht0_i
+    } else if (role < R_CG) {
+        beat_product_role<NR, 4, true>(c, 128 * (role - R_PI), bp.bi_w, DH, bp.bi_b, G_H1B, DH, G_C, DH, nb);           // c_i
+    } else {
+        beat_product_role<NR, 3, false>(c, 96 * (role - R_CG), bp.wih0_c, bp.wih0_ld, nullptr, G_C, DH, G_CGI, D3, nb); // cgi_i
+    }
+}
+
+template <int NJ, bool FUSED, int NB, int NBB>
 __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
-    __shared__ __attribute__((aligned(16))) float xs[NB][2][XS];
+    __shared__ __attribute__((aligned(16))) float xs[NB > NBB ? NB : NBB][2][XS];
     __shared__ float lgs[NB][32 * NJ];
     __shared__ int toks[NB];
     __shared__ int bad_s;
     if (blockIdx.x % a.stride) return;
     // more than four rows: `teams` teams of the tick path's workgroups, NB rows and one granule area per row each, nothing shared
-    const int wg = blockIdx.x / a.stride, team = a.teams > 1 ? wg / kTickRoles : 0, role = a.teams > 1 ? wg % kTickRoles : wg;
+    // (workgroup order with several teams: the teams' tick workgroups first, the beat path's 80 behind them when it is folded in)
+    const int wg = blockIdx.x / a.stride, tick_wgs = a.teams * kTickRoles;
+    const int team = (a.teams > 1 && wg < tick_wgs) ? wg / kTickRoles : 0;
+    const int role = a.teams > 1 ? (wg < tick_wgs ? wg % kTickRoles : kTickRoles + (wg - tick_wgs)) : wg;
     const int rb = team * NB, nrow = min(NB, a.B - rb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* const ex = a.ex + (long)rb * G_END;
@@ -612,119 +741,9 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     } else if (role < kTickRoles) {
         tick_recurrent_role<NB>(c, role - R_TBH, a.W_hh1, a.b_hh1, 1, G_H1, G_GH1, MG ? G_H1X : G_H1, G_GH1);
     } else if (FUSED) {
-        if (role < R_BA) {
-            // ---- Z2B_k: hb0 = SELU(W_zb z + b_zb) (decoder.py:455-461), 256 rows per workgroup, K = 256: 8 rows x 16 values per thread ----
-            const int k = role - R_Z2B, p = tid >> 4, s = tid & 15;
-            int row[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) row[i] = 256 * k + 8 * p + i;
-            float w[8][16];
-            load_rows<8, 16>(w, bp.zb_w, DZ, row, s);
-            if (tid < DZ) {
-#pragma unroll
-                for (int r = 0; r < NB; ++r) xs[r][0][xs_index<16>(tid)] = bp.z[(long)(rb + min(r, nrow - 1)) * DZ + tid];
-            }
-            lds_barrier();
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                float y[8];
-                dot_rows<8, 16>(w, xs[r][0] + 20 * s, y);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (s == j) put(ex + (long)r * G_END + G_HB0 + row[j], selu_f(y[j] + bp.zb_b[row[j]]), 1u);
-            }
-        } else if (role < R_BBI) {
-            // ---- BA_k: beat layer 0, product and cell (the input gates are the constant gvec0 = b_0 W_ih[:, 0] + b_ih) ----
-            const int k = role - R_BA, p = tid >> 4, s = tid & 15, u = UW * k + p;
-            const int row[3] = {u, DH + u, 2 * DH + u};
-            float w[3][32];
-            load_rows<3, 32>(w, bp.W_hh0, DH, row, s);
-            const bool cell = s == 0;
-            float gv[3] = {0.f, 0.f, 0.f}, bh[3] = {0.f, 0.f, 0.f}, h[NB];
-            if (cell) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) { gv[g] = bp.gvec0[g * DH + u]; bh[g] = bp.b_hh0[g * DH + u]; }
-            }
-            for (int i = 0; i < nb; ++i) {
-                c.gather(i == 0 ? G_HB0 : G_H0B + (i - 1) * DH, 1u, i & 1);
-                lds_barrier();
-                if (*bad) break;
-#pragma unroll
-                for (int r = 0; r < NB; ++r) {
-                    float y[3];
-                    dot_rows<3, 32>(w, xs[r][i & 1] + 36 * s, y);
-                    if (cell) {
-                        if (i == 0) h[r] = xs[r][0][xs_index<32>(u)];
-                        h[r] = gru_cell(gv[0], gv[1], gv[2], y[0] + bh[0], y[1] + bh[1], y[2] + bh[2], h[r]);
-                        put(ex + (long)r * G_END + G_H0B + i * DH + u, h[r], 1u);
-                    }
-                }
-            }
-        } else if (role < R_BBH) {
-            // ---- BBi_k: beat layer 1's input-side product and its cell -> the beat outputs ----
-            const int k = role - R_BBI, p = tid >> 4, s = tid & 15, u = UW * k + p;
-            const int row[3] = {u, DH + u, 2 * DH + u};
-            float w[3][32];
-            load_rows<3, 32>(w, bp.W_ih1, DH, row, s);
-            const bool cell = s == 0;
-            float bi[3] = {0.f, 0.f, 0.f}, h[NB];
-#pragma unroll
-            for (int r = 0; r < NB; ++r) h[r] = 0.f;
-            if (cell) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) bi[g] = bp.b_ih1[g * DH + u];
-                unsigned long long hw0[NB];
-                if (!get_n<NB>(ex + G_HB0 + DH + u, G_END, 1u, a.status, h, hw0)) *bad = 1;      // layer 1's initial state
-            }
-            for (int i = 0; i < nb; ++i) {
-                float gh[NB][3];
-                unsigned long long hw[NB][3];
-                if (cell && !get_2d<NB, 3>(ex + G_GH1B + i * D3 + u, G_END, DH, 1u, a.status, gh, hw)) *bad = 1;
-                c.gather(G_H0B + i * DH, 1u, i & 1);
-                lds_barrier();
-                if (*bad) break;
-#pragma unroll
-                for (int r = 0; r < NB; ++r) {
-                    float y[3];
-                    dot_rows<3, 32>(w, xs[r][i & 1] + 36 * s, y);
-                    if (cell) {
-                        h[r] = gru_cell(y[0] + bi[0], y[1] + bi[1], y[2] + bi[2], gh[r][0], gh[r][1], gh[r][2], h[r]);
-                        put(ex + (long)r * G_END + G_H1B + i * DH + u, h[r], 1u);
-                    }
-                }
-            }
-        } else if (role < R_PH) {
-            // ---- BBh_k: beat layer 1's recurrent-side product for step i from the output of step i - 1 (the initial state at i = 0) ----
-            const int k = role - R_BBH, p = tid >> 4, s = tid & 15, u = UW * k + p;
-            const int row[3] = {u, DH + u, 2 * DH + u};
-            float w[3][32];
-            load_rows<3, 32>(w, bp.W_hh1, DH, row, s);
-            float b[3] = {0.f, 0.f, 0.f};
-            if (s == 0) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) b[g] = bp.b_hh1[g * DH + u];
-            }
-            for (int i = 0; i < nb; ++i) {
-                c.gather(i == 0 ? G_HB0 + DH : G_H1B + (i - 1) * DH, 1u, i & 1);
-                lds_barrier();
-                if (*bad) break;
-#pragma unroll
-                for (int r = 0; r < NB; ++r) {
-                    float y[3];
-                    dot_rows<3, 32>(w, xs[r][i & 1] + 36 * s, y);
-                    if (s == 0) {
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) put(ex + (long)r * G_END + G_GH1B + i * D3 + g * DH + u, y[g] + b[g], 1u);
-                    }
-                }
-            }
-        } else if (role < R_PI) {
-            beat_product_role<NB, 4, true>(c, 128 * (role - R_PH), bp.bh_w, DH, bp.bh_b, G_H1B, DH, G_HT0, 2 * DH, nb);     // ht0_i
-        } else if (role < R_CG) {
-            beat_product_role<NB, 4, true>(c, 128 * (role - R_PI), bp.bi_w, DH, bp.bi_b, G_H1B, DH, G_C, DH, nb);           // c_i
-        } else {
-            beat_product_role<NB, 3, false>(c, 96 * (role - R_CG), bp.wih0_c, bp.wih0_ld, nullptr, G_C, DH, G_CGI, D3, nb); // cgi_i
-        }
+        // (one team: the beat path serves the team's NB rows; several teams: all NBB rows of the call, from the call's first granule area)
+        const Ctx<NBB> cb{a, a.ex, xs, bad, tid, 0, min(NBB, a.B)};
+        beat_path_role<NBB>(cb, role, nb);
     }
     __syncthreads();
     if (bad_s && tid == 0) chain::raise_timeout(a.status);
@@ -740,8 +759,15 @@ int mode() {
     }
     return g_mode;
 }
-int rows_nb(int B) { return decode_b1_rows(B); }
 }  // namespace
+
+int decode_b1_team_rows(int B) {
+    static const int forced = [] { const char* v = std::getenv("INET_DECODE_B1_TEAM_ROWS"); return v ? std::atoi(v) : 0; }();
+    if (B <= 1) return 1;
+    if (B <= 2) return 2;
+    if (forced == 2 || forced == 4) return (B + forced - 1) / forced * kTickRoles <= 256 ? forced : 4;
+    return B <= 10 ? 2 : 4;
+}
 
 void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 3) ? 3 : m; }
 
@@ -749,7 +775,12 @@ bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
     return mode() != 0 && chain_enabled() && B >= 1 && B <= kDecodeB1MaxRows && H == DH && V >= 1 && V <= 128 && T % G == 0 && T / G <= 4 &&
            kFusedRoles <= chain_capacity() && decode_b1_teams(B) * kTickRoles <= chain_capacity();
 }
-bool decode_b1_fused(int Z, int B) { return mode() == 3 && Z == DZ && decode_b1_teams(B) == 1; }
+// the beat path's 80 workgroups go into the same launch when they fit beside the teams: one team, or two / three two-row teams (B <= 6:
+// 3 x 49 + 80 = 227 of 256 CUs); they then serve all (up to kBeatRowsMax) rows of the call
+bool decode_b1_fused(int Z, int B) {
+    const int teams = decode_b1_teams(B);
+    return mode() == 3 && Z == DZ && (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax));
+}
 bool decode_b1_ok(const DecodeChainArgs& a) {
     const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;
     return decode_b1_shape_ok(a.B, a.H, a.V, a.T, a.G) && !train && a.b1ex;
@@ -775,12 +806,14 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const double beat_w = a.fused ? 2.0 * DH * DZ + 9.0 * DH * DH + 3.0 * DH * DH + 3.0 * DH * DH : 0.0;
     ProfScope prof(PROF_GRU_FWD, 2.0 * d.B * (d.T * (9.0 * DH * DH + (double)d.V * DH) + beat_mac), s, label,
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
-    const dim3 grid((a.fused ? kFusedRoles : a.teams * kTickRoles) * a.stride);
-    const int nj = (d.V + 31) / 32, nbr = a.teams > 1 ? 4 : rows_nb(d.B);
-#define INET_B1(NJ, NBR)                                                                                        \
-    do {                                                                                                        \
-        if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR>), grid, dim3(NT), 0, s, a);            \
-        else hipLaunchKernelGGL((decode_b1_kernel<NJ, false, NBR>), grid, dim3(NT), 0, s, a);                   \
+    const dim3 grid((a.teams * kTickRoles + (a.fused ? kFusedRoles - kTickRoles : 0)) * a.stride);
+    const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
+    if (a.fused && a.teams > 1 && (nbr != 2 || a.teams * 2 > kDecodeB1BeatRowsMax)) return -1;
+#define INET_B1(NJ, NBR)                                                                                                    \
+    do {                                                                                                                    \
+        if (a.fused && a.teams > 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 2, kDecodeB1BeatRowsMax>), grid, dim3(NT), 0, s, a); \
+        else if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR, NBR>), grid, dim3(NT), 0, s, a);             \
+        else hipLaunchKernelGGL((decode_b1_kernel<NJ, false, NBR, NBR>), grid, dim3(NT), 0, s, a);                        \
     } while (0)
 #define INET_B1N(NJ) do { if (nbr == 1) INET_B1(NJ, 1); else if (nbr == 2) INET_B1(NJ, 2); else INET_B1(NJ, 4); } while (0)
     if (nj <= 1) INET_B1N(1); else if (nj == 2) INET_B1N(2); else if (nj == 3) INET_B1N(3); else INET_B1N(4);

@@ -51,13 +51,23 @@ bool decode_chain_ok(int B, int H, int V, int T, int G);
 int launch_decode_chain(DecodeChainArgs a, hipStream_t s);
 // one to sixteen measures, inference: the register-resident persistent launch of decode_b1.hip (launch_decode_chain takes it when it applies;
 // INET_DECODE_B1 / inet_set_option key 15: 0 = never; 1 / 2 = the tick path only, behind the beat path's own launches, on consecutive
-// workgroup ids / on every 8th id (one XCD); 3 = default: up to four measures with the beat path folded into the same launch, 129 workgroups; five to sixteen: teams of the tick path's workgroups)
+// workgroup ids / on every 8th id (one XCD); 3 = default: up to six measures with the beat path folded into the same launch; three to sixteen: teams of the tick path's workgroups)
 constexpr int kDecodeB1WordsPerRow = 2 * 29696;   // 32-bit words of ONE row's granule area (decode_b1.hip's map: tick exchange + one slot per beat step)
 constexpr int kDecodeB1StampWords = 2 * 2 * 32 * 8;   // 32-bit words of the stamp area (2 roles x <= 32 ticks x 8 stamps of 8 bytes)
 constexpr int kDecodeB1MaxRows = 16;              // rows (measures) per call the register-resident launch takes: 1 / 2 / 4 per team of
-                                                  // workgroups, up to four teams (tick path only beyond four rows)
-inline int decode_b1_teams(int B) { return B <= 4 ? 1 : (B + 3) / 4; }
-inline int decode_b1_rows(int B) { return B <= 1 ? 1 : B <= 2 ? 2 : 4 * decode_b1_teams(B); }
+                                                  // workgroups, up to five teams (tick path only beyond one team)
+// rows per team and teams for a call of B rows.  One team up to B = 2; beyond, teams of TWO rows while they fit
+// the chip (a two-row tick is 5.5 us, a four-row tick 8.4: 5 teams x 49 workgroups = 245 of 256 CUs -> B <= 10), else of four.
+// (INET_DECODE_B1_TEAM_ROWS=4: four-row teams from B = 3 on, with the beat path folded in at B = 3, 4: the first build of the round.)
+int decode_b1_team_rows(int B);                   // (decode_b1.hip: the rule above, or INET_DECODE_B1_TEAM_ROWS)
+inline int decode_b1_teams(int B) { const int r = decode_b1_team_rows(B); return (B + r - 1) / r; }
+constexpr int kDecodeB1BeatRowsMax = 6;           // rows the beat path's workgroups serve when they share the launch with several teams
+// granule areas of a call: one per row of every team; three to six measures: at least kDecodeB1BeatRowsMax (the folded beat path
+// computes that many rows, whatever B is -- rows beyond B repeat row B - 1)
+inline int decode_b1_rows(int B) {
+    const int r = decode_b1_teams(B) * decode_b1_team_rows(B);
+    return (B >= 3 && B <= kDecodeB1BeatRowsMax && r < kDecodeB1BeatRowsMax) ? kDecodeB1BeatRowsMax : r;
+}
 inline long decode_b1_words(int B) { return (long)decode_b1_rows(B) * kDecodeB1WordsPerRow; }
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G);
 bool decode_b1_fused(int Z, int B);                    // ... and the beat path goes into the same launch

@@ -354,11 +354,11 @@ def test_fused_decode_matches_per_tick_path_repeatedly():
 
 
 @pytest.mark.parametrize("V,B", [(48, 1), (20, 1), (61, 1), (93, 1), (128, 1), (48, 2), (20, 2), (48, 3), (48, 4), (61, 4), (125, 3),
-                                 (48, 5), (48, 8), (61, 13), (48, 16), (100, 16)])
+                                 (48, 5), (48, 8), (20, 7), (48, 10), (48, 11), (61, 13), (48, 16), (100, 16)])
 def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V, B):
     """(One row with V <= 64 / two rows with V <= 32: the merged build, where every layer-1 workgroup also runs layer 0's cell, the head and
-    the argmax for itself -- one hand-off per tick; five to sixteen rows: two to four teams of the tick path's 49 workgroups, four rows
-    each, behind the beat path's launches.)
+    the argmax for itself -- one hand-off per tick; three to sixteen rows: teams of the tick path's 49 workgroups behind the beat path's
+    launches, two rows each up to ten rows, four rows each beyond.)
     One measure (the call the north_star prices: LatentRNNTester.generate, decode_mid_point) -- and the two to four measures of the
     reference's non-auto-regressive inpainting call -- through csrc/decode_b1.hip -- 129
     resident workgroups (49 for the ticks, 80 for the beat path folded into the same launch), every weight matrix in registers, 8-byte {value, tick} granules, two hand-offs per tick, the rows looped inside every phase -- against the

@@ -30,7 +30,7 @@ ops.set_option(15, 3)
 
 # two to four measures (the reference's non-auto-regressive inpainting call) on the register-resident kernel (mode 3) and on
 # decode_chain.hip's exchange kernel (mode 0)
-for b in (2, 3, 4, 5, 8):
+for b in (2, 3, 4, 5, 6, 8, 10, 11, 12, 16):
     z = torch.randn(b, vae.latent_space_dim, device="cuda")
     dummy = torch.zeros(b, 24, device="cuda")
     line = []
