@@ -779,7 +779,8 @@ bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
 // 3 x 49 + 80 = 227 of 256 CUs); they then serve all (up to kBeatRowsMax) rows of the call
 bool decode_b1_fused(int Z, int B) {
     const int teams = decode_b1_teams(B);
-    return mode() == 3 && Z == DZ && (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax));
+    return mode() == 3 && Z == DZ && (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax)) &&
+           teams * kTickRoles + (kFusedRoles - kTickRoles) <= chain_capacity();
 }
 bool decode_b1_ok(const DecodeChainArgs& a) {
     const bool train = a.sv0 || a.sv1 || a.mask || a.h0out || a.h1seq;
