@@ -379,7 +379,7 @@ def _token_pass(x, mode, hc_init=None, first_tok=None):
                               x["b_hh1"], x["W1"], x["b1"], x["W2"], x["b2"], hc_init=hc_init, first_tok=first_tok)
         torch.cuda.synchronize()
     finally:
-        ops.set_option(14, 2)
+        ops.set_option(14, 3)
     return t
 
 
@@ -393,7 +393,7 @@ def test_arnn_token_pass_persistent_kernel_equals_the_per_tick_launches(V, L):
     ref = _token_pass(x, 0)
     assert ops.chain_status() == 0
     assert int(ref.min()) >= 0 and int(ref.max()) < V and len(torch.unique(ref)) > 3      # (a sequence worth comparing)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):                                        # 3 = the default: one XCD + XCD-local granule stores
         got = _token_pass(x, mode)
         assert ops.chain_status() == 0
         same = (got == ref)
@@ -404,6 +404,7 @@ def test_arnn_token_pass_persistent_kernel_equals_the_per_tick_launches(V, L):
     ft = torch.tensor([V], dtype=torch.int64).cuda()             # a token the head cannot produce (row V of the embedding table)
     ref = _token_pass(x, 0, hc_init=hc, first_tok=ft)
     got = _token_pass(x, 1, hc_init=hc, first_tok=ft)
+    assert torch.equal(got, _token_pass(x, 3, hc_init=hc, first_tok=ft))
     assert torch.equal(got, ref)
     assert not torch.equal(got, _token_pass(x, 1))                # (the state and the token matter)
 
@@ -414,12 +415,12 @@ def test_arnn_token_pass_with_nan_weights_stays_inside_the_vocabulary():
     the reference reports it -- Trainer.finish() / check_steps() raise ValueError('... has become nan')."""
     x = _token_pass_inputs(L=64, V=48)
     x["W2"][:] = float("nan")
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         t = _token_pass(x, mode)
         assert int(t.min()) == 0 and int(t.max()) == 0
     x = _token_pass_inputs(L=64, V=48)
     x["W_hh1"][5, 7] = float("nan")                              # the state becomes NaN at tick 1, the logits with it
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         t = _token_pass(x, mode)
         assert 0 <= int(t.min()) and int(t.max()) < 48
     assert ops.chain_status() == 0
