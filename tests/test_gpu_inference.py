@@ -411,3 +411,45 @@ def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V, B):
             assert float((outs[3][0][:, 0] - outs[2][0][:, 0]).abs().max()) < 2e-5 * float(outs[2][0].abs().max())
     finally:
         ops.set_option(15, 3)
+
+
+def test_decode_every_batch_size_up_to_sixteen_against_the_exchange_kernel():
+    """Every B from 1 to 16 through csrc/decode_b1.hip's plan for it (one team with the beat path folded in; two-row teams, with or
+    without the beat path's workgroups in the launch; four-row teams) against decode_chain.hip's exchange kernel (option key 15 = 0):
+    tick 0 equal to round-off on every row (it depends on no sampled token), whole rows equal wherever the two paths sampled the same
+    tokens, and that is nearly everywhere; twice per size, the second time on a dirtied allocator pool."""
+    from tests.test_gpu_kernels import pack
+    from inpaintnet_amd import layout
+    c = G.CFGS["full"]
+    V = c["V"]
+    cfg = ops.vae_config(V, c["E"], c["H"], c["Z"], c["H"])
+    table, total = ops.vae_param_table(cfg)
+    shapes = layout.vae_param_shapes(V, c["E"], c["H"], c["Z"], c["H"])
+    P = {k: torch.from_numpy(synthetic.det_param(k, s)) for k, s in shapes.items()}
+    params = pack(table, total, P)
+    same_rows = total_rows = 0
+    try:
+        for B in range(1, 17):
+            for it in range(2):
+                z = torch.from_numpy(synthetic.det_normal(f"every/{B}/{it}", (B, c["Z"]))).cuda()
+                if it:
+                    junk = torch.empty(16 << 20, device="cuda").uniform_(-100, 100)
+                    del junk
+                out = {}
+                for mode in (3, 0):
+                    ops.set_option(15, mode)
+                    w, s_, _ = ops.decoder_fwd(cfg, z, None, False, params)
+                    torch.cuda.synchronize()
+                    out[mode] = (w.clone(), s_.clone())
+                assert ops.chain_status() == 0, B
+                (w3, s3), (w0, s0) = out[3], out[0]
+                scale = float(w0.abs().max())
+                assert int(s3.min()) >= 0 and int(s3.max()) < V and s3.shape == s0.shape
+                assert float((w3[:, 0] - w0[:, 0]).abs().max()) < 2e-5 * scale, B
+                same = (s3 == s0).all(dim=-1).reshape(-1)
+                same_rows += int(same.sum()); total_rows += B
+                if bool(same.any()):
+                    assert float((w3[same] - w0[same]).abs().max()) < 2e-5 * scale, B
+    finally:
+        ops.set_option(15, 3)
+    assert same_rows >= 0.9 * total_rows, (same_rows, total_rows)
