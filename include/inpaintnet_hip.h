@@ -363,6 +363,10 @@ int inet_twin_stream(void** stream);
  * leaves parameters and moments untouched (a device-side twin of the counter is read by the kernel), so a failed step
  * can never reach the weights.  reset != 0 clears both (synchronises the device).  -2: the counter could not be allocated. */
 int inet_chain_status(int reset);
+/* Diagnostics: copies the first nbytes (<= 16384) of the library's device-side scratch area to the host (synchronises the device).
+ * Only instrumented builds write there -- csrc/gru_chain2.hip compiled with -DINET_CHAIN2_STAMPS=1 records the wall-clock stamps of
+ * one wave's steps (tools/chain2_anatomy.py) --, a normal build leaves it zero. */
+int inet_debug_read(void* dst, int64_t nbytes);
 
 /* ---- measurement hooks (bench.py roofline line; not part of the reference surface) --------------- */
 /* class 0 = batched MFMA GEMM, 1 = fused GRU/LSTM step forward, 2 = fused GRU/LSTM step backward, 3 = HBM-bound

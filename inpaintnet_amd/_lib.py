@@ -123,6 +123,7 @@ _SIGNATURES = {
     "inet_arnn_generate": (C.c_int, [_I] * 6 + [_P, _P, _L] + [_P] * 12 + [_P, _P, _P, _P, _L, _P]),
     "inet_side_wait": (C.c_int, [_P]),
     "inet_twin_stream": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "inet_debug_read": (C.c_int, [_P, _L]),
     "inet_chain_status": (C.c_int, [_I]),
     "inet_prof_enable": (C.c_int, [_I]),
     "inet_prof_dump": (C.c_int, [C.c_char_p]),

@@ -469,6 +469,13 @@ int inet_chain_status(int reset) {
     return v;
 }
 
+int inet_debug_read(void* dst, int64_t nbytes) {
+    unsigned* d = chain_dev_status();
+    if (!dst || nbytes <= 0 || nbytes > kChainDiagBytes || !d) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    return hipMemcpy(dst, d + kChainDiagWord, (size_t)nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+
 int inet_side_join(void* stream) { return side_join_now((hipStream_t)stream); }
 int inet_side_wait(void* stream) { return side_wait_on((hipStream_t)stream); }
 int inet_twin_stream(void** stream) {

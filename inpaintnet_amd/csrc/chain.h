@@ -206,6 +206,10 @@ unsigned* chain_host_status();
 // process-wide device-memory twin of that counter (null if it could not be allocated): non-zero after any timeout, read by
 // the Adam kernel (pw_adam) so that a failed step leaves the parameters untouched; inet_chain_status(reset) clears both
 unsigned* chain_dev_status();
+// behind the process-wide device status word: a scratch area that instrumented builds (INET_CHAIN2_STAMPS) write wall-clock stamps
+// into -- chain::Status.gdev + kChainDiagWord -- and inet_debug_read() copies to the host
+constexpr int kChainDiagWord = 64;
+constexpr int kChainDiagBytes = 16384;
 int chain_status_reset();
 // host-mapped count of token indices outside [0, V) seen by a module's prologue (decoder.py:36-45 check_index raises
 // ValueError; here the host raises at its next status read); null if it could not be allocated

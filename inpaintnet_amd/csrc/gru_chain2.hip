@@ -32,6 +32,11 @@ namespace {
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 using chain::u32x4;
+#ifndef INET_CHAIN2_STAMPS
+#define INET_CHAIN2_STAMPS 0      // 1: wave 0 of the first workgroup records six wall-clock stamps per step (tools/chain2_anatomy.py)
+#endif
+#define C2_STAMP(i) do { if (INET_CHAIN2_STAMPS && stamping && lane == 0 && step < 32) \
+        reinterpret_cast<unsigned long long*>(status.gdev + kChainDiagWord)[step * 8 + (i)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ void split3(float x, __bf16& a0, __bf16& a1, __bf16& a2) {
     a0 = (__bf16)x;                                  // round to nearest: |x - a0| <= 2^-9 |x|
@@ -298,9 +303,11 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
     long tok[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) tok[r] = idxp[brow[r] * idx_bs + (rev ? T - 1 : 0) * idx_ts];
+    const bool stamping = INET_CHAIN2_STAMPS && group == 0 && member == 0 && w == 0 && status.gdev != nullptr && T >= 12;
     for (int step = 0; step < T; ++step) {
         const int tt = rev ? T - 1 - step : step;
         const int tn = step + 1 < T ? (rev ? tt - 1 : tt + 1) : tt;
+        C2_STAMP(0);
         float pgt[4][3], pgd[4][3], pm[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -317,7 +324,10 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
         for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (step > 0 || has_h0) {
             if ((step > 0 || publish_h0) && !wait_rows(counter, (unsigned)((step + arrivals0) * members), status, lane)) return;
+            C2_STAMP(1);
             contract2<3, S32, NP>(acc, wl, rs, abase, ((step + 1) & 1) * slot_bytes, pb, lane);
+            if (INET_CHAIN2_STAMPS && stamping) asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));   // (the stamp behind the MFMAs)
+            C2_STAMP(2);
         }
         float er[4], ez[4], en[4], eg[4], eh[4], ehp[4];
 #pragma unroll
@@ -336,22 +346,26 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) em_v[r] = has_mask ? eh[r] * pm[r] : eh[r];
         if (!EM) {
+            C2_STAMP(3);
             if (step != T - 1) {                               // nobody reads the last state from the exchange
                 __builtin_amdgcn_wave_barrier();               // (the tile is exchanged between lanes: see the backward kernel)
                 if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
                 __builtin_amdgcn_wave_barrier();
                 arrive_rows(counter, lane);
             }
+            C2_STAMP(4);
         } else {
             // One pass through the wave's transpose tiles: tile 0 = the new state (the exchange's next operand), tile 1 = the
             // masked state (the row pieces of the layer's output).  The exchange stores go first and the arrival right behind
             // them (its vmcnt(0) then only waits for those); the piece outputs follow, re-read from the tiles.
             const bool rows_masked = em_rows && has_mask;
+            C2_STAMP(3);
             if (step != T - 1) {
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 32) publish8(rs, (step & 1) * slot_bytes + pub_off, pb, myxt + (lane & 15) * 16 + 8 * (lane >> 4));
                 arrive_rows(counter, lane);
             }
+            C2_STAMP(4);
             if (em_rows) {                                     // (everything below is behind the hand-off)
                 if (rows_masked) {
 #pragma unroll
@@ -381,6 +395,7 @@ __global__ __launch_bounds__(64 * WV) void gru_chain2_fwd_kernel(GruChainFwd A) 
                 }
             }
         }
+        C2_STAMP(5);
     }
 }
 
