@@ -24,6 +24,10 @@ Prints ONE JSON line on rank 0 (contract in the task brief) carrying
                  committed rocprofv3 PMC pass (profiles/), and the same table for the top kernels;
   cpu_baseline   the oracle's CPU port of the same step on the host cores (bounded sample, best thread count);
   parity_checked one un-timed step at the bench's own batch compared with the oracle (loss, logits, every gradient).
+In front of the line's other fields: `chain_timeouts`, the timed steps one by one (`first_steps_ms` GPU timeline, `first_steps_host_ms`)
+and `gc_in_timed_region`.  Before the W warm-up steps the vae workload runs one full step per branch of the teacher-forcing coin
+(`prime_branches`, `config.priming_steps`; --no-prime skips it): the K timed steps are unchanged, the first pass through a branch --
+one-time host work -- just never falls into a region that starts on an empty queue.
 """
 import argparse
 import collections
