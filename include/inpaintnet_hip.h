@@ -335,7 +335,8 @@ int inet_set_option(int key, int value);
  * key 14 = AnticipationRNN's token pass (inet_arnn_generate; INET_ARNN_GEN): 3 (default) = one persistent launch where the shape
  * allows, its 13 workgroups on every 8th workgroup id (one XCD as dispatched today) and -- once they have FOUND themselves on one XCD
  * (they compare XCC ids at the start of the launch) -- granules as plain stores that stay in that XCD's L2; 2 = the same with
- * agent-scope stores; 1 = on 13 consecutive ids; 0 = four launches per tick.
+ * agent-scope stores; 1 = on 13 consecutive ids; 0 = four launches per tick; 4 = test hook: 3's request on consecutive ids (the
+ * XCC-id check must refuse it).
  * key 15 = the free-running decode of ONE to SIXTEEN measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 3 (default) =
  * one or two measures: ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for
  * the 24 ticks -- two hand-offs per tick; one where a single workgroup kind can hold layer 1, the head and the argmax: one row with

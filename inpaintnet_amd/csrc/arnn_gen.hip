@@ -370,12 +370,13 @@ int g_mode = -1;                                 // 0 = the per-tick launches, 1
                                                  // 2 = on every 8th workgroup of 104: one XCD under the round-robin dispatch observed
                                                  // today (speed only, 4.0 vs 4.2 us per tick; correct under any placement),
                                                  // 3 (default) = 2 + plain granule stores once the workgroups have FOUND themselves on
-                                                 // one XCD (granule.h: 3.6 -> 3.2 us per tick; agent-scope stores otherwise)
+                                                 // one XCD (granule.h: 3.6 -> 3.2 us per tick; agent-scope stores otherwise);
+                                                 // 4 = test hook: 3's request on consecutive workgroup ids (the check must say no)
 int mode() {
     if (g_mode < 0) {
         const char* v = std::getenv("INET_ARNN_GEN");
         g_mode = v ? std::atoi(v) : 3;
-        if (g_mode < 0 || g_mode > 3) g_mode = 3;
+        if (g_mode < 0 || g_mode > 4) g_mode = 3;
     }
     return g_mode;
 }
@@ -383,7 +384,7 @@ constexpr long kExGranules = kExXcc + 16;         // 8-byte granules of the exch
 constexpr long kExFloats = 2 * kExGranules + 64; // ... as floats, + the launch's status word (64 floats behind them)
 }  // namespace
 
-void arnn_gen_set_mode(int m) { g_mode = (m < 0 || m > 3) ? 3 : m; }
+void arnn_gen_set_mode(int m) { g_mode = (m < 0 || m > 4) ? 3 : m; }
 
 bool arnn_token_pass_ok(int H, int U, int V) { return mode() != 0 && chain_enabled() && H == GH && U == GH && V >= 1 && V <= 128; }
 
@@ -408,7 +409,8 @@ int arnn_token_pass(int L, int E, int Hc, int V, const float* emb, const float* 
     const int nb_t0 = (int)(((long)V * G4 + 255) / 256);
     hipLaunchKernelGGL(arnn_gen_prep_kernel, dim3(p.nb_pre + nb_t0), dim3(256), 0, s, p);
     GenArgs a{};
-    a.L = L; a.V = V; a.E = E; a.K0 = E + Hc; a.stride = mode() >= 2 ? 8 : 1; a.near = mode() == 3;
+    a.L = L; a.V = V; a.E = E; a.K0 = E + Hc; a.stride = (mode() == 2 || mode() == 3) ? 8 : 1; a.near = mode() >= 3;   // (4: test hook -- XCD-local stores REQUESTED on
+                                                                                // consecutive ids: the workgroups must find out that they do not share an XCD)
     a.emb = emb; a.W_ih0 = W_ih0; a.W_hh0 = W_hh0; a.W_ih1 = W_ih1; a.b_ih1 = b_ih1; a.W_hh1 = W_hh1; a.b_hh1 = b_hh1;
     a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.pre = pre; a.T0 = T0;
     a.hc_init = hc_init; a.first_tok = first_tok; a.tokens = tokens; a.ex = ex;

@@ -393,7 +393,9 @@ def test_arnn_token_pass_persistent_kernel_equals_the_per_tick_launches(V, L):
     ref = _token_pass(x, 0)
     assert ops.chain_status() == 0
     assert int(ref.min()) >= 0 and int(ref.max()) < V and len(torch.unique(ref)) > 3      # (a sequence worth comparing)
-    for mode in (1, 2, 3):                                        # 3 = the default: one XCD + XCD-local granule stores
+    # 3 = the default: one XCD + XCD-local granule stores; 4 = the same REQUEST on consecutive workgroup ids, where the workgroups
+    # sit on eight XCDs: their XCC-id check has to say no (a plain store is never seen across XCDs: the pass would time out)
+    for mode in (1, 2, 3, 4):
         got = _token_pass(x, mode)
         assert ops.chain_status() == 0
         same = (got == ref)
