@@ -16,7 +16,7 @@ Launching: with --gpus N > 1 and no WORLD_SIZE in the environment this process o
 code; under torch.distributed.run it is one rank.  --gpus must equal the world size RCCL reports, and N may not exceed
 the visible devices: a mismatch is an error, never a silent 1-GPU number.
 
-Prints ONE JSON line on rank 0 (contract in the task brief) carrying
+Prints ONE JSON line (< 4 KB) on rank 0 (contract in the task brief) carrying
   roofline       the kernel with the largest summed time in the step (per-launch HIP-event timing on the launch
                  stream during separate un-timed steps), its algorithmic FLOPs and bytes per launch against the MFMA roof of
                  the pipe it runs on (157.3 TFLOP/s f32-input; kernels on the bf16 pipe through exact three-piece splits:
@@ -24,10 +24,11 @@ Prints ONE JSON line on rank 0 (contract in the task brief) carrying
                  committed rocprofv3 PMC pass (profiles/), and the same table for the top kernels;
   cpu_baseline   the oracle's CPU port of the same step on the host cores (bounded sample, best thread count);
   parity_checked one un-timed step at the bench's own batch compared with the oracle (loss, logits, every gradient).
-In front of the line's other fields: `chain_timeouts`, the timed steps one by one (`first_steps_ms` GPU timeline, `first_steps_host_ms`)
-and `gc_in_timed_region`.  Before the W warm-up steps the vae workload runs one full step per branch of the teacher-forcing coin
-(`prime_branches`, `config.priming_steps`; --no-prime skips it): the K timed steps are unchanged, the first pass through a branch --
-one-time host work -- just never falls into a region that starts on an empty queue.
+plus `chain_timeouts`, `slow_waits` (the library's recorder of waits > ~50 us inside persistent kernels, timed region only), the
+timed steps one by one (`first_steps_ms`) and one scalar per secondary workload.  The line is HARD-LIMITED to 4 KB (compact_line;
+round 5's 20 KB line was dropped by the driver): kernel tables, per-step host times, parity detail and workload prose go to
+bench_detail.json beside this file and to stderr.  --warmup W means W: nothing runs in front of it (round 5 primed both branches of
+the teacher-forcing coin; the one-time host work of a kernel's first launch is now done by inet_preload() at trainer construction).
 """
 import argparse
 import collections
@@ -72,11 +73,18 @@ def launch_ranks(args, argv):
         print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to report a "
               f"{have}-GPU number as a {args.gpus}-GPU result", file=sys.stderr)
         return 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd, env = rank_command(args.gpus, argv)
     return subprocess.call(cmd, env=env)
+
+
+def rank_command(gpus, argv, environ=None):
+    """(command, environment) of the rank launcher: one process per GPU over RCCL, rendezvous on 127.0.0.1 (the container's
+    hostname may not resolve), dmabuf IPC (the host driver has no legacy IPC: RCCL's hipIpcGetMemHandle fails without it)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ if environ is None else environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return cmd, env
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs (un-timed)
@@ -328,27 +336,6 @@ class LatentWorkload:
                 "parallelism": f"dp{world}"}
 
 
-def prime_branches(wl):
-    """One full training step per branch of the teacher-forcing coin, at workload construction, before the warm-up steps.
-    `--warmup 5` leaves it to the coin whether the free-running branch has ever run when the timed region starts (with this
-    file's seed the first free-running step IS the first timed step), and the first pass through a branch does one-time host
-    work: +1.3 ms typically, 11 and 16 ms in two of ~25 fresh-process runs of round 5 (no collection, no hipMalloc: `tools/
-    cold_start.py` shows the allocator's 14 segments all made in step 0) -- on an empty queue that is GPU idle time, 58.8 k instead
-    of 70 k measures/s for a 20-step region.  The `random` stream is put back, so warm-up and timed steps see the coins they saw
-    before.  Reported as `priming_steps`; --no-prime skips it."""
-    dec = wl.model.decoder
-    st = random.getstate()
-    p0 = dec.teacher_forcing_prob
-    try:
-        for p in (1.0, 0.0):                                   # random.random() < 1.0: always teacher-forced; < 0.0: never
-            dec.teacher_forcing_prob = p
-            wl.step()
-    finally:
-        dec.teacher_forcing_prob = p0
-        random.setstate(st)
-    return 2
-
-
 def timed(step, steps, warmup, fence, trace=None):
     """W un-timed steps, a fence, EXACTLY `steps` timed steps, a fence.  trace (a dict): also the first 32 timed steps one by one --
     host time to queue each and the GPU's time between events recorded behind consecutive steps -- and Python's garbage
@@ -476,15 +463,29 @@ def kernel_table(step, nprof=4):
     return table
 
 
-def secondary_table(step, top=8):
+def secondary_table(step, top=8, ms_per_step=None):
     """The per-kernel roofline table of a secondary workload (LatentRNN, AnticipationRNN): the same rows as roofline.kernels,
-    without PMC traffic (the committed PMC passes profile the headline step)."""
+    without PMC traffic (the committed PMC passes profile the headline step).  ms_per_step: the un-profiled step the table must
+    be consistent with -- a table whose kernels sum to more than twice that step is not evidence (BENCH_r05: lstm_chain_bwd read
+    470 us per launch under per-launch events on the driver's box, 110 everywhere else) and is reported as "inconsistent" with
+    what the library's slow-wait recorder saw during the profiled steps."""
+    from inpaintnet_amd import ops
     keep = ("kernel", "launches_per_step", "avg_us", "ms_per_step", "tflops", "mfma_pipe", "peak_tflops", "frac_mfma", "gbps", "frac_hbm")
+    ops.slow_waits(reset=True)
     table = kernel_table(step, nprof=3)
-    return {"step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
-            "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
-            "launches_per_step": round(sum(r["launches_per_step"] for r in table), 1),
-            "top": [{k: r[k] for k in keep if k in r} for r in table[:top]]}
+    slow = ops.slow_waits(reset=True)
+    out = {"step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
+           "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
+           "launches_per_step": round(sum(r["launches_per_step"] for r in table), 1),
+           "slow_waits_while_profiled": slow["count"]}
+    if ms_per_step is not None and out["step_kernel_ms"] > 2.0 * ms_per_step:
+        out["kernels"] = "inconsistent"
+        out["unprofiled_ms_per_step"] = ms_per_step
+        out["slow_wait_entries"] = slow["entries"][:8]
+        out["largest"] = {k: table[0][k] for k in ("kernel", "launches_per_step", "avg_us", "ms_per_step")} if table else None
+        return out
+    out["top"] = [{k: r[k] for k in keep if k in r} for r in table[:top]]
+    return out
 
 
 def piece_products(label):
@@ -921,12 +922,92 @@ def arnn_extra(batch=32, steps=30, warmup=4, tables=True, free_steps=10):
                                            "what": "the trainer's own call (trim=True) over sixteen windows drawn by its sampler: the generation "
                                                    "LSTMs and the head skip the ticks behind the window, which nobody reads (window_end_ticks .. "
                                                    "383; the lines above use ONE batch whose window ends at tick %d and compute all 384 ticks)" % int(data[4])},
-                                       "kernels": secondary_table(step) if tables else None,
+                                       "kernels": secondary_table(step, ms_per_step=1e3 * dt / steps) if tables else None,
                                        "workload": "AnticipationRNN gauss-reg (LSTM 2x2 layers, H=256), teacher-forced "
                                                    "train step, 32 sequences x 384 ticks"}}
 
 
 # ------------------------------------------------------------------------------------------------ main
+LINE_LIMIT = 4096        # bytes: the driver's capture dropped round 5's 20 KB line (BENCH_r05.json: parsed null)
+DETAIL_FILE = os.environ.get("INET_BENCH_DETAIL", os.path.join(REPO, "bench_detail.json"))
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract's keys, the dominant kernel's roofline row, the CPU baseline and one scalar per secondary
+    workload -- hard limit LINE_LIMIT bytes (tests/test_bench_keys.py).  Kernel tables, per-step host times, parity detail and
+    workload prose stay in `out`, which main() writes to DETAIL_FILE and stderr."""
+    ex = out.get("extras") or {}
+    cfg = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "batch_per_gpu", "global_batch", "parallelism", "final_loss") if k in cfg}
+    r = out.get("roofline")
+    line["roofline"] = None if not r else {k: r.get(k) for k in (
+        "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mfma_pipe", "frac_of_f32_input_peak",
+        "algorithmic_mbytes_per_launch", "algorithmic_gflop_per_launch", "avg_launch_us", "launches_per_step", "step_gflop",
+        "step_kernel_ms")}
+    c = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not c else {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    for k in ("parity_checked", "max_rel_err", "kink_violations", "chain_timeouts", "slow_waits"):
+        if k in out:
+            line[k] = out[k]
+    if out.get("first_steps_ms"):
+        line["first_steps_ms"] = out["first_steps_ms"][:20]
+    if _get(out, "gc_in_timed_region", "collections") is not None:
+        line["gc_in_timed_region"] = out["gc_in_timed_region"]["collections"]
+    for k in ("per_rank_units_per_s", "allreduce_ms_per_step", "allreduce_mbytes"):
+        if k in out:
+            line[k] = out[k]
+    if out.get("dp"):
+        line["dp"] = {k: out["dp"].get(k) for k in ("ms_per_step_without_exchange", "exposed_exchange_ms_per_step",
+                                                     "chain_timeouts_per_rank", "skipped_steps_per_rank")}
+    scal = {
+        "latent_ms": _get(ex, "latent_rnn_train", "ms_per_step"),
+        "latent_seq_per_s": _get(ex, "latent_rnn_train", "sequences_per_s"),
+        "latent_default_ms": _get(ex, "latent_rnn_train_default", "ms_per_step"),
+        "latent_ar_ms": _get(ex, "latent_rnn_train_auto_reg", "ms_per_step"),
+        "latent_dp_ms": _get(ex, "latent_rnn_train_dp", "ms_per_step"),
+        "latent_dp_seq_per_s": _get(ex, "latent_rnn_train_dp", "sequences_per_s"),
+        "arnn_tf_ms": _get(ex, "anticipation_rnn_train", "ms_per_step"),
+        "arnn_fr_ms": _get(ex, "anticipation_rnn_train", "ms_per_step_free_running"),
+        "arnn_trimmed_tf_ms": _get(ex, "anticipation_rnn_train", "default_trimmed", "ms_per_step"),
+        "decode_b1_ms": _get(ex, "decoder_eval", "b1", "ms_per_call"),
+        "decode_b16_ms": _get(ex, "decoder_eval", "b16", "ms_per_call"),
+        "decode_b256_ms": _get(ex, "decoder_eval", "b256", "ms_per_call"),
+        "decode_b1_frac_hbm": _get(ex, "decoder_eval", "b1", "frac_hbm_roofline"),
+        "decode_b1_floor_ms": _get(ex, "decoder_eval", "b1", "latency_floor_ms"),
+        "epoch_loop_measures_per_s": _get(ex, "epoch_loop", "measures_per_s"),
+        "vae4096_measures_per_s": _get(ex, "vae_train_4096", "measures_per_s"),
+        "vae4096_ms": _get(ex, "vae_train_4096", "ms_per_step"),
+        "vae_v61_ms": _get(ex, "vae_train_v61", "ms_per_step"),
+        "f32_input_chains_ms": _get(ex, "chain_generations", "f32_input_mfma", "ms_per_step"),
+    }
+    scal = {k: v for k, v in scal.items() if v is not None}
+    if scal:
+        line["extras"] = scal
+    line["detail"] = os.path.basename(DETAIL_FILE)
+    # the limit is hard: optional keys go first, then the config's prose, before a line the driver cannot read is printed
+    for drop in ("first_steps_ms", "extras", "dp", "per_rank_units_per_s"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) >= LINE_LIMIT:
+        line["config"]["workload"] = line["config"].get("workload", "")[:120]
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"].pop("sample", None)
+    text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -937,7 +1018,6 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--no-prime", action="store_true", help="skip the two priming steps (one per coin branch) in front of the warm-up")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -985,9 +1065,7 @@ def main():
     dp.seed_shared(4321)                                       # the teacher-forcing coin is shared by all ranks
     wl = (VaeWorkload if args.workload == "vae" else LatentWorkload)(dev, rank)
     dp.broadcast_params(wl.model.flat)
-    priming_steps = 0
-    if args.workload == "vae" and coin not in ("tf", "fr") and not args.no_prime:
-        priming_steps = prime_branches(wl)
+    ops.slow_waits(reset=True)                                 # the recorder covers this process's steps from here on
 
     def fence():
         torch.cuda.synchronize()
@@ -1018,6 +1096,7 @@ def main():
     except _ops.ChainTimeoutError:
         skipped_steps = len(wl.trainer._lost)
     chain_timeouts = max(_ops.chain_status(reset=True), 0)
+    slow = _ops.slow_waits(reset=True)                         # waits > ~50 us inside persistent kernels during warm-up + timed steps
     health = torch.zeros(2 * world, dtype=torch.float64, device=dev)
     health[2 * rank], health[2 * rank + 1] = float(chain_timeouts), float(skipped_steps)
     if world > 1:
@@ -1076,7 +1155,7 @@ def main():
                 extras["latent_rnn_train"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * 20 / ldt, 1),
                                               "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 20 / ldt, 1),
                                               "ms_per_step": round(1e3 * ldt / 20, 3), **lw.describe(1),
-                                              "kernels": secondary_table(lw.step)}
+                                              "kernels": secondary_table(lw.step, ms_per_step=1e3 * ldt / 20)}
                 del lw
                 ld = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds, encode_all=False)
                 ddt, _ = timed(ld.step, 20, 4, fence)
@@ -1087,7 +1166,7 @@ def main():
                                 "nothing reads their latents (auto_reg=False: never; the reference encodes them in every forward pass and "
                                 "drops the result, latent_rnn.py:133,148-149): 12 instead of 16 frozen-encoder passes per sequence, "
                                 "identical outputs, gradients and weights",
-                    "kernels": secondary_table(ld.step)}
+                    "kernels": secondary_table(ld.step, ms_per_step=1e3 * ddt / 20)}
                 del ld
                 random.seed(99)
                 la = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds, auto_reg=True)
@@ -1096,7 +1175,7 @@ def main():
                                                        "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 20 / adt, 1),
                                                        "ms_per_step": round(1e3 * adt / 20, 3), **la.describe(1),
                                                        # (the mean over the teacher-forcing coin of the four profiled steps)
-                                                       "kernels": secondary_table(la.step)}
+                                                       "kernels": secondary_table(la.step, ms_per_step=1e3 * adt / 20)}
                 del la
                 wl.model.trainable = True                      # (LatentRNN froze the shared VAE)
                 wl.model.train()
@@ -1127,6 +1206,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
             "chain_timeouts": chain_timeouts,                      # inet_chain_status after the timed region: 0 = healthy
+            "slow_waits": slow["count"],                           # the recorder's count over warm-up + timed steps (entries: detail file)
+            "slow_wait_entries": slow["entries"][:16],
             # the timed steps one by one (the first 32): GPU time between events behind consecutive steps, host time to queue each,
             # Python garbage collections inside the region -- a cold-start transient shows up HERE (profiles/r05_cold_start.txt)
             **trace,
@@ -1142,7 +1223,7 @@ def main():
                           "float64, ::test_gemm_bf3_layouts); every other product runs on the f32-input MFMA (v_mfma_f32_*_f32).  "
                           "INET_CHAIN2=0 / INET_GEMM_BF3=0 select the f32-input forms (extras.chain_generations times them).",
             "data": "synthetic",
-            "config": dict(wl.describe(world), final_loss=round(final_loss, 5), priming_steps=priming_steps),
+            "config": dict(wl.describe(world), final_loss=round(final_loss, 5)),
             "roofline": roof,
         }
         if world > 1:
@@ -1161,7 +1242,14 @@ def main():
                 cpu = cpu_baseline(VAE_BATCH_PER_GPU)
         out["cpu_baseline"] = cpu
         out["extras"] = extras or None
-        print(json.dumps(out), flush=True, file=_REAL_STDOUT)   # the ONE line of the contract
+        detail = json.dumps(out)
+        try:
+            with open(DETAIL_FILE, "w") as f:                  # tables, per-step traces, parity detail, workload prose
+                f.write(detail + "\n")
+        except OSError as e:
+            print(f"[bench] could not write {DETAIL_FILE}: {e}", file=sys.stderr)
+        print("[bench detail] " + detail, file=sys.stderr, flush=True)
+        print(compact_line(out), flush=True, file=_REAL_STDOUT)   # the ONE line of the contract (< LINE_LIMIT bytes)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

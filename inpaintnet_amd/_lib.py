@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INET_LIB_PATH") or os.path.join(_HERE, "libinpaintnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["arnn_gen.hip", "decode_b1.hip", "gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip", "gemm_bf3.hip", "gru_step_bf3.hip"]
+SOURCES = ["preload.hip", "arnn_gen.hip", "decode_b1.hip", "gemm.hip", "gru.hip", "pointwise.hip", "seq.hip", "vae.hip", "api.hip", "prof.hip", "side.hip", "lstm.hip", "gru_chain.hip", "decode_chain.hip", "gru_chain2.hip", "gemm_bf3.hip", "gru_step_bf3.hip"]
 
 _lib = None
 
@@ -54,7 +54,9 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd, cwd=CSRC)
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(stale)))) as ex:
         list(ex.map(compile_one, stale))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    # -Bsymbolic-functions: the library's own constructors bind to ITS __hipRegisterFunction (csrc/preload.hip), which files every
+    # kernel handle for inet_preload() and passes the call on to the HIP runtime
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print("[inpaintnet_amd] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
@@ -125,6 +127,9 @@ _SIGNATURES = {
     "inet_twin_stream": (C.c_int, [C.POINTER(C.c_void_p)]),
     "inet_debug_read": (C.c_int, [_P, _L]),
     "inet_chain_status": (C.c_int, [_I]),
+    "inet_slow_waits": (C.c_int, [_P, _I, _I]),
+    "inet_preload": (C.c_int, []),
+    "inet_kernel_count": (C.c_int, []),
     "inet_prof_enable": (C.c_int, [_I]),
     "inet_prof_dump": (C.c_int, [C.c_char_p]),
     "inet_prof_read": (C.c_int, [_I, C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

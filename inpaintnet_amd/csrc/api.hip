@@ -8,6 +8,7 @@
 #include "decode_chain.h"
 #include "gemm_bf3.h"
 #include "gru_step_bf3.h"
+#include "side.h"
 
 namespace {
 
@@ -475,6 +476,22 @@ int inet_debug_read(void* dst, int64_t nbytes) {
     if (hipDeviceSynchronize() != hipSuccess) return -2;
     return hipMemcpy(dst, d + kChainDiagWord, (size_t)nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
+
+int inet_slow_waits(unsigned* dst, int max_entries, int reset) {
+    unsigned* d = chain_dev_status();
+    if (!d || max_entries < 0 || (max_entries > 0 && !dst)) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    unsigned seen = 0;
+    if (hipMemcpy(&seen, d + chain::kRecWord, 4, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    const int have = (int)(seen < (unsigned)chain::kRecEntries ? seen : (unsigned)chain::kRecEntries);
+    const int n = have < max_entries ? have : max_entries;
+    if (n > 0 && hipMemcpy(dst, d + chain::kRecWord + 8, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    if (reset && seen != 0 && hipMemset(d + chain::kRecWord, 0, 4 * (size_t)chain::kRecWords) != hipSuccess) return -2;
+    return (int)(seen > 0x7fffffffu ? 0x7fffffffu : seen);
+}
+
+int inet_preload(void) { return preload_kernels(); }
+int inet_kernel_count(void) { return preload_kernel_count(); }
 
 int inet_side_join(void* stream) { return side_join_now((hipStream_t)stream); }
 int inet_side_wait(void* stream) { return side_wait_on((hipStream_t)stream); }

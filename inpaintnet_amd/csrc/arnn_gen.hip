@@ -20,8 +20,13 @@
 // launches: the input-side product of layer 0 does not depend on the sequence (pre[t] = W_ih0[:, E:] oc_t + b_ih0 + b_hh0 for all
 // ticks and T0[v] = W_ih0[:, :E] emb[v] for every token are made by one small launch in front), and both recurrent products are
 // started the moment their state exists and arrive before they are needed (their granules are REQUESTED a phase early and looked at
-// late: a granule read is a ~0.8 us round trip through the memory side).  Single-buffered granules are safe by dependency: every
-// producer's next write waits for values that its consumers only publish after their workgroup barrier behind the read.
+// late: a granule read is a ~0.8 us round trip through the memory side).  The gate summands hh0 / hh1 have ONE reader per granule
+// (the cell thread of the unit) and are single-buffered: their writer's next write needs the whole next state, which the reader
+// publishes behind its read.  The state vectors h0 / h1 have FIVE readers (the four recurrent-side workgroups and the next stage)
+// while their writer's next write waits only for the summands of its own unit, from ONE of the four: they alternate between two
+// slots by tag parity -- the overwrite of h_t happens at h_{t+2}, which needs hh_{t+2} of the unit, which needs ALL of h_{t+1},
+// whose every unit needed hh_{t+1} from its own recurrent-side workgroup: all four have read h_t by then.  (With one slot a
+// recurrent-side workgroup a tick late found tag t + 2 where it looked for t + 1 and ran into its bound: ADVICE r05.)
 // Measured (tools/arnn_token_pass.py, INET_ARNN_GEN_STAMPS=1; profiles/r05_arnn_token_pass.txt): 4.0 us per tick = 0.74 + 0.89 us
 // for the two hand-offs, 0.4 us per 256 x 256 product, 0.25 each for the head's product and the argmax, the rest barriers and the
 // cells: 384 ticks in 1.5 ms (round 4: 5.5).
@@ -29,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "chain.h"
+#define INET_GRANULE_KID chain::K_ARNN_GEN
 #include "granule.h"
 #include "prof.h"
 #include "lstm.h"
@@ -38,7 +44,7 @@ namespace {
 using namespace granule;
 
 constexpr int GH = 256, G4 = 4 * GH;
-constexpr int kExXcc = 2 * GH + 2 * G4;          // granules behind the exchange: the workgroups' XCC ids (granule::same_xcd)
+constexpr int kExXcc = 4 * GH + 2 * G4;          // granules behind the exchange: the workgroups' XCC ids (granule::same_xcd)
 
 struct GenArgs {
     int L, V, E, K0, stride, near;                   // K0 = E + Hc: row stride of W_ih0; stride: block b works iff b % stride == 0, role b / stride
@@ -47,7 +53,7 @@ struct GenArgs {
     const float* W1; const float* b1; const float* W2; const float* b2;
     const float* pre; const float* T0;           // [L][4H], [V][4H]
     const float* hc_init; const long long* first_tok; long long* tokens;
-    unsigned long long* ex;                      // granules: h0 [256] | h1 [256] | hh0 [1024] | hh1 [1024]
+    unsigned long long* ex;                      // granules: h0 [2][256] | h1 [2][256] | hh0 [1024] | hh1 [1024]  (h: slot = tag & 1)
     unsigned long long* stamps;                  // diagnostics (INET_ARNN_GEN_STAMPS=1): [C, Bi_0][L][8] wall-clock ticks (10 ns), or null
     chain::Status status;
 };
@@ -114,7 +120,7 @@ __device__ __forceinline__ void recurrent_role(const GenArgs& a, int k, const fl
         } else {
             if (tid < GH) {
                 float x;
-                if (!get_1(xin + tid, (unsigned)t, a.status, x)) *bad = 1;
+                if (!get_1(xin + (t & 1) * GH + tid, (unsigned)t, a.status, x)) *bad = 1;
                 xs[t & 1][xs_index(tid)] = x;
             }
             lds_barrier();
@@ -135,9 +141,9 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
     const int role = blockIdx.x / a.stride;
     const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
     unsigned long long* const e_h0 = a.ex;
-    unsigned long long* const e_h1 = a.ex + GH;
-    unsigned long long* const e_hh0 = a.ex + 2 * GH;
-    unsigned long long* const e_hh1 = a.ex + 2 * GH + G4;
+    unsigned long long* const e_h1 = a.ex + 2 * GH;
+    unsigned long long* const e_hh0 = a.ex + 4 * GH;
+    unsigned long long* const e_hh1 = a.ex + 4 * GH + G4;
     volatile int* const bad = &bad_s;
     if (tid == 0) bad_s = 0;
     __syncthreads();
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
             if (k == 0) GEN_STAMP(1, t, 1);
             if (tid < GH) {
                 float x;
-                if (!get_1(e_h0 + tid, (unsigned)t + 1u, a.status, x)) *bad = 1;
+                if (!get_1(e_h0 + ((t + 1) & 1) * GH + tid, (unsigned)t + 1u, a.status, x)) *bad = 1;
                 xs[t & 1][xs_index(tid)] = x;
             }
             if (k == 0) GEN_STAMP(1, t, 2);
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
                 const float ig = sigmoid_f(y[0] + bb[0] + hh[0]), fg = sigmoid_f(y[1] + bb[1] + hh[1]);
                 const float gv = tanh_f(y[2] + bb[2] + hh[2]), og = sigmoid_f(y[3] + bb[3] + hh[3]);
                 c1 = fg * c1 + ig * gv;
-                put(e_h1 + 64 * k + j, og * tanh_f(c1), (unsigned)t + 1u, near);
+                put(e_h1 + ((t + 1) & 1) * GH + 64 * k + j, og * tanh_f(c1), (unsigned)t + 1u, near);
             }
             if (k == 0) GEN_STAMP(1, t, 5);
         }
@@ -234,14 +240,14 @@ __global__ __launch_bounds__(NT) void arnn_token_pass_kernel(GenArgs a) {
                 }
                 const float ig = sigmoid_f(gate[0]), fg = sigmoid_f(gate[1]), gv = tanh_f(gate[2]), og = sigmoid_f(gate[3]);
                 c0 = fg * c0 + ig * gv;
-                put(e_h0 + tid, og * tanh_f(c0), (unsigned)t + 1u, near);
+                put(e_h0 + ((t + 1) & 1) * GH + tid, og * tanh_f(c0), (unsigned)t + 1u, near);
                 GEN_STAMP(0, t, 1);
                 if (more) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) pr[g] = a.pre[(long)(t + 1) * G4 + g * GH + tid];
                 }
                 float x;
-                if (!get_1(e_h1 + tid, (unsigned)t + 1u, a.status, x)) *bad = 1;
+                if (!get_1(e_h1 + ((t + 1) & 1) * GH + tid, (unsigned)t + 1u, a.status, x)) *bad = 1;
                 GEN_STAMP(0, t, 2);
                 xs[0][xs_index(tid)] = x;
             }

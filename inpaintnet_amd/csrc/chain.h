@@ -34,6 +34,22 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kSpinLimit = 400000;          // polls (~1 us each with s_sleep): ~0.4 s before giving up
 enum { ST_OK = 0, ST_TIMEOUT = 1 };
 
+// Layout of the process-wide device status area (side.hip chain_dev_status()), in 32-bit words: word 0 = the status; from kDiagWord:
+// kDiagBytes of scratch for instrumented builds (inet_debug_read); from kRecWord: the SLOW-WAIT RECORDER -- word 0 = waits seen
+// since the last reset, words 8.. = the first kRecEntries of them, 8 words each (Rec below).  Every bounded wait of the library
+// that needed more than kSlowSpins polls (a poll is a ~0.8 us round trip + s_sleep: ~50 us) files one entry when it ENDS -- arrived
+// or given up -- so that a lost hand-off, a workgroup that became resident late, or a launch that shared its CUs with another
+// queue leaves its coordinates behind instead of a bare status word (four events without a trace).
+// inet_slow_waits() copies it out; ChainTimeoutError, bench.py (`slow_waits`) and the test suite's teardown print it.
+constexpr int kDiagWord = 64, kDiagBytes = 16384, kRecWord = kDiagWord + kDiagBytes / 4, kRecEntries = 127, kRecWords = 8 * (1 + kRecEntries);
+constexpr unsigned kSlowSpins = 64;
+#ifndef INET_RECORDER
+#define INET_RECORDER 1                          // 0: build without the recorder (A/B of what it costs the chain kernels)
+#endif
+// kernel ids of the recorder (a template constant of every wait)
+enum { K_GRU_FWD = 1, K_GRU_BWD = 2, K_GRU2_FWD = 3, K_GRU2_BWD = 4, K_LSTM_FWD = 5, K_LSTM_BWD = 6, K_LSTM_PIPE = 7, K_DECODE_CHAIN = 8,
+       K_ARNN_GEN = 9, K_DECODE_B1 = 10 };
+
 // buffer resource over a (wave-uniform) base pointer; 2 GB window, raw addressing
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -72,22 +88,48 @@ __device__ __forceinline__ void arrive(unsigned* counter) {
 #define INET_CHAIN_POLL_SLEEP 1                   // s_sleep units (64 clocks) between two polls of the group counter
 #endif
 struct Status { unsigned* dev; unsigned* host; unsigned* gdev; };
+// one recorder entry, written by ONE lane behind a wait that was slow: {kernel id | XCC id << 8 | gave up << 15 | site << 16,
+// workgroup, expected tag or counter, polls, wall clock (100 MHz) lo, hi, 0, 0}.  The kernel id is a template constant of the
+// wait (a Status field cost the chain kernels ten scalar registers and their first scalar spills: tools/kernel_resources.py).
+template <int KID>
+__device__ __forceinline__ void record_slow(const Status& st, unsigned site, unsigned expected, unsigned spins, bool gave_up) {
+    if (!INET_RECORDER || !st.gdev) return;
+    // (every temporary of this cold path is derived from a VECTOR zero: as uniform values they would sit in scalar registers,
+    //  and the chain kernels have none to spare inside their step loops -- the first build of the recorder added 15-20 scalar
+    //  spills to each of them, tools/kernel_resources.py; vector registers are free at a wait, between two steps)
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    unsigned* rec = st.gdev + kRecWord + z;
+    const unsigned n = __hip_atomic_fetch_add(rec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n >= (unsigned)kRecEntries) return;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned* e = rec + 8 * (1 + n);
+    e[0] = ((unsigned)KID + z) | ((xcc & 0xfu) << 8) | (gave_up ? 0x8000u : 0u) | (site << 16);
+    e[1] = blockIdx.x + z; e[2] = expected + z; e[3] = spins + z;
+    const unsigned long long now = wall_clock64();
+    e[4] = (unsigned)now; e[5] = (unsigned)(now >> 32); e[6] = 0u; e[7] = 0u;
+}
 __device__ __forceinline__ void raise_timeout(Status status) {
     __hip_atomic_store(status.dev, (unsigned)ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (status.gdev) __hip_atomic_store(status.gdev, (unsigned)ST_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (status.host) __hip_atomic_fetch_add(status.host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+template <int KID>
 __device__ __forceinline__ bool wait_group(unsigned* counter, unsigned target, Status status, unsigned* flag) {
     if (threadIdx.x == 0) {
         unsigned ok = 1, spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (++spins > kSpinLimit ||
                 ((spins & 63) == 0 && __hip_atomic_load(status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ST_OK)) {
-                raise_timeout(status);
                 ok = 0;
                 break;
             }
             __builtin_amdgcn_s_sleep(INET_CHAIN_POLL_SLEEP);
+        }
+        if (spins >= kSlowSpins) {                              // (a wait that gave up has polled at least kSlowSpins times)
+            if (!ok) raise_timeout(status);
+            record_slow<KID>(status, 0u, target, spins, ok == 0);
         }
         *flag = ok;
     }
@@ -207,9 +249,10 @@ unsigned* chain_host_status();
 // the Adam kernel (pw_adam) so that a failed step leaves the parameters untouched; inet_chain_status(reset) clears both
 unsigned* chain_dev_status();
 // behind the process-wide device status word: a scratch area that instrumented builds (INET_CHAIN2_STAMPS) write wall-clock stamps
-// into -- chain::Status.gdev + kChainDiagWord -- and inet_debug_read() copies to the host
-constexpr int kChainDiagWord = 64;
-constexpr int kChainDiagBytes = 16384;
+// into -- chain::Status.gdev + kChainDiagWord -- and inet_debug_read() copies to the host; behind it the slow-wait recorder (chain::kRecWord)
+constexpr int kChainDiagWord = chain::kDiagWord;
+constexpr int kChainDiagBytes = chain::kDiagBytes;
+constexpr size_t kChainStatusAreaBytes = 4 * (size_t)(chain::kRecWord + chain::kRecWords);
 int chain_status_reset();
 // host-mapped count of token indices outside [0, V) seen by a module's prologue (decoder.py:36-45 check_index raises
 // ValueError; here the host raises at its next status read); null if it could not be allocated

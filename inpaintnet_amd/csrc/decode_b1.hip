@@ -57,6 +57,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "chain.h"
+#define INET_GRANULE_KID chain::K_DECODE_B1
 #include "granule.h"
 #include "prof.h"
 #include "decode_chain.h"
@@ -71,8 +72,18 @@ constexpr int R_C = 0, R_TA = 1, R_TBI = R_TA + NU, R_TBH = R_TBI + NU, kTickRol
 constexpr int R_Z2B = kTickRoles, R_BA = R_Z2B + 4, R_BBI = R_BA + NU, R_BBH = R_BBI + NU, R_PH = R_BBH + NU, R_PI = R_PH + 8,
               R_CG = R_PI + 4, kFusedRoles = R_CG + NU;
 // granule map of ONE row (8-byte units); row r lives at r * G_END
-constexpr int G_H0 = 0, G_H1 = DH, G_GH0 = 2 * DH, G_GH1 = 2 * DH + D3, G_H1X = 2 * DH + 2 * D3, G_GH0X = G_H1X + DH, G_TICK_END = G_GH0X + D3;
-// (G_H1X / G_GH0X: the second slots of h1 and gh0 in the merged build, which alternates between two slots by the tag's parity)
+constexpr int G_H0 = 0, G_H1 = DH, G_GH0 = 2 * DH, G_GH1 = 2 * DH + D3, G_H1X = 2 * DH + 2 * D3, G_GH0X = G_H1X + DH, G_H0X = G_GH0X + D3,
+              G_TICK_END = G_H0X + DH;
+// (G_H0X / G_H1X: the second slots of h0 and h1 -- every state vector alternates between two slots by its tag's parity, see "Two
+//  slots" below; G_GH0X: the second slot of gh0 in the merged build, where gh0 has 16 readers as well)
+// Two slots.  A state vector (h0_t, h1_t) is read by SEVENTEEN workgroups -- the 16 recurrent-side ones of its layer and the next
+// stage -- while its writer's next write waits only for what ITS units need (gh of its own units, from ONE of those 16): with one
+// slot a recurrent-side workgroup that is a tick late would find tag t + 2 where it looks for t + 1, exact-match tags never
+// match again and the wait runs into its bound (a liveness margin of one tick, ~3 us).  With two slots by tag parity
+// the overwrite of h_t happens at h_{t+2}, whose writer needs gh_{t+2} of its units, which needs ALL of h_{t+1}, whose every unit
+// needed gh_{t+1} from its own recurrent-side workgroup -- so all 16 have read h_t by then, transitively.
+__device__ __forceinline__ int slot_h0(unsigned tag) { return (tag & 1) ? G_H0X : G_H0; }
+__device__ __forceinline__ int slot_h1(unsigned tag) { return (tag & 1) ? G_H1X : G_H1; }
 constexpr int G_HB0 = G_TICK_END, G_H0B = G_HB0 + 2 * DH, G_H1B = G_H0B + 4 * DH, G_GH1B = G_H1B + 4 * DH, G_C = G_GH1B + 4 * D3,
               G_HT0 = G_C + 4 * DH, G_CGI = G_HT0 + 4 * 2 * DH, G_END = G_CGI + 4 * D3;
 static_assert(2 * G_END == kDecodeB1WordsPerRow, "the workspace's granule area holds the map");
@@ -158,11 +169,14 @@ __device__ __forceinline__ bool get_2d(const unsigned long long* g, int rs, int 
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int i = 0; i < NG; ++i) v[r][i] = __uint_as_float((unsigned)w[r][i]);
+            if (spins > chain::kSlowSpins) note_slow(st, tag, spins, false);
             return true;
         }
         if (++spins > kSpin ||
-            ((spins & 1023) == 0 && __hip_atomic_load(st.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK))
+            ((spins & 1023) == 0 && __hip_atomic_load(st.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK)) {
+            note_slow(st, tag, spins, true);
             return false;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -453,10 +467,10 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 for (int r = 0; r < NB; ++r)
                     h0[r] = gru_cell(cg[r][0] + tb[r][0], cg[r][1] + tb[r][1], cg[r][2] + tb[r][2], gh[r][0], gh[r][1], gh[r][2], h0[r]);
 #pragma unroll
-                for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + G_H0 + u, h0[r], (unsigned)t + 1u);
+                for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + slot_h0((unsigned)t + 1u) + u, h0[r], (unsigned)t + 1u);
             }
             B1_STAMP(0, t, 1);
-            c.gather(G_H1, (unsigned)t + 1u, 0);
+            c.gather(slot_h1((unsigned)t + 1u), (unsigned)t + 1u, 0);
             B1_STAMP(0, t, 2);
             lds_barrier();
             if (*bad) break;
@@ -525,15 +539,15 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             B1_STAMP(0, t, 6);
         }
     } else if (role < R_TBI) {
-        tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0, MG ? G_GH0X : G_GH0);
+        tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0);
     } else if (role < R_TBH && MG) {
         // ---- CB_k (merged build): C's work REPLICATED in every TBi_k.  Layer 0's cell needs no product (its summands arrive), the
         // head is V x 512: cheap enough to compute 16 times over, and then h0_t never leaves the workgroup and the token never
         // travels -- of the two hand-offs of a tick (C -> TBi -> C) only the all-gather of h1_t among the 16 workgroups is left.
         // All of them run the same instructions on the same values, so they agree on every token bit for bit.  CB_0 alone
-        // publishes h0_t (for TA) and writes the outputs.  h1 and gh0 alternate between two granule slots by tag parity: a CB
+        // publishes h0_t (for TA) and writes the outputs.  h0, h1 and gh0 alternate between two granule slots by tag parity: a CB
         // workgroup does not wait for its 15 peers to have READ a value before it writes the next one (a peer's read of h1_t is
-        // ordered before its own h1_t+1, which the writer of h1_t+2 has to have seen: two slots are enough; likewise gh0).
+        // ordered before its own h1_t+1, which the writer of h1_t+2 has to have seen: two slots are enough; likewise gh0, h0).
         const int k = role - R_TBI, p = tid >> 4, s = tid & 15, uc = UW * k + p;
         const int row[3] = {uc, DH + uc, 2 * DH + uc};
         float w[3][32];
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
         for (int t = 0; t < a.T; ++t) {
             const bool more = t + 1 < a.T;
             const unsigned tag = (unsigned)t + 1u;
-            const int g_h1 = (tag & 1) ? G_H1X : G_H1;
+            const int g_h1 = slot_h1(tag);
             float gh1[NB][3];
             unsigned long long hw1[NB][3];
             if (t % a.G == 0) {
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 }
                 if (out) {
 #pragma unroll
-                    for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + G_H0 + u, h0[r], tag);
+                    for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + slot_h0(tag) + u, h0[r], tag);
                 }
             }
             if (out) B1_STAMP(0, t, 1);
@@ -720,7 +734,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 }
             }
             if (k == 0) B1_STAMP(1, t, 1);
-            c.gather(G_H0, (unsigned)t + 1u, t & 1);
+            c.gather(slot_h0((unsigned)t + 1u), (unsigned)t + 1u, t & 1);
             if (k == 0) B1_STAMP(1, t, 2);
             lds_barrier();
             if (*bad) break;
@@ -734,12 +748,12 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 for (int r = 0; r < NB; ++r)
                     h1[r] = gru_cell(y[r][0] + bi[0], y[r][1] + bi[1], y[r][2] + bi[2], gh[r][0], gh[r][1], gh[r][2], h1[r]);
 #pragma unroll
-                for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + G_H1 + u, h1[r], (unsigned)t + 1u);
+                for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + slot_h1((unsigned)t + 1u) + u, h1[r], (unsigned)t + 1u);
             }
             if (k == 0) B1_STAMP(1, t, 4);
         }
     } else if (role < kTickRoles) {
-        tick_recurrent_role<NB>(c, role - R_TBH, a.W_hh1, a.b_hh1, 1, G_H1, G_GH1, MG ? G_H1X : G_H1, G_GH1);
+        tick_recurrent_role<NB>(c, role - R_TBH, a.W_hh1, a.b_hh1, 1, G_H1, G_GH1, G_H1X, G_GH1);
     } else if (FUSED) {
         // (one team: the beat path serves the team's NB rows; several teams: all NBB rows of the call, from the call's first granule area)
         const Ctx<NBB> cb{a, a.ex, xs, bad, tid, 0, min(NBB, a.B)};

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
                 hp1[p] = P.ht0[((long)beat * Bs + brow[p]) * 2 * H + H + jc];
             }
         }
-        if (NV == 0 && tick > 0 && !chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;   // tokens of tick-1
+        if (NV == 0 && tick > 0 && !chain::wait_group<chain::K_DECODE_CHAIN>(counter, phase * members, status, &flag[phase & 1])) return;   // tokens of tick-1
         long tok[MS];
 #pragma unroll
         for (int p = 0; p < MS; ++p) tok[p] = tick == 0 ? V : (NV > 0 ? own_tok : token_of(tick - 1, p));
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
                 else contract_b<MS, 3, SQ>(acc, sh, gb, r_hx1, ((tick + 1) & 1) * pkh * 4, rb0, rb_last, S, w * SQ, lane);
             }
         }
-        if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;               // h0 of this tick
+        if (!chain::wait_group<chain::K_DECODE_CHAIN>(counter, phase * members, status, &flag[phase & 1])) return;               // h0 of this tick
         {
             const int sx[3] = {0, 1, 2};
             auto gb = [&](int g, int si) { return *reinterpret_cast<const f32x4*>(wih + ((g * S + w * SQ + si) * 64 + lane) * 4); };
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
         // member that skipped this wait could arrive a third time while a slow one has not arrived twice -- the count
         // then reaches 2 x members too early and a logits tile contracts a k-slice that is not published yet (seen as
         // one wrong 16 x 16 logits tile at tick 0 in ~5 % of the B = 256 calls before this wait was made unconditional).
-        if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;               // h1 of this tick
+        if (!chain::wait_group<chain::K_DECODE_CHAIN>(counter, phase * members, status, &flag[phase & 1])) return;               // h1 of this tick
         if constexpr (NV > 0) {
             f32x4 la[1][4];
 #pragma unroll
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(DecodeChainArgs P) {
     }
     // the last tick's tokens
     if (NV == 0 && member == 0) {
-        if (!chain::wait_group(counter, phase * members, status, &flag[phase & 1])) return;
+        if (!chain::wait_group<chain::K_DECODE_CHAIN>(counter, phase * members, status, &flag[phase & 1])) return;
         if ((t & 15) == 0) {
 #pragma unroll
             for (int p = 0; p < MS; ++p)

@@ -10,7 +10,7 @@
 
 namespace granule {
 
-constexpr unsigned kSpin = 4000000;              // polls per wait before a workgroup gives up (~0.5 s)
+constexpr unsigned kSpin = 500000;               // polls per wait before a workgroup gives up: a poll is a ~0.8-1 us round trip + s_sleep, ~0.5 s
 
 __device__ __forceinline__ void put(unsigned long long* g, float v, unsigned tag) {
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -31,6 +31,12 @@ __device__ __forceinline__ void put(unsigned long long* g, float v, unsigned tag
 __device__ __forceinline__ unsigned long long peek(const unsigned long long* g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the slow-wait recorder (chain.h) for granule waits: every lane polls for itself, the first slow lane of the wave files the entry
+// (INET_GRANULE_KID: the including kernel file's id for the recorder, chain.h)
+__device__ __forceinline__ void note_slow(const chain::Status& st, unsigned tag, unsigned spins, bool gave_up) {
+    const unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) chain::record_slow<INET_GRANULE_KID>(st, 1u, tag, spins, gave_up);
+}
 // N granules, `stride` apart, of one tick: ALL of them are requested before the first is looked at (a granule read is a round trip
 // through the memory side, ~1 us: four of them one after the other were half of the first build's tick).  `w` may hold an earlier
 // request of the same granules (first = false skips the first request).  false: gave up (bounded spin, or the launch was aborted).
@@ -50,11 +56,14 @@ __device__ __forceinline__ bool get_n(const unsigned long long* g, int stride, u
         if (all) {
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = __uint_as_float((unsigned)w[i]);
+            if (spins > chain::kSlowSpins) note_slow(st, tag, spins, false);
             return true;
         }
         if (++spins > kSpin ||
-            ((spins & 1023) == 0 && __hip_atomic_load(st.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK))
+            ((spins & 1023) == 0 && __hip_atomic_load(st.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK)) {
+            note_slow(st, tag, spins, true);
             return false;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
 }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
         }
         const bool recur = step > 0 || has_h0;
         if ((step > 0 || publish_h0) &&
-            !chain::wait_group(counter, (unsigned)((step + arrivals0) * members), status, &flag[step & 1])) return;
+            !chain::wait_group<chain::K_GRU_FWD>(counter, (unsigned)((step + arrivals0) * members), status, &flag[step & 1])) return;
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
 #pragma unroll
         for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
         if (step != T - 1) {
-            if (!chain::wait_group(counter, (unsigned)((T - 1 - step) * members), status, &flag[step & 1])) return;
+            if (!chain::wait_group<chain::K_GRU_BWD>(counter, (unsigned)((T - 1 - step) * members), status, &flag[step & 1])) return;
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -177,15 +177,20 @@ __device__ __forceinline__ void contract2(f32x4 (&acc)[NG], const unsigned char*
 // bounded poll of one row block's counter by a whole wave (all lanes read the same word: one request)
 __device__ __forceinline__ bool wait_rows(unsigned* counter, unsigned target, chain::Status status, int lane) {
     unsigned spins = 0;
+    bool ok = true;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         if (++spins > chain::kSpinLimit ||
             ((spins & 63) == 0 && __hip_atomic_load(status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK)) {
-            if (lane == 0) chain::raise_timeout(status);
-            return false;
+            ok = false;
+            break;
         }
         __builtin_amdgcn_s_sleep(INET_CHAIN_POLL_SLEEP);
     }
-    return true;
+    if (spins >= chain::kSlowSpins && lane == 0) {              // (a wait that gave up has polled at least kSlowSpins times)
+        if (!ok) chain::raise_timeout(status);
+        chain::record_slow<chain::K_GRU2_FWD>(status, 2u, target, spins, !ok);
+    }
+    return ok;
 }
 
 __device__ __forceinline__ void arrive_rows(unsigned* counter, int lane) {

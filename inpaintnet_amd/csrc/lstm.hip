@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
 #pragma unroll
             for (int a = 0; a < 4; ++a) pg[p][a] = P.gi[((long)tt * B + b) * 4 * H + a * H + jc];
         }
-        if (step > 0 && !chain::wait_group(P.counters + group * kCounterStride, (unsigned)(step * P.members), P.status, &flag[step & 1])) return;
+        if (step > 0 && !chain::wait_group<chain::K_LSTM_FWD>(P.counters + group * kCounterStride, (unsigned)(step * P.members), P.status, &flag[step & 1])) return;
         f32x4 acc[MS][4];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -371,10 +371,13 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_tag_kernel(LstmChainFwdArg
                     const chain::u32x4 bits = __builtin_bit_cast(chain::u32x4, A[ms][si]);
                     ok = ok && bits[0] != 0xffffffffu && bits[1] != 0xffffffffu && bits[2] != 0xffffffffu && bits[3] != 0xffffffffu;
                 }
-            if (__all(ok)) break;
+            if (__all(ok)) {
+                if (spins > chain::kSlowSpins && lane == 0) chain::record_slow<chain::K_LSTM_FWD>(P.status, 3u, (unsigned)step, spins, false);
+                break;
+            }
             if (spins > chain::kSpinLimit ||
                 ((spins & 63) == 63 && __hip_atomic_load(P.status.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK)) {
-                if (lane == 0) chain::raise_timeout(P.status);
+                if (lane == 0) { chain::raise_timeout(P.status); chain::record_slow<chain::K_LSTM_FWD>(P.status, 3u, (unsigned)step, spins, true); }
                 break;                             // carry on with what is there: the host reports the launch as failed
             }
             __builtin_amdgcn_s_sleep(1);
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(LstmChainBwdArgs P)
 #pragma unroll
         for (int p = 0; p < MS; ++p) v[p][0] = 0.f;
         if (step != T - 1) {
-            if (!chain::wait_group(P.counters + group * kCounterStride, (unsigned)((T - 1 - step) * P.members), P.status, &flag[step & 1])) return;
+            if (!chain::wait_group<chain::K_LSTM_BWD>(P.counters + group * kCounterStride, (unsigned)((T - 1 - step) * P.members), P.status, &flag[step & 1])) return;
             f32x4 acc[MS][4];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -31,3 +31,7 @@ int stream_wait(hipStream_t waiter, hipStream_t on);
 // A non-atomic accumulation into `dest` is about to be queued on side stream `s`: if another side stream has queued one into
 // the same tensor since the last join, `s` first waits for that stream (two applications of one module in a step).
 int side_order_dest(const void* dest, hipStream_t s);
+// csrc/preload.hip: first-touch of every kernel of the library on the current device (code objects + function objects, without a
+// launch); idempotent per device; returns the number of kernels touched, -2 without a device
+int preload_kernels();
+int preload_kernel_count();

@@ -195,8 +195,9 @@ unsigned* chain_dev_status() {
     if (!tried) {
         tried = true;
         void* q = nullptr;
-        // (word 0: the status; from kChainDiagWord on: kChainDiagBytes of scratch for instrumented builds, inet_debug_read)
-        const size_t n = 4 * kChainDiagWord + kChainDiagBytes;
+        // (word 0: the status; from kChainDiagWord on: kChainDiagBytes of scratch for instrumented builds, inet_debug_read; behind it
+        //  the slow-wait recorder, chain::kRecWord)
+        const size_t n = kChainStatusAreaBytes;
         if (hipMalloc(&q, n) == hipSuccess && hipMemset(q, 0, n) == hipSuccess) p = static_cast<unsigned*>(q);
     }
     return p;

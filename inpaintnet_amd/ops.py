@@ -609,6 +609,51 @@ class ChainTimeoutError(RuntimeError):
     """A persistent (chain) kernel gave up waiting for its group: results computed since are not valid."""
 
 
+_KERNEL_NAMES = {1: "gru_chain_fwd", 2: "gru_chain_bwd", 3: "gru_chain2_fwd", 4: "gru_chain2_bwd", 5: "lstm_chain_fwd", 6: "lstm_chain_bwd",
+                 7: "lstm_pipeline", 8: "decode_chain", 9: "arnn_token_pass", 10: "decode_b1"}
+_SITE_NAMES = {0: "group counter", 1: "granule", 2: "row-block counter", 3: "tagged fragments"}
+
+
+def slow_waits(reset=False, max_entries=127):
+    """The library's slow-wait recorder (include/inpaintnet_hip.h inet_slow_waits): every bounded wait inside a persistent kernel that
+    needed more than ~50 us files one entry when it ends.  Returns {"count": waits since the last reset, "entries": the first ones
+    kept, decoded}.  Synchronises the device.  A slow wait is not an error; it is what an unexplained timeout or a slow launch leaves
+    behind: which kernel, which workgroup on which XCD, what it waited for and for how long."""
+    import numpy as np
+    buf = np.zeros((max(int(max_entries), 1), 8), dtype=np.uint32)
+    n = int(_lib.lib().inet_slow_waits(C.c_void_p(buf.ctypes.data), int(max_entries), int(bool(reset))))
+    if n < 0:
+        return {"count": n, "entries": []}
+    out = []
+    for e in buf[:min(n, int(max_entries), 127)]:
+        w0 = int(e[0])
+        out.append({"kernel": _KERNEL_NAMES.get(w0 & 0xff, str(w0 & 0xff)), "xcc": (w0 >> 8) & 0xf, "gave_up": bool(w0 & 0x8000),
+                    "site": _SITE_NAMES.get(w0 >> 16, str(w0 >> 16)), "workgroup": int(e[1]), "expected": int(e[2]), "polls": int(e[3]),
+                    "clock_10ns": int(e[4]) | (int(e[5]) << 32)})
+    return {"count": n, "entries": out}
+
+
+def slow_waits_summary(reset=False, top=6):
+    """One line for error messages and logs: the count and the longest few waits of the recorder."""
+    r = slow_waits(reset=reset)
+    if r["count"] <= 0:
+        return f"no slow waits recorded ({r['count']})"
+    es = sorted(r["entries"], key=lambda e: -e["polls"])[:top]
+    return f"{r['count']} slow waits; longest: " + "; ".join(
+        f"{e['kernel']} wg {e['workgroup']} xcc {e['xcc']} {e['site']} expected {e['expected']} after {e['polls']} polls"
+        + (" GAVE UP" if e["gave_up"] else "") for e in es)
+
+
+def preload():
+    """First-touch of every kernel of the library on the current device (csrc/preload.hip): code objects and function objects the HIP
+    runtime would otherwise build on the launch path of each kernel's first launch.  Idempotent per device; the trainers and the
+    models call it at construction so that no step pays a first launch.  Returns the number of kernels touched (0: done before)."""
+    n = int(_lib.lib().inet_preload())
+    if n < 0:
+        raise _lib.InetError("inet_preload: no HIP device, or a kernel of the library could not be loaded on it")
+    return n
+
+
 def check_chains(what=""):
     """Raise if any chain-kernel workgroup has timed out (reads the host-mapped counter: no synchronisation, ~1 us).
     The inference wrappers call it after their device->host reads (Trainer.step() reads step reports instead: check_steps).
@@ -618,5 +663,5 @@ def check_chains(what=""):
         raise ChainTimeoutError(f"{n} chain-kernel workgroups gave up waiting for their group ({what or 'inet_chain_status'}): "
                                 "the results are not valid.  All workgroups of such a launch must be resident at once -- "
                                 "is the GPU shared, partitioned or CU-masked?  INET_CHAIN=0 (or ops.set_option(4, 0)) "
-                                "selects the per-step kernels.")
+                                f"selects the per-step kernels.  Recorder: {slow_waits_summary()}")
     check_tokens(what)

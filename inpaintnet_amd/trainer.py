@@ -16,6 +16,7 @@ Plotting / tensorboard plumbing of the reference is out of scope.
 """
 import gc
 import os
+import sys
 import time
 from abc import ABC, abstractmethod
 from collections import deque
@@ -41,12 +42,21 @@ def settle_python_heap():
     36-40 ms on the GPU box: the launch queue drains, the GPU idles for ten steps' worth of time, and a 20-step epoch (a
     validation pass, the driver's `bench.py --steps 20 --warmup 5`) measures 1.7x the steady state -- the whole of round 4's
     "cold-start transient" (6.31 vs 3.65 ms per step).  With the old heap frozen a full collection only looks at what was
-    created since: < 1 ms.  INET_GC_FREEZE=0 leaves the collector alone."""
-    if os.environ.get("INET_GC_FREEZE", "1") == "0":
+    created since: < 1 ms.
+
+    A process-global side effect (INTEGRATION.md section 1 states it): objects alive at the FIRST trainer's construction are never
+    examined by the cyclic collector again (reference counting still frees them).  Once per process -- later trainers do not
+    freeze what the application has built since; INET_GC_FREEZE=0 leaves the collector alone altogether."""
+    global _heap_settled
+    if _heap_settled or os.environ.get("INET_GC_FREEZE", "1") == "0":
         return False
     gc.collect()
     gc.freeze()
+    _heap_settled = True
     return True
+
+
+_heap_settled = False
 
 
 class _CrossEntropyFn(torch.autograd.Function):
@@ -163,6 +173,10 @@ class Trainer(ABC):
         # in the middle of the first steps (settle_python_heap)
         settle_python_heap()
         if model.grad.is_cuda:                       # the report ring and its events exist before the first step, not in it
+            # ... and so does every kernel of the library: the HIP runtime loads code objects and builds function objects on the
+            # launch path of a kernel's FIRST launch, and which kernels a step meets first depends on its branch (the first
+            # free-running step of a process paid 1.3 ms of host time for it, 11-16 ms now and then: csrc/preload.hip)
+            ops.preload()
             self._report_slot(0)
             for e in self._report_events:
                 e.record()
@@ -198,7 +212,13 @@ class Trainer(ABC):
                     return
         finally:
             if self._inflight:                       # (every exit path: nothing a late report holds may go unread)
-                self.finish()
+                if sys.exc_info()[0] is None:
+                    self.finish()
+                else:                                # an exception is on its way out already: do not mask it (as __exit__)
+                    try:
+                        self.finish()
+                    except Exception:
+                        pass
 
     # ---- utils/trainer.py:126-163 ---------------------------------------------------
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
@@ -404,7 +424,7 @@ class Trainer(ABC):
                 f"optimizer step(s) {self._lost} skipped: a chain kernel gave up waiting for its group (on this or another "
                 "rank), the gradients of those steps are not valid and the weights were left alone.  All workgroups of such a "
                 "launch must be resident at once -- is the GPU shared, partitioned or CU-masked?  INET_CHAIN=0 (or "
-                "ops.set_option(4, 0)) selects the per-step kernels.")
+                f"ops.set_option(4, 0)) selects the per-step kernels.  Recorder: {ops.slow_waits_summary()}")
         if nonfinite:
             raise ValueError(f"{type(self.model).__name__} has become nan (a parameter left the finite range in an optimizer step)")
         if badtok:

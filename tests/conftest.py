@@ -12,6 +12,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "expects_chain_timeout: the test provokes a persistent-kernel timeout on purpose")
 
 
 @pytest.fixture(scope="session")
@@ -84,5 +85,9 @@ def _clean_chain_status(request):
         from inpaintnet_amd import ops
         left = ops.chain_status()
         if left:
-            print(f"\n[conftest] chain status {left} left behind by {request.node.nodeid}")
             ops.chain_status(reset=True)
+            if request.node.get_closest_marker("expects_chain_timeout") is None:
+                # the fallbacks recompute correct results behind a timeout, so a test that does not look at the word itself would
+                # pass over a lost hand-off: the culprit fails HERE, with what the library's recorder saw (ops.slow_waits)
+                seen = ops.slow_waits(reset=True) if hasattr(ops, "slow_waits") else None
+                pytest.fail(f"chain status {left} left behind by {request.node.nodeid}; recorder: {seen}", pytrace=False)

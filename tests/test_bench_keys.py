@@ -82,3 +82,80 @@ def test_stale_traffic_file_is_refused(bench):
     table2 = [{"kernel": lab_b}]
     assert bench.attach_traffic(table2, {"kernels": doc["kernels"]}) == [] and table2[0]["traffic_mbytes_per_launch"] == 474.0
     assert bench.piece_products("gru_step_bf3 p9 np2 B2048 H512 sv") == 9
+
+
+# ------------------------------------------------------------------------------------------------ the ONE stdout line
+def _canned():
+    """A full result as main() assembles it: round 5's 20 KB line, the one the driver could not parse (BENCH_r05.json)."""
+    import json
+    return json.load(open(os.path.join(ROOT, "profiles", "r05_zz_bench_driver_command.json")))
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_stdout_line_is_small_and_complete(bench):
+    import json
+    full = _canned()
+    assert len(json.dumps(full)) > 16384                     # the canned result really is the one that was dropped
+    text = bench.compact_line(full)
+    assert "\n" not in text and len(text) < bench.LINE_LIMIT == 4096
+    line = json.loads(text)
+    for k in CONTRACT_KEYS:
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    assert line["config"]["workload"].startswith("MeasureVAE training") and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert line["roofline"][k] == full["roofline"][k], k
+    assert line["roofline"]["frac"] == pytest.approx(line["roofline"]["achieved"] / line["roofline"]["peak"], rel=1e-3)
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert line["cpu_baseline"][k] == full["cpu_baseline"][k], k
+    assert line["parity_checked"] is True and line["chain_timeouts"] == 0
+    for k in ("latent_ms", "latent_ar_ms", "arnn_tf_ms", "arnn_fr_ms", "decode_b1_ms", "decode_b16_ms", "vae4096_measures_per_s"):
+        assert isinstance(line["extras"][k], float), k
+    assert all(not isinstance(v, (dict, list)) for v in line["extras"].values())      # one scalar per extra, no tables
+
+
+def test_stdout_line_stays_under_the_limit_whatever_the_extras_hold(bench):
+    """The limit is hard: a result with absurdly long fields still prints a parseable line with every contract key."""
+    import json
+    full = _canned()
+    full["config"]["workload"] = "w" * 6000
+    full["cpu_baseline"]["sample"] = "s" * 6000
+    full["first_steps_ms"] = [3.5] * 32
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    for k in CONTRACT_KEYS:
+        assert k in line, k
+    assert line["value"] == full["value"]
+
+
+def test_multi_gpu_line_and_launcher(bench):
+    """--gpus 8: the launcher's command and environment, and rank 0's line with the data-parallel fields, under the limit."""
+    import json
+    import sys
+    cmd, env = bench.rank_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], environ={"PATH": "/usr/bin"})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7] == os.path.join(ROOT, "bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/usr/bin"
+    assert bench.rank_command(2, [], environ={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})[1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+    full = _canned()
+    full.update(n_gpus=8, value=8 * full["value"], cpu_baseline=None,
+                per_rank_units_per_s=[71305.1] * 8, allreduce_ms_per_step=0.4321, allreduce_mbytes=70.7,
+                dp={"ranges": [{"kind": "bucket", "mbytes": 10.0}] * 7, "ms_per_step_without_exchange": 3.6,
+                    "exposed_exchange_ms_per_step": 0.2, "chain_timeouts_per_rank": [0] * 8, "skipped_steps_per_rank": [0] * 8,
+                    "side_streams_in_rotation": 1})
+    full["config"].update(global_batch=2048, parallelism="dp8")
+    full["extras"] = {"latent_rnn_train_dp": {"sequences_per_s": 100000.0, "measures_per_s": 1.6e6, "ms_per_step": 10.2,
+                                              "allreduce_ms": 1.0, "arena_mbytes": 159.6, "workload": "x" * 300}}
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak"
+    assert len(line["per_rank_units_per_s"]) == 8 and line["allreduce_ms_per_step"] == 0.4321 and line["allreduce_mbytes"] == 70.7
+    assert line["dp"]["exposed_exchange_ms_per_step"] == 0.2 and line["extras"]["latent_dp_ms"] == 10.2
+    assert line["cpu_baseline"] is None and line["vs_baseline"] is None

@@ -192,10 +192,21 @@ def test_injected_chain_timeout_skips_adam_and_trainer_falls_back():
         loss, acc = trainer.loss_and_acc_for_batch(tok, 0, train=True)
         loss.backward()
         trainer.step()                               # (queues the optimizer launch; its report is read later)
-        with pytest.raises(ops.ChainTimeoutError):
+        ops.slow_waits(reset=True)
+        with pytest.raises(ops.ChainTimeoutError) as err:
             trainer.check_steps(wait_all=True)       # waits for that launch (the spin takes ~0.4 s)
         torch.cuda.synchronize()
         assert ops.chain_status() > 0
+        # the recorder names the launch: forward GRU chain workgroups that gave up on their group / row-block counter after the
+        # whole bounded spin, each with its workgroup id and XCC id -- and the error message carries the same summary
+        rec = ops.slow_waits()
+        gave_up = [e for e in rec["entries"] if e["gave_up"]]
+        assert rec["count"] >= len(gave_up) > 0
+        assert all(e["kernel"] in ("gru_chain_fwd", "gru_chain2_fwd") and e["site"] in ("group counter", "row-block counter")
+                   and e["polls"] >= 64 and 0 <= e["xcc"] < 8 for e in gave_up), gave_up
+        assert max(e["polls"] for e in gave_up) > 100000             # at least one of them ran the whole bound
+        assert "Recorder:" in str(err.value) and "GAVE UP" in str(err.value)
+        assert ops.slow_waits(reset=True)["count"] == rec["count"] and ops.slow_waits()["count"] == 0
         assert torch.equal(model.flat, before)       # Adam was queued and skipped itself
         assert ops.chain_status(reset=True) > 0 and ops.chain_status() == 0
         # (b) the epoch loop: the fault hits batch 0 of 5; its report is read two steps later, by which time steps 1 and 2 were
@@ -307,3 +318,34 @@ def test_error_in_the_last_step_of_a_manual_loop_surfaces_at_finish():
         with VAETrainer(ds, model, lr=1e-4) as t4:
             one_step(t4)
             raise KeyError("the loop's own")
+
+
+def test_preload_touches_every_kernel_once_and_a_healthy_step_records_no_slow_wait():
+    """csrc/preload.hip: the library files every kernel handle hipcc registers (template instantiations included) and
+    inet_preload() loads them all on the current device without a launch -- idempotent.  A healthy training step of both
+    coin branches leaves the slow-wait recorder empty: no wait inside a persistent kernel took longer than ~50 us."""
+    from inpaintnet_amd import _lib, synthetic
+    from inpaintnet_amd.measure_vae import MeasureVAE
+    from inpaintnet_amd.vae_trainer import VAETrainer
+    L = _lib.lib()
+    assert L.inet_kernel_count() >= 200
+    first = ops.preload()
+    assert first in (0, L.inet_kernel_count())       # (0: a trainer of an earlier test did it)
+    assert ops.preload() == 0
+    ds = synthetic.SyntheticFolkDataset(num_notes=48)
+    model = MeasureVAE(ds)
+    trainer = VAETrainer(ds, model, lr=1e-4)
+    model.train()
+    tok = torch.from_numpy(synthetic.det_tokens("preload", (256, 24), 48)).cuda()
+    eps = torch.from_numpy(synthetic.det_normal("preload/eps", (256, 256))).cuda()
+    ops.slow_waits(reset=True)
+    for tf in (True, False, True, False):
+        trainer.zero_grad()
+        w, s_, z_dist, prior, z, zp = model(tok, train=True, eps=eps, teacher_forced=tf)
+        ce, acc = trainer.mean_crossentropy_loss_and_accuracy(w, tok)
+        (ce + trainer.compute_kld_loss(z_dist, prior)).backward()
+        trainer.step()
+    trainer.finish()
+    rec = ops.slow_waits(reset=True)
+    assert ops.chain_status() == 0
+    assert rec["count"] == 0, rec

@@ -21,3 +21,28 @@ def test_library_loaded_before_torch_then_smoke():
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "[smoke] ok" in r.stdout
+
+
+def test_bench_prints_exactly_one_small_line():
+    """The driver's command (short form: no extras, no CPU baseline) in a subprocess: stdout is ONE JSON line under bench.py's
+    4 KB limit with the contract's keys; the detail went to bench_detail.json (round 5's 20 KB line was dropped by the driver)."""
+    import json
+    detail = os.path.join(ROOT, "gpurun_out", "bench_detail_test.json")
+    os.makedirs(os.path.dirname(detail), exist_ok=True)
+    env = dict(os.environ, INET_BENCH_DETAIL=detail)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--no-extras", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    assert len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["chain_timeouts"] == 0
+    assert line["parity_checked"] is True
+    assert "priming_steps" not in line["config"]               # --warmup 5 means five
+    assert line["roofline"]["bound"] in ("mfma", "hbm") and 0.0 < line["roofline"]["frac"] < 1.0
+    full = json.load(open(detail))
+    assert full["value"] == line["value"] and len(full["roofline"]["kernels"]) >= 4
