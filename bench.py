@@ -477,7 +477,7 @@ def secondary_table(step, top=8, ms_per_step=None):
     out = {"step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
            "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
            "launches_per_step": round(sum(r["launches_per_step"] for r in table), 1),
-           "slow_waits_while_profiled": slow["count"]}
+           "slow_waits_while_profiled": slow["count"], "waits_noted_while_profiled": slow["noted"]}
     if ms_per_step is not None and out["step_kernel_ms"] > 2.0 * ms_per_step:
         out["kernels"] = "inconsistent"
         out["unprofiled_ms_per_step"] = ms_per_step
@@ -1206,7 +1206,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
             "chain_timeouts": chain_timeouts,                      # inet_chain_status after the timed region: 0 = healthy
-            "slow_waits": slow["count"],                           # the recorder's count over warm-up + timed steps (entries: detail file)
+            "slow_waits": slow["count"],                           # the recorder over warm-up + timed steps: waits of 16384+ polls (~6 ms) / given up
+            "waits_noted": slow["noted"],                          # ... of 16+ polls (overlapping launches becoming resident: normal)
             "slow_wait_entries": slow["entries"][:16],
             # the timed steps one by one (the first 32): GPU time between events behind consecutive steps, host time to queue each,
             # Python garbage collections inside the region -- a cold-start transient shows up HERE (profiles/r05_cold_start.txt)

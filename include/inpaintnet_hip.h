@@ -368,16 +368,18 @@ int inet_chain_status(int reset);
  * Only instrumented builds write there -- csrc/gru_chain2.hip compiled with -DINET_CHAIN2_STAMPS=1 records the wall-clock stamps of
  * one wave's steps (tools/chain2_anatomy.py) --, a normal build leaves it zero. */
 int inet_debug_read(void* dst, int64_t nbytes);
-/* The slow-wait recorder.  Every bounded wait inside a persistent kernel that needed more than 64 polls (~50 us: a hand-off takes
- * 1-3) files one entry when it ends, whether the value arrived or the wait gave up: 8 words {kernel id (1 = gru_chain fwd, 2 = bwd,
- * 3 = gru_chain2 fwd, 5 = lstm fwd, 6 = lstm bwd, 8 = decode_chain, 9 = arnn token pass, 10 = decode_b1) | XCC id << 8 |
- * gave up << 15 | site << 16 (0 = group counter, 1 = granule, 2 = row-block counter, 3 = tagged fragments), workgroup id,
- * expected tag / counter, last value seen, polls, 0, wall clock lo, hi (100 MHz)}.  Copies up to max_entries (<= 127 are kept:
- * the FIRST ones since the last reset) into dst and returns how many waits were slow since the last reset (may exceed what is
- * kept); reset != 0 clears the recorder.  Synchronises the device.  A slow wait is not an error -- a workgroup that became
- * resident late because the launch shared the chip produces one -- it is the trace an unexplained timeout or a slow launch
- * leaves behind (csrc/chain.h record_slow).  -1 bad arguments, -2 runtime failure. */
-int inet_slow_waits(unsigned* dst, int max_entries, int reset);
+/* The slow-wait recorder.  Every bounded wait inside a persistent kernel that needed at least 16 polls (a steady-state hand-off
+ * takes 3-8; a counter poll is ~0.4 us, a granule poll ~1 us) is NOTED (*noted, if not null: how many since the last reset); a
+ * wait of at least the entry threshold (default 16384 polls ~ 6 ms, inet_set_option key 16: any value >= 16) or one that GAVE UP is SLOW and files one entry
+ * when it ends: 8 words {kernel id (1 = gru_chain fwd, 2 = bwd, 3 = gru_chain2 fwd, 5 = lstm fwd, 6 = lstm bwd, 8 = decode_chain,
+ * 9 = arnn token pass, 10 = decode_b1) | XCC id << 8 | gave up << 15 | site << 16 (0 = group counter, 1 = granule, 2 = row-block
+ * counter, 3 = tagged fragments), workgroup id, expected tag / counter, polls, wall clock lo, hi (100 MHz), 0, 0}.  Copies up to
+ * max_entries (<= 127 are kept: the FIRST ones since the last reset) into dst and returns how many waits were slow since the last
+ * reset (may exceed what is kept); reset != 0 clears counts and entries (not the threshold).  Synchronises the device.  Noted
+ * waits are normal wherever launches overlap -- the members of a chain group wait ~100 us at their first step while the launch
+ * becomes resident beside a weight-gradient product --; slow ones are the trace an unexplained timeout or a stalled launch leaves
+ * behind (csrc/chain.h record_slow).  -1 bad arguments, -2 runtime failure. */
+int inet_slow_waits(unsigned* dst, int max_entries, int reset, int64_t* noted);
 /* Loads every kernel of the library on the CURRENT device (code objects and function objects, which the HIP runtime otherwise
  * builds lazily on the launch path of each kernel's first launch: csrc/preload.hip) without launching anything.  Idempotent per
  * device; returns the number of kernels touched (0 when the device was done already), -2 without a device or on a runtime

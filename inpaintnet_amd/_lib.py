@@ -127,7 +127,7 @@ _SIGNATURES = {
     "inet_twin_stream": (C.c_int, [C.POINTER(C.c_void_p)]),
     "inet_debug_read": (C.c_int, [_P, _L]),
     "inet_chain_status": (C.c_int, [_I]),
-    "inet_slow_waits": (C.c_int, [_P, _I, _I]),
+    "inet_slow_waits": (C.c_int, [_P, _I, _I, C.POINTER(_L)]),
     "inet_preload": (C.c_int, []),
     "inet_kernel_count": (C.c_int, []),
     "inet_prof_enable": (C.c_int, [_I]),

@@ -459,6 +459,13 @@ int inet_set_option(int key, int value) {
     if (key == 13) { if (value < 0 || value > 3) return -1; side_set_active(value); return 0; }
     if (key == 14) { if (value < 0 || value > 4) return -1; arnn_gen_set_mode(value); return 0; }
     if (key == 15) { if (value < 0 || value > 3) return -1; decode_b1_set_mode(value); return 0; }
+    if (key == 16) {                                           // entry threshold of the slow-wait recorder, in polls (chain.h)
+        unsigned* d = chain_dev_status();
+        const unsigned polls = (unsigned)value;
+        if (value < (int)chain::kSlowSpins || !d) return -1;
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(d + chain::kRecWord + 1, &polls, 4, hipMemcpyHostToDevice) != hipSuccess) return -2;
+        return 0;
+    }
     return -1;
 }
 
@@ -477,17 +484,22 @@ int inet_debug_read(void* dst, int64_t nbytes) {
     return hipMemcpy(dst, d + kChainDiagWord, (size_t)nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 
-int inet_slow_waits(unsigned* dst, int max_entries, int reset) {
+int inet_slow_waits(unsigned* dst, int max_entries, int reset, int64_t* noted) {
     unsigned* d = chain_dev_status();
     if (!d || max_entries < 0 || (max_entries > 0 && !dst)) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -2;
-    unsigned seen = 0;
-    if (hipMemcpy(&seen, d + chain::kRecWord, 4, hipMemcpyDeviceToHost) != hipSuccess) return -2;
-    const int have = (int)(seen < (unsigned)chain::kRecEntries ? seen : (unsigned)chain::kRecEntries);
+    unsigned head[3] = {0, 0, 0};                             // waits noted, entry threshold, slow waits
+    if (hipMemcpy(head, d + chain::kRecWord, sizeof head, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    if (noted) *noted = (int64_t)head[0];
+    const unsigned slow = head[2];
+    const int have = (int)(slow < (unsigned)chain::kRecEntries ? slow : (unsigned)chain::kRecEntries);
     const int n = have < max_entries ? have : max_entries;
     if (n > 0 && hipMemcpy(dst, d + chain::kRecWord + 8, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) return -2;
-    if (reset && seen != 0 && hipMemset(d + chain::kRecWord, 0, 4 * (size_t)chain::kRecWords) != hipSuccess) return -2;
-    return (int)(seen > 0x7fffffffu ? 0x7fffffffu : seen);
+    if (reset && head[0] != 0) {                              // (the threshold, word 1, stays)
+        if (hipMemset(d + chain::kRecWord, 0, 4) != hipSuccess ||
+            hipMemset(d + chain::kRecWord + 2, 0, 4 * (size_t)(chain::kRecWords - 2)) != hipSuccess) return -2;
+    }
+    return (int)(slow > 0x7fffffffu ? 0x7fffffffu : slow);
 }
 
 int inet_preload(void) { return preload_kernels(); }

@@ -35,14 +35,20 @@ constexpr unsigned kSpinLimit = 400000;          // polls (~1 us each with s_sle
 enum { ST_OK = 0, ST_TIMEOUT = 1 };
 
 // Layout of the process-wide device status area (side.hip chain_dev_status()), in 32-bit words: word 0 = the status; from kDiagWord:
-// kDiagBytes of scratch for instrumented builds (inet_debug_read); from kRecWord: the SLOW-WAIT RECORDER -- word 0 = waits seen
-// since the last reset, words 8.. = the first kRecEntries of them, 8 words each (Rec below).  Every bounded wait of the library
-// that needed more than kSlowSpins polls (a poll is a ~0.8 us round trip + s_sleep: ~50 us) files one entry when it ENDS -- arrived
-// or given up -- so that a lost hand-off, a workgroup that became resident late, or a launch that shared its CUs with another
-// queue leaves its coordinates behind instead of a bare status word (four events without a trace).
+// kDiagBytes of scratch for instrumented builds (inet_debug_read); from kRecWord: the SLOW-WAIT RECORDER -- word 0 = waits of at
+// least kSlowSpins polls since the last reset ("noted": a poll of a counter is ~0.4 us, of a granule ~1 us; a hand-off in
+// steady state takes 3-8), word 1 = the entry threshold in polls (default kRecDefaultPolls ~ 6 ms, inet_set_option key 16), word 2 =
+// waits of at least that many polls ("slow"), words 8.. = the first kRecEntries slow ones, 8 words each (record_slow below).
+// A wait files its entry when it ENDS -- arrived or given up (always filed) -- so that a lost hand-off or a workgroup that
+// became resident very late leaves its coordinates behind instead of a bare status word (four events without
+// a trace).  What the first runs showed at once: in EVERY training step the early members of some BPTT chain groups wait 200-300
+// polls (~100 us) on one box and 1000-1300 (~0.4 ms) on another for the group's first arrival -- the launch becomes resident
+// group by group while the weight-gradient products of the side streams hold CUs (the overlap of DESIGN.md section 8 "leaf
+// schedule" seen from inside the chain) -- hence two levels: the noted count says how much such waiting there is, entries are kept
+// for waits no overlap explains (the default threshold is several steps' worth of time; diagnosis runs lower it).
 // inet_slow_waits() copies it out; ChainTimeoutError, bench.py (`slow_waits`) and the test suite's teardown print it.
 constexpr int kDiagWord = 64, kDiagBytes = 16384, kRecWord = kDiagWord + kDiagBytes / 4, kRecEntries = 127, kRecWords = 8 * (1 + kRecEntries);
-constexpr unsigned kSlowSpins = 64;
+constexpr unsigned kSlowSpins = 16, kRecDefaultPolls = 16384;
 #ifndef INET_RECORDER
 #define INET_RECORDER 1                          // 0: build without the recorder (A/B of what it costs the chain kernels)
 #endif
@@ -100,7 +106,9 @@ __device__ __forceinline__ void record_slow(const Status& st, unsigned site, uns
     int z;
     asm volatile("v_mov_b32 %0, 0" : "=v"(z));
     unsigned* rec = st.gdev + kRecWord + z;
-    const unsigned n = __hip_atomic_fetch_add(rec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(rec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!gave_up && spins < __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const unsigned n = __hip_atomic_fetch_add(rec + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n >= (unsigned)kRecEntries) return;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

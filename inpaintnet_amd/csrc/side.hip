@@ -198,7 +198,10 @@ unsigned* chain_dev_status() {
         // (word 0: the status; from kChainDiagWord on: kChainDiagBytes of scratch for instrumented builds, inet_debug_read; behind it
         //  the slow-wait recorder, chain::kRecWord)
         const size_t n = kChainStatusAreaBytes;
-        if (hipMalloc(&q, n) == hipSuccess && hipMemset(q, 0, n) == hipSuccess) p = static_cast<unsigned*>(q);
+        const unsigned polls = chain::kRecDefaultPolls;
+        if (hipMalloc(&q, n) == hipSuccess && hipMemset(q, 0, n) == hipSuccess &&
+            hipMemcpy(static_cast<unsigned*>(q) + chain::kRecWord + 1, &polls, 4, hipMemcpyHostToDevice) == hipSuccess)
+            p = static_cast<unsigned*>(q);
     }
     return p;
 }

@@ -615,31 +615,33 @@ _SITE_NAMES = {0: "group counter", 1: "granule", 2: "row-block counter", 3: "tag
 
 
 def slow_waits(reset=False, max_entries=127):
-    """The library's slow-wait recorder (include/inpaintnet_hip.h inet_slow_waits): every bounded wait inside a persistent kernel that
-    needed more than ~50 us files one entry when it ends.  Returns {"count": waits since the last reset, "entries": the first ones
-    kept, decoded}.  Synchronises the device.  A slow wait is not an error; it is what an unexplained timeout or a slow launch leaves
-    behind: which kernel, which workgroup on which XCD, what it waited for and for how long."""
+    """The library's slow-wait recorder (include/inpaintnet_hip.h inet_slow_waits).  Returns {"count": waits of at least the entry
+    threshold (default 16384 polls, set_option(16, polls)) or that gave up, since the last reset; "noted": waits of at least 16 polls
+    (normal wherever launches overlap); "entries": the first 127 slow ones, decoded}.  Synchronises the device.  A slow wait is what
+    an unexplained timeout or a stalled launch leaves behind: which kernel, which workgroup on which XCD, what it waited for and
+    for how many polls (a counter poll is ~0.4 us, a granule poll ~1 us)."""
     import numpy as np
     buf = np.zeros((max(int(max_entries), 1), 8), dtype=np.uint32)
-    n = int(_lib.lib().inet_slow_waits(C.c_void_p(buf.ctypes.data), int(max_entries), int(bool(reset))))
+    noted = C.c_int64(0)
+    n = int(_lib.lib().inet_slow_waits(C.c_void_p(buf.ctypes.data), int(max_entries), int(bool(reset)), C.byref(noted)))
     if n < 0:
-        return {"count": n, "entries": []}
+        return {"count": n, "noted": 0, "entries": []}
     out = []
     for e in buf[:min(n, int(max_entries), 127)]:
         w0 = int(e[0])
         out.append({"kernel": _KERNEL_NAMES.get(w0 & 0xff, str(w0 & 0xff)), "xcc": (w0 >> 8) & 0xf, "gave_up": bool(w0 & 0x8000),
                     "site": _SITE_NAMES.get(w0 >> 16, str(w0 >> 16)), "workgroup": int(e[1]), "expected": int(e[2]), "polls": int(e[3]),
                     "clock_10ns": int(e[4]) | (int(e[5]) << 32)})
-    return {"count": n, "entries": out}
+    return {"count": n, "noted": int(noted.value), "entries": out}
 
 
 def slow_waits_summary(reset=False, top=6):
     """One line for error messages and logs: the count and the longest few waits of the recorder."""
     r = slow_waits(reset=reset)
     if r["count"] <= 0:
-        return f"no slow waits recorded ({r['count']})"
+        return f"no slow waits recorded ({r['count']}; {r['noted']} waits of 16+ polls noted)"
     es = sorted(r["entries"], key=lambda e: -e["polls"])[:top]
-    return f"{r['count']} slow waits; longest: " + "; ".join(
+    return f"{r['count']} slow waits ({r['noted']} of 16+ polls noted); longest: " + "; ".join(
         f"{e['kernel']} wg {e['workgroup']} xcc {e['xcc']} {e['site']} expected {e['expected']} after {e['polls']} polls"
         + (" GAVE UP" if e["gave_up"] else "") for e in es)
 

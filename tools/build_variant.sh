@@ -12,5 +12,5 @@ for f in $srcs; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment "$@" -c inpaintnet_amd/csrc/$f.hip -o build/obj_$name/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/lib_$name.so build/obj_$name/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic-functions -o build/lib_$name.so build/obj_$name/*.o -ldl
 echo build/lib_$name.so
