@@ -774,6 +774,8 @@ def vae4096_extra(wl, batch=4096, steps=6, warmup=2):
     dt = time.perf_counter() - t0
     return {"vae_train_4096": {"measures_per_s": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
                                "batch": batch, "launches_per_step": len(labels), "per_step_gru_launches": per_step,
+                               # per-kernel table (side streams off, per-launch events; mean over the coin of the profiled steps)
+                               "kernels": secondary_table(step, top=12, ms_per_step=1e3 * dt / steps),
                                "final_loss": round(float(loss.detach()), 5),
                                "workload": "MeasureVAE training at the reference's default batch: 256 sequences x 16 bars = "
                                            "4096 measures per step (train_measure_vae.py:33); above INET_CHAIN_CHUNK_MAX = 1024 rows the H = 512 "
@@ -1207,7 +1209,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4),
             "chain_timeouts": chain_timeouts,                      # inet_chain_status after the timed region: 0 = healthy
             "slow_waits": slow["count"],                           # the recorder over warm-up + timed steps: waits of 16384+ polls (~6 ms) / given up
-            "waits_noted": slow["noted"],                          # ... of 16+ polls (overlapping launches becoming resident: normal)
+            "waits_noted": slow["noted"],                          # ... of 64+ polls (overlapping launches becoming resident: normal)
             "slow_wait_entries": slow["entries"][:16],
             # the timed steps one by one (the first 32): GPU time between events behind consecutive steps, host time to queue each,
             # Python garbage collections inside the region -- a cold-start transient shows up HERE (profiles/r05_cold_start.txt)

@@ -337,7 +337,10 @@ int inet_set_option(int key, int value);
  * (they compare XCC ids at the start of the launch) -- granules as plain stores that stay in that XCD's L2; 2 = the same with
  * agent-scope stores; 1 = on 13 consecutive ids; 0 = four launches per tick; 4 = test hook: 3's request on consecutive ids (the
  * XCC-id check must refuse it).
- * key 15 = the free-running decode of ONE to SIXTEEN measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 3 (default) =
+ * key 15 = the free-running decode of ONE to SIXTEEN measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 4 (default) =
+ * 3 with every team's critical workgroups (C + 16 TBi, or the 16 CB of the merged build) on workgroup ids of one residue mod 8 --
+ * one XCD under today's round-robin dispatch -- and, once they have CHECKED that they share an XCD, XCD-local copies of h0 / h1
+ * written with plain stores next to the agent-scope ones (correct under any placement: a failed check uses the agent-scope copies); 3 =
  * one or two measures: ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for
  * the 24 ticks -- two hand-offs per tick; one where a single workgroup kind can hold layer 1, the head and the argmax: one row with
  * V <= 64 -- and 80 for the beat path); three to sixteen: teams of the 49 tick workgroups in one launch, two rows per team up to ten
@@ -368,8 +371,8 @@ int inet_chain_status(int reset);
  * Only instrumented builds write there -- csrc/gru_chain2.hip compiled with -DINET_CHAIN2_STAMPS=1 records the wall-clock stamps of
  * one wave's steps (tools/chain2_anatomy.py) --, a normal build leaves it zero. */
 int inet_debug_read(void* dst, int64_t nbytes);
-/* The slow-wait recorder.  Every bounded wait inside a persistent kernel that needed at least 16 polls (a steady-state hand-off
- * takes 3-8; a counter poll is ~0.4 us, a granule poll ~1 us) is NOTED (*noted, if not null: how many since the last reset); a
+/* The slow-wait recorder.  Every bounded wait on a group / row-block counter inside a persistent kernel that needed at least 64 polls (a
+ * steady-state hand-off takes 3-8; a counter poll is ~0.4 us; granule waits, polled by every thread, only from 4096 polls on) is NOTED (*noted, if not null: how many since the last reset); a
  * wait of at least the entry threshold (default 16384 polls ~ 6 ms, inet_set_option key 16: any value >= 16) or one that GAVE UP is SLOW and files one entry
  * when it ends: 8 words {kernel id (1 = gru_chain fwd, 2 = bwd, 3 = gru_chain2 fwd, 5 = lstm fwd, 6 = lstm bwd, 8 = decode_chain,
  * 9 = arnn token pass, 10 = decode_b1) | XCC id << 8 | gave up << 15 | site << 16 (0 = group counter, 1 = granule, 2 = row-block

@@ -36,8 +36,8 @@ enum { ST_OK = 0, ST_TIMEOUT = 1 };
 
 // Layout of the process-wide device status area (side.hip chain_dev_status()), in 32-bit words: word 0 = the status; from kDiagWord:
 // kDiagBytes of scratch for instrumented builds (inet_debug_read); from kRecWord: the SLOW-WAIT RECORDER -- word 0 = waits of at
-// least kSlowSpins polls since the last reset ("noted": a poll of a counter is ~0.4 us, of a granule ~1 us; a hand-off in
-// steady state takes 3-8), word 1 = the entry threshold in polls (default kRecDefaultPolls ~ 6 ms, inet_set_option key 16), word 2 =
+// least kSlowSpins polls since the last reset ("noted": a poll of a counter is ~0.4 us, of a granule 0.1-0.3 us; a hand-off in
+// steady state takes 3-8; granule waits are not noted below kGranuleSlowSpins), word 1 = the entry threshold in polls (default kRecDefaultPolls ~ 6 ms, inet_set_option key 16), word 2 =
 // waits of at least that many polls ("slow"), words 8.. = the first kRecEntries slow ones, 8 words each (record_slow below).
 // A wait files its entry when it ENDS -- arrived or given up (always filed) -- so that a lost hand-off or a workgroup that
 // became resident very late leaves its coordinates behind instead of a bare status word (four events without
@@ -48,7 +48,12 @@ enum { ST_OK = 0, ST_TIMEOUT = 1 };
 // for waits no overlap explains (the default threshold is several steps' worth of time; diagnosis runs lower it).
 // inet_slow_waits() copies it out; ChainTimeoutError, bench.py (`slow_waits`) and the test suite's teardown print it.
 constexpr int kDiagWord = 64, kDiagBytes = 16384, kRecWord = kDiagWord + kDiagBytes / 4, kRecEntries = 127, kRecWords = 8 * (1 + kRecEntries);
-constexpr unsigned kSlowSpins = 16, kRecDefaultPolls = 16384;
+constexpr unsigned kSlowSpins = 64, kRecDefaultPolls = 16384;
+// Granule waits (granule.h) are polled by EVERY thread and a recurrent-side workgroup of the register-resident kernels waits most of
+// a tick for its next input as a matter of course: noting those (one atomic on one word per wave and wait, and a dependent load of
+// the threshold behind it) quadrupled the decode call -- 0.12 -> 0.4-0.5 ms, every phase of the tick slower, a feedback loop:
+// slower ticks, longer waits, more atomics.  Granule waits therefore reach the recorder only from kGranuleSlowSpins polls on.
+constexpr unsigned kGranuleSlowSpins = 4096;
 #ifndef INET_RECORDER
 #define INET_RECORDER 1                          // 0: build without the recorder (A/B of what it costs the chain kernels)
 #endif

@@ -85,11 +85,47 @@ constexpr int G_H0 = 0, G_H1 = DH, G_GH0 = 2 * DH, G_GH1 = 2 * DH + D3, G_H1X = 
 __device__ __forceinline__ int slot_h0(unsigned tag) { return (tag & 1) ? G_H0X : G_H0; }
 __device__ __forceinline__ int slot_h1(unsigned tag) { return (tag & 1) ? G_H1X : G_H1; }
 constexpr int G_HB0 = G_TICK_END, G_H0B = G_HB0 + 2 * DH, G_H1B = G_H0B + 4 * DH, G_GH1B = G_H1B + 4 * DH, G_C = G_GH1B + 4 * D3,
-              G_HT0 = G_C + 4 * DH, G_CGI = G_HT0 + 4 * 2 * DH, G_END = G_CGI + 4 * D3;
+              G_HT0 = G_C + 4 * DH, G_CGI = G_HT0 + 4 * 2 * DH, G_H0N = G_CGI + 4 * D3, G_H1N = G_H0N + 2 * DH, G_XCC = G_H1N + 2 * DH,
+              G_END = G_XCC + 32;
+// (G_H0N / G_H1N: XCD-LOCAL copies of h0 / h1, two slots each, written with plain stores for the readers on the writer's XCD -- "One
+//  XCD for the critical path" below; G_XCC: the critical workgroups' XCC ids, granule::same_xcd)
 static_assert(2 * G_END == kDecodeB1WordsPerRow, "the workspace's granule area holds the map");
+// One XCD for the critical path (round 6).  A tick's critical hand-offs run among C and the 16 TBi (h0 out, h1 back), or among
+// the 16 CB of the merged build (the all-gather of h1: 1.54 of a 3.78 us tick, profiles/r05_n_decode_b1_merged_stamps.txt); the
+// recurrent-side workgroups TA / TBh read the same vectors a tick early, off the critical path.  An agent-scope granule store
+// drops the line from the XCD's L2 and sends every reader through the memory side; a PLAIN store stays in L2, where the sc1
+// loads of readers ON THE SAME XCD find it (granule.h: 10 % of AnticipationRNN's token pass) -- and is never seen from another
+// XCD.  So the launch maps workgroup ids to roles such that every team's critical workgroups are ids of one residue mod 8
+// (`place`: one XCD under the round-robin dispatch observed today), the critical workgroups CHECK that they really share an XCD
+// (same_xcd: XCC ids exchanged with agent-scope granules, one hand-off at the start), and if so every state vector is stored
+// TWICE: a plain store into the XCD-local copy for the critical readers, the agent-scope store for TA / TBh wherever they run.
+// If the check says no, everybody uses the agent-scope copies: correct under any placement.
+__device__ __forceinline__ int slot_h0n(unsigned tag) { return G_H0N + (int)(tag & 1) * DH; }
+__device__ __forceinline__ int slot_h1n(unsigned tag) { return G_H1N + (int)(tag & 1) * DH; }
+__device__ __forceinline__ void put_local(unsigned long long* g, float v, unsigned tag) {
+    const unsigned long long x = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(x) : "memory");
+}
+constexpr int kCrit = 17;                        // critical workgroups per team: C and the 16 TBi (merged build: C's slot idles)
+// workgroup id -> (team, role) with every team's critical workgroups on ids of one residue mod 8; false: no role (the id leaves)
+__host__ __device__ inline int crit_below(int b, int teams) {
+    int n = 0;
+    for (int x = 0; x < teams; ++x)
+        if (b > x) { const int c = (b - x + 7) / 8; n += c < kCrit ? c : kCrit; }
+    return n;
+}
+__host__ __device__ inline bool place_role(int b, int teams, int beat_wgs, int& team, int& role) {
+    const int x = b & 7, i = b >> 3;
+    if (x < teams && i < kCrit) { team = x; role = i == 0 ? R_C : R_TBI + i - 1; return true; }
+    const int n = b - crit_below(b, teams);                     // the id's rank among the non-critical ones
+    if (n < teams * 2 * NU) { team = n / (2 * NU); const int r = n % (2 * NU); role = r < NU ? R_TA + r : R_TBH + (r - NU); return true; }
+    if (n - teams * 2 * NU < beat_wgs) { team = 0; role = kTickRoles + (n - teams * 2 * NU); return true; }
+    return false;
+}
 
 struct B1Args {
     int B, T, G, V, Z, stride, fused, teams;     // teams: groups of kTickRoles workgroups, NB rows each (tick path only beyond one)
+    int place;                                   // 1: ids -> roles by place_role (critical workgroups of a team on one XCD), XCD-local copies requested
     const float* W_hh0; const float* b_hh0; const float* cgi; const float* table;
     const float* W_ih1; const float* b_ih1; const float* W_hh1; const float* b_hh1;
     const float* W_out; const float* b_out; const float* ht0;
@@ -169,7 +205,7 @@ __device__ __forceinline__ bool get_2d(const unsigned long long* g, int rs, int 
             for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int i = 0; i < NG; ++i) v[r][i] = __uint_as_float((unsigned)w[r][i]);
-            if (spins > chain::kSlowSpins) note_slow(st, tag, spins, false);
+            if (spins > chain::kGranuleSlowSpins) note_slow(st, tag, spins, false);
             return true;
         }
         if (++spins > kSpin ||
@@ -399,12 +435,15 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     __shared__ float lgs[NB][32 * NJ];
     __shared__ int toks[NB];
     __shared__ int bad_s;
+    __shared__ int near_s;
     if (blockIdx.x % a.stride) return;
     // more than four rows: `teams` teams of the tick path's workgroups, NB rows and one granule area per row each, nothing shared
-    // (workgroup order with several teams: the teams' tick workgroups first, the beat path's 80 behind them when it is folded in)
+    // (workgroup order with several teams: the teams' tick workgroups first, the beat path's 80 behind them when it is folded in;
+    //  a.place: place_role's order instead)
     const int wg = blockIdx.x / a.stride, tick_wgs = a.teams * kTickRoles;
-    const int team = (a.teams > 1 && wg < tick_wgs) ? wg / kTickRoles : 0;
-    const int role = a.teams > 1 ? (wg < tick_wgs ? wg % kTickRoles : kTickRoles + (wg - tick_wgs)) : wg;
+    int team = (a.teams > 1 && wg < tick_wgs) ? wg / kTickRoles : 0;
+    int role = a.teams > 1 ? (wg < tick_wgs ? wg % kTickRoles : kTickRoles + (wg - tick_wgs)) : wg;
+    if (a.place && !place_role((int)blockIdx.x, a.teams, a.fused ? kFusedRoles - kTickRoles : 0, team, role)) return;
     const int rb = team * NB, nrow = min(NB, a.B - rb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* const ex = a.ex + (long)rb * G_END;
@@ -421,6 +460,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     if (role == R_C) {
         if (MG) return;
         // ---- C: layer 0's cell (its three summands are made elsewhere and arrive), the output projection, argmax ----
+        const bool near = a.place && same_xcd(ex + G_XCC, 0, kCrit, a.status, &near_s);
         const int rv = tid >> 4, s = tid & 15;
         int row[NJ];
 #pragma unroll
@@ -467,10 +507,13 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 for (int r = 0; r < NB; ++r)
                     h0[r] = gru_cell(cg[r][0] + tb[r][0], cg[r][1] + tb[r][1], cg[r][2] + tb[r][2], gh[r][0], gh[r][1], gh[r][2], h0[r]);
 #pragma unroll
-                for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + slot_h0((unsigned)t + 1u) + u, h0[r], (unsigned)t + 1u);
+                for (int r = 0; r < NB; ++r) {
+                    if (near) put_local(ex + (long)r * G_END + slot_h0n((unsigned)t + 1u) + u, h0[r], (unsigned)t + 1u);
+                    put(ex + (long)r * G_END + slot_h0((unsigned)t + 1u) + u, h0[r], (unsigned)t + 1u);
+                }
             }
             B1_STAMP(0, t, 1);
-            c.gather(slot_h1((unsigned)t + 1u), (unsigned)t + 1u, 0);
+            c.gather(near ? slot_h1n((unsigned)t + 1u) : slot_h1((unsigned)t + 1u), (unsigned)t + 1u, 0);
             B1_STAMP(0, t, 2);
             lds_barrier();
             if (*bad) break;
@@ -549,6 +592,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
         // workgroup does not wait for its 15 peers to have READ a value before it writes the next one (a peer's read of h1_t is
         // ordered before its own h1_t+1, which the writer of h1_t+2 has to have seen: two slots are enough; likewise gh0, h0).
         const int k = role - R_TBI, p = tid >> 4, s = tid & 15, uc = UW * k + p;
+        const bool near = a.place && same_xcd(ex + G_XCC, k, NU, a.status, &near_s);
         const int row[3] = {uc, DH + uc, 2 * DH + uc};
         float w[3][32];
         load_rows<3, 32>(w, a.W_ih1, DH, row, s);
@@ -633,11 +677,14 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                     for (int r = 0; r < NB; ++r)
                         h1[r] = gru_cell(y[r][0] + bi[0], y[r][1] + bi[1], y[r][2] + bi[2], gh1[r][0], gh1[r][1], gh1[r][2], h1[r]);
 #pragma unroll
-                    for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + g_h1 + uc, h1[r], tag);
+                    for (int r = 0; r < NB; ++r) {
+                        if (near) put_local(ex + (long)r * G_END + slot_h1n(tag) + uc, h1[r], tag);
+                        put(ex + (long)r * G_END + g_h1 + uc, h1[r], tag);
+                    }
                 }
             }
             if (out) B1_STAMP(0, t, 2);
-            c.gather(g_h1, tag, 1);
+            c.gather(near ? slot_h1n(tag) : g_h1, tag, 1);
             if (out) B1_STAMP(0, t, 3);
             lds_barrier();
             if (*bad) break;
@@ -703,6 +750,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     } else if (role < R_TBH) {
         // ---- TBi_k: tick layer 1's input-side product and its cell ----
         const int k = role - R_TBI, p = tid >> 4, s = tid & 15, u = UW * k + p;
+        const bool near = a.place && same_xcd(ex + G_XCC, 1 + k, kCrit, a.status, &near_s);
         const int row[3] = {u, DH + u, 2 * DH + u};
         float w[3][32];
         load_rows<3, 32>(w, a.W_ih1, DH, row, s);
@@ -734,7 +782,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 }
             }
             if (k == 0) B1_STAMP(1, t, 1);
-            c.gather(slot_h0((unsigned)t + 1u), (unsigned)t + 1u, t & 1);
+            c.gather(near ? slot_h0n((unsigned)t + 1u) : slot_h0((unsigned)t + 1u), (unsigned)t + 1u, t & 1);
             if (k == 0) B1_STAMP(1, t, 2);
             lds_barrier();
             if (*bad) break;
@@ -748,7 +796,10 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 for (int r = 0; r < NB; ++r)
                     h1[r] = gru_cell(y[r][0] + bi[0], y[r][1] + bi[1], y[r][2] + bi[2], gh[r][0], gh[r][1], gh[r][2], h1[r]);
 #pragma unroll
-                for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + slot_h1((unsigned)t + 1u) + u, h1[r], (unsigned)t + 1u);
+                for (int r = 0; r < NB; ++r) {
+                    if (near) put_local(ex + (long)r * G_END + slot_h1n((unsigned)t + 1u) + u, h1[r], (unsigned)t + 1u);
+                    put(ex + (long)r * G_END + slot_h1((unsigned)t + 1u) + u, h1[r], (unsigned)t + 1u);
+                }
             }
             if (k == 0) B1_STAMP(1, t, 4);
         }
@@ -764,14 +815,23 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
 }
 
 int g_mode = -1;                                 // 0 = off (decode_chain.hip's small-batch builds); 1 = tick path only, consecutive workgroup ids;
-                                                 // 2 = tick path only, every 4th id; 3 (default) = beat path folded in
+                                                 // 2 = tick path only, every 4th id; 3 = beat path folded in; 4 (default) = 3 + every
+                                                 // team's critical workgroups on one XCD with XCD-local copies of h0 / h1 (place_role)
 int mode() {
     if (g_mode < 0) {
         const char* v = std::getenv("INET_DECODE_B1");
-        g_mode = v ? std::atoi(v) : 3;
-        if (g_mode < 0 || g_mode > 3) g_mode = 3;
+        g_mode = v ? std::atoi(v) : 4;
+        if (g_mode < 0 || g_mode > 4) g_mode = 4;
     }
     return g_mode;
+}
+// workgroup ids a placed launch needs: the smallest count whose non-critical ids hold every non-critical role (and past the last
+// critical id)
+int placed_grid(int teams, int beat_wgs) {
+    const int need = teams * 2 * NU + beat_wgs;
+    int g = 8 * (kCrit - 1) + teams;
+    while (g - crit_below(g, teams) < need) ++g;
+    return g;
 }
 }  // namespace
 
@@ -783,7 +843,7 @@ int decode_b1_team_rows(int B) {
     return B <= 10 ? 2 : 4;
 }
 
-void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 3) ? 3 : m; }
+void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 4) ? 4 : m; }
 
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
     return mode() != 0 && chain_enabled() && B >= 1 && B <= kDecodeB1MaxRows && H == DH && V >= 1 && V <= 128 && T % G == 0 && T / G <= 4 &&
@@ -793,7 +853,7 @@ bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
 // 3 x 49 + 80 = 227 of 256 CUs); they then serve all (up to kBeatRowsMax) rows of the call
 bool decode_b1_fused(int Z, int B) {
     const int teams = decode_b1_teams(B);
-    return mode() == 3 && Z == DZ && (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax)) &&
+    return mode() >= 3 && Z == DZ && (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax)) &&
            teams * kTickRoles + (kFusedRoles - kTickRoles) <= chain_capacity();
 }
 bool decode_b1_ok(const DecodeChainArgs& a) {
@@ -821,7 +881,9 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const double beat_w = a.fused ? 2.0 * DH * DZ + 9.0 * DH * DH + 3.0 * DH * DH + 3.0 * DH * DH : 0.0;
     ProfScope prof(PROF_GRU_FWD, 2.0 * d.B * (d.T * (9.0 * DH * DH + (double)d.V * DH) + beat_mac), s, label,
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
-    const dim3 grid((a.teams * kTickRoles + (a.fused ? kFusedRoles - kTickRoles : 0)) * a.stride);
+    a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, a.fused ? kFusedRoles - kTickRoles : 0) <= chain_capacity();
+    const dim3 grid(a.place ? placed_grid(a.teams, a.fused ? kFusedRoles - kTickRoles : 0)
+                            : (a.teams * kTickRoles + (a.fused ? kFusedRoles - kTickRoles : 0)) * a.stride);
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
     if (a.fused && a.teams > 1 && (nbr != 2 || a.teams * 2 > kDecodeB1BeatRowsMax)) return -1;
 #define INET_B1(NJ, NBR)                                                                                                    \

@@ -56,7 +56,7 @@ __device__ __forceinline__ bool get_n(const unsigned long long* g, int stride, u
         if (all) {
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = __uint_as_float((unsigned)w[i]);
-            if (spins > chain::kSlowSpins) note_slow(st, tag, spins, false);
+            if (spins > chain::kGranuleSlowSpins) note_slow(st, tag, spins, false);
             return true;
         }
         if (++spins > kSpin ||

@@ -616,7 +616,7 @@ _SITE_NAMES = {0: "group counter", 1: "granule", 2: "row-block counter", 3: "tag
 
 def slow_waits(reset=False, max_entries=127):
     """The library's slow-wait recorder (include/inpaintnet_hip.h inet_slow_waits).  Returns {"count": waits of at least the entry
-    threshold (default 16384 polls, set_option(16, polls)) or that gave up, since the last reset; "noted": waits of at least 16 polls
+    threshold (default 16384 polls, set_option(16, polls)) or that gave up, since the last reset; "noted": waits of at least 64 polls
     (normal wherever launches overlap); "entries": the first 127 slow ones, decoded}.  Synchronises the device.  A slow wait is what
     an unexplained timeout or a stalled launch leaves behind: which kernel, which workgroup on which XCD, what it waited for and
     for how many polls (a counter poll is ~0.4 us, a granule poll ~1 us)."""
@@ -639,9 +639,9 @@ def slow_waits_summary(reset=False, top=6):
     """One line for error messages and logs: the count and the longest few waits of the recorder."""
     r = slow_waits(reset=reset)
     if r["count"] <= 0:
-        return f"no slow waits recorded ({r['count']}; {r['noted']} waits of 16+ polls noted)"
+        return f"no slow waits recorded ({r['count']}; {r['noted']} waits of 64+ polls noted)"
     es = sorted(r["entries"], key=lambda e: -e["polls"])[:top]
-    return f"{r['count']} slow waits ({r['noted']} of 16+ polls noted); longest: " + "; ".join(
+    return f"{r['count']} slow waits ({r['noted']} of 64+ polls noted); longest: " + "; ".join(
         f"{e['kernel']} wg {e['workgroup']} xcc {e['xcc']} {e['site']} expected {e['expected']} after {e['polls']} polls"
         + (" GAVE UP" if e["gave_up"] else "") for e in es)
 

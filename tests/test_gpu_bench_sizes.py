@@ -60,14 +60,16 @@ def _labels(path):
         return [row["label"] for row in csv.DictReader(f)]
 
 
-@pytest.mark.parametrize("tf,B", [(True, 256), (False, 256), (True, 512), (False, 512), (True, 2048)],
-                         ids=["tf-256", "fr-256", "tf-512", "fr-512", "tf-2048"])
+@pytest.mark.parametrize("tf,B", [(True, 256), (False, 256), (True, 512), (False, 512), (True, 2048), (True, 4096), (False, 4096)],
+                         ids=["tf-256", "fr-256", "tf-512", "fr-512", "tf-2048", "tf-4096", "fr-4096"])
 def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     """B = 256: the bench batch, every recurrent layer one resident chain launch.  B = 512: more rows than one launch holds
     (the reference's default VAE batch is 4096 measures, train_measure_vae.py:33): every layer runs as chain launches over
     256-row chunks WITH backward saves, forward and backward -- no per-step launches for the H = 512 layers.  B = 2048: beyond
     INET_CHAIN_CHUNK_MAX (1024 rows) the per-step kernels take over -- at that size one launch per step over all rows is
-    the faster form (profiles/r03_e_batch_crossover.txt) -- and the same parity bar holds."""
+    the faster form (profiles/r03_e_batch_crossover.txt) -- and the same parity bar holds.  B = 4096: the reference's default step
+    (256 sequences x 16 bars, train_measure_vae.py:33, vae_trainer.py:49-52), both sides of the teacher-forcing coin: what
+    bench.py's `vae4096_measures_per_s` times."""
     T = 24
     c = G.CFGS["full"]
     H = c["H"]
@@ -89,9 +91,9 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
     ops.prof_dump(tmp_path / "launches.csv")
     ops.prof_enable(False)
     labels = _labels(tmp_path / "launches.csv")
-    if B == 2048:                     # the encoder's layers: bf16-pipe step kernels, forward (with backward saves) and backward
-        assert sum(l == "gru_step_bf3 p9 np2 B2048 H512 sv" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
-        assert sum(l == "gru_step_bf3_bwd p9 np2 B2048 H512" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
+    if B >= 2048:                     # the encoder's layers: bf16-pipe step kernels, forward (with backward saves) and backward
+        assert sum(l == f"gru_step_bf3 p9 np2 B{B} H512 sv" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
+        assert sum(l == f"gru_step_bf3_bwd p9 np2 B{B} H512" for l in labels) == 48, sorted(set(l for l in labels if l.startswith("gru")))
     if B == 512:
         gl = sorted(set(l for l in labels if l.startswith("gru") or l.startswith("dec")))
         assert not any(l.startswith("gru_fwd") or l.startswith("gru_bwd") for l in labels), gl      # no per-step launches
@@ -102,14 +104,14 @@ def test_vae_step_at_bench_batch_vs_oracle(tf, B, tmp_path):
         assert sum(l.startswith("gru_chain_bwd") and " T6 " in l for l in labels) in (2, 4), gl
         if not tf:                                               # 512 free-running rows: ONE launch of the 64-row build
             assert sum(l == "decode_chain_train ms4 T24 B512 H512 V48" for l in labels) == 1, gl
-    if B == 2048:
+    if B >= 2048:
         assert any(l.startswith("gru_fwd") for l in labels) and any(l.startswith("gru_bwd") for l in labels)
         assert not any(l.startswith("gru_chain") for l in labels), sorted(set(l for l in labels if l.startswith("gru")))
     # (iv) the instantiations the bench spends its time in were the ones that ran
     if B == 256:        # encoder layers, two directions, one launch per layer; encoder BPTT
         for kind in ("fwd", "bwd"):
             assert sum(G.is_chain(l, kind, 2, 24, 256) for l in labels) == 2, sorted(set(l for l in labels if l.startswith("gru")))
-    assert B == 2048 or any(G.is_chain(l, "bwd", 4, 6, 256) for l in labels)   # decoder tick layers: 4 beats x 256 rows in one launch
+    assert B >= 2048 or any(G.is_chain(l, "bwd", 4, 6, 256) for l in labels)   # decoder tick layers: 4 beats x 256 rows in one launch
     if tf and B == 256:   # teacher-forced ticks: each tick layer = two chain launches of two beats (6 steps), no per-tick launches
         assert sum(G.is_chain(l, "fwd", 2, 6, 256) for l in labels) == 4, sorted(set(l for l in labels if l.startswith("gru")))
         assert not any(l.startswith("gru_fwd") for l in labels)

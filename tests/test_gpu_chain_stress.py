@@ -203,7 +203,7 @@ def test_injected_chain_timeout_skips_adam_and_trainer_falls_back():
         gave_up = [e for e in rec["entries"] if e["gave_up"]]
         assert rec["count"] >= len(gave_up) > 0
         assert all(e["kernel"] in ("gru_chain_fwd", "gru_chain2_fwd") and e["site"] in ("group counter", "row-block counter")
-                   and e["polls"] >= 16 and 0 <= e["xcc"] < 8 for e in gave_up), gave_up
+                   and e["polls"] >= 64 and 0 <= e["xcc"] < 8 for e in gave_up), gave_up
         assert max(e["polls"] for e in gave_up) > 100000             # at least one of them ran the whole bound
         assert "Recorder:" in str(err.value) and "GAVE UP" in str(err.value)
         assert ops.slow_waits(reset=True)["count"] == rec["count"] and ops.slow_waits()["count"] == 0
@@ -324,7 +324,7 @@ def test_preload_touches_every_kernel_once_and_a_healthy_step_records_no_slow_wa
     """csrc/preload.hip: the library files every kernel handle hipcc registers (template instantiations included) and
     inet_preload() loads them all on the current device without a launch -- idempotent.  A healthy training step of both
     coin branches files no entry in the slow-wait recorder: no wait inside a persistent kernel reached the entry threshold (waits
-    of 16+ polls are noted, and there are hundreds per step: chain launches become resident group by group beside the
+    of 64+ polls are noted, and there are hundreds per step: chain launches become resident group by group beside the
     weight-gradient products of the side streams, and the early members of a group poll until its last one is there).  With the
     threshold lowered to 64 polls (set_option 16) the same steps DO file entries, all of that kind: a first arrival (expected =
     one round of the group's members) awaited at a group counter."""

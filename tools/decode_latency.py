@@ -15,7 +15,7 @@ vae = wl.model
 vae.eval()
 z = torch.randn(1, vae.latent_space_dim, device="cuda")
 dummy = torch.zeros(1, 24, device="cuda")
-for mode in (0, 1, 2, 3):
+for mode in (0, 1, 2, 3, 4):
     ops.set_option(15, mode)
     with torch.no_grad():
         for _ in range(5):
@@ -26,7 +26,7 @@ for mode in (0, 1, 2, 3):
             vae.decoder(z, dummy, train=False)
         torch.cuda.synchronize()
     print(f"b = 1, decode kernel mode {mode}: {1e3 * (time.perf_counter() - t0) / 300:.4f} ms per call, chain status {ops.chain_status()}")
-ops.set_option(15, 3)
+ops.set_option(15, 4)
 
 # two to four measures (the reference's non-auto-regressive inpainting call) on the register-resident kernel (mode 3) and on
 # decode_chain.hip's exchange kernel (mode 0)
@@ -34,7 +34,7 @@ for b in (2, 3, 4, 5, 6, 8, 10, 11, 12, 16):
     z = torch.randn(b, vae.latent_space_dim, device="cuda")
     dummy = torch.zeros(b, 24, device="cuda")
     line = []
-    for mode in (0, 3):
+    for mode in (0, 3, 4):
         ops.set_option(15, mode)
         with torch.no_grad():
             for _ in range(5):
@@ -46,7 +46,7 @@ for b in (2, 3, 4, 5, 6, 8, 10, 11, 12, 16):
             torch.cuda.synchronize()
         line.append(f"mode {mode}: {1e3 * (time.perf_counter() - t0) / 200:.4f} ms")
     print(f"b = {b}: " + ", ".join(line) + f", chain status {ops.chain_status()}")
-ops.set_option(15, 3)
+ops.set_option(15, 4)
 
 if os.environ.get("INET_DECODE_B1_STAMPS") == "1":
     # anatomy of a tick from in-kernel wall-clock stamps (10 ns units), workgroup C and workgroup TBi_0
