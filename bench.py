@@ -703,15 +703,20 @@ def decode_latency_extra(vae, iters=20):
         out[f"b{b}"] = {"ms_per_call": round(ms, 4), "measures_per_s": round(b / ms * 1e3, 1),
                         "weights_once_GBps": round(gbps, 2), "frac_hbm_roofline": round(gbps / PEAK_HBM_GBPS, 5)}
     out["north_star_target_frac"] = 0.40
-    # What bounds the b = 1 call is a chain of dependent hand-offs, not bytes: 24 ticks x 1 hand-off on the critical path (the
-    # all-gather of h1_t among the 16 layer-1 workgroups, csrc/decode_b1.hip's merged build; two per tick -- C -> TBi -> C -- where
-    # that build does not fit) + 5 for beat 0 (z2b -> beat layer 0 -> layer 1 -> projection -> cgi), each >= 0.8 us on this part
-    # (MI355X_MICROARCH.md "handoff-1to1"; 0.74 / 0.89 us measured one-to-one in profiles/r05_arnn_token_pass.txt, 1.5 us for the
-    # all-gather among 16 in profiles/r05_decode_b1_latency.txt) -- the floor of THIS algorithm next to the 40 % HBM target (8.3 us
-    # per call), which it cannot reach.
-    handoffs = 24 * 1 + 5
-    out["b1"]["latency_floor_ms"] = round(handoffs * 0.8e-3, 4)
-    out["b1"]["latency_floor"] = f"{handoffs} dependent hand-offs x 0.8 us (one per tick + five for beat 0)"
+    # What bounds the b = 1 call is a chain of dependent hand-offs AND the work between them, not bytes.  Per tick (in-kernel stamps of
+    # workgroup CB_0, profiles/r06_decode_stamps.txt: tick period 3.28 us): ONE hand-off on the critical path -- the all-gather of h1_t
+    # among the 16 layer-1 workgroups of csrc/decode_b1.hip's merged build, 0.8 us now that they share an XCD and write XCD-local
+    # copies (1.54 us with agent-scope stores across XCDs in round 5; a one-to-one hand-off inside an XCD measures 0.6) -- plus
+    # 2.47 us of LOCAL work no hand-off hides: the token's rows of the gather table and layer 0's cells 0.50, barrier + the W_ih1
+    # product + layer 1's cells 0.67, barrier + head + barrier 0.62, argmax 0.19, the next tick's recurrent summands 0.25, the rest
+    # stamps' own cost.  In front of the 24 ticks: five hand-offs of beat 0 (z2b -> beat layer 0 -> layer 1 -> projection -> cgi)
+    # with one 512-wide product behind each.  The floor of THIS design is therefore hand-offs x 0.6 us + 24 x the measured local
+    # work -- not the 0.023 ms round 5 printed from the hand-offs alone, and nowhere near the 40 % HBM target (8.3 us per call).
+    handoffs, local_us = 24 * 1 + 5, 2.47
+    out["b1"]["latency_floor_ms"] = round((handoffs * 0.6 + 24 * local_us + 5 * 0.4) * 1e-3, 4)
+    out["b1"]["latency_floor"] = (f"{handoffs} dependent hand-offs x 0.6 us (one per tick + five for beat 0, same XCD) + 24 ticks x {local_us} us of "
+                                  "local work between them (cells, two products, three barriers, argmax: profiles/r06_decode_stamps.txt) + five "
+                                  "beat-path products x 0.4 us")
     vae.train()
     return {"decoder_eval": out}
 

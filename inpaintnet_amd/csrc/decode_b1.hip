@@ -114,17 +114,19 @@ __host__ __device__ inline int crit_below(int b, int teams) {
         if (b > x) { const int c = (b - x + 7) / 8; n += c < kCrit ? c : kCrit; }
     return n;
 }
-__host__ __device__ inline bool place_role(int b, int teams, int beat_wgs, int& team, int& role) {
+// (rteams: the groups of 2 NU recurrent-side workgroups -- one per team, or the shared groups' count; `team` of such a role = its group)
+__host__ __device__ inline bool place_role(int b, int teams, int rteams, int beat_wgs, int& team, int& role) {
     const int x = b & 7, i = b >> 3;
     if (x < teams && i < kCrit) { team = x; role = i == 0 ? R_C : R_TBI + i - 1; return true; }
     const int n = b - crit_below(b, teams);                     // the id's rank among the non-critical ones
-    if (n < teams * 2 * NU) { team = n / (2 * NU); const int r = n % (2 * NU); role = r < NU ? R_TA + r : R_TBH + (r - NU); return true; }
-    if (n - teams * 2 * NU < beat_wgs) { team = 0; role = kTickRoles + (n - teams * 2 * NU); return true; }
+    if (n < rteams * 2 * NU) { team = n / (2 * NU); const int r = n % (2 * NU); role = r < NU ? R_TA + r : R_TBH + (r - NU); return true; }
+    if (n - rteams * 2 * NU < beat_wgs) { team = 0; role = kTickRoles + (n - rteams * 2 * NU); return true; }
     return false;
 }
 
 struct B1Args {
     int B, T, G, V, Z, stride, fused, teams;     // teams: groups of kTickRoles workgroups, NB rows each (tick path only beyond one)
+    int rgroups;                                 // > 0: SHARED recurrent groups -- TA / TBh workgroups of NBR rows each serve several critical teams ("Shared recurrent groups")
     int place;                                   // 1: ids -> roles by place_role (critical workgroups of a team on one XCD), XCD-local copies requested
     const float* W_hh0; const float* b_hh0; const float* cgi; const float* table;
     const float* W_ih1; const float* b_ih1; const float* W_hh1; const float* b_hh1;
@@ -217,15 +219,46 @@ __device__ __forceinline__ bool get_2d(const unsigned long long* g, int rs, int 
     }
 }
 
+// NB granules of one tag, one per row, where only the first `nact` rows have a producer: the others read row nact - 1 again
+template <int NB>
+__device__ __forceinline__ bool get_rows(const unsigned long long* g, int nact, unsigned tag, const chain::Status& st, float (&v)[NB],
+                                         unsigned long long (&w)[NB]) {
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) w[i] = peek(g + (long)min(i, nact - 1) * G_END);
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) all &= (unsigned)(w[i] >> 32) == tag;
+        if (all) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) v[i] = __uint_as_float((unsigned)w[i]);
+            if (spins > chain::kGranuleSlowSpins) note_slow(st, tag, spins, false);
+            return true;
+        }
+        if (++spins > kSpin ||
+            ((spins & 1023) == 0 && __hip_atomic_load(st.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain::ST_OK)) {
+            note_slow(st, tag, spins, true);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 template <int NB>
 struct Ctx {                                     // what every role needs
     const B1Args& a; unsigned long long* ex; float (*xs)[2][XS]; volatile int* bad; int tid;
     int rb, nrow;                                // the team's first row, and how many of its NB rows exist
+    int nact;                                    // rows that have a producer (NB for a team; a shared recurrent group's may be fewer)
     // every thread fetches granule `tid` (of the vector at `off`) of every row and files it as that row's x (buffer `buf`)
     __device__ __forceinline__ void gather(int off, unsigned tag, int buf) const {
         float v[NB];
         unsigned long long w[NB];
-        if (!get_n<NB>(ex + off + tid, G_END, tag, a.status, v, w)) *bad = 1;
+        if (nact == NB) {
+            if (!get_n<NB>(ex + off + tid, G_END, tag, a.status, v, w)) *bad = 1;
+        } else {
+            if (!get_rows<NB>(ex + off + tid, nact, tag, a.status, v, w)) *bad = 1;
+        }
 #pragma unroll
         for (int r = 0; r < NB; ++r) xs[r][buf][xs_index<32>(tid)] = v[r];
     }
@@ -264,6 +297,7 @@ __device__ __forceinline__ void tick_recurrent_role(const Ctx<NB>& c, int k, con
         if (*c.bad) break;
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
+            if (r >= c.nact) continue;                         // (a shared recurrent group's rows without a team)
             float y[3];
             dot_rows<3, 32>(w, c.xs[r][t & 1] + 36 * s, y);
             if (s == 0) {
@@ -429,9 +463,16 @@ __device__ __forceinline__ void beat_path_role(const Ctx<NR>& c, int role, int n
     }
 }
 
-template <int NJ, bool FUSED, int NB, int NBB>
+// Shared recurrent groups (round 6, NBR > NB): seven to sixteen measures used to run as teams of FOUR rows (49 workgroups each: four
+// two-row teams are all the chip holds) at 8-9 us per tick against 4.7 for a two-row team.  But only 17 of a team's 49 workgroups
+// are on the tick's critical path (C and the 16 TBi); TA and TBh produce the NEXT tick's recurrent summands and idle most of a
+// tick.  So they are shared: two-row critical teams (17 workgroups each, on one XCD) for every pair of rows, and recurrent groups
+// of 32 workgroups that serve NBR = 6 rows -- three teams -- each: 8 x 17 + 3 x 32 = 232 workgroups for sixteen measures, every
+// row on a two-row tick.  A group's rows without a team (the last group of a call) are skipped (Ctx.nact).
+template <int NJ, bool FUSED, int NB, int NBB, int NBR = NB>
 __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
-    __shared__ __attribute__((aligned(16))) float xs[NB > NBB ? NB : NBB][2][XS];
+    constexpr int XROWS = NB > NBB ? (NB > NBR ? NB : NBR) : (NBB > NBR ? NBB : NBR);
+    __shared__ __attribute__((aligned(16))) float xs[XROWS][2][XS];
     __shared__ float lgs[NB][32 * NJ];
     __shared__ int toks[NB];
     __shared__ int bad_s;
@@ -443,7 +484,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     const int wg = blockIdx.x / a.stride, tick_wgs = a.teams * kTickRoles;
     int team = (a.teams > 1 && wg < tick_wgs) ? wg / kTickRoles : 0;
     int role = a.teams > 1 ? (wg < tick_wgs ? wg % kTickRoles : kTickRoles + (wg - tick_wgs)) : wg;
-    if (a.place && !place_role((int)blockIdx.x, a.teams, a.fused ? kFusedRoles - kTickRoles : 0, team, role)) return;
+    if (a.place && !place_role((int)blockIdx.x, a.teams, a.rgroups ? a.rgroups : a.teams, a.fused ? kFusedRoles - kTickRoles : 0, team, role)) return;
     const int rb = team * NB, nrow = min(NB, a.B - rb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* const ex = a.ex + (long)rb * G_END;
@@ -451,7 +492,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     volatile int* const bad = &bad_s;
     if (tid == 0) bad_s = 0;
     __syncthreads();
-    const Ctx<NB> c{a, ex, xs, bad, tid, rb, nrow};
+    const Ctx<NB> c{a, ex, xs, bad, tid, rb, nrow, NB};
     const int nb = a.T / a.G;
     const DecodeB1Beat& bp = a.bp;
     // MG, the merged build: workgroup C does not exist, every TBi_k does C's work for itself next to its own (CB below)
@@ -476,6 +517,11 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
         int tok[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) { h0[r] = 0.f; tok[r] = a.V; }      // row V of the table: the start symbol x_0
+        float tb[NB][3];                                       // the tokens' rows of the gather table, requested a phase ahead
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
         if (!get_2d<NB, 3>(ex + G_GH0 + u, G_END, DH, 1u, a.status, gh, hw)) *bad = 1;
         for (int t = 0; t < a.T; ++t) {
             const bool more = t + 1 < a.T;
@@ -497,12 +543,8 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             }
             B1_STAMP(0, t, 0);
             {
-                // every row's token rows of the table are requested before the first cell (three L2 round trips per row otherwise)
-                float tb[NB][3];
-#pragma unroll
-                for (int r = 0; r < NB; ++r)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
+                // (every row's token rows of the table were requested the moment the tokens were known, behind the previous tick's
+                //  argmax and IN FRONT of the wait for this tick's gh0: two round trips side by side instead of one after the other)
 #pragma unroll
                 for (int r = 0; r < NB; ++r)
                     h0[r] = gru_cell(cg[r][0] + tb[r][0], cg[r][1] + tb[r][1], cg[r][2] + tb[r][2], gh[r][0], gh[r][1], gh[r][2], h0[r]);
@@ -578,10 +620,21 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 for (int r = 0; r < NB; ++r) tok[r] = toks[r];
             }
             B1_STAMP(0, t, 5);
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
+            }
             if (more && !get_2d<NB, 3>(ex + G_GH0 + u, G_END, DH, (unsigned)t + 2u, a.status, gh, hw, false)) *bad = 1;
             B1_STAMP(0, t, 6);
         }
     } else if (role < R_TBI) {
+        if (NBR != NB) {                                       // a shared group: rows [NBR team, NBR team + NBR) of the call
+            const int rbr = team * NBR;
+            const Ctx<NBR> cr{a, a.ex + (long)rbr * G_END, xs, bad, tid, rbr, min(NBR, a.B - rbr), min(NBR, a.teams * NB - rbr)};
+            tick_recurrent_role<NBR>(cr, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0);
+        } else
         tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0);
     } else if (role < R_TBH && MG) {
         // ---- CB_k (merged build): C's work REPLICATED in every TBi_k.  Layer 0's cell needs no product (its summands arrive), the
@@ -616,6 +669,11 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
         int tok[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) { h0[r] = 0.f; h1[r] = 0.f; tok[r] = a.V; }
+        float tb[NB][3];                                       // the tokens' rows of the gather table, requested a phase ahead
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
         if (!get_2d<NB, 3>(ex + G_GH0X + u, G_END, DH, 1u, a.status, gh, hw)) *bad = 1;
         for (int t = 0; t < a.T; ++t) {
             const bool more = t + 1 < a.T;
@@ -643,12 +701,8 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             }
             if (out) B1_STAMP(0, t, 0);
             {
-                float tb[NB][3];
-#pragma unroll
-                for (int r = 0; r < NB; ++r)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
-                // layer 1's recurrent summands were started a tick ago: requested here, next to the table rows
+                // (the token's rows of the table were requested behind the previous tick's argmax, in front of the wait for gh0)
+                // layer 1's recurrent summands were started a tick ago: requested here
                 if (cell) {
 #pragma unroll
                     for (int r = 0; r < NB; ++r)
@@ -744,6 +798,12 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 for (int r = 0; r < NB; ++r) tok[r] = toks[r];
             }
             if (out) B1_STAMP(0, t, 5);
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
+            }
             if (more && !get_2d<NB, 3>(ex + (((tag + 1u) & 1) ? G_GH0X : G_GH0) + u, G_END, DH, tag + 1u, a.status, gh, hw, false)) *bad = 1;
             if (out) B1_STAMP(0, t, 6);
         }
@@ -804,10 +864,15 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             if (k == 0) B1_STAMP(1, t, 4);
         }
     } else if (role < kTickRoles) {
+        if (NBR != NB) {
+            const int rbr = team * NBR;
+            const Ctx<NBR> cr{a, a.ex + (long)rbr * G_END, xs, bad, tid, rbr, min(NBR, a.B - rbr), min(NBR, a.teams * NB - rbr)};
+            tick_recurrent_role<NBR>(cr, role - R_TBH, a.W_hh1, a.b_hh1, 1, G_H1, G_GH1, G_H1X, G_GH1);
+        } else
         tick_recurrent_role<NB>(c, role - R_TBH, a.W_hh1, a.b_hh1, 1, G_H1, G_GH1, G_H1X, G_GH1);
     } else if (FUSED) {
         // (one team: the beat path serves the team's NB rows; several teams: all NBB rows of the call, from the call's first granule area)
-        const Ctx<NBB> cb{a, a.ex, xs, bad, tid, 0, min(NBB, a.B)};
+        const Ctx<NBB> cb{a, a.ex, xs, bad, tid, 0, min(NBB, a.B), NBB};
         beat_path_role<NBB>(cb, role, nb);
     }
     __syncthreads();
@@ -827,18 +892,23 @@ int mode() {
 }
 // workgroup ids a placed launch needs: the smallest count whose non-critical ids hold every non-critical role (and past the last
 // critical id)
-int placed_grid(int teams, int beat_wgs) {
-    const int need = teams * 2 * NU + beat_wgs;
+int placed_grid(int teams, int rteams, int beat_wgs) {
+    const int need = rteams * 2 * NU + beat_wgs;
     int g = 8 * (kCrit - 1) + teams;
     while (g - crit_below(g, teams) < need) ++g;
     return g;
 }
 }  // namespace
 
+constexpr int kSharedRows = 6;                   // rows a shared recurrent group serves (8: the group's tick is longer than the two-row teams' and sets the pace)
+// seven measures and more under mode 4: two-row critical teams + shared recurrent groups (the kernel's "Shared recurrent groups")
+static bool shared_groups(int B) { return mode() == 4 && B > 10; }    // (up to ten measures five whole two-row teams fit the chip: faster)
+static int shared_group_count(int B) { return (2 * ((B + 1) / 2) + kSharedRows - 1) / kSharedRows; }
 int decode_b1_team_rows(int B) {
     static const int forced = [] { const char* v = std::getenv("INET_DECODE_B1_TEAM_ROWS"); return v ? std::atoi(v) : 0; }();
     if (B <= 1) return 1;
     if (B <= 2) return 2;
+    if (shared_groups(B)) return 2;
     if (forced == 2 || forced == 4) return (B + forced - 1) / forced * kTickRoles <= 256 ? forced : 4;
     return B <= 10 ? 2 : 4;
 }
@@ -847,7 +917,8 @@ void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 4) ? 4 : m; }
 
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
     return mode() != 0 && chain_enabled() && B >= 1 && B <= kDecodeB1MaxRows && H == DH && V >= 1 && V <= 128 && T % G == 0 && T / G <= 4 &&
-           kFusedRoles <= chain_capacity() && decode_b1_teams(B) * kTickRoles <= chain_capacity();
+           kFusedRoles <= chain_capacity() &&
+           (shared_groups(B) ? placed_grid(decode_b1_teams(B), shared_group_count(B), 0) : decode_b1_teams(B) * kTickRoles) <= chain_capacity();
 }
 // the beat path's 80 workgroups go into the same launch when they fit beside the teams: one team, or two / three two-row teams (B <= 6:
 // 3 x 49 + 80 = 227 of 256 CUs); they then serve all (up to kBeatRowsMax) rows of the call
@@ -881,15 +952,18 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const double beat_w = a.fused ? 2.0 * DH * DZ + 9.0 * DH * DH + 3.0 * DH * DH + 3.0 * DH * DH : 0.0;
     ProfScope prof(PROF_GRU_FWD, 2.0 * d.B * (d.T * (9.0 * DH * DH + (double)d.V * DH) + beat_mac), s, label,
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
-    a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, a.fused ? kFusedRoles - kTickRoles : 0) <= chain_capacity();
-    const dim3 grid(a.place ? placed_grid(a.teams, a.fused ? kFusedRoles - kTickRoles : 0)
-                            : (a.teams * kTickRoles + (a.fused ? kFusedRoles - kTickRoles : 0)) * a.stride);
+    a.rgroups = (!a.fused && shared_groups(d.B)) ? shared_group_count(d.B) : 0;
+    const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
+    a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs) <= chain_capacity();
+    if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
+    const dim3 grid(a.place ? placed_grid(a.teams, rteams, beat_wgs) : (a.teams * kTickRoles + beat_wgs) * a.stride);
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
     if (a.fused && a.teams > 1 && (nbr != 2 || a.teams * 2 > kDecodeB1BeatRowsMax)) return -1;
 #define INET_B1(NJ, NBR)                                                                                                    \
     do {                                                                                                                    \
         if (a.fused && a.teams > 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 2, kDecodeB1BeatRowsMax>), grid, dim3(NT), 0, s, a); \
         else if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR, NBR>), grid, dim3(NT), 0, s, a);             \
+        else if (a.rgroups) hipLaunchKernelGGL((decode_b1_kernel<NJ, false, 2, 2, kSharedRows>), grid, dim3(NT), 0, s, a);     \
         else hipLaunchKernelGGL((decode_b1_kernel<NJ, false, NBR, NBR>), grid, dim3(NT), 0, s, a);                        \
     } while (0)
 #define INET_B1N(NJ) do { if (nbr == 1) INET_B1(NJ, 1); else if (nbr == 2) INET_B1(NJ, 2); else INET_B1(NJ, 4); } while (0)
