@@ -672,7 +672,7 @@ def roofline(step):
            "step_gflop": round(sum(r["gflop_per_launch"] * r["launches_per_step"] for r in table), 2),
            "step_kernel_ms": round(sum(r["ms_per_step"] for r in table), 4),
            "largest_by_instantiation": by_instantiation(table)[:3],
-           "kernels": table[:int(os.environ.get("INET_BENCH_TOPK", "8"))]}
+           "kernels": table[:8]}
     out["traffic_label_hash"] = pmc.get("label_hash")
     if stale:
         out["traffic_stale"] = {"reason": "the library launches labels the committed PMC file has never seen: its figures are "
@@ -963,7 +963,7 @@ def compact_line(out):
         "step_kernel_ms")}
     c = out.get("cpu_baseline")
     line["cpu_baseline"] = None if not c else {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
-    for k in ("parity_checked", "max_rel_err", "kink_violations", "chain_timeouts", "slow_waits"):
+    for k in ("parity_checked", "max_rel_err", "kink_violations", "chain_timeouts", "slow_waits", "waits_noted"):
         if k in out:
             line[k] = out[k]
     if out.get("first_steps_ms"):

@@ -302,14 +302,14 @@ int inet_gru_step(int batch, int H, const float* gi, const float* h_prev, const 
 int inet_set_option(int key, int value);
 /* key 2 = force the batched-GEMM tile configuration: value -1 = cost model (default), 0..4 = 64x64, 128x128, 192x64,
  * 192x128, 192x192 block tiles; key 3 = forced split-K factor (0 = none) used while key 2 is forced.  Test hooks: the
- * parity tests drive every tile configuration through the same shapes (also INET_GEMM_FORCE="cfg,split"). */
+ * parity tests drive every tile configuration through the same shapes (keys 2 and 3). */
 /* key 1 = deferred joins (default 0).  With 0 every *_bwd entry point makes `stream` wait for the side stream before
  * it returns.  With 1 it does not: the caller must keep every workspace passed to a *_bwd call alive and call
  * inet_side_join(stream) before anything reads the gradient arena (optimizer step, all-reduce) or frees those
  * workspaces.  Lets the leaf GEMMs of one module's backward overlap the next module's BPTT chain. */
 /* key 4 = chain kernels (default 1; INET_CHAIN=0): one persistent launch per recurrent layer, weights resident in
  * registers, the hidden state exchanged between workgroups once per step (csrc/chain.h).  0 = one launch per step. */
-/* key 5 = LDS-free GEMM kernels (csrc/gemm.hip; also INET_GEMM_DIRECT): 0 = LDS-tiled kernels only, 1 = by shape
+/* key 5 = LDS-free GEMM kernels (csrc/gemm.hip): 0 = LDS-tiled kernels only, 1 = by shape
  * (default: shared-strip direct kernels for the big products, workgroup split-K for the medium / small ones), 2 = the
  * direct kernels whenever the shape qualifies (test hook), 3 = direct kernels only (no split-K), 4 = split-K first, also for
  * the long weight-gradient products. */
@@ -322,11 +322,11 @@ int inet_set_option(int key, int value);
  * registers).  The BPTT chains always run on the first generation. */
 /* key 8 = the encoder's large products (csrc/gemm_bf3.hip; INET_GEMM_BF3): 9 (default) = on the bf16 matrix cores through the same
  * exact three-piece split, nine piece products; 0 = on the f32-input kernels of csrc/gemm.hip.
- * key 9 = which bf16 pieces the chain kernels write themselves (INET_EMIT; bit 0 the forward chains' rows, 1 their transposed pieces,
+ * key 9 = which bf16 pieces the chain kernels write themselves (bit 0 the forward chains' rows, 1 their transposed pieces,
  * 2 the BPTT kernel's dgi rows; default 7) -- what they do not write, bf3_split launches make from the f32 arrays: same results.
  * (Round 3's keys 10 and 11 and the value 6 of keys 7 / 8 -- weight-gradient pipe per layer, second-generation BPTT kernel, six
  * piece products -- selected builds that lost their A/Bs or were not fp32 arithmetic; they were removed in round 4: -1.)
- * key 12 = big-batch GRU forward steps on the bf16 pipe (csrc/gru_step_bf3.hip; INET_STEP_BF3_MIN_TILES): a layer whose single time
+ * key 12 = big-batch GRU forward steps on the bf16 pipe (csrc/gru_step_bf3.hip): a layer whose single time
  * step has at least this many tiles of 128 rows x 64 units (default 256 = one per CU: B = 2048 at H = 512, two directions) runs one
  * product per step with the GRU cell as its epilogue instead of chunked chain launches; 0 = never.
  * key 13 = how many of the side streams take leaf work in rotation from now on (0 = all that exist, default; 1: what a process with

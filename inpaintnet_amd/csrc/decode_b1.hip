@@ -905,7 +905,7 @@ constexpr int kSharedRows = 6;                   // rows a shared recurrent grou
 static bool shared_groups(int B) { return mode() == 4 && B > 10; }    // (up to ten measures five whole two-row teams fit the chip: faster)
 static int shared_group_count(int B) { return (2 * ((B + 1) / 2) + kSharedRows - 1) / kSharedRows; }
 int decode_b1_team_rows(int B) {
-    static const int forced = [] { const char* v = std::getenv("INET_DECODE_B1_TEAM_ROWS"); return v ? std::atoi(v) : 0; }();
+    constexpr int forced = 0;                                  // (round 5: an environment switch forced two- or four-row teams)
     if (B <= 1) return 1;
     if (B <= 2) return 2;
     if (shared_groups(B)) return 2;
@@ -959,16 +959,16 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const dim3 grid(a.place ? placed_grid(a.teams, rteams, beat_wgs) : (a.teams * kTickRoles + beat_wgs) * a.stride);
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
     if (a.fused && a.teams > 1 && (nbr != 2 || a.teams * 2 > kDecodeB1BeatRowsMax)) return -1;
-#define INET_B1(NJ, NBR)                                                                                                    \
+#define DISPATCH_B1(NJ, NBR)                                                                                                    \
     do {                                                                                                                    \
         if (a.fused && a.teams > 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 2, kDecodeB1BeatRowsMax>), grid, dim3(NT), 0, s, a); \
         else if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR, NBR>), grid, dim3(NT), 0, s, a);             \
         else if (a.rgroups) hipLaunchKernelGGL((decode_b1_kernel<NJ, false, 2, 2, kSharedRows>), grid, dim3(NT), 0, s, a);     \
         else hipLaunchKernelGGL((decode_b1_kernel<NJ, false, NBR, NBR>), grid, dim3(NT), 0, s, a);                        \
     } while (0)
-#define INET_B1N(NJ) do { if (nbr == 1) INET_B1(NJ, 1); else if (nbr == 2) INET_B1(NJ, 2); else INET_B1(NJ, 4); } while (0)
-    if (nj <= 1) INET_B1N(1); else if (nj == 2) INET_B1N(2); else if (nj == 3) INET_B1N(3); else INET_B1N(4);
-#undef INET_B1N
-#undef INET_B1
+#define DISPATCH_B1N(NJ) do { if (nbr == 1) DISPATCH_B1(NJ, 1); else if (nbr == 2) DISPATCH_B1(NJ, 2); else DISPATCH_B1(NJ, 4); } while (0)
+    if (nj <= 1) DISPATCH_B1N(1); else if (nj == 2) DISPATCH_B1N(2); else if (nj == 3) DISPATCH_B1N(3); else DISPATCH_B1N(4);
+#undef DISPATCH_B1N
+#undef DISPATCH_B1
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -58,8 +58,7 @@ constexpr int kDecodeB1MaxRows = 16;              // rows (measures) per call th
                                                   // workgroups, up to five teams (tick path only beyond one team)
 // rows per team and teams for a call of B rows.  One team up to B = 2; beyond, teams of TWO rows while they fit
 // the chip (a two-row tick is 5.5 us, a four-row tick 8.4: 5 teams x 49 workgroups = 245 of 256 CUs -> B <= 10), else of four.
-// (INET_DECODE_B1_TEAM_ROWS=4: four-row teams from B = 3 on, with the beat path folded in at B = 3, 4: the first build of the round.)
-int decode_b1_team_rows(int B);                   // (decode_b1.hip: the rule above, or INET_DECODE_B1_TEAM_ROWS)
+int decode_b1_team_rows(int B);                   // (decode_b1.hip: the rule above; mode 4 shares the recurrent groups beyond ten measures)
 inline int decode_b1_teams(int B) { const int r = decode_b1_team_rows(B); return (B + r - 1) / r; }
 constexpr int kDecodeB1BeatRowsMax = 6;           // rows the beat path's workgroups serve when they share the launch with several teams
 // granule areas of a call: one per row of every team; three to six measures: at least kDecodeB1BeatRowsMax (the folded beat path

@@ -460,7 +460,7 @@ inline int groups_of(int B) { const int ms = rows_ms(B); return (B + 16 * ms - 1
 bool decode_chain_ok(int B, int H, int V, int T, int G) {
     if (!chain_enabled() || (H != 256 && H != 512) || B < 1 || V < 1 || V > 128 || T % G != 0) return false;
     if (groups_of(B) > kDecodeMaxGroups || groups_of(B) * (H / 16) > chain_capacity()) return false;   // every workgroup resident at once
-    static const bool off = [] { const char* v = std::getenv("INET_DECODE_CHAIN"); return v && v[0] == '0'; }();
+    constexpr bool off = false;
     if (off) return false;
     const int ms = rows_ms(B);
     return ((V + 15) / 16) * ms <= H / 16;                   // one member per (row block, 16-column block) logits tile
@@ -489,7 +489,7 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
                    4.0 * (9.0 * a.H * a.H + (double)a.V * a.H + (double)a.B * a.T * a.V +
                           (train ? 13.0 * a.T * a.B * a.H : 0.0)));
     const dim3 grid(chain::blocks_for(groups, a.members));
-#define INET_DC5(M, Q, TR, NVV, VRR)                                                                                    \
+#define DISPATCH_DC5(M, Q, TR, NVV, VRR)                                                                                    \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
@@ -499,28 +499,28 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s) {
         }                                                                                                               \
         hipLaunchKernelGGL((decode_chain_kernel<M, Q, TR, NVV, VRR>), grid, dim3(256), lds, s, a);                      \
     } while (0)
-#define INET_DC4(M, Q, TR, NVV) INET_DC5(M, Q, TR, NVV, 0)
-#define INET_DC(M, Q, TR) INET_DC4(M, Q, TR, 0)
+#define DISPATCH_DC4(M, Q, TR, NVV) DISPATCH_DC5(M, Q, TR, NVV, 0)
+#define DISPATCH_DC(M, Q, TR) DISPATCH_DC4(M, Q, TR, 0)
     if (train) {
-        if (a.H == 512) { if (ms == 1) INET_DC(1, 8, true); else if (ms == 2) INET_DC(2, 8, true); else INET_DC(4, 8, true); }
-        else { if (ms == 1) INET_DC(1, 4, true); else if (ms == 2) INET_DC(2, 4, true); else INET_DC(4, 4, true); }
+        if (a.H == 512) { if (ms == 1) DISPATCH_DC(1, 8, true); else if (ms == 2) DISPATCH_DC(2, 8, true); else DISPATCH_DC(4, 8, true); }
+        else { if (ms == 1) DISPATCH_DC(1, 4, true); else if (ms == 2) DISPATCH_DC(2, 4, true); else DISPATCH_DC(4, 4, true); }
     } else {
         // small-batch inference (one row block per group, V <= 64): every member computes the whole logits row itself
-        static const bool fullv = [] { const char* v = std::getenv("INET_DECODE_FULLV"); return !(v && v[0] == '0'); }();
+        constexpr bool fullv = true;
         const int nv = (fullv && ms == 1 && a.V <= 64) ? (a.V <= 48 ? 3 : 4) : 0;
         // one row (b = 1 inpainting): the contractions on the VALU instead of one-sixteenth-full MFMA tiles
-        static const bool valu = [] { const char* v = std::getenv("INET_DECODE_VALU"); return !(v && v[0] == '0'); }();
+        constexpr bool valu = true;
         // (one row only: the four-row build of the H = 512 kernel spills ~300 registers)
         const int vr = (valu && nv > 0 && a.B == 1) ? 1 : 0;
-        if (nv == 3 && vr == 1) { if (a.H == 512) INET_DC5(1, 8, false, 3, 1); else INET_DC5(1, 4, false, 3, 1); }
-        else if (nv == 4 && vr == 1) { if (a.H == 512) INET_DC5(1, 8, false, 4, 1); else INET_DC5(1, 4, false, 4, 1); }
-        else if (nv == 3) { if (a.H == 512) INET_DC4(1, 8, false, 3); else INET_DC4(1, 4, false, 3); }
-        else if (nv == 4) { if (a.H == 512) INET_DC4(1, 8, false, 4); else INET_DC4(1, 4, false, 4); }
-        else if (a.H == 512) { if (ms == 1) INET_DC(1, 8, false); else if (ms == 2) INET_DC(2, 8, false); else INET_DC(4, 8, false); }
-        else { if (ms == 1) INET_DC(1, 4, false); else if (ms == 2) INET_DC(2, 4, false); else INET_DC(4, 4, false); }
+        if (nv == 3 && vr == 1) { if (a.H == 512) DISPATCH_DC5(1, 8, false, 3, 1); else DISPATCH_DC5(1, 4, false, 3, 1); }
+        else if (nv == 4 && vr == 1) { if (a.H == 512) DISPATCH_DC5(1, 8, false, 4, 1); else DISPATCH_DC5(1, 4, false, 4, 1); }
+        else if (nv == 3) { if (a.H == 512) DISPATCH_DC4(1, 8, false, 3); else DISPATCH_DC4(1, 4, false, 3); }
+        else if (nv == 4) { if (a.H == 512) DISPATCH_DC4(1, 8, false, 4); else DISPATCH_DC4(1, 4, false, 4); }
+        else if (a.H == 512) { if (ms == 1) DISPATCH_DC(1, 8, false); else if (ms == 2) DISPATCH_DC(2, 8, false); else DISPATCH_DC(4, 8, false); }
+        else { if (ms == 1) DISPATCH_DC(1, 4, false); else if (ms == 2) DISPATCH_DC(2, 4, false); else DISPATCH_DC(4, 4, false); }
     }
-#undef INET_DC
-#undef INET_DC4
-#undef INET_DC5
+#undef DISPATCH_DC
+#undef DISPATCH_DC4
+#undef DISPATCH_DC5
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -711,10 +711,9 @@ __global__ void gemm_epilogue_kernel(float* __restrict__ C, long ldc, int M, int
     }
 }
 
-// INET_GEMV=0: products of <= 8 rows on the tile kernels (A/B switch)
 bool gemv_enabled() { return true; }
-int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (INET_GEMM_FORCE="cfg,split"), -1: cost model
-int g_direct = -1;   // INET_GEMM_DIRECT: 0 never, 1 (default) by shape, 2 direct whenever applicable, 3 big shapes only, 4 split-K first
+int g_force_cfg = -2, g_force_split = 0;      // -2: not read yet (inet_set_option keys 2, 3), -1: cost model
+int g_direct = 1;    // direct kernels (inet_set_option key 5): 0 never, 1 (default) by shape, 2 direct whenever applicable, 3 big shapes only, 4 split-K first
 
 struct DirectCfg { int ta, tb; };
 const DirectCfg kDirect[] = {{3, 2}, {2, 2}, {3, 3}};
@@ -859,7 +858,7 @@ int launch_gemm_ks(const GemmArgs& gin, hipStream_t s, int force_split) {
     const double kL2[] = {1.0, 1.15, 1.5, 0.95, 0.95};
     int bi = -1, bs = 1;
     double best = 1e300;
-    static const bool wide46 = [] { const char* v = std::getenv("INET_KS_64x96"); return !(v && v[0] == '0'); }();
+    constexpr bool wide46 = true;
     for (int ci = 0; ci < 5; ++ci) {
         const KsCfg& c = kKs[ci];
         if (g.M % (16 * c.ta) || g.N % (16 * c.tb)) continue;
@@ -921,10 +920,9 @@ void launch_ks_group(const GemmGroupArgs& a, bool akm, bool bkm, dim3 grid, hipS
 }
 
 // Independent products in ONE launch of the workgroup split-K kernel when all of them have the same operand layout and a
-// common tile shape divides them (INET_GEMM_GROUP=0: always one after the other); else one launch each.
+// common tile shape divides them (a switch of earlier rounds ran them one after the other); else one launch each.
 int launch_gemm_group(const GemmArgs* list, int n, hipStream_t s) {
-    static const bool grouped = [] { const char* v = std::getenv("INET_GEMM_GROUP"); return !(v && v[0] == '0'); }();
-    if (g_direct < 0) { const char* v = std::getenv("INET_GEMM_DIRECT"); g_direct = v ? std::atoi(v) : 1; }
+    constexpr bool grouped = true;
     {   // a group of few-row products of one M (the beat -> tick projections of a b = 1 decode call): one launch of the wave-per-column kernel
         bool gv = grouped && n >= 2 && n <= kGemmGroupMax && g_force_cfg < 0 && gemv_enabled() && list[0].M >= 1 && list[0].M <= 8;
         int maxN = 0;
@@ -1037,14 +1035,7 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     GemmArgs g = gin;
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.K <= 0) return -1;
-    if (g_direct < 0) {
-        const char* v = std::getenv("INET_GEMM_DIRECT");
-        g_direct = v ? std::atoi(v) : 1;
-    }
-    if (g_force_cfg == -2) {
-        g_force_cfg = -1;
-        if (const char* v = std::getenv("INET_GEMM_FORCE")) std::sscanf(v, "%d,%d", &g_force_cfg, &g_force_split);
-    }
+    if (g_force_cfg == -2) g_force_cfg = -1;
     if (g.nbatch > 1) {
         // several products of one shape: one launch of the shared-strip direct kernel when it applies (half the split-K
         // factor of a single product for the same 256 workgroups), else one product after the other
@@ -1101,7 +1092,7 @@ int launch_gemm(const GemmArgs& gin, hipStream_t s) {
     }
     if (g_direct > 0 && force_cfg < 0) {
         // The long weight-gradient products go to the shared-strip direct kernel first.  Workgroup split-K with 96x64 tiles
-        // (INET_GEMM_DIRECT=4 tries it first) is 8-15 % faster alone (no zero-fill, 1/4 of the atomics) but 1 % slower
+        // (g_direct = 4 tries it first) is 8-15 % faster alone (no zero-fill, 1/4 of the atomics) but 1 % slower
         // in the training step, where its doubled L2 traffic competes with the BPTT chain on the other stream.
         int rc = 1;
         if (gin.a_kmajor && g_direct != 4) rc = launch_gemm_direct(gin, s, force_split);

@@ -222,7 +222,7 @@ int launch_cfg(const Bf3Gemm& g, int kb_per, hipStream_t s) {
     const size_t lds = (size_t)2 * (TMB + TNB) * 3 * 1024;
     // XCD-aware tile order (Bf3Map): the arrangement with the fewest strip bytes per XCD, counting every block of 32 tiles as
     // fetching its strips afresh (an L2 holds ~4 MB; a strip is K * 6 bytes * 192 or 128 rows)
-    static const int map_on = [] { const char* v = std::getenv("INET_BF3_MAP"); return v ? std::atoi(v) : 1; }();
+    constexpr int map_on = 1;
     Bf3Map mp{1, 0, 0, 0, 0};
     if (map_on && g.ksplit == 1 && g.nbatch <= 1 && (tiles_m * tiles_n) % 256 == 0) {
         double best = 0.0;

@@ -420,14 +420,14 @@ int launch_gru_fwd(const GruFwdBatch& bin, hipStream_t s) {
         by += 4.0 * (3.0 * b.H * (b.H + (hasx ? b.p[i].K2 : 0)) +
                      (double)b.p[i].B * b.H * (2 + (b.p[i].gi_dense ? 3 : 0) + (b.p[i].sv_r ? 5 : 0) + (hasx ? 1 : 0)));
     ProfScope prof(PROF_GRU_FWD, fl, s, label, by);
-#define INET_FWD(X, M)                                                                                       \
+#define DISPATCH_FWD(X, M)                                                                                       \
     do {                                                                                                     \
         if (pk) hipLaunchKernelGGL((gru_step_fwd_kernel<X, M, true>), grid, dim3(256), 0, s, b);             \
         else hipLaunchKernelGGL((gru_step_fwd_kernel<X, M, false>), grid, dim3(256), 0, s, b);               \
     } while (0)
-    if (hasx) { if (ms == 2) INET_FWD(true, 2); else INET_FWD(true, 4); }
-    else { if (ms == 2) INET_FWD(false, 2); else INET_FWD(false, 4); }
-#undef INET_FWD
+    if (hasx) { if (ms == 2) DISPATCH_FWD(true, 2); else DISPATCH_FWD(true, 4); }
+    else { if (ms == 2) DISPATCH_FWD(false, 2); else DISPATCH_FWD(false, 4); }
+#undef DISPATCH_FWD
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -457,15 +457,15 @@ int launch_gru_bwd(const GruBwdBatch& bin, hipStream_t s) {
     for (int i = 0; i < b.nprob; ++i)
         by += 4.0 * ((b.p[i].dgh_next ? 3.0 * b.H * b.H : 0.0) + (double)b.p[i].B * b.H * (3 + 6 + 5 + 2 + 1));
     ProfScope prof(PROF_GRU_BWD, fl, s, label, by);
-#define INET_BWD(M, C)                                                                                       \
+#define DISPATCH_BWD(M, C)                                                                                       \
     do {                                                                                                     \
         if (pk) hipLaunchKernelGGL((gru_step_bwd_kernel<M, C, true>), grid, dim3(256), 0, s, b);             \
         else hipLaunchKernelGGL((gru_step_bwd_kernel<M, C, false>), grid, dim3(256), 0, s, b);               \
     } while (0)
-    if (nc == 2) INET_BWD(4, 2);
-    else if (ms == 2) INET_BWD(2, 1);
-    else INET_BWD(4, 1);
-#undef INET_BWD
+    if (nc == 2) DISPATCH_BWD(4, 2);
+    else if (ms == 2) DISPATCH_BWD(2, 1);
+    else DISPATCH_BWD(4, 1);
+#undef DISPATCH_BWD
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -478,17 +478,17 @@ int launch_logits_argmax(const float* h, long ldh, int B, int H, const float* W,
     const bool pk = hpk && Wpk && H % 256 == 0;
     const float* a = pk ? hpk : h;
     const float* w = pk ? Wpk : W;
-#define INET_LOGITS(NBV)                                                                                                \
+#define DISPATCH_LOGITS(NBV)                                                                                                \
     do {                                                                                                                \
         if (pk) hipLaunchKernelGGL((logits_argmax_kernel<NBV, true>), grid, dim3(256), 0, s, a, ldh, B, H, w, bias, out, ldo, samples, sstride);  \
         else hipLaunchKernelGGL((logits_argmax_kernel<NBV, false>), grid, dim3(256), 0, s, a, ldh, B, H, w, bias, out, ldo, samples, sstride);    \
     } while (0)
     switch (V / 16) {
-        case 1: INET_LOGITS(1); break;
-        case 2: INET_LOGITS(2); break;
-        case 3: INET_LOGITS(3); break;
-        default: INET_LOGITS(4); break;
+        case 1: DISPATCH_LOGITS(1); break;
+        case 2: DISPATCH_LOGITS(2); break;
+        case 3: DISPATCH_LOGITS(3); break;
+        default: DISPATCH_LOGITS(4); break;
     }
-#undef INET_LOGITS
+#undef DISPATCH_LOGITS
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -19,12 +19,8 @@
 // Contraction schedule of the forward / backward kernels (chain.h): the backward kernels (K = 3H, 24 k-steps per wave)
 // stream their A fragments with dealt, pinned loads -- 274 -> 246 us per encoder launch, 4.354 -> 4.340 ms per training
 // step; the forward kernels (8 k-steps per wave) measure the same either way and keep the chunked double buffer.
-#ifndef INET_GRU_CONTRACT
-#define INET_GRU_CONTRACT contract
-#endif
-#ifndef INET_GRU_CONTRACT_B
-#define INET_GRU_CONTRACT_B contract_stream
-#endif
+#define GRU_CONTRACT contract
+#define GRU_CONTRACT_B contract_stream
 
 using namespace ksplit;
 
@@ -134,7 +130,7 @@ __global__ __launch_bounds__(256, OCC) void gru_chain_fwd_kernel(GruChainFwd A) 
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
             for (int a = 0; a < 3; ++a) acc[ms][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (recur) chain::INET_GRU_CONTRACT<MS, 3, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
+        if (recur) chain::GRU_CONTRACT<MS, 3, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S, w * SQ, lane);
         float v[MS][3];
         reduce_waves<MS, 3>(acc, red, t, v);
         // gates first, then the hand-off (what the other members wait for), then the stores nobody in the launch reads
@@ -278,12 +274,12 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(GruChainBwd A) {
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) acc[ms][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (MS == 8) {               // two 64-row tiles against the same register-resident W slice
-                chain::INET_GRU_CONTRACT_B<4, 1, SQ>(reinterpret_cast<f32x4(&)[4][4]>(acc[0]), Wr, rs, ((step + 1) & 1) * slot_bytes, rb0,
+                chain::GRU_CONTRACT_B<4, 1, SQ>(reinterpret_cast<f32x4(&)[4][4]>(acc[0]), Wr, rs, ((step + 1) & 1) * slot_bytes, rb0,
                                           rb_last, S3, w * SQ, lane);
-                chain::INET_GRU_CONTRACT_B<4, 1, SQ>(reinterpret_cast<f32x4(&)[4][4]>(acc[4]), Wr, rs, ((step + 1) & 1) * slot_bytes, rb0 + 4,
+                chain::GRU_CONTRACT_B<4, 1, SQ>(reinterpret_cast<f32x4(&)[4][4]>(acc[4]), Wr, rs, ((step + 1) & 1) * slot_bytes, rb0 + 4,
                                           rb_last, S3, w * SQ, lane);
             } else {
-                chain::INET_GRU_CONTRACT_B<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S3, w * SQ, lane);
+                chain::GRU_CONTRACT_B<MS, 1, SQ>(acc, Wr, rs, ((step + 1) & 1) * slot_bytes, rb0, rb_last, S3, w * SQ, lane);
             }
             reduce_waves<MS, 1>(acc, red, t, v);
         }
@@ -395,8 +391,8 @@ int chain_prio() {
 }  // namespace
 
 // H = 1024 (LatentRNN's generator; round 4): first-generation kernels with 192 registers of W_hh per lane, a group's 64 members
-// on two XCDs (chain.h decode_block); INET_CHAIN_H1024=0: that layer on the per-step kernels, as in rounds 1-3
-static bool h1024_on() { static const bool v = [] { const char* e = std::getenv("INET_CHAIN_H1024"); return !(e && e[0] == '0'); }(); return v; }
+// on two XCDs (chain.h decode_block); (rounds 1-3 ran that layer on the per-step kernels)
+static bool h1024_on() { return true; }
 bool gru_chain_ok(int H, int B, int T, int nprob) {
     if (H == 1024 && !h1024_on()) return false;
     if ((double)T * B * 6.0 * H >= 2.0e9) return false;   // the kernels index with 32-bit element offsets
@@ -449,12 +445,12 @@ int launch_gru_chain_fwd(GruChainFwd a, hipStream_t s) {
     ProfScope prof(PROF_GRU_FWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))));
     const dim3 grid(chain::blocks_for(groups, a.members));
-#define INET_CF(M, Q, O) hipLaunchKernelGGL((gru_chain_fwd_kernel<M, Q, O>), grid, dim3(256), 0, s, a)
-    if (a.shared_chip && ms == 4) { if (a.H == 512) INET_CF(4, 8, 2); else INET_CF(4, 4, 2); }
-    else if (a.H == 1024) { if (ms == 1) INET_CF(1, 16, 1); else if (ms == 2) INET_CF(2, 16, 1); else INET_CF(4, 16, 1); }   // (LatentRNN's generator: 192 registers of W_hh per lane)
-    else if (a.H == 512) { if (ms == 1) INET_CF(1, 8, 1); else if (ms == 2) INET_CF(2, 8, 1); else INET_CF(4, 8, 1); }
-    else { if (ms == 1) INET_CF(1, 4, 1); else if (ms == 2) INET_CF(2, 4, 1); else INET_CF(4, 4, 1); }
-#undef INET_CF
+#define DISPATCH_CF(M, Q, O) hipLaunchKernelGGL((gru_chain_fwd_kernel<M, Q, O>), grid, dim3(256), 0, s, a)
+    if (a.shared_chip && ms == 4) { if (a.H == 512) DISPATCH_CF(4, 8, 2); else DISPATCH_CF(4, 4, 2); }
+    else if (a.H == 1024) { if (ms == 1) DISPATCH_CF(1, 16, 1); else if (ms == 2) DISPATCH_CF(2, 16, 1); else DISPATCH_CF(4, 16, 1); }   // (LatentRNN's generator: 192 registers of W_hh per lane)
+    else if (a.H == 512) { if (ms == 1) DISPATCH_CF(1, 8, 1); else if (ms == 2) DISPATCH_CF(2, 8, 1); else DISPATCH_CF(4, 8, 1); }
+    else { if (ms == 1) DISPATCH_CF(1, 4, 1); else if (ms == 2) DISPATCH_CF(2, 4, 1); else DISPATCH_CF(4, 4, 1); }
+#undef DISPATCH_CF
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -486,12 +482,12 @@ int launch_gru_chain_bwd(GruChainBwd a, hipStream_t s) {
     ProfScope prof(PROF_GRU_BWD, 2.0 * rows * 3.0 * a.H * a.H, s, label,
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (6 + 5 + 1)) + (emr ? 18.0 * rows * a.H : 0.0));
     const dim3 grid(chain::blocks_for(groups, a.members));
-#define INET_CB(M, Q) hipLaunchKernelGGL((gru_chain_bwd_kernel<M, Q>), grid, dim3(256), 0, s, a)
+#define DISPATCH_CB(M, Q) hipLaunchKernelGGL((gru_chain_bwd_kernel<M, Q>), grid, dim3(256), 0, s, a)
     if (emr) hipLaunchKernelGGL((gru_chain_bwd_kernel<4, 24, true>), grid, dim3(256), 0, s, a);
     else
-    if (a.H == 1024) { if (ms == 1) INET_CB(1, 48); else if (ms == 2) INET_CB(2, 48); else if (ms == 4) INET_CB(4, 48); else return -1; }
-    else if (a.H == 512) { if (ms == 1) INET_CB(1, 24); else if (ms == 2) INET_CB(2, 24); else if (ms == 4) INET_CB(4, 24); else INET_CB(8, 24); }
-    else { if (ms == 1) INET_CB(1, 12); else if (ms == 2) INET_CB(2, 12); else if (ms == 4) INET_CB(4, 12); else INET_CB(8, 12); }
-#undef INET_CB
+    if (a.H == 1024) { if (ms == 1) DISPATCH_CB(1, 48); else if (ms == 2) DISPATCH_CB(2, 48); else if (ms == 4) DISPATCH_CB(4, 48); else return -1; }
+    else if (a.H == 512) { if (ms == 1) DISPATCH_CB(1, 24); else if (ms == 2) DISPATCH_CB(2, 24); else if (ms == 4) DISPATCH_CB(4, 24); else DISPATCH_CB(8, 24); }
+    else { if (ms == 1) DISPATCH_CB(1, 12); else if (ms == 2) DISPATCH_CB(2, 12); else if (ms == 4) DISPATCH_CB(4, 12); else DISPATCH_CB(8, 12); }
+#undef DISPATCH_CB
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -17,7 +17,7 @@
 //   piece p of a [rows, K] state: [row/16][K/32][lane = (k%32)/8 * 16 + row%16][8 bf16 = k%8]   (1 KB per fragment)
 // Semantics (operand sources, masks, saves, h0 / hlast / dh0, reverse, row chunks) are those of the first-generation kernels;
 // tests run both against the oracle (INET_CHAIN2=0 selects the first generation).  The forward kernel is the default for chains of
-// >= 6 steps; the BPTT kernel is behind INET_CHAIN2_BWD=1: it is the faster kernel alone and the slower step, because a workgroup
+// >= 6 steps; the second-generation BPTT kernel was removed in round 4: it was the faster kernel alone and the slower step, because a workgroup
 // of it holds the CU's LDS and keeps the backward pass's leaf work out (gru_chain.hip gru_chain_bwd_is_v2).
 #include <cstdio>
 #include <cstdlib>
@@ -27,9 +27,6 @@
 
 namespace {
 
-#ifndef INET_EM_TOUCH
-#define INET_EM_TOUCH 0           // 1: the ChainEmit descriptor is pinned in SGPRs before the step loop (27 spilled SGPRs in the forward build)
-#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 using chain::u32x4;
 #ifndef INET_CHAIN2_STAMPS
@@ -459,7 +456,7 @@ int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
                    4.0 * (a.nprob * 3.0 * a.H * a.H + rows * a.H * (2 + 3 + (a.p[0].sv ? 5 : 0))) + em_bytes);
     const dim3 grid(chain::blocks_for(groups, a.members));
     const size_t lds = (size_t)3 * 3 * (a.H / 32) * 1024 + (size_t)wv * 256 * 4 * (em ? 4 : 1);
-#define INET_C2F_(W, S, N, E)                                                                                           \
+#define DISPATCH_C2F_(W, S, N, E)                                                                                           \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
@@ -469,15 +466,15 @@ int launch_gru_chain2_fwd(GruChainFwd a, hipStream_t s) {
         }                                                                                                               \
         hipLaunchKernelGGL((gru_chain2_fwd_kernel<W, S, N, E>), grid, dim3(64 * W), lds, s, a);                         \
     } while (0)
-#define INET_C2F(W, S, N)                                                                                               \
+#define DISPATCH_C2F(W, S, N)                                                                                               \
     do {                                                                                                                \
-        if (em) INET_C2F_(4, S, N, true);                                                                               \
-        else INET_C2F_(4, S, N, false);                                                                                 \
+        if (em) DISPATCH_C2F_(4, S, N, true);                                                                               \
+        else DISPATCH_C2F_(4, S, N, false);                                                                                 \
     } while (0)
     if (np != 9 || wv != 4) return -1;
-    if (a.H == 512) INET_C2F(4, 16, 9);
-    else INET_C2F(4, 8, 9);
-#undef INET_C2F
-#undef INET_C2F_
+    if (a.H == 512) DISPATCH_C2F(4, 16, 9);
+    else DISPATCH_C2F(4, 8, 9);
+#undef DISPATCH_C2F
+#undef DISPATCH_C2F_
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -12,7 +12,7 @@ struct GruStepsBf3 {
     const unsigned char* Wp[2];          // gru_step_bf3_split_w() of W_hh: gru_step_bf3_w_bytes(H) bytes each
 };
 // shape rule: bf3 products on, H % 64 == 0, B % 128 == 0, one launch fills the chip (>= 256 tiles of 128 rows x 64 units;
-// INET_STEP_BF3_MIN_TILES overrides, 0 = never)
+// inet_set_option key 12 overrides, 0 = never)
 bool gru_step_bf3_ok(int H, int B, int T, int nd);
 void gru_step_bf3_set_min_tiles(int n);                    // inet_set_option key 12 (0: never take this path)
 size_t gru_step_bf3_w_bytes(int H);

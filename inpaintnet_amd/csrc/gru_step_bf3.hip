@@ -467,7 +467,7 @@ int launch_one(const StepArgs& a, hipStream_t s) {
 namespace {
 int g_min_tiles = -1;
 int min_tiles_now() {
-    if (g_min_tiles < 0) { const char* v = std::getenv("INET_STEP_BF3_MIN_TILES"); g_min_tiles = v ? std::atoi(v) : 256; if (g_min_tiles < 0) g_min_tiles = 0; }
+    if (g_min_tiles < 0) g_min_tiles = 256;
     return g_min_tiles;
 }
 }  // namespace

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void lstm_chain_fwd_kernel(LstmChainFwdArgs P)
     }
 }
 
-// The same layer with a DATA-DRIVEN hand-off (INET_LSTM_TAG=1): no counter.  The exchange is a ring of 4 slots; a slot that
+// The same layer with a DATA-DRIVEN hand-off (the default for small tiles): no counter.  The exchange is a ring of 4 slots; a slot that
 // is about to receive step t's state holds a sentinel (all bits set: no finite float) in every element, the members poll the
 // fragments they need themselves until no lane sees the sentinel, and every producer re-arms the slot of step t + 2 right
 // after publishing step t (its previous contents, step t - 2, have been consumed by everybody: a member that publishes step t
@@ -699,10 +699,10 @@ int lstm_chunk_fwd(int B, int T, int H, const float* gi, const float* W_hh, cons
     const long BH = (long)B * H, TBH = (long)T * BH;
     const int ms = chain_ms(B, H), groups = (B + 16 * ms - 1) / (16 * ms);
     const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
-    // tagged hand-off (lstm_chain_fwd_tag_kernel) for the small tiles; INET_LSTM_TAG=0: the counter protocol.  (The same
+    // tagged hand-off (lstm_chain_fwd_tag_kernel) for the small tiles; the counter protocol otherwise.  (The same
     // for the backward chain -- 16 fragments per lane to poll, four gate blocks per member to wait for -- measured slower
     // than its counter: 9.34 vs 9.23 ms per AnticipationRNN step with both, 8.87 with the forward chains only.)
-    static const bool tag_on = [] { const char* e = std::getenv("INET_LSTM_TAG"); return !(e && e[0] == '0'); }();
+    constexpr bool tag_on = true;
     const bool tagged = tag_on && H == 256 && chain_ms(B, H) <= 2;
     // counters zeroed; tagged: slots 0, 1 armed and slot 3 = the previous step's h; counter protocol: slot 1 = that h
     // (a tagged chunk behind another chunk of the same layer and call finds all of that in the ring: ring_goes_on)
@@ -766,10 +766,9 @@ int lstm_chunk_bwd(int B, int T, int H, const float* dout, const float* dhT, con
                      : launch_chain(lstm_chain_bwd_kernel<4, 32>, a, groups, s);
 }
 
-// XCD the second chain of a two-layer pipeline starts its groups on (the first starts on XCD 0): INET_LSTM_XROT
+// XCD the second chain of a two-layer pipeline starts its groups on (the first starts on XCD 0)
 int lstm_pipe_xrot() {
-    static const int v = [] { const char* e = std::getenv("INET_LSTM_XROT"); return e ? std::atoi(e) & 7 : 4; }();
-    return v;
+    return 4;
 }
 int lstm_chunk_steps() {
     static const int v = [] { const char* e = std::getenv("INET_LSTM_CHUNK"); return e ? std::atoi(e) : 32; }();
@@ -800,8 +799,8 @@ int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, con
     const long BH = (long)B * H;
     if (pw_zero(w0.zeros, BH, s) != 0 || pw_zero(w1.zeros, BH, s) != 0) return -2;
     hipStream_t s2 = twin_fork(s);
-    static const bool third = [] { const char* e = std::getenv("INET_LSTM_THIRD"); return !(e && e[0] == '0'); }();
-    static const bool ring_on = [] { const char* e = std::getenv("INET_LSTM_RING"); return !(e && e[0] == '0'); }();
+    constexpr bool third = true;
+    constexpr bool ring_on = true;
     for (int s_lo = 0; s_lo < T; s_lo += CH) {
         const int nt = T - s_lo < CH ? T - s_lo : CH;
         const long t_lo = reverse ? T - (s_lo + nt) : s_lo, tp = reverse ? t_lo + nt : t_lo - 1;
@@ -835,7 +834,7 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
     INET_TRY(pw_transpose(W_hh0, H, w0.whhT, 4L * H, 4 * H, H, s));
     INET_TRY(pw_transpose(W_hh1, H, w1.whhT, 4L * H, 4 * H, H, s));
     hipStream_t s2 = twin_fork(s);
-    static const bool third = [] { const char* e = std::getenv("INET_LSTM_THIRD"); return !(e && e[0] == '0'); }();
+    constexpr bool third = true;
     const int nchunks = (T + CH - 1) / CH;
     const bool areas = nchunks <= kMaxChunks;            // one pre-zeroed counter area per chunk and layer
     if (areas && (hipMemsetAsync(w0.sync + kSyncWords, 0, (kSyncWordsAll - kSyncWords) * sizeof(unsigned), s) != hipSuccess ||
@@ -863,8 +862,8 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
     // was slower -- 9.2 -> 10.5 ms per AnticipationRNN step: beside the chains they slow every hand-off):
     // dW_hh += sum_t dg(t)^T h_prev(t) with h_prev(t) = out(t -/+ 1) (zero initial state); dW_ih1 += dgi1^T out0.
     // Layer 1's two products start when ITS last chunk is done -- the caller's stream, before it joins layer 0's -- and run under
-    // layer 0's last chunk; only dW_hh0 is left behind the pipeline (INET_LSTM_WGRAD_EARLY=0: all three behind it).
-    static const bool early = [] { const char* e = std::getenv("INET_LSTM_WGRAD_EARLY"); return !(e && e[0] == '0'); }();
+    // layer 0's last chunk; only dW_hh0 is left behind the pipeline (a switch of round 4 put all three behind it).
+    constexpr bool early = true;
     auto wgrad1 = [&](hipStream_t ss) -> int {
         INET_TRY(linear_wgrad(reverse ? dgi1 : dgi1 + B4H, 4L * H, reverse ? out1 + BH : out1, H, dW_hh1, H, (T - 1) * B, 4 * H, H, ss));
         INET_TRY(linear_wgrad(dgi1, 4L * H, out0, H, dW_ih1, H, T * B, 4 * H, H, ss));

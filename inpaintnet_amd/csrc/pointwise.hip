@@ -807,7 +807,7 @@ int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, lo
     const int rows_per = (rows + row_blocks - 1) / row_blocks;
     const dim3 grid(col_blocks, row_blocks);
     const size_t lds = (size_t)(W + 1) * 256 * sizeof(float);
-#define INET_SEG(C)                                                                                                        \
+#define DISPATCH_SEG(C)                                                                                                        \
     do {                                                                                                                   \
         static bool attr = false;                              /* more than 64 KB of dynamic LDS needs the opt-in */        \
         if (!attr) {                                                                                                       \
@@ -818,8 +818,8 @@ int pw_token_segsum(const float* X, long ld, const long long* idx, int inner, lo
         hipLaunchKernelGGL(token_segsum_kernel<C>, grid, dim3(256), lds, s, X, ld, idx, inner, s_outer, s_inner, rows,     \
                            rows_per, W, ncols, out, row_scale);                                                            \
     } while (0)
-    if (cw == 32) INET_SEG(32); else if (cw == 64) INET_SEG(64); else INET_SEG(256);
-#undef INET_SEG
+    if (cw == 32) DISPATCH_SEG(32); else if (cw == 64) DISPATCH_SEG(64); else DISPATCH_SEG(256);
+#undef DISPATCH_SEG
     return ok();
 }
 int pw_table_grad(const float* dtab, int W, int N3, int ndir, int E, const float* emb, long ld_emb, const float* const* Wih,

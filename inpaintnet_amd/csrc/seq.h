@@ -86,7 +86,7 @@ int chain_chunk_rows_bwd(int H, int B, int T, int nd);
 // whether gru_layer_fwd / gru_layer_bwd write ChainEmit outputs for this shape (the kernels that run are the second generation's,
 // rows in multiples of 32): the same decision the layer functions make, for callers that must know it in another library call
 bool gru_layer_fwd_emits(int H, int B, int T, int nd, bool save);
-void bf3_set_emit_mask(int m);      // which piece outputs the chain kernels write themselves (INET_EMIT)
+void bf3_set_emit_mask(int m);      // which piece outputs the chain kernels write themselves (inet_set_option key 9)
 int gru_layer_fwd(int H, int B, int T, int nd, const DirFwd* d, hipStream_t s);
 int gru_layer_bwd(int H, int B, int T, int nd, const DirBwd* d, hipStream_t s);
 int gru_layer_bwd_range(int H, int B, int T, int nd, const DirBwd* d, int step_hi, int step_lo, hipStream_t s);

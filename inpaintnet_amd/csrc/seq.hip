@@ -18,8 +18,8 @@ static int chunk_max_rows() {
 int chain_chunk_rows(int H, int B, int T, int nd, int save) {
     if (gru_chain_ok(H, B, T, nd)) return B;
     // (forward-only passes -- LatentRNN's frozen encoder, 2048 rows -- chunk at any size: two chunks run side by side there;
-    //  INET_CHAIN_CHUNK_MAX_FWD caps them too)
-    static const int fwd_cap = [] { const char* e = std::getenv("INET_CHAIN_CHUNK_MAX_FWD"); return e ? std::atoi(e) : (1 << 30); }();
+    //  no cap)
+    constexpr int fwd_cap = 1 << 30;
     if (B > (save ? chunk_max_rows() : fwd_cap)) return 0;
     for (int ch = 1024; ch >= 64; ch >>= 1)
         if (ch < B && B % ch == 0 && gru_chain_ok(H, ch, T, nd)) return ch;
@@ -35,10 +35,10 @@ int chain_chunk_rows_bwd(int H, int B, int T, int nd) {
 
 // which piece outputs the chains write themselves (bit 0: the forward chains' rows, 1: their transposed pieces, 2: the first-generation
 // BPTT kernel's dgi rows); what they do not write is split from the f32 arrays by bf3_split launches (the transposed ones on the
-// side stream).  inet_set_option key 9 / INET_EMIT: the tests run the same step both ways.
+// side stream).  inet_set_option key 9: the tests run the same step both ways.
 static int g_emit_mask = -1;
 static int emit_mask() {
-    if (g_emit_mask < 0) { const char* v = std::getenv("INET_EMIT"); g_emit_mask = v ? std::atoi(v) & 7 : 7; }
+    if (g_emit_mask < 0) g_emit_mask = 7;
     return g_emit_mask;
 }
 void bf3_set_emit_mask(int m) { g_emit_mask = m & 7; }

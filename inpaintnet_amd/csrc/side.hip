@@ -8,7 +8,7 @@ namespace {
 // Leaf work (weight-gradient products, bias sums) goes to low-priority side streams, one fork "session" per call of
 // side_fork().  Sessions are independent of each other (distinct gradient tensors, scratch private to a session), so
 // they rotate over kMaxSide streams: the tail of one 256-workgroup product (skewed finishers, atomics) overlaps the
-// start of the next (4.345 -> 4.231 ms per training step with two streams instead of one; INET_SIDE_STREAMS=n).
+// start of the next (4.345 -> 4.231 ms per training step with two streams instead of one).
 constexpr int kMaxSide = 3;           // measured: 1 -> 4.35, 2 -> 4.24, 3 -> 4.29 ms per step; 4 -> 7.57 (the queues get multiplexed)
 hipStream_t g_sides[kMaxSide] = {nullptr, nullptr, nullptr};
 bool g_dirty[kMaxSide] = {false, false, false};          // something was queued on stream i since the last join
@@ -58,13 +58,12 @@ hipStream_t side_fork(hipStream_t main_stream) {
     if (!side_enabled()) return main_stream;
     if (!g_init) {
         g_init = true;
-        // (the twin stream first, whoever asks first: see twin_fork.  INET_TWIN_EAGER=0: only when a two-layer LSTM pipeline asks)
-        static const bool eager = [] { const char* v = std::getenv("INET_TWIN_EAGER"); return !(v && v[0] == '0'); }();
+        // (the twin stream first, whoever asks first: see twin_fork.  a switch of round 4 created it only when a two-layer LSTM pipeline asked)
+        constexpr bool eager = true;
         if (eager) twin_create();
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char* v = std::getenv("INET_SIDE_STREAMS");
-        int want = v ? std::atoi(v) : 2;
+        int want = 2;                                              // (two rotating side streams: the header's measurement)
         want = want < 1 ? 1 : (want > kMaxSide ? kMaxSide : want);
         if (g_active > 0 && g_active < want) want = g_active;      // (key 13 set before the first fork: no more streams than will be used)
         for (int i = 0; i < want; ++i) {

@@ -294,17 +294,16 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     const bool pk = w.wpk_t0 != nullptr;
     constexpr bool tf_batch = true;
     const long pkh = (long)pk_floats(B, H);
-    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
-    static const bool train_chain = [] { const char* v = std::getenv("INET_DECODE_CHAIN_TRAIN"); return !(v && v[0] == '0'); }();
+    constexpr bool beat_chain = true;                         // (rounds 2-4 had an environment switch for the per-step beat path)
+    constexpr bool train_chain = true;
     // Which kernels will run: the chain kernels read W_hh / W_ih as stored, only the per-step kernels want the
     // fragment-major twins -- each is packed only if its consumer runs.
     const bool beats_chained = pk && beat_chain && chain_chunk_rows(H, B, nb, 1, save) > 0;   // (one launch, or one per row chunk)
     const bool fused_shape = pk && !teacher_forced && !multinomial_seed && ((!save && !mask_tick) || train_chain);
     // batches beyond one resident launch (LatentRNN decodes 512 measures per step): the rows are independent, so the fused
     // kernel runs over chunks of 512 rows (the 64-row build: 27 us per tick instead of 2 x 20) or 256, one launch after the other
-    // (INET_DECODE_CHUNKS=0: per-tick launches)
     const int kDecodeChunk = B % 512 == 0 ? 512 : 256;
-    static const bool dec_chunks = [] { const char* v = std::getenv("INET_DECODE_CHUNKS"); return !(v && v[0] == '0'); }();
+    constexpr bool dec_chunks = true;
     const bool fused_whole = fused_shape && decode_chain_ok(B, H, V, T, G);
     const bool fused_chunked = fused_shape && !fused_whole && dec_chunks && B > kDecodeChunk && B % kDecodeChunk == 0 &&
                                decode_chain_ok(kDecodeChunk, H, V, T, G);
@@ -315,7 +314,7 @@ int vae_decoder_fwd(const inet_vae_config& c, int B, const float* z, const long 
     const bool b1_fused = b1_decode && !mask_beat && decode_b1_fused((int)Z, B);   // ... with the beat path inside the same launch
     // teacher-forced ticks: every input token is known and the 4 beats are independent, so each tick layer is a chain of
     // G steps over the beats as problems -- `npl` beats per launch, as many as fit the chip at once (2 at B = 256)
-    static const bool tf_chain = [] { const char* v = std::getenv("INET_TF_CHAIN"); return !(v && v[0] == '0'); }();
+    constexpr bool tf_chain = true;
     int npl = 0;
     if (pk && teacher_forced && tf_batch && tf_chain) {
         for (int n = nb; n >= 1 && !npl; --n)                  // whole batch in one launch per `n` beats ...
@@ -593,7 +592,7 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     DecWs w{};
     dec_carve(c, B, 1, ws, w);
     const GruDirOff* gr[4] = {&L.beat[0], &L.beat[1], &L.tick[0], &L.tick[1]};
-    static const bool beat_chain = [] { const char* v = std::getenv("INET_BEAT_CHAIN"); return !(v && v[0] == '0'); }();
+    constexpr bool beat_chain = true;                         // (rounds 2-4 had an environment switch for the per-step beat path)
     // the backward chain kernels read W_hh as stored (transposed on the fly, once): the fragment-major W_hh^T twins are
     // only packed for layers that fall back to one launch per step
     const bool beats_chained = w.wpkT[0] && w.dghpk && beat_chain && chain_chunk_rows_bwd(H, B, nb, 1) > 0;
@@ -639,9 +638,9 @@ int vae_decoder_bwd(const inet_vae_config& c, int B, const float* dweights, cons
     // Layer 1's leaf work is issued BEHIND the layer-0 chain, not beside it (round 5, profiles/r05_s_leaf_schedule.txt): beside the
     // chain its 6144-row products doubled the chain's time (231 us against 124 alone -- a persistent chain and a throughput product on
     // the same CUs overlap almost not at all), behind it they run beside the beat path's small latency-bound products, which lose
-    // little: 3.60 -> 3.55 ms per step.  (INET_DEC_LEAF=0: beside the layer-0 chain, as rounds 2-4 had it; 2: with the beat path's
+    // little: 3.60 -> 3.55 ms per step.  (leaf_when 0: beside the layer-0 chain, as rounds 2-4 had it; 2: with the beat path's
     // session at the end -- beside the encoder's layer-1 BPTT chain, 3.76 ms.)
-    static const int leaf_when = [] { const char* v = std::getenv("INET_DEC_LEAF"); return v ? std::atoi(v) : 1; }();
+    constexpr int leaf_when = 1;
     auto layer1_leaf = [&](hipStream_t ss) -> int {
         INET_TRY(linear_wgrad2(w.dgh1t, w.dgi1t, 3L * H, w.svt1 + 4 * TBH, x1, H, g + L.tick[1].w_hh, g + L.tick[1].w_ih, H,
                                T * B, 3 * H, H, ss));      // recurrent and input weights of layer 1 in one launch
