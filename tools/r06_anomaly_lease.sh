@@ -14,5 +14,4 @@ print(json.dumps({'lease': $tag, 'what': 'c', 'value': [r['value'] for r in rows
 python tools/arnn_anomaly_rep.py 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read()); print(json.dumps({'lease': $tag, 'what': 'd', **d}))" >> gpurun_out/r06_anomaly_lease_$tag.jsonl
-for ch in 32 48 64 96; do INET_LSTM_CHUNK=$ch python tools/arnn_time.py 2>&1 | grep -o "'ms_per_step': [0-9.]*, 'ms_per_step_free_running': [0-9.]*" | head -1 | sed "s/^/chunk $ch: /"; done >> gpurun_out/r06_anomaly_lease_$tag.jsonl
 cat gpurun_out/r06_anomaly_lease_$tag.jsonl
