@@ -340,7 +340,8 @@ int inet_set_option(int key, int value);
  * key 15 = the free-running decode of ONE to SIXTEEN measures at H = 512 (inference; csrc/decode_b1.hip; INET_DECODE_B1): 4 (default) =
  * 3 with every team's critical workgroups (C + 16 TBi, or the 16 CB of the merged build) on workgroup ids of one residue mod 8 --
  * one XCD under today's round-robin dispatch -- and, once they have CHECKED that they share an XCD, XCD-local copies of h0 / h1
- * written with plain stores next to the agent-scope ones (correct under any placement: a failed check uses the agent-scope copies); 3 =
+ * written with plain stores next to the agent-scope ones (correct under any placement: a failed check uses the agent-scope copies; 5 = test
+ * hook: the same request on consecutive workgroup ids, where the check has to refuse); 3 =
  * one or two measures: ONE register-resident persistent launch for the whole call behind the prologue launch (129 workgroups: 49 for
  * the 24 ticks -- two hand-offs per tick; one where a single workgroup kind can hold layer 1, the head and the argmax: one row with
  * V <= 64 -- and 80 for the beat path); three to sixteen: teams of the 49 tick workgroups in one launch, two rows per team up to ten

@@ -458,7 +458,7 @@ int inet_set_option(int key, int value) {
     if (key == 12) { gru_step_bf3_set_min_tiles(value); return 0; }
     if (key == 13) { if (value < 0 || value > 3) return -1; side_set_active(value); return 0; }
     if (key == 14) { if (value < 0 || value > 4) return -1; arnn_gen_set_mode(value); return 0; }
-    if (key == 15) { if (value < 0 || value > 4) return -1; decode_b1_set_mode(value); return 0; }
+    if (key == 15) { if (value < 0 || value > 5) return -1; decode_b1_set_mode(value); return 0; }
     if (key == 16) {                                           // entry threshold of the slow-wait recorder, in polls (chain.h)
         unsigned* d = chain_dev_status();
         const unsigned polls = (unsigned)value;

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     const int wg = blockIdx.x / a.stride, tick_wgs = a.teams * kTickRoles;
     int team = (a.teams > 1 && wg < tick_wgs) ? wg / kTickRoles : 0;
     int role = a.teams > 1 ? (wg < tick_wgs ? wg % kTickRoles : kTickRoles + (wg - tick_wgs)) : wg;
-    if (a.place && !place_role((int)blockIdx.x, a.teams, a.rgroups ? a.rgroups : a.teams, a.fused ? kFusedRoles - kTickRoles : 0, team, role)) return;
+    if (a.place == 1 && !place_role((int)blockIdx.x, a.teams, a.rgroups ? a.rgroups : a.teams, a.fused ? kFusedRoles - kTickRoles : 0, team, role)) return;
     const int rb = team * NB, nrow = min(NB, a.B - rb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* const ex = a.ex + (long)rb * G_END;
@@ -881,12 +881,14 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
 
 int g_mode = -1;                                 // 0 = off (decode_chain.hip's small-batch builds); 1 = tick path only, consecutive workgroup ids;
                                                  // 2 = tick path only, every 4th id; 3 = beat path folded in; 4 (default) = 3 + every
-                                                 // team's critical workgroups on one XCD with XCD-local copies of h0 / h1 (place_role)
+                                                 // team's critical workgroups on one XCD with XCD-local copies of h0 / h1 (place_role);
+                                                 // 5 = test hook: 4's REQUEST for XCD-local copies on mode 3's consecutive ids, where the
+                                                 // critical workgroups do not share an XCD -- the XCC-id check has to refuse
 int mode() {
     if (g_mode < 0) {
         const char* v = std::getenv("INET_DECODE_B1");
         g_mode = v ? std::atoi(v) : 4;
-        if (g_mode < 0 || g_mode > 4) g_mode = 4;
+        if (g_mode < 0 || g_mode > 5) g_mode = 4;
     }
     return g_mode;
 }
@@ -913,7 +915,7 @@ int decode_b1_team_rows(int B) {
     return B <= 10 ? 2 : 4;
 }
 
-void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 4) ? 4 : m; }
+void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 5) ? 4 : m; }
 
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
     return mode() != 0 && chain_enabled() && B >= 1 && B <= kDecodeB1MaxRows && H == DH && V >= 1 && V <= 128 && T % G == 0 && T / G <= 4 &&
@@ -956,7 +958,8 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
     a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs) <= chain_capacity();
     if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
-    const dim3 grid(a.place ? placed_grid(a.teams, rteams, beat_wgs) : (a.teams * kTickRoles + beat_wgs) * a.stride);
+    if (mode() == 5 && a.stride == 1) a.place = 2;             // (test hook: the request without the placement)
+    const dim3 grid(a.place == 1 ? placed_grid(a.teams, rteams, beat_wgs) : (a.teams * kTickRoles + beat_wgs) * a.stride);
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
     if (a.fused && a.teams > 1 && (nbr != 2 || a.teams * 2 > kDecodeB1BeatRowsMax)) return -1;
 #define DISPATCH_B1(NJ, NBR)                                                                                                    \

@@ -381,7 +381,7 @@ def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V, B):
             junk = torch.empty(int(rng.randint(1, 32)) << 20, device="cuda").uniform_(-100, 100)
             del junk
             outs = {}
-            for mode in (4, 3, 2, 1, 0):                     # 4 = default: 3 with the critical workgroups on one XCD and XCD-local copies; 3 = the beat path folded into the launch, 2 / 1 = tick path only
+            for mode in (5, 4, 3, 2, 1, 0):                  # 5 = test hook: 4's request for XCD-local copies on consecutive workgroup ids (the XCC-id check must refuse); 4 = default: 3 with the critical workgroups on one XCD and XCD-local copies; 3 = the beat path folded into the launch, 2 / 1 = tick path only
                 ops.set_option(15, mode)
                 w, s_, _ = ops.decoder_fwd(cfg, z, None, False, params)
                 torch.cuda.synchronize()
@@ -391,6 +391,9 @@ def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V, B):
             # beat path is folded into the launch; with its own launches in front their split-K sums differ by round-off per run)
             if B <= 6:
                 assert torch.equal(outs[4][1], outs[3][1]) and torch.equal(outs[4][0], outs[3][0]), (V, B, it)
+                # ... and where the critical workgroups do NOT share an XCD the check refuses the XCD-local copies: had it not, plain stores
+                # would never be seen across XCDs and every wait would have run into its bound (chain_status above)
+                assert torch.equal(outs[5][1], outs[3][1]) and torch.equal(outs[5][0], outs[3][0]), (V, B, it)
             else:
                 assert float((outs[4][0][:, 0] - outs[3][0][:, 0]).abs().max()) < 2e-5 * float(outs[3][0].abs().max())
             with torch.no_grad():

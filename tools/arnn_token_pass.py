@@ -10,7 +10,8 @@ import torch, bench
 from inpaintnet_amd import ops, synthetic
 from inpaintnet_amd.arnn import ConstraintModelGaussianReg
 sys.stdout = sys.stderr
-ds = synthetic.SyntheticFolkDataset(num_notes=bench.NUM_NOTES)
+NOTES = int(sys.argv[1]) if len(sys.argv) > 1 else bench.NUM_NOTES          # (V > 64: the two-register-set build of the token pass)
+ds = synthetic.SyntheticFolkDataset(num_notes=NOTES)
 ds.metadatas = [types.SimpleNamespace(num_values=6), types.SimpleNamespace(num_values=6)]
 m = ConstraintModelGaussianReg(ds, note_embedding_dim=10, metadata_embedding_dim=2, num_lstm_constraints_units=256,
                                num_lstm_generation_units=256, linear_hidden_size=256, num_layers=2, dropout_input_prob=0.2,
@@ -29,17 +30,17 @@ for mode in (0, 1, 2, 3):
     for _ in range(10): t = ops.arnn_generate(*args)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
-    print(f"mode {mode}: token pass, 384 ticks: {1e3 * dt:.2f} ms  ({1e6 * dt / 384:.2f} us per tick)  tokens {t[:8].tolist()} "
+    print(f"V = {NOTES}, mode {mode}: token pass, 384 ticks: {1e3 * dt:.2f} ms  ({1e6 * dt / 384:.2f} us per tick)  tokens {t[:8].tolist()} "
           f"chain status {ops.chain_status()}")
 ops.set_option(14, 2)
 
 if os.environ.get("INET_ARNN_GEN_STAMPS") == "1":
-    L, V = 384, bench.NUM_NOTES
+    L, V = 384, NOTES
     ops._ARNN_KEEP_WS.append(None)
     t = ops.arnn_generate(*args)
     torch.cuda.synchronize()
     ws = ops._ARNN_KEEP_WS[0]
-    off = L * 1024 + V * 1024 + (2 * (512 + 2048) + 64) + 64
+    off = L * 1024 + V * 1024 + (2 * (4 * 256 + 2 * 1024 + 16) + 64) + 64      # csrc/arnn_gen.hip arnn_token_pass_stamps_offset
     st = ws[off:off + 32 * L].cpu().view(torch.int64).view(2, L, 8).double() * 0.01        # us (100 MHz wall clock)
     c, b = st[0, 8:L - 1], st[1, 8:L - 1]
     names_c = ["tok known -> gates, cell, publish h0", "wait for h1 (Bi's product + cell + two hand-offs)", "barrier", "linear_1 product + barrier",
