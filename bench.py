@@ -56,7 +56,7 @@ PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s HBM3E (6.3 TB/s 
 NUM_NOTES = 48
 VAE_BATCH_PER_GPU = 256
 LATENT_SEQ_PER_GPU = 128
-PMC_FILE = os.path.join(REPO, "profiles", "r05_pmc_traffic.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r06_pmc_traffic.json")
 
 
 # ------------------------------------------------------------------------------------------------ launcher
