@@ -981,6 +981,7 @@ def compact_line(out):
         "latent_seq_per_s": _get(ex, "latent_rnn_train", "sequences_per_s"),
         "latent_default_ms": _get(ex, "latent_rnn_train_default", "ms_per_step"),
         "latent_ar_ms": _get(ex, "latent_rnn_train_auto_reg", "ms_per_step"),
+        "latent_ar_fr_ms": _get(ex, "latent_rnn_train_auto_reg", "ms_per_step_free_running"),
         "latent_dp_ms": _get(ex, "latent_rnn_train_dp", "ms_per_step"),
         "latent_dp_seq_per_s": _get(ex, "latent_rnn_train_dp", "sequences_per_s"),
         "arnn_tf_ms": _get(ex, "anticipation_rnn_train", "ms_per_step"),
@@ -1178,9 +1179,23 @@ def main():
                 random.seed(99)
                 la = LatentWorkload(dev, rank, vae=wl.model, ds=wl.ds, auto_reg=True)
                 adt, _ = timed(la.step, 20, 4, fence)
+                # the two sides of the teacher-forcing coin on their own (the coin is LatentRNN.forward's `random.random() < 0.5`): the
+                # teacher-forced side is the non-auto-regressive step plus the target encodes, the free-running side decodes and
+                # re-encodes measure by measure at 128 rows -- 280 launches, GPU-bound (profiles/r06_e_latent_ar_fr_table.txt)
+                sides = {}
+                real_random = random.random
+                try:
+                    for name, val in (("teacher_forced", 0.0), ("free_running", 0.99)):
+                        random.random = (lambda v=val: v)
+                        sdt, _ = timed(la.step, 10, 2, fence)
+                        sides[name] = round(1e3 * sdt / 10, 3)
+                finally:
+                    random.random = real_random
                 extras["latent_rnn_train_auto_reg"] = {"sequences_per_s": round(LATENT_SEQ_PER_GPU * 20 / adt, 1),
                                                        "measures_per_s": round(16 * LATENT_SEQ_PER_GPU * 20 / adt, 1),
-                                                       "ms_per_step": round(1e3 * adt / 20, 3), **la.describe(1),
+                                                       "ms_per_step": round(1e3 * adt / 20, 3),
+                                                       "ms_per_step_teacher_forced": sides.get("teacher_forced"),
+                                                       "ms_per_step_free_running": sides.get("free_running"), **la.describe(1),
                                                        # (the mean over the teacher-forcing coin of the four profiled steps)
                                                        "kernels": secondary_table(la.step, ms_per_step=1e3 * adt / 20)}
                 del la
