@@ -21,6 +21,8 @@ class LatentRNNTester(object):
         self.dataset = dataset
         self.model = model
         self.model.eval()
+        if self.model.flat.is_cuda:
+            ops.preload()                            # no generation call pays a kernel's first launch (csrc/preload.hip)
         self.filepath = os.path.join('models/', self.model.__repr__())
         self.min_num_measures_target = 1
         self.max_num_measure_target = 4

@@ -18,6 +18,8 @@ class VAETester(object):
         self.dataset = dataset
         self.model = model
         self.model.eval()
+        if self.model.flat.is_cuda:
+            ops.preload()                            # no generation call pays a kernel's first launch (csrc/preload.hip)
         self.filepath = os.path.join('models/', self.model.__repr__())
         self.decoder = self.model.decoder
         self.train = False
