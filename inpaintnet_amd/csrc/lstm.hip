@@ -777,18 +777,6 @@ int lstm_chunk_steps() {
 
 }  // namespace
 
-// Chunk lengths of a two-layer pipeline in PROCESSING order: CH steps each, the last chunk tapered to CH/2, CH/4, CH/4 (round 6).  The
-// pipeline's critical path is one layer's whole sequence plus the OTHER layer's last chunk (the drain: 84 us forward, 110 + the
-// chunk's product backward, four times per AnticipationRNN step); a short last chunk shortens exactly that, for two more launches per
-// layer.  (Shorter chunks everywhere cost more than they save: INET_LSTM_CHUNK = 16 / 24 measured 7.35 / 6.77 ms against 6.62.)
-static int chunk_plan(int T, int CH, int* lens, int max_chunks) {
-    int n = 0, left = T;
-    while (left > CH && n < max_chunks - 3) { lens[n++] = CH; left -= CH; }
-    if (left <= CH && left >= 16 && left % 4 == 0 && T >= 3 * CH) { lens[n++] = left / 2; lens[n++] = left / 4; lens[n++] = left / 4; left = 0; }
-    while (left > 0 && n < max_chunks) { const int l = left < CH ? left : CH; lens[n++] = l; left -= l; }
-    return left == 0 ? n : -1;
-}
-
 bool lstm2_ok(int B, int T, int H) {
     const int CH = lstm_chunk_steps();
     return lstm_chain_ok(B, H) && CH >= 2 && T >= 2 * CH;
@@ -813,11 +801,8 @@ int lstm2_seq_fwd(int B, int T, int H, const float* gi0, const float* W_hh0, con
     hipStream_t s2 = twin_fork(s);
     constexpr bool third = true;
     constexpr bool ring_on = true;
-    int lens[64];
-    const int nchunks = chunk_plan(T, CH, lens, 64);
-    if (nchunks < 0) return 1;
-    for (int c = 0, s_lo = 0; c < nchunks; s_lo += lens[c], ++c) {
-        const int nt = lens[c];
+    for (int s_lo = 0; s_lo < T; s_lo += CH) {
+        const int nt = T - s_lo < CH ? T - s_lo : CH;
         const long t_lo = reverse ? T - (s_lo + nt) : s_lo, tp = reverse ? t_lo + nt : t_lo - 1;
         INET_TRY(lstm_chunk_fwd(B, T, H, gi0, W_hh0, b_hh0, s_lo ? out0 + tp * BH : w0.zeros, s_lo ? w0.cseq + tp * BH : w0.zeros,
                                 reverse, out0, w0, save, s_lo, nt, s, 0, ring_on));
@@ -850,15 +835,14 @@ int lstm2_seq_bwd(int B, int T, int H, const float* W_hh0, const float* W_ih1, c
     INET_TRY(pw_transpose(W_hh1, H, w1.whhT, 4L * H, 4 * H, H, s));
     hipStream_t s2 = twin_fork(s);
     constexpr bool third = true;
-    int lens[64];
-    const int nchunks = chunk_plan(T, CH, lens, 64);
-    if (nchunks < 0) return 1;
+    const int nchunks = (T + CH - 1) / CH;
     const bool areas = nchunks <= kMaxChunks;            // one pre-zeroed counter area per chunk and layer
     if (areas && (hipMemsetAsync(w0.sync + kSyncWords, 0, (kSyncWordsAll - kSyncWords) * sizeof(unsigned), s) != hipSuccess ||
                   hipMemsetAsync(w1.sync + kSyncWords, 0, (kSyncWordsAll - kSyncWords) * sizeof(unsigned), s) != hipSuccess)) return -2;
     if (s2 != s) INET_TRY(stream_wait(s2, s));           // (the second stream's first launch must see those zeros)
-    for (int c = 0, s_end = T; c < nchunks; s_end -= lens[c], ++c) {
-        const int nt = lens[c], s_lo = s_end - nt;
+    int c = 0;
+    for (int s_end = T; s_end > 0; s_end -= CH, ++c) {
+        const int nt = s_end < CH ? s_end : CH, s_lo = s_end - nt;
         const long t_lo = reverse ? T - (s_lo + nt) : s_lo;
         float* in1 = w1.carry + (long)((c + 1) & 1) * 2 * BH;   // written by the previous chunk of this layer
         float* ou1 = w1.carry + (long)(c & 1) * 2 * BH;
