@@ -934,6 +934,13 @@ int pw_split_measures(const int* score, int B, int M, int L, int n_past, int n_t
 int pw_prologue(const PwPrologue& p, hipStream_t s) {
     PwPrologue q = p;
     q.tok_bad = q.tok_V > 0 ? token_host_status() : nullptr;
-    hipLaunchKernelGGL(prologue_kernel, dim3(48, 7), dim3(256), 0, s, q);
+    // grid.x: one pass over the largest job -- the tick GRU's gather table, (V + 1) x 3H outputs of E dependent multiply-adds each, every
+    // thread walking its own row of W_ih -- instead of six (48 workgroups per job until round 6: the launch took 11.8 us, a tenth of a
+    // one-measure decode call); every job strides over the grid, so any width is correct
+    long widest = 0;
+    for (int j = 0; j < q.ntab && j < 4; ++j) widest = widest > (long)q.tab[j].rows * q.tab[j].N ? widest : (long)q.tab[j].rows * q.tab[j].N;
+    widest = widest > q.nzero / 4 ? widest : q.nzero / 4;
+    const int gx = (int)((widest + 255) / 256 < 48 ? 48 : ((widest + 255) / 256 > 512 ? 512 : (widest + 255) / 256));
+    hipLaunchKernelGGL(prologue_kernel, dim3(gx, 7), dim3(256), 0, s, q);
     return ok();
 }
