@@ -28,6 +28,20 @@ def test_exports_match_header(L):
     assert L.inet_abi_version() == 1
 
 
+def test_kernel_handles_are_collected_without_a_gpu(L):
+    """csrc/preload.hip: the library defines __hipRegisterFunction itself (it is linked -Bsymbolic-functions), files every kernel
+    handle its translation units register at load time and passes the call on to the HIP runtime -- so inet_preload() can first-touch
+    ALL kernels, template instantiations included, with no list to keep in step by hand.  No GPU needed for the count; without a
+    device inet_preload() refuses (-2) instead of pretending."""
+    import subprocess
+    assert L.inet_kernel_count() >= 200
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert " T __hipRegisterFunction" in syms
+    import torch
+    if not torch.cuda.is_available():
+        assert L.inet_preload() == -2
+
+
 def _entries(cfg, count_fn, info_fn):
     n = count_fn(C.byref(cfg))
     out = []
