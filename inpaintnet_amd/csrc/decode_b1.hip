@@ -907,12 +907,9 @@ constexpr int kSharedRows = 6;                   // rows a shared recurrent grou
 static bool shared_groups(int B) { return mode() == 4 && B > 10; }    // (up to ten measures five whole two-row teams fit the chip: faster)
 static int shared_group_count(int B) { return (2 * ((B + 1) / 2) + kSharedRows - 1) / kSharedRows; }
 int decode_b1_team_rows(int B) {
-    constexpr int forced = 0;                                  // (round 5: an environment switch forced two- or four-row teams)
     if (B <= 1) return 1;
-    if (B <= 2) return 2;
-    if (shared_groups(B)) return 2;
-    if (forced == 2 || forced == 4) return (B + forced - 1) / forced * kTickRoles <= 256 ? forced : 4;
-    return B <= 10 ? 2 : 4;
+    if (B <= 2 || shared_groups(B)) return 2;
+    return B <= 10 ? 2 : 4;                                    // (whole two-row teams while five of them fit the chip; modes 1-3 beyond: four rows)
 }
 
 void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 5) ? 4 : m; }
