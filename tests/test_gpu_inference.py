@@ -354,7 +354,8 @@ def test_fused_decode_matches_per_tick_path_repeatedly():
 
 
 @pytest.mark.parametrize("V,B", [(48, 1), (20, 1), (61, 1), (93, 1), (128, 1), (48, 2), (20, 2), (48, 3), (48, 4), (61, 4), (125, 3),
-                                 (48, 5), (48, 8), (20, 7), (48, 10), (48, 11), (61, 13), (48, 16), (100, 16)])
+                                 (48, 5), (48, 8), (20, 7), (48, 10), (48, 11), (61, 13), (48, 16), (100, 16),
+                                 (20, 12), (32, 16), (128, 14)])     # (shared recurrent groups with the merged build: V <= 32; with the widest head)
 def test_decode_b1_persistent_kernel_matches_decode_chain_and_oracle(V, B):
     """(One row with V <= 64 / two rows with V <= 32: the merged build, where every layer-1 workgroup also runs layer 0's cell, the head and
     the argmax for itself -- one hand-off per tick; three to sixteen rows: teams of the tick path's 49 workgroups behind the beat path's
