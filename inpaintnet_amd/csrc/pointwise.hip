@@ -717,8 +717,11 @@ int pw_pack_frag_multi(const float* const* ins, float* const* outs, int n, long 
 int pw_cross_entropy(const float* W, long ld_w, int rows, int V, const long long* tgt, float* dW, long ld_dw,
                      float scale, float out_scale, float* loss_sum, float* correct, hipStream_t s, const float* scale_dev,
                      const float* add_term, float add_scale, float* fwd_out, float fwd_scale) {
-    const int g = grid_for((long)rows * 64, 256, 512);        // (2048 blocks = one row per wave measured SLOWER: 77 vs 54 us for the
-                                                              // loss glue of the B = 256 step -- one atomic pair per block on one word)
+    // blocks: every block ends with one atomic pair on the same two words, and those serialise (~20 ns each): 2048 blocks (one row
+    // per wave) measured 77 us for the loss glue of the B = 256 step, 512 blocks 54 us with the forward launch at 18.7 us against
+    // 6.2 for the backward launch that has no sums (profiles/r06_p_timeline_full_step.txt).  With sums: 128 blocks (12 rows per
+    // wave at 6144 rows); without (the backward launch): as many as there are rows to go round
+    const int g = grid_for((long)rows * 64, 256, (loss_sum || correct) ? 128 : 512);
     hipLaunchKernelGGL(ce_kernel, dim3(g), dim3(256), 0, s, W, ld_w, rows, V, tgt, dW, ld_dw, scale, out_scale, loss_sum,
                        correct, scale_dev, add_term, add_scale, fwd_out, fwd_scale);
     return ok();

@@ -73,11 +73,17 @@ class _DecoderFn(ops.TrackedFunction):
             dec.last_ws = ws
         ctx.save_for_backward(weights, samples)
         ctx.mark_non_differentiable(samples)
+        # (no zero tensor for the gradient of `samples`: autograd would launch a fill kernel for it in every backward pass -- 6 us of
+        #  stream time for a tensor nobody reads)
+        ctx.set_materialize_grads(False)
         return weights, samples
 
     @staticmethod
     def backward(ctx, dweights, _dsamples):
         dec = ctx.dec
+        if dweights is None:                            # nothing downstream depends on the weights
+            ctx.ws = None
+            return None, None, None, None, None, None, None, None
         weights, samples = ctx.saved_tensors
         grads = dec.owner.grad if dec.owner.trainable else None
         dz = ops.decoder_bwd(dec.cfg, dweights.contiguous(), weights, samples, dec.owner.flat, grads, ctx.mb, ctx.mt,

@@ -72,12 +72,15 @@ class _CrossEntropyFn(torch.autograd.Function):
         ctx.dW = dW
         loss, acc = out[0], out[1]                  # the kernel accumulated the means: no follow-up launch
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)            # (no fill launch for the accuracy's gradient)
         return loss, acc
 
     @staticmethod
     def backward(ctx, gloss, _gacc):
         dW = ctx.dW
         ctx.dW = None
+        if gloss is None or dW is None:
+            return None, None
         return dW * gloss, None
 
 
@@ -99,10 +102,13 @@ class _ElboFn(torch.autograd.Function):
         res = out2.clone()
         loss, acc = res[0], res[1]
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)            # (no fill launch for the accuracy's gradient)
         return loss, acc
 
     @staticmethod
     def backward(ctx, gloss, _gacc):
+        if gloss is None:
+            return None, None, None, None, None
         w, t = ctx.saved_tensors
         dW = torch.empty_like(w)
         gkl = torch.empty((), dtype=torch.float32, device=w.device)
