@@ -85,10 +85,10 @@ constexpr int G_H0 = 0, G_H1 = DH, G_GH0 = 2 * DH, G_GH1 = 2 * DH + D3, G_H1X = 
 __device__ __forceinline__ int slot_h0(unsigned tag) { return (tag & 1) ? G_H0X : G_H0; }
 __device__ __forceinline__ int slot_h1(unsigned tag) { return (tag & 1) ? G_H1X : G_H1; }
 constexpr int G_HB0 = G_TICK_END, G_H0B = G_HB0 + 2 * DH, G_H1B = G_H0B + 4 * DH, G_GH1B = G_H1B + 4 * DH, G_C = G_GH1B + 4 * D3,
-              G_HT0 = G_C + 4 * DH, G_CGI = G_HT0 + 4 * 2 * DH, G_H0N = G_CGI + 4 * D3, G_H1N = G_H0N + 2 * DH, G_XCC = G_H1N + 2 * DH,
-              G_END = G_XCC + 32;
-// (G_H0N / G_H1N: XCD-LOCAL copies of h0 / h1, two slots each, written with plain stores for the readers on the writer's XCD -- "One
-//  XCD for the critical path" below; G_XCC: the critical workgroups' XCC ids, granule::same_xcd)
+              G_HT0 = G_C + 4 * DH, G_CGI = G_HT0 + 4 * 2 * DH, G_H0N = G_CGI + 4 * D3, G_H1N = G_H0N + 2 * DH, G_GH0N = G_H1N + 2 * DH,
+              G_XCC = G_GH0N + 2 * D3, G_END = G_XCC + 64;
+// (G_H0N / G_H1N / G_GH0N: XCD-LOCAL copies of h0 / h1 / gh0, two slots each, written with plain stores for the readers on the writer's
+//  XCD -- "One XCD for the critical path" below; G_XCC: the critical workgroups' XCC ids, granule::same_xcd)
 static_assert(2 * G_END == kDecodeB1WordsPerRow, "the workspace's granule area holds the map");
 // One XCD for the critical path (round 6).  A tick's critical hand-offs run among C and the 16 TBi (h0 out, h1 back), or among
 // the 16 CB of the merged build (the all-gather of h1: 1.54 of a 3.78 us tick, profiles/r05_n_decode_b1_merged_stamps.txt); the
@@ -107,26 +107,41 @@ __device__ __forceinline__ void put_local(unsigned long long* g, float v, unsign
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(x) : "memory");
 }
 constexpr int kCrit = 17;                        // critical workgroups per team: C and the 16 TBi (merged build: C's slot idles)
+// ... and kCritTA = 32 in the ONE-team merged build: the 16 TA join them (16 CB + 16 TA = the 32 CUs of an XCD).  There layer 0's
+// recurrent summands were the last thing a tick waited for (0.27 us: TA gathers h0_t, multiplies, publishes gh0 -- two cross-XCD
+// hand-offs that end ~0.3 us behind the argmax); inside the XCD both hand-offs use plain stores and gh0 is there when it is looked at.
+constexpr int kCritTA = 2 * NU;                  // (no slot for C: it does not exist in the merged build)
 // workgroup id -> (team, role) with every team's critical workgroups on ids of one residue mod 8; false: no role (the id leaves)
-__host__ __device__ inline int crit_below(int b, int teams) {
+__host__ __device__ inline int crit_below(int b, int teams, int crit) {
     int n = 0;
     for (int x = 0; x < teams; ++x)
-        if (b > x) { const int c = (b - x + 7) / 8; n += c < kCrit ? c : kCrit; }
+        if (b > x) { const int c = (b - x + 7) / 8; n += c < crit ? c : crit; }
     return n;
 }
 // (rteams: the groups of 2 NU recurrent-side workgroups -- one per team, or the shared groups' count; `team` of such a role = its group)
-__host__ __device__ inline bool place_role(int b, int teams, int rteams, int beat_wgs, int& team, int& role) {
+__host__ __device__ inline bool place_role(int b, int teams, int rteams, int beat_wgs, int crit, int& team, int& role) {
     const int x = b & 7, i = b >> 3;
-    if (x < teams && i < kCrit) { team = x; role = i == 0 ? R_C : R_TBI + i - 1; return true; }
-    const int n = b - crit_below(b, teams);                     // the id's rank among the non-critical ones
-    if (n < rteams * 2 * NU) { team = n / (2 * NU); const int r = n % (2 * NU); role = r < NU ? R_TA + r : R_TBH + (r - NU); return true; }
-    if (n - rteams * 2 * NU < beat_wgs) { team = 0; role = kTickRoles + (n - rteams * 2 * NU); return true; }
+    if (x < teams && i < crit) {
+        team = x;
+        role = crit == kCritTA ? (i < NU ? R_TBI + i : R_TA + (i - NU)) : (i == 0 ? R_C : R_TBI + i - 1);
+        return true;
+    }
+    const int n = b - crit_below(b, teams, crit);               // the id's rank among the non-critical ones
+    const int per = crit == kCritTA ? NU : 2 * NU;              // recurrent-side workgroups per team that are NOT critical
+    if (n < rteams * per) {
+        team = n / per;
+        const int r = n % per;
+        role = crit == kCritTA ? R_TBH + r : (r < NU ? R_TA + r : R_TBH + (r - NU));
+        return true;
+    }
+    if (n - rteams * per < beat_wgs) { team = 0; role = kTickRoles + (n - rteams * per); return true; }
     return false;
 }
 
 struct B1Args {
     int B, T, G, V, Z, stride, fused, teams;     // teams: groups of kTickRoles workgroups, NB rows each (tick path only beyond one)
     int rgroups;                                 // > 0: SHARED recurrent groups -- TA / TBh workgroups of NBR rows each serve several critical teams ("Shared recurrent groups")
+    int crit;                                    // critical workgroups per team under place_role: kCrit, or kCritTA (one-team merged build)
     int place;                                   // 1: ids -> roles by place_role (critical workgroups of a team on one XCD), XCD-local copies requested
     const float* W_hh0; const float* b_hh0; const float* cgi; const float* table;
     const float* W_ih1; const float* b_ih1; const float* W_hh1; const float* b_hh1;
@@ -266,9 +281,12 @@ struct Ctx {                                     // what every role needs
 
 // ---- tick path: recurrent side of a layer, off the critical path: gh for tick t = W_hh x + b_hh, x = the beat's initial state at
 // a beat's first tick, else the layer's output of tick t - 1 ----
+// `near` (TA of the one-team merged build, once the 32 critical workgroups have found themselves on one XCD): the input is read from
+// its XCD-local copy (g_in_near + parity * DH) and the output is ALSO written there (g_out_near + parity * D3) with plain stores.
 template <int NB>
 __device__ __forceinline__ void tick_recurrent_role(const Ctx<NB>& c, int k, const float* __restrict__ W, const float* __restrict__ bias,
-                                                    int layer, int g_in, int g_out, int g_in_odd, int g_out_odd) {
+                                                    int layer, int g_in, int g_out, int g_in_odd, int g_out_odd, bool near = false,
+                                                    int g_in_near = 0, int g_out_near = 0) {
     const B1Args& a = c.a;
     const int tid = c.tid, p = tid >> 4, s = tid & 15, u = UW * k + p;
     const int row[3] = {u, DH + u, 2 * DH + u};
@@ -283,7 +301,7 @@ __device__ __forceinline__ void tick_recurrent_role(const Ctx<NB>& c, int k, con
         // (the previous tick's output is waited for at a beat's first tick too, although the beat's initial state is what gets
         //  multiplied: the single-buffered granules are safe only while every producer stays behind its consumers -- a workgroup
         //  that ran ahead here would overwrite gh of tick t - 1 before the cell that needs it has looked)
-        if (t > 0) c.gather((t & 1) ? g_in_odd : g_in, (unsigned)t, t & 1);
+        if (t > 0) c.gather(near ? g_in_near + (t & 1) * DH : ((t & 1) ? g_in_odd : g_in), (unsigned)t, t & 1);
         if (t % a.G == 0) {
             const int beat = t / a.G;
             if (a.fused) c.gather(G_HT0 + beat * 2 * DH + layer * DH, 1u, t & 1);
@@ -302,8 +320,10 @@ __device__ __forceinline__ void tick_recurrent_role(const Ctx<NB>& c, int k, con
             dot_rows<3, 32>(w, c.xs[r][t & 1] + 36 * s, y);
             if (s == 0) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
+                for (int g = 0; g < 3; ++g) {
+                    if (near) put_local(c.ex + (long)r * G_END + g_out_near + ((t + 1) & 1) * D3 + g * DH + u, y[g] + b[g], (unsigned)t + 1u);
                     put(c.ex + (long)r * G_END + (((t + 1) & 1) ? g_out_odd : g_out) + g * DH + u, y[g] + b[g], (unsigned)t + 1u);
+                }
             }
         }
     }
@@ -484,7 +504,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
     const int wg = blockIdx.x / a.stride, tick_wgs = a.teams * kTickRoles;
     int team = (a.teams > 1 && wg < tick_wgs) ? wg / kTickRoles : 0;
     int role = a.teams > 1 ? (wg < tick_wgs ? wg % kTickRoles : kTickRoles + (wg - tick_wgs)) : wg;
-    if (a.place == 1 && !place_role((int)blockIdx.x, a.teams, a.rgroups ? a.rgroups : a.teams, a.fused ? kFusedRoles - kTickRoles : 0, team, role)) return;
+    if (a.place == 1 && !place_role((int)blockIdx.x, a.teams, a.rgroups ? a.rgroups : a.teams, a.fused ? kFusedRoles - kTickRoles : 0, a.crit, team, role)) return;
     const int rb = team * NB, nrow = min(NB, a.B - rb);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* const ex = a.ex + (long)rb * G_END;
@@ -634,8 +654,11 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             const int rbr = team * NBR;
             const Ctx<NBR> cr{a, a.ex + (long)rbr * G_END, xs, bad, tid, rbr, min(NBR, a.B - rbr), min(NBR, a.teams * NB - rbr)};
             tick_recurrent_role<NBR>(cr, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0);
-        } else
-        tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0);
+        } else {
+            // (one-team merged build under place_role: the TA are critical workgroups, index 16 + k of the XCC-id check's 32)
+            const bool ta_near = MG && a.place == 1 && a.crit == kCritTA && same_xcd(ex + G_XCC, NU + (role - R_TA), 2 * NU, a.status, &near_s);
+            tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0, ta_near, G_H0N, G_GH0N);
+        }
     } else if (role < R_TBH && MG) {
         // ---- CB_k (merged build): C's work REPLICATED in every TBi_k.  Layer 0's cell needs no product (its summands arrive), the
         // head is V x 512: cheap enough to compute 16 times over, and then h0_t never leaves the workgroup and the token never
@@ -645,7 +668,9 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
         // workgroup does not wait for its 15 peers to have READ a value before it writes the next one (a peer's read of h1_t is
         // ordered before its own h1_t+1, which the writer of h1_t+2 has to have seen: two slots are enough; likewise gh0, h0).
         const int k = role - R_TBI, p = tid >> 4, s = tid & 15, uc = UW * k + p;
-        const bool near = a.place && same_xcd(ex + G_XCC, k, NU, a.status, &near_s);
+        const bool with_ta = a.place == 1 && a.crit == kCritTA;           // the 16 TA are part of the check (and of the XCD)
+        const bool near = a.place && same_xcd(ex + G_XCC, k, with_ta ? 2 * NU : NU, a.status, &near_s);
+        const bool gh0_near = near && with_ta;
         const int row[3] = {uc, DH + uc, 2 * DH + uc};
         float w[3][32];
         load_rows<3, 32>(w, a.W_ih1, DH, row, s);
@@ -674,7 +699,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
         for (int r = 0; r < NB; ++r)
 #pragma unroll
             for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
-        if (!get_2d<NB, 3>(ex + G_GH0X + u, G_END, DH, 1u, a.status, gh, hw)) *bad = 1;
+        if (!get_2d<NB, 3>(ex + (gh0_near ? G_GH0N + D3 : G_GH0X) + u, G_END, DH, 1u, a.status, gh, hw)) *bad = 1;
         for (int t = 0; t < a.T; ++t) {
             const bool more = t + 1 < a.T;
             const unsigned tag = (unsigned)t + 1u;
@@ -716,7 +741,10 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 }
                 if (out) {
 #pragma unroll
-                    for (int r = 0; r < NB; ++r) put(ex + (long)r * G_END + slot_h0(tag) + u, h0[r], tag);
+                    for (int r = 0; r < NB; ++r) {
+                        if (gh0_near) put_local(ex + (long)r * G_END + slot_h0n(tag) + u, h0[r], tag);
+                        put(ex + (long)r * G_END + slot_h0(tag) + u, h0[r], tag);
+                    }
                 }
             }
             if (out) B1_STAMP(0, t, 1);
@@ -742,13 +770,6 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             if (out) B1_STAMP(0, t, 3);
             lds_barrier();
             if (*bad) break;
-            if (more) {
-                const int g_gh0 = ((tag + 1u) & 1) ? G_GH0X : G_GH0;
-#pragma unroll
-                for (int r = 0; r < NB; ++r)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) hw[r][g] = peek(ex + (long)r * G_END + g_gh0 + g * DH + u);
-            }
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 float y[NJ];
@@ -763,6 +784,16 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                         if (out && r < nrow) a.weights[((long)(rb + r) * a.T + t) * a.V + v] = lg;
                     }
                 }
+            }
+            // the next tick's recurrent summands: TA publishes them ~2 us behind h0_t (gather + product + store), i.e. about HERE -- requested
+            // behind the head product, looked at behind the argmax.  (Requested in front of the head product, 1.4 us behind h0_t, the
+            // request came back stale most ticks and the look behind the argmax paid a second round trip.)
+            if (more) {
+                const int g_gh0 = gh0_near ? G_GH0N + (int)((tag + 1u) & 1) * D3 : (((tag + 1u) & 1) ? G_GH0X : G_GH0);
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) hw[r][g] = peek(ex + (long)r * G_END + g_gh0 + g * DH + u);
             }
             lds_barrier();
             if (out) B1_STAMP(0, t, 4);
@@ -804,7 +835,8 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
 #pragma unroll
                     for (int g = 0; g < 3; ++g) tb[r][g] = a.table[(long)tok[r] * D3 + g * DH + u];
             }
-            if (more && !get_2d<NB, 3>(ex + (((tag + 1u) & 1) ? G_GH0X : G_GH0) + u, G_END, DH, tag + 1u, a.status, gh, hw, false)) *bad = 1;
+            if (more && !get_2d<NB, 3>(ex + (gh0_near ? G_GH0N + (int)((tag + 1u) & 1) * D3 : (((tag + 1u) & 1) ? G_GH0X : G_GH0)) + u, G_END, DH, tag + 1u,
+                                       a.status, gh, hw, false)) *bad = 1;
             if (out) B1_STAMP(0, t, 6);
         }
     } else if (role < R_TBH) {
@@ -894,10 +926,10 @@ int mode() {
 }
 // workgroup ids a placed launch needs: the smallest count whose non-critical ids hold every non-critical role (and past the last
 // critical id)
-int placed_grid(int teams, int rteams, int beat_wgs) {
-    const int need = rteams * 2 * NU + beat_wgs;
-    int g = 8 * (kCrit - 1) + teams;
-    while (g - crit_below(g, teams) < need) ++g;
+int placed_grid(int teams, int rteams, int beat_wgs, int crit = kCrit) {
+    const int need = rteams * (crit == kCritTA ? NU : 2 * NU) + beat_wgs;
+    int g = 8 * (crit - 1) + teams;
+    while (g - crit_below(g, teams, crit) < need) ++g;
     return g;
 }
 }  // namespace
@@ -953,11 +985,13 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
     a.rgroups = (!a.fused && shared_groups(d.B)) ? shared_group_count(d.B) : 0;
     const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
-    a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs) <= chain_capacity();
-    if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
-    if (mode() == 5 && a.stride == 1) a.place = 2;             // (test hook: the request without the placement)
-    const dim3 grid(a.place == 1 ? placed_grid(a.teams, rteams, beat_wgs) : (a.teams * kTickRoles + beat_wgs) * a.stride);
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
+    // one team of the merged build (one row with V <= 64, two with V <= 32): the TA join the critical set -- 32 workgroups = one XCD
+    a.crit = (a.teams == 1 && nbr * nj <= 2 && placed_grid(1, 1, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA : kCrit;
+    a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs, a.crit) <= chain_capacity();
+    if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
+    if (mode() == 5 && a.stride == 1) { a.place = 2; a.crit = kCrit; }   // (test hook: the request without the placement)
+    const dim3 grid(a.place == 1 ? placed_grid(a.teams, rteams, beat_wgs, a.crit) : (a.teams * kTickRoles + beat_wgs) * a.stride);
     if (a.fused && a.teams > 1 && (nbr != 2 || a.teams * 2 > kDecodeB1BeatRowsMax)) return -1;
 #define DISPATCH_B1(NJ, NBR)                                                                                                    \
     do {                                                                                                                    \

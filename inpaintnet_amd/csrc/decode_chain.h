@@ -52,7 +52,7 @@ int launch_decode_chain(DecodeChainArgs a, hipStream_t s);
 // one to sixteen measures, inference: the register-resident persistent launch of decode_b1.hip (launch_decode_chain takes it when it applies;
 // INET_DECODE_B1 / inet_set_option key 15: 0 = never; 1 / 2 = the tick path only, behind the beat path's own launches, on consecutive
 // workgroup ids / on every 8th id (one XCD); 3 = default: up to six measures with the beat path folded into the same launch; three to sixteen: teams of the tick path's workgroups)
-constexpr int kDecodeB1WordsPerRow = 2 * 32288;   // 32-bit words of ONE row's granule area (decode_b1.hip's map: tick exchange + one slot per beat step)
+constexpr int kDecodeB1WordsPerRow = 2 * 35392;   // 32-bit words of ONE row's granule area (decode_b1.hip's map: tick exchange + one slot per beat step)
 constexpr int kDecodeB1StampWords = 2 * 2 * 32 * 8;   // 32-bit words of the stamp area (2 roles x <= 32 ticks x 8 stamps of 8 bytes)
 constexpr int kDecodeB1MaxRows = 16;              // rows (measures) per call the register-resident launch takes: 1 / 2 / 4 per team of
                                                   // workgroups, up to five teams (tick path only beyond one team)
