@@ -628,7 +628,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 bi = bi < a.V ? bi : 0;
                 if (NB == 1) {
                     tok[0] = bi;
-                    if (tid == 0) a.samples[t] = bi;
+                    if (tid == 0) a.samples[(long)rb * a.T + t] = bi;
                 } else if (lane == 0) {
                     toks[arow] = bi;
                     if (arow < nrow) a.samples[(long)(rb + arow) * a.T + t] = bi;
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             const Ctx<NBR> cr{a, a.ex + (long)rbr * G_END, xs, bad, tid, rbr, min(NBR, a.B - rbr), min(NBR, a.teams * NB - rbr)};
             tick_recurrent_role<NBR>(cr, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0);
         } else {
-            // (one-team merged build under place_role: the TA are critical workgroups, index 16 + k of the XCC-id check's 32)
+            // (merged build under place_role with kCritTA: the TA are critical workgroups, index 16 + k of the team's XCC-id check of 32)
             const bool ta_near = MG && a.place == 1 && a.crit == kCritTA && same_xcd(ex + G_XCC, NU + (role - R_TA), 2 * NU, a.status, &near_s);
             tick_recurrent_role<NB>(c, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0, ta_near, G_H0N, G_GH0N);
         }
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
                 best = best < a.V ? best : 0;
                 if (NB == 1) {
                     tok[0] = best;
-                    if (out && tid == 0) a.samples[t] = best;
+                    if (out && tid == 0) a.samples[(long)rb * a.T + t] = best;
                 } else if (lane == 0) {
                     toks[arow] = best;
                     if (out && arow < nrow) a.samples[(long)(rb + arow) * a.T + t] = best;
@@ -940,6 +940,11 @@ static bool shared_groups(int B) { return mode() == 4 && B > 10; }    // (up to 
 static int shared_group_count(int B) { return (2 * ((B + 1) / 2) + kSharedRows - 1) / kSharedRows; }
 int decode_b1_team_rows(int B) {
     if (B <= 1) return 1;
+    // two or three measures under mode 4: ONE row per team (round 6).  Two or three one-row teams and the beat path's 80 workgroups fit
+    // the chip (3 x 48 + 80), a one-row tick is 3.2 us (merged build, V <= 64) against 4.6 for a two-row team, and each team's 32
+    // critical workgroups get an XCD of their own -- the reference's non-auto-regressive inpainting call decodes its 2 .. 4 target
+    // measures in one call (LatentRNN/latent_rnn.py:237-240)
+    if (mode() == 4 && B <= kDecodeB1OneRowTeamsMax) return 1;       // (four one-row teams behind the beat path's own launches: 0.181 ms against 0.169)
     if (B <= 2 || shared_groups(B)) return 2;
     return B <= 10 ? 2 : 4;                                    // (whole two-row teams while five of them fit the chip; modes 1-3 beyond: four rows)
 }
@@ -955,7 +960,8 @@ bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
 // 3 x 49 + 80 = 227 of 256 CUs); they then serve all (up to kBeatRowsMax) rows of the call
 bool decode_b1_fused(int Z, int B) {
     const int teams = decode_b1_teams(B);
-    return mode() >= 3 && Z == DZ && (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax)) &&
+    return mode() >= 3 && Z == DZ &&
+           (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax) || (decode_b1_team_rows(B) == 1 && teams <= kDecodeB1OneRowTeamsMax)) &&
            teams * kTickRoles + (kFusedRoles - kTickRoles) <= chain_capacity();
 }
 bool decode_b1_ok(const DecodeChainArgs& a) {
@@ -986,16 +992,17 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     a.rgroups = (!a.fused && shared_groups(d.B)) ? shared_group_count(d.B) : 0;
     const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
-    // one team of the merged build (one row with V <= 64, two with V <= 32): the TA join the critical set -- 32 workgroups = one XCD
-    a.crit = (a.teams == 1 && nbr * nj <= 2 && placed_grid(1, 1, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA : kCrit;
+    // teams of the merged build (one row with V <= 64, two with V <= 32): the TA join the critical set -- 32 workgroups = one XCD per team
+    a.crit = (!a.rgroups && nbr * nj <= 2 && placed_grid(a.teams, a.teams, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA : kCrit;
     a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs, a.crit) <= chain_capacity();
     if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
     if (mode() == 5 && a.stride == 1) { a.place = 2; a.crit = kCrit; }   // (test hook: the request without the placement)
     const dim3 grid(a.place == 1 ? placed_grid(a.teams, rteams, beat_wgs, a.crit) : (a.teams * kTickRoles + beat_wgs) * a.stride);
-    if (a.fused && a.teams > 1 && (nbr != 2 || a.teams * 2 > kDecodeB1BeatRowsMax)) return -1;
+    if (a.fused && a.teams > 1 && (nbr > 2 || a.teams * nbr > (nbr == 1 ? kDecodeB1OneRowTeamsMax : kDecodeB1BeatRowsMax))) return -1;
 #define DISPATCH_B1(NJ, NBR)                                                                                                    \
     do {                                                                                                                    \
-        if (a.fused && a.teams > 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 2, kDecodeB1BeatRowsMax>), grid, dim3(NT), 0, s, a); \
+        if (a.fused && a.teams > 1 && nbr == 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 1, kDecodeB1OneRowTeamsMax>), grid, dim3(NT), 0, s, a); \
+        else if (a.fused && a.teams > 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 2, kDecodeB1BeatRowsMax>), grid, dim3(NT), 0, s, a); \
         else if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR, NBR>), grid, dim3(NT), 0, s, a);             \
         else if (a.rgroups) hipLaunchKernelGGL((decode_b1_kernel<NJ, false, 2, 2, kSharedRows>), grid, dim3(NT), 0, s, a);     \
         else hipLaunchKernelGGL((decode_b1_kernel<NJ, false, NBR, NBR>), grid, dim3(NT), 0, s, a);                        \

@@ -61,11 +61,13 @@ constexpr int kDecodeB1MaxRows = 16;              // rows (measures) per call th
 int decode_b1_team_rows(int B);                   // (decode_b1.hip: the rule above; mode 4 shares the recurrent groups beyond ten measures)
 inline int decode_b1_teams(int B) { const int r = decode_b1_team_rows(B); return (B + r - 1) / r; }
 constexpr int kDecodeB1BeatRowsMax = 6;           // rows the beat path's workgroups serve when they share the launch with several teams
+constexpr int kDecodeB1OneRowTeamsMax = 3;        // ... with ONE-row teams (two or three measures under mode 4): the beat path serves three rows
 // granule areas of a call: one per row of every team; three to six measures: at least kDecodeB1BeatRowsMax (the folded beat path
 // computes that many rows, whatever B is -- rows beyond B repeat row B - 1)
 inline int decode_b1_rows(int B) {
     const int r = decode_b1_teams(B) * decode_b1_team_rows(B);
-    return (B >= 3 && B <= kDecodeB1BeatRowsMax && r < kDecodeB1BeatRowsMax) ? kDecodeB1BeatRowsMax : r;
+    if (decode_b1_teams(B) > 1 && decode_b1_team_rows(B) == 1) return r < kDecodeB1OneRowTeamsMax ? kDecodeB1OneRowTeamsMax : r;
+    return (decode_b1_teams(B) > 1 && B <= kDecodeB1BeatRowsMax && r < kDecodeB1BeatRowsMax) ? kDecodeB1BeatRowsMax : r;
 }
 inline long decode_b1_words(int B) { return (long)decode_b1_rows(B) * kDecodeB1WordsPerRow; }
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G);
