@@ -687,7 +687,7 @@ def decode_latency_extra(vae, iters=20):
     north_star target for this call is 40 % of the 8 TB/s roofline."""
     out = {}
     vae.eval()
-    for b in (1, 16, 256):
+    for b in (1, 2, 4, 16, 256):
         z = torch.randn(b, vae.latent_space_dim, device=vae.flat.device)
         dummy = torch.zeros(b, 24, device=z.device)
         with torch.no_grad():
@@ -988,6 +988,8 @@ def compact_line(out):
         "arnn_fr_ms": _get(ex, "anticipation_rnn_train", "ms_per_step_free_running"),
         "arnn_trimmed_tf_ms": _get(ex, "anticipation_rnn_train", "default_trimmed", "ms_per_step"),
         "decode_b1_ms": _get(ex, "decoder_eval", "b1", "ms_per_call"),
+        "decode_b2_ms": _get(ex, "decoder_eval", "b2", "ms_per_call"),
+        "decode_b4_ms": _get(ex, "decoder_eval", "b4", "ms_per_call"),
         "decode_b16_ms": _get(ex, "decoder_eval", "b16", "ms_per_call"),
         "decode_b256_ms": _get(ex, "decoder_eval", "b256", "ms_per_call"),
         "decode_b1_frac_hbm": _get(ex, "decoder_eval", "b1", "frac_hbm_roofline"),
