@@ -123,7 +123,7 @@ __host__ __device__ inline bool place_role(int b, int teams, int rteams, int bea
     const int x = b & 7, i = b >> 3;
     if (x < teams && i < crit) {
         team = x;
-        role = crit == kCritTA ? (i < NU ? R_TBI + i : R_TA + (i - NU)) : (i == 0 ? R_C : R_TBI + i - 1);
+        role = crit == kCritTA ? (i < NU ? R_TBI + i : R_TA + (i - NU)) : crit == NU ? R_TBI + i : (i == 0 ? R_C : R_TBI + i - 1);
         return true;
     }
     const int n = b - crit_below(b, teams, crit);               // the id's rank among the non-critical ones
@@ -934,17 +934,24 @@ int placed_grid(int teams, int rteams, int beat_wgs, int crit = kCrit) {
 }
 }  // namespace
 
-constexpr int kSharedRows = 6;                   // rows a shared recurrent group serves (8: the group's tick is longer than the two-row teams' and sets the pace)
-// seven measures and more under mode 4: two-row critical teams + shared recurrent groups (the kernel's "Shared recurrent groups")
-static bool shared_groups(int B) { return mode() == 4 && B > 10; }    // (up to ten measures five whole two-row teams fit the chip: faster)
-static int shared_group_count(int B) { return (2 * ((B + 1) / 2) + kSharedRows - 1) / kSharedRows; }
+constexpr int kSharedRows = 6;                   // rows a shared recurrent group serves beyond ten measures (8: the group's tick is longer than the two-row teams' and sets the pace)
+constexpr int kSharedRowsSmall = 3;              // ... and for four to six measures, where the critical teams have ONE row
+// Shared recurrent groups under mode 4 (the kernel's "Shared recurrent groups"): four to six measures = one-row critical teams (the
+// 16 CB of the merged build, or C + 16 TBi) + groups of three rows + the beat path's 80 workgroups in the same launch (6 x 17 + 2 x 32
+// + 80 = 246); eleven and more = two-row critical teams + groups of six rows.  (Seven to ten: five whole two-row teams fit the chip.)
+static bool shared_groups(int B) { return mode() == 4 && (B > 10 || (B > kDecodeB1OneRowTeamsMax && B <= kDecodeB1BeatRowsMax)); }
+static int shared_rows(int B) { return B <= kDecodeB1BeatRowsMax ? kSharedRowsSmall : kSharedRows; }
+static int shared_group_count(int B) {
+    const int rows = B <= kDecodeB1BeatRowsMax ? B : 2 * ((B + 1) / 2);         // rows that have a critical team
+    return (rows + shared_rows(B) - 1) / shared_rows(B);
+}
 int decode_b1_team_rows(int B) {
     if (B <= 1) return 1;
     // two or three measures under mode 4: ONE row per team (round 6).  Two or three one-row teams and the beat path's 80 workgroups fit
     // the chip (3 x 48 + 80), a one-row tick is 3.2 us (merged build, V <= 64) against 4.6 for a two-row team, and each team's 32
     // critical workgroups get an XCD of their own -- the reference's non-auto-regressive inpainting call decodes its 2 .. 4 target
     // measures in one call (LatentRNN/latent_rnn.py:237-240)
-    if (mode() == 4 && B <= kDecodeB1OneRowTeamsMax) return 1;       // (four one-row teams behind the beat path's own launches: 0.181 ms against 0.169)
+    if (mode() == 4 && B <= kDecodeB1BeatRowsMax) return 1;          // (two, three: whole one-row teams; four to six: one-row CRITICAL teams + shared groups)
     if (B <= 2 || shared_groups(B)) return 2;
     return B <= 10 ? 2 : 4;                                    // (whole two-row teams while five of them fit the chip; modes 1-3 beyond: four rows)
 }
@@ -954,14 +961,17 @@ void decode_b1_set_mode(int m) { g_mode = (m < 0 || m > 5) ? 4 : m; }
 bool decode_b1_shape_ok(int B, int H, int V, int T, int G) {
     return mode() != 0 && chain_enabled() && B >= 1 && B <= kDecodeB1MaxRows && H == DH && V >= 1 && V <= 128 && T % G == 0 && T / G <= 4 &&
            kFusedRoles <= chain_capacity() &&
-           (shared_groups(B) ? placed_grid(decode_b1_teams(B), shared_group_count(B), 0) : decode_b1_teams(B) * kTickRoles) <= chain_capacity();
+           (shared_groups(B) ? placed_grid(decode_b1_teams(B), shared_group_count(B), B <= kDecodeB1BeatRowsMax ? kFusedRoles - kTickRoles : 0)
+                             : decode_b1_teams(B) * kTickRoles) <= chain_capacity();
 }
 // the beat path's 80 workgroups go into the same launch when they fit beside the teams: one team, or two / three two-row teams (B <= 6:
 // 3 x 49 + 80 = 227 of 256 CUs); they then serve all (up to kBeatRowsMax) rows of the call
 bool decode_b1_fused(int Z, int B) {
     const int teams = decode_b1_teams(B);
-    return mode() >= 3 && Z == DZ &&
-           (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax) || (decode_b1_team_rows(B) == 1 && teams <= kDecodeB1OneRowTeamsMax)) &&
+    if (mode() < 3 || Z != DZ) return false;
+    if (shared_groups(B))                                      // four to six measures: one-row critical teams + shared groups + the beat path
+        return B <= kDecodeB1BeatRowsMax && placed_grid(teams, shared_group_count(B), kFusedRoles - kTickRoles) <= chain_capacity();
+    return (teams == 1 || (decode_b1_team_rows(B) == 2 && teams * 2 <= kDecodeB1BeatRowsMax) || (decode_b1_team_rows(B) == 1 && teams <= kDecodeB1OneRowTeamsMax)) &&
            teams * kTickRoles + (kFusedRoles - kTickRoles) <= chain_capacity();
 }
 bool decode_b1_ok(const DecodeChainArgs& a) {
@@ -989,19 +999,21 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const double beat_w = a.fused ? 2.0 * DH * DZ + 9.0 * DH * DH + 3.0 * DH * DH + 3.0 * DH * DH : 0.0;
     ProfScope prof(PROF_GRU_FWD, 2.0 * d.B * (d.T * (9.0 * DH * DH + (double)d.V * DH) + beat_mac), s, label,
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
-    a.rgroups = (!a.fused && shared_groups(d.B)) ? shared_group_count(d.B) : 0;
+    a.rgroups = shared_groups(d.B) ? shared_group_count(d.B) : 0;
     const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
     // teams of the merged build (one row with V <= 64, two with V <= 32): the TA join the critical set -- 32 workgroups = one XCD per team
-    a.crit = (!a.rgroups && nbr * nj <= 2 && placed_grid(a.teams, a.teams, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA : kCrit;
+    a.crit = (!a.rgroups && nbr * nj <= 2 && placed_grid(a.teams, a.teams, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA
+             : (a.rgroups && nbr * nj <= 2) ? NU : kCrit;        // (merged build with shared groups: the 16 CB alone are a team's critical set)
     a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs, a.crit) <= chain_capacity();
     if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
     if (mode() == 5 && a.stride == 1) { a.place = 2; a.crit = kCrit; }   // (test hook: the request without the placement)
     const dim3 grid(a.place == 1 ? placed_grid(a.teams, rteams, beat_wgs, a.crit) : (a.teams * kTickRoles + beat_wgs) * a.stride);
-    if (a.fused && a.teams > 1 && (nbr > 2 || a.teams * nbr > (nbr == 1 ? kDecodeB1OneRowTeamsMax : kDecodeB1BeatRowsMax))) return -1;
+    if (a.fused && a.teams > 1 && (nbr > 2 || a.teams * nbr > ((nbr == 1 && !a.rgroups) ? kDecodeB1OneRowTeamsMax : kDecodeB1BeatRowsMax))) return -1;
 #define DISPATCH_B1(NJ, NBR)                                                                                                    \
     do {                                                                                                                    \
-        if (a.fused && a.teams > 1 && nbr == 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 1, kDecodeB1OneRowTeamsMax>), grid, dim3(NT), 0, s, a); \
+        if (a.fused && a.rgroups) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 1, kDecodeB1BeatRowsMax, kSharedRowsSmall>), grid, dim3(NT), 0, s, a); \
+        else if (a.fused && a.teams > 1 && nbr == 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 1, kDecodeB1OneRowTeamsMax>), grid, dim3(NT), 0, s, a); \
         else if (a.fused && a.teams > 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 2, kDecodeB1BeatRowsMax>), grid, dim3(NT), 0, s, a); \
         else if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR, NBR>), grid, dim3(NT), 0, s, a);             \
         else if (a.rgroups) hipLaunchKernelGGL((decode_b1_kernel<NJ, false, 2, 2, kSharedRows>), grid, dim3(NT), 0, s, a);     \

@@ -66,7 +66,8 @@ constexpr int kDecodeB1OneRowTeamsMax = 3;        // ... with ONE-row teams (two
 // computes that many rows, whatever B is -- rows beyond B repeat row B - 1)
 inline int decode_b1_rows(int B) {
     const int r = decode_b1_teams(B) * decode_b1_team_rows(B);
-    if (decode_b1_teams(B) > 1 && decode_b1_team_rows(B) == 1) return r < kDecodeB1OneRowTeamsMax ? kDecodeB1OneRowTeamsMax : r;
+    if (decode_b1_teams(B) > 1 && decode_b1_team_rows(B) == 1)          // (one-row teams: the folded beat path computes three rows, or six)
+        return r <= kDecodeB1OneRowTeamsMax ? kDecodeB1OneRowTeamsMax : kDecodeB1BeatRowsMax;
     return (decode_b1_teams(B) > 1 && B <= kDecodeB1BeatRowsMax && r < kDecodeB1BeatRowsMax) ? kDecodeB1BeatRowsMax : r;
 }
 inline long decode_b1_words(int B) { return (long)decode_b1_rows(B) * kDecodeB1WordsPerRow; }
