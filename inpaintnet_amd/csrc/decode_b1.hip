@@ -650,7 +650,7 @@ __global__ __launch_bounds__(NT) void decode_b1_kernel(B1Args a) {
             B1_STAMP(0, t, 6);
         }
     } else if (role < R_TBI) {
-        if (NBR != NB) {                                       // a shared group: rows [NBR team, NBR team + NBR) of the call
+        if (NBR != NB && a.crit != kCritTA) {                  // a shared group: rows [NBR team, NBR team + NBR) of the call
             const int rbr = team * NBR;
             const Ctx<NBR> cr{a, a.ex + (long)rbr * G_END, xs, bad, tid, rbr, min(NBR, a.B - rbr), min(NBR, a.teams * NB - rbr)};
             tick_recurrent_role<NBR>(cr, role - R_TA, a.W_hh0, a.b_hh0, 0, G_H0, G_GH0, G_H0X, MG ? G_GH0X : G_GH0);
@@ -1000,10 +1000,16 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     ProfScope prof(PROF_GRU_FWD, 2.0 * d.B * (d.T * (9.0 * DH * DH + (double)d.V * DH) + beat_mac), s, label,
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
     a.rgroups = shared_groups(d.B) ? shared_group_count(d.B) : 0;
-    const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
     const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
+    // FOUR measures with the merged build (V <= 64): every team keeps its 16 TA next to its 16 CB on an XCD of its own (layer 0's
+    // recurrent summands stay inside the XCD), only the TBh are shared, two rows per group: 4 x 32 + 2 x 16 + 80 = 240 workgroups.
+    // (Five and six would need 288 / 336: they keep the groups of three rows for both recurrent sides.)
+    const bool tbh_pairs = a.fused && a.rgroups && d.B == 4 && nbr == 1 && nj <= 2;
+    if (tbh_pairs) a.rgroups = 2;
+    const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
     // teams of the merged build (one row with V <= 64, two with V <= 32): the TA join the critical set -- 32 workgroups = one XCD per team
-    a.crit = (!a.rgroups && nbr * nj <= 2 && placed_grid(a.teams, a.teams, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA
+    a.crit = tbh_pairs ? kCritTA
+             : (!a.rgroups && nbr * nj <= 2 && placed_grid(a.teams, a.teams, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA
              : (a.rgroups && nbr * nj <= 2) ? NU : kCrit;        // (merged build with shared groups: the 16 CB alone are a team's critical set)
     a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs, a.crit) <= chain_capacity();
     if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
@@ -1012,7 +1018,8 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     if (a.fused && a.teams > 1 && (nbr > 2 || a.teams * nbr > ((nbr == 1 && !a.rgroups) ? kDecodeB1OneRowTeamsMax : kDecodeB1BeatRowsMax))) return -1;
 #define DISPATCH_B1(NJ, NBR)                                                                                                    \
     do {                                                                                                                    \
-        if (a.fused && a.rgroups) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 1, kDecodeB1BeatRowsMax, kSharedRowsSmall>), grid, dim3(NT), 0, s, a); \
+        if (tbh_pairs && NJ <= 2) hipLaunchKernelGGL((decode_b1_kernel<(NJ <= 2 ? NJ : 1), true, 1, kDecodeB1BeatRowsMax, 2>), grid, dim3(NT), 0, s, a); \
+        else if (a.fused && a.rgroups) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 1, kDecodeB1BeatRowsMax, kSharedRowsSmall>), grid, dim3(NT), 0, s, a); \
         else if (a.fused && a.teams > 1 && nbr == 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 1, kDecodeB1OneRowTeamsMax>), grid, dim3(NT), 0, s, a); \
         else if (a.fused && a.teams > 1) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, 2, kDecodeB1BeatRowsMax>), grid, dim3(NT), 0, s, a); \
         else if (a.fused) hipLaunchKernelGGL((decode_b1_kernel<NJ, true, NBR, NBR>), grid, dim3(NT), 0, s, a);             \
