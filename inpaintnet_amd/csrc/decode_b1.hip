@@ -934,6 +934,15 @@ int placed_grid(int teams, int rteams, int beat_wgs, int crit = kCrit) {
 }
 }  // namespace
 
+// The launch plan per call size under mode 4 (the default), in one place.  "critical" = the workgroups on a tick's critical path, which get
+// workgroup ids of one residue mod 8 (one XCD) and XCD-local copies of what they exchange; M = merged build (rows x ceil(V / 32) <= 2).
+//   B = 1        one team, beat path folded in.            M: 16 CB + 16 TA critical (kCritTA), 16 TBh, 80 beat = 129 workgroups
+//   B = 2, 3     B one-row teams, beat path folded in (serves three rows).  M: 32 critical per team                  <= 224
+//   B = 4 (M)    four one-row teams with CB + TA critical, TBh shared in pairs of rows, beat path folded in             240
+//   B = 4 .. 6   B one-row critical teams (16 CB, or C + 16 TBi), TA + TBh shared by groups of three rows, beat folded <= 246
+//   B = 7 .. 10  whole two-row teams (49 workgroups, 17 critical) behind the beat path's own launches                  <= 245
+//   B = 11 .. 16 two-row critical teams (17) + TA / TBh shared by groups of six rows, behind the beat path's launches  <= 232
+// Modes 1-3 keep round 5's plans (one team up to two rows, two-row teams to ten, four-row teams beyond); mode 5 = test hook.
 constexpr int kSharedRows = 6;                   // rows a shared recurrent group serves beyond ten measures (8: the group's tick is longer than the two-row teams' and sets the pace)
 constexpr int kSharedRowsSmall = 3;              // ... and for four to six measures, where the critical teams have ONE row
 // Shared recurrent groups under mode 4 (the kernel's "Shared recurrent groups"): four to six measures = one-row critical teams (the
