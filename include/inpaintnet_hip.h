@@ -384,6 +384,13 @@ int inet_debug_read(void* dst, int64_t nbytes);
  * becomes resident beside a weight-gradient product --; slow ones are the trace an unexplained timeout or a stalled launch leaves
  * behind (csrc/chain.h record_slow).  -1 bad arguments, -2 runtime failure. */
 int inet_slow_waits(unsigned* dst, int max_entries, int reset, int64_t* noted);
+/* The launch plan of the register-resident decode (csrc/decode_b1.hip) for a call of B measures with V notes and latent size Z, and
+ * a host-side self-check of it -- no GPU needed (tests/test_decode_plan.py).  out8 = {teams, rows per team, shared recurrent groups,
+ * critical workgroups per team, placed (1: workgroup ids are mapped to roles so that a team's critical workgroups share a residue mod
+ * 8), grid, live workgroups, ok}; ok = every (team, role) the kernel expects appears exactly once among the ids of the grid, every
+ * team's critical roles sit on ONE residue, no residue carries more than 32 live workgroups, the grid fits the chip.  0, or -1 for a
+ * call the register-resident launch does not take (B > 16, V > 128, ...). */
+int inet_decode_b1_plan(int B, int V, int Z, int* out8);
 /* Loads every kernel of the library on the CURRENT device (code objects and function objects, which the HIP runtime otherwise
  * builds lazily on the launch path of each kernel's first launch: csrc/preload.hip) without launching anything.  Idempotent per
  * device; returns the number of kernels touched (0 when the device was done already), -2 without a device or on a runtime

@@ -128,6 +128,7 @@ _SIGNATURES = {
     "inet_debug_read": (C.c_int, [_P, _L]),
     "inet_chain_status": (C.c_int, [_I]),
     "inet_slow_waits": (C.c_int, [_P, _I, _I, C.POINTER(_L)]),
+    "inet_decode_b1_plan": (C.c_int, [_I, _I, _I, C.POINTER(C.c_int)]),
     "inet_preload": (C.c_int, []),
     "inet_kernel_count": (C.c_int, []),
     "inet_prof_enable": (C.c_int, [_I]),

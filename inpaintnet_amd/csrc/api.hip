@@ -502,6 +502,8 @@ int inet_slow_waits(unsigned* dst, int max_entries, int reset, int64_t* noted) {
     return (int)(slow > 0x7fffffffu ? 0x7fffffffu : slow);
 }
 
+int inet_decode_b1_plan(int B, int V, int Z, int* out8) { return decode_b1_plan_check(B, V, Z, out8); }
+
 int inet_preload(void) { return preload_kernels(); }
 int inet_kernel_count(void) { return preload_kernel_count(); }
 

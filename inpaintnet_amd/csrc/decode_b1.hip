@@ -988,6 +988,76 @@ bool decode_b1_ok(const DecodeChainArgs& a) {
     return decode_b1_shape_ok(a.B, a.H, a.V, a.T, a.G) && !train && a.b1ex;
 }
 
+// What launch_decode_b1 decides for a call, as a value (also behind inet_decode_b1_plan: the planner is tested without a GPU).
+struct B1Plan { int teams, nbr, nj, rgroups, crit, place, grid, beat_wgs; bool tbh_pairs; };
+static B1Plan make_plan(int B, int V, bool fused, int stride) {
+    B1Plan p{};
+    p.teams = decode_b1_teams(B);
+    p.rgroups = shared_groups(B) ? shared_group_count(B) : 0;
+    p.nj = (V + 31) / 32; p.nbr = decode_b1_team_rows(B);
+    // FOUR measures with the merged build (V <= 64): every team keeps its 16 TA next to its 16 CB on an XCD of its own (layer 0's
+    // recurrent summands stay inside the XCD), only the TBh are shared, two rows per group: 4 x 32 + 2 x 16 + 80 = 240 workgroups.
+    // (Five and six would need 288 / 336: they keep the groups of three rows for both recurrent sides.)
+    p.tbh_pairs = fused && p.rgroups && B == 4 && p.nbr == 1 && p.nj <= 2;
+    if (p.tbh_pairs) p.rgroups = 2;
+    const int rteams = p.rgroups ? p.rgroups : p.teams;
+    p.beat_wgs = fused ? kFusedRoles - kTickRoles : 0;
+    // teams of the merged build (one row with V <= 64, two with V <= 32): the TA join the critical set -- 32 workgroups = one XCD per team
+    p.crit = p.tbh_pairs ? kCritTA
+             : (!p.rgroups && p.nbr * p.nj <= 2 && placed_grid(p.teams, p.teams, p.beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA
+             : (p.rgroups && p.nbr * p.nj <= 2) ? NU : kCrit;    // (merged build with shared groups: the 16 CB alone are a team's critical set)
+    p.place = mode() == 4 && stride == 1 && placed_grid(p.teams, rteams, p.beat_wgs, p.crit) <= chain_capacity();
+    if (mode() == 5 && stride == 1) { p.place = 2; p.crit = kCrit; }   // (test hook: the request without the placement)
+    p.grid = p.place == 1 ? placed_grid(p.teams, rteams, p.beat_wgs, p.crit) : (p.teams * kTickRoles + p.beat_wgs) * stride;
+    return p;
+}
+
+// Planner self-check without a GPU (tests/test_decode_plan.py): out[8] = {teams, rows per team, shared groups, critical workgroups per
+// team, placed, grid, live workgroups, ok}.  ok = every (team, role) the kernel expects appears exactly once among the ids of a placed
+// grid, every team's critical roles sit on ids of ONE residue mod 8, no residue carries more than 32 live workgroups (one XCD's CUs),
+// and the grid fits the chip.  Returns 0, or -1 for a call the register-resident launch does not take.
+int decode_b1_plan_check(int B, int V, int Z, int* out) {
+    if (!out || !decode_b1_shape_ok(B, DH, V, 24, 6)) return -1;
+    const bool fused = decode_b1_fused(Z, B);
+    const B1Plan p = make_plan(B, V, fused, 1);
+    int live = 0, ok = 1;
+    if (p.place == 1) {
+        const int rteams = p.rgroups ? p.rgroups : p.teams;
+        const bool merged = p.nbr * p.nj <= 2;
+        int per_residue[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // expected roles: per team the critical ones (+ its own recurrent side unless shared), per shared group its recurrent roles, the beat path
+        static int seen[16][kFusedRoles], crit_res[16];
+        for (int t = 0; t < 16; ++t) { crit_res[t] = -1; for (int r = 0; r < kFusedRoles; ++r) seen[t][r] = 0; }
+        for (int b = 0; b < p.grid; ++b) {
+            int team = 0, role = 0;
+            if (!place_role(b, p.teams, rteams, p.beat_wgs, p.crit, team, role)) continue;
+            if (team < 0 || team >= 16 || role < 0 || role >= kFusedRoles) { ok = 0; continue; }
+            ++seen[team][role]; ++live; ++per_residue[b & 7];
+            const bool critical = role == R_C || (role >= R_TBI && role < R_TBH) || (p.crit == kCritTA && role >= R_TA && role < R_TBI);
+            if (critical && role < kTickRoles) {
+                if (crit_res[team] < 0) crit_res[team] = b & 7;
+                else if (crit_res[team] != (b & 7)) ok = 0;
+            }
+        }
+        for (int t = 0; t < p.teams; ++t) {
+            for (int r = R_TBI; r < R_TBH; ++r) if (seen[t][r] != 1) ok = 0;
+            if (!merged && seen[t][R_C] != 1) ok = 0;
+            if (merged && seen[t][R_C] != 0) ok = 0;
+        }
+        const bool ta_shared = p.rgroups && p.crit != kCritTA;
+        for (int t = 0; t < (ta_shared ? p.rgroups : p.teams); ++t) for (int r = R_TA; r < R_TBI; ++r) if (seen[t][r] != 1) ok = 0;
+        for (int t = 0; t < (p.rgroups ? p.rgroups : p.teams); ++t) for (int r = R_TBH; r < kTickRoles; ++r) if (seen[t][r] != 1) ok = 0;
+        for (int r = kTickRoles; r < kFusedRoles; ++r) if (seen[0][r] != (fused ? 1 : 0)) ok = 0;
+        for (int x = 0; x < 8; ++x) if (per_residue[x] > 32) ok = 0;
+        if (p.grid > chain_capacity() || live > chain_capacity()) ok = 0;
+    } else {
+        live = p.grid;
+        if (p.grid > chain_capacity()) ok = 0;
+    }
+    out[0] = p.teams; out[1] = p.nbr; out[2] = p.rgroups; out[3] = p.crit; out[4] = p.place; out[5] = p.grid; out[6] = live; out[7] = ok;
+    return 0;
+}
+
 int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     B1Args a{};
     a.fused = d.beat.z != nullptr;
@@ -1008,22 +1078,12 @@ int launch_decode_b1(const DecodeChainArgs& d, hipStream_t s) {
     const double beat_w = a.fused ? 2.0 * DH * DZ + 9.0 * DH * DH + 3.0 * DH * DH + 3.0 * DH * DH : 0.0;
     ProfScope prof(PROF_GRU_FWD, 2.0 * d.B * (d.T * (9.0 * DH * DH + (double)d.V * DH) + beat_mac), s, label,
                    4.0 * (9.0 * DH * DH + (double)d.V * DH + (double)d.B * d.T * d.V + beat_w));
-    a.rgroups = shared_groups(d.B) ? shared_group_count(d.B) : 0;
-    const int nj = (d.V + 31) / 32, nbr = decode_b1_team_rows(d.B);
-    // FOUR measures with the merged build (V <= 64): every team keeps its 16 TA next to its 16 CB on an XCD of its own (layer 0's
-    // recurrent summands stay inside the XCD), only the TBh are shared, two rows per group: 4 x 32 + 2 x 16 + 80 = 240 workgroups.
-    // (Five and six would need 288 / 336: they keep the groups of three rows for both recurrent sides.)
-    const bool tbh_pairs = a.fused && a.rgroups && d.B == 4 && nbr == 1 && nj <= 2;
-    if (tbh_pairs) a.rgroups = 2;
-    const int rteams = a.rgroups ? a.rgroups : a.teams, beat_wgs = a.fused ? kFusedRoles - kTickRoles : 0;
-    // teams of the merged build (one row with V <= 64, two with V <= 32): the TA join the critical set -- 32 workgroups = one XCD per team
-    a.crit = tbh_pairs ? kCritTA
-             : (!a.rgroups && nbr * nj <= 2 && placed_grid(a.teams, a.teams, beat_wgs, kCritTA) <= chain_capacity()) ? kCritTA
-             : (a.rgroups && nbr * nj <= 2) ? NU : kCrit;        // (merged build with shared groups: the 16 CB alone are a team's critical set)
-    a.place = mode() == 4 && a.stride == 1 && placed_grid(a.teams, rteams, beat_wgs, a.crit) <= chain_capacity();
-    if (a.rgroups && !a.place) return -1;                      // (decode_b1_shape_ok has checked that the placed launch fits)
-    if (mode() == 5 && a.stride == 1) { a.place = 2; a.crit = kCrit; }   // (test hook: the request without the placement)
-    const dim3 grid(a.place == 1 ? placed_grid(a.teams, rteams, beat_wgs, a.crit) : (a.teams * kTickRoles + beat_wgs) * a.stride);
+    const B1Plan pl = make_plan(d.B, d.V, a.fused != 0, a.stride);
+    a.rgroups = pl.rgroups; a.crit = pl.crit; a.place = pl.place;
+    const int nj = pl.nj, nbr = pl.nbr;
+    const bool tbh_pairs = pl.tbh_pairs;
+    if (pl.rgroups && pl.place != 1) return -1;                // (decode_b1_shape_ok has checked that the placed launch fits)
+    const dim3 grid(pl.grid);
     if (a.fused && a.teams > 1 && (nbr > 2 || a.teams * nbr > ((nbr == 1 && !a.rgroups) ? kDecodeB1OneRowTeamsMax : kDecodeB1BeatRowsMax))) return -1;
 #define DISPATCH_B1(NJ, NBR)                                                                                                    \
     do {                                                                                                                    \

@@ -76,3 +76,5 @@ bool decode_b1_fused(int Z, int B);                    // ... and the beat path 
 bool decode_b1_ok(const DecodeChainArgs& a);
 int launch_decode_b1(const DecodeChainArgs& a, hipStream_t s);
 void decode_b1_set_mode(int m);
+// the launch plan of a call of B measures (V notes, latent size Z) and a host-side self-check of it: decode_b1.hip, no GPU needed
+int decode_b1_plan_check(int B, int V, int Z, int* out8);
